@@ -1,0 +1,107 @@
+/* Fake libSoapySDR -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Implements the handful of SoapySDR C entry points the reference links against
+ * (see soapy_stub/SoapySDR/Device.h) on top of an in-memory cs16 sample source, so
+ * that the reference's own translation units can be linked and, where wanted, its
+ * main()/threads driven end to end without radio hardware.  Nothing here is DSP.
+ *
+ * The sample source is installed with soapy_fake_set_source(); readStream hands out
+ * consecutive chunks of it and reports SOAPY_SDR_STREAM_ERROR once it is exhausted
+ * (after calling the optional end-of-stream hook).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <SoapySDR/Device.h>
+#include <SoapySDR/Formats.h>
+
+struct SoapySDRDevice { double freq, rate, bw; };
+struct SoapySDRStream { int active; };
+
+static struct SoapySDRDevice g_dev;
+static struct SoapySDRStream g_stream;
+
+static const int16_t *g_src;      /* interleaved I,Q */
+static size_t g_src_len;          /* complex samples */
+static size_t g_src_pos;
+static size_t g_max_chunk;        /* 0 = hand out whatever is asked for */
+static void (*g_eos_hook)(void);
+static const void *g_discard;     /* reads into this buffer are flush reads: zero-fill, consume nothing */
+
+void soapy_fake_set_source(const int16_t *iq, size_t n_complex, size_t max_chunk)
+{
+	g_src = iq; g_src_len = n_complex; g_src_pos = 0; g_max_chunk = max_chunk;
+}
+void soapy_fake_set_discard_buffer(const void *p) { g_discard = p; }
+void soapy_fake_set_eos_hook(void (*fn)(void)) { g_eos_hook = fn; }
+size_t soapy_fake_position(void) { return g_src_pos; }
+
+size_t SoapySDR_formatToSize(const char *format)
+{
+	/* bytes per element: complex formats carry two components */
+	size_t bits = 0, is_complex = 0;
+	const char *p = format;
+	if (*p == 'C') { is_complex = 1; p++; }
+	if (*p) p++;                     /* F / S / U */
+	bits = (size_t)atoi(p);
+	return (is_complex ? 2 : 1) * ((bits + 7) / 8);
+}
+
+SoapySDRKwargs SoapySDRKwargs_fromString(const char *markup) { SoapySDRKwargs k = {0, NULL, NULL}; (void)markup; return k; }
+void SoapySDRKwargs_clear(SoapySDRKwargs *args) { if (args) args->size = 0; }
+
+const char *SoapySDRDevice_lastError(void) { return "fake"; }
+SoapySDRDevice *SoapySDRDevice_makeStrArgs(const char *args) { (void)args; return &g_dev; }
+int SoapySDRDevice_unmake(SoapySDRDevice *d) { (void)d; return 0; }
+char *SoapySDRDevice_getDriverKey(const SoapySDRDevice *d) { (void)d; return strdup("fake"); }
+char *SoapySDRDevice_getHardwareKey(const SoapySDRDevice *d) { (void)d; return strdup("fake"); }
+SoapySDRKwargs SoapySDRDevice_getHardwareInfo(const SoapySDRDevice *d) { SoapySDRKwargs k = {0, NULL, NULL}; (void)d; return k; }
+size_t SoapySDRDevice_getNumChannels(const SoapySDRDevice *d, const int dir) { (void)d; (void)dir; return 1; }
+
+SoapySDRStream *SoapySDRDevice_setupStream(SoapySDRDevice *d, const int dir, const char *fmt,
+	const size_t *ch, const size_t n, const SoapySDRKwargs *a)
+{ (void)d; (void)dir; (void)fmt; (void)ch; (void)n; (void)a; return &g_stream; }
+int SoapySDRDevice_closeStream(SoapySDRDevice *d, SoapySDRStream *s) { (void)d; (void)s; return 0; }
+int SoapySDRDevice_activateStream(SoapySDRDevice *d, SoapySDRStream *s, const int f, const long long t, const size_t n)
+{ (void)d; (void)f; (void)t; (void)n; s->active = 1; return 0; }
+int SoapySDRDevice_deactivateStream(SoapySDRDevice *d, SoapySDRStream *s, const int f, const long long t)
+{ (void)d; (void)f; (void)t; s->active = 0; return 0; }
+
+int SoapySDRDevice_readStream(SoapySDRDevice *d, SoapySDRStream *s, void * const *buffs,
+	const size_t numElems, int *flags, long long *timeNs, const long timeoutUs)
+{
+	size_t n = numElems;
+	(void)d; (void)s; (void)flags; (void)timeNs; (void)timeoutUs;
+	if (g_discard && buffs[0] == g_discard) {
+		memset(buffs[0], 0, n * 2 * sizeof(int16_t));
+		return (int)n;
+	}
+	if (!g_src || g_src_pos >= g_src_len) {
+		if (g_eos_hook) { void (*h)(void) = g_eos_hook; g_eos_hook = NULL; h(); }
+		return SOAPY_SDR_STREAM_ERROR;
+	}
+	if (g_max_chunk && n > g_max_chunk) n = g_max_chunk;
+	if (n > g_src_len - g_src_pos) n = g_src_len - g_src_pos;
+	memcpy(buffs[0], g_src + 2 * g_src_pos, n * 2 * sizeof(int16_t));
+	g_src_pos += n;
+	return (int)n;
+}
+
+int SoapySDRDevice_setAntenna(SoapySDRDevice *d, const int dir, const size_t ch, const char *n) { (void)d; (void)dir; (void)ch; (void)n; return 0; }
+static char **empty_list(size_t *length) { *length = 0; return NULL; }
+char **SoapySDRDevice_listAntennas(const SoapySDRDevice *d, const int dir, const size_t ch, size_t *l) { (void)d; (void)dir; (void)ch; return empty_list(l); }
+char **SoapySDRDevice_listGains(const SoapySDRDevice *d, const int dir, const size_t ch, size_t *l) { (void)d; (void)dir; (void)ch; return empty_list(l); }
+int SoapySDRDevice_setGainMode(SoapySDRDevice *d, const int dir, const size_t ch, const bool a) { (void)d; (void)dir; (void)ch; (void)a; return 0; }
+int SoapySDRDevice_setGain(SoapySDRDevice *d, const int dir, const size_t ch, const double v) { (void)d; (void)dir; (void)ch; (void)v; return 0; }
+int SoapySDRDevice_setGainElement(SoapySDRDevice *d, const int dir, const size_t ch, const char *n, const double v) { (void)d; (void)dir; (void)ch; (void)n; (void)v; return 0; }
+int SoapySDRDevice_setFrequency(SoapySDRDevice *d, const int dir, const size_t ch, const double f, const SoapySDRKwargs *a) { (void)dir; (void)ch; (void)a; d->freq = f; return 0; }
+double SoapySDRDevice_getFrequency(const SoapySDRDevice *d, const int dir, const size_t ch) { (void)dir; (void)ch; return d->freq; }
+char **SoapySDRDevice_listFrequencies(const SoapySDRDevice *d, const int dir, const size_t ch, size_t *l) { (void)d; (void)dir; (void)ch; return empty_list(l); }
+int SoapySDRDevice_setFrequencyCorrection(SoapySDRDevice *d, const int dir, const size_t ch, const double v) { (void)d; (void)dir; (void)ch; (void)v; return 0; }
+int SoapySDRDevice_setSampleRate(SoapySDRDevice *d, const int dir, const size_t ch, const double r) { (void)dir; (void)ch; d->rate = r; return 0; }
+double *SoapySDRDevice_listSampleRates(const SoapySDRDevice *d, const int dir, const size_t ch, size_t *l) { (void)d; (void)dir; (void)ch; *l = 0; return NULL; }
+int SoapySDRDevice_setBandwidth(SoapySDRDevice *d, const int dir, const size_t ch, const double bw) { (void)dir; (void)ch; d->bw = bw; return 0; }
+double SoapySDRDevice_getBandwidth(const SoapySDRDevice *d, const int dir, const size_t ch) { (void)dir; (void)ch; return d->bw; }
+double *SoapySDRDevice_listBandwidths(const SoapySDRDevice *d, const int dir, const size_t ch, size_t *l) { (void)d; (void)dir; (void)ch; *l = 0; return NULL; }
+int SoapySDRDevice_writeSetting(SoapySDRDevice *d, const char *k, const char *v) { (void)d; (void)k; (void)v; return 0; }
+char *SoapySDRDevice_readSetting(const SoapySDRDevice *d, const char *k) { (void)d; (void)k; return strdup("true"); }
