@@ -1,0 +1,181 @@
+/* rxgpu.h -- C ABI of librxgpu.so: the rx_tools sample-stream DSP path on MI355X (gfx950).
+ *
+ * Plain C, plain pointers and sizes.  The reference (rxseger/rx_tools v1.0.3) has no
+ * plugin/FFI layer; its boundary for this path is four C call sites and the structs they
+ * mutate.  Each entry point below names the reference interface it replaces (file:line
+ * under /root/reference/src).  INTEGRATION.md shows the two-line patches that bind them.
+ *
+ * Error convention: the reference's path functions are void and report to stderr
+ * (SURVEY.md section 8b).  The drop-in entry points keep that; everything else returns 0 on
+ * success or a negative RXGPU_E* code, with text from rxgpu_last_error().  Nothing here
+ * ever writes to stdout (fd 1 carries the audio/CSV stream in the reference), and there
+ * is NO CPU fallback: without a usable HIP device every compute entry point fails.
+ */
+#ifndef RXGPU_H
+#define RXGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+struct demod_state;     /* rtl_fm.c:124-159    (layout: rxgpu_ref_structs.h) */
+struct dongle_state;    /* rtl_fm.c:104-122 */
+struct tuning_state;    /* rtl_power.c:89-108 */
+
+enum {
+	RXGPU_OK = 0,
+	RXGPU_ENODEV = -1,        /* no HIP device / runtime error (text in rxgpu_last_error) */
+	RXGPU_EINVAL = -2,        /* bad argument */
+	RXGPU_EUNSUPPORTED = -3,  /* geometry or mode outside what the device path implements */
+	RXGPU_ENOMEM = -4,
+	RXGPU_ECAPACITY = -5      /* caller-provided buffer too small */
+};
+
+/* ------------------------------------------------------------------ runtime */
+
+/* Bind the calling process to one HIP device and create the library's streams.
+ * device < 0: use $RXGPU_DEVICE, else $LOCAL_RANK, else 0 (drop-in binaries gain no new
+ * flag; SURVEY.md section 5 "Config").  Idempotent for the same device. */
+int rxgpu_init(int device);
+void rxgpu_shutdown(void);
+int rxgpu_device_count(void);
+const char *rxgpu_last_error(void);
+/* the hipStream_t (as void*) all kernels of this library are launched on */
+void *rxgpu_stream(void);
+int rxgpu_sync(void);
+
+/* Per-kernel device timing with hipEvents on the launch stream.  While enabled every
+ * launch of the named kernels is bracketed by events; totals are read back here.
+ * name: "fm_decimate", "fm_disc", "fm_deemph", "fm_resample", "fm_fifth", "pw_fft", ... */
+void rxgpu_prof_enable(int on);
+void rxgpu_prof_reset(void);
+int rxgpu_prof_get(const char *name, double *total_ms, long *launches);
+
+/* ------------------------------------------------------------- rx_fm: drop-in */
+
+/* Replaces full_demod(d) at rtl_fm.c:923 (definition rtl_fm.c:759-824).
+ * In: d->lowpassed[0..d->lp_len) already scaled and rotated by the callback, all
+ * parameters and carries in *d.  Out: d->result[0..d->result_len), d->lowpassed[0..lp_len')
+ * (decimated IQ), and every carry (lp_len, now_r/now_j/prev_index, pre_r/pre_j, lp_*_hist,
+ * droop_*_hist, now_lpr/prev_lpr_index) exactly as the CPU leaves them.  deemph_filter's
+ * function-static `avg` (rtl_fm.c:669) has no field in the struct: it lives in a side-car
+ * keyed by the demod_state address (rxgpu_deemph_state).  Modes the device path does not
+ * cover (am/usb/lsb/raw, squelch, -o, lut/ale atan, dc blocks) print to stderr and
+ * exit(1): there is no CPU fallback. */
+void rxgpu_full_demod(struct demod_state *d);
+
+/* Replaces rtlsdr_callback(buf, len, ctx) at rtl_fm.c:899 (definition 828-863):
+ * mute-zero, CS16 -> 8-bit-range scale, rotate16_90 unless offset tuning, hand-off into
+ * s->demod_target->lowpassed under d->rw, signal d->ready.  len = int16 count. */
+void rxgpu_callback(int16_t *buf, uint32_t len, void *ctx);
+
+/* side-car for the de-emphasis accumulator of a given demod_state */
+int *rxgpu_deemph_state(const struct demod_state *d);
+
+/* -------------------------------------------------------- rx_fm: batched stream */
+
+/* Parameters of the chain: the demod_state fields full_demod reads (rtl_fm.c:136-151)
+ * plus dongle_state.offset_tuning (rtl_fm.c:854). */
+typedef struct rxgpu_fm_params {
+	int downsample;          /* low_pass boxcar length when downsample_passes == 0 */
+	int downsample_passes;   /* > 0: fifth_order cascade (the -F path) */
+	int comp_fir_size;       /* 9: cic_9_tables droop compensation after the cascade */
+	int custom_atan;         /* 0 = libm atan2 discriminator, 1 = fast_atan2 (-A fast) */
+	int deemph;              /* deemph_filter on/off */
+	int deemph_a;
+	int rate_out;            /* low_pass_real input rate */
+	int rate_out2;           /* low_pass_real output rate; <= 0 disables it */
+	int offset_tuning;       /* != 0: no rotate16_90 */
+	int prescaled;           /* != 0: input is already lowpassed[] (skip scale + rotate) */
+} rxgpu_fm_params;
+
+/* Every value the chain carries from one call to the next (SURVEY.md section 8b contract) */
+typedef struct rxgpu_fm_carry {
+	int now_r, now_j, prev_index;           /* low_pass          rtl_fm.c:139,141 */
+	int pre_r, pre_j;                        /* fm_demod          rtl_fm.c:140 */
+	int16_t lp_i_hist[10][6], lp_q_hist[10][6];   /* fifth_order  rtl_fm.c:130-131 */
+	int16_t droop_i_hist[9], droop_q_hist[9];     /* generic_fir  rtl_fm.c:133-134 */
+	int deemph_avg;                          /* deemph_filter's static, rtl_fm.c:669 */
+	int now_lpr, prev_lpr_index;             /* low_pass_real     rtl_fm.c:150-151 */
+} rxgpu_fm_carry;
+
+typedef struct rxgpu_fm_stream rxgpu_fm_stream;
+
+/* Workspace for up to max_blocks blocks of block_len int16 (I,Q interleaved) per run. */
+int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
+                           size_t max_blocks, size_t block_len);
+void rxgpu_fm_stream_destroy(rxgpu_fm_stream *s);
+int rxgpu_fm_stream_set_carry(rxgpu_fm_stream *s, const rxgpu_fm_carry *c);
+int rxgpu_fm_stream_get_carry(rxgpu_fm_stream *s, rxgpu_fm_carry *c);
+
+/* n_blocks consecutive callback blocks through rtlsdr_callback's pre-stage + full_demod,
+ * with exactly the per-block semantics of the reference (rotation phase restart, libm
+ * discriminator on each block's first sample, fifth_order seam rule, carries).
+ * d_iq : DEVICE pointer, n_blocks * block_len int16, resident in HBM.
+ * d_out: DEVICE pointer, capacity out_cap int16; receives the concatenated result[] of all
+ *        blocks.  *out_len = int16 written.  block_out_len (HOST, optional, n_blocks ints)
+ *        = result_len of each block.  Synchronous: returns after the device finished and
+ *        the carries were read back. */
+int rxgpu_fm_stream_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks, size_t block_len,
+                        int16_t *d_out, size_t out_cap, size_t *out_len, int *block_out_len);
+
+/* Same with HOST input/output buffers (staged through pinned memory over PCIe). */
+int rxgpu_fm_stream_run_host(rxgpu_fm_stream *s, const int16_t *h_iq, size_t n_blocks, size_t block_len,
+                             int16_t *h_out, size_t out_cap, size_t *out_len, int *block_out_len);
+
+/* Number of blocks whose libm-discriminator sample had to be re-evaluated on the host in
+ * the last run (device fp64 atan2 result too close to an integer boundary to trust). */
+long rxgpu_fm_stream_host_fixups(const rxgpu_fm_stream *s);
+
+/* --------------------------------------------------------- rx_power: drop-in */
+
+/* Replaces scanner(channel)'s per-tune compute at rtl_power.c:709-770 for tunes whose
+ * buf16 the caller has already filled (the device I/O part of scanner(), 683-703, stays with
+ * the caller): for every tune, ts->avg[] += / MAX= and ts->samples += exactly as the CPU.
+ * Globals of the reference are passed explicitly: window_coefs (rtl_power.c:87,1034-1037),
+ * Sinewave (82,240-254; 3/4 * 2^bin_e entries), boxcar/comp_fir_size/peak_hold (115-117). */
+int rxgpu_scan(struct tuning_state *tunes, int tune_count, const int *window_coefs,
+               const int16_t *sinewave, int boxcar, int comp_fir_size, int peak_hold);
+
+/* Replaces csv_dbm(ts) (rtl_power.c:774-817), writing to `file`. Host code, unchanged math. */
+void rxgpu_csv_dbm(struct tuning_state *ts, void *file /* FILE* */);
+
+/* Host-side planners/tables with the reference's exact arithmetic (needed to size shards):
+ * frequency_range (rtl_power.c:431-543), sine_table (240-254), window tables (322-401). */
+typedef struct rxgpu_power_plan {
+	int tune_count, bin_e, buf_len, downsample, downsample_passes, rate;
+	int64_t first_freq, bw_seen;
+	double crop;
+} rxgpu_power_plan;
+int rxgpu_power_plan_range(const char *range, double crop, int boxcar, rxgpu_power_plan *plan);
+int rxgpu_sine_table(int log2n, int16_t *sinewave /* 3n/4 entries */);
+int rxgpu_window_coefs(const char *name, int length, int *coefs);
+
+/* -------------------------------------------------------- rx_power: batched scan */
+
+typedef struct rxgpu_power_params {
+	int bin_e, buf_len, downsample, downsample_passes;
+	int boxcar, comp_fir_size, peak_hold;
+} rxgpu_power_params;
+
+typedef struct rxgpu_power_scan rxgpu_power_scan;
+
+int rxgpu_power_scan_create(rxgpu_power_scan **out, const rxgpu_power_params *p, int max_tunes,
+                            const int *window_coefs, const int16_t *sinewave);
+void rxgpu_power_scan_destroy(rxgpu_power_scan *s);
+
+/* `passes` scanner() passes over `tunes` tunes.
+ * d_in  : DEVICE, [passes][tunes][buf_len] int16.
+ * d_avg : DEVICE, [tunes][1<<bin_e] int64, accumulated into (+= or MAX with peak_hold).
+ * d_samples: DEVICE, [tunes] int32, accumulated into.
+ * Asynchronous on rxgpu_stream(); call rxgpu_sync() (or a hipStreamSynchronize) to wait. */
+int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, int tunes,
+                         int64_t *d_avg, int32_t *d_samples);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

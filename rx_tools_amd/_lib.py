@@ -1,0 +1,65 @@
+"""Loads librxgpu.so and declares the C ABI of include/rxgpu.h for ctypes."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librxgpu.so")
+
+
+class RxGpuError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# every symbol include/rxgpu.h declares; tests/test_abi.py checks they are all exported
+EXPORTS = [
+    "rxgpu_init", "rxgpu_shutdown", "rxgpu_device_count", "rxgpu_last_error", "rxgpu_stream", "rxgpu_sync",
+    "rxgpu_prof_enable", "rxgpu_prof_reset", "rxgpu_prof_get",
+    "rxgpu_full_demod", "rxgpu_callback", "rxgpu_deemph_state",
+    "rxgpu_fm_stream_create", "rxgpu_fm_stream_destroy", "rxgpu_fm_stream_set_carry", "rxgpu_fm_stream_get_carry",
+    "rxgpu_fm_stream_run", "rxgpu_fm_stream_run_host", "rxgpu_fm_stream_host_fixups",
+    "rxgpu_scan", "rxgpu_csv_dbm", "rxgpu_power_plan_range", "rxgpu_sine_table", "rxgpu_window_coefs",
+    "rxgpu_power_scan_create", "rxgpu_power_scan_destroy", "rxgpu_power_scan_run",
+]
+
+
+def lib():
+    """The loaded library.  Raises if it has not been built -- there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RxGpuError(
+                "librxgpu.so is missing (%s); build it with `make -C rx_tools_amd/csrc` or "
+                "__graft_entry__.build().  rx_tools_amd has no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.rxgpu_last_error.restype = C.c_char_p
+        L.rxgpu_stream.restype = C.c_void_p
+        L.rxgpu_deemph_state.restype = C.POINTER(C.c_int)
+        L.rxgpu_fm_stream_host_fixups.restype = C.c_long
+        L.rxgpu_fm_stream_host_fixups.argtypes = [C.c_void_p]
+        L.rxgpu_prof_get.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_long)]
+        L.rxgpu_fm_stream_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t, C.c_size_t]
+        L.rxgpu_fm_stream_destroy.argtypes = [C.c_void_p]
+        L.rxgpu_fm_stream_set_carry.argtypes = [C.c_void_p, C.c_void_p]
+        L.rxgpu_fm_stream_get_carry.argtypes = [C.c_void_p, C.c_void_p]
+        L.rxgpu_fm_stream_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
+                                          C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+        L.rxgpu_fm_stream_run_host.argtypes = L.rxgpu_fm_stream_run.argtypes
+        L.rxgpu_power_scan_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.rxgpu_power_scan_destroy.argtypes = [C.c_void_p]
+        L.rxgpu_power_scan_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.rxgpu_power_plan_range.argtypes = [C.c_char_p, C.c_double, C.c_int, C.c_void_p]
+        L.rxgpu_sine_table.argtypes = [C.c_int, C.c_void_p]
+        L.rxgpu_window_coefs.argtypes = [C.c_char_p, C.c_int, C.c_void_p]
+        L.rxgpu_scan.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.rxgpu_csv_dbm.argtypes = [C.c_void_p, C.c_void_p]
+        L.rxgpu_full_demod.argtypes = [C.c_void_p]
+        L.rxgpu_callback.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RxGpuError("librxgpu error %d: %s" % (rc, lib().rxgpu_last_error().decode()))

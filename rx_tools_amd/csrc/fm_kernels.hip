@@ -1,0 +1,794 @@
+// fm_kernels.hip -- gfx950 kernels for the rx_fm stream pre-stage + full_demod() chain.
+//
+// Reference behaviour (file:line under /root/reference/src):
+//   F0 scale        rtl_fm.c:845-848     F1 rotate16_90   rtl_fm.c:309-327
+//   F2 low_pass     rtl_fm.c:351-371     F3 fifth_order   rtl_fm.c:411-440, 764-769
+//   F5 fm_demod     rtl_fm.c:584-615     F6 polar_disc_fast/fast_atan2 rtl_fm.c:485-513
+//   F8 deemph       rtl_fm.c:667-682     F9 low_pass_real rtl_fm.c:389-409
+//   F12 generic_fir rtl_fm.c:442-465
+//
+// All arithmetic is integer and bit-exact with the C reference except where the reference
+// itself goes through libm (polar_discriminant, rtl_fm.c:476-483): there the device
+// evaluates in fp64 and flags results too close to a truncation boundary for the host to
+// re-evaluate with the same libm the reference uses.
+//
+// Data layout: the IQ stream is int16 I,Q interleaved (cs16) exactly as SoapySDR delivers
+// it; one complex sample = one dword.  A lane reads 4 consecutive samples with one
+// global_load_dwordx4 (1 KiB per wave instruction, fully coalesced).  Decimated IQ is kept
+// packed (I | Q<<16) mod 2^16, which is exactly the int16 truncation the reference applies
+// when it stores int sums back into lowpassed[].
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernels.h"
+
+typedef unsigned long long u64;
+typedef long long i64;
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define DEC_THREADS 256
+#define DEC_WAVE_SPAN (RXK_DEC_SPAN / 4)     // samples per wave
+#define DEC_TILE 256                         // samples per wave load (64 lanes x 4)
+#define DEC_TILES (DEC_WAVE_SPAN / DEC_TILE) // 16
+
+// ------------------------------------------------------------------ small helpers
+
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b)
+{
+	s16x2 r = __builtin_bit_cast(s16x2, a) + __builtin_bit_cast(s16x2, b);   // v_pk_add_u16
+	return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b)
+{
+	s16x2 r = __builtin_bit_cast(s16x2, a) - __builtin_bit_cast(s16x2, b);   // v_pk_sub_u16
+	return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pack_iq(int i, int q) { return ((uint32_t)i & 0xffffu) | ((uint32_t)q << 16); }
+__device__ __forceinline__ int lo16(uint32_t w) { return (int)(short)(w & 0xffffu); }
+__device__ __forceinline__ int hi16(uint32_t w) { return (int)w >> 16; }
+
+// F0, rtl_fm.c:846: (int16)(x / 32767.0 * 128.0 + 0.4) in double, truncated.  One fp32
+// fma reproduces it for all 65536 inputs (checked exhaustively in tests/test_scale.py and
+// on the device in tests/test_gpu_fm.py): the result is never closer than 6.0e-6 to an
+// integer while the single rounding error of fma at magnitude <= 128.4 is <= 3.9e-6 and
+// the coefficient error contributes <= 3.8e-6 of the same sign budget.
+__device__ __forceinline__ int scale_cs16(int x)
+{
+	return (int)__builtin_fmaf((float)x, (float)(128.0 / 32767.0), 0.4f);
+}
+
+// wave64 inclusive scan of packed int16 pairs with DPP (row_shr 1,2,4,8 then row_bcast 15/31)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_step(uint32_t v)
+{
+	uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+	return pk_add(v, t);
+}
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
+{
+	v = dpp_step<0x111, 0xf>(v);
+	v = dpp_step<0x112, 0xf>(v);
+	v = dpp_step<0x114, 0xf>(v);
+	v = dpp_step<0x118, 0xf>(v);
+	v = dpp_step<0x142, 0xa>(v);
+	v = dpp_step<0x143, 0xc>(v);
+	return v;
+}
+
+// ------------------------------------------------------------------ F0+F1+F2 fused
+
+// One workgroup = RXK_DEC_SPAN consecutive complex samples of the stream, 4 waves of
+// DEC_WAVE_SPAN each.  Every lane turns its 4 samples into rotated, scaled partial sums,
+// a wave-level DPP scan gives the running (I,Q) prefix, and the lane that holds the last
+// sample of a boxcar window drops the prefix at that point into an LDS slot.  After a
+// barrier, output j = slot[j] - slot[j-1].  The window that straddles the workgroup start
+// is finished by rxk_fm_disc from head[]/tail[].
+template <bool PRESCALED, bool ROTATE>
+__global__ __launch_bounds__(DEC_THREADS) void k_fm_decimate(
+	const u32x4 *__restrict__ iq, u64 T, int ds, int p0, unsigned magic,
+	uint32_t *__restrict__ lp_raw, uint32_t *__restrict__ head, uint32_t *__restrict__ tail, unsigned slot_cap)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+	uint32_t *slot = lds;
+	uint32_t *wtot = lds + slot_cap;
+
+	const u64 wg0 = (u64)blockIdx.x * RXK_DEC_SPAN;
+	const u64 left = T - wg0;
+	const unsigned span = left < (u64)RXK_DEC_SPAN ? (unsigned)left : (unsigned)RXK_DEC_SPAN;
+	const u64 t0 = wg0 + (unsigned)p0;
+	const u64 m_base = t0 / (unsigned)ds;                  // outputs completed before this span
+	const unsigned ph = (unsigned)(t0 - m_base * (unsigned)ds);
+	const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const u32x4 *src = iq + (wg0 >> 2);
+
+	uint32_t run = 0;                                       // wave-uniform running prefix
+#pragma unroll
+	for (int half = 0; half < 2; half++) {
+		u32x4 v[DEC_TILES / 2];
+#pragma unroll
+		for (int u = 0; u < DEC_TILES / 2; u++) {
+			unsigned rel = wave * DEC_WAVE_SPAN + (half * (DEC_TILES / 2) + u) * DEC_TILE + lane * 4;
+			v[u] = rel < span ? __builtin_nontemporal_load(src + (rel >> 2)) : (u32x4)(0u);
+		}
+#pragma unroll
+		for (int u = 0; u < DEC_TILES / 2; u++) {
+			const unsigned rel = wave * DEC_WAVE_SPAN + (half * (DEC_TILES / 2) + u) * DEC_TILE + lane * 4;
+			int i0 = lo16(v[u].x), q0 = hi16(v[u].x), i1 = lo16(v[u].y), q1 = hi16(v[u].y);
+			int i2 = lo16(v[u].z), q2 = hi16(v[u].z), i3 = lo16(v[u].w), q3 = hi16(v[u].w);
+			if (!PRESCALED) {
+				i0 = scale_cs16(i0); q0 = scale_cs16(q0); i1 = scale_cs16(i1); q1 = scale_cs16(q1);
+				i2 = scale_cs16(i2); q2 = scale_cs16(q2); i3 = scale_cs16(i3); q3 = scale_cs16(q3);
+			}
+			// rotate16_90: sample n of the block times j^n; a lane's 4 samples sit at phases 0..3
+			int c1i = i0, c1q = q0;
+			int c2i = c1i + (ROTATE ? -q1 : i1), c2q = c1q + (ROTATE ? i1 : q1);
+			int c3i = c2i + (ROTATE ? -i2 : i2), c3q = c2q + (ROTATE ? -q2 : q2);
+			int c4i = c3i + (ROTATE ? q3 : i3), c4q = c3q + (ROTATE ? -i3 : q3);
+			const uint32_t tot = pack_iq(c4i, c4q);
+			const uint32_t incl = wave_scan_incl(tot);
+			// does a window end inside this lane?  windows end (exclusive) at (j+1)*ds - ph
+			const unsigned qn = rel + 4 + ph;
+			const unsigned k = __umulhi(qn, magic);         // floor(qn / ds)
+			const unsigned e = k * (unsigned)ds - ph;
+			if (k >= 1 && e > rel && rel < span) {
+				const unsigned cnt = e - rel;               // 1..4 samples of this lane belong to it
+				const int si = cnt == 1 ? c1i : cnt == 2 ? c2i : cnt == 3 ? c3i : c4i;
+				const int sq = cnt == 1 ? c1q : cnt == 2 ? c2q : cnt == 3 ? c3q : c4q;
+				slot[k - 1] = pk_add(pk_add(run, pk_sub(incl, tot)), pack_iq(si, sq));
+			}
+			run = pk_add(run, (uint32_t)__builtin_amdgcn_readlane((int)incl, 63));
+		}
+	}
+	if (lane == 0)
+		wtot[wave] = run;
+	__syncthreads();
+
+	const uint32_t b1 = wtot[0], b2 = pk_add(b1, wtot[1]), b3 = pk_add(b2, wtot[2]);
+	const uint32_t total = pk_add(b3, wtot[3]);
+	const unsigned n_b = (span + ph) / (unsigned)ds;
+	for (unsigned j = threadIdx.x; j < n_b; j += DEC_THREADS) {
+		const unsigned e = (j + 1) * (unsigned)ds - ph;
+		const unsigned wv = (e - 1) / DEC_WAVE_SPAN;
+		const uint32_t pj = pk_add(slot[j], wv == 0 ? 0u : wv == 1 ? b1 : wv == 2 ? b2 : b3);
+		if (j == 0) {
+			head[blockIdx.x] = pj;
+		} else {
+			const unsigned wq = (e - (unsigned)ds - 1) / DEC_WAVE_SPAN;
+			const uint32_t pm = pk_add(slot[j - 1], wq == 0 ? 0u : wq == 1 ? b1 : wq == 2 ? b2 : b3);
+			lp_raw[m_base + j] = pk_sub(pj, pm);
+		}
+	}
+	if (threadIdx.x == 0) {
+		uint32_t last = 0;
+		if (n_b) {
+			const unsigned e = n_b * (unsigned)ds - ph;
+			const unsigned wv = (e - 1) / DEC_WAVE_SPAN;
+			last = pk_add(slot[n_b - 1], wv == 0 ? 0u : wv == 1 ? b1 : wv == 2 ? b2 : b3);
+		} else {
+			head[blockIdx.x] = 0;
+		}
+		tail[blockIdx.x] = pk_sub(total, last);
+	}
+}
+
+// One sample, scaled and rotated by its position in its block (exact int)
+template <bool PRESCALED>
+__device__ __forceinline__ void load_rot(const uint32_t *iq, u64 pos, unsigned phase, int &ri, int &rq)
+{
+	const uint32_t w = iq[pos];
+	int i = lo16(w), q = hi16(w);
+	if (!PRESCALED) { i = scale_cs16(i); q = scale_cs16(q); }
+	switch (phase & 3) {
+	case 0: ri = i; rq = q; break;
+	case 1: ri = -q; rq = i; break;
+	case 2: ri = -i; rq = -q; break;
+	default: ri = q; rq = -i; break;
+	}
+}
+
+// Generic form: one thread per output, any ds, any block length (rotation phase = position
+// in the block, rtl_fm.c:315).
+template <bool PRESCALED>
+__global__ void k_fm_decimate_generic(const uint32_t *__restrict__ iq, u64 T, int ds, int p0, u64 n_per_block,
+                                      int rotate, const rxk_fm_dev *__restrict__ dev, uint32_t *__restrict__ lp, u64 M)
+{
+	const u64 m = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (m >= M)
+		return;
+	u64 start = m ? m * (u64)ds - (u64)p0 : 0;
+	const u64 end = (m + 1) * (u64)ds - (u64)p0;
+	int si = 0, sq = 0;
+	if (m == 0) { si = dev->in_now_r; sq = dev->in_now_j; }
+	u64 inblk = start % n_per_block;
+	for (u64 pos = start; pos < end; pos++) {
+		int ri, rq;
+		load_rot<PRESCALED>(iq, pos, rotate ? (unsigned)inblk : 0u, ri, rq);
+		si += ri; sq += rq;
+		if (++inblk == n_per_block) inblk = 0;
+	}
+	lp[m] = pack_iq(si, sq);
+}
+
+// ------------------------------------------------------------------ F5/F6 discriminator
+
+// rtl_fm.c:485-506 with the int32 wrap of `pi4 * (x -/+ yabs)` and C's truncating division
+__device__ __forceinline__ int fast_atan2_dev(int y, int x)
+{
+	if (x == 0 && y == 0)
+		return 0;
+	const unsigned ux = (unsigned)x;
+	const unsigned ay = y < 0 ? 0u - (unsigned)y : (unsigned)y;
+	int ang;
+	if (x >= 0) {
+		const int num = (int)(4096u * (ux - ay));
+		const int den = (int)(ux + ay);
+		ang = 4096 - num / den;
+	} else {
+		const int num = (int)(4096u * (ux + ay));
+		const int den = (int)(ay - ux);
+		ang = 12288 - num / den;
+	}
+	return y < 0 ? -ang : ang;
+}
+
+__device__ __forceinline__ uint32_t lp_final(u64 m, int ds, int p0, int seams, const uint32_t *lp_raw,
+                                             const uint32_t *head, const uint32_t *tail, uint32_t carry)
+{
+	if (!seams)
+		return lp_raw[m];
+	const u64 e1 = (m + 1) * (u64)ds - (u64)p0 - 1;          // stream position of the window's last sample
+	const u64 g = e1 >> RXK_DEC_SPAN_LOG2;
+	const u64 mb = ((g << RXK_DEC_SPAN_LOG2) + (u64)p0) / (u64)ds;
+	if (mb == m)
+		return pk_add(g ? tail[g - 1] : carry, head[g]);
+	return lp_raw[m];
+}
+
+// grid: ceil(M/256) blocks for the outputs (+1 block for the exact low_pass tail sums)
+template <bool PRESCALED>
+__global__ __launch_bounds__(256) void k_fm_disc(
+	const uint32_t *__restrict__ iq, u64 T, int ds, int p0, u64 n_per_block, int rotate, int seams,
+	const uint32_t *__restrict__ lp_raw, const uint32_t *__restrict__ head, const uint32_t *__restrict__ tail,
+	uint32_t *__restrict__ lp, u64 M, int first_mode, u64 uniform_k, int custom_atan, int do_tail,
+	int16_t *__restrict__ pcm, rxk_fm_dev *__restrict__ dev, u64 *__restrict__ flag_list, unsigned out_blocks)
+{
+	if (blockIdx.x >= out_blocks) {
+		// ---- low_pass carry: exact int32 sums of the samples after the last complete window
+		__shared__ int red[2][4];
+		const u64 done = M ? M * (u64)ds - (u64)p0 : 0;        // samples consumed by complete windows
+		int si = 0, sq = 0;
+		for (u64 pos = done + threadIdx.x; pos < T; pos += 256) {
+			int ri, rq;
+			load_rot<PRESCALED>(iq, pos, rotate ? (unsigned)(pos % n_per_block) : 0u, ri, rq);
+			si += ri; sq += rq;
+		}
+		for (int off = 32; off; off >>= 1) { si += __shfl_down(si, off); sq += __shfl_down(sq, off); }
+		if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = si; red[1][threadIdx.x >> 6] = sq; }
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			si = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+			sq = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+			if (M == 0) { si += dev->in_now_r; sq += dev->in_now_j; }
+			dev->out_now_r = si;
+			dev->out_now_j = sq;
+			dev->out_prev_index = (int)((u64)p0 + T - M * (u64)ds);
+		}
+		return;
+	}
+	const u64 m = (u64)blockIdx.x * 256 + threadIdx.x;
+	if (m >= M)
+		return;
+	const uint32_t carry = pack_iq(dev->in_now_r, dev->in_now_j);
+	const uint32_t a = lp_final(m, ds, p0, seams, lp_raw, head, tail, carry);
+	if (seams)
+		lp[m] = a;
+	int br, bj;
+	if (m) {
+		const uint32_t b = lp_final(m - 1, ds, p0, seams, lp_raw, head, tail, carry);
+		br = lo16(b); bj = hi16(b);
+	} else {
+		br = dev->in_pre_r; bj = dev->in_pre_j;
+	}
+	const int ar = lo16(a), aj = hi16(a);
+	// multiply(a, conj(b)), rtl_fm.c:470-474 via 480/511, wrapping like -fwrapv
+	const int cr = (int)((unsigned)ar * (unsigned)br + (unsigned)aj * (unsigned)bj);
+	const int cj = (int)((unsigned)aj * (unsigned)br - (unsigned)ar * (unsigned)bj);
+
+	bool first;
+	if (first_mode == RXK_FIRST_UNIFORM) {
+		first = (m % uniform_k) == 0;
+	} else {
+		const u64 e1 = (m + 1) * (u64)ds - (u64)p0 - 1;
+		const u64 b = e1 / n_per_block;
+		first = ((b * n_per_block + (u64)p0) / (u64)ds) == m;
+	}
+	int out;
+	if (first || custom_atan == 0) {
+		// polar_discriminant, rtl_fm.c:476-483: (int)(atan2(cj,cr) / 3.14159 * (1<<14))
+		const double ang = atan2((double)cj, (double)cr);
+		const double v = ang / 3.14159 * 16384.0;
+		out = (int)v;
+		if (v != 0.0 && fabs(v - rint(v)) < 1e-6) {
+			const int idx = atomicAdd(&dev->flag_cnt, 1);
+			if (idx < RXK_FLAG_CAP)
+				flag_list[idx] = m;
+		}
+	} else {
+		out = fast_atan2_dev(cj, cr);
+	}
+	pcm[m] = (int16_t)out;
+	if (m == M - 1) {
+		dev->out_pre_r = ar;
+		dev->out_pre_j = aj;
+	}
+}
+
+// ------------------------------------------------------------------ F8 de-emphasis
+
+// avg += trunc((d +- a/2) / a), rtl_fm.c:674-679  ==  avg += sign(d) * floor((|d| + a/2) / a)
+__device__ __forceinline__ int deemph_step(int avg, int x, int a, int h, unsigned magic)
+{
+	const int d = x - avg;
+	const unsigned t = (unsigned)(d < 0 ? -d : d) + (unsigned)h;
+	const unsigned q = a == 1 ? t : __umulhi(t, magic);
+	return avg + (d < 0 ? -(int)q : (int)q);
+}
+
+// The per-sample map avg -> avg' is monotone with slope 0 or 1, so trajectories started from
+// the two ends of the possible state range sandwich the true one and their gap shrinks by
+// at least floor(gap/a) per step.  After `warm` samples the gap is < a <= GS; the GS lanes of
+// a group then carry every still-possible start state through the chunk, giving the exact
+// chunk map as a table.  Chunks whose trajectories merged (gap 0) are final immediately.
+template <int GS>
+__global__ __launch_bounds__(256) void k_fm_deemph_scan(
+	const int16_t *__restrict__ pcm, u64 M, int a, unsigned magic, int chunk, int warm, int lo0, int hi0,
+	int16_t *__restrict__ y, int *__restrict__ tab, int *__restrict__ lo_arr, int *__restrict__ gap_arr,
+	rxk_fm_dev *__restrict__ dev)
+{
+	extern __shared__ __attribute__((aligned(16))) int16_t xs[];
+	const int groups = 256 / GS;
+	const int grp = threadIdx.x / GS, k = threadIdx.x % GS;
+	const u64 c = (u64)blockIdx.x * groups + grp;
+	const u64 n_chunks = (M + chunk - 1) / chunk;
+	if (c >= n_chunks)
+		return;                                   // whole group leaves together; no barriers below
+	int16_t *buf = xs + (size_t)grp * (warm + chunk);
+	const u64 c0 = c * (u64)chunk;
+	const bool exact = c0 <= (u64)warm;           // the run's carried state is in reach
+	const u64 ws = exact ? 0 : c0 - warm;
+	const u64 c1 = (c0 + chunk < M) ? c0 + chunk : M;
+	const int nw = (int)(c0 - ws), nc = (int)(c1 - c0);
+	for (int i = k; i < nw + nc; i += GS)
+		buf[i] = pcm[ws + i];
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	const int h = a / 2;
+	int s = exact ? dev->in_deemph_avg : (k == 0 ? lo0 : hi0);
+	for (int i = 0; i < nw; i++)
+		s = deemph_step(s, buf[i], a, h, magic);
+	const int base = (threadIdx.x & 63) - k;      // first lane of this group within the wave
+	const int lo = __shfl(s, base), hi = __shfl(s, base + (GS > 1 ? 1 : 0));
+	int gap = exact ? 0 : hi - lo;
+	if (gap >= GS) {                              // cannot happen for warm from rxgpu_fm.c; checked anyway
+		if (k == 0) atomicExch(&dev->err, 1);
+		gap = GS - 1;
+	}
+	s = lo + (k < gap ? k : gap);
+	const bool writer = (gap == 0 && k == 0);
+	for (int i = 0; i < nc; i++) {
+		s = deemph_step(s, buf[nw + i], a, h, magic);
+		if (writer)
+			buf[nw + i] = (int16_t)s;
+	}
+	tab[c * GS + k] = s;
+	if (k == 0) {
+		lo_arr[c] = lo;
+		gap_arr[c] = gap;
+		if (gap)
+			atomicOr(&dev->any_unmerged, 1);
+		else if (c == n_chunks - 1)
+			dev->out_deemph_avg = s;
+	}
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	if (gap == 0)
+		for (int i = k; i < nc; i += GS)
+			y[c0 + i] = buf[nw + i];
+}
+
+// Start state of every chunk.  Merged chunks know theirs; a run of unmerged chunks is walked
+// by the thread of its first chunk through the tables.
+__global__ void k_fm_deemph_resolve(u64 n_chunks, int gs, const int *__restrict__ tab, const int *__restrict__ lo_arr,
+                                    const int *__restrict__ gap_arr, int *__restrict__ start_arr,
+                                    const rxk_fm_dev *__restrict__ dev)
+{
+	if (!dev->any_unmerged)
+		return;
+	const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= n_chunks)
+		return;
+	if (gap_arr[c] == 0) {
+		start_arr[c] = lo_arr[c];
+		return;
+	}
+	if (gap_arr[c - 1] != 0)                     // chunk 0 always has gap 0, so c >= 1 here
+		return;
+	int s = tab[(c - 1) * gs];                    // previous chunk merged: lane 0 ran the true state
+	start_arr[c] = s;
+	u64 cc = c;
+	while (cc + 1 < n_chunks && gap_arr[cc + 1] != 0) {
+		s = tab[cc * gs + (s - lo_arr[cc])];
+		cc++;
+		start_arr[cc] = s;
+	}
+}
+
+__global__ void k_fm_deemph_fix(const int16_t *__restrict__ pcm, u64 M, int a, unsigned magic, int gs, int chunk,
+                                const int *__restrict__ gap_arr, const int *__restrict__ start_arr,
+                                int16_t *__restrict__ y, rxk_fm_dev *__restrict__ dev)
+{
+	if (!dev->any_unmerged)
+		return;
+	const u64 n_chunks = (M + chunk - 1) / chunk;
+	const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= n_chunks || gap_arr[c] == 0)
+		return;
+	const u64 c0 = c * (u64)chunk;
+	const u64 c1 = (c0 + chunk < M) ? c0 + chunk : M;
+	const int h = a / 2;
+	int s = start_arr[c];
+	for (u64 i = c0; i < c1; i++) {
+		s = deemph_step(s, pcm[i], a, h, magic);
+		y[i] = (int16_t)s;
+	}
+	if (c == n_chunks - 1)
+		dev->out_deemph_avg = s;
+}
+
+__global__ void k_fm_deemph_serial(const int16_t *__restrict__ pcm, u64 M, int a, int16_t *__restrict__ y,
+                                   rxk_fm_dev *__restrict__ dev)
+{
+	if (threadIdx.x || blockIdx.x)
+		return;
+	int s = dev->in_deemph_avg;
+	const int h = a / 2;
+	for (u64 i = 0; i < M; i++) {
+		const int d = pcm[i] - s;
+		s += d > 0 ? (d + h) / a : (d - h) / a;
+		y[i] = (int16_t)s;
+	}
+	dev->out_deemph_avg = s;
+}
+
+// ------------------------------------------------------------------ F9 low_pass_real
+
+// rtl_fm.c:389-409 in closed form.  With phase p0 < fast and slow <= fast, after i inputs
+// floor((p0 + i*slow)/fast) outputs exist, so output j sums inputs [E(j-1), E(j)) with
+// E(j) = ceil(((j+1)*fast - p0) / slow), E(-1) = 0, and is (int16)(sum / (fast/slow)).
+__device__ __forceinline__ u64 lpr_end(u64 j, u64 fast, u64 slow, u64 p0)
+{
+	return ((j + 1) * fast - p0 + slow - 1) / slow;
+}
+
+__global__ void k_fm_resample(const int16_t *__restrict__ y, u64 n, int fast, int slow, u64 J,
+                              int16_t *__restrict__ out, rxk_fm_dev *__restrict__ dev)
+{
+	const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	const u64 p0 = (u64)dev->in_prev_lpr_index;
+	const int ratio = fast / slow;
+	if (j < J) {
+		const u64 b = j ? lpr_end(j - 1, fast, slow, p0) : 0;
+		const u64 e = lpr_end(j, fast, slow, p0);
+		int sum = j ? 0 : dev->in_now_lpr;
+		for (u64 i = b; i < e; i++)
+			sum += y[i];
+		out[j] = (int16_t)(sum / ratio);
+	}
+	if (j == J) {                                 // one extra thread: the carries
+		const u64 b = J ? lpr_end(J - 1, fast, slow, p0) : 0;
+		int sum = J ? 0 : dev->in_now_lpr;
+		for (u64 i = b; i < n; i++)
+			sum += y[i];
+		dev->out_now_lpr = sum;
+		dev->out_prev_lpr_index = (int)(p0 + n * (u64)slow - J * (u64)fast);
+	}
+}
+
+__global__ void k_fm_passthrough_carry(rxk_fm_dev *dev, int deemph_off, int resample_off)
+{
+	if (deemph_off)
+		dev->out_deemph_avg = dev->in_deemph_avg;
+	if (resample_off) {
+		dev->out_now_lpr = dev->in_now_lpr;
+		dev->out_prev_lpr_index = dev->in_prev_lpr_index;
+	}
+}
+
+// ------------------------------------------------------------------ F3 fifth_order cascade
+
+// One pass of rtl_fm.c:411-440 over every block at once.  On the strided sequence s_k of one
+// component, output k of a block is
+//   (s[2k-5] + 5(s[2k-4] + s[2k-1]) + 10(s[2k-3] + s[2k-2]) + s[2k]) >> 4      (int, then int16)
+// where negative indices reach into the previous block's SAME-pass input: its samples
+// 2K'-4 .. 2K' with K' = ceil(n/2)-1 the index of its last output (for even n the block's last
+// sample is never consumed, rtl_fm.c:424-432).  Block 0 of a run takes them from the carried
+// lp_*_hist[pass][1..5].
+template <bool RAW, bool PRESCALED, bool ROTATE>
+__device__ __forceinline__ void fifth_tap(const void *in, u64 blk, unsigned idx, unsigned in_stride, int &ri, int &rq)
+{
+	if (RAW) {
+		const uint32_t *p = (const uint32_t *)in + blk * (u64)in_stride;
+		const uint32_t w = p[idx];
+		int i = lo16(w), q = hi16(w);
+		if (!PRESCALED) { i = scale_cs16(i); q = scale_cs16(q); }
+		if (ROTATE) {
+			switch (idx & 3) {
+			case 0: ri = i; rq = q; break;
+			case 1: ri = -q; rq = i; break;
+			case 2: ri = -i; rq = -q; break;
+			default: ri = q; rq = -i; break;
+			}
+			// the reference stores the rotated value back into int16 (rtl_fm.c:316-325)
+			ri = (int)(short)ri; rq = (int)(short)rq;
+		} else {
+			ri = i; rq = q;
+		}
+	} else {
+		const uint32_t w = ((const uint32_t *)in)[blk * (u64)in_stride + idx];
+		ri = lo16(w); rq = hi16(w);
+	}
+}
+
+template <bool RAW, bool PRESCALED, bool ROTATE>
+__global__ __launch_bounds__(256) void k_fm_fifth_pass(
+	const void *__restrict__ in, u64 n_blocks, unsigned n_in, unsigned in_stride, uint32_t *__restrict__ out,
+	unsigned out_stride, const int16_t *__restrict__ hist_in, int16_t *__restrict__ hist_out)
+{
+	const unsigned n_out = (n_in + 1) / 2;
+	const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
+	if (gid >= n_blocks * (u64)n_out)
+		return;
+	const u64 blk = gid / n_out;
+	const unsigned k = (unsigned)(gid - blk * n_out);
+	const unsigned kl = n_out - 1;                 // K' of any (equal-length) block
+	int ti[6], tq[6];
+#pragma unroll
+	for (int t = 0; t < 6; t++) {
+		const int idx = (int)(2 * k) - 5 + t;
+		if (idx >= 0) {
+			fifth_tap<RAW, PRESCALED, ROTATE>(in, blk, (unsigned)idx, in_stride, ti[t], tq[t]);
+		} else if (blk == 0) {
+			// carried history: s[-5..-1] = hist[1..5]
+			ti[t] = hist_in[6 + idx];
+			tq[t] = hist_in[6 + 6 + idx];
+		} else {
+			// previous block, same pass: s[-1] = its sample 2K', s[-5] = 2K'-4
+			const int pidx = (int)(2 * kl) + 1 + idx;  // idx in -5..-1 -> 2K'-4 .. 2K'
+			if (pidx >= 0) {
+				fifth_tap<RAW, PRESCALED, ROTATE>(in, blk - 1, (unsigned)pidx, in_stride, ti[t], tq[t]);
+			} else {
+				ti[t] = 0; tq[t] = 0;              // blocks shorter than the filter: rejected by the host
+			}
+		}
+	}
+	const int oi = (ti[0] + (ti[1] + ti[4]) * 5 + (ti[2] + ti[3]) * 10 + ti[5]) >> 4;
+	const int oq = (tq[0] + (tq[1] + tq[4]) * 5 + (tq[2] + tq[3]) * 10 + tq[5]) >> 4;
+	out[blk * (u64)out_stride + k] = pack_iq(oi, oq);
+	if (blk == n_blocks - 1 && k == kl) {
+		// archive, rtl_fm.c:434-439: the last window
+#pragma unroll
+		for (int t = 0; t < 6; t++) {
+			hist_out[t] = (int16_t)ti[t];
+			hist_out[6 + t] = (int16_t)tq[t];
+		}
+	}
+}
+
+// ------------------------------------------------------------------ F12 droop FIR
+
+// rtl_fm.c:442-465: out[t] = (sum over the 9 samples BEFORE t) >> 15; hist carries across blocks,
+// so over the concatenated post-cascade stream it is a plain FIR on s[t-9 .. t-1].
+__global__ void k_fm_droop(const uint32_t *__restrict__ in, u64 M, const int *__restrict__ fir,
+                           const int16_t *__restrict__ hist_in, int16_t *__restrict__ hist_out, uint32_t *__restrict__ out)
+{
+	const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= M)
+		return;
+	int hi[9], hq[9];
+#pragma unroll
+	for (int j = 0; j < 9; j++) {
+		const i64 idx = (i64)t - 9 + j;
+		if (idx >= 0) {
+			const uint32_t w = in[idx];
+			hi[j] = lo16(w); hq[j] = hi16(w);
+		} else {
+			hi[j] = hist_in[9 + idx];              // hist[0..8] = s[-9..-1]
+			hq[j] = hist_in[9 + 9 + idx];
+		}
+	}
+	const int f1 = fir[1], f2 = fir[2], f3 = fir[3], f4 = fir[4], f5 = fir[5];
+	const int si = (hi[0] + hi[8]) * f1 + (hi[1] + hi[7]) * f2 + (hi[2] + hi[6]) * f3 + (hi[3] + hi[5]) * f4 + hi[4] * f5;
+	const int sq = (hq[0] + hq[8]) * f1 + (hq[1] + hq[7]) * f2 + (hq[2] + hq[6]) * f3 + (hq[3] + hq[5]) * f4 + hq[4] * f5;
+	out[t] = pack_iq(si >> 15, sq >> 15);
+	if (t == M - 1) {
+		// new history = the last 9 INPUT samples s[M-9 .. M-1]
+		for (int j = 0; j < 9; j++) {
+			const i64 idx = (i64)M - 9 + j;
+			if (idx >= 0) {
+				const uint32_t w = in[idx];
+				hist_out[j] = (int16_t)lo16(w);
+				hist_out[9 + j] = (int16_t)hi16(w);
+			} else {
+				hist_out[j] = hist_in[9 + idx + 0];
+				hist_out[9 + j] = hist_in[9 + 9 + idx];
+			}
+		}
+	}
+}
+
+// ------------------------------------------------------------------ callback pre-stage alone
+
+// rtlsdr_callback's scale + rotate (rtl_fm.c:845-857) as an elementwise pass, for the
+// drop-in callback that has to hand a host lowpassed[] back to the reference's threads.
+__global__ void k_fm_prestage(const uint32_t *__restrict__ in, unsigned n, int rotate, uint32_t *__restrict__ out)
+{
+	const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+		return;
+	int ri, rq;
+	load_rot<false>(in, i, rotate ? i : 0u, ri, rq);
+	out[i] = pack_iq(ri, rq);
+}
+
+// ------------------------------------------------------------------ launchers
+
+#define LAUNCH_RET() return (int)hipGetLastError()
+
+extern "C" int rxk_fm_decimate(void *stream, const int16_t *iq, u64 T, int ds, int p0, int prescaled, int rotate,
+                               uint32_t *lp_raw, uint32_t *head, uint32_t *tail)
+{
+	const unsigned grid = (unsigned)((T + RXK_DEC_SPAN - 1) / RXK_DEC_SPAN);
+	const unsigned magic = (unsigned)((1ull << 32) / (unsigned)ds + 1);
+	const unsigned slot_cap = (RXK_DEC_SPAN + ds) / ds + 4;
+	const size_t shm = (size_t)(slot_cap + 4) * sizeof(uint32_t);
+	hipStream_t s = (hipStream_t)stream;
+	const u32x4 *p = (const u32x4 *)iq;
+	if (prescaled)
+		hipLaunchKernelGGL((k_fm_decimate<true, false>), dim3(grid), dim3(DEC_THREADS), shm, s, p, T, ds, p0, magic, lp_raw, head, tail, slot_cap);
+	else if (rotate)
+		hipLaunchKernelGGL((k_fm_decimate<false, true>), dim3(grid), dim3(DEC_THREADS), shm, s, p, T, ds, p0, magic, lp_raw, head, tail, slot_cap);
+	else
+		hipLaunchKernelGGL((k_fm_decimate<false, false>), dim3(grid), dim3(DEC_THREADS), shm, s, p, T, ds, p0, magic, lp_raw, head, tail, slot_cap);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_fm_decimate_generic(void *stream, const int16_t *iq, u64 T, int ds, int p0, u64 n_per_block,
+                                       int prescaled, int rotate, const rxk_fm_dev *dev, uint32_t *lp, u64 M)
+{
+	if (!M)
+		return 0;
+	const unsigned grid = (unsigned)((M + 255) / 256);
+	hipStream_t s = (hipStream_t)stream;
+	if (prescaled)
+		hipLaunchKernelGGL((k_fm_decimate_generic<true>), dim3(grid), dim3(256), 0, s, (const uint32_t *)iq, T, ds, p0, n_per_block, 0, dev, lp, M);
+	else
+		hipLaunchKernelGGL((k_fm_decimate_generic<false>), dim3(grid), dim3(256), 0, s, (const uint32_t *)iq, T, ds, p0, n_per_block, rotate, dev, lp, M);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_fm_disc(void *stream, const int16_t *iq, u64 T, int ds, int p0, u64 n_per_block, int prescaled,
+                           int rotate, int seams, const uint32_t *lp_raw, const uint32_t *head, const uint32_t *tail,
+                           uint32_t *lp, u64 M, int first_mode, u64 uniform_k, int custom_atan, int do_tail,
+                           int16_t *pcm, rxk_fm_dev *dev, u64 *flag_list)
+{
+	const unsigned out_blocks = (unsigned)((M + 255) / 256);
+	const unsigned grid = out_blocks + (do_tail ? 1 : 0);
+	if (!grid)
+		return 0;
+	hipStream_t s = (hipStream_t)stream;
+	if (prescaled)
+		hipLaunchKernelGGL((k_fm_disc<true>), dim3(grid), dim3(256), 0, s, (const uint32_t *)iq, T, ds, p0, n_per_block, 0, seams,
+		                   lp_raw, head, tail, lp, M, first_mode, uniform_k, custom_atan, do_tail, pcm, dev, flag_list, out_blocks);
+	else
+		hipLaunchKernelGGL((k_fm_disc<false>), dim3(grid), dim3(256), 0, s, (const uint32_t *)iq, T, ds, p0, n_per_block, rotate, seams,
+		                   lp_raw, head, tail, lp, M, first_mode, uniform_k, custom_atan, do_tail, pcm, dev, flag_list, out_blocks);
+	LAUNCH_RET();
+}
+
+static unsigned magic_for(int a) { return a > 1 ? (unsigned)((1ull << 32) / (unsigned)a + 1) : 0u; }
+
+extern "C" int rxk_fm_deemph_scan(void *stream, const int16_t *pcm, u64 M, int a, int group, int chunk, int warm,
+                                  int lo0, int hi0, int16_t *y, int *tab, int *lo_arr, int *gap_arr, rxk_fm_dev *dev)
+{
+	if (!M)
+		return 0;
+	const u64 n_chunks = (M + chunk - 1) / chunk;
+	const int groups = 256 / group;
+	const unsigned grid = (unsigned)((n_chunks + groups - 1) / groups);
+	const size_t shm = (size_t)groups * (warm + chunk) * sizeof(int16_t);
+	hipStream_t s = (hipStream_t)stream;
+	if (group == 16)
+		hipLaunchKernelGGL((k_fm_deemph_scan<16>), dim3(grid), dim3(256), shm, s, pcm, M, a, magic_for(a), chunk, warm, lo0, hi0, y, tab, lo_arr, gap_arr, dev);
+	else
+		hipLaunchKernelGGL((k_fm_deemph_scan<64>), dim3(grid), dim3(256), shm, s, pcm, M, a, magic_for(a), chunk, warm, lo0, hi0, y, tab, lo_arr, gap_arr, dev);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_fm_deemph_resolve(void *stream, u64 n_chunks, int group, const int *tab, const int *lo_arr,
+                                     const int *gap_arr, int *start_arr, rxk_fm_dev *dev)
+{
+	if (!n_chunks)
+		return 0;
+	hipLaunchKernelGGL(k_fm_deemph_resolve, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+	                   n_chunks, group, tab, lo_arr, gap_arr, start_arr, dev);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_fm_deemph_fix(void *stream, const int16_t *pcm, u64 M, int a, int group, int chunk, const int *tab,
+                                 const int *lo_arr, const int *gap_arr, const int *start_arr, int16_t *y, rxk_fm_dev *dev)
+{
+	(void)tab; (void)lo_arr;
+	if (!M)
+		return 0;
+	const u64 n_chunks = (M + chunk - 1) / chunk;
+	hipLaunchKernelGGL(k_fm_deemph_fix, dim3((unsigned)((n_chunks + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
+	                   pcm, M, a, magic_for(a), group, chunk, gap_arr, start_arr, y, dev);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_fm_deemph_serial(void *stream, const int16_t *pcm, u64 M, int a, int16_t *y, rxk_fm_dev *dev)
+{
+	hipLaunchKernelGGL(k_fm_deemph_serial, dim3(1), dim3(64), 0, (hipStream_t)stream, pcm, M, a, y, dev);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_fm_resample(void *stream, const int16_t *y, u64 n, int fast, int slow, u64 J, int16_t *out, rxk_fm_dev *dev)
+{
+	hipLaunchKernelGGL(k_fm_resample, dim3((unsigned)((J + 1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, n, fast, slow, J, out, dev);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_fm_passthrough_carry(void *stream, rxk_fm_dev *dev, int deemph_off, int resample_off)
+{
+	hipLaunchKernelGGL(k_fm_passthrough_carry, dim3(1), dim3(1), 0, (hipStream_t)stream, dev, deemph_off, resample_off);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_fm_fifth_pass(void *stream, const void *in, int in_is_raw, int prescaled, int rotate, u64 n_blocks,
+                                 unsigned n_in, unsigned in_stride, uint32_t *out, unsigned out_stride,
+                                 const int16_t *hist_in, int16_t *hist_out)
+{
+	const unsigned n_out = (n_in + 1) / 2;
+	const u64 total = n_blocks * (u64)n_out;
+	if (!total)
+		return 0;
+	const unsigned grid = (unsigned)((total + 255) / 256);
+	hipStream_t s = (hipStream_t)stream;
+	if (!in_is_raw)
+		hipLaunchKernelGGL((k_fm_fifth_pass<false, true, false>), dim3(grid), dim3(256), 0, s, in, n_blocks, n_in, in_stride, out, out_stride, hist_in, hist_out);
+	else if (prescaled)
+		hipLaunchKernelGGL((k_fm_fifth_pass<true, true, false>), dim3(grid), dim3(256), 0, s, in, n_blocks, n_in, in_stride, out, out_stride, hist_in, hist_out);
+	else if (rotate)
+		hipLaunchKernelGGL((k_fm_fifth_pass<true, false, true>), dim3(grid), dim3(256), 0, s, in, n_blocks, n_in, in_stride, out, out_stride, hist_in, hist_out);
+	else
+		hipLaunchKernelGGL((k_fm_fifth_pass<true, false, false>), dim3(grid), dim3(256), 0, s, in, n_blocks, n_in, in_stride, out, out_stride, hist_in, hist_out);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_fm_droop(void *stream, const uint32_t *in, u64 M, const int *fir, const int16_t *hist_in,
+                            int16_t *hist_out, uint32_t *out)
+{
+	if (!M)
+		return 0;
+	hipLaunchKernelGGL(k_fm_droop, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, M, fir, hist_in, hist_out, out);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_fm_prestage(void *stream, const int16_t *in, unsigned n_complex, int rotate, int16_t *out)
+{
+	if (!n_complex)
+		return 0;
+	hipLaunchKernelGGL(k_fm_prestage, dim3((n_complex + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+	                   (const uint32_t *)in, n_complex, rotate, (uint32_t *)out);
+	LAUNCH_RET();
+}

@@ -1,0 +1,127 @@
+/* kernels.h -- internal C interface between the C host code (rxgpu_*.c) and the HIP
+ * kernels (fm_kernels.hip, power_kernels.hip).  Launchers only enqueue on the given
+ * stream and return the hipError_t of the launch as int (0 == hipSuccess).
+ * Not part of the public ABI (include/rxgpu.h is). */
+#ifndef RXGPU_KERNELS_H
+#define RXGPU_KERNELS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* complex samples one workgroup of the fast boxcar decimator covers (power of two) */
+#define RXK_DEC_SPAN 16384
+#define RXK_DEC_SPAN_LOG2 14
+/* largest boxcar the fast decimator takes: every workgroup but the last must hold an
+ * output boundary */
+#define RXK_DEC_MAX_DS (RXK_DEC_SPAN / 2)
+
+/* device-resident scalars of one rx_fm run: carries in, carries out, status */
+typedef struct rxk_fm_dev {
+	/* carry in (host fills before the run) */
+	int in_now_r, in_now_j, in_prev_index;
+	int in_pre_r, in_pre_j;
+	int in_deemph_avg;
+	int in_now_lpr, in_prev_lpr_index;
+	/* carry out (kernels fill) */
+	int out_now_r, out_now_j, out_prev_index;
+	int out_pre_r, out_pre_j;
+	int out_deemph_avg;
+	int out_now_lpr, out_prev_lpr_index;
+	/* status */
+	int flag_cnt;          /* libm-discriminator samples needing host re-evaluation */
+	int any_unmerged;      /* some de-emphasis chunk could not pin its start state alone */
+	int err;               /* != 0: device-side invariant violated */
+	int pad;
+} rxk_fm_dev;
+
+#define RXK_FLAG_CAP 4096
+
+enum { RXK_FIRST_LOWPASS = 0, RXK_FIRST_UNIFORM = 1 };
+
+/* F0+F1+F2 fused (rtl_fm.c:845-848, 309-327, 351-371): cs16 -> scaled -> rotated ->
+ * boxcar sums.  T complex samples (T % 4 == 0), 4 <= ds <= RXK_DEC_MAX_DS.
+ * lp_raw[m] valid for outputs completed strictly inside one workgroup span, head/tail
+ * hold the per-workgroup partial sums at the seams (packed int16 I | Q<<16, mod 2^16). */
+int rxk_fm_decimate(void *stream, const int16_t *iq, unsigned long long T, int ds, int p0,
+                    int prescaled, int rotate, uint32_t *lp_raw, uint32_t *head, uint32_t *tail);
+
+/* same maths, one thread per output, any ds >= 1 and any block length; writes final lp[] */
+int rxk_fm_decimate_generic(void *stream, const int16_t *iq, unsigned long long T, int ds, int p0,
+                            unsigned long long n_per_block, int prescaled, int rotate,
+                            const rxk_fm_dev *dev, uint32_t *lp, unsigned long long M);
+
+/* seam fix-up + F5/F6 discriminator (rtl_fm.c:584-615, 476-513) over M decimated samples,
+ * plus the exact int32 tail sums for the low_pass carry.  seams != 0: lp_raw/head/tail come
+ * from rxk_fm_decimate and lp[] is produced; seams == 0: lp[] is already final. */
+int rxk_fm_disc(void *stream, const int16_t *iq, unsigned long long T, int ds, int p0,
+                unsigned long long n_per_block, int prescaled, int rotate, int seams,
+                const uint32_t *lp_raw, const uint32_t *head, const uint32_t *tail,
+                uint32_t *lp, unsigned long long M, int first_mode, unsigned long long uniform_k,
+                int custom_atan, int do_tail, int16_t *pcm, rxk_fm_dev *dev, unsigned long long *flag_list);
+
+/* F8 de-emphasis (rtl_fm.c:667-682), chunk-parallel.  group = 16 or 64 candidate lanes */
+int rxk_fm_deemph_scan(void *stream, const int16_t *pcm, unsigned long long M, int a, int group,
+                       int chunk, int warm, int lo0, int hi0, int16_t *y, int *tab, int *lo_arr,
+                       int *gap_arr, rxk_fm_dev *dev);
+int rxk_fm_deemph_resolve(void *stream, unsigned long long n_chunks, int group, const int *tab,
+                          const int *lo_arr, const int *gap_arr, int *start_arr, rxk_fm_dev *dev);
+int rxk_fm_deemph_fix(void *stream, const int16_t *pcm, unsigned long long M, int a, int group, int chunk,
+                      const int *tab, const int *lo_arr, const int *gap_arr, const int *start_arr,
+                      int16_t *y, rxk_fm_dev *dev);
+/* any a, any state: one lane, serial (degenerate fallback, still on the device) */
+int rxk_fm_deemph_serial(void *stream, const int16_t *pcm, unsigned long long M, int a, int16_t *y, rxk_fm_dev *dev);
+
+/* F9 low_pass_real (rtl_fm.c:389-409): J outputs from n inputs, closed-form windows */
+int rxk_fm_resample(void *stream, const int16_t *y, unsigned long long n, int fast, int slow,
+                    unsigned long long J, int16_t *out, rxk_fm_dev *dev);
+/* carries when a stage is disabled */
+int rxk_fm_passthrough_carry(void *stream, rxk_fm_dev *dev, int deemph_off, int resample_off);
+
+/* F3 fifth_order cascade (rtl_fm.c:411-440, 764-769): one pass over every block.
+ * in/out are per-block contiguous arrays of packed IQ (uint32) except pass 0, which reads
+ * the raw cs16 stream and applies scale + rotate on the fly.
+ * n_in complex samples per block in, n_out = ceil(n_in/2) out; hist_i/hist_q: the carried
+ * lp_i_hist[pass]/lp_q_hist[pass] (6 int16 each) for block 0; hist_out receives the new ones. */
+int rxk_fm_fifth_pass(void *stream, const void *in, int in_is_raw, int prescaled, int rotate,
+                      unsigned long long n_blocks, unsigned n_in, unsigned in_stride, uint32_t *out,
+                      unsigned out_stride, const int16_t *hist_in, int16_t *hist_out);
+/* F12 generic_fir droop compensation (rtl_fm.c:442-465, 771-776) over the concatenated stream */
+int rxk_fm_droop(void *stream, const uint32_t *in, unsigned long long M, const int *fir,
+                 const int16_t *hist_in, int16_t *hist_out, uint32_t *out);
+
+/* rtlsdr_callback's scale + rotate alone (rtl_fm.c:845-857), n_complex samples */
+int rxk_fm_prestage(void *stream, const int16_t *in, unsigned n_complex, int rotate, int16_t *out);
+
+/* ------------------------------------------------------------- rx_power */
+
+/* P1,P4-P8 fused (rtl_power.c:715-720, 744-770) for ds == 1 or pre-downsampled input:
+ * one workgroup per (tune, pass-group): remove_dc over the tune buffer, then per FFT block
+ * window -> fix_fft in LDS -> |X|^2, accumulated into d_avg[tune][n] (atomic add / max).
+ * eff_len = int16 per tune actually transformed (buf_len / ds). */
+int rxk_pw_fft(void *stream, const int16_t *in, size_t tune_stride, size_t pass_stride, int passes,
+               int tunes, int bin_e, int eff_len, int dc_len, const int *window, const uint32_t *twiddle,
+               int peak_hold, int passes_per_group, long long *avg);
+/* samples[t] += blocks_per_tune * ds * passes (rtl_power.c:769) */
+int rxk_pw_samples(void *stream, int *samples, int tunes, int add);
+/* P2 boxcar (rtl_power.c:723-733): every buffer of buf_len int16 -> same-size buffer whose
+ * complex slot k holds the wrapped sum of samples [k*ds,(k+1)*ds), zero elsewhere */
+int rxk_pw_boxcar(void *stream, const int16_t *in, int16_t *out, size_t n_bufs, int buf_len, int ds);
+/* P3 one stateless fifth_order pass on I and Q (rtl_power.c:582-607, 656-662): n_in complex
+ * samples per buffer -> ceil(n_in/2); strides in complex samples */
+int rxk_pw_fifth(void *stream, const int16_t *in, int16_t *out, size_t n_bufs, int n_in, int in_stride, int out_stride);
+/* generic_fir (rtl_power.c:626-654) over n complex samples per buffer */
+int rxk_pw_droop(void *stream, const int16_t *in, int16_t *out, size_t n_bufs, int n, int stride, const int *fir);
+/* P9 rms_power sums: t[b] = sum s, p[b] = sum s^2 (int64, exact) per buffer, then the fp64
+ * dc correction + accumulate (rtl_power.c:418-428) */
+int rxk_pw_rms_sums(void *stream, const int16_t *in, size_t n_bufs, int buf_len, long long *t, long long *p);
+int rxk_pw_rms_apply(void *stream, const long long *t, const long long *p, int passes, int tunes, int buf_len,
+                     int peak_hold, long long *avg, int *samples);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

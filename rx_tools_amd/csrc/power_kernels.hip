@@ -1,0 +1,377 @@
+// power_kernels.hip -- gfx950 kernels for the rx_power scanner() per-tune chain.
+//
+// Reference behaviour (file:line under /root/reference/src/rtl_power.c):
+//   P1 copy 715-720      P2 boxcar 723-733     P3 fifth_order 582-607 / downsample_iq 656-662
+//   P4 remove_dc 609-624 P5 window 749-758     P6 FIX_MPY 256-262
+//   P7 fix_fft 264-320   P8 real_conj + accumulate 664-668, 760-768
+//   P9 rms_power sums 403-417                  generic_fir 626-654
+//
+// Everything is int16/int32/int64 and bit-exact with the C reference, including the int16
+// wrap of the window product, of every FIX_MPY result and of every butterfly store.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernels.h"
+
+typedef unsigned long long u64;
+typedef long long i64;
+
+__device__ __forceinline__ uint32_t pw_pack(int i, int q) { return ((uint32_t)i & 0xffffu) | ((uint32_t)q << 16); }
+__device__ __forceinline__ int pw_lo(uint32_t w) { return (int)(short)(w & 0xffffu); }
+__device__ __forceinline__ int pw_hi(uint32_t w) { return (int)w >> 16; }
+
+// FIX_MPY, rtl_power.c:256-262: c = (a*b)>>14; (c>>1) + (c&1)  ==  (a*b + 16384) >> 15,
+// then truncated to int16 by the return type.
+__device__ __forceinline__ int fix_mpy(int a, int b) { return (int)(short)((a * b + 16384) >> 15); }
+
+// one radix-2 DIT butterfly of fix_fft, rtl_power.c:302-314 (shift == 1 always)
+__device__ __forceinline__ void butterfly(uint32_t &lo, uint32_t &hi, uint32_t tw)
+{
+	const int wr = pw_lo(tw), wi = pw_hi(tw);
+	const int xr = pw_lo(hi), xi = pw_hi(hi);
+	const int tr = (int)(short)(fix_mpy(wr, xr) - fix_mpy(wi, xi));
+	const int ti = (int)(short)(fix_mpy(wr, xi) + fix_mpy(wi, xr));
+	const int qr = pw_lo(lo) >> 1, qi = pw_hi(lo) >> 1;
+	hi = pw_pack(qr - tr, qi - ti);
+	lo = pw_pack(qr + tr, qi + ti);
+}
+
+// ------------------------------------------------------------------ P4-P8, any N that fits LDS
+
+// One workgroup per (tune, pass group).  For each pass of the group: remove_dc sums over
+// the tune buffer, then per FFT block: window -> LDS (bit-reversed) -> m radix-2 stages in LDS
+// -> |X|^2 accumulated.  N <= 4096 keeps per-thread int64 accumulators across the group's
+// passes (bins k = tid + 256 r) and touches global memory once; larger N adds per block.
+template <int ACC>
+__global__ __launch_bounds__(256) void k_pw_fft(
+	const int16_t *__restrict__ in, size_t tune_stride, size_t pass_stride, int passes, int bin_e, int eff_len,
+	const int *__restrict__ window, const uint32_t *__restrict__ twiddle, int peak_hold, int ppg,
+	i64 *__restrict__ avg)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t x[];     // N packed IQ, then 16 reduction words
+	const int n = 1 << bin_e;
+	i64 *red = (i64 *)(x + n);
+	const int tune = blockIdx.x;
+	const int p_begin = blockIdx.y * ppg;
+	const int p_end = min(passes, p_begin + ppg);
+	const int tid = threadIdx.x;
+	const int n_blocks = (eff_len + 2 * n - 1) / (2 * n);
+	i64 acc[ACC > 0 ? ACC : 1];
+#pragma unroll
+	for (int r = 0; r < (ACC > 0 ? ACC : 1); r++)
+		acc[r] = 0;
+	i64 *avg_t = avg + (size_t)tune * n;
+
+	for (int pass = p_begin; pass < p_end; pass++) {
+		const uint32_t *buf = (const uint32_t *)(in + (size_t)pass * pass_stride + (size_t)tune * tune_stride);
+		// ---- remove_dc, rtl_power.c:609-624 via 744-745: I over int16 indices 0,2,.. < L,
+		// Q over 1,3,.. < L (i.e. data+1, length L-1); divide by the int16 COUNT
+		const int L = eff_len;
+		const int ci = (L + 1) / 2, cq = L / 2;            // complex samples taking part
+		i64 si = 0, sq = 0;
+		for (int c = tid; c < ci; c += 256) {
+			const uint32_t w = buf[c];
+			si += pw_lo(w);
+			if (c < cq) sq += pw_hi(w);
+		}
+		for (int off = 32; off; off >>= 1) { si += __shfl_down(si, off); sq += __shfl_down(sq, off); }
+		__syncthreads();
+		if ((tid & 63) == 0) { red[tid >> 6] = si; red[4 + (tid >> 6)] = sq; }
+		__syncthreads();
+		si = red[0] + red[1] + red[2] + red[3];
+		sq = red[4] + red[5] + red[6] + red[7];
+		const int ave_i = (int)(short)(si / (i64)L);
+		const int ave_q = (L > 1) ? (int)(short)(sq / (i64)(L - 1)) : 0;
+
+		for (int blk = 0; blk < n_blocks; blk++) {
+			const int c0 = blk * n;
+			// ---- window, rtl_power.c:749-758, into bit-reversed LDS slots (275-290)
+			for (int j = tid; j < n; j += 256) {
+				const int c = c0 + j;
+				const uint32_t w = buf[c];
+				int vi = pw_lo(w), vq = pw_hi(w);
+				if (c < ci) vi = (int)(short)(vi - ave_i);
+				if (c < cq) vq = (int)(short)(vq - ave_q);
+				const int coef = window[j];
+				vi = vi * coef;                                // int32, then (int16) truncation
+				vq = vq * coef;
+				x[__brev((unsigned)j) >> (32 - bin_e)] = pw_pack(vi, vq);
+			}
+			__syncthreads();
+			// ---- fix_fft stages, rtl_power.c:291-318
+			for (int s = 0; s < bin_e; s++) {
+				const int half = 1 << s;
+				for (int b = tid; b < n / 2; b += 256) {
+					const int t = b & (half - 1);
+					const int lo_i = ((b >> s) << (s + 1)) | t;
+					uint32_t lo = x[lo_i], hi = x[lo_i + half];
+					butterfly(lo, hi, twiddle[t << (bin_e - 1 - s)]);
+					x[lo_i] = lo;
+					x[lo_i + half] = hi;
+				}
+				__syncthreads();
+			}
+			// ---- real_conj + accumulate, rtl_power.c:664-668, 760-768
+			if (ACC > 0) {
+#pragma unroll
+				for (int r = 0; r < ACC; r++) {
+					const int k = tid + 256 * r;
+					if (k < n) {
+						const uint32_t w = x[k];
+						const i64 re = pw_lo(w), im = pw_hi(w);
+						const i64 pw = re * re + im * im;
+						acc[r] = peak_hold ? (pw > acc[r] ? pw : acc[r]) : acc[r] + pw;
+					}
+				}
+			} else {
+				for (int k = tid; k < n; k += 256) {
+					const uint32_t w = x[k];
+					const i64 re = pw_lo(w), im = pw_hi(w);
+					const i64 pw = re * re + im * im;
+					if (peak_hold) atomicMax((long long *)&avg_t[k], pw);
+					else atomicAdd((unsigned long long *)&avg_t[k], (unsigned long long)pw);
+				}
+			}
+			__syncthreads();
+		}
+	}
+	if (ACC > 0) {
+#pragma unroll
+		for (int r = 0; r < ACC; r++) {
+			const int k = tid + 256 * r;
+			if (k < n) {
+				if (peak_hold) atomicMax((long long *)&avg_t[k], acc[r]);
+				else atomicAdd((unsigned long long *)&avg_t[k], (unsigned long long)acc[r]);
+			}
+		}
+	}
+}
+
+__global__ void k_pw_samples(int *samples, int tunes, int add)
+{
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t < tunes)
+		samples[t] += add;
+}
+
+// ------------------------------------------------------------------ P2 boxcar
+
+// rtl_power.c:723-733.  In-place on the reference: slot k (int16 2k,2k+1) ends up holding the
+// int16-wrapped sum of complex samples [k*ds, (k+1)*ds) that exist, every other position of
+// the buffer is left zero.
+__global__ void k_pw_boxcar(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t n_bufs, int n_complex, int ds)
+{
+	const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (gid >= n_bufs * (u64)n_complex)
+		return;
+	const u64 b = gid / (unsigned)n_complex;
+	const int k = (int)(gid - b * (unsigned)n_complex);
+	const uint32_t *src = in + b * (u64)n_complex;
+	int si = 0, sq = 0;
+	const i64 first = (i64)k * ds;
+	if (first < n_complex) {
+		const int last = (int)min((i64)n_complex, first + ds);
+		for (int c = (int)first; c < last; c++) {
+			const uint32_t w = src[c];
+			si += pw_lo(w);
+			sq += pw_hi(w);
+		}
+	}
+	out[b * (u64)n_complex + k] = pw_pack(si, sq);
+}
+
+// ------------------------------------------------------------------ P3 fifth_order (stateless)
+
+// One pass of rtl_power.c:582-607 on both components (downsample_iq 656-662), out of place:
+// the in-place original never overwrites a sample it still has to read, so every output is a
+// function of the pass input.  n_in complex samples in (int16 length 2*n_in for I, 2*n_in-1 for
+// Q: both yield outputs k with 4k < length, i.e. k < ceil(n_in/2)).
+__global__ void k_pw_fifth(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t n_bufs,
+                           int n_in, int in_stride, int out_stride)
+{
+	const int n_out = (n_in + 1) / 2;
+	const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (gid >= n_bufs * (u64)n_out)
+		return;
+	const u64 b = gid / (unsigned)n_out;
+	const int k = (int)(gid - b * (unsigned)n_out);
+	const uint32_t *src = in + b * (u64)in_stride;
+	int oi, oq;
+	if (k >= 5) {
+		int ti[6], tq[6];
+#pragma unroll
+		for (int t = 0; t < 6; t++) {
+			const uint32_t w = src[2 * k - 5 + t];
+			ti[t] = pw_lo(w); tq[t] = pw_hi(w);
+		}
+		oi = (ti[0] + (ti[1] + ti[4]) * 5 + (ti[2] + ti[3]) * 10 + ti[5]) >> 4;
+		oq = (tq[0] + (tq[1] + tq[4]) * 5 + (tq[2] + tq[3]) * 10 + tq[5]) >> 4;
+	} else {
+		// ease-in, rtl_power.c:587-597 and the first two loop turns, which re-read sample 5
+		int si[9], sq[9];
+#pragma unroll
+		for (int t = 0; t < 9; t++) {
+			const uint32_t w = (t < n_in) ? src[t] : 0u;
+			si[t] = pw_lo(w); sq[t] = pw_hi(w);
+		}
+#define EASE(s, o) do { \
+		const int a = s[0], b_ = s[1], c = s[2], d = s[3], e = s[4], f = s[5]; \
+		switch (k) { \
+		case 0: o = ((a + b_) * 10 + (c + d) * 5 + d + f) >> 4; break; \
+		case 1: o = ((b_ + c) * 10 + (a + d) * 5 + e + f) >> 4; break; \
+		case 2: o = (a + (b_ + e) * 5 + (c + d) * 10 + f) >> 4; break; \
+		case 3: o = (c + (d + f) * 5 + (e + f) * 10 + s[6]) >> 4; break; \
+		default: o = (e + (f + s[7]) * 5 + (f + s[6]) * 10 + s[8]) >> 4; break; \
+		} } while (0)
+		EASE(si, oi);
+		EASE(sq, oq);
+#undef EASE
+	}
+	out[b * (u64)out_stride + k] = pw_pack(oi, oq);
+}
+
+// rtl_power.c:626-654: samples 0..8 pass through, sample t >= 9 becomes FIR(s[t-9..t-1]) >> 15
+__global__ void k_pw_droop(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t n_bufs, int n,
+                           int stride, const int *__restrict__ fir)
+{
+	const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (gid >= n_bufs * (u64)n)
+		return;
+	const u64 b = gid / (unsigned)n;
+	const int t = (int)(gid - b * (unsigned)n);
+	const uint32_t *src = in + b * (u64)stride;
+	if (t < 9) {
+		out[b * (u64)stride + t] = src[t];
+		return;
+	}
+	int hi[9], hq[9];
+#pragma unroll
+	for (int j = 0; j < 9; j++) {
+		const uint32_t w = src[t - 9 + j];
+		hi[j] = pw_lo(w); hq[j] = pw_hi(w);
+	}
+	const int f1 = fir[1], f2 = fir[2], f3 = fir[3], f4 = fir[4], f5 = fir[5];
+	const int si = (hi[0] + hi[8]) * f1 + (hi[1] + hi[7]) * f2 + (hi[2] + hi[6]) * f3 + (hi[3] + hi[5]) * f4 + hi[4] * f5;
+	const int sq = (hq[0] + hq[8]) * f1 + (hq[1] + hq[7]) * f2 + (hq[2] + hq[6]) * f3 + (hq[3] + hq[5]) * f4 + hq[4] * f5;
+	out[b * (u64)stride + t] = pw_pack(si >> 15, sq >> 15);
+}
+
+// ------------------------------------------------------------------ P9 rms_power sums
+
+__global__ __launch_bounds__(256) void k_pw_rms_sums(const int16_t *__restrict__ in, size_t n_bufs, int buf_len,
+                                                     i64 *__restrict__ t_out, i64 *__restrict__ p_out)
+{
+	__shared__ i64 red[8];
+	const size_t b = blockIdx.x;
+	if (b >= n_bufs)
+		return;
+	const int16_t *src = in + b * (size_t)buf_len;
+	i64 t = 0, p = 0;
+	for (int i = threadIdx.x; i < buf_len; i += 256) {
+		const i64 s = src[i];
+		t += s;
+		p += s * s;
+	}
+	for (int off = 32; off; off >>= 1) { t += __shfl_down(t, off); p += __shfl_down(p, off); }
+	if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = t; red[4 + (threadIdx.x >> 6)] = p; }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		t_out[b] = red[0] + red[1] + red[2] + red[3];
+		p_out[b] = red[4] + red[5] + red[6] + red[7];
+	}
+}
+
+// rtl_power.c:418-428: the fp64 dc correction and the accumulate, pass after pass per tune.
+// Plain IEEE fp64 ops in the reference's order (this file is built with -ffp-contract=off).
+__global__ void k_pw_rms_apply(const i64 *__restrict__ t_in, const i64 *__restrict__ p_in, int passes, int tunes,
+                               int buf_len, int peak_hold, i64 *__restrict__ avg, int *__restrict__ samples)
+{
+	const int tune = blockIdx.x * blockDim.x + threadIdx.x;
+	if (tune >= tunes)
+		return;
+	i64 a = avg[tune];
+	for (int pass = 0; pass < passes; pass++) {
+		const i64 t = t_in[(size_t)pass * tunes + tune];
+		i64 p = p_in[(size_t)pass * tunes + tune];
+		const double dc = (double)t / (double)buf_len;
+		const double lhs = (double)(t * 2) * dc;
+		const double rhs = dc * dc * (double)buf_len;
+		const double err = lhs - rhs;
+		p -= (i64)round(err);
+		a = peak_hold ? (p > a ? p : a) : a + p;
+	}
+	avg[tune] = a;
+	samples[tune] += passes;
+}
+
+// ------------------------------------------------------------------ launchers
+
+#define LAUNCH_RET() return (int)hipGetLastError()
+
+extern "C" int rxk_pw_fft(void *stream, const int16_t *in, size_t tune_stride, size_t pass_stride, int passes, int tunes,
+                          int bin_e, int eff_len, int dc_len, const int *window, const uint32_t *twiddle, int peak_hold,
+                          int passes_per_group, long long *avg)
+{
+	(void)dc_len;
+	const int n = 1 << bin_e;
+	const size_t shm = (size_t)n * 4 + 16 * 8;
+	const int groups = (passes + passes_per_group - 1) / passes_per_group;
+	dim3 grid((unsigned)tunes, (unsigned)groups);
+	hipStream_t s = (hipStream_t)stream;
+#define GO(A) do { \
+		if (shm > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_pw_fft<A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+		hipLaunchKernelGGL((k_pw_fft<A>), grid, dim3(256), shm, s, in, tune_stride, pass_stride, passes, bin_e, eff_len, \
+		                   window, twiddle, peak_hold, passes_per_group, (i64 *)avg); } while (0)
+	if (n <= 256) GO(1);
+	else if (n <= 512) GO(2);
+	else if (n <= 1024) GO(4);
+	else if (n <= 2048) GO(8);
+	else if (n <= 4096) GO(16);
+	else GO(0);
+#undef GO
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_pw_samples(void *stream, int *samples, int tunes, int add)
+{
+	hipLaunchKernelGGL(k_pw_samples, dim3((tunes + 255) / 256), dim3(256), 0, (hipStream_t)stream, samples, tunes, add);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_pw_boxcar(void *stream, const int16_t *in, int16_t *out, size_t n_bufs, int buf_len, int ds)
+{
+	const int nc = buf_len / 2;
+	const u64 total = (u64)n_bufs * nc;
+	hipLaunchKernelGGL(k_pw_boxcar, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+	                   (const uint32_t *)in, (uint32_t *)out, n_bufs, nc, ds);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_pw_fifth(void *stream, const int16_t *in, int16_t *out, size_t n_bufs, int n_in, int in_stride, int out_stride)
+{
+	const u64 total = (u64)n_bufs * ((n_in + 1) / 2);
+	hipLaunchKernelGGL(k_pw_fifth, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+	                   (const uint32_t *)in, (uint32_t *)out, n_bufs, n_in, in_stride, out_stride);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_pw_droop(void *stream, const int16_t *in, int16_t *out, size_t n_bufs, int n, int stride, const int *fir)
+{
+	const u64 total = (u64)n_bufs * n;
+	hipLaunchKernelGGL(k_pw_droop, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+	                   (const uint32_t *)in, (uint32_t *)out, n_bufs, n, stride, fir);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_pw_rms_sums(void *stream, const int16_t *in, size_t n_bufs, int buf_len, long long *t, long long *p)
+{
+	hipLaunchKernelGGL(k_pw_rms_sums, dim3((unsigned)n_bufs), dim3(256), 0, (hipStream_t)stream, in, n_bufs, buf_len, (i64 *)t, (i64 *)p);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_pw_rms_apply(void *stream, const long long *t, const long long *p, int passes, int tunes, int buf_len,
+                                int peak_hold, long long *avg, int *samples)
+{
+	hipLaunchKernelGGL(k_pw_rms_apply, dim3((tunes + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+	                   (const i64 *)t, (const i64 *)p, passes, tunes, buf_len, peak_hold, (i64 *)avg, samples);
+	LAUNCH_RET();
+}

@@ -1,0 +1,611 @@
+/* rxgpu_fm.c -- host side of the rx_fm path: the batched stream object and the two drop-in
+ * entry points.  C over the HIP C API; all arithmetic on samples happens in fm_kernels.hip.
+ *
+ * Reference call sites replaced (under /root/reference/src):
+ *   full_demod(d)                rtl_fm.c:923  (definition 759-824)
+ *   rtlsdr_callback(buf,len,ctx) rtl_fm.c:899  (definition 828-863)
+ */
+#include "rxgpu_internal.h"
+#include "rxgpu_ref_structs.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define DEEMPH_CHUNK 256
+
+struct rxgpu_fm_stream {
+	rxgpu_fm_params p;
+	rxgpu_fm_carry carry;
+	size_t max_blocks, block_len;        /* capacity */
+	size_t max_T, max_M;
+	/* device workspaces */
+	uint32_t *lp_raw, *lp, *head, *tail;
+	uint32_t *cas[2];                    /* fifth_order ping-pong */
+	int16_t *pcm, *y;
+	int *tab, *lo_arr, *gap_arr, *start_arr;
+	unsigned long long *flag_list;
+	rxk_fm_dev *dev;
+	int16_t *hist_dev;                   /* [10][12] cascade hist in, [10][12] out, [18] droop in, [18] out */
+	int *fir_dev;                        /* 10 ints */
+	/* pinned host mirrors */
+	rxk_fm_dev *dev_host;
+	int16_t *hist_host;
+	unsigned long long *flag_host;
+	/* host staging for run_host */
+	int16_t *stage_in, *stage_out;
+	size_t stage_in_cap, stage_out_cap;
+	/* de-emphasis geometry */
+	int group, warm, lo0, hi0;
+	long fixups;
+};
+
+/* rtl_fm.c:288-300 */
+static const int cic_9_tables[11][10] = {
+	{0},
+	{9, -156,  -97, 2798, -15489, 61019, -15489, 2798,  -97, -156},
+	{9, -128, -568, 5593, -24125, 74126, -24125, 5593, -568, -128},
+	{9, -129, -639, 6187, -26281, 77511, -26281, 6187, -639, -129},
+	{9, -122, -612, 6082, -26353, 77818, -26353, 6082, -612, -122},
+	{9, -120, -602, 6015, -26269, 77757, -26269, 6015, -602, -120},
+	{9, -120, -582, 5951, -26128, 77542, -26128, 5951, -582, -120},
+	{9, -119, -580, 5931, -26094, 77505, -26094, 5931, -580, -119},
+	{9, -119, -578, 5921, -26077, 77484, -26077, 5921, -578, -119},
+	{9, -119, -577, 5917, -26067, 77473, -26067, 5917, -577, -119},
+	{9, -199, -362, 5303, -25505, 77489, -25505, 5303, -362, -199},
+};
+
+#define HIST_CAS_IN   0
+#define HIST_CAS_OUT  (10 * 12)
+#define HIST_DROOP_IN (20 * 12)
+#define HIST_DROOP_OUT (20 * 12 + 18)
+#define HIST_TOTAL    (20 * 12 + 36)
+
+static int validate_params(const rxgpu_fm_params *p)
+{
+	if (p->downsample_passes < 0 || p->downsample_passes > 10)
+		return rxgpu_fail(RXGPU_EINVAL, "downsample_passes %d outside 0..10", p->downsample_passes);
+	if (!p->downsample_passes && p->downsample < 1)
+		return rxgpu_fail(RXGPU_EINVAL, "downsample %d < 1", p->downsample);
+	if (p->custom_atan != 0 && p->custom_atan != 1)
+		return rxgpu_fail(RXGPU_EUNSUPPORTED, "custom_atan %d: only std (0) and fast (1) run on the device", p->custom_atan);
+	if (p->deemph && p->deemph_a < 1)
+		return rxgpu_fail(RXGPU_EINVAL, "deemph_a %d < 1", p->deemph_a);
+	if (p->rate_out2 > 0 && (p->rate_out < p->rate_out2 || p->rate_out <= 0))
+		return rxgpu_fail(RXGPU_EUNSUPPORTED, "low_pass_real needs rate_out >= rate_out2 > 0 (got %d, %d)", p->rate_out, p->rate_out2);
+	return RXGPU_OK;
+}
+
+/* worst-case samples until trajectories from the two ends of [lo0,hi0] are < a apart:
+ * the gap g shrinks by at least floor(g/a) per sample (see k_fm_deemph_scan) */
+static int deemph_warm(int a, long long range)
+{
+	int n = 0;
+	long long g = range;
+	while (g >= a) {
+		g -= g / a;
+		n++;
+	}
+	return n + 1;
+}
+
+static void deemph_geometry(rxgpu_fm_stream *s)
+{
+	int a = s->p.deemph_a, avg = s->carry.deemph_avg;
+	s->lo0 = avg < -32768 ? avg : -32768;
+	s->hi0 = avg > 32767 ? avg : 32767;
+	s->group = a <= 16 ? 16 : (a <= 64 ? 64 : 0);
+	s->warm = s->group ? deemph_warm(a, (long long)s->hi0 - s->lo0) : 0;
+	if (s->warm > 8192)
+		s->group = 0;                 /* absurd carried state: take the serial kernel */
+}
+
+int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params, size_t max_blocks, size_t block_len)
+{
+	int rc;
+	rxgpu_fm_stream *s;
+	if (!out || !params || !max_blocks || block_len < 2 || (block_len & 1))
+		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_fm_stream_create: bad arguments");
+	if ((rc = validate_params(params)) != RXGPU_OK)
+		return rc;
+	if ((rc = rxgpu_ensure_init()) != RXGPU_OK)
+		return rc;
+	s = calloc(1, sizeof(*s));
+	if (!s)
+		return rxgpu_fail(RXGPU_ENOMEM, "out of host memory");
+	s->p = *params;
+	s->max_blocks = max_blocks;
+	s->block_len = block_len;
+	s->max_T = max_blocks * (block_len / 2);
+	if (params->downsample_passes)
+		s->max_M = max_blocks * (((block_len / 2) >> params->downsample_passes) + 1);
+	else
+		s->max_M = s->max_T / (size_t)params->downsample + 2;
+	size_t n_wg = (s->max_T + RXK_DEC_SPAN - 1) / RXK_DEC_SPAN + 1;
+	size_t n_chunks = (s->max_M + DEEMPH_CHUNK - 1) / DEEMPH_CHUNK + 1;
+#define DMALLOC(ptr, bytes) do { if (hipMalloc((void **)&(ptr), (bytes)) != hipSuccess) { \
+	rxgpu_fm_stream_destroy(s); return rxgpu_fail(RXGPU_ENOMEM, "hipMalloc(%zu) failed", (size_t)(bytes)); } } while (0)
+	DMALLOC(s->lp_raw, s->max_M * 4);
+	DMALLOC(s->lp, s->max_M * 4);
+	DMALLOC(s->head, n_wg * 4);
+	DMALLOC(s->tail, n_wg * 4);
+	DMALLOC(s->pcm, s->max_M * 2);
+	DMALLOC(s->y, s->max_M * 2);
+	DMALLOC(s->tab, n_chunks * 64 * 4);
+	DMALLOC(s->lo_arr, n_chunks * 4);
+	DMALLOC(s->gap_arr, n_chunks * 4);
+	DMALLOC(s->start_arr, n_chunks * 4);
+	DMALLOC(s->flag_list, RXK_FLAG_CAP * 8);
+	DMALLOC(s->dev, sizeof(rxk_fm_dev));
+	DMALLOC(s->hist_dev, HIST_TOTAL * 2);
+	DMALLOC(s->fir_dev, 10 * 4);
+	if (params->downsample_passes) {
+		/* pass 0 output is half the input, later passes shrink further: two buffers suffice */
+		DMALLOC(s->cas[0], (s->max_T / 2 + max_blocks) * 4);
+		DMALLOC(s->cas[1], (s->max_T / 4 + max_blocks) * 4);
+	}
+	if (hipHostMalloc((void **)&s->dev_host, sizeof(rxk_fm_dev), 0) != hipSuccess ||
+	    hipHostMalloc((void **)&s->hist_host, HIST_TOTAL * 2, 0) != hipSuccess ||
+	    hipHostMalloc((void **)&s->flag_host, RXK_FLAG_CAP * 8, 0) != hipSuccess) {
+		rxgpu_fm_stream_destroy(s);
+		return rxgpu_fail(RXGPU_ENOMEM, "hipHostMalloc failed");
+	}
+	*out = s;
+	return RXGPU_OK;
+}
+
+void rxgpu_fm_stream_destroy(rxgpu_fm_stream *s)
+{
+	if (!s)
+		return;
+	hipFree(s->lp_raw); hipFree(s->lp); hipFree(s->head); hipFree(s->tail);
+	hipFree(s->cas[0]); hipFree(s->cas[1]);
+	hipFree(s->pcm); hipFree(s->y);
+	hipFree(s->tab); hipFree(s->lo_arr); hipFree(s->gap_arr); hipFree(s->start_arr);
+	hipFree(s->flag_list); hipFree(s->dev); hipFree(s->hist_dev); hipFree(s->fir_dev);
+	if (s->dev_host) hipHostFree(s->dev_host);
+	if (s->hist_host) hipHostFree(s->hist_host);
+	if (s->flag_host) hipHostFree(s->flag_host);
+	if (s->stage_in) hipFree(s->stage_in);
+	if (s->stage_out) hipFree(s->stage_out);
+	free(s);
+}
+
+int rxgpu_fm_stream_set_carry(rxgpu_fm_stream *s, const rxgpu_fm_carry *c)
+{
+	if (!s || !c)
+		return rxgpu_fail(RXGPU_EINVAL, "null argument");
+	s->carry = *c;
+	return RXGPU_OK;
+}
+
+int rxgpu_fm_stream_get_carry(rxgpu_fm_stream *s, rxgpu_fm_carry *c)
+{
+	if (!s || !c)
+		return rxgpu_fail(RXGPU_EINVAL, "null argument");
+	*c = s->carry;
+	return RXGPU_OK;
+}
+
+long rxgpu_fm_stream_host_fixups(const rxgpu_fm_stream *s) { return s ? s->fixups : 0; }
+
+/* polar_discriminant with the host libm, exactly rtl_fm.c:470-483 */
+static int polar_discriminant_host(int ar, int aj, int br, int bj)
+{
+	int cr = (int)((unsigned)ar * (unsigned)br + (unsigned)aj * (unsigned)bj);
+	int cj = (int)((unsigned)aj * (unsigned)br - (unsigned)ar * (unsigned)bj);
+	double angle = atan2((double)cj, (double)cr);
+	return (int)(angle / 3.14159 * (1 << 14));
+}
+
+/* de-emphasis + resampler stages; pcm (M samples) -> d_out.  Re-runnable. */
+static int run_audio_stages(rxgpu_fm_stream *s, unsigned long long M, unsigned long long J, int16_t *d_out)
+{
+	hipStream_t st = rxgpu_hip_stream();
+	const rxgpu_fm_params *p = &s->p;
+	const int resample = p->rate_out2 > 0;
+	int16_t *deemph_dst = resample ? s->y : d_out;
+	const int16_t *audio = s->pcm;
+	if (p->deemph && M) {
+		rxgpu_prof_begin("fm_deemph");
+		if (s->group) {
+			unsigned long long n_chunks = (M + DEEMPH_CHUNK - 1) / DEEMPH_CHUNK;
+			RX_K(rxk_fm_deemph_scan(st, s->pcm, M, p->deemph_a, s->group, DEEMPH_CHUNK, s->warm, s->lo0, s->hi0,
+			                        deemph_dst, s->tab, s->lo_arr, s->gap_arr, s->dev));
+			RX_K(rxk_fm_deemph_resolve(st, n_chunks, s->group, s->tab, s->lo_arr, s->gap_arr, s->start_arr, s->dev));
+			RX_K(rxk_fm_deemph_fix(st, s->pcm, M, p->deemph_a, s->group, DEEMPH_CHUNK, s->tab, s->lo_arr, s->gap_arr,
+			                       s->start_arr, deemph_dst, s->dev));
+		} else {
+			RX_K(rxk_fm_deemph_serial(st, s->pcm, M, p->deemph_a, deemph_dst, s->dev));
+		}
+		rxgpu_prof_end("fm_deemph");
+		audio = deemph_dst;
+	}
+	if (resample) {
+		rxgpu_prof_begin("fm_resample");
+		RX_K(rxk_fm_resample(st, audio, M, p->rate_out, p->rate_out2, J, d_out, s->dev));
+		rxgpu_prof_end("fm_resample");
+	} else if (!(p->deemph && M) && M) {
+		/* neither stage: the discriminator output is the result */
+		RX_HIP(hipMemcpyAsync(d_out, s->pcm, M * 2, hipMemcpyDeviceToDevice, st));
+	}
+	if (!(p->deemph && M) || !resample)
+		RX_K(rxk_fm_passthrough_carry(st, s->dev, !(p->deemph && M), !resample));
+	return RXGPU_OK;
+}
+
+int rxgpu_fm_stream_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks, size_t block_len,
+                        int16_t *d_out, size_t out_cap, size_t *out_len, int *block_out_len)
+{
+	hipStream_t st;
+	int rc;
+	if (!s || !d_iq || !d_out || !n_blocks || block_len < 2 || (block_len & 1))
+		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_fm_stream_run: bad arguments");
+	if ((rc = rxgpu_ensure_init()) != RXGPU_OK)
+		return rc;
+	st = rxgpu_hip_stream();
+	const rxgpu_fm_params *p = &s->p;
+	const unsigned long long n = block_len / 2;              /* complex samples per block */
+	const unsigned long long T = n * n_blocks;
+	if (T > s->max_T)
+		return rxgpu_fail(RXGPU_ECAPACITY, "stream created for %zu samples, run asks %llu", s->max_T, T);
+	const int passes = p->downsample_passes;
+	const int ds = passes ? 1 : p->downsample;
+	const int p0 = passes ? 0 : s->carry.prev_index;
+	const int rotate = !p->prescaled && !p->offset_tuning;
+	unsigned long long M, K = 0;
+	if (passes) {
+		if (n % (1ull << passes))
+			return rxgpu_fail(RXGPU_EUNSUPPORTED, "fifth_order path needs block samples %% 2^passes == 0 (n=%llu, passes=%d)", n, passes);
+		K = n >> passes;
+		if ((n >> (passes - 1)) < 6)
+			return rxgpu_fail(RXGPU_EUNSUPPORTED, "block too short for %d fifth_order passes", passes);
+		M = K * n_blocks;
+	} else {
+		if (p0 < 0 || p0 >= ds)
+			return rxgpu_fail(RXGPU_EINVAL, "prev_index %d outside [0,%d)", p0, ds);
+		if (n < (unsigned long long)ds)
+			return rxgpu_fail(RXGPU_EUNSUPPORTED, "block of %llu samples shorter than downsample %d", n, ds);
+		M = ((unsigned long long)p0 + T) / (unsigned long long)ds;
+	}
+	if (M > s->max_M)
+		return rxgpu_fail(RXGPU_ECAPACITY, "workspace too small for %llu decimated samples", M);
+	if (!M)
+		return rxgpu_fail(RXGPU_EUNSUPPORTED, "run produces no decimated sample");
+	/* result sizes, closed form */
+	const int resample = p->rate_out2 > 0;
+	unsigned long long J = M;
+	if (resample) {
+		if (s->carry.prev_lpr_index < 0 || s->carry.prev_lpr_index >= p->rate_out)
+			return rxgpu_fail(RXGPU_EINVAL, "prev_lpr_index %d outside [0,rate_out)", s->carry.prev_lpr_index);
+		J = ((unsigned long long)s->carry.prev_lpr_index + M * (unsigned long long)p->rate_out2) / (unsigned long long)p->rate_out;
+	}
+	if (J > out_cap)
+		return rxgpu_fail(RXGPU_ECAPACITY, "output needs %llu int16, capacity %zu", J, out_cap);
+	if (p->deemph)
+		deemph_geometry(s);
+
+	/* carries in, status cleared */
+	rxk_fm_dev *h = s->dev_host;
+	memset(h, 0, sizeof(*h));
+	h->in_now_r = s->carry.now_r; h->in_now_j = s->carry.now_j; h->in_prev_index = s->carry.prev_index;
+	h->in_pre_r = s->carry.pre_r; h->in_pre_j = s->carry.pre_j;
+	h->in_deemph_avg = s->carry.deemph_avg;
+	h->in_now_lpr = s->carry.now_lpr; h->in_prev_lpr_index = s->carry.prev_lpr_index;
+	h->out_now_r = h->in_now_r; h->out_now_j = h->in_now_j; h->out_prev_index = h->in_prev_index;
+	RX_HIP(hipMemcpyAsync(s->dev, h, sizeof(*h), hipMemcpyHostToDevice, st));
+
+	const uint32_t *lp_final = s->lp;
+	if (!passes) {
+		const int fast = ds >= 4 && ds <= RXK_DEC_MAX_DS && (n % 4) == 0;
+		if (fast) {
+			rxgpu_prof_begin("fm_decimate");
+			RX_K(rxk_fm_decimate(st, d_iq, T, ds, p0, p->prescaled, rotate, s->lp_raw, s->head, s->tail));
+			rxgpu_prof_end("fm_decimate");
+		} else {
+			rxgpu_prof_begin("fm_decimate_generic");
+			RX_K(rxk_fm_decimate_generic(st, d_iq, T, ds, p0, n, p->prescaled, rotate, s->dev, s->lp, M));
+			rxgpu_prof_end("fm_decimate_generic");
+		}
+		rxgpu_prof_begin("fm_disc");
+		RX_K(rxk_fm_disc(st, d_iq, T, ds, p0, n, p->prescaled, rotate, fast, fast ? s->lp_raw : s->lp, s->head, s->tail, s->lp, M,
+		                 RXK_FIRST_LOWPASS, 0, p->custom_atan, 1, s->pcm, s->dev, s->flag_list));
+		rxgpu_prof_end("fm_disc");
+	} else {
+		/* F3: cascade, one launch per pass; F12 optional */
+		int16_t *hh = s->hist_host;
+		for (int i = 0; i < 10; i++) {
+			memcpy(hh + HIST_CAS_IN + i * 12, s->carry.lp_i_hist[i], 12);
+			memcpy(hh + HIST_CAS_IN + i * 12 + 6, s->carry.lp_q_hist[i], 12);
+		}
+		memcpy(hh + HIST_DROOP_IN, s->carry.droop_i_hist, 18);
+		memcpy(hh + HIST_DROOP_IN + 9, s->carry.droop_q_hist, 18);
+		RX_HIP(hipMemcpyAsync(s->hist_dev, hh, HIST_TOTAL * 2, hipMemcpyHostToDevice, st));
+		rxgpu_prof_begin("fm_fifth");
+		const void *src = d_iq;
+		unsigned n_in = (unsigned)n, in_stride = (unsigned)n;
+		for (int i = 0; i < passes; i++) {
+			uint32_t *dst = s->cas[i & 1];
+			unsigned n_out = n_in / 2;
+			RX_K(rxk_fm_fifth_pass(st, src, i == 0, p->prescaled, rotate, n_blocks, n_in, in_stride, dst, n_out,
+			                       s->hist_dev + HIST_CAS_IN + i * 12, s->hist_dev + HIST_CAS_OUT + i * 12));
+			src = dst;
+			n_in = n_out;
+			in_stride = n_out;
+		}
+		rxgpu_prof_end("fm_fifth");
+		lp_final = (const uint32_t *)src;            /* [n_blocks][K] contiguous == M samples */
+		if (p->comp_fir_size == 9) {
+			RX_HIP(hipMemcpyAsync(s->fir_dev, cic_9_tables[passes], 10 * sizeof(int), hipMemcpyHostToDevice, st));
+			rxgpu_prof_begin("fm_droop");
+			RX_K(rxk_fm_droop(st, lp_final, M, s->fir_dev, s->hist_dev + HIST_DROOP_IN, s->hist_dev + HIST_DROOP_OUT, s->lp));
+			rxgpu_prof_end("fm_droop");
+			lp_final = s->lp;
+		}
+		rxgpu_prof_begin("fm_disc");
+		RX_K(rxk_fm_disc(st, d_iq, T, 1, 0, n, p->prescaled, rotate, 0, lp_final, NULL, NULL, NULL, M,
+		                 RXK_FIRST_UNIFORM, K, p->custom_atan, 0, s->pcm, s->dev, s->flag_list));
+		rxgpu_prof_end("fm_disc");
+		RX_HIP(hipMemcpyAsync(hh, s->hist_dev, HIST_TOTAL * 2, hipMemcpyDeviceToHost, st));
+	}
+
+	if ((rc = run_audio_stages(s, M, J, d_out)) != RXGPU_OK)
+		return rc;
+	RX_HIP(hipMemcpyAsync(h, s->dev, sizeof(*h), hipMemcpyDeviceToHost, st));
+	RX_HIP(hipStreamSynchronize(st));
+
+	s->fixups = 0;
+	if (h->flag_cnt) {
+		/* libm-discriminator samples the device could not decide: re-evaluate with the host libm
+		 * (the one the reference uses), patch pcm[], redo the audio stages */
+		int cnt = h->flag_cnt;
+		if (cnt > RXK_FLAG_CAP)
+			return rxgpu_fail(RXGPU_EUNSUPPORTED, "%d undecided libm discriminator samples (cap %d)", cnt, RXK_FLAG_CAP);
+		RX_HIP(hipMemcpy(s->flag_host, s->flag_list, (size_t)cnt * 8, hipMemcpyDeviceToHost));
+		for (int i = 0; i < cnt; i++) {
+			unsigned long long m = s->flag_host[i];
+			uint32_t a, b;
+			int br, bj;
+			RX_HIP(hipMemcpy(&a, lp_final + m, 4, hipMemcpyDeviceToHost));
+			if (m) {
+				RX_HIP(hipMemcpy(&b, lp_final + m - 1, 4, hipMemcpyDeviceToHost));
+				br = (int16_t)(b & 0xffff); bj = (int16_t)(b >> 16);
+			} else {
+				br = s->carry.pre_r; bj = s->carry.pre_j;
+			}
+			int16_t v = (int16_t)polar_discriminant_host((int16_t)(a & 0xffff), (int16_t)(a >> 16), br, bj);
+			RX_HIP(hipMemcpy(s->pcm + m, &v, 2, hipMemcpyHostToDevice));
+		}
+		s->fixups = cnt;
+		h->flag_cnt = 0; h->any_unmerged = 0;
+		/* status words only; carries in/out already on the device */
+		RX_HIP(hipMemcpyAsync(&s->dev->flag_cnt, &h->flag_cnt, 2 * sizeof(int), hipMemcpyHostToDevice, st));
+		if ((rc = run_audio_stages(s, M, J, d_out)) != RXGPU_OK)
+			return rc;
+		RX_HIP(hipMemcpyAsync(h, s->dev, sizeof(*h), hipMemcpyDeviceToHost, st));
+		RX_HIP(hipStreamSynchronize(st));
+	}
+	rxgpu_prof_collect();
+	if (h->err)
+		return rxgpu_fail(RXGPU_ENODEV, "device-side invariant violated in the de-emphasis scan (err=%d)", h->err);
+
+	/* carries out */
+	if (!passes) {
+		s->carry.now_r = h->out_now_r; s->carry.now_j = h->out_now_j; s->carry.prev_index = h->out_prev_index;
+	} else {
+		const int16_t *hh = s->hist_host;
+		for (int i = 0; i < passes; i++) {
+			memcpy(s->carry.lp_i_hist[i], hh + HIST_CAS_OUT + i * 12, 12);
+			memcpy(s->carry.lp_q_hist[i], hh + HIST_CAS_OUT + i * 12 + 6, 12);
+		}
+		if (p->comp_fir_size == 9) {
+			memcpy(s->carry.droop_i_hist, hh + HIST_DROOP_OUT, 18);
+			memcpy(s->carry.droop_q_hist, hh + HIST_DROOP_OUT + 9, 18);
+		}
+	}
+	s->carry.pre_r = h->out_pre_r; s->carry.pre_j = h->out_pre_j;
+	const int pr0 = s->carry.prev_lpr_index;
+	s->carry.deemph_avg = h->out_deemph_avg;
+	s->carry.now_lpr = h->out_now_lpr; s->carry.prev_lpr_index = h->out_prev_lpr_index;
+
+	if (out_len)
+		*out_len = (size_t)J;
+	if (block_out_len) {
+		unsigned long long cum_prev = 0, j_prev = 0;
+		for (size_t b = 0; b < n_blocks; b++) {
+			unsigned long long cum = passes ? K * (b + 1) : ((unsigned long long)p0 + n * (b + 1)) / (unsigned long long)ds;
+			unsigned long long jj = resample ? ((unsigned long long)pr0 + cum * (unsigned long long)p->rate_out2) / (unsigned long long)p->rate_out : cum;
+			block_out_len[b] = (int)(jj - j_prev);
+			(void)cum_prev;
+			cum_prev = cum;
+			j_prev = jj;
+		}
+	}
+	return RXGPU_OK;
+}
+
+int rxgpu_fm_stream_run_host(rxgpu_fm_stream *s, const int16_t *h_iq, size_t n_blocks, size_t block_len,
+                             int16_t *h_out, size_t out_cap, size_t *out_len, int *block_out_len)
+{
+	int rc;
+	size_t got = 0;
+	if (!s || !h_iq || !h_out)
+		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_fm_stream_run_host: bad arguments");
+	if ((rc = rxgpu_ensure_init()) != RXGPU_OK)
+		return rc;
+	hipStream_t st = rxgpu_hip_stream();
+	size_t in_bytes = n_blocks * block_len * 2;
+	if (s->stage_in_cap < in_bytes) {
+		if (s->stage_in) hipFree(s->stage_in);
+		s->stage_in = NULL; s->stage_in_cap = 0;
+		RX_HIP(hipMalloc((void **)&s->stage_in, in_bytes));
+		s->stage_in_cap = in_bytes;
+	}
+	size_t out_bytes = (s->max_M + 16) * 2;
+	if (s->stage_out_cap < out_bytes) {
+		if (s->stage_out) hipFree(s->stage_out);
+		s->stage_out = NULL; s->stage_out_cap = 0;
+		RX_HIP(hipMalloc((void **)&s->stage_out, out_bytes));
+		s->stage_out_cap = out_bytes;
+	}
+	RX_HIP(hipMemcpyAsync(s->stage_in, h_iq, in_bytes, hipMemcpyHostToDevice, st));
+	rc = rxgpu_fm_stream_run(s, s->stage_in, n_blocks, block_len, s->stage_out, s->max_M + 16, &got, block_out_len);
+	if (rc != RXGPU_OK)
+		return rc;
+	if (got > out_cap)
+		return rxgpu_fail(RXGPU_ECAPACITY, "output needs %zu int16, capacity %zu", got, out_cap);
+	RX_HIP(hipMemcpy(h_out, s->stage_out, got * 2, hipMemcpyDeviceToHost));
+	if (out_len)
+		*out_len = got;
+	return RXGPU_OK;
+}
+
+/* ------------------------------------------------------------------ drop-in entry points */
+
+#define SIDECARS 16
+static struct { const struct demod_state *d; int avg; rxgpu_fm_stream *s; rxgpu_fm_params p; } g_side[SIDECARS];
+static int16_t *g_cb_in, *g_cb_out;          /* device staging for the callback */
+
+static int side_slot(const struct demod_state *d)
+{
+	int free_slot = -1;
+	for (int i = 0; i < SIDECARS; i++) {
+		if (g_side[i].d == d)
+			return i;
+		if (!g_side[i].d && free_slot < 0)
+			free_slot = i;
+	}
+	if (free_slot >= 0)
+		g_side[free_slot].d = d;
+	return free_slot;
+}
+
+int *rxgpu_deemph_state(const struct demod_state *d)
+{
+	int i = side_slot(d);
+	return i < 0 ? NULL : &g_side[i].avg;
+}
+
+static void die(const char *what)
+{
+	fprintf(stderr, "rxgpu: %s: %s\n", what, rxgpu_last_error());
+	exit(1);
+}
+
+void rxgpu_full_demod(struct demod_state *d)
+{
+	int slot = side_slot(d);
+	if (slot < 0) {
+		rxgpu_fail(RXGPU_ECAPACITY, "more than %d demod_state objects", SIDECARS);
+		die("rxgpu_full_demod");
+	}
+	if (d->squelch_level || d->post_downsample > 1 || d->dc_block_audio) {
+		rxgpu_fail(RXGPU_EUNSUPPORTED, "squelch / -o / adc are not on the device path (squelch_level=%d post_downsample=%d dc_block_audio=%d)",
+		           d->squelch_level, d->post_downsample, d->dc_block_audio);
+		die("rxgpu_full_demod");
+	}
+	rxgpu_fm_params p;
+	memset(&p, 0, sizeof(p));
+	p.downsample = d->downsample;
+	p.downsample_passes = d->downsample_passes;
+	p.comp_fir_size = d->comp_fir_size;
+	p.custom_atan = d->custom_atan;
+	p.deemph = d->deemph;
+	p.deemph_a = d->deemph_a;
+	p.rate_out = d->rate_out;
+	p.rate_out2 = d->rate_out2;
+	p.prescaled = 1;                       /* lowpassed[] is already scaled + rotated by the callback */
+	if (!g_side[slot].s || memcmp(&p, &g_side[slot].p, sizeof(p))) {
+		if (g_side[slot].s)
+			rxgpu_fm_stream_destroy(g_side[slot].s);
+		g_side[slot].s = NULL;
+		if (rxgpu_fm_stream_create(&g_side[slot].s, &p, 1, RXGPU_MAXIMUM_BUF_LENGTH) != RXGPU_OK)
+			die("rxgpu_full_demod");
+		g_side[slot].p = p;
+	}
+	rxgpu_fm_stream *s = g_side[slot].s;
+	rxgpu_fm_carry c;
+	memset(&c, 0, sizeof(c));
+	c.now_r = d->now_r; c.now_j = d->now_j; c.prev_index = d->prev_index;
+	c.pre_r = d->pre_r; c.pre_j = d->pre_j;
+	memcpy(c.lp_i_hist, d->lp_i_hist, sizeof(c.lp_i_hist));
+	memcpy(c.lp_q_hist, d->lp_q_hist, sizeof(c.lp_q_hist));
+	memcpy(c.droop_i_hist, d->droop_i_hist, sizeof(c.droop_i_hist));
+	memcpy(c.droop_q_hist, d->droop_q_hist, sizeof(c.droop_q_hist));
+	c.deemph_avg = g_side[slot].avg;
+	c.now_lpr = d->now_lpr; c.prev_lpr_index = d->prev_lpr_index;
+	rxgpu_fm_stream_set_carry(s, &c);
+	size_t got = 0;
+	if (rxgpu_fm_stream_run_host(s, d->lowpassed, 1, (size_t)d->lp_len, d->result, RXGPU_MAXIMUM_BUF_LENGTH, &got, NULL) != RXGPU_OK)
+		die("rxgpu_full_demod");
+	rxgpu_fm_stream_get_carry(s, &c);
+	/* decimated IQ back into lowpassed[], like the CPU's in-place stages leave it */
+	{
+		int passes = d->downsample_passes;
+		unsigned long long n = (unsigned long long)d->lp_len / 2;
+		unsigned long long M = passes ? (n >> passes) : ((unsigned long long)d->prev_index + n) / (unsigned long long)d->downsample;
+		const uint32_t *src = s->lp;
+		if (passes && d->comp_fir_size != 9)
+			src = s->cas[(passes - 1) & 1];
+		if (hipMemcpy(d->lowpassed, src, M * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+			rxgpu_fail(RXGPU_ENODEV, "copy of decimated IQ failed");
+			die("rxgpu_full_demod");
+		}
+		d->lp_len = (int)(2 * M);
+	}
+	d->result_len = (int)got;
+	d->now_r = c.now_r; d->now_j = c.now_j; d->prev_index = c.prev_index;
+	d->pre_r = c.pre_r; d->pre_j = c.pre_j;
+	memcpy(d->lp_i_hist, c.lp_i_hist, sizeof(c.lp_i_hist));
+	memcpy(d->lp_q_hist, c.lp_q_hist, sizeof(c.lp_q_hist));
+	memcpy(d->droop_i_hist, c.droop_i_hist, sizeof(c.droop_i_hist));
+	memcpy(d->droop_q_hist, c.droop_q_hist, sizeof(c.droop_q_hist));
+	g_side[slot].avg = c.deemph_avg;
+	d->now_lpr = c.now_lpr; d->prev_lpr_index = c.prev_lpr_index;
+}
+
+void rxgpu_callback(int16_t *buf, uint32_t len, void *ctx)
+{
+	struct dongle_state *s = ctx;
+	struct demod_state *d;
+	if (!s)
+		return;
+	d = s->demod_target;
+	if (rxgpu_ensure_init() != RXGPU_OK)
+		die("rxgpu_callback");
+	if (d->dc_block_raw) {
+		rxgpu_fail(RXGPU_EUNSUPPORTED, "-E rdc is not on the device path");
+		die("rxgpu_callback");
+	}
+	if (len > RXGPU_MAXIMUM_BUF_LENGTH || (len & 1)) {
+		rxgpu_fail(RXGPU_EINVAL, "callback length %u", len);
+		die("rxgpu_callback");
+	}
+	if (s->mute) {                                   /* rtl_fm.c:839-843 */
+		for (int i = 0; i < s->mute && i < (int)len; i++)
+			buf[i] = 0;
+		s->mute = 0;
+	}
+	if (!g_cb_in) {
+		if (hipMalloc((void **)&g_cb_in, RXGPU_MAXIMUM_BUF_LENGTH * 2) != hipSuccess ||
+		    hipMalloc((void **)&g_cb_out, RXGPU_MAXIMUM_BUF_LENGTH * 2) != hipSuccess) {
+			rxgpu_fail(RXGPU_ENOMEM, "hipMalloc failed");
+			die("rxgpu_callback");
+		}
+	}
+	hipStream_t st = rxgpu_hip_stream();
+	if (hipMemcpyAsync(g_cb_in, buf, (size_t)len * 2, hipMemcpyHostToDevice, st) != hipSuccess ||
+	    rxk_fm_prestage(st, g_cb_in, len / 2, !s->offset_tuning, g_cb_out) != 0 ||
+	    hipMemcpyAsync(s->buf16, g_cb_out, (size_t)len * 2, hipMemcpyDeviceToHost, st) != hipSuccess ||
+	    hipStreamSynchronize(st) != hipSuccess) {
+		rxgpu_fail(RXGPU_ENODEV, "device pre-stage failed: %s", hipGetErrorString(hipGetLastError()));
+		die("rxgpu_callback");
+	}
+	pthread_rwlock_wrlock(&d->rw);                   /* rtl_fm.c:858-862 */
+	memcpy(d->lowpassed, s->buf16, 2 * (size_t)len);
+	d->lp_len = (int)len;
+	pthread_rwlock_unlock(&d->rw);
+	pthread_mutex_lock(&d->ready_m);
+	pthread_cond_signal(&d->ready);
+	pthread_mutex_unlock(&d->ready_m);
+}

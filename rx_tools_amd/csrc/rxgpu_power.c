@@ -1,0 +1,430 @@
+/* rxgpu_power.c -- host side of the rx_power path: range planner, tables, batched scan
+ * object, the scanner()/csv_dbm() drop-ins.  C over the HIP C API; sample arithmetic is in
+ * power_kernels.hip.
+ *
+ * Reference call sites replaced (under /root/reference/src/rtl_power.c):
+ *   scanner(channel)   1040 (definition 670-772; the compute part 709-770)
+ *   csv_dbm(&tunes[i]) 1049 (definition 774-817)
+ * and the host-side set-up they depend on: frequency_range 431-543, sine_table 240-254,
+ * window functions 322-401 with the quantisation at 1034-1037.
+ */
+#include "rxgpu_internal.h"
+#include "rxgpu_ref_structs.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MAXIMUM_RATE 2800000     /* rtl_power.c:74 */
+#define MINIMUM_RATE 1000000     /* rtl_power.c:75 */
+#define DEFAULT_BUF_LENGTH 16384 /* rtl_power.c:71 */
+#define MAX_TUNES 10000          /* rtl_power.c:111 */
+
+/* ------------------------------------------------------------------ host tables */
+
+/* atofs, convenience.c:65-88: a float with an optional k/K, M, G suffix */
+static double parse_suffixed(const char *s)
+{
+	size_t len = strlen(s);
+	double mult = 1.0;
+	char tmp[64];
+	if (!len)
+		return 0.0;
+	switch (s[len - 1]) {
+	case 'g': case 'G': mult = 1e9; break;
+	case 'm': case 'M': mult = 1e6; break;
+	case 'k': case 'K': mult = 1e3; break;
+	default: return atof(s);
+	}
+	if (len > sizeof(tmp))
+		len = sizeof(tmp);
+	memcpy(tmp, s, len - 1);
+	tmp[len - 1] = 0;
+	return atof(tmp) * mult;
+}
+
+/* frequency_range, rtl_power.c:431-543, without the allocation and the stderr report */
+int rxgpu_power_plan_range(const char *range, double crop, int boxcar, rxgpu_power_plan *plan)
+{
+	char buf[192];
+	char *stop, *step;
+	int i, bin_e = 0, buf_len, tune_count = 0;
+	int64_t upper, lower, max_size, bw_seen = 0, bw_used = 0, downsample = 1, downsample_passes = 0;
+	double bin_size;
+	if (!range || !plan || strlen(range) >= sizeof(buf))
+		return rxgpu_fail(RXGPU_EINVAL, "bad range string");
+	strcpy(buf, range);
+	stop = strchr(buf, ':');
+	if (!stop)
+		return rxgpu_fail(RXGPU_EINVAL, "range must be lower:upper:bin_size");
+	*stop++ = 0;
+	step = strchr(stop, ':');
+	if (!step)
+		return rxgpu_fail(RXGPU_EINVAL, "range must be lower:upper:bin_size");
+	*step++ = 0;
+	lower = (int64_t)parse_suffixed(buf);
+	upper = (int64_t)parse_suffixed(stop);
+	max_size = (int64_t)parse_suffixed(step);
+	/* evenly sized ranges, as close to MAXIMUM_RATE as possible (456-463) */
+	for (i = 1; i < 1500; i++) {
+		bw_seen = (upper - lower) / i;
+		bw_used = (int64_t)((double)bw_seen / (1.0 - crop));
+		if (bw_used > MAXIMUM_RATE)
+			continue;
+		tune_count = i;
+		break;
+	}
+	/* unless small bandwidth (465-473) */
+	if (bw_used < MINIMUM_RATE) {
+		tune_count = 1;
+		if (bw_used <= 0)
+			return rxgpu_fail(RXGPU_EINVAL, "unsupported bandwidth");
+		downsample = MAXIMUM_RATE / bw_used;
+		if (downsample <= 0)
+			return rxgpu_fail(RXGPU_EINVAL, "unsupported bandwidth");
+		bw_used = bw_used * downsample;
+	}
+	if (!boxcar && downsample > 1) {                       /* 474-482 */
+		downsample_passes = (int)log2((double)downsample);
+		downsample = 1 << downsample_passes;
+		bw_used = (int)((double)(bw_seen * downsample) / (1.0 - crop));
+	}
+	/* number of bins is power-of-two, bin size is under limit (485-491) */
+	for (i = 1; i <= 21; i++) {
+		bin_e = i;
+		bin_size = (double)bw_used / (double)((1 << i) * downsample);
+		if (bin_size <= (double)max_size)
+			break;
+	}
+	/* unless giant bins (493-499) */
+	if (max_size >= MINIMUM_RATE) {
+		bw_seen = max_size;
+		bw_used = max_size;
+		tune_count = (int)((upper - lower) / bw_seen);
+		bin_e = 0;
+		crop = 0;
+	}
+	if (tune_count > MAX_TUNES)
+		return rxgpu_fail(RXGPU_EINVAL, "bandwidth too wide");
+	buf_len = 2 * (1 << bin_e) * (int)downsample;          /* 504-507 */
+	if (buf_len < DEFAULT_BUF_LENGTH)
+		buf_len = DEFAULT_BUF_LENGTH;
+	plan->tune_count = tune_count;
+	plan->bin_e = bin_e;
+	plan->buf_len = buf_len;
+	plan->downsample = (int)downsample;
+	plan->downsample_passes = (int)downsample_passes;
+	plan->rate = (int)bw_used;
+	plan->first_freq = lower + bw_seen / 2;                /* tune i: lower + i*bw_seen + bw_seen/2 (511) */
+	plan->bw_seen = bw_seen;
+	plan->crop = crop;
+	return RXGPU_OK;
+}
+
+/* sine_table, rtl_power.c:240-254 */
+int rxgpu_sine_table(int log2n, int16_t *sinewave)
+{
+	int n, i;
+	if (log2n < 0 || log2n > 21 || !sinewave)
+		return rxgpu_fail(RXGPU_EINVAL, "bad sine table size");
+	n = 1 << log2n;
+	for (i = 0; i < n * 3 / 4; i++) {
+		double d = (double)i * 2.0 * M_PI / n;
+		sinewave[i] = (int16_t)(int)round(32767 * sin(d));
+	}
+	return RXGPU_OK;
+}
+
+/* the window shapes of rtl_power.c:322-401 by their -w names (881-897) */
+static double window_value(const char *name, int i, int length)
+{
+	const double N1 = (double)(length - 1);
+	if (!strcmp(name, "hamming"))
+		return 25.0 / 46.0 - (21.0 / 46.0) * cos(2 * i * M_PI / N1);
+	if (!strcmp(name, "blackman"))
+		return 7938.0 / 18608.0 - (9240.0 / 18608.0) * cos(2 * i * M_PI / N1) + (1430.0 / 18608.0) * cos(4 * i * M_PI / N1);
+	if (!strcmp(name, "blackman-harris"))
+		return 0.35875 - 0.48829 * cos(2 * i * M_PI / N1) + 0.14128 * cos(4 * i * M_PI / N1) - 0.01168 * cos(6 * i * M_PI / N1);
+	if (!strcmp(name, "hann-poisson"))
+		return 0.5 * (1 - cos(2 * M_PI * i / N1)) * pow(M_E, (-2.0 * (double)abs((int)(N1 - 1 - 2 * i))) / N1);
+	if (!strcmp(name, "youssef")) {
+		double w = 0.35875 - 0.48829 * cos(2 * i * M_PI / N1) + 0.14128 * cos(4 * i * M_PI / N1) - 0.01168 * cos(6 * i * M_PI / N1);
+		return w * pow(M_E, (-0.0025 * (double)abs((int)(N1 - 1 - 2 * i))) / N1);
+	}
+	if (!strcmp(name, "bartlett")) {
+		double L = (double)length, w = (i - N1 / 2) / (L / 2);
+		if (w < 0)
+			w = -w;
+		return 1 - w;
+	}
+	return 1.0;   /* rectangle, kaiser (385-389) and, like the reference, anything unknown */
+}
+
+int rxgpu_window_coefs(const char *name, int length, int *coefs)
+{
+	if (!name || !coefs || length < 1)
+		return rxgpu_fail(RXGPU_EINVAL, "bad window request");
+	for (int i = 0; i < length; i++)
+		coefs[i] = (int)(256 * window_value(name, i, length));     /* rtl_power.c:1036 */
+	return RXGPU_OK;
+}
+
+/* ------------------------------------------------------------------ batched scan */
+
+struct rxgpu_power_scan {
+	rxgpu_power_params p;
+	int max_tunes;
+	int *window_dev;
+	uint32_t *twiddle_dev;
+	int *fir_dev;
+	int16_t *work[2];
+	size_t work_cap;
+	long long *rms_t, *rms_p;
+	size_t rms_cap;
+};
+
+/* rtl_fm.c:288-300 == rtl_power.c:213-225 */
+static const int cic_9_tables[11][10] = {
+	{0},
+	{9, -156,  -97, 2798, -15489, 61019, -15489, 2798,  -97, -156},
+	{9, -128, -568, 5593, -24125, 74126, -24125, 5593, -568, -128},
+	{9, -129, -639, 6187, -26281, 77511, -26281, 6187, -639, -129},
+	{9, -122, -612, 6082, -26353, 77818, -26353, 6082, -612, -122},
+	{9, -120, -602, 6015, -26269, 77757, -26269, 6015, -602, -120},
+	{9, -120, -582, 5951, -26128, 77542, -26128, 5951, -582, -120},
+	{9, -119, -580, 5931, -26094, 77505, -26094, 5931, -580, -119},
+	{9, -119, -578, 5921, -26077, 77484, -26077, 5921, -578, -119},
+	{9, -119, -577, 5917, -26067, 77473, -26067, 5917, -577, -119},
+	{9, -199, -362, 5303, -25505, 77489, -25505, 5303, -362, -199},
+};
+
+#define PW_MAX_BIN_E 15       /* 2^15 complex samples = 128 KiB of the 160 KiB LDS */
+
+int rxgpu_power_scan_create(rxgpu_power_scan **out, const rxgpu_power_params *p, int max_tunes,
+                            const int *window_coefs, const int16_t *sinewave)
+{
+	int rc;
+	rxgpu_power_scan *s;
+	if (!out || !p || max_tunes < 1)
+		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_power_scan_create: bad arguments");
+	if (p->bin_e < 0 || p->bin_e > 21 || p->buf_len < 2 || (p->buf_len & 1) || p->downsample < 1)
+		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_power_scan_create: bad geometry");
+	if (p->bin_e > PW_MAX_BIN_E)
+		return rxgpu_fail(RXGPU_EUNSUPPORTED, "FFT of 2^%d points does not fit the LDS-resident kernel (max 2^%d)", p->bin_e, PW_MAX_BIN_E);
+	if (p->bin_e > 0 && (!window_coefs || !sinewave))
+		return rxgpu_fail(RXGPU_EINVAL, "window and sine tables are required for bin_e > 0");
+	if (p->bin_e > 0 && p->buf_len < 2 * (1 << p->bin_e))
+		return rxgpu_fail(RXGPU_EINVAL, "buf_len %d shorter than one FFT block", p->buf_len);
+	if ((rc = rxgpu_ensure_init()) != RXGPU_OK)
+		return rc;
+	s = calloc(1, sizeof(*s));
+	if (!s)
+		return rxgpu_fail(RXGPU_ENOMEM, "out of host memory");
+	s->p = *p;
+	s->max_tunes = max_tunes;
+	if (p->bin_e > 0) {
+		const int n = 1 << p->bin_e;
+		uint32_t *tw = malloc((size_t)(n / 2 + 1) * 4);
+		if (!tw) { free(s); return rxgpu_fail(RXGPU_ENOMEM, "out of host memory"); }
+		/* twiddles exactly as fix_fft forms them, rtl_power.c:297-301: halve AFTER negating */
+		for (int j = 0; j < n / 2; j++) {
+			int16_t wr = sinewave[j + n / 4];
+			int16_t wi = (int16_t)(-sinewave[j]);
+			wr >>= 1;
+			wi >>= 1;
+			tw[j] = ((uint32_t)(uint16_t)wr) | ((uint32_t)(uint16_t)wi << 16);
+		}
+		if (hipMalloc((void **)&s->window_dev, (size_t)n * 4) != hipSuccess ||
+		    hipMalloc((void **)&s->twiddle_dev, (size_t)(n / 2 + 1) * 4) != hipSuccess ||
+		    hipMalloc((void **)&s->fir_dev, 10 * 4) != hipSuccess ||
+		    hipMemcpy(s->window_dev, window_coefs, (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess ||
+		    hipMemcpy(s->twiddle_dev, tw, (size_t)(n / 2 + (n < 2)) * 4, hipMemcpyHostToDevice) != hipSuccess ||
+		    hipMemcpy(s->fir_dev, cic_9_tables[p->downsample_passes <= 10 ? p->downsample_passes : 0], 40, hipMemcpyHostToDevice) != hipSuccess) {
+			free(tw);
+			rxgpu_power_scan_destroy(s);
+			return rxgpu_fail(RXGPU_ENOMEM, "device table allocation failed");
+		}
+		free(tw);
+	}
+	*out = s;
+	return RXGPU_OK;
+}
+
+void rxgpu_power_scan_destroy(rxgpu_power_scan *s)
+{
+	if (!s)
+		return;
+	hipFree(s->window_dev); hipFree(s->twiddle_dev); hipFree(s->fir_dev);
+	hipFree(s->work[0]); hipFree(s->work[1]);
+	hipFree(s->rms_t); hipFree(s->rms_p);
+	free(s);
+}
+
+int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, int tunes,
+                         int64_t *d_avg, int32_t *d_samples)
+{
+	if (!s || !d_in || !d_avg || !d_samples || passes < 1 || tunes < 1)
+		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_power_scan_run: bad arguments");
+	hipStream_t st = rxgpu_hip_stream();
+	const rxgpu_power_params *p = &s->p;
+	const size_t n_bufs = (size_t)passes * (size_t)tunes;
+	const int buf_len = p->buf_len, ds = p->downsample, ds_p = p->downsample_passes;
+
+	if (p->bin_e == 0) {                                   /* rms_power, rtl_power.c:710-713 */
+		if (s->rms_cap < n_bufs) {
+			hipFree(s->rms_t); hipFree(s->rms_p);
+			s->rms_t = s->rms_p = NULL; s->rms_cap = 0;
+			RX_HIP(hipMalloc((void **)&s->rms_t, n_bufs * 8));
+			RX_HIP(hipMalloc((void **)&s->rms_p, n_bufs * 8));
+			s->rms_cap = n_bufs;
+		}
+		rxgpu_prof_begin("pw_rms");
+		RX_K(rxk_pw_rms_sums(st, d_in, n_bufs, buf_len, s->rms_t, s->rms_p));
+		RX_K(rxk_pw_rms_apply(st, s->rms_t, s->rms_p, passes, tunes, buf_len, p->peak_hold, (long long *)d_avg, d_samples));
+		rxgpu_prof_end("pw_rms");
+		return RXGPU_OK;
+	}
+
+	const int16_t *fft_in = d_in;
+	int eff_len = buf_len;
+	if (ds > 1 && (p->boxcar || ds_p)) {
+		const size_t need = n_bufs * (size_t)buf_len * 2;
+		if (s->work_cap < need) {
+			hipFree(s->work[0]); hipFree(s->work[1]);
+			s->work[0] = s->work[1] = NULL; s->work_cap = 0;
+			RX_HIP(hipMalloc((void **)&s->work[0], need));
+			RX_HIP(hipMalloc((void **)&s->work[1], need));
+			s->work_cap = need;
+		}
+		rxgpu_prof_begin("pw_downsample");
+		if (p->boxcar) {                                   /* rtl_power.c:723-733 */
+			RX_K(rxk_pw_boxcar(st, d_in, s->work[0], n_bufs, buf_len, ds));
+			fft_in = s->work[0];
+		} else {                                           /* rtl_power.c:734-743 */
+			const int16_t *src = d_in;
+			int n_in = buf_len / 2, which = 0;
+			for (int j = 0; j < ds_p; j++) {
+				RX_K(rxk_pw_fifth(st, src, s->work[which], n_bufs, n_in, buf_len / 2, buf_len / 2));
+				src = s->work[which];
+				which ^= 1;
+				n_in = (n_in + 1) / 2;
+			}
+			if (p->comp_fir_size == 9 && ds_p <= 10) {
+				RX_K(rxk_pw_droop(st, src, s->work[which], n_bufs, (buf_len >> ds_p) / 2, buf_len / 2, s->fir_dev));
+				src = s->work[which];
+			}
+			fft_in = src;
+		}
+		rxgpu_prof_end("pw_downsample");
+		eff_len = buf_len / ds;
+	}
+	/* enough workgroups to fill 256 CUs several times over, few enough that the per-group
+	 * int64 accumulators amortise the global atomics */
+	int groups = (4096 + tunes - 1) / tunes;
+	if (groups > passes) groups = passes;
+	if (groups < 1) groups = 1;
+	const int ppg = (passes + groups - 1) / groups;
+	const int n_blocks = (eff_len + 2 * (1 << p->bin_e) - 1) / (2 * (1 << p->bin_e));
+	rxgpu_prof_begin("pw_fft");
+	RX_K(rxk_pw_fft(st, fft_in, (size_t)buf_len, (size_t)tunes * (size_t)buf_len, passes, tunes, p->bin_e, eff_len, eff_len,
+	                s->window_dev, s->twiddle_dev, p->peak_hold, ppg, (long long *)d_avg));
+	rxgpu_prof_end("pw_fft");
+	RX_K(rxk_pw_samples(st, d_samples, tunes, n_blocks * ds * passes));   /* rtl_power.c:769 */
+	return RXGPU_OK;
+}
+
+/* ------------------------------------------------------------------ drop-ins */
+
+int rxgpu_scan(struct tuning_state *tunes, int tune_count, const int *window_coefs,
+               const int16_t *sinewave, int boxcar, int comp_fir_size, int peak_hold)
+{
+	int rc;
+	rxgpu_power_scan *s = NULL;
+	rxgpu_power_params p;
+	int16_t *d_in = NULL;
+	int64_t *d_avg = NULL;
+	int32_t *d_samples = NULL;
+	if (!tunes || tune_count < 1)
+		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_scan: no tunes");
+	/* scanner() uses tunes[0]'s geometry for every tune, rtl_power.c:676-678 */
+	memset(&p, 0, sizeof(p));
+	p.bin_e = tunes[0].bin_e;
+	p.buf_len = tunes[0].buf_len;
+	p.downsample = tunes[0].downsample;
+	p.downsample_passes = tunes[0].downsample_passes;
+	p.boxcar = boxcar;
+	p.comp_fir_size = comp_fir_size;
+	p.peak_hold = peak_hold;
+	if ((rc = rxgpu_power_scan_create(&s, &p, tune_count, window_coefs, sinewave)) != RXGPU_OK)
+		return rc;
+	const size_t n = (size_t)1 << p.bin_e;
+	const size_t in_bytes = (size_t)tune_count * p.buf_len * 2;
+	rc = RXGPU_ENOMEM;
+	if (hipMalloc((void **)&d_in, in_bytes) != hipSuccess || hipMalloc((void **)&d_avg, (size_t)tune_count * n * 8) != hipSuccess ||
+	    hipMalloc((void **)&d_samples, (size_t)tune_count * 4) != hipSuccess) {
+		rxgpu_fail(RXGPU_ENOMEM, "rxgpu_scan: hipMalloc failed");
+		goto done;
+	}
+	hipStream_t st = rxgpu_hip_stream();
+	for (int i = 0; i < tune_count; i++) {
+		hipMemcpyAsync(d_in + (size_t)i * p.buf_len, tunes[i].buf16, (size_t)p.buf_len * 2, hipMemcpyHostToDevice, st);
+		hipMemcpyAsync(d_avg + (size_t)i * n, tunes[i].avg, n * 8, hipMemcpyHostToDevice, st);
+		hipMemcpyAsync(d_samples + i, &tunes[i].samples, 4, hipMemcpyHostToDevice, st);
+	}
+	if ((rc = rxgpu_power_scan_run(s, d_in, 1, tune_count, d_avg, d_samples)) != RXGPU_OK)
+		goto done;
+	for (int i = 0; i < tune_count; i++) {
+		hipMemcpyAsync(tunes[i].avg, d_avg + (size_t)i * n, n * 8, hipMemcpyDeviceToHost, st);
+		hipMemcpyAsync(&tunes[i].samples, d_samples + i, 4, hipMemcpyDeviceToHost, st);
+	}
+	if (hipStreamSynchronize(st) != hipSuccess) {
+		rc = rxgpu_fail(RXGPU_ENODEV, "rxgpu_scan: %s", hipGetErrorString(hipGetLastError()));
+		goto done;
+	}
+	rxgpu_prof_collect();
+	rc = RXGPU_OK;
+done:
+	hipFree(d_in); hipFree(d_avg); hipFree(d_samples);
+	rxgpu_power_scan_destroy(s);
+	return rc;
+}
+
+/* csv_dbm, rtl_power.c:774-817 (host; fed with bit-exact avg[] it prints the same text) */
+void rxgpu_csv_dbm(struct tuning_state *ts, void *file)
+{
+	FILE *f = (FILE *)file;
+	int i, len, ds, i1, i2, bw2, bin_count;
+	int64_t tmp;
+	double dbm;
+	len = 1 << ts->bin_e;
+	ds = ts->downsample;
+	if (ts->bin_e > 0) {
+		ts->avg[0] = ts->avg[1];                           /* nuke DC (784) */
+		for (i = 0; i < len / 2; i++) {                    /* half swap (786-790) */
+			tmp = ts->avg[i];
+			ts->avg[i] = ts->avg[i + len / 2];
+			ts->avg[i + len / 2] = tmp;
+		}
+	}
+	bin_count = (int)((double)len * (1.0 - ts->crop));
+	bw2 = (int)(((double)ts->rate * (double)bin_count) / (len * 2 * ds));
+	fprintf(f, "%lli, %lli, %.2f, %i, ", (long long)ts->freq - bw2, (long long)ts->freq + bw2,
+	        (double)ts->rate / (double)(len * ds), ts->samples);
+	i1 = 0 + (int)((double)len * ts->crop * 0.5);
+	i2 = (len - 1) - (int)((double)len * ts->crop * 0.5);
+	for (i = i1; i <= i2; i++) {
+		dbm = (double)ts->avg[i];
+		dbm /= (double)ts->rate;
+		dbm /= (double)ts->samples;
+		dbm = 10 * log10(dbm);
+		fprintf(f, "%.2f, ", dbm);
+	}
+	dbm = (double)ts->avg[i2] / ((double)ts->rate * (double)ts->samples);
+	if (ts->bin_e == 0)
+		dbm = ((double)ts->avg[0] / ((double)ts->rate * (double)ts->samples));
+	dbm = 10 * log10(dbm);
+	fprintf(f, "%.2f\n", dbm);
+	for (i = 0; i < len; i++)
+		ts->avg[i] = 0L;
+	ts->samples = 0;
+}

@@ -1,0 +1,136 @@
+"""-m gpu: the rx_fm HIP path against the oracle, through the C ABI (librxgpu.so)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from support import (oracle_fm_stream, oracle_fm_state, sig_fm, sig_noise, sig_alternating, oracle)
+
+pytestmark = pytest.mark.gpu
+
+
+def _signals(n_int16):
+    return {
+        "fm": sig_fm(n_int16 // 2),
+        "noise_full": sig_noise(n_int16, seed=777),
+        "noise_small": sig_noise(n_int16, seed=5, amp=700),
+        "alternating": sig_alternating(n_int16),
+        "zeros": np.zeros(n_int16, np.int16),
+        "dc": np.full(n_int16, 3000, np.int16),
+    }
+
+
+def _check(iq, block_len, n_runs=1, **params):
+    from gpu_support import gpu_fm_stream, carry_tuple, carry_from_oracle_state
+    want, want_lens, st = oracle_fm_stream(iq, block_len, **params)
+    got, got_lens, carry, _ = gpu_fm_stream(iq, block_len, n_runs=n_runs, **params)
+    assert len(got) == len(want)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, "first mismatch at %d: got %d want %d (%d bad of %d)" % (
+        bad[0], got[bad[0]], want[bad[0]], bad.size, len(want))
+    assert np.array_equal(got_lens, want_lens)
+    assert carry_tuple(carry)[:8] == carry_tuple(carry_from_oracle_state(st))[:8]
+    return carry, st
+
+
+@pytest.mark.parametrize("sig", ["fm", "noise_full", "noise_small", "alternating", "zeros", "dc"])
+@pytest.mark.parametrize("ds", [118, 6])
+def test_low_pass_chain_bit_exact(sig, ds):
+    """config 2 geometry (ds=118) and the -M wbfm default (ds=6), 16 blocks of 8192 complex"""
+    iq = _signals(16 * 16384)[sig]
+    _check(iq, 16384, downsample=ds)
+
+
+@pytest.mark.parametrize("ds,block_len", [(118, 2 * 131072), (5, 2 * 20352), (7, 4096 + 8), (1, 4096), (3, 8192),
+                                          (250, 8192), (118, 2 * 1180)])
+def test_low_pass_geometries(ds, block_len):
+    """fast and generic decimator, block lengths that are / are not multiples of 8 int16"""
+    n_blocks = 3 if block_len > 100000 else 9
+    iq = sig_fm(n_blocks * block_len // 2, seed=99)
+    _check(iq, block_len, downsample=ds)
+
+
+def test_config1_wbfm_240k():
+    """BASELINE config 1: -M wbfm -s 240000 (ds=5, deemph_a=19), 1 s = 1.2 M samples as
+    9 blocks of 131072 -- through the device path (the CPU plumbing case is in test_oracle)"""
+    iq = sig_fm(9 * 131072, seed=4)
+    _check(iq, 2 * 131072, downsample=5, rate_out=240000, deemph_a=19)
+
+
+@pytest.mark.parametrize("n_runs", [2, 5])
+def test_carry_across_runs(n_runs):
+    """several rxgpu_fm_stream_run calls == one: every carry crosses the call boundary"""
+    iq = sig_fm(20 * 8192, seed=1)
+    _check(iq, 16384, n_runs=n_runs, downsample=118)
+    _check(sig_noise(20 * 16384, seed=3), 16384, n_runs=n_runs, downsample=6)
+
+
+@pytest.mark.parametrize("params", [
+    dict(downsample=118, deemph=0),
+    dict(downsample=118, rate_out2=-1),
+    dict(downsample=118, deemph=0, rate_out2=-1),
+    dict(downsample=10, custom_atan=0),
+    dict(downsample=118, offset_tuning=1),
+    dict(downsample=20, deemph_a=40),          # 64-lane candidate groups
+    dict(downsample=20, deemph_a=200),         # serial de-emphasis kernel
+    dict(downsample=20, deemph_a=1),
+    dict(downsample=20, deemph_a=2),
+    dict(downsample=8, rate_out=48000, rate_out2=48000),
+])
+def test_stage_switches(params):
+    iq = sig_fm(8 * 8192, seed=7)
+    _check(iq, 16384, **params)
+    _check(sig_noise(8 * 16384, seed=8, amp=2000), 16384, **params)
+
+
+@pytest.mark.parametrize("passes,fir", [(3, 0), (3, 9), (7, 0), (1, 9), (5, 9)])
+@pytest.mark.parametrize("sig", ["fm", "noise_full", "zeros"])
+def test_fifth_order_chain_bit_exact(passes, fir, sig):
+    """-F path: fifth_order cascade (+ droop FIR), including the block-seam rule"""
+    iq = _signals(6 * 16384)[sig]
+    carry, st = _check(iq, 16384, downsample_passes=passes, comp_fir_size=fir)
+    from gpu_support import carry_tuple, carry_from_oracle_state
+    want = carry_tuple(carry_from_oracle_state(st))
+    got = carry_tuple(carry)
+    # histories of the passes that ran
+    assert got[8][:12 * passes] == want[8][:12 * passes]
+    assert got[9][:12 * passes] == want[9][:12 * passes]
+    if fir == 9:
+        assert got[10] == want[10] and got[11] == want[11]
+
+
+def test_fifth_order_carry_across_runs():
+    iq = sig_noise(12 * 16384, seed=21, amp=20000)
+    _check(iq, 16384, n_runs=3, downsample_passes=3, comp_fir_size=9)
+
+
+def test_scale_formula_exhaustive_on_device():
+    """F0 on the device for all 65536 int16 values == the reference's fp64 expression"""
+    from gpu_support import gpu_fm_stream
+    x = np.arange(-32768, 32768, dtype=np.int16)
+    iq = np.zeros(4 * 65536, np.int16)
+    iq[0::4] = x          # I of even samples; ds=1, no rotation: the decimated I is the scaled value
+    iq[3::4] = x[::-1]    # Q of odd samples
+    O = oracle()
+    want = np.array([O.rxo_scale_sample(int(v)) for v in x], dtype=np.int16)
+    # ds=1 + offset tuning + raw output of the discriminator is awkward to read back; use
+    # the boxcar with ds=4 on a stream where only one of four samples is non-zero instead
+    iq2 = np.zeros(8 * 65536, np.int16)
+    iq2[0::8] = x
+    iq2[1::8] = x[::-1]
+    from support import oracle_fm_stream
+    got, _, c, _ = gpu_fm_stream(iq2, 8 * 65536, downsample=4, offset_tuning=1, deemph=0, rate_out2=-1)
+    ref, _, _ = oracle_fm_stream(iq2, 8 * 65536, downsample=4, offset_tuning=1, deemph=0, rate_out2=-1)
+    assert np.array_equal(got, ref)
+    assert want[0] == -127 and want[-1] == 128
+
+
+def test_full_size_block_and_properties():
+    """2^22 samples (32 blocks of 131072) at ds=118: bit-exact vs oracle, plus the
+    size-independent properties used at bench size: output count and carry closed forms"""
+    n_blocks, bl = 32, 2 * 131072
+    iq = np.tile(sig_fm(4 * 131072, seed=12345), n_blocks // 4)
+    carry, st = _check(iq, bl, downsample=118)
+    T = n_blocks * 131072
+    assert carry.prev_index == T % 118
+    assert carry.prev_lpr_index == ((T // 118) * 32000) % 170000

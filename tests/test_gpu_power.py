@@ -1,0 +1,94 @@
+"""-m gpu: the rx_power HIP path against the oracle, through the C ABI (librxgpu.so)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import rx_tools_amd as R
+from support import oracle, sig_noise, PowerCfg, ptr16, ptr32, ptr64
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_scan(data, passes, tunes, plan, window, sinewave, boxcar, comp_fir, peak_hold):
+    O = oracle()
+    n = 1 << plan.bin_e
+    wc = np.ascontiguousarray(window, np.int32)
+    sw = np.ascontiguousarray(sinewave, np.int16)
+    cfg = PowerCfg(plan.bin_e, plan.buf_len, plan.downsample, plan.downsample_passes, boxcar, comp_fir, peak_hold,
+                   ptr32(wc), ptr16(sw))
+    avg = np.zeros((tunes, n), np.int64)
+    samples = np.zeros(tunes, np.int32)
+    work = np.zeros(plan.buf_len, np.int16)
+    d3 = data.reshape(passes, tunes, plan.buf_len)
+    for p in range(passes):
+        for t in range(tunes):
+            s = C.c_int(int(samples[t]))
+            O.rxo_power_tune(C.byref(cfg), ptr16(np.ascontiguousarray(d3[p, t])), ptr16(work), ptr64(avg[t]), C.byref(s))
+            samples[t] = s.value
+    return avg, samples
+
+
+def gpu_scan(data, passes, tunes, plan, window, sinewave, boxcar, comp_fir, peak_hold, avg0=None):
+    from gpu_support import to_dev, torch_cuda
+    torch = torch_cuda()
+    n = 1 << plan.bin_e
+    p = R.PowerParams(plan.bin_e, plan.buf_len, plan.downsample, plan.downsample_passes, boxcar, comp_fir, peak_hold)
+    s = R.PowerScan(p, tunes, window, sinewave)
+    d_in = to_dev(data)
+    d_avg = torch.zeros((tunes, n), dtype=torch.int64, device="cuda") if avg0 is None else to_dev(avg0)
+    d_samples = torch.zeros(tunes, dtype=torch.int32, device="cuda")
+    s.run(d_in.data_ptr(), passes, tunes, d_avg.data_ptr(), d_samples.data_ptr())
+    R.check(R.lib().rxgpu_sync())
+    out = d_avg.cpu().numpy(), d_samples.cpu().numpy()
+    s.close()
+    return out
+
+
+CASES = [
+    # range, crop, window, (boxcar, comp_fir, peak_hold), amplitude, passes, max tunes
+    ("24M:1.7G:1k", 0.0, "rectangle", (1, 0, 0), 100, 3, 7),        # config 3 geometry, no window wrap
+    ("24M:1.7G:1k", 0.0, "rectangle", (1, 0, 0), 32768, 2, 5),      # full scale: wraps everywhere
+    ("24M:1.7G:1k", 0.0, "hamming", (1, 0, 1), 3000, 3, 4),         # peak hold
+    ("88M:108M:125k", 0.0, "blackman-harris", (1, 0, 0), 5000, 2, 8),   # N=32
+    ("100M:101M:1k", 0.2, "bartlett", (1, 0, 0), 500, 2, 1),        # N=1024
+    ("100M:100.1M:10", 0.0, "rectangle", (1, 0, 0), 2000, 1, 1),    # N=16384, boxcar ds=28
+    ("100M:100.1M:10", 0.0, "youssef", (0, 0, 0), 2000, 2, 1),      # fifth_order ds=16
+    ("100M:100.1M:10", 0.0, "hann-poisson", (0, 9, 0), 30000, 1, 1),    # + droop FIR
+    ("100M:100.3M:100", 0.0, "rectangle", (1, 0, 0), 9000, 2, 1),   # boxcar, odd ds
+    ("100M:110M:1M", 0.0, "rectangle", (1, 0, 0), 5000, 3, 10),     # rms_power path
+    ("100M:110M:1M", 0.0, "rectangle", (1, 0, 1), 5000, 3, 10),
+]
+
+
+@pytest.mark.parametrize("rng,crop,window,flags,amp,passes,max_tunes", CASES)
+def test_scan_bit_exact(rng, crop, window, flags, amp, passes, max_tunes):
+    plan = R.plan_range(rng, crop, flags[0])
+    tunes = min(plan.tune_count, max_tunes)
+    n = 1 << plan.bin_e
+    wc = R.window_coefs(window, n)
+    sw = R.sine_table(plan.bin_e)
+    data = sig_noise(passes * tunes * plan.buf_len, seed=777, amp=amp)
+    want_avg, want_samples = oracle_scan(data, passes, tunes, plan, wc, sw, *flags)
+    got_avg, got_samples = gpu_scan(data, passes, tunes, plan, wc, sw, *flags)
+    assert np.array_equal(got_samples, want_samples)
+    bad = np.argwhere(got_avg != want_avg)
+    assert bad.size == 0, "first mismatch at %s: got %d want %d (%d bad)" % (
+        bad[0], got_avg[tuple(bad[0])], want_avg[tuple(bad[0])], len(bad))
+
+
+def test_scan_linearity_in_passes_full_geometry():
+    """size-independent property at config-3 size: avg over 2P identical passes == 2 x avg over P,
+    all 599 tunes"""
+    plan = R.plan_range("24M:1.7G:1k", 0.0, 1)
+    n = 1 << plan.bin_e
+    wc = R.window_coefs("rectangle", n)
+    sw = R.sine_table(plan.bin_e)
+    one = sig_noise(plan.tune_count * plan.buf_len, seed=31, amp=800)
+    a1, s1 = gpu_scan(one, 1, plan.tune_count, plan, wc, sw, 1, 0, 0)
+    a4, s4 = gpu_scan(np.tile(one, 4), 4, plan.tune_count, plan, wc, sw, 1, 0, 0)
+    assert np.array_equal(a4, 4 * a1)
+    assert np.array_equal(s4, 4 * s1)
+    # and a few tunes against the oracle
+    want, _ = oracle_scan(one[:3 * plan.buf_len], 1, 3, plan, wc, sw, 1, 0, 0)
+    assert np.array_equal(a1[:3], want)
