@@ -1,0 +1,282 @@
+#!/usr/bin/env python3
+"""bench.py -- the rx_tools hot path on MI355X, measured the way BASELINE.json asks.
+
+Headline (`value`): complex IQ MSample/s through the rx_fm callback pre-stage + full_demod()
+chain at the "20 Msps" WBFM geometry of BASELINE config 2 (downsample=118 -> 170 ksps ->
+32 ksps audio, -A fast, de-emphasis on), blocks of 131072 complex samples, input resident in
+HBM.  One step = one rxgpu_fm_stream_run over --blocks blocks (default 2048 = 1 GiB of cs16).
+The same JSON line carries, under "rx_power", FFT bins/s of the scanner() chain at the
+config-3 geometry (-f 24M:1.7G:1k: 599 tunes x 16384 int16, N=4096), tunes sharded across the
+ranks with one RCCL gather of the avg[] rows to rank 0 per step.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+rx_fm does not shard (one stream, sequential carries): N>1 runs N independent replicas
+("replicas only", weak scaling).  rx_power shards by tune (strong scaling of one sweep).
+torch is used for device buffers and torch.distributed only; every sample is processed by
+librxgpu.so through its C ABI.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_fm(block_len, budget_s):
+    """The reference's own callback + full_demod (oracle/_ref, gcc -O2) -- or, where that
+    prebuilt object is absent, the oracle port -- on one host core, config-2 parameters."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import support
+    import rx_tools_amd as R
+    n_buf = 16
+    iq = R.synth.sig_fm(n_buf * block_len // 2, seed=12345)
+    if support.have_ref():
+        L = support.ref_fm()
+        support.ref_fm_reset(L, downsample=118)
+        scratch = np.zeros(block_len, np.int16)
+        calls, t0 = 0, time.perf_counter()
+        while True:
+            L.ref_fm_run_blocks(support.ptr16(iq), n_buf, block_len, 64, support.ptr16(scratch), None, 0)
+            calls += 64
+            dt = time.perf_counter() - t0
+            if dt >= budget_s:
+                break
+        kind = "reference"
+    else:
+        O = support.oracle()
+        st = support.oracle_fm_state(downsample=118)
+        out = np.zeros(n_buf * block_len // 2, np.int16)
+        calls, t0 = 0, time.perf_counter()
+        while True:
+            O.rxo_fm_stream(C.byref(st), support.ptr16(iq), n_buf, block_len, support.ptr16(out), None)
+            calls += n_buf
+            dt = time.perf_counter() - t0
+            if dt >= budget_s:
+                break
+        kind = "port"
+    samples = calls * (block_len // 2)
+    return {"value": samples / dt / 1e6, "unit": "MSample/s", "cores": 1, "kind": kind,
+            "sample": "%d blocks of %d complex samples, rtlsdr_callback+full_demod, ds=118 wbfm, %.1f s on 1 thread (%s)"
+                      % (calls, block_len // 2, dt, cpu_model())}
+
+
+def cpu_baseline_power(plan, budget_s):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import support
+    import rx_tools_amd as R
+    tunes = 64
+    n = 1 << plan.bin_e
+    data = R.synth.sig_noise(tunes * plan.buf_len, seed=777, amp=100)
+    O = support.oracle()
+    wc, sw = R.window_coefs("rectangle", n), R.sine_table(plan.bin_e)
+    cfg = support.PowerCfg(plan.bin_e, plan.buf_len, 1, 0, 1, 0, 0, support.ptr32(wc), support.ptr16(sw))
+    avg = np.zeros(n, np.int64)
+    work = np.zeros(plan.buf_len, np.int16)
+    smp = C.c_int(0)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        for t in range(tunes):
+            O.rxo_power_tune(C.byref(cfg), support.ptr16(data[t * plan.buf_len:(t + 1) * plan.buf_len]),
+                             support.ptr16(work), support.ptr64(avg), C.byref(smp))
+        done += tunes
+        dt = time.perf_counter() - t0
+        if dt >= budget_s:
+            break
+    bins = done * (plan.buf_len // 2)
+    return {"value": bins / dt / 1e6, "unit": "Mbins/s", "cores": 1, "kind": "port",
+            "sample": "%d tune buffers of %d int16 (N=%d), scanner() per-tune chain, %.1f s on 1 thread" % (done, plan.buf_len, n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--blocks", type=int, default=2048, help="rx_fm blocks of 131072 complex samples per step")
+    ap.add_argument("--passes", type=int, default=128, help="rx_power scanner() passes per step")
+    ap.add_argument("--workload", default="both", choices=["both", "rx_fm", "rx_power"])
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU baseline budget per path (0 = skip)")
+    ap.add_argument("--prof-level", type=int, default=1)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import rx_tools_amd as R
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    R.check(R.lib().rxgpu_init(local))
+    L = R.lib()
+    dev = torch.device("cuda", local)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(seconds):
+        if world == 1:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def prof(name):
+        ms, n = C.c_double(0), C.c_long(0)
+        L.rxgpu_prof_get(name.encode(), C.byref(ms), C.byref(n))
+        return ms.value, n.value
+
+    result = {}
+
+    # ------------------------------------------------------------------ rx_fm (headline)
+    if args.workload in ("both", "rx_fm"):
+        block_len = 2 * 131072
+        n_blocks = args.blocks
+        base = R.synth.sig_fm(8 * 131072, seed=12345 + rank)          # 8 blocks of signal (A)
+        d_base = torch.from_numpy(base).to(dev)
+        d_iq = d_base.repeat(n_blocks // 8 + 1)[: n_blocks * block_len].contiguous()
+        del d_base
+        T = n_blocks * (block_len // 2)
+        d_out = torch.zeros(T // 118 + 64, dtype=torch.int16, device=dev)
+        s = R.FmStream(R.FmParams.wbfm(downsample=118), n_blocks, block_len)
+        for _ in range(args.warmup):
+            s.run(d_iq.data_ptr(), n_blocks, block_len, d_out.data_ptr(), d_out.numel())
+        L.rxgpu_prof_reset()
+        L.rxgpu_prof_enable(args.prof_level)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            s.run(d_iq.data_ptr(), n_blocks, block_len, d_out.data_ptr(), d_out.numel())
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        L.rxgpu_prof_enable(0)
+        ms, launches = prof("fm_decimate")
+        fixups = s.host_fixups
+        s.close()
+        del d_iq, d_out
+        torch.cuda.empty_cache()
+        value = world * T * args.steps / dt / 1e6
+        achieved = (4.0 * T) / (ms / launches * 1e-3) / 1e9 if launches else 0.0
+        result.update({
+            "metric": "rx_fm full_demod complex IQ MSample/s (20 Msps WBFM geometry, ds=118)",
+            "value": value, "unit": "MSample/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int16/int32 (fp32 fma for the cs16 scale, fp64 for one atan2 per block)",
+            "data": "synthetic",
+            "config": {"workload": "rx_fm WBFM 20.06 Msps -> 170 ksps -> 32 ksps: callback scale+rotate, low_pass ds=118, "
+                                   "polar_disc_fast, deemph a=13, low_pass_real (BASELINE configs[1])",
+                       "blocks_per_step": n_blocks, "block_complex_samples": block_len // 2,
+                       "bytes_per_step": 4 * T, "parallelism": "replicas x%d (rx_fm does not shard)" % world,
+                       "host_fixups_last_step": fixups},
+            "roofline": {"bound": "hbm", "kernel": "k_fm_decimate (F0+F1+F2)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": 4 * T, "avg_launch_ms": (ms / launches) if launches else None},
+        })
+        if rank == 0 and args.cpu_seconds > 0 and world == 1:
+            result["cpu_baseline"] = cpu_baseline_fm(block_len, args.cpu_seconds)
+
+    # ------------------------------------------------------------------ rx_power
+    if args.workload in ("both", "rx_power"):
+        plan = R.plan_range("24M:1.7G:1k", 0.0, 1)
+        n = 1 << plan.bin_e
+        total_tunes = plan.tune_count
+        per = (total_tunes + world - 1) // world                  # contiguous tune ranges, SURVEY section 8(e)
+        lo = min(total_tunes, rank * per)
+        mine = min(total_tunes, lo + per) - lo
+        passes = args.passes
+        wc, sw = R.window_coefs("rectangle", n), R.sine_table(plan.bin_e)
+        ps = R.PowerScan(R.PowerParams(plan.bin_e, plan.buf_len, plan.downsample, plan.downsample_passes, 1, 0, 0),
+                         per, wc, sw)
+        g = torch.Generator(device=dev)
+        g.manual_seed(777 + rank)
+        d_in = torch.randint(-100, 101, (passes, max(mine, 1), plan.buf_len), dtype=torch.int16, device=dev, generator=g)
+        d_avg = torch.zeros((per, n), dtype=torch.int64, device=dev)        # padded to `per` rows for the gather
+        d_smp = torch.zeros(per, dtype=torch.int32, device=dev)
+        gathered = [torch.zeros_like(d_avg) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+        def step():
+            if mine:
+                ps.run(d_in.data_ptr(), passes, mine, d_avg.data_ptr(), d_smp.data_ptr())
+            if world > 1:
+                # order the gather (torch's stream) after the scan (librxgpu's stream)
+                L.rxgpu_sync()
+                dist.gather(d_avg, gathered, dst=0)
+
+        for _ in range(args.warmup):
+            step()
+        L.rxgpu_prof_reset()
+        L.rxgpu_prof_enable(args.prof_level)
+        barrier()
+        L.rxgpu_sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        L.rxgpu_sync()
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        L.rxgpu_prof_enable(0)
+        ms, launches = prof("pw_fft")
+        bins_per_step_all = passes * total_tunes * (plan.buf_len // 2)
+        bins_local = passes * mine * (plan.buf_len // 2)
+        achieved = (4.0 * bins_local) / (ms / launches * 1e-3) / 1e9 if launches else 0.0
+        pw = {
+            "metric": "rx_power FFT bins/s (scanner() chain, -f 24M:1.7G:1k geometry)",
+            "value": bins_per_step_all * args.steps / dt / 1e6, "unit": "Mbins/s", "n_gpus": world,
+            "ms_per_step": dt / args.steps * 1e3, "scaling": "strong", "dtype": "int16/int32/int64",
+            "config": {"workload": "599 tunes x 16384 int16, N=4096, 2 FFT blocks/tune/pass, rectangle window (BASELINE configs[2]/[3])",
+                       "passes_per_step": passes, "tunes_this_rank": mine,
+                       "parallelism": "tunes sharded x%d, one RCCL gather of avg[] to rank 0 per step" % world},
+            "roofline": {"bound": "hbm", "kernel": "k_pw_fft (P4-P8)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": 4 * bins_local,
+                         "avg_launch_ms": (ms / launches) if launches else None,
+                         "note": "integer-VALU/LDS bound on paper (SURVEY section 8d); HBM fraction reported as asked"},
+        }
+        if rank == 0 and args.cpu_seconds > 0 and world == 1:
+            pw["cpu_baseline"] = cpu_baseline_power(plan, args.cpu_seconds / 2)
+        ps.close()
+        if args.workload == "rx_power":
+            result.update(pw)
+            result.update({"steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
+                           "data": "synthetic"})
+        else:
+            result["rx_power"] = pw
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

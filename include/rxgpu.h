@@ -47,10 +47,11 @@ const char *rxgpu_last_error(void);
 void *rxgpu_stream(void);
 int rxgpu_sync(void);
 
-/* Per-kernel device timing with hipEvents on the launch stream.  While enabled every
- * launch of the named kernels is bracketed by events; totals are read back here.
- * name: "fm_decimate", "fm_disc", "fm_deemph", "fm_resample", "fm_fifth", "pw_fft", ... */
-void rxgpu_prof_enable(int on);
+/* Per-kernel device timing with hipEvents on the launch stream.  level 1 brackets only the
+ * kernels that dominate each path ("fm_decimate", "fm_fifth", "pw_fft"), level 2 every
+ * stage ("fm_disc", "fm_deemph", "fm_resample", "fm_droop", "pw_downsample", "pw_rms", ...);
+ * 0 switches it off.  Totals are read back with rxgpu_prof_get. */
+void rxgpu_prof_enable(int level);
 void rxgpu_prof_reset(void);
 int rxgpu_prof_get(const char *name, double *total_ms, long *launches);
 

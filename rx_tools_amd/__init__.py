@@ -7,3 +7,4 @@ no CPU implementation here: without librxgpu.so and a HIP device every call fail
 from ._lib import lib, RxGpuError, check          # noqa: F401
 from .fm import FmParams, FmCarry, FmStream        # noqa: F401
 from .power import PowerParams, PowerPlan, PowerScan, plan_range, sine_table, window_coefs  # noqa: F401
+from . import synth  # noqa: F401

@@ -32,6 +32,13 @@ def lib():
             raise RxGpuError(
                 "librxgpu.so is missing (%s); build it with `make -C rx_tools_amd/csrc` or "
                 "__graft_entry__.build().  rx_tools_amd has no CPU fallback." % LIB_PATH)
+        # torch (used by tests/bench for device buffers and torch.distributed) bundles its own HIP
+        # runtime; if it is going to share the process it has to be loaded first, otherwise the
+        # two runtimes' global symbols interleave and device discovery fails.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.rxgpu_last_error.restype = C.c_char_p
         L.rxgpu_stream.restype = C.c_void_p

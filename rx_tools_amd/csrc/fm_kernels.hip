@@ -334,115 +334,200 @@ __device__ __forceinline__ int deemph_step(int avg, int x, int a, int h, unsigne
 	return avg + (d < 0 ? -(int)q : (int)q);
 }
 
-// The per-sample map avg -> avg' is monotone with slope 0 or 1, so trajectories started from
-// the two ends of the possible state range sandwich the true one and their gap shrinks by
-// at least floor(gap/a) per step.  After `warm` samples the gap is < a <= GS; the GS lanes of
-// a group then carry every still-possible start state through the chunk, giving the exact
-// chunk map as a table.  Chunks whose trajectories merged (gap 0) are final immediately.
+// The recurrence is a non-linear integer IIR, but the per-sample map avg -> avg' is monotone
+// with slope 0 or 1.  So (1) trajectories started from the two ends of the possible state
+// range sandwich the true one, and their gap shrinks by at least floor(gap/a) per sample:
+// after `warm` samples fewer than GS (>= a) start states remain possible for a chunk; and
+// (2) the map of a whole chunk restricted to those states is a table of <= GS entries.
+// Tables compose associatively, which turns the serial recurrence into a tree scan:
+//   k_fm_deemph_scan   chunk tables (GS candidate lanes per chunk) + the composite of every
+//                      DEEMPH_FAN consecutive chunks (level 1)
+//   k_fm_deemph_up     composite of DEEMPH_FAN tables of one level -> next level (only for very
+//                      long runs)
+//   k_fm_deemph_top    one workgroup walks the top level from the carried state (sqrt split)
+//   k_fm_deemph_down   start state of every table one level down
+//   k_fm_deemph_apply  every chunk replayed once from its exact start state -> output
+#define DEEMPH_FAN 16
+
 template <int GS>
-__global__ __launch_bounds__(256) void k_fm_deemph_scan(
+__global__ __launch_bounds__(DEEMPH_FAN * GS) void k_fm_deemph_scan(
 	const int16_t *__restrict__ pcm, u64 M, int a, unsigned magic, int chunk, int warm, int lo0, int hi0,
-	int16_t *__restrict__ y, int *__restrict__ tab, int *__restrict__ lo_arr, int *__restrict__ gap_arr,
-	rxk_fm_dev *__restrict__ dev)
+	int *__restrict__ tab, int *__restrict__ lo_arr, int *__restrict__ gap_arr,
+	int *__restrict__ l1_tab, int *__restrict__ l1_lo, int *__restrict__ l1_gap, rxk_fm_dev *__restrict__ dev)
 {
 	extern __shared__ __attribute__((aligned(16))) int16_t xs[];
-	const int groups = 256 / GS;
+	__shared__ int tabs[DEEMPH_FAN][GS];
+	__shared__ int los[DEEMPH_FAN], gaps[DEEMPH_FAN];
 	const int grp = threadIdx.x / GS, k = threadIdx.x % GS;
-	const u64 c = (u64)blockIdx.x * groups + grp;
 	const u64 n_chunks = (M + chunk - 1) / chunk;
-	if (c >= n_chunks)
-		return;                                   // whole group leaves together; no barriers below
-	int16_t *buf = xs + (size_t)grp * (warm + chunk);
-	const u64 c0 = c * (u64)chunk;
-	const bool exact = c0 <= (u64)warm;           // the run's carried state is in reach
-	const u64 ws = exact ? 0 : c0 - warm;
-	const u64 c1 = (c0 + chunk < M) ? c0 + chunk : M;
-	const int nw = (int)(c0 - ws), nc = (int)(c1 - c0);
-	for (int i = k; i < nw + nc; i += GS)
-		buf[i] = pcm[ws + i];
-	__builtin_amdgcn_wave_barrier();
-	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-	const int h = a / 2;
-	int s = exact ? dev->in_deemph_avg : (k == 0 ? lo0 : hi0);
-	for (int i = 0; i < nw; i++)
-		s = deemph_step(s, buf[i], a, h, magic);
-	const int base = (threadIdx.x & 63) - k;      // first lane of this group within the wave
-	const int lo = __shfl(s, base), hi = __shfl(s, base + (GS > 1 ? 1 : 0));
-	int gap = exact ? 0 : hi - lo;
-	if (gap >= GS) {                              // cannot happen for warm from rxgpu_fm.c; checked anyway
-		if (k == 0) atomicExch(&dev->err, 1);
-		gap = GS - 1;
+	const u64 c = (u64)blockIdx.x * DEEMPH_FAN + grp;
+	const bool valid = c < n_chunks;
+	if (valid) {
+		int16_t *buf = xs + (size_t)grp * (warm + chunk);
+		const u64 c0 = c * (u64)chunk;
+		const bool exact = c0 <= (u64)warm;           // the run's carried state is in reach
+		const u64 ws = exact ? 0 : c0 - warm;
+		const u64 c1 = (c0 + chunk < M) ? c0 + chunk : M;
+		const int nw = (int)(c0 - ws), nc = (int)(c1 - c0);
+		for (int i = k; i < nw + nc; i += GS)
+			buf[i] = pcm[ws + i];
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		const int h = a / 2;
+		int s = exact ? dev->in_deemph_avg : (k == 0 ? lo0 : hi0);
+		for (int i = 0; i < nw; i++)
+			s = deemph_step(s, buf[i], a, h, magic);
+		const int base = (threadIdx.x & 63) - (GS == 64 ? (threadIdx.x & 63) : k);   // group's first lane in its wave
+		const int lo = __shfl(s, base), hi = __shfl(s, base + 1);
+		int gap = exact ? 0 : hi - lo;
+		if (gap >= GS) {                              // excluded by `warm` (rxgpu_fm.c); checked anyway
+			if (k == 0) atomicExch(&dev->err, 1);
+			gap = GS - 1;
+		}
+		s = lo + (k < gap ? k : gap);
+		for (int i = 0; i < nc; i++)
+			s = deemph_step(s, buf[nw + i], a, h, magic);
+		tabs[grp][k] = s;
+		tab[c * GS + k] = s;
+		if (k == 0) {
+			los[grp] = lo; gaps[grp] = gap;
+			lo_arr[c] = lo; gap_arr[c] = gap;
+		}
 	}
-	s = lo + (k < gap ? k : gap);
-	const bool writer = (gap == 0 && k == 0);
-	for (int i = 0; i < nc; i++) {
-		s = deemph_step(s, buf[nw + i], a, h, magic);
-		if (writer)
-			buf[nw + i] = (int16_t)s;
-	}
-	tab[c * GS + k] = s;
-	if (k == 0) {
-		lo_arr[c] = lo;
-		gap_arr[c] = gap;
-		if (gap)
-			atomicOr(&dev->any_unmerged, 1);
-		else if (c == n_chunks - 1)
-			dev->out_deemph_avg = s;
-	}
-	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-	if (gap == 0)
-		for (int i = k; i < nc; i += GS)
-			y[c0 + i] = buf[nw + i];
-}
-
-// Start state of every chunk.  Merged chunks know theirs; a run of unmerged chunks is walked
-// by the thread of its first chunk through the tables.
-__global__ void k_fm_deemph_resolve(u64 n_chunks, int gs, const int *__restrict__ tab, const int *__restrict__ lo_arr,
-                                    const int *__restrict__ gap_arr, int *__restrict__ start_arr,
-                                    const rxk_fm_dev *__restrict__ dev)
-{
-	if (!dev->any_unmerged)
-		return;
-	const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= n_chunks)
-		return;
-	if (gap_arr[c] == 0) {
-		start_arr[c] = lo_arr[c];
-		return;
-	}
-	if (gap_arr[c - 1] != 0)                     // chunk 0 always has gap 0, so c >= 1 here
-		return;
-	int s = tab[(c - 1) * gs];                    // previous chunk merged: lane 0 ran the true state
-	start_arr[c] = s;
-	u64 cc = c;
-	while (cc + 1 < n_chunks && gap_arr[cc + 1] != 0) {
-		s = tab[cc * gs + (s - lo_arr[cc])];
-		cc++;
-		start_arr[cc] = s;
+	__syncthreads();
+	if (threadIdx.x < GS) {
+		// level 1: composite of this workgroup's chunks, on the first chunk's candidates
+		const u64 first = (u64)blockIdx.x * DEEMPH_FAN;
+		const int cnt = (int)((n_chunks - first) < DEEMPH_FAN ? (n_chunks - first) : DEEMPH_FAN);
+		const int g0 = gaps[0];
+		int v = los[0] + ((int)threadIdx.x < g0 ? (int)threadIdx.x : g0);
+		for (int i = 0; i < cnt; i++)
+			v = tabs[i][v - los[i]];
+		l1_tab[(u64)blockIdx.x * GS + threadIdx.x] = v;
+		if (threadIdx.x == 0) { l1_lo[blockIdx.x] = los[0]; l1_gap[blockIdx.x] = g0; }
 	}
 }
 
-__global__ void k_fm_deemph_fix(const int16_t *__restrict__ pcm, u64 M, int a, unsigned magic, int gs, int chunk,
-                                const int *__restrict__ gap_arr, const int *__restrict__ start_arr,
-                                int16_t *__restrict__ y, rxk_fm_dev *__restrict__ dev)
+// one thread group of gs lanes per parent table: walk DEEMPH_FAN children (global, dependent)
+__global__ void k_fm_deemph_up(u64 n_child, int gs, const int *__restrict__ tab, const int *__restrict__ lo,
+                               const int *__restrict__ gap, int *__restrict__ p_tab, int *__restrict__ p_lo,
+                               int *__restrict__ p_gap)
 {
-	if (!dev->any_unmerged)
+	const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	const u64 parent = gid / gs;
+	const int k = (int)(gid % gs);
+	const u64 first = parent * DEEMPH_FAN;
+	if (first >= n_child)
 		return;
-	const u64 n_chunks = (M + chunk - 1) / chunk;
-	const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= n_chunks || gap_arr[c] == 0)
-		return;
-	const u64 c0 = c * (u64)chunk;
-	const u64 c1 = (c0 + chunk < M) ? c0 + chunk : M;
-	const int h = a / 2;
-	int s = start_arr[c];
-	for (u64 i = c0; i < c1; i++) {
-		s = deemph_step(s, pcm[i], a, h, magic);
-		y[i] = (int16_t)s;
+	const int cnt = (int)((n_child - first) < DEEMPH_FAN ? (n_child - first) : DEEMPH_FAN);
+	const int g0 = gap[first];
+	int v = lo[first] + (k < g0 ? k : g0);
+	for (int i = 0; i < cnt; i++)
+		v = tab[(first + i) * gs + (v - lo[first + i])];
+	p_tab[parent * gs + k] = v;
+	if (k == 0) { p_lo[parent] = lo[first]; p_gap[parent] = g0; }
+}
+
+// single workgroup: n tables staged in LDS, walked in sqrt(n) segments
+__global__ __launch_bounds__(1024) void k_fm_deemph_top(int n, int gs, const int *__restrict__ tab,
+                                                         const int *__restrict__ lo, const int *__restrict__ gap,
+                                                         int *__restrict__ start, rxk_fm_dev *__restrict__ dev)
+{
+	extern __shared__ __attribute__((aligned(16))) int sm[];
+	int R = 1;
+	while (R * R < n) R++;
+	const int nseg = (n + R - 1) / R;
+	int *t = sm;                      // [n][gs]
+	int *l = t + n * gs;              // [n]
+	int *g = l + n;                   // [n]
+	int *segtab = g + n;              // [nseg][gs]
+	int *segstart = segtab + nseg * gs;   // [nseg]
+	for (int i = threadIdx.x; i < n * gs; i += blockDim.x) t[i] = tab[i];
+	for (int i = threadIdx.x; i < n; i += blockDim.x) { l[i] = lo[i]; g[i] = gap[i]; }
+	__syncthreads();
+	for (int w = threadIdx.x; w < nseg * gs; w += blockDim.x) {
+		const int seg = w / gs, k = w % gs;
+		const int first = seg * R, last = min(n, first + R);
+		int v = l[first] + (k < g[first] ? k : g[first]);
+		for (int i = first; i < last; i++)
+			v = t[i * gs + (v - l[i])];
+		segtab[w] = v;
 	}
-	if (c == n_chunks - 1)
-		dev->out_deemph_avg = s;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		int s = dev->in_deemph_avg;
+		for (int seg = 0; seg < nseg; seg++) {
+			segstart[seg] = s;
+			s = segtab[seg * gs + (s - l[seg * R])];
+		}
+		dev->out_deemph_avg = s;      // state after the last sample of the run
+	}
+	__syncthreads();
+	for (int seg = threadIdx.x; seg < nseg; seg += blockDim.x) {
+		const int first = seg * R, last = min(n, first + R);
+		int s = segstart[seg];
+		for (int i = first; i < last; i++) {
+			start[i] = s;
+			s = t[i * gs + (s - l[i])];
+		}
+	}
+}
+
+// start states one level down: thread per parent walks its DEEMPH_FAN children
+__global__ void k_fm_deemph_down(u64 n_child, int gs, const int *__restrict__ tab, const int *__restrict__ lo,
+                                 const int *__restrict__ p_start, int *__restrict__ start)
+{
+	const u64 parent = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	const u64 first = parent * DEEMPH_FAN;
+	if (first >= n_child)
+		return;
+	const int cnt = (int)((n_child - first) < DEEMPH_FAN ? (n_child - first) : DEEMPH_FAN);
+	int s = p_start[parent];
+	for (int i = 0; i < cnt; i++) {
+		start[first + i] = s;
+		s = tab[(first + i) * gs + (s - lo[first + i])];
+	}
+}
+
+// every chunk replayed from its exact start state; workgroup = the same DEEMPH_FAN chunks as in
+// the scan, staged through LDS so that global traffic stays coalesced
+__global__ __launch_bounds__(256) void k_fm_deemph_apply(
+	const int16_t *__restrict__ pcm, u64 M, int a, unsigned magic, int gs, int chunk,
+	const int *__restrict__ tab, const int *__restrict__ lo_arr, const int *__restrict__ l1_start,
+	int16_t *__restrict__ y)
+{
+	extern __shared__ __attribute__((aligned(16))) int16_t xs[];      // DEEMPH_FAN * chunk samples
+	__shared__ int starts[DEEMPH_FAN];
+	const u64 n_chunks = (M + chunk - 1) / chunk;
+	const u64 first = (u64)blockIdx.x * DEEMPH_FAN;
+	const int cnt = (int)((n_chunks - first) < DEEMPH_FAN ? (n_chunks - first) : DEEMPH_FAN);
+	const u64 s0 = first * (u64)chunk;
+	const u64 s1 = (s0 + (u64)DEEMPH_FAN * chunk < M) ? s0 + (u64)DEEMPH_FAN * chunk : M;
+	const int n = (int)(s1 - s0);
+	for (int i = threadIdx.x; i < n; i += 256)
+		xs[i] = pcm[s0 + i];
+	if (threadIdx.x == 0) {
+		int s = l1_start[blockIdx.x];
+		for (int i = 0; i < cnt; i++) {
+			starts[i] = s;
+			s = tab[(first + i) * gs + (s - lo_arr[first + i])];
+		}
+	}
+	__syncthreads();
+	if ((int)threadIdx.x < cnt) {
+		const int h = a / 2;
+		int s = starts[threadIdx.x];
+		int16_t *buf = xs + threadIdx.x * chunk;
+		const int nc = min(chunk, n - (int)threadIdx.x * chunk);
+		for (int i = 0; i < nc; i++) {
+			s = deemph_step(s, buf[i], a, h, magic);
+			buf[i] = (int16_t)s;
+		}
+	}
+	__syncthreads();
+	for (int i = threadIdx.x; i < n; i += 256)
+		y[s0 + i] = xs[i];
 }
 
 __global__ void k_fm_deemph_serial(const int16_t *__restrict__ pcm, u64 M, int a, int16_t *__restrict__ y,
@@ -698,41 +783,66 @@ extern "C" int rxk_fm_disc(void *stream, const int16_t *iq, u64 T, int ds, int p
 static unsigned magic_for(int a) { return a > 1 ? (unsigned)((1ull << 32) / (unsigned)a + 1) : 0u; }
 
 extern "C" int rxk_fm_deemph_scan(void *stream, const int16_t *pcm, u64 M, int a, int group, int chunk, int warm,
-                                  int lo0, int hi0, int16_t *y, int *tab, int *lo_arr, int *gap_arr, rxk_fm_dev *dev)
+                                  int lo0, int hi0, int *tab, int *lo_arr, int *gap_arr, int *l1_tab, int *l1_lo,
+                                  int *l1_gap, rxk_fm_dev *dev)
 {
 	if (!M)
 		return 0;
 	const u64 n_chunks = (M + chunk - 1) / chunk;
-	const int groups = 256 / group;
-	const unsigned grid = (unsigned)((n_chunks + groups - 1) / groups);
-	const size_t shm = (size_t)groups * (warm + chunk) * sizeof(int16_t);
+	const unsigned grid = (unsigned)((n_chunks + DEEMPH_FAN - 1) / DEEMPH_FAN);
+	const size_t shm = (size_t)DEEMPH_FAN * (warm + chunk) * sizeof(int16_t);
 	hipStream_t s = (hipStream_t)stream;
 	if (group == 16)
-		hipLaunchKernelGGL((k_fm_deemph_scan<16>), dim3(grid), dim3(256), shm, s, pcm, M, a, magic_for(a), chunk, warm, lo0, hi0, y, tab, lo_arr, gap_arr, dev);
+		hipLaunchKernelGGL((k_fm_deemph_scan<16>), dim3(grid), dim3(DEEMPH_FAN * 16), shm, s, pcm, M, a, magic_for(a), chunk, warm,
+		                   lo0, hi0, tab, lo_arr, gap_arr, l1_tab, l1_lo, l1_gap, dev);
 	else
-		hipLaunchKernelGGL((k_fm_deemph_scan<64>), dim3(grid), dim3(256), shm, s, pcm, M, a, magic_for(a), chunk, warm, lo0, hi0, y, tab, lo_arr, gap_arr, dev);
+		hipLaunchKernelGGL((k_fm_deemph_scan<64>), dim3(grid), dim3(DEEMPH_FAN * 64), shm, s, pcm, M, a, magic_for(a), chunk, warm,
+		                   lo0, hi0, tab, lo_arr, gap_arr, l1_tab, l1_lo, l1_gap, dev);
 	LAUNCH_RET();
 }
 
-extern "C" int rxk_fm_deemph_resolve(void *stream, u64 n_chunks, int group, const int *tab, const int *lo_arr,
-                                     const int *gap_arr, int *start_arr, rxk_fm_dev *dev)
+extern "C" int rxk_fm_deemph_up(void *stream, u64 n_child, int group, const int *tab, const int *lo, const int *gap,
+                                int *p_tab, int *p_lo, int *p_gap)
 {
-	if (!n_chunks)
-		return 0;
-	hipLaunchKernelGGL(k_fm_deemph_resolve, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-	                   n_chunks, group, tab, lo_arr, gap_arr, start_arr, dev);
+	const u64 parents = (n_child + DEEMPH_FAN - 1) / DEEMPH_FAN;
+	const u64 threads = parents * group;
+	hipLaunchKernelGGL(k_fm_deemph_up, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+	                   n_child, group, tab, lo, gap, p_tab, p_lo, p_gap);
 	LAUNCH_RET();
 }
 
-extern "C" int rxk_fm_deemph_fix(void *stream, const int16_t *pcm, u64 M, int a, int group, int chunk, const int *tab,
-                                 const int *lo_arr, const int *gap_arr, const int *start_arr, int16_t *y, rxk_fm_dev *dev)
+extern "C" int rxk_fm_deemph_top(void *stream, int n, int group, const int *tab, const int *lo, const int *gap,
+                                 int *start, rxk_fm_dev *dev)
 {
-	(void)tab; (void)lo_arr;
+	int R = 1;
+	while (R * R < n) R++;
+	const int nseg = (n + R - 1) / R;
+	const size_t shm = ((size_t)n * group + 2 * (size_t)n + (size_t)nseg * group + nseg) * sizeof(int);
+	if (shm > 64 * 1024)
+		(void)hipFuncSetAttribute((const void *)k_fm_deemph_top, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+	hipLaunchKernelGGL(k_fm_deemph_top, dim3(1), dim3(1024), shm, (hipStream_t)stream, n, group, tab, lo, gap, start, dev);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_fm_deemph_down(void *stream, u64 n_child, int group, const int *tab, const int *lo,
+                                  const int *p_start, int *start)
+{
+	const u64 parents = (n_child + DEEMPH_FAN - 1) / DEEMPH_FAN;
+	hipLaunchKernelGGL(k_fm_deemph_down, dim3((unsigned)((parents + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+	                   n_child, group, tab, lo, p_start, start);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_fm_deemph_apply(void *stream, const int16_t *pcm, u64 M, int a, int group, int chunk, const int *tab,
+                                   const int *lo_arr, const int *l1_start, int16_t *y)
+{
 	if (!M)
 		return 0;
 	const u64 n_chunks = (M + chunk - 1) / chunk;
-	hipLaunchKernelGGL(k_fm_deemph_fix, dim3((unsigned)((n_chunks + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
-	                   pcm, M, a, magic_for(a), group, chunk, gap_arr, start_arr, y, dev);
+	const unsigned grid = (unsigned)((n_chunks + DEEMPH_FAN - 1) / DEEMPH_FAN);
+	const size_t shm = (size_t)DEEMPH_FAN * chunk * sizeof(int16_t);
+	hipLaunchKernelGGL(k_fm_deemph_apply, dim3(grid), dim3(256), shm, (hipStream_t)stream, pcm, M, a, magic_for(a), group, chunk,
+	                   tab, lo_arr, l1_start, y);
 	LAUNCH_RET();
 }
 

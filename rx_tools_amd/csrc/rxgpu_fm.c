@@ -12,7 +12,9 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define DEEMPH_CHUNK 256
+#define DEEMPH_CHUNK 128
+#define DEEMPH_LEVELS 8
+#define DEEMPH_TOPCAP(group) ((group) == 16 ? 2048 : 512)   /* tables the single-workgroup top walk stages in LDS */
 
 struct rxgpu_fm_stream {
 	rxgpu_fm_params p;
@@ -23,7 +25,9 @@ struct rxgpu_fm_stream {
 	uint32_t *lp_raw, *lp, *head, *tail;
 	uint32_t *cas[2];                    /* fifth_order ping-pong */
 	int16_t *pcm, *y;
-	int *tab, *lo_arr, *gap_arr, *start_arr;
+	int *tab, *lo_arr, *gap_arr;          /* level 0: one table per chunk */
+	int *lvl_tab, *lvl_lo, *lvl_gap, *lvl_start;   /* levels >= 1, packed back to back */
+	size_t lvl_cap;
 	unsigned long long *flag_list;
 	rxk_fm_dev *dev;
 	int16_t *hist_dev;                   /* [10][12] cascade hist in, [10][12] out, [18] droop in, [18] out */
@@ -37,6 +41,7 @@ struct rxgpu_fm_stream {
 	size_t stage_in_cap, stage_out_cap;
 	/* de-emphasis geometry */
 	int group, warm, lo0, hi0;
+	int topcap_override;                 /* $RXGPU_DEEMPH_TOPCAP: forces the multi-level scan (tests) */
 	long fixups;
 };
 
@@ -114,6 +119,10 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 	if (!s)
 		return rxgpu_fail(RXGPU_ENOMEM, "out of host memory");
 	s->p = *params;
+	{
+		const char *e = getenv("RXGPU_DEEMPH_TOPCAP");
+		s->topcap_override = (e && atoi(e) > 0) ? atoi(e) : 0;
+	}
 	s->max_blocks = max_blocks;
 	s->block_len = block_len;
 	s->max_T = max_blocks * (block_len / 2);
@@ -134,7 +143,11 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 	DMALLOC(s->tab, n_chunks * 64 * 4);
 	DMALLOC(s->lo_arr, n_chunks * 4);
 	DMALLOC(s->gap_arr, n_chunks * 4);
-	DMALLOC(s->start_arr, n_chunks * 4);
+	s->lvl_cap = n_chunks / RXK_DEEMPH_FAN + n_chunks / (RXK_DEEMPH_FAN * (RXK_DEEMPH_FAN - 1)) + 2 * DEEMPH_LEVELS + 2;
+	DMALLOC(s->lvl_tab, s->lvl_cap * 64 * 4);
+	DMALLOC(s->lvl_lo, s->lvl_cap * 4);
+	DMALLOC(s->lvl_gap, s->lvl_cap * 4);
+	DMALLOC(s->lvl_start, s->lvl_cap * 4);
 	DMALLOC(s->flag_list, RXK_FLAG_CAP * 8);
 	DMALLOC(s->dev, sizeof(rxk_fm_dev));
 	DMALLOC(s->hist_dev, HIST_TOTAL * 2);
@@ -161,7 +174,8 @@ void rxgpu_fm_stream_destroy(rxgpu_fm_stream *s)
 	hipFree(s->lp_raw); hipFree(s->lp); hipFree(s->head); hipFree(s->tail);
 	hipFree(s->cas[0]); hipFree(s->cas[1]);
 	hipFree(s->pcm); hipFree(s->y);
-	hipFree(s->tab); hipFree(s->lo_arr); hipFree(s->gap_arr); hipFree(s->start_arr);
+	hipFree(s->tab); hipFree(s->lo_arr); hipFree(s->gap_arr);
+	hipFree(s->lvl_tab); hipFree(s->lvl_lo); hipFree(s->lvl_gap); hipFree(s->lvl_start);
 	hipFree(s->flag_list); hipFree(s->dev); hipFree(s->hist_dev); hipFree(s->fir_dev);
 	if (s->dev_host) hipHostFree(s->dev_host);
 	if (s->hist_host) hipHostFree(s->hist_host);
@@ -209,12 +223,31 @@ static int run_audio_stages(rxgpu_fm_stream *s, unsigned long long M, unsigned l
 	if (p->deemph && M) {
 		rxgpu_prof_begin("fm_deemph");
 		if (s->group) {
-			unsigned long long n_chunks = (M + DEEMPH_CHUNK - 1) / DEEMPH_CHUNK;
-			RX_K(rxk_fm_deemph_scan(st, s->pcm, M, p->deemph_a, s->group, DEEMPH_CHUNK, s->warm, s->lo0, s->hi0,
-			                        deemph_dst, s->tab, s->lo_arr, s->gap_arr, s->dev));
-			RX_K(rxk_fm_deemph_resolve(st, n_chunks, s->group, s->tab, s->lo_arr, s->gap_arr, s->start_arr, s->dev));
-			RX_K(rxk_fm_deemph_fix(st, s->pcm, M, p->deemph_a, s->group, DEEMPH_CHUNK, s->tab, s->lo_arr, s->gap_arr,
-			                       s->start_arr, deemph_dst, s->dev));
+			/* tree scan over chunk maps: level 0 = chunks, level l+1 = composites of RXK_DEEMPH_FAN level-l tables */
+			const int g = s->group;
+			unsigned long long cnt[DEEMPH_LEVELS + 1], off[DEEMPH_LEVELS + 1];
+			int top = 1;
+			cnt[0] = (M + DEEMPH_CHUNK - 1) / DEEMPH_CHUNK;
+			cnt[1] = (cnt[0] + RXK_DEEMPH_FAN - 1) / RXK_DEEMPH_FAN;
+			off[1] = 0;
+			RX_K(rxk_fm_deemph_scan(st, s->pcm, M, p->deemph_a, g, DEEMPH_CHUNK, s->warm, s->lo0, s->hi0,
+			                        s->tab, s->lo_arr, s->gap_arr, s->lvl_tab, s->lvl_lo, s->lvl_gap, s->dev));
+			const unsigned long long topcap = s->topcap_override ? (unsigned long long)s->topcap_override : (unsigned long long)DEEMPH_TOPCAP(g);
+			while (cnt[top] > topcap) {
+				if (top == DEEMPH_LEVELS)
+					return rxgpu_fail(RXGPU_EUNSUPPORTED, "de-emphasis scan deeper than %d levels", DEEMPH_LEVELS);
+				cnt[top + 1] = (cnt[top] + RXK_DEEMPH_FAN - 1) / RXK_DEEMPH_FAN;
+				off[top + 1] = off[top] + cnt[top];
+				RX_K(rxk_fm_deemph_up(st, cnt[top], g, s->lvl_tab + off[top] * g, s->lvl_lo + off[top], s->lvl_gap + off[top],
+				                      s->lvl_tab + off[top + 1] * g, s->lvl_lo + off[top + 1], s->lvl_gap + off[top + 1]));
+				top++;
+			}
+			RX_K(rxk_fm_deemph_top(st, (int)cnt[top], g, s->lvl_tab + off[top] * g, s->lvl_lo + off[top], s->lvl_gap + off[top],
+			                       s->lvl_start + off[top], s->dev));
+			for (int l = top; l > 1; l--)
+				RX_K(rxk_fm_deemph_down(st, cnt[l - 1], g, s->lvl_tab + off[l - 1] * g, s->lvl_lo + off[l - 1],
+				                        s->lvl_start + off[l], s->lvl_start + off[l - 1]));
+			RX_K(rxk_fm_deemph_apply(st, s->pcm, M, p->deemph_a, g, DEEMPH_CHUNK, s->tab, s->lo_arr, s->lvl_start, deemph_dst));
 		} else {
 			RX_K(rxk_fm_deemph_serial(st, s->pcm, M, p->deemph_a, deemph_dst, s->dev));
 		}

@@ -121,9 +121,17 @@ static hipEvent_t prof_event(void)
 
 void rxgpu_prof_enable(int on) { g_prof_on = on; }
 
+/* level 1 times only the kernels that dominate each path, level 2 everything */
+static int prof_wanted(const char *name)
+{
+	if (g_prof_on >= 2)
+		return 1;
+	return !strcmp(name, "fm_decimate") || !strcmp(name, "pw_fft") || !strcmp(name, "fm_fifth");
+}
+
 void rxgpu_prof_begin(const char *name)
 {
-	if (!g_prof_on || g_npend == PROF_PENDING)
+	if (!g_prof_on || g_npend == PROF_PENDING || !prof_wanted(name))
 		return;
 	struct prof_pair *p = &g_pend[g_npend];
 	p->slot = prof_slot(name);
@@ -136,8 +144,7 @@ void rxgpu_prof_begin(const char *name)
 
 void rxgpu_prof_end(const char *name)
 {
-	(void)name;
-	if (!g_prof_on || g_npend == PROF_PENDING)
+	if (!g_prof_on || g_npend == PROF_PENDING || !prof_wanted(name))
 		return;
 	struct prof_pair *p = &g_pend[g_npend];
 	if (p->slot < 0 || !p->a)

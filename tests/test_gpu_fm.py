@@ -104,6 +104,16 @@ def test_fifth_order_carry_across_runs():
     _check(iq, 16384, n_runs=3, downsample_passes=3, comp_fir_size=9)
 
 
+@pytest.mark.parametrize("topcap", ["1", "3"])
+def test_deemph_multi_level_tree(topcap, monkeypatch):
+    """forces the up/down levels of the de-emphasis tree scan (normally only for >4M audio samples)"""
+    monkeypatch.setenv("RXGPU_DEEMPH_TOPCAP", topcap)
+    for sig in ("fm", "zeros", "noise_small"):
+        iq = _signals(40 * 16384)[sig]
+        _check(iq, 16384, downsample=4)
+        _check(iq, 16384, downsample=4, deemph_a=33)
+
+
 def test_scale_formula_exhaustive_on_device():
     """F0 on the device for all 65536 int16 values == the reference's fp64 expression"""
     from gpu_support import gpu_fm_stream
