@@ -210,9 +210,8 @@ def main():
         plan = R.plan_range("24M:1.7G:1k", 0.0, 1)
         n = 1 << plan.bin_e
         total_tunes = plan.tune_count
-        per = (total_tunes + world - 1) // world                  # contiguous tune ranges, SURVEY section 8(e)
-        lo = min(total_tunes, rank * per)
-        mine = min(total_tunes, lo + per) - lo
+        from rx_tools_amd import shard
+        lo, mine, per = shard.tune_range(rank, world, total_tunes)   # contiguous tune ranges, SURVEY section 8(e)
         passes = args.passes
         wc, sw = R.window_coefs("rectangle", n), R.sine_table(plan.bin_e)
         ps = R.PowerScan(R.PowerParams(plan.bin_e, plan.buf_len, plan.downsample, plan.downsample_passes, 1, 0, 0),
@@ -222,7 +221,6 @@ def main():
         d_in = torch.randint(-100, 101, (passes, max(mine, 1), plan.buf_len), dtype=torch.int16, device=dev, generator=g)
         d_avg = torch.zeros((per, n), dtype=torch.int64, device=dev)        # padded to `per` rows for the gather
         d_smp = torch.zeros(per, dtype=torch.int32, device=dev)
-        gathered = [torch.zeros_like(d_avg) for _ in range(world)] if (world > 1 and rank == 0) else None
 
         def step():
             if mine:
@@ -230,7 +228,7 @@ def main():
             if world > 1:
                 # order the gather (torch's stream) after the scan (librxgpu's stream)
                 L.rxgpu_sync()
-                dist.gather(d_avg, gathered, dst=0)
+                shard.gather_rows(d_avg, dst=0)
 
         for _ in range(args.warmup):
             step()

@@ -1,0 +1,62 @@
+"""CPU: host-side logic of librxgpu (range planner, tables, csv_dbm) against golden vectors
+generated from the reference and against the oracle."""
+import ast
+import ctypes as C
+import os
+
+import numpy as np
+
+import rx_tools_amd as R
+from rx_tools_amd.structs import TuningState
+from support import GOLDEN_DIR, oracle, ptr16, ptr32, ptr64
+
+
+def test_plan_range_matches_reference_frequency_range():
+    rows = np.load(os.path.join(GOLDEN_DIR, "plans.npz"))["rows"]
+    assert len(rows) >= 8
+    for r in rows:
+        rng, crop, boxcar, n, bin_e, buf_len, ds, ds_p, rate, f0, df, crop_out = ast.literal_eval(str(r))
+        p = R.plan_range(rng, crop, boxcar)
+        assert (p.tune_count, p.bin_e, p.buf_len, p.downsample, p.downsample_passes, p.rate) == (n, bin_e, buf_len, ds, ds_p, rate), rng
+        assert p.first_freq == f0 and (n == 1 or p.bw_seen == df) and p.crop == crop_out, rng
+
+
+def test_config3_geometry():
+    p = R.plan_range("24M:1.7G:1k")
+    assert (p.tune_count, p.rate, p.bin_e, p.downsample, p.buf_len) == (599, 2797996, 12, 1, 16384)
+
+
+def test_tables_match_oracle():
+    O = oracle()
+    for e in (0, 1, 3, 5, 12, 14):
+        n = 1 << e
+        want = np.zeros(max(1, n * 3 // 4), np.int16)
+        O.rxo_sine_table(e, ptr16(want))
+        assert np.array_equal(R.sine_table(e)[:n * 3 // 4], want[:n * 3 // 4])
+    for w in ("rectangle", "hamming", "blackman", "blackman-harris", "hann-poisson", "youssef", "kaiser", "bartlett"):
+        for n in (2, 32, 4096):
+            want = np.zeros(n, np.int32)
+            O.rxo_window_coefs(w.encode(), n, ptr32(want))
+            assert np.array_equal(R.window_coefs(w, n), want), (w, n)
+
+
+def test_csv_dbm_matches_reference_rows(tmp_path):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+    from gen_golden import POWER_CASES
+    z = np.load(os.path.join(GOLDEN_DIR, "power_cases.npz"))
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fclose.argtypes = [C.c_void_p]
+    for name, *_ in POWER_CASES:
+        bin_e, buf_len, ds, ds_p, rate, _n = map(int, z[name + "__meta"])
+        avg = z[name + "__avg"].copy()
+        path = str(tmp_path / (name + ".csv"))
+        f = libc.fopen(path.encode(), b"wb")
+        for t in range(avg.shape[0]):
+            ts = TuningState(int(z[name + "__freqs"][t]), rate, bin_e, ptr64(avg[t]), int(z[name + "__samples"][t]), ds, ds_p,
+                             float(z[name + "__crop"][0]), None, buf_len)
+            R.lib().rxgpu_csv_dbm(C.byref(ts), f)
+            assert ts.samples == 0 and not avg[t].any()
+        libc.fclose(f)
+        assert open(path).read().splitlines() == [str(r) for r in z[name + "__csv"]], name

@@ -1,0 +1,83 @@
+"""CPU, this container only: the oracle restatement against the reference's own code compiled
+unmodified (oracle/_ref), on seeded random and adversarial inputs beyond the golden fixtures."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from support import (have_ref, ref_fm, ref_power, oracle, ref_fm_stream, oracle_fm_stream, sig_fm, sig_noise,
+                     sig_alternating, PowerCfg, ptr16, ptr32, ptr64)
+
+pytestmark = [pytest.mark.ref, pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built (needs /root/reference)")]
+
+
+@pytest.mark.parametrize("params", [
+    dict(downsample=6), dict(downsample=118), dict(downsample=5, rate_out=240000, deemph_a=19),
+    dict(downsample_passes=3), dict(downsample_passes=3, comp_fir_size=9), dict(downsample_passes=7),
+    dict(downsample=9, custom_atan=0), dict(downsample=118, offset_tuning=1), dict(downsample=6, mute=4096),
+])
+def test_fm_stream_matches_reference(params):
+    L = ref_fm()
+    sigs = [sig_fm(4 * 8192), sig_noise(8 * 8192), sig_alternating(8 * 8192), np.zeros(8 * 8192, np.int16)]
+    for iq in sigs:
+        for bl in (8192, 16384, 4096 + 8):
+            if params.get("downsample_passes") and (bl // 2) % (1 << params["downsample_passes"]):
+                continue
+            a, la, d = ref_fm_stream(L, iq, bl, **params)
+            b, lb, st = oracle_fm_stream(iq, bl, **params)
+            assert np.array_equal(a, b) and np.array_equal(la, lb)
+            assert (d.now_r, d.now_j, d.prev_index, d.pre_r, d.pre_j, d.now_lpr, d.prev_lpr_index) == \
+                (st.now_r, st.now_j, st.prev_index, st.pre_r, st.pre_j, st.now_lpr, st.prev_lpr_index)
+
+
+def test_struct_layout_matches_reference():
+    from rx_tools_amd.structs import DemodState, DongleState, TuningState
+    L, P = ref_fm(), ref_power()
+    assert C.sizeof(DemodState) == L.ref_fm_sizeof_demod_state() == 1049160
+    assert C.sizeof(DongleState) == L.ref_fm_sizeof_dongle_state()
+    assert C.sizeof(TuningState) == P.ref_power_sizeof_tuning_state()
+    names = ['lowpassed', 'lp_len', 'lp_i_hist', 'result', 'result_len', 'rate_in', 'now_r', 'downsample', 'deemph',
+             'now_lpr', 'mode_demod', 'rw', 'output_target', 'droop_i_hist', 'dc_block_audio']
+    for i, n in enumerate(names):
+        assert getattr(DemodState, n).offset == L.ref_fm_offsetof(i), n
+    for i, n in zip((15, 16, 17, 18), ('buf16', 'mute', 'demod_target', 'offset_tuning')):
+        assert getattr(DongleState, n).offset == L.ref_fm_offsetof(i), n
+
+
+@pytest.mark.parametrize("rng,crop,window,flags,amp,passes", [
+    ("88M:108M:125k", 0.0, "rectangle", (1, 0, 0), 100, 2),
+    ("88M:108M:125k", 0.2, "blackman-harris", (1, 0, 1), 3000, 2),
+    ("100M:100.1M:100", 0.0, "rectangle", (1, 0, 0), 2000, 1),
+    ("100M:100.1M:100", 0.0, "youssef", (0, 9, 0), 2000, 1),
+    ("100M:101M:1k", 0.0, "bartlett", (1, 0, 0), 500, 2),
+    ("100M:110M:1M", 0.0, "rectangle", (1, 0, 1), 5000, 2),
+    ("24M:50M:1k", 0.0, "hann-poisson", (1, 0, 0), 32768, 1),
+])
+def test_power_scan_matches_reference(rng, crop, window, flags, amp, passes, capfd):
+    from rx_tools_amd.structs import TuningState
+    P, O = ref_power(), oracle()
+    P.ref_power_set_flags(*flags)
+    n = P.ref_power_setup(rng.encode(), crop, window.encode())
+    tunes = (TuningState * n).from_address(P.ref_power_tunes())
+    t0 = tunes[0]
+    buf_len, N = t0.buf_len, 1 << t0.bin_e
+    data = sig_noise(passes * n * buf_len, seed=777, amp=amp)
+    P.ref_power_scan(ptr16(data), passes)
+    ref_avg = np.stack([np.ctypeslib.as_array(tunes[i].avg, (N,)).copy() for i in range(n)])
+    ref_samples = [tunes[i].samples for i in range(n)]
+    sw = np.zeros(max(1, N * 3 // 4), np.int16)
+    O.rxo_sine_table(t0.bin_e, ptr16(sw))
+    wc = np.zeros(N, np.int32)
+    O.rxo_window_coefs(window.encode(), N, ptr32(wc))
+    assert np.array_equal(wc, np.ctypeslib.as_array(P.ref_power_window_coefs(), (N,)))
+    cfg = PowerCfg(t0.bin_e, buf_len, t0.downsample, t0.downsample_passes, flags[0], flags[1], flags[2], ptr32(wc), ptr16(sw))
+    avg = np.zeros((n, N), np.int64)
+    samples = np.zeros(n, np.int32)
+    work = np.zeros(buf_len, np.int16)
+    d3 = data.reshape(passes, n, buf_len)
+    for p in range(passes):
+        for i in range(n):
+            s = C.c_int(int(samples[i]))
+            O.rxo_power_tune(C.byref(cfg), ptr16(np.ascontiguousarray(d3[p, i])), ptr16(work), ptr64(avg[i]), C.byref(s))
+            samples[i] = s.value
+    assert np.array_equal(avg, ref_avg) and list(samples) == ref_samples
