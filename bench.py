@@ -4,7 +4,7 @@
 Headline (`value`): complex IQ MSample/s through the rx_fm callback pre-stage + full_demod()
 chain at the "20 Msps" WBFM geometry of BASELINE config 2 (downsample=118 -> 170 ksps ->
 32 ksps audio, -A fast, de-emphasis on), blocks of 131072 complex samples, input resident in
-HBM.  One step = one rxgpu_fm_stream_run over --blocks blocks (default 2048 = 1 GiB of cs16).
+HBM.  One step = one rxgpu_fm_stream_run over --blocks blocks (default 8192 = 2^30 samples = 4 GiB of cs16).
 The same JSON line carries, under "rx_power", FFT bins/s of the scanner() chain at the
 config-3 geometry (-f 24M:1.7G:1k: 599 tunes x 16384 int16, N=4096), tunes sharded across the
 ranks with one RCCL gather of the avg[] rows to rank 0 per step.
@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--blocks", type=int, default=2048, help="rx_fm blocks of 131072 complex samples per step")
+    ap.add_argument("--blocks", type=int, default=8192, help="rx_fm blocks of 131072 complex samples per step (8192 = 4 GiB of cs16)")
     ap.add_argument("--passes", type=int, default=128, help="rx_power scanner() passes per step")
     ap.add_argument("--workload", default="both", choices=["both", "rx_fm", "rx_power"])
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU baseline budget per path (0 = skip)")

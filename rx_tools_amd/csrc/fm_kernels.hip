@@ -236,10 +236,12 @@ __device__ __forceinline__ uint32_t lp_final(u64 m, int ds, int p0, int seams, c
 {
 	if (!seams)
 		return lp_raw[m];
-	const u64 e1 = (m + 1) * (u64)ds - (u64)p0 - 1;          // stream position of the window's last sample
-	const u64 g = e1 >> RXK_DEC_SPAN_LOG2;
-	const u64 mb = ((g << RXK_DEC_SPAN_LOG2) + (u64)p0) / (u64)ds;
-	if (mb == m)
+	// window m covers stream samples [m*ds - p0, (m+1)*ds - p0); it is the one the decimator left
+	// in head/tail form iff it is the first window ENDING inside its workgroup span, i.e. iff it
+	// starts at or before that span's first sample
+	const i64 w0 = (i64)(m * (u64)ds) - (i64)p0;
+	const u64 g = ((u64)(w0 + ds - 1)) >> RXK_DEC_SPAN_LOG2;
+	if (w0 <= (i64)(g << RXK_DEC_SPAN_LOG2))
 		return pk_add(g ? tail[g - 1] : carry, head[g]);
 	return lp_raw[m];
 }
@@ -294,13 +296,16 @@ __global__ __launch_bounds__(256) void k_fm_disc(
 	const int cr = (int)((unsigned)ar * (unsigned)br + (unsigned)aj * (unsigned)bj);
 	const int cj = (int)((unsigned)aj * (unsigned)br - (unsigned)ar * (unsigned)bj);
 
+	// first output of a callback block (rtl_fm.c:588-590)?
 	bool first;
 	if (first_mode == RXK_FIRST_UNIFORM) {
-		first = (m % uniform_k) == 0;
+		first = (uniform_k & (uniform_k - 1)) ? (m % uniform_k) == 0 : (m & (uniform_k - 1)) == 0;
 	} else {
-		const u64 e1 = (m + 1) * (u64)ds - (u64)p0 - 1;
-		const u64 b = e1 / n_per_block;
-		first = ((b * n_per_block + (u64)p0) / (u64)ds) == m;
+		// the window ends in block b; it is that block's first iff it starts at or before the block
+		const i64 w0 = (i64)(m * (u64)ds) - (i64)p0;
+		const u64 e1 = (u64)(w0 + ds - 1);
+		const u64 b = (n_per_block & (n_per_block - 1)) ? e1 / n_per_block : e1 >> (63 - __clzll((long long)n_per_block));
+		first = w0 <= (i64)(b * n_per_block);
 	}
 	int out;
 	if (first || custom_atan == 0) {
@@ -334,6 +339,22 @@ __device__ __forceinline__ int deemph_step(int avg, int x, int a, int h, unsigne
 	return avg + (d < 0 ? -(int)q : (int)q);
 }
 
+// The same map with the sign handling folded into one biased unsigned division:
+//   d > 0 : floor((d + h) / a)            d <= 0 : -floor((-d + h) / a) = floor((d - h + a - 1) / a)
+// and a - 1 - h == h for odd a, h - 1 for even a.  With xb = x + h + bias*a staged once per sample,
+//   avg' = avg + floor((xb - avg - (EVEN && x <= avg)) / a) - bias,
+// 3 VALU ops per sample for odd a (13 at 170 kHz / 75 us, 19 at 240 kHz, 9 for 50 us).
+// Valid for int16 x and avg (rxgpu_fm.c sends anything else to the serial kernel): the dividend is
+// in [0, 2^18) and magic = floor(2^32/a) + 1 is exact there for a < 2^14.
+template <bool EVEN>
+__device__ __forceinline__ int deemph_step_b(int avg, int xb, int x, unsigned magic, int bias)
+{
+	unsigned t = (unsigned)(xb - avg);
+	if (EVEN)
+		t -= (x <= avg) ? 1u : 0u;
+	return avg + (int)__umulhi(t, magic) - bias;
+}
+
 // The recurrence is a non-linear integer IIR, but the per-sample map avg -> avg' is monotone
 // with slope 0 or 1.  So (1) trajectories started from the two ends of the possible state
 // range sandwich the true one, and their gap shrinks by at least floor(gap/a) per sample:
@@ -349,36 +370,35 @@ __device__ __forceinline__ int deemph_step(int avg, int x, int a, int h, unsigne
 //   k_fm_deemph_apply  every chunk replayed once from its exact start state -> output
 #define DEEMPH_FAN 16
 
-template <int GS>
+template <int GS, bool EVEN>
 __global__ __launch_bounds__(DEEMPH_FAN * GS) void k_fm_deemph_scan(
-	const int16_t *__restrict__ pcm, u64 M, int a, unsigned magic, int chunk, int warm, int lo0, int hi0,
-	int *__restrict__ tab, int *__restrict__ lo_arr, int *__restrict__ gap_arr,
-	int *__restrict__ l1_tab, int *__restrict__ l1_lo, int *__restrict__ l1_gap, rxk_fm_dev *__restrict__ dev)
+	const int16_t *__restrict__ pcm, u64 M, int a, unsigned magic, int bias, int chunk, int warm, int lo0, int hi0,
+	int *__restrict__ pre, int *__restrict__ l1_tab, int *__restrict__ l1_lo, int *__restrict__ l1_gap,
+	rxk_fm_dev *__restrict__ dev)
 {
-	extern __shared__ __attribute__((aligned(16))) int16_t xs[];
+	extern __shared__ __attribute__((aligned(16))) int xs[];      // per group: warm + chunk biased samples
 	__shared__ int tabs[DEEMPH_FAN][GS];
 	__shared__ int los[DEEMPH_FAN], gaps[DEEMPH_FAN];
 	const int grp = threadIdx.x / GS, k = threadIdx.x % GS;
 	const u64 n_chunks = (M + chunk - 1) / chunk;
 	const u64 c = (u64)blockIdx.x * DEEMPH_FAN + grp;
-	const bool valid = c < n_chunks;
-	if (valid) {
-		int16_t *buf = xs + (size_t)grp * (warm + chunk);
+	if (c < n_chunks) {
+		int *buf = xs + (size_t)grp * (warm + chunk);
 		const u64 c0 = c * (u64)chunk;
 		const bool exact = c0 <= (u64)warm;           // the run's carried state is in reach
 		const u64 ws = exact ? 0 : c0 - warm;
 		const u64 c1 = (c0 + chunk < M) ? c0 + chunk : M;
 		const int nw = (int)(c0 - ws), nc = (int)(c1 - c0);
+		const int xoff = a / 2 + bias * a;
 		for (int i = k; i < nw + nc; i += GS)
-			buf[i] = pcm[ws + i];
+			buf[i] = (int)pcm[ws + i] + xoff;
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		const int h = a / 2;
 		int s = exact ? dev->in_deemph_avg : (k == 0 ? lo0 : hi0);
 		for (int i = 0; i < nw; i++)
-			s = deemph_step(s, buf[i], a, h, magic);
-		const int base = (threadIdx.x & 63) - (GS == 64 ? (threadIdx.x & 63) : k);   // group's first lane in its wave
+			s = deemph_step_b<EVEN>(s, buf[i], buf[i] - xoff, magic, bias);
+		const int base = (threadIdx.x & 63) - (GS == 64 ? (int)(threadIdx.x & 63) : k);   // group's first lane in its wave
 		const int lo = __shfl(s, base), hi = __shfl(s, base + 1);
 		int gap = exact ? 0 : hi - lo;
 		if (gap >= GS) {                              // excluded by `warm` (rxgpu_fm.c); checked anyway
@@ -387,23 +407,22 @@ __global__ __launch_bounds__(DEEMPH_FAN * GS) void k_fm_deemph_scan(
 		}
 		s = lo + (k < gap ? k : gap);
 		for (int i = 0; i < nc; i++)
-			s = deemph_step(s, buf[nw + i], a, h, magic);
+			s = deemph_step_b<EVEN>(s, buf[nw + i], buf[nw + i] - xoff, magic, bias);
 		tabs[grp][k] = s;
-		tab[c * GS + k] = s;
-		if (k == 0) {
-			los[grp] = lo; gaps[grp] = gap;
-			lo_arr[c] = lo; gap_arr[c] = gap;
-		}
+		if (k == 0) { los[grp] = lo; gaps[grp] = gap; }
 	}
 	__syncthreads();
 	if (threadIdx.x < GS) {
-		// level 1: composite of this workgroup's chunks, on the first chunk's candidates
+		// level 1: composite of this workgroup's chunks on the first chunk's candidates; on the way,
+		// pre[c][k] = state at the start of chunk c for candidate k (what k_fm_deemph_apply needs)
 		const u64 first = (u64)blockIdx.x * DEEMPH_FAN;
 		const int cnt = (int)((n_chunks - first) < DEEMPH_FAN ? (n_chunks - first) : DEEMPH_FAN);
 		const int g0 = gaps[0];
 		int v = los[0] + ((int)threadIdx.x < g0 ? (int)threadIdx.x : g0);
-		for (int i = 0; i < cnt; i++)
+		for (int i = 0; i < cnt; i++) {
+			pre[(first + i) * GS + threadIdx.x] = v;
 			v = tabs[i][v - los[i]];
+		}
 		l1_tab[(u64)blockIdx.x * GS + threadIdx.x] = v;
 		if (threadIdx.x == 0) { l1_lo[blockIdx.x] = los[0]; l1_gap[blockIdx.x] = g0; }
 	}
@@ -492,42 +511,35 @@ __global__ void k_fm_deemph_down(u64 n_child, int gs, const int *__restrict__ ta
 
 // every chunk replayed from its exact start state; workgroup = the same DEEMPH_FAN chunks as in
 // the scan, staged through LDS so that global traffic stays coalesced
+template <bool EVEN>
 __global__ __launch_bounds__(256) void k_fm_deemph_apply(
-	const int16_t *__restrict__ pcm, u64 M, int a, unsigned magic, int gs, int chunk,
-	const int *__restrict__ tab, const int *__restrict__ lo_arr, const int *__restrict__ l1_start,
+	const int16_t *__restrict__ pcm, u64 M, int a, unsigned magic, int bias, int gs, int chunk,
+	const int *__restrict__ pre, const int *__restrict__ l1_lo, const int *__restrict__ l1_start,
 	int16_t *__restrict__ y)
 {
-	extern __shared__ __attribute__((aligned(16))) int16_t xs[];      // DEEMPH_FAN * chunk samples
-	__shared__ int starts[DEEMPH_FAN];
+	extern __shared__ __attribute__((aligned(16))) int xs[];          // DEEMPH_FAN * chunk samples
 	const u64 n_chunks = (M + chunk - 1) / chunk;
 	const u64 first = (u64)blockIdx.x * DEEMPH_FAN;
 	const int cnt = (int)((n_chunks - first) < DEEMPH_FAN ? (n_chunks - first) : DEEMPH_FAN);
 	const u64 s0 = first * (u64)chunk;
 	const u64 s1 = (s0 + (u64)DEEMPH_FAN * chunk < M) ? s0 + (u64)DEEMPH_FAN * chunk : M;
 	const int n = (int)(s1 - s0);
+	const int xoff = a / 2 + bias * a;
 	for (int i = threadIdx.x; i < n; i += 256)
-		xs[i] = pcm[s0 + i];
-	if (threadIdx.x == 0) {
-		int s = l1_start[blockIdx.x];
-		for (int i = 0; i < cnt; i++) {
-			starts[i] = s;
-			s = tab[(first + i) * gs + (s - lo_arr[first + i])];
-		}
-	}
+		xs[i] = (int)pcm[s0 + i] + xoff;
 	__syncthreads();
 	if ((int)threadIdx.x < cnt) {
-		const int h = a / 2;
-		int s = starts[threadIdx.x];
-		int16_t *buf = xs + threadIdx.x * chunk;
+		int s = pre[(first + threadIdx.x) * gs + (l1_start[blockIdx.x] - l1_lo[blockIdx.x])];
+		int *buf = xs + threadIdx.x * chunk;
 		const int nc = min(chunk, n - (int)threadIdx.x * chunk);
 		for (int i = 0; i < nc; i++) {
-			s = deemph_step(s, buf[i], a, h, magic);
-			buf[i] = (int16_t)s;
+			s = deemph_step_b<EVEN>(s, buf[i], buf[i] - xoff, magic, bias);
+			buf[i] = s;
 		}
 	}
 	__syncthreads();
 	for (int i = threadIdx.x; i < n; i += 256)
-		y[s0 + i] = xs[i];
+		y[s0 + i] = (int16_t)xs[i];
 }
 
 __global__ void k_fm_deemph_serial(const int16_t *__restrict__ pcm, u64 M, int a, int16_t *__restrict__ y,
@@ -782,22 +794,26 @@ extern "C" int rxk_fm_disc(void *stream, const int16_t *iq, u64 T, int ds, int p
 
 static unsigned magic_for(int a) { return a > 1 ? (unsigned)((1ull << 32) / (unsigned)a + 1) : 0u; }
 
+static int bias_for(int a) { return 65536 / a + 2; }
+
 extern "C" int rxk_fm_deemph_scan(void *stream, const int16_t *pcm, u64 M, int a, int group, int chunk, int warm,
-                                  int lo0, int hi0, int *tab, int *lo_arr, int *gap_arr, int *l1_tab, int *l1_lo,
-                                  int *l1_gap, rxk_fm_dev *dev)
+                                  int lo0, int hi0, int *pre, int *l1_tab, int *l1_lo, int *l1_gap, rxk_fm_dev *dev)
 {
 	if (!M)
 		return 0;
 	const u64 n_chunks = (M + chunk - 1) / chunk;
 	const unsigned grid = (unsigned)((n_chunks + DEEMPH_FAN - 1) / DEEMPH_FAN);
-	const size_t shm = (size_t)DEEMPH_FAN * (warm + chunk) * sizeof(int16_t);
+	const size_t shm = (size_t)DEEMPH_FAN * (warm + chunk) * sizeof(int);
 	hipStream_t s = (hipStream_t)stream;
-	if (group == 16)
-		hipLaunchKernelGGL((k_fm_deemph_scan<16>), dim3(grid), dim3(DEEMPH_FAN * 16), shm, s, pcm, M, a, magic_for(a), chunk, warm,
-		                   lo0, hi0, tab, lo_arr, gap_arr, l1_tab, l1_lo, l1_gap, dev);
-	else
-		hipLaunchKernelGGL((k_fm_deemph_scan<64>), dim3(grid), dim3(DEEMPH_FAN * 64), shm, s, pcm, M, a, magic_for(a), chunk, warm,
-		                   lo0, hi0, tab, lo_arr, gap_arr, l1_tab, l1_lo, l1_gap, dev);
+	const unsigned mg = magic_for(a);
+	const int bias = bias_for(a);
+#define GO(GS, EV) do { \
+		if (shm > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_fm_deemph_scan<GS, EV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+		hipLaunchKernelGGL((k_fm_deemph_scan<GS, EV>), dim3(grid), dim3(DEEMPH_FAN * GS), shm, s, pcm, M, a, mg, bias, chunk, warm, \
+		                   lo0, hi0, pre, l1_tab, l1_lo, l1_gap, dev); } while (0)
+	if (group == 16) { if (a & 1) GO(16, false); else GO(16, true); }
+	else { if (a & 1) GO(64, false); else GO(64, true); }
+#undef GO
 	LAUNCH_RET();
 }
 
@@ -833,16 +849,20 @@ extern "C" int rxk_fm_deemph_down(void *stream, u64 n_child, int group, const in
 	LAUNCH_RET();
 }
 
-extern "C" int rxk_fm_deemph_apply(void *stream, const int16_t *pcm, u64 M, int a, int group, int chunk, const int *tab,
-                                   const int *lo_arr, const int *l1_start, int16_t *y)
+extern "C" int rxk_fm_deemph_apply(void *stream, const int16_t *pcm, u64 M, int a, int group, int chunk, const int *pre,
+                                   const int *l1_lo, const int *l1_start, int16_t *y)
 {
 	if (!M)
 		return 0;
 	const u64 n_chunks = (M + chunk - 1) / chunk;
 	const unsigned grid = (unsigned)((n_chunks + DEEMPH_FAN - 1) / DEEMPH_FAN);
-	const size_t shm = (size_t)DEEMPH_FAN * chunk * sizeof(int16_t);
-	hipLaunchKernelGGL(k_fm_deemph_apply, dim3(grid), dim3(256), shm, (hipStream_t)stream, pcm, M, a, magic_for(a), group, chunk,
-	                   tab, lo_arr, l1_start, y);
+	const size_t shm = (size_t)DEEMPH_FAN * chunk * sizeof(int);
+	if (a & 1)
+		hipLaunchKernelGGL((k_fm_deemph_apply<false>), dim3(grid), dim3(256), shm, (hipStream_t)stream, pcm, M, a, magic_for(a),
+		                   bias_for(a), group, chunk, pre, l1_lo, l1_start, y);
+	else
+		hipLaunchKernelGGL((k_fm_deemph_apply<true>), dim3(grid), dim3(256), shm, (hipStream_t)stream, pcm, M, a, magic_for(a),
+		                   bias_for(a), group, chunk, pre, l1_lo, l1_start, y);
 	LAUNCH_RET();
 }
 

@@ -25,7 +25,7 @@ struct rxgpu_fm_stream {
 	uint32_t *lp_raw, *lp, *head, *tail;
 	uint32_t *cas[2];                    /* fifth_order ping-pong */
 	int16_t *pcm, *y;
-	int *tab, *lo_arr, *gap_arr;          /* level 0: one table per chunk */
+	int *pre;                             /* level 0: per chunk, start state for each candidate of its level-1 parent */
 	int *lvl_tab, *lvl_lo, *lvl_gap, *lvl_start;   /* levels >= 1, packed back to back */
 	size_t lvl_cap;
 	unsigned long long *flag_list;
@@ -100,6 +100,8 @@ static void deemph_geometry(rxgpu_fm_stream *s)
 	s->lo0 = avg < -32768 ? avg : -32768;
 	s->hi0 = avg > 32767 ? avg : 32767;
 	s->group = a <= 16 ? 16 : (a <= 64 ? 64 : 0);
+	if (a < 2 || avg < -32768 || avg > 32767)
+		s->group = 0;                 /* a == 1 or a carried state outside int16: the serial kernel */
 	s->warm = s->group ? deemph_warm(a, (long long)s->hi0 - s->lo0) : 0;
 	if (s->warm > 8192)
 		s->group = 0;                 /* absurd carried state: take the serial kernel */
@@ -140,9 +142,7 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 	DMALLOC(s->tail, n_wg * 4);
 	DMALLOC(s->pcm, s->max_M * 2);
 	DMALLOC(s->y, s->max_M * 2);
-	DMALLOC(s->tab, n_chunks * 64 * 4);
-	DMALLOC(s->lo_arr, n_chunks * 4);
-	DMALLOC(s->gap_arr, n_chunks * 4);
+	DMALLOC(s->pre, n_chunks * 64 * 4);
 	s->lvl_cap = n_chunks / RXK_DEEMPH_FAN + n_chunks / (RXK_DEEMPH_FAN * (RXK_DEEMPH_FAN - 1)) + 2 * DEEMPH_LEVELS + 2;
 	DMALLOC(s->lvl_tab, s->lvl_cap * 64 * 4);
 	DMALLOC(s->lvl_lo, s->lvl_cap * 4);
@@ -174,7 +174,7 @@ void rxgpu_fm_stream_destroy(rxgpu_fm_stream *s)
 	hipFree(s->lp_raw); hipFree(s->lp); hipFree(s->head); hipFree(s->tail);
 	hipFree(s->cas[0]); hipFree(s->cas[1]);
 	hipFree(s->pcm); hipFree(s->y);
-	hipFree(s->tab); hipFree(s->lo_arr); hipFree(s->gap_arr);
+	hipFree(s->pre);
 	hipFree(s->lvl_tab); hipFree(s->lvl_lo); hipFree(s->lvl_gap); hipFree(s->lvl_start);
 	hipFree(s->flag_list); hipFree(s->dev); hipFree(s->hist_dev); hipFree(s->fir_dev);
 	if (s->dev_host) hipHostFree(s->dev_host);
@@ -231,7 +231,7 @@ static int run_audio_stages(rxgpu_fm_stream *s, unsigned long long M, unsigned l
 			cnt[1] = (cnt[0] + RXK_DEEMPH_FAN - 1) / RXK_DEEMPH_FAN;
 			off[1] = 0;
 			RX_K(rxk_fm_deemph_scan(st, s->pcm, M, p->deemph_a, g, DEEMPH_CHUNK, s->warm, s->lo0, s->hi0,
-			                        s->tab, s->lo_arr, s->gap_arr, s->lvl_tab, s->lvl_lo, s->lvl_gap, s->dev));
+			                        s->pre, s->lvl_tab, s->lvl_lo, s->lvl_gap, s->dev));
 			const unsigned long long topcap = s->topcap_override ? (unsigned long long)s->topcap_override : (unsigned long long)DEEMPH_TOPCAP(g);
 			while (cnt[top] > topcap) {
 				if (top == DEEMPH_LEVELS)
@@ -247,7 +247,7 @@ static int run_audio_stages(rxgpu_fm_stream *s, unsigned long long M, unsigned l
 			for (int l = top; l > 1; l--)
 				RX_K(rxk_fm_deemph_down(st, cnt[l - 1], g, s->lvl_tab + off[l - 1] * g, s->lvl_lo + off[l - 1],
 				                        s->lvl_start + off[l], s->lvl_start + off[l - 1]));
-			RX_K(rxk_fm_deemph_apply(st, s->pcm, M, p->deemph_a, g, DEEMPH_CHUNK, s->tab, s->lo_arr, s->lvl_start, deemph_dst));
+			RX_K(rxk_fm_deemph_apply(st, s->pcm, M, p->deemph_a, g, DEEMPH_CHUNK, s->pre, s->lvl_lo, s->lvl_start, deemph_dst));
 		} else {
 			RX_K(rxk_fm_deemph_serial(st, s->pcm, M, p->deemph_a, deemph_dst, s->dev));
 		}
