@@ -146,6 +146,181 @@ __global__ __launch_bounds__(256) void k_pw_fft(
 	}
 }
 
+// ------------------------------------------------------------------ P4-P8, N = 4096, register-blocked
+
+typedef short pw_s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pw_pk_add(uint32_t a, uint32_t b)
+{
+	pw_s16x2 r = __builtin_bit_cast(pw_s16x2, a) + __builtin_bit_cast(pw_s16x2, b);
+	return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pw_pk_sub(uint32_t a, uint32_t b)
+{
+	pw_s16x2 r = __builtin_bit_cast(pw_s16x2, a) - __builtin_bit_cast(pw_s16x2, b);
+	return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pw_pk_mul(uint32_t a, uint32_t b)
+{
+	pw_s16x2 r = __builtin_bit_cast(pw_s16x2, a) * __builtin_bit_cast(pw_s16x2, b);   // low 16 bits: the int16 wrap
+	return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pw_pk_half(uint32_t a)
+{
+	pw_s16x2 r = __builtin_bit_cast(pw_s16x2, a) >> (pw_s16x2)(1);
+	return __builtin_bit_cast(uint32_t, r);
+}
+
+// the same butterfly as `butterfly` above on packed registers: only the low 16 bits of tr/ti
+// survive the int16 stores, so the per-product truncations can be dropped (truncation to int16
+// is a ring homomorphism) and the halves are combined with one v_perm
+__device__ __forceinline__ void bfly_pk(uint32_t &lo, uint32_t &hi, uint32_t tw)
+{
+	const int wr = pw_lo(tw), wi = pw_hi(tw);
+	const int xr = pw_lo(hi), xi = pw_hi(hi);
+	const int tr = ((wr * xr + 16384) >> 15) - ((wi * xi + 16384) >> 15);
+	const int ti = ((wr * xi + 16384) >> 15) + ((wi * xr + 16384) >> 15);
+	const uint32_t t = __builtin_amdgcn_perm((uint32_t)ti, (uint32_t)tr, 0x05040100u);
+	const uint32_t q = pw_pk_half(lo);
+	hi = pw_pk_sub(q, t);
+	lo = pw_pk_add(q, t);
+}
+
+template <int BITS> __device__ __forceinline__ constexpr int crev(int v)
+{
+	int r = 0;
+	for (int i = 0; i < BITS; i++) r |= ((v >> i) & 1) << (BITS - 1 - i);
+	return r;
+}
+
+// Four consecutive radix-2 stages on 16 registers.  The reference runs its DIT stages on the
+// bit-reversed array; on the natural-order index n stage s pairs n with n + 2^(11-s) and its
+// twiddle index is rev_s(top s bits of n) << (11-s).  A thread holds the 16 values of one
+// 4-bit field of n, so within a pass the pair distance is 8,4,2,1 registers and the twiddle index
+// is  (base << (sh - s')) + (rev_s'(r >> (4-s')) << (11 - s'))  with `base` the reversed bits above
+// the field (0 for the first pass).
+template <int SH, bool FIRST>
+__device__ __forceinline__ void radix16_pass(uint32_t (&v)[16], const uint32_t *__restrict__ tw, unsigned base)
+{
+#pragma unroll
+	for (int sp = 0; sp < 4; sp++) {
+		const int d = 8 >> sp;
+#pragma unroll
+		for (int g = 0; g < (1 << sp); g++) {
+			const unsigned j = (FIRST ? 0u : (base << (SH - sp))) + ((unsigned)crev<4>(g << (4 - sp)) << (11 - sp));
+			const uint32_t w = tw[j];
+#pragma unroll
+			for (int q = 0; q < d; q++) {
+				const int r = g * 2 * d + q;
+				bfly_pk(v[r], v[r + d], w);
+			}
+		}
+	}
+}
+
+#define F4K_ROW 20                       // 16 data dwords + 4 pad: rows stay 16-byte aligned, b128 reads conflict-free
+#define F4K_BUF (256 * F4K_ROW)
+
+// One workgroup (256 threads, 16 values each) per (tune, pass group); NB FFT blocks per tune buffer
+// are loaded once into registers, remove_dc is reduced from them, then per block:
+//   window -> stages 0-3 in registers -> LDS transpose -> stages 4-7 -> LDS transpose -> stages 8-11
+//   -> |X|^2 into 16 per-thread int64 accumulators (bin = rev8(tid) + 256 * rev4(r)).
+template <int NB, bool PEAK>
+__global__ __launch_bounds__(256) void k_pw_fft4096(
+	const int16_t *__restrict__ in, size_t tune_stride, size_t pass_stride, int passes,
+	const int *__restrict__ window, const uint32_t *__restrict__ twiddle, int ppg, i64 *__restrict__ avg)
+{
+	__shared__ __attribute__((aligned(16))) uint32_t xa[F4K_BUF];
+	__shared__ __attribute__((aligned(16))) uint32_t xb[F4K_BUF];
+	__shared__ i64 red[8];
+	const int tid = threadIdx.x;
+	const int tune = blockIdx.x;
+	const int p_begin = blockIdx.y * ppg;
+	const int p_end = min(passes, p_begin + ppg);
+	const unsigned hi4 = tid >> 4, lo4 = tid & 15;
+	const unsigned base_b = __brev(hi4) >> 28;           // rev4 of bits 11..8
+	const unsigned base_c = __brev((unsigned)tid) >> 24; // rev8 of bits 11..4
+	uint32_t wcoef[16];
+#pragma unroll
+	for (int r = 0; r < 16; r++) {
+		const uint32_t c = (uint32_t)window[tid + 256 * r] & 0xffffu;
+		wcoef[r] = c | (c << 16);
+	}
+	i64 acc[16];
+#pragma unroll
+	for (int r = 0; r < 16; r++)
+		acc[r] = 0;
+
+	for (int pass = p_begin; pass < p_end; pass++) {
+		const uint32_t *buf = (const uint32_t *)(in + (size_t)pass * pass_stride + (size_t)tune * tune_stride);
+		uint32_t d[NB][16];
+		int si = 0, sq = 0;              // 8192 * NB samples of int16: fits int32 for NB <= 8
+#pragma unroll
+		for (int b = 0; b < NB; b++)
+#pragma unroll
+			for (int r = 0; r < 16; r++) {
+				d[b][r] = buf[b * 4096 + tid + 256 * r];
+				si += pw_lo(d[b][r]);
+				sq += pw_hi(d[b][r]);
+			}
+		// remove_dc, rtl_power.c:609-624 via 744-745 (L = 2*4096*NB int16, both halves complete)
+		for (int off = 32; off; off >>= 1) { si += __shfl_down(si, off); sq += __shfl_down(sq, off); }
+		__syncthreads();
+		if ((tid & 63) == 0) { red[tid >> 6] = si; red[4 + (tid >> 6)] = sq; }
+		__syncthreads();
+		const i64 ti64 = red[0] + red[1] + red[2] + red[3], tq64 = red[4] + red[5] + red[6] + red[7];
+		const int L = 2 * 4096 * NB;
+		const uint32_t ave = pw_pack((int)(short)(ti64 / L), (int)(short)(tq64 / (L - 1)));
+
+#pragma unroll
+		for (int b = 0; b < NB; b++) {
+			uint32_t v[16];
+#pragma unroll
+			for (int r = 0; r < 16; r++)
+				v[r] = pw_pk_mul(pw_pk_sub(d[b][r], ave), wcoef[r]);       // window, rtl_power.c:749-758
+			// stages 0-3: this thread holds n = tid + 256 r, r = bits 11..8
+			radix16_pass<0, true>(v, twiddle, 0u);
+			// transpose 1: next field is bits 7..4; row (hi4', lo4) gets the 16 values of that field
+#pragma unroll
+			for (int r = 0; r < 16; r++)
+				xa[(r * 16 + lo4) * F4K_ROW + hi4] = v[r];
+			__syncthreads();
+#pragma unroll
+			for (int c = 0; c < 4; c++) {
+				const uint4 t4 = *reinterpret_cast<const uint4 *>(&xa[tid * F4K_ROW + 4 * c]);
+				v[4 * c] = t4.x; v[4 * c + 1] = t4.y; v[4 * c + 2] = t4.z; v[4 * c + 3] = t4.w;
+			}
+			// stages 4-7: n = hi4<<8 | r<<4 | lo4
+			radix16_pass<7, false>(v, twiddle, base_b);
+			// transpose 2: next field is bits 3..0; row = bits 11..4
+#pragma unroll
+			for (int r = 0; r < 16; r++)
+				xb[(hi4 * 16 + r) * F4K_ROW + lo4] = v[r];
+			__syncthreads();
+#pragma unroll
+			for (int c = 0; c < 4; c++) {
+				const uint4 t4 = *reinterpret_cast<const uint4 *>(&xb[tid * F4K_ROW + 4 * c]);
+				v[4 * c] = t4.x; v[4 * c + 1] = t4.y; v[4 * c + 2] = t4.z; v[4 * c + 3] = t4.w;
+			}
+			// stages 8-11: n = tid<<4 | r
+			radix16_pass<3, false>(v, twiddle, base_c);
+			// real_conj + accumulate, rtl_power.c:664-668, 760-768; re^2+im^2 <= 2^31 fits u32
+#pragma unroll
+			for (int r = 0; r < 16; r++) {
+				const int re = pw_lo(v[r]), im = pw_hi(v[r]);
+				const i64 pw = (i64)(uint32_t)(re * re + im * im);
+				acc[r] = PEAK ? (pw > acc[r] ? pw : acc[r]) : acc[r] + pw;
+			}
+		}
+	}
+	i64 *avg_t = avg + (size_t)tune * 4096;
+#pragma unroll
+	for (int r = 0; r < 16; r++) {
+		const unsigned bin = base_c + 256u * (unsigned)crev<4>(r);
+		if (PEAK) atomicMax((long long *)&avg_t[bin], acc[r]);
+		else atomicAdd((unsigned long long *)&avg_t[bin], (unsigned long long)acc[r]);
+	}
+}
+
 __global__ void k_pw_samples(int *samples, int tunes, int add)
 {
 	const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -317,6 +492,14 @@ extern "C" int rxk_pw_fft(void *stream, const int16_t *in, size_t tune_stride, s
 	const int groups = (passes + passes_per_group - 1) / passes_per_group;
 	dim3 grid((unsigned)tunes, (unsigned)groups);
 	hipStream_t s = (hipStream_t)stream;
+	if (bin_e == 12 && (eff_len == 8192 || eff_len == 16384 || eff_len == 32768)) {
+		const int nb = eff_len / 8192;
+#define GO4K(NB) do { if (peak_hold) hipLaunchKernelGGL((k_pw_fft4096<NB, true>), grid, dim3(256), 0, s, in, tune_stride, pass_stride, passes, window, twiddle, passes_per_group, (i64 *)avg); \
+		else hipLaunchKernelGGL((k_pw_fft4096<NB, false>), grid, dim3(256), 0, s, in, tune_stride, pass_stride, passes, window, twiddle, passes_per_group, (i64 *)avg); } while (0)
+		if (nb == 1) GO4K(1); else if (nb == 2) GO4K(2); else GO4K(4);
+#undef GO4K
+		LAUNCH_RET();
+	}
 #define GO(A) do { \
 		if (shm > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_pw_fft<A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
 		hipLaunchKernelGGL((k_pw_fft<A>), grid, dim3(256), shm, s, in, tune_stride, pass_stride, passes, bin_e, eff_len, \
