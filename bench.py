@@ -186,6 +186,14 @@ def main():
         del d_iq, d_out
         torch.cuda.empty_cache()
         value = world * T * args.steps / dt / 1e6
+        traffic, traffic_src = None, None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))["k_fm_decimate"]
+            # measured on the default 2^30-sample launch; bytes scale with the launch
+            traffic = pmc["hbm_bytes_per_launch"] * (T / float(1 << 30))
+            traffic_src = "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per gfx950 note)"
+        except (OSError, KeyError, ValueError):
+            pass
         achieved = (4.0 * T) / (ms / launches * 1e-3) / 1e9 if launches else 0.0
         result.update({
             "metric": "rx_fm full_demod complex IQ MSample/s (20 Msps WBFM geometry, ds=118)",
@@ -199,7 +207,7 @@ def main():
                        "bytes_per_step": 4 * T, "parallelism": "replicas x%d (rx_fm does not shard)" % world,
                        "host_fixups_last_step": fixups},
             "roofline": {"bound": "hbm", "kernel": "k_fm_decimate (F0+F1+F2)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": 4 * T, "avg_launch_ms": (ms / launches) if launches else None},
         })
         if rank == 0 and args.cpu_seconds > 0 and world == 1:

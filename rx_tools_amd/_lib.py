@@ -43,6 +43,9 @@ def lib():
         L.rxgpu_last_error.restype = C.c_char_p
         L.rxgpu_stream.restype = C.c_void_p
         L.rxgpu_deemph_state.restype = C.POINTER(C.c_int)
+        L.rxgpu_deemph_state.argtypes = [C.c_void_p]
+        L.rxgpu_init.argtypes = [C.c_int]
+        L.rxgpu_prof_enable.argtypes = [C.c_int]
         L.rxgpu_fm_stream_host_fixups.restype = C.c_long
         L.rxgpu_fm_stream_host_fixups.argtypes = [C.c_void_p]
         L.rxgpu_prof_get.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_long)]

@@ -1,0 +1,113 @@
+"""-m gpu: the drop-in entry points on the reference's own structs (rxgpu_full_demod,
+rxgpu_callback, rxgpu_scan, rxgpu_csv_dbm) against the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import rx_tools_amd as R
+from rx_tools_amd.structs import DemodState, DongleState, TuningState
+from support import (oracle, oracle_fm_state, sig_fm, sig_noise, ptr16, ptr32, ptr64, PowerCfg)
+
+pytestmark = pytest.mark.gpu
+
+
+def fresh_demod(**kw):
+    d = DemodState()
+    d.rate_in = d.rate_out = kw.get("rate_out", 170000)
+    d.rate_out2 = kw.get("rate_out2", 32000)
+    d.custom_atan = kw.get("custom_atan", 1)
+    d.deemph = kw.get("deemph", 1)
+    d.deemph_a = kw.get("deemph_a", 13)
+    d.downsample = kw.get("downsample", 6)
+    d.downsample_passes = kw.get("downsample_passes", 0)
+    d.comp_fir_size = kw.get("comp_fir_size", 0)
+    d.post_downsample = 1
+    d.output_scale = 1
+    libc = C.CDLL(None)
+    libc.pthread_rwlock_init(C.byref(d, DemodState.rw.offset), None)
+    libc.pthread_cond_init(C.byref(d, DemodState.ready.offset), None)
+    libc.pthread_mutex_init(C.byref(d, DemodState.ready_m.offset), None)
+    return d
+
+
+@pytest.mark.parametrize("kw", [dict(downsample=6), dict(downsample=118), dict(downsample_passes=3, comp_fir_size=9),
+                                dict(downsample=9, custom_atan=0, deemph=0, rate_out2=-1)])
+def test_full_demod_and_callback_dropin(kw):
+    """rxgpu_callback + rxgpu_full_demod, block after block on a struct demod_state, == the oracle's
+    rtlsdr_callback pre-stage + full_demod, including lowpassed[], lp_len and every carry"""
+    L, O = R.lib(), oracle()
+    R.check(L.rxgpu_init(0))
+    block_len, n_blocks = 16384, 5
+    iq = sig_fm(n_blocks * block_len // 2, seed=42)
+    d = fresh_demod(**kw)
+    s = DongleState()
+    s.demod_target = C.pointer(d)
+    s.mute = 100
+    st = oracle_fm_state(**kw)
+    st.mute = 100
+    # the side-car accumulator is keyed by the struct's address; a recycled address keeps its value
+    L.rxgpu_deemph_state(C.addressof(d)).contents.value = 0
+    lp = np.zeros(block_len, np.int16)
+    want = np.zeros(block_len, np.int16)
+    for b in range(n_blocks):
+        blk = np.ascontiguousarray(iq[b * block_len:(b + 1) * block_len])
+        lp_len = C.c_int(0)
+        n_want = O.rxo_fm_block(C.byref(st), ptr16(blk.copy()), block_len, ptr16(lp), C.byref(lp_len), ptr16(want))
+        buf = blk.copy()
+        L.rxgpu_callback(buf.ctypes.data, block_len, C.addressof(s))
+        assert d.lp_len == block_len and s.mute == 0
+        L.rxgpu_full_demod(C.addressof(d))
+        assert d.result_len == n_want
+        assert np.array_equal(np.ctypeslib.as_array(d.result)[:n_want], want[:n_want])
+        assert d.lp_len == lp_len.value
+        assert np.array_equal(np.ctypeslib.as_array(d.lowpassed)[:d.lp_len], lp[:lp_len.value])
+        assert (d.now_r, d.now_j, d.prev_index, d.pre_r, d.pre_j, d.now_lpr, d.prev_lpr_index) == \
+            (st.now_r, st.now_j, st.prev_index, st.pre_r, st.pre_j, st.now_lpr, st.prev_lpr_index)
+        assert bytes(d.lp_i_hist) == bytes(st.lp_i_hist) and bytes(d.lp_q_hist) == bytes(st.lp_q_hist)
+        assert bytes(d.droop_i_hist) == bytes(st.droop_i_hist) and bytes(d.droop_q_hist) == bytes(st.droop_q_hist)
+        assert L.rxgpu_deemph_state(C.addressof(d)).contents.value == st.deemph_avg
+
+
+@pytest.mark.parametrize("rng,flags,window", [("24M:60M:1k", (1, 0, 0), "hamming"), ("100M:105M:1M", (1, 0, 1), "rectangle"),
+                                              ("100M:100.1M:100", (0, 9, 0), "blackman")])
+def test_scan_and_csv_dropin(rng, flags, window, tmp_path):
+    """rxgpu_scan on an array of struct tuning_state (+ rxgpu_csv_dbm) == the oracle's scanner()/csv_dbm, two passes"""
+    L, O = R.lib(), oracle()
+    plan = R.plan_range(rng, 0.0, flags[0])
+    tunes, n = min(plan.tune_count, 5), 1 << plan.bin_e
+    wc, sw = R.window_coefs(window, n), R.sine_table(plan.bin_e)
+    bufs = [np.zeros(plan.buf_len, np.int16) for _ in range(tunes)]
+    avgs = [np.zeros(n, np.int64) for _ in range(tunes)]
+    arr = (TuningState * tunes)()
+    for t in range(tunes):
+        arr[t] = TuningState(plan.first_freq + t * plan.bw_seen, plan.rate, plan.bin_e, ptr64(avgs[t]), 0, plan.downsample,
+                             plan.downsample_passes, plan.crop, ptr16(bufs[t]), plan.buf_len)
+    cfg = PowerCfg(plan.bin_e, plan.buf_len, plan.downsample, plan.downsample_passes, flags[0], flags[1], flags[2],
+                   ptr32(wc), ptr16(sw))
+    want_avg = np.zeros((tunes, n), np.int64)
+    want_samples = np.zeros(tunes, np.int32)
+    work = np.zeros(plan.buf_len, np.int16)
+    for p in range(2):
+        data = sig_noise(tunes * plan.buf_len, seed=50 + p, amp=2500).reshape(tunes, plan.buf_len)
+        for t in range(tunes):
+            bufs[t][:] = data[t]
+            smp = C.c_int(int(want_samples[t]))
+            O.rxo_power_tune(C.byref(cfg), ptr16(np.ascontiguousarray(data[t])), ptr16(work), ptr64(want_avg[t]), C.byref(smp))
+            want_samples[t] = smp.value
+        R.check(L.rxgpu_scan(arr, tunes, wc.ctypes.data, sw.ctypes.data, *flags))
+        for t in range(tunes):
+            assert np.array_equal(avgs[t], want_avg[t]) and arr[t].samples == want_samples[t]
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fclose.argtypes = [C.c_void_p]
+    f = libc.fopen(str(tmp_path / "o.csv").encode(), b"wb")
+    rows = []
+    buf = C.create_string_buffer(1 << 20)
+    for t in range(tunes):
+        smp = C.c_int(int(want_samples[t]))
+        O.rxo_csv_row(buf, len(buf), arr[t].freq, plan.rate, plan.bin_e, plan.downsample, plan.crop, ptr64(want_avg[t]), C.byref(smp))
+        rows.append(buf.value.decode())
+        L.rxgpu_csv_dbm(C.byref(arr[t]), f)
+    libc.fclose(f)
+    assert open(str(tmp_path / "o.csv")).read() == "".join(rows)
