@@ -681,6 +681,191 @@ __global__ __launch_bounds__(256) void k_fm_fifth_pass(
 	}
 }
 
+// ------------------------------------------------------------------ F3 fused: first 1-3 passes in LDS
+
+// For the raw cs16 stream the callback's scale bounds every sample by 128, each fifth_order pass
+// has gain 2, so through three passes every tap sum stays below 2^15: the int arithmetic of
+// rtl_fm.c:423/431 can be done on packed int16 pairs (I and Q at once) without changing a bit.
+// A workgroup turns FF_RAW raw samples (+36 of left halo) into FF_RAW>>FUSE samples, keeping the
+// intermediate levels in LDS.  Level-p sample i of block b is written V_p(b,i); negative i reach
+// into the previous block through the seam rule (s[-q] = its sample n_p-1-q) -- those five values
+// per block and level come precomputed from k_fm_fifth_seams, block 0 takes the carried hist.
+#define FF_RAW 2048
+
+typedef short ff_s16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t fifth_pk(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t e, uint32_t f)
+{
+	const ff_s16x2 va = __builtin_bit_cast(ff_s16x2, a), vb = __builtin_bit_cast(ff_s16x2, b), vc = __builtin_bit_cast(ff_s16x2, c);
+	const ff_s16x2 vd = __builtin_bit_cast(ff_s16x2, d), ve = __builtin_bit_cast(ff_s16x2, e), vf = __builtin_bit_cast(ff_s16x2, f);
+	const ff_s16x2 sum = (va + vf) + (vb + ve) * (ff_s16x2)(5) + (vc + vd) * (ff_s16x2)(10);
+	return __builtin_bit_cast(uint32_t, sum >> (ff_s16x2)(4));
+}
+
+template <bool ROTATE>
+__device__ __forceinline__ uint32_t raw_scaled(uint32_t w, unsigned idx)
+{
+	const int i = scale_cs16(lo16(w)), q = scale_cs16(hi16(w));
+	if (!ROTATE)
+		return pack_iq(i, q);
+	switch (idx & 3) {
+	case 0: return pack_iq(i, q);
+	case 1: return pack_iq(-q, i);
+	case 2: return pack_iq(-i, -q);
+	default: return pack_iq(q, -i);
+	}
+}
+
+// level-P sample idx (>= 0, far enough from the block start that no tap is negative)
+template <int P, bool ROTATE>
+__device__ uint32_t level_val(const uint32_t *__restrict__ blk_raw, int idx)
+{
+	if constexpr (P == 0) {
+		return raw_scaled<ROTATE>(blk_raw[idx], (unsigned)idx);
+	} else {
+		uint32_t t[6];
+#pragma unroll
+		for (int k = 0; k < 6; k++)
+			t[k] = level_val<P - 1, ROTATE>(blk_raw, 2 * idx - 5 + k);
+		return fifth_pk(t[0], t[1], t[2], t[3], t[4], t[5]);
+	}
+}
+
+// seams[b][p][q] = V_p(b, -5+q), p < 3, q < 5; plus the carried-out histories of the fused passes
+template <bool ROTATE>
+__global__ void k_fm_fifth_seams(const uint32_t *__restrict__ iq, u64 n_blocks, unsigned n, int fuse,
+                                 const int16_t *__restrict__ hist_in, uint32_t *__restrict__ seams,
+                                 int16_t *__restrict__ hist_out)
+{
+	const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	const u64 b = gid / 16;
+	const int slot = (int)(gid % 16), p = slot / 5, q = slot % 5;
+	if (b < n_blocks && slot < 15 && p < fuse) {
+		uint32_t v;
+		if (b == 0) {
+			// carried history: s[-5..-1] = hist[1..5] (rtl_fm.c:416-420)
+			v = pack_iq(hist_in[p * 12 + 1 + q], hist_in[p * 12 + 6 + 1 + q]);
+		} else {
+			const uint32_t *prev = iq + (b - 1) * (u64)n;
+			const int idx = (int)(n >> p) - 6 + q;          // s[-5+q] = previous block's sample n_p-1+(-5+q)
+			v = p == 0 ? level_val<0, ROTATE>(prev, idx) : p == 1 ? level_val<1, ROTATE>(prev, idx) : level_val<2, ROTATE>(prev, idx);
+		}
+		seams[(b * 3 + p) * 5 + q] = v;
+	}
+	if (b == n_blocks && slot < 15) {
+		// archive (rtl_fm.c:434-439): pass p leaves its last window, samples n_p-7 .. n_p-2
+		if (p < fuse) {
+			const uint32_t *last = iq + (n_blocks - 1) * (u64)n;
+			for (int t = q; t < 6; t += 5) {
+				const int idx = (int)(n >> p) - 7 + t;
+				const uint32_t v = p == 0 ? level_val<0, ROTATE>(last, idx) : p == 1 ? level_val<1, ROTATE>(last, idx) : level_val<2, ROTATE>(last, idx);
+				hist_out[p * 12 + t] = (int16_t)lo16(v);
+				hist_out[p * 12 + 6 + t] = (int16_t)hi16(v);
+			}
+		}
+	}
+}
+
+// four outputs i..i+3 of one pass from the 16 inputs 2i-8 .. 2i+7
+__device__ __forceinline__ uint4 fifth_quad(const uint32_t *__restrict__ src)
+{
+	const uint4 w0 = *reinterpret_cast<const uint4 *>(src), w1 = *reinterpret_cast<const uint4 *>(src + 4);
+	const uint4 w2 = *reinterpret_cast<const uint4 *>(src + 8), w3 = *reinterpret_cast<const uint4 *>(src + 12);
+	uint4 o;
+	o.x = fifth_pk(w0.w, w1.x, w1.y, w1.z, w1.w, w2.x);     // inputs 3..8
+	o.y = fifth_pk(w1.y, w1.z, w1.w, w2.x, w2.y, w2.z);     // 5..10
+	o.z = fifth_pk(w1.w, w2.x, w2.y, w2.z, w2.w, w3.x);     // 7..12
+	o.w = fifth_pk(w2.y, w2.z, w2.w, w3.x, w3.y, w3.z);     // 9..14
+	return o;
+}
+
+template <int FUSE, bool ROTATE>
+__global__ __launch_bounds__(256) void k_fm_fifth_fused(
+	const uint32_t *__restrict__ iq, unsigned n, unsigned tiles_per_block, const uint32_t *__restrict__ seams,
+	uint32_t *__restrict__ out)
+{
+	// l0[j] = V0[t0 + j - 40], l1[j] = V1[t0/2 + j - 24], l2[j] = V2[t0/4 + j - 8]
+	__shared__ __attribute__((aligned(16))) uint32_t l0[FF_RAW + 40];
+	__shared__ __attribute__((aligned(16))) uint32_t l1[FF_RAW / 2 + 24 + 8];
+	__shared__ __attribute__((aligned(16))) uint32_t l2[FF_RAW / 4 + 8 + 8];
+	const u64 blk = blockIdx.x / tiles_per_block;
+	const unsigned tile = blockIdx.x % tiles_per_block;
+	const unsigned t0 = tile * FF_RAW;
+	const bool first = tile == 0;
+	const uint32_t *braw = iq + blk * (u64)n;
+	const uint32_t *sm = seams + blk * 15;
+	const int tid = threadIdx.x;
+
+	// level 0: FF_RAW samples + 36 of halo, 4 per lane per load; all loads issued before any is used
+	{
+		constexpr int NV = (FF_RAW + 36) / 4;              // 521 vectors
+		u32x4 w[3];
+#pragma unroll
+		for (int u = 0; u < 3; u++) {
+			const int v4 = tid + 256 * u;
+			const int rel = 4 * v4 - 36;
+			const bool on = v4 < NV && !(first && rel < 0);
+			w[u] = on ? __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(braw + t0 + rel)) : (u32x4)(0u);
+		}
+#pragma unroll
+		for (int u = 0; u < 3; u++) {
+			const int v4 = tid + 256 * u;
+			const int rel = 4 * v4 - 36;                   // relative to t0; t0 + rel is a multiple of 4: phases 0..3
+			if (v4 < NV && !(first && rel < 0)) {
+				uint4 o;
+				o.x = raw_scaled<ROTATE>(w[u].x, 0u); o.y = raw_scaled<ROTATE>(w[u].y, 1u);
+				o.z = raw_scaled<ROTATE>(w[u].z, 2u); o.w = raw_scaled<ROTATE>(w[u].w, 3u);
+				*reinterpret_cast<uint4 *>(&l0[rel + 40]) = o;
+			}
+		}
+	}
+	if (first && tid < 5)
+		l0[35 + tid] = sm[tid];                            // V0[-5..-1]
+	__syncthreads();
+
+	// pass 0: V1[t0/2 + i], i = -16 + 4q
+	for (int q = tid; q < FF_RAW / 8 + 4; q += 256) {
+		if (first && q < 4)
+			continue;
+		const uint4 o = fifth_quad(&l0[8 * q]);
+		if (FUSE == 1) {
+			if (q >= 4)
+				*reinterpret_cast<uint4 *>(out + blk * (u64)(n >> 1) + t0 / 2 + 4 * (q - 4)) = o;
+		} else {
+			*reinterpret_cast<uint4 *>(&l1[8 + 4 * q]) = o;
+		}
+	}
+	if (FUSE == 1)
+		return;
+	if (first && tid < 5)
+		l1[19 + tid] = sm[5 + tid];                        // V1[-5..-1]
+	__syncthreads();
+
+	// pass 1: V2[t0/4 + i], i = -8 + 4q
+	for (int q = tid; q < FF_RAW / 16 + 2; q += 256) {
+		if (first && q < 2)
+			continue;
+		const uint4 o = fifth_quad(&l1[8 * q]);
+		if (FUSE == 2) {
+			if (q >= 2)
+				*reinterpret_cast<uint4 *>(out + blk * (u64)(n >> 2) + t0 / 4 + 4 * (q - 2)) = o;
+		} else {
+			*reinterpret_cast<uint4 *>(&l2[4 * q]) = o;
+		}
+	}
+	if (FUSE == 2)
+		return;
+	if (first && tid < 5)
+		l2[3 + tid] = sm[10 + tid];                        // V2[-5..-1]
+	__syncthreads();
+
+	// pass 2: V3[t0/8 + i], i = 4q
+	if (tid < FF_RAW / 32) {
+		const uint4 o = fifth_quad(&l2[8 * tid]);
+		*reinterpret_cast<uint4 *>(out + blk * (u64)(n >> 3) + t0 / 8 + 4 * tid) = o;
+	}
+}
+
 // ------------------------------------------------------------------ F12 droop FIR
 
 // rtl_fm.c:442-465: out[t] = (sum over the 9 samples BEFORE t) >> 15; hist carries across blocks,
@@ -920,5 +1105,25 @@ extern "C" int rxk_fm_prestage(void *stream, const int16_t *in, unsigned n_compl
 		return 0;
 	hipLaunchKernelGGL(k_fm_prestage, dim3((n_complex + 255) / 256), dim3(256), 0, (hipStream_t)stream,
 	                   (const uint32_t *)in, n_complex, rotate, (uint32_t *)out);
+	LAUNCH_RET();
+}
+
+// first min(passes,3) fifth_order passes fused; returns the number of passes done through *fused
+extern "C" int rxk_fm_fifth_fused(void *stream, const int16_t *iq, int rotate, u64 n_blocks, unsigned n, int fuse,
+                                  const int16_t *hist_in, int16_t *hist_out, uint32_t *seams, uint32_t *out)
+{
+	hipStream_t s = (hipStream_t)stream;
+	const unsigned tiles = n / FF_RAW;
+	const u64 seam_threads = (n_blocks + 1) * 16;
+	const unsigned grid = (unsigned)(n_blocks * tiles);
+	const uint32_t *p = (const uint32_t *)iq;
+	if (rotate)
+		hipLaunchKernelGGL((k_fm_fifth_seams<true>), dim3((unsigned)((seam_threads + 255) / 256)), dim3(256), 0, s, p, n_blocks, n, fuse, hist_in, seams, hist_out);
+	else
+		hipLaunchKernelGGL((k_fm_fifth_seams<false>), dim3((unsigned)((seam_threads + 255) / 256)), dim3(256), 0, s, p, n_blocks, n, fuse, hist_in, seams, hist_out);
+#define GO(F) do { if (rotate) hipLaunchKernelGGL((k_fm_fifth_fused<F, true>), dim3(grid), dim3(256), 0, s, p, n, tiles, seams, out); \
+		else hipLaunchKernelGGL((k_fm_fifth_fused<F, false>), dim3(grid), dim3(256), 0, s, p, n, tiles, seams, out); } while (0)
+	if (fuse == 1) GO(1); else if (fuse == 2) GO(2); else GO(3);
+#undef GO
 	LAUNCH_RET();
 }

@@ -24,6 +24,7 @@ struct rxgpu_fm_stream {
 	/* device workspaces */
 	uint32_t *lp_raw, *lp, *head, *tail;
 	uint32_t *cas[2];                    /* fifth_order ping-pong */
+	uint32_t *seams;                     /* per block: 3 levels x 5 history samples for the fused passes */
 	int16_t *pcm, *y;
 	int *pre;                             /* level 0: per chunk, start state for each candidate of its level-1 parent */
 	int *lvl_tab, *lvl_lo, *lvl_gap, *lvl_start;   /* levels >= 1, packed back to back */
@@ -156,6 +157,7 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 		/* pass 0 output is half the input, later passes shrink further: two buffers suffice */
 		DMALLOC(s->cas[0], (s->max_T / 2 + max_blocks) * 4);
 		DMALLOC(s->cas[1], (s->max_T / 4 + max_blocks) * 4);
+		DMALLOC(s->seams, (max_blocks + 1) * 15 * 4);
 	}
 	if (hipHostMalloc((void **)&s->dev_host, sizeof(rxk_fm_dev), 0) != hipSuccess ||
 	    hipHostMalloc((void **)&s->hist_host, HIST_TOTAL * 2, 0) != hipSuccess ||
@@ -172,7 +174,7 @@ void rxgpu_fm_stream_destroy(rxgpu_fm_stream *s)
 	if (!s)
 		return;
 	hipFree(s->lp_raw); hipFree(s->lp); hipFree(s->head); hipFree(s->tail);
-	hipFree(s->cas[0]); hipFree(s->cas[1]);
+	hipFree(s->cas[0]); hipFree(s->cas[1]); hipFree(s->seams);
 	hipFree(s->pcm); hipFree(s->y);
 	hipFree(s->pre);
 	hipFree(s->lvl_tab); hipFree(s->lvl_lo); hipFree(s->lvl_gap); hipFree(s->lvl_start);
@@ -357,7 +359,19 @@ int rxgpu_fm_stream_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks
 		rxgpu_prof_begin("fm_fifth");
 		const void *src = d_iq;
 		unsigned n_in = (unsigned)n, in_stride = (unsigned)n;
-		for (int i = 0; i < passes; i++) {
+		int first_pass = 0;
+		if (!p->prescaled && (n % RXK_FIFTH_TILE) == 0) {
+			/* the first up-to-three passes fused in LDS (raw input only: packed int16 maths is exact there) */
+			const int fuse = passes < 3 ? passes : 3;
+			uint32_t *dst = s->cas[(fuse - 1) & 1];
+			RX_K(rxk_fm_fifth_fused(st, d_iq, rotate, n_blocks, (unsigned)n, fuse, s->hist_dev + HIST_CAS_IN,
+			                        s->hist_dev + HIST_CAS_OUT, s->seams, dst));
+			src = dst;
+			n_in = (unsigned)(n >> fuse);
+			in_stride = n_in;
+			first_pass = fuse;
+		}
+		for (int i = first_pass; i < passes; i++) {
 			uint32_t *dst = s->cas[i & 1];
 			unsigned n_out = n_in / 2;
 			RX_K(rxk_fm_fifth_pass(st, src, i == 0, p->prescaled, rotate, n_blocks, n_in, in_stride, dst, n_out,
