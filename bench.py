@@ -175,8 +175,10 @@ def main():
         L.rxgpu_prof_enable(args.prof_level)
         barrier()
         t0 = time.perf_counter()
+        # pipelined: run r+1's decimator (stream A) overlaps run r's audio stages (stream B); one wait at the end
         for _ in range(args.steps):
-            s.run(d_iq.data_ptr(), n_blocks, block_len, d_out.data_ptr(), d_out.numel())
+            s.run_async(d_iq.data_ptr(), n_blocks, block_len, d_out.data_ptr(), d_out.numel())
+        s.wait()
         barrier()
         dt = max_over_ranks(time.perf_counter() - t0)
         L.rxgpu_prof_enable(0)

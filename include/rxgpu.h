@@ -123,6 +123,18 @@ int rxgpu_fm_stream_get_carry(rxgpu_fm_stream *s, rxgpu_fm_carry *c);
 int rxgpu_fm_stream_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks, size_t block_len,
                         int16_t *d_out, size_t out_cap, size_t *out_len, int *block_out_len);
 
+/* Pipelined form: enqueue and return.  The HBM-bound decimator of run r+1 overlaps the
+ * latency-bound audio stages of run r on a second stream; carries are chained on the device.
+ * *out_len and block_out_len are filled immediately (they are closed-form in the geometry).
+ * rxgpu_fm_stream_wait() blocks until every enqueued run has finished and brings the carries
+ * back; get_carry/set_carry/run wait implicitly.  If a libm-discriminator sample of a pipelined
+ * sequence is undecided on the device (see host_fixups; never observed), wait() returns
+ * RXGPU_EUNSUPPORTED after rolling the carries back to the start of the sequence, and the
+ * caller replays those blocks with rxgpu_fm_stream_run. */
+int rxgpu_fm_stream_run_async(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks, size_t block_len,
+                              int16_t *d_out, size_t out_cap, size_t *out_len, int *block_out_len);
+int rxgpu_fm_stream_wait(rxgpu_fm_stream *s);
+
 /* Same with HOST input/output buffers (staged through pinned memory over PCIe). */
 int rxgpu_fm_stream_run_host(rxgpu_fm_stream *s, const int16_t *h_iq, size_t n_blocks, size_t block_len,
                              int16_t *h_out, size_t out_cap, size_t *out_len, int *block_out_len);

@@ -18,7 +18,8 @@ EXPORTS = [
     "rxgpu_prof_enable", "rxgpu_prof_reset", "rxgpu_prof_get",
     "rxgpu_full_demod", "rxgpu_callback", "rxgpu_deemph_state",
     "rxgpu_fm_stream_create", "rxgpu_fm_stream_destroy", "rxgpu_fm_stream_set_carry", "rxgpu_fm_stream_get_carry",
-    "rxgpu_fm_stream_run", "rxgpu_fm_stream_run_host", "rxgpu_fm_stream_host_fixups",
+    "rxgpu_fm_stream_run", "rxgpu_fm_stream_run_async", "rxgpu_fm_stream_wait", "rxgpu_fm_stream_run_host",
+    "rxgpu_fm_stream_host_fixups",
     "rxgpu_scan", "rxgpu_csv_dbm", "rxgpu_power_plan_range", "rxgpu_sine_table", "rxgpu_window_coefs",
     "rxgpu_power_scan_create", "rxgpu_power_scan_destroy", "rxgpu_power_scan_run",
 ]
@@ -56,6 +57,8 @@ def lib():
         L.rxgpu_fm_stream_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
                                           C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
         L.rxgpu_fm_stream_run_host.argtypes = L.rxgpu_fm_stream_run.argtypes
+        L.rxgpu_fm_stream_run_async.argtypes = L.rxgpu_fm_stream_run.argtypes
+        L.rxgpu_fm_stream_wait.argtypes = [C.c_void_p]
         L.rxgpu_power_scan_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.rxgpu_power_scan_destroy.argtypes = [C.c_void_p]
         L.rxgpu_power_scan_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]

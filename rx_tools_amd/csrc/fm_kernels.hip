@@ -591,6 +591,15 @@ __global__ void k_fm_resample(const int16_t *__restrict__ y, u64 n, int fast, in
 	}
 }
 
+// pipelined runs: what the previous run left as carries-out is this run's carries-in
+__global__ void k_fm_carry_advance(rxk_fm_dev *dev)
+{
+	dev->in_now_r = dev->out_now_r; dev->in_now_j = dev->out_now_j; dev->in_prev_index = dev->out_prev_index;
+	dev->in_pre_r = dev->out_pre_r; dev->in_pre_j = dev->out_pre_j;
+	dev->in_deemph_avg = dev->out_deemph_avg;
+	dev->in_now_lpr = dev->out_now_lpr; dev->in_prev_lpr_index = dev->out_prev_lpr_index;
+}
+
 __global__ void k_fm_passthrough_carry(rxk_fm_dev *dev, int deemph_off, int resample_off)
 {
 	if (deemph_off)
@@ -1060,6 +1069,12 @@ extern "C" int rxk_fm_deemph_serial(void *stream, const int16_t *pcm, u64 M, int
 extern "C" int rxk_fm_resample(void *stream, const int16_t *y, u64 n, int fast, int slow, u64 J, int16_t *out, rxk_fm_dev *dev)
 {
 	hipLaunchKernelGGL(k_fm_resample, dim3((unsigned)((J + 1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, n, fast, slow, J, out, dev);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_fm_carry_advance(void *stream, rxk_fm_dev *dev)
+{
+	hipLaunchKernelGGL(k_fm_carry_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, dev);
 	LAUNCH_RET();
 }
 

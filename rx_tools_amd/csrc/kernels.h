@@ -83,6 +83,8 @@ int rxk_fm_deemph_serial(void *stream, const int16_t *pcm, unsigned long long M,
 /* F9 low_pass_real (rtl_fm.c:389-409): J outputs from n inputs, closed-form windows */
 int rxk_fm_resample(void *stream, const int16_t *y, unsigned long long n, int fast, int slow,
                     unsigned long long J, int16_t *out, rxk_fm_dev *dev);
+/* chained runs: carries-out -> carries-in on the device */
+int rxk_fm_carry_advance(void *stream, rxk_fm_dev *dev);
 /* carries when a stage is disabled */
 int rxk_fm_passthrough_carry(void *stream, rxk_fm_dev *dev, int deemph_off, int resample_off);
 

@@ -16,13 +16,21 @@
 #define DEEMPH_LEVELS 8
 #define DEEMPH_TOPCAP(group) ((group) == 16 ? 2048 : 512)   /* tables the single-workgroup top walk stages in LDS */
 
+/* geometry of one run, everything the host can know without the device */
+struct run_geom {
+	unsigned long long n, T, M, K, J;
+	int passes, ds, p0, pr0, rotate, fast;
+};
+
 struct rxgpu_fm_stream {
 	rxgpu_fm_params p;
 	rxgpu_fm_carry carry;
 	size_t max_blocks, block_len;        /* capacity */
 	size_t max_T, max_M;
 	/* device workspaces */
-	uint32_t *lp_raw, *lp, *head, *tail;
+	uint32_t *lp_raw[2], *head[2], *tail[2];   /* decimator outputs, double-buffered across pipelined runs */
+	uint32_t *lp;
+	const uint32_t *lp_final;            /* where the last run left the final decimated IQ */
 	uint32_t *cas[2];                    /* fifth_order ping-pong */
 	uint32_t *seams;                     /* per block: 3 levels x 5 history samples for the fused passes */
 	int16_t *pcm, *y;
@@ -44,6 +52,16 @@ struct rxgpu_fm_stream {
 	int group, warm, lo0, hi0;
 	int topcap_override;                 /* $RXGPU_DEEMPH_TOPCAP: forces the multi-level scan (tests) */
 	long fixups;
+	/* pipelining state */
+	hipEvent_t ev_dec[2], ev_small[2];
+	int ev_small_valid[2];
+	int db;                              /* decimator buffer set the next run uses */
+	int pending;                         /* runs enqueued and not yet waited for */
+	int chained;                         /* device carries are ahead of the host copy */
+	int h_prev_index, h_prev_lpr_index;  /* the two carries the host can track in closed form */
+	rxgpu_fm_carry carry_at_enqueue;     /* for rolling a pipelined sequence back */
+	struct run_geom last;
+	int16_t *last_out;
 };
 
 /* rtl_fm.c:288-300 */
@@ -137,10 +155,17 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 	size_t n_chunks = (s->max_M + DEEMPH_CHUNK - 1) / DEEMPH_CHUNK + 1;
 #define DMALLOC(ptr, bytes) do { if (hipMalloc((void **)&(ptr), (bytes)) != hipSuccess) { \
 	rxgpu_fm_stream_destroy(s); return rxgpu_fail(RXGPU_ENOMEM, "hipMalloc(%zu) failed", (size_t)(bytes)); } } while (0)
-	DMALLOC(s->lp_raw, s->max_M * 4);
+	for (int i = 0; i < 2; i++) {
+		DMALLOC(s->lp_raw[i], s->max_M * 4);
+		DMALLOC(s->head[i], n_wg * 4);
+		DMALLOC(s->tail[i], n_wg * 4);
+		if (hipEventCreateWithFlags(&s->ev_dec[i], hipEventDisableTiming) != hipSuccess ||
+		    hipEventCreateWithFlags(&s->ev_small[i], hipEventDisableTiming) != hipSuccess) {
+			rxgpu_fm_stream_destroy(s);
+			return rxgpu_fail(RXGPU_ENODEV, "hipEventCreate failed");
+		}
+	}
 	DMALLOC(s->lp, s->max_M * 4);
-	DMALLOC(s->head, n_wg * 4);
-	DMALLOC(s->tail, n_wg * 4);
 	DMALLOC(s->pcm, s->max_M * 2);
 	DMALLOC(s->y, s->max_M * 2);
 	DMALLOC(s->pre, n_chunks * 64 * 4);
@@ -173,7 +198,16 @@ void rxgpu_fm_stream_destroy(rxgpu_fm_stream *s)
 {
 	if (!s)
 		return;
-	hipFree(s->lp_raw); hipFree(s->lp); hipFree(s->head); hipFree(s->tail);
+	if (s->pending) {
+		hipStreamSynchronize(rxgpu_hip_stream());
+		hipStreamSynchronize(rxgpu_hip_stream2());
+	}
+	for (int i = 0; i < 2; i++) {
+		hipFree(s->lp_raw[i]); hipFree(s->head[i]); hipFree(s->tail[i]);
+		if (s->ev_dec[i]) hipEventDestroy(s->ev_dec[i]);
+		if (s->ev_small[i]) hipEventDestroy(s->ev_small[i]);
+	}
+	hipFree(s->lp);
 	hipFree(s->cas[0]); hipFree(s->cas[1]); hipFree(s->seams);
 	hipFree(s->pcm); hipFree(s->y);
 	hipFree(s->pre);
@@ -187,18 +221,26 @@ void rxgpu_fm_stream_destroy(rxgpu_fm_stream *s)
 	free(s);
 }
 
+static int finish_runs(rxgpu_fm_stream *s);
+
 int rxgpu_fm_stream_set_carry(rxgpu_fm_stream *s, const rxgpu_fm_carry *c)
 {
+	int rc;
 	if (!s || !c)
 		return rxgpu_fail(RXGPU_EINVAL, "null argument");
+	if (s->pending && (rc = finish_runs(s)) != RXGPU_OK)
+		return rc;
 	s->carry = *c;
 	return RXGPU_OK;
 }
 
 int rxgpu_fm_stream_get_carry(rxgpu_fm_stream *s, rxgpu_fm_carry *c)
 {
+	int rc;
 	if (!s || !c)
 		return rxgpu_fail(RXGPU_EINVAL, "null argument");
+	if (s->pending && (rc = finish_runs(s)) != RXGPU_OK)
+		return rc;
 	*c = s->carry;
 	return RXGPU_OK;
 }
@@ -214,16 +256,15 @@ static int polar_discriminant_host(int ar, int aj, int br, int bj)
 	return (int)(angle / 3.14159 * (1 << 14));
 }
 
-/* de-emphasis + resampler stages; pcm (M samples) -> d_out.  Re-runnable. */
-static int run_audio_stages(rxgpu_fm_stream *s, unsigned long long M, unsigned long long J, int16_t *d_out)
+/* de-emphasis + resampler stages on stream st; pcm (M samples) -> d_out.  Re-runnable. */
+static int run_audio_stages(rxgpu_fm_stream *s, hipStream_t st, unsigned long long M, unsigned long long J, int16_t *d_out)
 {
-	hipStream_t st = rxgpu_hip_stream();
 	const rxgpu_fm_params *p = &s->p;
 	const int resample = p->rate_out2 > 0;
 	int16_t *deemph_dst = resample ? s->y : d_out;
 	const int16_t *audio = s->pcm;
 	if (p->deemph && M) {
-		rxgpu_prof_begin("fm_deemph");
+		rxgpu_prof_begin_on("fm_deemph", st);
 		if (s->group) {
 			/* tree scan over chunk maps: level 0 = chunks, level l+1 = composites of RXK_DEEMPH_FAN level-l tables */
 			const int g = s->group;
@@ -253,13 +294,13 @@ static int run_audio_stages(rxgpu_fm_stream *s, unsigned long long M, unsigned l
 		} else {
 			RX_K(rxk_fm_deemph_serial(st, s->pcm, M, p->deemph_a, deemph_dst, s->dev));
 		}
-		rxgpu_prof_end("fm_deemph");
+		rxgpu_prof_end_on("fm_deemph", st);
 		audio = deemph_dst;
 	}
 	if (resample) {
-		rxgpu_prof_begin("fm_resample");
+		rxgpu_prof_begin_on("fm_resample", st);
 		RX_K(rxk_fm_resample(st, audio, M, p->rate_out, p->rate_out2, J, d_out, s->dev));
-		rxgpu_prof_end("fm_resample");
+		rxgpu_prof_end_on("fm_resample", st);
 	} else if (!(p->deemph && M) && M) {
 		/* neither stage: the discriminator output is the result */
 		RX_HIP(hipMemcpyAsync(d_out, s->pcm, M * 2, hipMemcpyDeviceToDevice, st));
@@ -269,153 +310,223 @@ static int run_audio_stages(rxgpu_fm_stream *s, unsigned long long M, unsigned l
 	return RXGPU_OK;
 }
 
-int rxgpu_fm_stream_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks, size_t block_len,
-                        int16_t *d_out, size_t out_cap, size_t *out_len, int *block_out_len)
+static int run_geometry(rxgpu_fm_stream *s, size_t n_blocks, size_t block_len, size_t out_cap, struct run_geom *g)
 {
-	hipStream_t st;
-	int rc;
-	if (!s || !d_iq || !d_out || !n_blocks || block_len < 2 || (block_len & 1))
-		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_fm_stream_run: bad arguments");
-	if ((rc = rxgpu_ensure_init()) != RXGPU_OK)
-		return rc;
-	st = rxgpu_hip_stream();
 	const rxgpu_fm_params *p = &s->p;
-	const unsigned long long n = block_len / 2;              /* complex samples per block */
-	const unsigned long long T = n * n_blocks;
-	if (T > s->max_T)
-		return rxgpu_fail(RXGPU_ECAPACITY, "stream created for %zu samples, run asks %llu", s->max_T, T);
-	const int passes = p->downsample_passes;
-	const int ds = passes ? 1 : p->downsample;
-	const int p0 = passes ? 0 : s->carry.prev_index;
-	const int rotate = !p->prescaled && !p->offset_tuning;
-	unsigned long long M, K = 0;
-	if (passes) {
-		if (n % (1ull << passes))
-			return rxgpu_fail(RXGPU_EUNSUPPORTED, "fifth_order path needs block samples %% 2^passes == 0 (n=%llu, passes=%d)", n, passes);
-		K = n >> passes;
-		if ((n >> (passes - 1)) < 6)
-			return rxgpu_fail(RXGPU_EUNSUPPORTED, "block too short for %d fifth_order passes", passes);
-		M = K * n_blocks;
+	g->n = block_len / 2;                                    /* complex samples per block */
+	g->T = g->n * n_blocks;
+	if (g->T > s->max_T)
+		return rxgpu_fail(RXGPU_ECAPACITY, "stream created for %zu samples, run asks %llu", s->max_T, g->T);
+	g->passes = p->downsample_passes;
+	g->ds = g->passes ? 1 : p->downsample;
+	g->p0 = g->passes ? 0 : s->h_prev_index;
+	g->pr0 = s->h_prev_lpr_index;
+	g->rotate = !p->prescaled && !p->offset_tuning;
+	g->K = 0;
+	g->fast = 0;
+	if (g->passes) {
+		if (g->n % (1ull << g->passes))
+			return rxgpu_fail(RXGPU_EUNSUPPORTED, "fifth_order path needs block samples %% 2^passes == 0 (n=%llu, passes=%d)", g->n, g->passes);
+		g->K = g->n >> g->passes;
+		if ((g->n >> (g->passes - 1)) < 16)
+			return rxgpu_fail(RXGPU_EUNSUPPORTED, "block too short for %d fifth_order passes", g->passes);
+		g->M = g->K * n_blocks;
 	} else {
-		if (p0 < 0 || p0 >= ds)
-			return rxgpu_fail(RXGPU_EINVAL, "prev_index %d outside [0,%d)", p0, ds);
-		if (n < (unsigned long long)ds)
-			return rxgpu_fail(RXGPU_EUNSUPPORTED, "block of %llu samples shorter than downsample %d", n, ds);
-		M = ((unsigned long long)p0 + T) / (unsigned long long)ds;
+		if (g->p0 < 0 || g->p0 >= g->ds)
+			return rxgpu_fail(RXGPU_EINVAL, "prev_index %d outside [0,%d)", g->p0, g->ds);
+		if (g->n < (unsigned long long)g->ds)
+			return rxgpu_fail(RXGPU_EUNSUPPORTED, "block of %llu samples shorter than downsample %d", g->n, g->ds);
+		g->M = ((unsigned long long)g->p0 + g->T) / (unsigned long long)g->ds;
+		g->fast = g->ds >= 4 && g->ds <= RXK_DEC_MAX_DS && (g->n % 4) == 0;
 	}
-	if (M > s->max_M)
-		return rxgpu_fail(RXGPU_ECAPACITY, "workspace too small for %llu decimated samples", M);
-	if (!M)
+	if (g->M > s->max_M)
+		return rxgpu_fail(RXGPU_ECAPACITY, "workspace too small for %llu decimated samples", g->M);
+	if (!g->M)
 		return rxgpu_fail(RXGPU_EUNSUPPORTED, "run produces no decimated sample");
-	/* result sizes, closed form */
-	const int resample = p->rate_out2 > 0;
-	unsigned long long J = M;
-	if (resample) {
-		if (s->carry.prev_lpr_index < 0 || s->carry.prev_lpr_index >= p->rate_out)
-			return rxgpu_fail(RXGPU_EINVAL, "prev_lpr_index %d outside [0,rate_out)", s->carry.prev_lpr_index);
-		J = ((unsigned long long)s->carry.prev_lpr_index + M * (unsigned long long)p->rate_out2) / (unsigned long long)p->rate_out;
+	g->J = g->M;
+	if (p->rate_out2 > 0) {
+		if (g->pr0 < 0 || g->pr0 >= p->rate_out)
+			return rxgpu_fail(RXGPU_EINVAL, "prev_lpr_index %d outside [0,rate_out)", g->pr0);
+		g->J = ((unsigned long long)g->pr0 + g->M * (unsigned long long)p->rate_out2) / (unsigned long long)p->rate_out;
 	}
-	if (J > out_cap)
-		return rxgpu_fail(RXGPU_ECAPACITY, "output needs %llu int16, capacity %zu", J, out_cap);
+	if (g->J > out_cap)
+		return rxgpu_fail(RXGPU_ECAPACITY, "output needs %llu int16, capacity %zu", g->J, out_cap);
+	return RXGPU_OK;
+}
+
+static void block_lengths(const rxgpu_fm_stream *s, const struct run_geom *g, size_t n_blocks, int *block_out_len)
+{
+	const rxgpu_fm_params *p = &s->p;
+	unsigned long long j_prev = 0;
+	for (size_t b = 0; b < n_blocks; b++) {
+		unsigned long long cum = g->passes ? g->K * (b + 1) : ((unsigned long long)g->p0 + g->n * (b + 1)) / (unsigned long long)g->ds;
+		unsigned long long jj = p->rate_out2 > 0 ? ((unsigned long long)g->pr0 + cum * (unsigned long long)p->rate_out2) / (unsigned long long)p->rate_out : cum;
+		block_out_len[b] = (int)(jj - j_prev);
+		j_prev = jj;
+	}
+}
+
+/* Enqueue one run.  The HBM-bound decimator goes on stream A, everything after it (1/ds of the
+ * data, latency-bound) on stream B behind an event, so that the next run's decimator overlaps
+ * this run's audio stages.  Carries stay on the device between chained runs. */
+static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks, size_t block_len,
+                       int16_t *d_out, const struct run_geom *g)
+{
+	hipStream_t sa = rxgpu_hip_stream(), sb = rxgpu_hip_stream2();
+	const rxgpu_fm_params *p = &s->p;
+	const int db = s->db;
+	rxk_fm_dev *h = s->dev_host;
 	if (p->deemph)
 		deemph_geometry(s);
 
-	/* carries in, status cleared */
-	rxk_fm_dev *h = s->dev_host;
-	memset(h, 0, sizeof(*h));
-	h->in_now_r = s->carry.now_r; h->in_now_j = s->carry.now_j; h->in_prev_index = s->carry.prev_index;
-	h->in_pre_r = s->carry.pre_r; h->in_pre_j = s->carry.pre_j;
-	h->in_deemph_avg = s->carry.deemph_avg;
-	h->in_now_lpr = s->carry.now_lpr; h->in_prev_lpr_index = s->carry.prev_lpr_index;
-	h->out_now_r = h->in_now_r; h->out_now_j = h->in_now_j; h->out_prev_index = h->in_prev_index;
-	RX_HIP(hipMemcpyAsync(s->dev, h, sizeof(*h), hipMemcpyHostToDevice, st));
-
-	const uint32_t *lp_final = s->lp;
-	if (!passes) {
-		const int fast = ds >= 4 && ds <= RXK_DEC_MAX_DS && (n % 4) == 0;
-		if (fast) {
-			rxgpu_prof_begin("fm_decimate");
-			RX_K(rxk_fm_decimate(st, d_iq, T, ds, p0, p->prescaled, rotate, s->lp_raw, s->head, s->tail));
-			rxgpu_prof_end("fm_decimate");
-		} else {
-			rxgpu_prof_begin("fm_decimate_generic");
-			RX_K(rxk_fm_decimate_generic(st, d_iq, T, ds, p0, n, p->prescaled, rotate, s->dev, s->lp, M));
-			rxgpu_prof_end("fm_decimate_generic");
+	if (!s->chained) {
+		/* carries in from the host copy, status cleared */
+		memset(h, 0, sizeof(*h));
+		h->in_now_r = s->carry.now_r; h->in_now_j = s->carry.now_j; h->in_prev_index = s->carry.prev_index;
+		h->in_pre_r = s->carry.pre_r; h->in_pre_j = s->carry.pre_j;
+		h->in_deemph_avg = s->carry.deemph_avg;
+		h->in_now_lpr = s->carry.now_lpr; h->in_prev_lpr_index = s->carry.prev_lpr_index;
+		h->out_now_r = h->in_now_r; h->out_now_j = h->in_now_j; h->out_prev_index = h->in_prev_index;
+		RX_HIP(hipMemcpyAsync(s->dev, h, sizeof(*h), hipMemcpyHostToDevice, sb));
+		if (g->passes) {
+			int16_t *hh = s->hist_host;
+			for (int i = 0; i < 10; i++) {
+				memcpy(hh + HIST_CAS_IN + i * 12, s->carry.lp_i_hist[i], 12);
+				memcpy(hh + HIST_CAS_IN + i * 12 + 6, s->carry.lp_q_hist[i], 12);
+			}
+			memcpy(hh + HIST_DROOP_IN, s->carry.droop_i_hist, 18);
+			memcpy(hh + HIST_DROOP_IN + 9, s->carry.droop_q_hist, 18);
+			RX_HIP(hipMemcpyAsync(s->hist_dev, hh, HIST_TOTAL * 2, hipMemcpyHostToDevice, sb));
 		}
-		rxgpu_prof_begin("fm_disc");
-		RX_K(rxk_fm_disc(st, d_iq, T, ds, p0, n, p->prescaled, rotate, fast, fast ? s->lp_raw : s->lp, s->head, s->tail, s->lp, M,
-		                 RXK_FIRST_LOWPASS, 0, p->custom_atan, 1, s->pcm, s->dev, s->flag_list));
-		rxgpu_prof_end("fm_disc");
 	} else {
-		/* F3: cascade, one launch per pass; F12 optional */
-		int16_t *hh = s->hist_host;
-		for (int i = 0; i < 10; i++) {
-			memcpy(hh + HIST_CAS_IN + i * 12, s->carry.lp_i_hist[i], 12);
-			memcpy(hh + HIST_CAS_IN + i * 12 + 6, s->carry.lp_q_hist[i], 12);
+		/* carries out of the previous run become this run's carries in, on the device */
+		RX_K(rxk_fm_carry_advance(sb, s->dev));
+		if (g->passes) {
+			RX_HIP(hipMemcpyAsync(s->hist_dev + HIST_CAS_IN, s->hist_dev + HIST_CAS_OUT, 10 * 12 * 2, hipMemcpyDeviceToDevice, sb));
+			if (p->comp_fir_size == 9)
+				RX_HIP(hipMemcpyAsync(s->hist_dev + HIST_DROOP_IN, s->hist_dev + HIST_DROOP_OUT, 18 * 2, hipMemcpyDeviceToDevice, sb));
 		}
-		memcpy(hh + HIST_DROOP_IN, s->carry.droop_i_hist, 18);
-		memcpy(hh + HIST_DROOP_IN + 9, s->carry.droop_q_hist, 18);
-		RX_HIP(hipMemcpyAsync(s->hist_dev, hh, HIST_TOTAL * 2, hipMemcpyHostToDevice, st));
-		rxgpu_prof_begin("fm_fifth");
+	}
+
+	s->lp_final = s->lp;
+	if (!g->passes) {
+		if (g->fast) {
+			/* buffer set `db` was last read by the audio chain two runs ago */
+			if (s->ev_small_valid[db])
+				RX_HIP(hipStreamWaitEvent(sa, s->ev_small[db], 0));
+			rxgpu_prof_begin_on("fm_decimate", sa);
+			RX_K(rxk_fm_decimate(sa, d_iq, g->T, g->ds, g->p0, p->prescaled, g->rotate, s->lp_raw[db], s->head[db], s->tail[db]));
+			rxgpu_prof_end_on("fm_decimate", sa);
+			RX_HIP(hipEventRecord(s->ev_dec[db], sa));
+			RX_HIP(hipStreamWaitEvent(sb, s->ev_dec[db], 0));
+		} else {
+			rxgpu_prof_begin_on("fm_decimate_generic", sb);
+			RX_K(rxk_fm_decimate_generic(sb, d_iq, g->T, g->ds, g->p0, g->n, p->prescaled, g->rotate, s->dev, s->lp, g->M));
+			rxgpu_prof_end_on("fm_decimate_generic", sb);
+		}
+		rxgpu_prof_begin_on("fm_disc", sb);
+		RX_K(rxk_fm_disc(sb, d_iq, g->T, g->ds, g->p0, g->n, p->prescaled, g->rotate, g->fast, g->fast ? s->lp_raw[db] : s->lp,
+		                 s->head[db], s->tail[db], s->lp, g->M, RXK_FIRST_LOWPASS, 0, p->custom_atan, 1, s->pcm, s->dev, s->flag_list));
+		rxgpu_prof_end_on("fm_disc", sb);
+	} else {
+		/* F3: cascade (first passes fused where the input is raw), F12 optional; all on stream B */
+		const int passes = g->passes;
+		rxgpu_prof_begin_on("fm_fifth", sb);
 		const void *src = d_iq;
-		unsigned n_in = (unsigned)n, in_stride = (unsigned)n;
+		unsigned n_in = (unsigned)g->n, in_stride = (unsigned)g->n;
 		int first_pass = 0;
-		if (!p->prescaled && (n % RXK_FIFTH_TILE) == 0) {
-			/* the first up-to-three passes fused in LDS (raw input only: packed int16 maths is exact there) */
+		if (!p->prescaled && (g->n % RXK_FIFTH_TILE) == 0) {
 			const int fuse = passes < 3 ? passes : 3;
 			uint32_t *dst = s->cas[(fuse - 1) & 1];
-			RX_K(rxk_fm_fifth_fused(st, d_iq, rotate, n_blocks, (unsigned)n, fuse, s->hist_dev + HIST_CAS_IN,
+			RX_K(rxk_fm_fifth_fused(sb, d_iq, g->rotate, n_blocks, (unsigned)g->n, fuse, s->hist_dev + HIST_CAS_IN,
 			                        s->hist_dev + HIST_CAS_OUT, s->seams, dst));
 			src = dst;
-			n_in = (unsigned)(n >> fuse);
+			n_in = (unsigned)(g->n >> fuse);
 			in_stride = n_in;
 			first_pass = fuse;
 		}
 		for (int i = first_pass; i < passes; i++) {
 			uint32_t *dst = s->cas[i & 1];
 			unsigned n_out = n_in / 2;
-			RX_K(rxk_fm_fifth_pass(st, src, i == 0, p->prescaled, rotate, n_blocks, n_in, in_stride, dst, n_out,
+			RX_K(rxk_fm_fifth_pass(sb, src, i == 0, p->prescaled, g->rotate, n_blocks, n_in, in_stride, dst, n_out,
 			                       s->hist_dev + HIST_CAS_IN + i * 12, s->hist_dev + HIST_CAS_OUT + i * 12));
 			src = dst;
 			n_in = n_out;
 			in_stride = n_out;
 		}
-		rxgpu_prof_end("fm_fifth");
-		lp_final = (const uint32_t *)src;            /* [n_blocks][K] contiguous == M samples */
+		rxgpu_prof_end_on("fm_fifth", sb);
+		s->lp_final = (const uint32_t *)src;             /* [n_blocks][K] contiguous == M samples */
 		if (p->comp_fir_size == 9) {
-			RX_HIP(hipMemcpyAsync(s->fir_dev, cic_9_tables[passes], 10 * sizeof(int), hipMemcpyHostToDevice, st));
-			rxgpu_prof_begin("fm_droop");
-			RX_K(rxk_fm_droop(st, lp_final, M, s->fir_dev, s->hist_dev + HIST_DROOP_IN, s->hist_dev + HIST_DROOP_OUT, s->lp));
-			rxgpu_prof_end("fm_droop");
-			lp_final = s->lp;
+			RX_HIP(hipMemcpyAsync(s->fir_dev, cic_9_tables[passes], 10 * sizeof(int), hipMemcpyHostToDevice, sb));
+			rxgpu_prof_begin_on("fm_droop", sb);
+			RX_K(rxk_fm_droop(sb, s->lp_final, g->M, s->fir_dev, s->hist_dev + HIST_DROOP_IN, s->hist_dev + HIST_DROOP_OUT, s->lp));
+			rxgpu_prof_end_on("fm_droop", sb);
+			s->lp_final = s->lp;
 		}
-		rxgpu_prof_begin("fm_disc");
-		RX_K(rxk_fm_disc(st, d_iq, T, 1, 0, n, p->prescaled, rotate, 0, lp_final, NULL, NULL, NULL, M,
-		                 RXK_FIRST_UNIFORM, K, p->custom_atan, 0, s->pcm, s->dev, s->flag_list));
-		rxgpu_prof_end("fm_disc");
-		RX_HIP(hipMemcpyAsync(hh, s->hist_dev, HIST_TOTAL * 2, hipMemcpyDeviceToHost, st));
+		rxgpu_prof_begin_on("fm_disc", sb);
+		RX_K(rxk_fm_disc(sb, d_iq, g->T, 1, 0, g->n, p->prescaled, g->rotate, 0, s->lp_final, NULL, NULL, NULL, g->M,
+		                 RXK_FIRST_UNIFORM, g->K, p->custom_atan, 0, s->pcm, s->dev, s->flag_list));
+		rxgpu_prof_end_on("fm_disc", sb);
 	}
-
-	if ((rc = run_audio_stages(s, M, J, d_out)) != RXGPU_OK)
+	int rc = run_audio_stages(s, sb, g->M, g->J, d_out);
+	if (rc != RXGPU_OK)
 		return rc;
-	RX_HIP(hipMemcpyAsync(h, s->dev, sizeof(*h), hipMemcpyDeviceToHost, st));
-	RX_HIP(hipStreamSynchronize(st));
+	if (!g->passes && g->fast) {
+		RX_HIP(hipEventRecord(s->ev_small[db], sb));
+		s->ev_small_valid[db] = 1;
+		s->db ^= 1;
+	}
+	/* what the next run needs from this one on the host side is closed-form */
+	if (!g->passes)
+		s->h_prev_index = (int)(((unsigned long long)g->p0 + g->T) - g->M * (unsigned long long)g->ds);
+	if (p->rate_out2 > 0)
+		s->h_prev_lpr_index = (int)((unsigned long long)g->pr0 + g->M * (unsigned long long)p->rate_out2 - g->J * (unsigned long long)p->rate_out);
+	s->chained = 1;
+	s->pending++;
+	s->last = *g;
+	s->last_out = d_out;
+	return RXGPU_OK;
+}
 
+/* Wait for everything enqueued, read the carries back, settle undecided libm samples. */
+static int finish_runs(rxgpu_fm_stream *s)
+{
+	hipStream_t sa = rxgpu_hip_stream(), sb = rxgpu_hip_stream2();
+	rxk_fm_dev *h = s->dev_host;
+	const rxgpu_fm_params *p = &s->p;
+	int rc;
+	if (!s->pending)
+		return RXGPU_OK;
+	const struct run_geom *g = &s->last;
+	if (g->passes)
+		RX_HIP(hipMemcpyAsync(s->hist_host, s->hist_dev, HIST_TOTAL * 2, hipMemcpyDeviceToHost, sb));
+	RX_HIP(hipMemcpyAsync(h, s->dev, sizeof(*h), hipMemcpyDeviceToHost, sb));
+	RX_HIP(hipStreamSynchronize(sb));
+	RX_HIP(hipStreamSynchronize(sa));
+	const int n_pending = s->pending;
+	s->pending = 0;
+	s->chained = 0;
 	s->fixups = 0;
 	if (h->flag_cnt) {
-		/* libm-discriminator samples the device could not decide: re-evaluate with the host libm
-		 * (the one the reference uses), patch pcm[], redo the audio stages */
+		/* libm-discriminator samples the device could not decide: re-evaluate them with the host libm
+		 * (the one the reference uses), patch pcm[], redo the audio stages.  Only possible when the
+		 * flagged run is the only one in flight; a pipelined sequence is rolled back instead. */
 		int cnt = h->flag_cnt;
-		if (cnt > RXK_FLAG_CAP)
-			return rxgpu_fail(RXGPU_EUNSUPPORTED, "%d undecided libm discriminator samples (cap %d)", cnt, RXK_FLAG_CAP);
+		if (n_pending > 1 || cnt > RXK_FLAG_CAP) {
+			s->carry = s->carry_at_enqueue;
+			s->h_prev_index = s->carry.prev_index;
+			s->h_prev_lpr_index = s->carry.prev_lpr_index;
+			return rxgpu_fail(RXGPU_EUNSUPPORTED, "%d undecided libm discriminator samples in %d pipelined runs: carries rolled back, "
+			                  "re-run these blocks one rxgpu_fm_stream_run at a time", cnt, n_pending);
+		}
 		RX_HIP(hipMemcpy(s->flag_host, s->flag_list, (size_t)cnt * 8, hipMemcpyDeviceToHost));
 		for (int i = 0; i < cnt; i++) {
 			unsigned long long m = s->flag_host[i];
 			uint32_t a, b;
 			int br, bj;
-			RX_HIP(hipMemcpy(&a, lp_final + m, 4, hipMemcpyDeviceToHost));
+			RX_HIP(hipMemcpy(&a, s->lp_final + m, 4, hipMemcpyDeviceToHost));
 			if (m) {
-				RX_HIP(hipMemcpy(&b, lp_final + m - 1, 4, hipMemcpyDeviceToHost));
+				RX_HIP(hipMemcpy(&b, s->lp_final + m - 1, 4, hipMemcpyDeviceToHost));
 				br = (int16_t)(b & 0xffff); bj = (int16_t)(b >> 16);
 			} else {
 				br = s->carry.pre_r; bj = s->carry.pre_j;
@@ -425,23 +536,22 @@ int rxgpu_fm_stream_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks
 		}
 		s->fixups = cnt;
 		h->flag_cnt = 0; h->any_unmerged = 0;
-		/* status words only; carries in/out already on the device */
-		RX_HIP(hipMemcpyAsync(&s->dev->flag_cnt, &h->flag_cnt, 2 * sizeof(int), hipMemcpyHostToDevice, st));
-		if ((rc = run_audio_stages(s, M, J, d_out)) != RXGPU_OK)
+		RX_HIP(hipMemcpyAsync(&s->dev->flag_cnt, &h->flag_cnt, 2 * sizeof(int), hipMemcpyHostToDevice, sb));
+		if ((rc = run_audio_stages(s, sb, g->M, g->J, s->last_out)) != RXGPU_OK)
 			return rc;
-		RX_HIP(hipMemcpyAsync(h, s->dev, sizeof(*h), hipMemcpyDeviceToHost, st));
-		RX_HIP(hipStreamSynchronize(st));
+		RX_HIP(hipMemcpyAsync(h, s->dev, sizeof(*h), hipMemcpyDeviceToHost, sb));
+		RX_HIP(hipStreamSynchronize(sb));
 	}
 	rxgpu_prof_collect();
 	if (h->err)
 		return rxgpu_fail(RXGPU_ENODEV, "device-side invariant violated in the de-emphasis scan (err=%d)", h->err);
 
 	/* carries out */
-	if (!passes) {
+	if (!g->passes) {
 		s->carry.now_r = h->out_now_r; s->carry.now_j = h->out_now_j; s->carry.prev_index = h->out_prev_index;
 	} else {
 		const int16_t *hh = s->hist_host;
-		for (int i = 0; i < passes; i++) {
+		for (int i = 0; i < g->passes; i++) {
 			memcpy(s->carry.lp_i_hist[i], hh + HIST_CAS_OUT + i * 12, 12);
 			memcpy(s->carry.lp_q_hist[i], hh + HIST_CAS_OUT + i * 12 + 6, 12);
 		}
@@ -451,24 +561,54 @@ int rxgpu_fm_stream_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks
 		}
 	}
 	s->carry.pre_r = h->out_pre_r; s->carry.pre_j = h->out_pre_j;
-	const int pr0 = s->carry.prev_lpr_index;
 	s->carry.deemph_avg = h->out_deemph_avg;
 	s->carry.now_lpr = h->out_now_lpr; s->carry.prev_lpr_index = h->out_prev_lpr_index;
-
-	if (out_len)
-		*out_len = (size_t)J;
-	if (block_out_len) {
-		unsigned long long cum_prev = 0, j_prev = 0;
-		for (size_t b = 0; b < n_blocks; b++) {
-			unsigned long long cum = passes ? K * (b + 1) : ((unsigned long long)p0 + n * (b + 1)) / (unsigned long long)ds;
-			unsigned long long jj = resample ? ((unsigned long long)pr0 + cum * (unsigned long long)p->rate_out2) / (unsigned long long)p->rate_out : cum;
-			block_out_len[b] = (int)(jj - j_prev);
-			(void)cum_prev;
-			cum_prev = cum;
-			j_prev = jj;
-		}
-	}
+	s->h_prev_index = s->carry.prev_index;
+	s->h_prev_lpr_index = s->carry.prev_lpr_index;
 	return RXGPU_OK;
+}
+
+int rxgpu_fm_stream_run_async(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks, size_t block_len,
+                              int16_t *d_out, size_t out_cap, size_t *out_len, int *block_out_len)
+{
+	int rc;
+	struct run_geom g;
+	if (!s || !d_iq || !d_out || !n_blocks || block_len < 2 || (block_len & 1))
+		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_fm_stream_run: bad arguments");
+	if ((rc = rxgpu_ensure_init()) != RXGPU_OK)
+		return rc;
+	if (!s->pending) {
+		s->carry_at_enqueue = s->carry;
+		s->h_prev_index = s->carry.prev_index;
+		s->h_prev_lpr_index = s->carry.prev_lpr_index;
+	}
+	if ((rc = run_geometry(s, n_blocks, block_len, out_cap, &g)) != RXGPU_OK)
+		return rc;
+	if ((rc = enqueue_run(s, d_iq, n_blocks, block_len, d_out, &g)) != RXGPU_OK)
+		return rc;
+	if (out_len)
+		*out_len = (size_t)g.J;
+	if (block_out_len)
+		block_lengths(s, &g, n_blocks, block_out_len);
+	return RXGPU_OK;
+}
+
+int rxgpu_fm_stream_wait(rxgpu_fm_stream *s)
+{
+	if (!s)
+		return rxgpu_fail(RXGPU_EINVAL, "null stream");
+	return finish_runs(s);
+}
+
+int rxgpu_fm_stream_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks, size_t block_len,
+                        int16_t *d_out, size_t out_cap, size_t *out_len, int *block_out_len)
+{
+	int rc;
+	if (s && s->pending && (rc = finish_runs(s)) != RXGPU_OK)
+		return rc;
+	if ((rc = rxgpu_fm_stream_run_async(s, d_iq, n_blocks, block_len, d_out, out_cap, out_len, block_out_len)) != RXGPU_OK)
+		return rc;
+	return finish_runs(s);
 }
 
 int rxgpu_fm_stream_run_host(rxgpu_fm_stream *s, const int16_t *h_iq, size_t n_blocks, size_t block_len,
@@ -582,6 +722,7 @@ void rxgpu_full_demod(struct demod_state *d)
 	c.deemph_avg = g_side[slot].avg;
 	c.now_lpr = d->now_lpr; c.prev_lpr_index = d->prev_lpr_index;
 	rxgpu_fm_stream_set_carry(s, &c);
+	const int c_in_prev_index = c.prev_index;
 	size_t got = 0;
 	if (rxgpu_fm_stream_run_host(s, d->lowpassed, 1, (size_t)d->lp_len, d->result, RXGPU_MAXIMUM_BUF_LENGTH, &got, NULL) != RXGPU_OK)
 		die("rxgpu_full_demod");
@@ -590,10 +731,8 @@ void rxgpu_full_demod(struct demod_state *d)
 	{
 		int passes = d->downsample_passes;
 		unsigned long long n = (unsigned long long)d->lp_len / 2;
-		unsigned long long M = passes ? (n >> passes) : ((unsigned long long)d->prev_index + n) / (unsigned long long)d->downsample;
-		const uint32_t *src = s->lp;
-		if (passes && d->comp_fir_size != 9)
-			src = s->cas[(passes - 1) & 1];
+		unsigned long long M = passes ? (n >> passes) : ((unsigned long long)c_in_prev_index + n) / (unsigned long long)d->downsample;
+		const uint32_t *src = s->lp_final;
 		if (hipMemcpy(d->lowpassed, src, M * 4, hipMemcpyDeviceToHost) != hipSuccess) {
 			rxgpu_fail(RXGPU_ENODEV, "copy of decimated IQ failed");
 			die("rxgpu_full_demod");

@@ -17,6 +17,7 @@ int rxgpu_fail(int code, const char *fmt, ...);
 /* make sure rxgpu_init ran (auto-initialises with device -1) */
 int rxgpu_ensure_init(void);
 hipStream_t rxgpu_hip_stream(void);
+hipStream_t rxgpu_hip_stream2(void);   /* second stream: the latency-bound tail of a pipelined rx_fm run */
 
 #define RX_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
 	return rxgpu_fail(RXGPU_ENODEV, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
@@ -24,8 +25,10 @@ hipStream_t rxgpu_hip_stream(void);
 	return rxgpu_fail(RXGPU_ENODEV, "%s launch failed: %s (%s:%d)", #call, hipGetErrorString((hipError_t)e_), __FILE__, __LINE__); } while (0)
 
 /* kernel timing: bracket launches with events when profiling is on */
-void rxgpu_prof_begin(const char *name);
-void rxgpu_prof_end(const char *name);
+void rxgpu_prof_begin_on(const char *name, hipStream_t st);
+void rxgpu_prof_end_on(const char *name, hipStream_t st);
+#define rxgpu_prof_begin(name) rxgpu_prof_begin_on((name), rxgpu_hip_stream())
+#define rxgpu_prof_end(name) rxgpu_prof_end_on((name), rxgpu_hip_stream())
 /* fold finished event pairs into the totals (call after a stream sync) */
 void rxgpu_prof_collect(void);
 

@@ -6,7 +6,7 @@
 #include <string.h>
 
 static int g_device = -1;
-static hipStream_t g_stream;
+static hipStream_t g_stream, g_stream2;
 static char g_err[512];
 
 int rxgpu_fail(int code, const char *fmt, ...)
@@ -47,6 +47,7 @@ int rxgpu_init(int device)
 		return rxgpu_fail(RXGPU_ENODEV, "device %d requested but only %d visible", device, n);
 	RX_HIP(hipSetDevice(device));
 	RX_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+	RX_HIP(hipStreamCreateWithFlags(&g_stream2, hipStreamNonBlocking));
 	g_device = device;
 	return RXGPU_OK;
 }
@@ -56,9 +57,11 @@ void rxgpu_shutdown(void)
 	if (g_device < 0)
 		return;
 	hipStreamSynchronize(g_stream);
+	hipStreamSynchronize(g_stream2);
 	rxgpu_prof_reset();
 	hipStreamDestroy(g_stream);
-	g_stream = NULL;
+	hipStreamDestroy(g_stream2);
+	g_stream = g_stream2 = NULL;
 	g_device = -1;
 }
 
@@ -70,6 +73,7 @@ int rxgpu_ensure_init(void)
 }
 
 hipStream_t rxgpu_hip_stream(void) { return g_stream; }
+hipStream_t rxgpu_hip_stream2(void) { return g_stream2; }
 void *rxgpu_stream(void) { return (void *)g_stream; }
 
 int rxgpu_sync(void)
@@ -77,6 +81,7 @@ int rxgpu_sync(void)
 	if (g_device < 0)
 		return rxgpu_fail(RXGPU_ENODEV, "rxgpu_sync before rxgpu_init");
 	RX_HIP(hipStreamSynchronize(g_stream));
+	RX_HIP(hipStreamSynchronize(g_stream2));
 	rxgpu_prof_collect();
 	return RXGPU_OK;
 }
@@ -129,7 +134,7 @@ static int prof_wanted(const char *name)
 	return !strcmp(name, "fm_decimate") || !strcmp(name, "pw_fft") || !strcmp(name, "fm_fifth");
 }
 
-void rxgpu_prof_begin(const char *name)
+void rxgpu_prof_begin_on(const char *name, hipStream_t st)
 {
 	if (!g_prof_on || g_npend == PROF_PENDING || !prof_wanted(name))
 		return;
@@ -139,10 +144,10 @@ void rxgpu_prof_begin(const char *name)
 		return;
 	p->a = prof_event();
 	p->b = NULL;
-	hipEventRecord(p->a, g_stream);
+	hipEventRecord(p->a, st);
 }
 
-void rxgpu_prof_end(const char *name)
+void rxgpu_prof_end_on(const char *name, hipStream_t st)
 {
 	if (!g_prof_on || g_npend == PROF_PENDING || !prof_wanted(name))
 		return;
@@ -150,7 +155,7 @@ void rxgpu_prof_end(const char *name)
 	if (p->slot < 0 || !p->a)
 		return;
 	p->b = prof_event();
-	hipEventRecord(p->b, g_stream);
+	hipEventRecord(p->b, st);
 	g_npend++;
 	if (g_npend < PROF_PENDING) {
 		g_pend[g_npend].a = NULL;
@@ -179,6 +184,7 @@ void rxgpu_prof_reset(void)
 {
 	if (g_device >= 0 && g_npend) {
 		hipStreamSynchronize(g_stream);
+		hipStreamSynchronize(g_stream2);
 		rxgpu_prof_collect();
 	}
 	g_ntot = 0;
@@ -188,6 +194,7 @@ int rxgpu_prof_get(const char *name, double *total_ms, long *launches)
 {
 	if (g_device >= 0 && g_npend) {
 		hipStreamSynchronize(g_stream);
+		hipStreamSynchronize(g_stream2);
 		rxgpu_prof_collect();
 	}
 	for (int i = 0; i < g_ntot; i++)

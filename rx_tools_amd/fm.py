@@ -65,6 +65,16 @@ class FmStream:
         check(lib().rxgpu_fm_stream_run(self._h, d_iq_ptr, n_blocks, block_len, d_out_ptr, out_cap, C.byref(n), lens))
         return n.value, (list(lens) if lens is not None else None)
 
+    def run_async(self, d_iq_ptr, n_blocks, block_len, d_out_ptr, out_cap, want_block_lens=False):
+        """Enqueue and return (pipelined with the previous run); call wait() before reading results."""
+        n = C.c_size_t(0)
+        lens = (C.c_int * n_blocks)() if want_block_lens else None
+        check(lib().rxgpu_fm_stream_run_async(self._h, d_iq_ptr, n_blocks, block_len, d_out_ptr, out_cap, C.byref(n), lens))
+        return n.value, (list(lens) if lens is not None else None)
+
+    def wait(self):
+        check(lib().rxgpu_fm_stream_wait(self._h))
+
     def run_host(self, h_iq_ptr, n_blocks, block_len, h_out_ptr, out_cap, want_block_lens=False):
         n = C.c_size_t(0)
         lens = (C.c_int * n_blocks)() if want_block_lens else None

@@ -34,7 +34,7 @@ def carry_tuple(c):
             bytes(c.lp_i_hist), bytes(c.lp_q_hist), bytes(c.droop_i_hist), bytes(c.droop_q_hist))
 
 
-def gpu_fm_stream(iq, block_len, n_runs=1, carry=None, **params):
+def gpu_fm_stream(iq, block_len, n_runs=1, carry=None, pipelined=False, **params):
     """Run iq (int16 numpy) through rxgpu_fm_stream_run in n_runs consecutive calls.
     Returns (out int16, per-block lens, final carry)."""
     torch = torch_cuda()
@@ -50,12 +50,22 @@ def gpu_fm_stream(iq, block_len, n_runs=1, carry=None, **params):
     d_out = torch.zeros(len(iq) // 2 + 64, dtype=torch.int16, device="cuda")
     outs, lens = [], []
     b = 0
+    pos = 0
     while b < n_blocks:
         nb = min(per, n_blocks - b)
-        n, bl = s.run(d_iq.data_ptr() + b * block_len * 2, nb, block_len, d_out.data_ptr(), d_out.numel(), True)
-        outs.append(d_out[:n].cpu().numpy().copy())
+        if pipelined:
+            # enqueue everything back to back (run r+1's decimator overlaps run r's audio stages), then wait once
+            n, bl = s.run_async(d_iq.data_ptr() + b * block_len * 2, nb, block_len, d_out.data_ptr() + 2 * pos,
+                                d_out.numel() - pos, True)
+            pos += n
+        else:
+            n, bl = s.run(d_iq.data_ptr() + b * block_len * 2, nb, block_len, d_out.data_ptr(), d_out.numel(), True)
+            outs.append(d_out[:n].cpu().numpy().copy())
         lens += bl
         b += nb
+    if pipelined:
+        s.wait()
+        outs.append(d_out[:pos].cpu().numpy().copy())
     c = s.get_carry()
     fix = s.host_fixups
     s.close()

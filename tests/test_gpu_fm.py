@@ -20,10 +20,10 @@ def _signals(n_int16):
     }
 
 
-def _check(iq, block_len, n_runs=1, **params):
+def _check(iq, block_len, n_runs=1, pipelined=False, **params):
     from gpu_support import gpu_fm_stream, carry_tuple, carry_from_oracle_state
     want, want_lens, st = oracle_fm_stream(iq, block_len, **params)
-    got, got_lens, carry, _ = gpu_fm_stream(iq, block_len, n_runs=n_runs, **params)
+    got, got_lens, carry, _ = gpu_fm_stream(iq, block_len, n_runs=n_runs, pipelined=pipelined, **params)
     assert len(got) == len(want)
     bad = np.nonzero(got != want)[0]
     assert bad.size == 0, "first mismatch at %d: got %d want %d (%d bad of %d)" % (
@@ -63,6 +63,21 @@ def test_carry_across_runs(n_runs):
     iq = sig_fm(20 * 8192, seed=1)
     _check(iq, 16384, n_runs=n_runs, downsample=118)
     _check(sig_noise(20 * 16384, seed=3), 16384, n_runs=n_runs, downsample=6)
+
+
+@pytest.mark.parametrize("params", [dict(downsample=118), dict(downsample=6), dict(downsample=7, deemph=0),
+                                    dict(downsample_passes=3, comp_fir_size=9), dict(downsample=3)])
+def test_pipelined_runs(params):
+    """rxgpu_fm_stream_run_async x7 + one wait == the oracle: carries chained on the device, the
+    decimator of run r+1 overlapping the audio stages of run r on a second stream"""
+    for iq in (sig_fm(28 * 8192, seed=77), sig_noise(28 * 16384, seed=78)):
+        carry, st = _check(iq, 16384, n_runs=7, pipelined=True, **params)
+        if params.get("downsample_passes"):
+            from gpu_support import carry_tuple, carry_from_oracle_state
+            p = params["downsample_passes"]
+            want, got = carry_tuple(carry_from_oracle_state(st)), carry_tuple(carry)
+            assert got[8][:12 * p] == want[8][:12 * p] and got[9][:12 * p] == want[9][:12 * p]
+            assert got[10] == want[10] and got[11] == want[11]
 
 
 @pytest.mark.parametrize("params", [
