@@ -83,10 +83,16 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
 // sample of a boxcar window drops the prefix at that point into an LDS slot.  After a
 // barrier, output j = slot[j] - slot[j-1].  The window that straddles the workgroup start
 // is finished by rxk_fm_disc from head[]/tail[].
-template <bool PRESCALED, bool ROTATE>
+__device__ __forceinline__ int fast_atan2_dev(int y, int x);
+
+// DISC: also run the -A fast discriminator (F5/F6) for every output whose predecessor was completed
+// by this workgroup too (all but its first two), while the sums are still in LDS/registers; the
+// two seam outputs per workgroup and each block's libm sample are left to k_fm_disc.
+template <bool PRESCALED, bool ROTATE, bool DISC>
 __global__ __launch_bounds__(DEC_THREADS) void k_fm_decimate(
 	const u32x4 *__restrict__ iq, u64 T, int ds, int p0, unsigned magic,
-	uint32_t *__restrict__ lp_raw, uint32_t *__restrict__ head, uint32_t *__restrict__ tail, unsigned slot_cap)
+	uint32_t *__restrict__ lp_raw, uint32_t *__restrict__ head, uint32_t *__restrict__ tail, unsigned slot_cap,
+	int16_t *__restrict__ pcm)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 	uint32_t *slot = lds;
@@ -155,7 +161,18 @@ __global__ __launch_bounds__(DEC_THREADS) void k_fm_decimate(
 		} else {
 			const unsigned wq = (e - (unsigned)ds - 1) / DEC_WAVE_SPAN;
 			const uint32_t pm = pk_add(slot[j - 1], wq == 0 ? 0u : wq == 1 ? b1 : wq == 2 ? b2 : b3);
-			lp_raw[m_base + j] = pk_sub(pj, pm);
+			const uint32_t a = pk_sub(pj, pm);
+			lp_raw[m_base + j] = a;
+			if (DISC && j >= 2) {
+				const unsigned wr = (e - 2 * (unsigned)ds - 1) / DEC_WAVE_SPAN;
+				const uint32_t pmm = pk_add(slot[j - 2], wr == 0 ? 0u : wr == 1 ? b1 : wr == 2 ? b2 : b3);
+				const uint32_t b = pk_sub(pm, pmm);
+				const int ar = lo16(a), aj = hi16(a), br = lo16(b), bj = hi16(b);
+				// multiply(a, conj(b)), rtl_fm.c:470-474 via 511, wrapping like -fwrapv
+				const int cr = (int)((unsigned)ar * (unsigned)br + (unsigned)aj * (unsigned)bj);
+				const int cj = (int)((unsigned)aj * (unsigned)br - (unsigned)ar * (unsigned)bj);
+				pcm[m_base + j] = (int16_t)fast_atan2_dev(cj, cr);
+			}
 		}
 	}
 	if (threadIdx.x == 0) {
@@ -250,9 +267,10 @@ __device__ __forceinline__ uint32_t lp_final(u64 m, int ds, int p0, int seams, c
 template <bool PRESCALED>
 __global__ __launch_bounds__(256) void k_fm_disc(
 	const uint32_t *__restrict__ iq, u64 T, int ds, int p0, u64 n_per_block, int rotate, int seams,
-	const uint32_t *__restrict__ lp_raw, const uint32_t *__restrict__ head, const uint32_t *__restrict__ tail,
-	uint32_t *__restrict__ lp, u64 M, int first_mode, u64 uniform_k, int custom_atan, int do_tail,
-	int16_t *__restrict__ pcm, rxk_fm_dev *__restrict__ dev, u64 *__restrict__ flag_list, unsigned out_blocks)
+	const uint32_t *lp_raw, const uint32_t *__restrict__ head, const uint32_t *__restrict__ tail,
+	uint32_t *lp /* may alias lp_raw: seam entries are finished in place */, u64 M, int first_mode, u64 uniform_k, int custom_atan, int do_tail,
+	int16_t *__restrict__ pcm, rxk_fm_dev *__restrict__ dev, u64 *__restrict__ flag_list, unsigned out_blocks,
+	int sparse, u64 n_wg, u64 n_blocks)
 {
 	if (blockIdx.x >= out_blocks) {
 		// ---- low_pass carry: exact int32 sums of the samples after the last complete window
@@ -277,7 +295,24 @@ __global__ __launch_bounds__(256) void k_fm_disc(
 		}
 		return;
 	}
-	const u64 m = (u64)blockIdx.x * 256 + threadIdx.x;
+	u64 m = (u64)blockIdx.x * 256 + threadIdx.x;
+	if (sparse) {
+		// only what k_fm_decimate<DISC> could not finish: the first two windows ending in each
+		// workgroup span, the first window of each callback block (libm), and the very last one (carry)
+		const u64 t = m;
+		if (t < 2 * n_wg) {
+			const u64 g = t >> 1;
+			m = ((g << RXK_DEC_SPAN_LOG2) + (u64)p0) / (u64)ds + (t & 1);
+			if (m >= M || (((m + 1) * (u64)ds - (u64)p0 - 1) >> RXK_DEC_SPAN_LOG2) != g)
+				return;
+		} else if (t < 2 * n_wg + n_blocks) {
+			m = ((t - 2 * n_wg) * n_per_block + (u64)p0) / (u64)ds;
+		} else if (t == 2 * n_wg + n_blocks) {
+			m = M - 1;
+		} else {
+			return;
+		}
+	}
 	if (m >= M)
 		return;
 	const uint32_t carry = pack_iq(dev->in_now_r, dev->in_now_j);
@@ -562,9 +597,18 @@ __global__ void k_fm_deemph_serial(const int16_t *__restrict__ pcm, u64 M, int a
 // rtl_fm.c:389-409 in closed form.  With phase p0 < fast and slow <= fast, after i inputs
 // floor((p0 + i*slow)/fast) outputs exist, so output j sums inputs [E(j-1), E(j)) with
 // E(j) = ceil(((j+1)*fast - p0) / slow), E(-1) = 0, and is (int16)(sum / (fast/slow)).
+// floor(num / den) for num < 2^52 through one fp64 division and an exact correction
+__device__ __forceinline__ u64 div_floor(u64 num, u64 den)
+{
+	u64 q = (u64)((double)num / (double)den);
+	const i64 r = (i64)(num - q * den);
+	if (r < 0) q--;
+	else if ((u64)r >= den) q++;
+	return q;
+}
 __device__ __forceinline__ u64 lpr_end(u64 j, u64 fast, u64 slow, u64 p0)
 {
-	return ((j + 1) * fast - p0 + slow - 1) / slow;
+	return div_floor((j + 1) * fast - p0 + slow - 1, slow);
 }
 
 __global__ void k_fm_resample(const int16_t *__restrict__ y, u64 n, int fast, int slow, u64 J,
@@ -936,7 +980,7 @@ __global__ void k_fm_prestage(const uint32_t *__restrict__ in, unsigned n, int r
 #define LAUNCH_RET() return (int)hipGetLastError()
 
 extern "C" int rxk_fm_decimate(void *stream, const int16_t *iq, u64 T, int ds, int p0, int prescaled, int rotate,
-                               uint32_t *lp_raw, uint32_t *head, uint32_t *tail)
+                               uint32_t *lp_raw, uint32_t *head, uint32_t *tail, int16_t *pcm)
 {
 	const unsigned grid = (unsigned)((T + RXK_DEC_SPAN - 1) / RXK_DEC_SPAN);
 	const unsigned magic = (unsigned)((1ull << 32) / (unsigned)ds + 1);
@@ -944,12 +988,13 @@ extern "C" int rxk_fm_decimate(void *stream, const int16_t *iq, u64 T, int ds, i
 	const size_t shm = (size_t)(slot_cap + 4) * sizeof(uint32_t);
 	hipStream_t s = (hipStream_t)stream;
 	const u32x4 *p = (const u32x4 *)iq;
-	if (prescaled)
-		hipLaunchKernelGGL((k_fm_decimate<true, false>), dim3(grid), dim3(DEC_THREADS), shm, s, p, T, ds, p0, magic, lp_raw, head, tail, slot_cap);
-	else if (rotate)
-		hipLaunchKernelGGL((k_fm_decimate<false, true>), dim3(grid), dim3(DEC_THREADS), shm, s, p, T, ds, p0, magic, lp_raw, head, tail, slot_cap);
-	else
-		hipLaunchKernelGGL((k_fm_decimate<false, false>), dim3(grid), dim3(DEC_THREADS), shm, s, p, T, ds, p0, magic, lp_raw, head, tail, slot_cap);
+#define GO(PS, RT) do { \
+		if (pcm) hipLaunchKernelGGL((k_fm_decimate<PS, RT, true>), dim3(grid), dim3(DEC_THREADS), shm, s, p, T, ds, p0, magic, lp_raw, head, tail, slot_cap, pcm); \
+		else hipLaunchKernelGGL((k_fm_decimate<PS, RT, false>), dim3(grid), dim3(DEC_THREADS), shm, s, p, T, ds, p0, magic, lp_raw, head, tail, slot_cap, pcm); } while (0)
+	if (prescaled) GO(true, false);
+	else if (rotate) GO(false, true);
+	else GO(false, false);
+#undef GO
 	LAUNCH_RET();
 }
 
@@ -970,19 +1015,20 @@ extern "C" int rxk_fm_decimate_generic(void *stream, const int16_t *iq, u64 T, i
 extern "C" int rxk_fm_disc(void *stream, const int16_t *iq, u64 T, int ds, int p0, u64 n_per_block, int prescaled,
                            int rotate, int seams, const uint32_t *lp_raw, const uint32_t *head, const uint32_t *tail,
                            uint32_t *lp, u64 M, int first_mode, u64 uniform_k, int custom_atan, int do_tail,
-                           int16_t *pcm, rxk_fm_dev *dev, u64 *flag_list)
+                           int16_t *pcm, rxk_fm_dev *dev, u64 *flag_list, int sparse, u64 n_blocks)
 {
-	const unsigned out_blocks = (unsigned)((M + 255) / 256);
+	const u64 n_wg = (T + RXK_DEC_SPAN - 1) / RXK_DEC_SPAN;
+	const unsigned out_blocks = sparse ? (unsigned)((2 * n_wg + n_blocks + 1 + 255) / 256) : (unsigned)((M + 255) / 256);
 	const unsigned grid = out_blocks + (do_tail ? 1 : 0);
 	if (!grid)
 		return 0;
 	hipStream_t s = (hipStream_t)stream;
 	if (prescaled)
 		hipLaunchKernelGGL((k_fm_disc<true>), dim3(grid), dim3(256), 0, s, (const uint32_t *)iq, T, ds, p0, n_per_block, 0, seams,
-		                   lp_raw, head, tail, lp, M, first_mode, uniform_k, custom_atan, do_tail, pcm, dev, flag_list, out_blocks);
+		                   lp_raw, head, tail, lp, M, first_mode, uniform_k, custom_atan, do_tail, pcm, dev, flag_list, out_blocks, sparse, n_wg, n_blocks);
 	else
 		hipLaunchKernelGGL((k_fm_disc<false>), dim3(grid), dim3(256), 0, s, (const uint32_t *)iq, T, ds, p0, n_per_block, rotate, seams,
-		                   lp_raw, head, tail, lp, M, first_mode, uniform_k, custom_atan, do_tail, pcm, dev, flag_list, out_blocks);
+		                   lp_raw, head, tail, lp, M, first_mode, uniform_k, custom_atan, do_tail, pcm, dev, flag_list, out_blocks, sparse, n_wg, n_blocks);
 	LAUNCH_RET();
 }
 

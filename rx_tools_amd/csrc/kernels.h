@@ -46,8 +46,9 @@ enum { RXK_FIRST_LOWPASS = 0, RXK_FIRST_UNIFORM = 1 };
  * boxcar sums.  T complex samples (T % 4 == 0), 4 <= ds <= RXK_DEC_MAX_DS.
  * lp_raw[m] valid for outputs completed strictly inside one workgroup span, head/tail
  * hold the per-workgroup partial sums at the seams (packed int16 I | Q<<16, mod 2^16). */
+/* pcm != NULL: also the -A fast discriminator for every output but the first two of each span */
 int rxk_fm_decimate(void *stream, const int16_t *iq, unsigned long long T, int ds, int p0,
-                    int prescaled, int rotate, uint32_t *lp_raw, uint32_t *head, uint32_t *tail);
+                    int prescaled, int rotate, uint32_t *lp_raw, uint32_t *head, uint32_t *tail, int16_t *pcm);
 
 /* same maths, one thread per output, any ds >= 1 and any block length; writes final lp[] */
 int rxk_fm_decimate_generic(void *stream, const int16_t *iq, unsigned long long T, int ds, int p0,
@@ -61,7 +62,10 @@ int rxk_fm_disc(void *stream, const int16_t *iq, unsigned long long T, int ds, i
                 unsigned long long n_per_block, int prescaled, int rotate, int seams,
                 const uint32_t *lp_raw, const uint32_t *head, const uint32_t *tail,
                 uint32_t *lp, unsigned long long M, int first_mode, unsigned long long uniform_k,
-                int custom_atan, int do_tail, int16_t *pcm, rxk_fm_dev *dev, unsigned long long *flag_list);
+                int custom_atan, int do_tail, int16_t *pcm, rxk_fm_dev *dev, unsigned long long *flag_list,
+                int sparse, unsigned long long n_blocks);
+/* sparse != 0 (after rxk_fm_decimate with pcm): only the two seam outputs of every span, each block's
+ * first (libm) output and the last output are processed */
 
 /* F8 de-emphasis (rtl_fm.c:667-682) as a tree scan over chunk maps (see fm_kernels.hip).
  * group = 16 or 64 candidate lanes; RXK_DEEMPH_FAN tables compose into one per level. */

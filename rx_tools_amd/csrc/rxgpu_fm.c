@@ -12,7 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define DEEMPH_CHUNK 128
+#define DEEMPH_CHUNK 512
 #define DEEMPH_LEVELS 8
 #define DEEMPH_TOPCAP(group) ((group) == 16 ? 2048 : 512)   /* tables the single-workgroup top walk stages in LDS */
 
@@ -33,7 +33,7 @@ struct rxgpu_fm_stream {
 	const uint32_t *lp_final;            /* where the last run left the final decimated IQ */
 	uint32_t *cas[2];                    /* fifth_order ping-pong */
 	uint32_t *seams;                     /* per block: 3 levels x 5 history samples for the fused passes */
-	int16_t *pcm, *y;
+	int16_t *pcm_buf[2], *pcm, *y;       /* pcm: the buffer the run in hand uses (double-buffered like lp_raw) */
 	int *pre;                             /* level 0: per chunk, start state for each candidate of its level-1 parent */
 	int *lvl_tab, *lvl_lo, *lvl_gap, *lvl_start;   /* levels >= 1, packed back to back */
 	size_t lvl_cap;
@@ -166,7 +166,9 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 		}
 	}
 	DMALLOC(s->lp, s->max_M * 4);
-	DMALLOC(s->pcm, s->max_M * 2);
+	DMALLOC(s->pcm_buf[0], s->max_M * 2);
+	DMALLOC(s->pcm_buf[1], s->max_M * 2);
+	s->pcm = s->pcm_buf[0];
 	DMALLOC(s->y, s->max_M * 2);
 	DMALLOC(s->pre, n_chunks * 64 * 4);
 	s->lvl_cap = n_chunks / RXK_DEEMPH_FAN + n_chunks / (RXK_DEEMPH_FAN * (RXK_DEEMPH_FAN - 1)) + 2 * DEEMPH_LEVELS + 2;
@@ -209,7 +211,7 @@ void rxgpu_fm_stream_destroy(rxgpu_fm_stream *s)
 	}
 	hipFree(s->lp);
 	hipFree(s->cas[0]); hipFree(s->cas[1]); hipFree(s->seams);
-	hipFree(s->pcm); hipFree(s->y);
+	hipFree(s->pcm_buf[0]); hipFree(s->pcm_buf[1]); hipFree(s->y);
 	hipFree(s->pre);
 	hipFree(s->lvl_tab); hipFree(s->lvl_lo); hipFree(s->lvl_gap); hipFree(s->lvl_start);
 	hipFree(s->flag_list); hipFree(s->dev); hipFree(s->hist_dev); hipFree(s->fir_dev);
@@ -409,13 +411,18 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks,
 	}
 
 	s->lp_final = s->lp;
+	s->pcm = s->pcm_buf[0];
 	if (!g->passes) {
+		const int fused_disc = g->fast && p->custom_atan == 1;
 		if (g->fast) {
+			s->pcm = s->pcm_buf[db];
+			s->lp_final = s->lp_raw[db];
 			/* buffer set `db` was last read by the audio chain two runs ago */
 			if (s->ev_small_valid[db])
 				RX_HIP(hipStreamWaitEvent(sa, s->ev_small[db], 0));
 			rxgpu_prof_begin_on("fm_decimate", sa);
-			RX_K(rxk_fm_decimate(sa, d_iq, g->T, g->ds, g->p0, p->prescaled, g->rotate, s->lp_raw[db], s->head[db], s->tail[db]));
+			RX_K(rxk_fm_decimate(sa, d_iq, g->T, g->ds, g->p0, p->prescaled, g->rotate, s->lp_raw[db], s->head[db], s->tail[db],
+			                     fused_disc ? s->pcm : NULL));
 			rxgpu_prof_end_on("fm_decimate", sa);
 			RX_HIP(hipEventRecord(s->ev_dec[db], sa));
 			RX_HIP(hipStreamWaitEvent(sb, s->ev_dec[db], 0));
@@ -425,8 +432,10 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks,
 			rxgpu_prof_end_on("fm_decimate_generic", sb);
 		}
 		rxgpu_prof_begin_on("fm_disc", sb);
+		/* fast path: lp_raw is finished in place (only seam entries change) and becomes the final decimated IQ */
 		RX_K(rxk_fm_disc(sb, d_iq, g->T, g->ds, g->p0, g->n, p->prescaled, g->rotate, g->fast, g->fast ? s->lp_raw[db] : s->lp,
-		                 s->head[db], s->tail[db], s->lp, g->M, RXK_FIRST_LOWPASS, 0, p->custom_atan, 1, s->pcm, s->dev, s->flag_list));
+		                 s->head[db], s->tail[db], g->fast ? s->lp_raw[db] : s->lp, g->M, RXK_FIRST_LOWPASS, 0, p->custom_atan, 1,
+		                 s->pcm, s->dev, s->flag_list, fused_disc, n_blocks));
 		rxgpu_prof_end_on("fm_disc", sb);
 	} else {
 		/* F3: cascade (first passes fused where the input is raw), F12 optional; all on stream B */
@@ -465,7 +474,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks,
 		}
 		rxgpu_prof_begin_on("fm_disc", sb);
 		RX_K(rxk_fm_disc(sb, d_iq, g->T, 1, 0, g->n, p->prescaled, g->rotate, 0, s->lp_final, NULL, NULL, NULL, g->M,
-		                 RXK_FIRST_UNIFORM, g->K, p->custom_atan, 0, s->pcm, s->dev, s->flag_list));
+		                 RXK_FIRST_UNIFORM, g->K, p->custom_atan, 0, s->pcm, s->dev, s->flag_list, 0, n_blocks));
 		rxgpu_prof_end_on("fm_disc", sb);
 	}
 	int rc = run_audio_stages(s, sb, g->M, g->J, d_out);
