@@ -9,7 +9,7 @@ The same JSON line carries, under "rx_power", FFT bins/s of the scanner() chain 
 config-3 geometry (-f 24M:1.7G:1k: 599 tunes x 16384 int16, N=4096), tunes sharded across the
 ranks with one RCCL gather of the avg[] rows to rank 0 per step.
 
-  python bench.py --gpus 1 --steps 20 --warmup 3
+  python bench.py --gpus 1 --steps 100 --warmup 10      (the defaults; about 10 s incl. the CPU baselines)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -111,8 +111,8 @@ def cpu_baseline_power(plan, budget_s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--blocks", type=int, default=8192, help="rx_fm blocks of 131072 complex samples per step (8192 = 4 GiB of cs16)")
     ap.add_argument("--passes", type=int, default=128, help="rx_power scanner() passes per step")
     ap.add_argument("--workload", default="both", choices=["both", "rx_fm", "rx_power"])
@@ -170,7 +170,8 @@ def main():
         d_out = torch.zeros(T // 118 + 64, dtype=torch.int16, device=dev)
         s = R.FmStream(R.FmParams.wbfm(downsample=118), n_blocks, block_len)
         for _ in range(args.warmup):
-            s.run(d_iq.data_ptr(), n_blocks, block_len, d_out.data_ptr(), d_out.numel())
+            s.run_async(d_iq.data_ptr(), n_blocks, block_len, d_out.data_ptr(), d_out.numel())
+        s.wait()
         L.rxgpu_prof_reset()
         L.rxgpu_prof_enable(args.prof_level)
         barrier()

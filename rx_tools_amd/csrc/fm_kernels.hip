@@ -484,7 +484,7 @@ __global__ void k_fm_deemph_up(u64 n_child, int gs, const int *__restrict__ tab,
 }
 
 // single workgroup: n tables staged in LDS, walked in sqrt(n) segments
-__global__ __launch_bounds__(1024) void k_fm_deemph_top(int n, int gs, const int *__restrict__ tab,
+__global__ __launch_bounds__(256) void k_fm_deemph_top(int n, int gs, const int *__restrict__ tab,
                                                          const int *__restrict__ lo, const int *__restrict__ gap,
                                                          int *__restrict__ start, rxk_fm_dev *__restrict__ dev)
 {
@@ -1074,9 +1074,12 @@ extern "C" int rxk_fm_deemph_top(void *stream, int n, int group, const int *tab,
 	while (R * R < n) R++;
 	const int nseg = (n + R - 1) / R;
 	const size_t shm = ((size_t)n * group + 2 * (size_t)n + (size_t)nseg * group + nseg) * sizeof(int);
-	if (shm > 64 * 1024)
-		(void)hipFuncSetAttribute((const void *)k_fm_deemph_top, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-	hipLaunchKernelGGL(k_fm_deemph_top, dim3(1), dim3(1024), shm, (hipStream_t)stream, n, group, tab, lo, gap, start, dev);
+	static size_t allowed = 64 * 1024;            /* raise the dynamic-LDS cap once, not per launch */
+	if (shm > allowed) {
+		(void)hipFuncSetAttribute((const void *)k_fm_deemph_top, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+		allowed = 144 * 1024;
+	}
+	hipLaunchKernelGGL(k_fm_deemph_top, dim3(1), dim3(256), shm, (hipStream_t)stream, n, group, tab, lo, gap, start, dev);
 	LAUNCH_RET();
 }
 

@@ -14,7 +14,9 @@
 
 #define DEEMPH_CHUNK 512
 #define DEEMPH_LEVELS 8
-#define DEEMPH_TOPCAP(group) ((group) == 16 ? 2048 : 512)   /* tables the single-workgroup top walk stages in LDS */
+/* tables the single-workgroup top walk stages in LDS.  Kept small (<= 16 KiB of LDS, 256 threads) so that
+ * the workgroup finds a slot on a CU that the pipelined decimator of the next run is saturating. */
+#define DEEMPH_TOPCAP(group) ((group) == 16 ? 224 : 56)
 
 /* geometry of one run, everything the host can know without the device */
 struct run_geom {

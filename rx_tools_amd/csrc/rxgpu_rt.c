@@ -47,7 +47,13 @@ int rxgpu_init(int device)
 		return rxgpu_fail(RXGPU_ENODEV, "device %d requested but only %d visible", device, n);
 	RX_HIP(hipSetDevice(device));
 	RX_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
-	RX_HIP(hipStreamCreateWithFlags(&g_stream2, hipStreamNonBlocking));
+	{
+		/* the tail stream carries many small kernels behind a saturating one: give it the high priority */
+		int lo_p = 0, hi_p = 0;
+		if (hipDeviceGetStreamPriorityRange(&lo_p, &hi_p) != hipSuccess)
+			lo_p = hi_p = 0;
+		RX_HIP(hipStreamCreateWithPriority(&g_stream2, hipStreamNonBlocking, hi_p));
+	}
 	g_device = device;
 	return RXGPU_OK;
 }
