@@ -26,6 +26,8 @@ static size_t g_src_len;          /* complex samples */
 static size_t g_src_pos;
 static size_t g_max_chunk;        /* 0 = hand out whatever is asked for */
 static void (*g_eos_hook)(void);
+static void (*g_pace_hook)(void); /* called before every data read but the first */
+static size_t g_reads;
 static const void *g_discard;     /* reads into this buffer are flush reads: zero-fill, consume nothing */
 
 void soapy_fake_set_source(const int16_t *iq, size_t n_complex, size_t max_chunk)
@@ -34,6 +36,7 @@ void soapy_fake_set_source(const int16_t *iq, size_t n_complex, size_t max_chunk
 }
 void soapy_fake_set_discard_buffer(const void *p) { g_discard = p; }
 void soapy_fake_set_eos_hook(void (*fn)(void)) { g_eos_hook = fn; }
+void soapy_fake_set_pace_hook(void (*fn)(void)) { g_pace_hook = fn; g_reads = 0; }
 size_t soapy_fake_position(void) { return g_src_pos; }
 
 size_t SoapySDR_formatToSize(const char *format)
@@ -76,6 +79,8 @@ int SoapySDRDevice_readStream(SoapySDRDevice *d, SoapySDRStream *s, void * const
 		memset(buffs[0], 0, n * 2 * sizeof(int16_t));
 		return (int)n;
 	}
+	if (g_pace_hook && g_reads++)
+		g_pace_hook();
 	if (!g_src || g_src_pos >= g_src_len) {
 		if (g_eos_hook) { void (*h)(void) = g_eos_hook; g_eos_hook = NULL; h(); }
 		return SOAPY_SDR_STREAM_ERROR;

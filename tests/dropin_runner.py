@@ -1,0 +1,89 @@
+"""Runs the reference's own rx_fm main() (oracle/_ref/libref_fm.so = rtl_fm.c compiled unmodified)
+on a synthetic cs16 capture served by the fake SoapySDR device, in one of two modes:
+  cpu : untouched -- the reference's threads call the reference's full_demod
+  gpu : oracle/_ref/libdropin.so is loaded first with RTLD_GLOBAL, so the same threads call
+        rxgpu_full_demod through the reference's own PLT (no source change)
+Usage: python dropin_runner.py cpu|gpu <iq.npy> <out.raw> [rx_fm args...]
+       python dropin_runner.py power-cpu|power-gpu <iq.npy> <out.csv> [rx_power args...]
+(rx_power: the capture holds P passes x tunes x buf_len int16; once it is exhausted scanner() adds nothing
+more, so the first report after -i 1 holds exactly P passes.)
+Separate process per run: the reference keeps its exit flag in a file-static."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = os.path.join(ROOT, "oracle", "_ref")
+
+
+def main_power(mode, iq, out_path, extra):
+    dropin = None
+    if mode == "power-gpu":
+        import rx_tools_amd as R
+        R.check(R.lib().rxgpu_init(0))
+        dropin = C.CDLL(os.path.join(REF, "libdropin.so"), mode=C.RTLD_GLOBAL)
+    ref = C.CDLL(os.path.join(REF, "libref_power.so"), mode=C.RTLD_GLOBAL)
+    ref.soapy_fake_set_source.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
+    # scanner() asks for buf_len complex elements but consumes buf_len int16: hand out buf_len/2 per read
+    buf_len = int(extra[extra.index("--buf-len") + 1])
+    del extra[extra.index("--buf-len"):extra.index("--buf-len") + 2]
+    ref.soapy_fake_set_source(iq.ctypes.data, len(iq) // 2, buf_len // 2)
+    args = [b"rx_power"] + [a.encode() for a in extra] + [out_path.encode()]
+    argv = (C.c_char_p * (len(args) + 1))(*args, None)
+    rc = ref.rx_power_main(len(args), argv)
+    if dropin is not None:
+        dropin.dropin_scans.restype = C.c_long
+        sys.stderr.write("dropin scanner passes: %d\n" % dropin.dropin_scans())
+    os._exit(rc)
+
+
+def main():
+    mode, iq_path, out_path = sys.argv[1:4]
+    extra = sys.argv[4:]
+    iq = np.load(iq_path)
+    if mode.startswith("power"):
+        return main_power(mode, iq, out_path, extra)
+    dropin = None
+    if mode == "gpu":
+        import rx_tools_amd as R          # loads torch's HIP runtime first, then librxgpu
+        R.check(R.lib().rxgpu_init(0))
+        dropin = C.CDLL(os.path.join(REF, "libdropin.so"), mode=C.RTLD_GLOBAL)
+    ref = C.CDLL(os.path.join(REF, "libref_fm.so"), mode=C.RTLD_GLOBAL)
+    ref.soapy_fake_set_source.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
+    ref.soapy_fake_set_source(iq.ctypes.data, len(iq) // 2, 0)
+    if dropin is not None:
+        ref.soapy_fake_set_pace_hook(C.cast(dropin.dropin_pace, C.c_void_p))
+        ref.soapy_fake_set_eos_hook(C.cast(dropin.dropin_eos, C.c_void_p))
+    else:
+        # same pacing/shutdown for the untouched run, from Python callbacks
+        import signal
+        import time
+        PACE = C.CFUNCTYPE(None)
+        state = {"n": 0}
+
+        def pace():
+            # wait until the demod thread has consumed the previous block: result_len changes per block;
+            # a fixed sleep well above one block's CPU time is enough here
+            time.sleep(0.02)
+
+        def eos():
+            time.sleep(0.1)
+            os.kill(os.getpid(), signal.SIGINT)
+        keep = (PACE(pace), PACE(eos))
+        state["keep"] = keep
+        ref.soapy_fake_set_pace_hook(keep[0])
+        ref.soapy_fake_set_eos_hook(keep[1])
+    args = [b"rx_fm"] + [a.encode() for a in extra] + [out_path.encode()]
+    argv = (C.c_char_p * (len(args) + 1))(*args, None)
+    rc = ref.rx_fm_main(len(args), argv)
+    if dropin is not None:
+        dropin.dropin_calls.restype = C.c_long
+        sys.stderr.write("dropin full_demod calls: %d\n" % dropin.dropin_calls())
+    os._exit(rc)
+
+
+if __name__ == "__main__":
+    main()
