@@ -33,7 +33,7 @@ typedef struct rxk_fm_dev {
 	int out_now_lpr, out_prev_lpr_index;
 	/* status */
 	int flag_cnt;          /* libm-discriminator samples needing host re-evaluation */
-	int any_unmerged;      /* some de-emphasis chunk could not pin its start state alone */
+	int reserved;
 	int err;               /* != 0: device-side invariant violated */
 	int pad;
 } rxk_fm_dev;

@@ -546,7 +546,7 @@ static int finish_runs(rxgpu_fm_stream *s)
 			RX_HIP(hipMemcpy(s->pcm + m, &v, 2, hipMemcpyHostToDevice));
 		}
 		s->fixups = cnt;
-		h->flag_cnt = 0; h->any_unmerged = 0;
+		h->flag_cnt = 0; h->reserved = 0;
 		RX_HIP(hipMemcpyAsync(&s->dev->flag_cnt, &h->flag_cnt, 2 * sizeof(int), hipMemcpyHostToDevice, sb));
 		if ((rc = run_audio_stages(s, sb, g->M, g->J, s->last_out)) != RXGPU_OK)
 			return rc;

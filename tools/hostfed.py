@@ -1,6 +1,6 @@
 """PCIe-inclusive rate of rxgpu_fm_stream_run_host (pageable host buffer in, host audio out)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import rx_tools_amd as R
 R.check(R.lib().rxgpu_init(0))

@@ -1,6 +1,6 @@
 """Print per-stage device times (hipEvents, prof level 2) for one rx_fm step and one rx_power step."""
 import ctypes as C, sys, os, json
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 import rx_tools_amd as R
 L = R.lib(); R.check(L.rxgpu_init(0))
