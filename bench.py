@@ -114,7 +114,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--blocks", type=int, default=8192, help="rx_fm blocks of 131072 complex samples per step (8192 = 4 GiB of cs16)")
-    ap.add_argument("--passes", type=int, default=128, help="rx_power scanner() passes per step")
+    ap.add_argument("--passes", type=int, default=512, help="rx_power scanner() passes per step (one report interval)")
     ap.add_argument("--workload", default="both", choices=["both", "rx_fm", "rx_power"])
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU baseline budget per path (0 = skip)")
     ap.add_argument("--prof-level", type=int, default=1)
@@ -232,6 +232,7 @@ def main():
         d_in = torch.randint(-100, 101, (passes, max(mine, 1), plan.buf_len), dtype=torch.int16, device=dev, generator=g)
         d_avg = torch.zeros((per, n), dtype=torch.int64, device=dev)        # padded to `per` rows for the gather
         d_smp = torch.zeros(per, dtype=torch.int32, device=dev)
+        gbuf = shard.gather_buffers(d_avg, dst=0) if world > 1 else None
 
         def step():
             if mine:
@@ -239,7 +240,7 @@ def main():
             if world > 1:
                 # order the gather (torch's stream) after the scan (librxgpu's stream)
                 L.rxgpu_sync()
-                shard.gather_rows(d_avg, dst=0)
+                shard.gather_rows(d_avg, dst=0, out=gbuf)
 
         for _ in range(args.warmup):
             step()

@@ -17,13 +17,21 @@ def tune_range(rank, world, total):
     return lo, hi - lo, per
 
 
-def gather_rows(local, dst=0):
-    """local: [per, N] tensor (any device).  Returns the list of per-rank blocks on dst, else None."""
+def gather_buffers(local, dst=0):
+    """Receive buffers for gather_rows on dst (allocate once, reuse every report interval)."""
     import torch
     import torch.distributed as dist
-    world, rank = dist.get_world_size(), dist.get_rank()
-    out = [torch.zeros_like(local) for _ in range(world)] if rank == dst else None
-    dist.gather(local, out, dst=dst)
+    if dist.get_rank() != dst:
+        return None
+    return [torch.zeros_like(local) for _ in range(dist.get_world_size())]
+
+
+def gather_rows(local, dst=0, out=None):
+    """local: [per, N] tensor (any device).  Returns the list of per-rank blocks on dst, else None."""
+    import torch.distributed as dist
+    if out is None:
+        out = gather_buffers(local, dst)
+    dist.gather(local, out if dist.get_rank() == dst else None, dst=dst)
     return out
 
 
