@@ -63,15 +63,21 @@ int rxgpu_prof_get(const char *name, double *total_ms, long *launches);
  * (decimated IQ), and every carry (lp_len, now_r/now_j/prev_index, pre_r/pre_j, lp_*_hist,
  * droop_*_hist, now_lpr/prev_lpr_index) exactly as the CPU leaves them.  deemph_filter's
  * function-static `avg` (rtl_fm.c:669) has no field in the struct: it lives in a side-car
- * keyed by the demod_state address (rxgpu_deemph_state).  Modes the device path does not
- * cover (am/usb/lsb/raw, squelch, -o, lut/ale atan, dc blocks) print to stderr and
- * exit(1): there is no CPU fallback. */
+ * keyed by the demod_state address (rxgpu_deemph_state).  Covered: -M fm|am|usb|lsb|raw,
+ * -A std|fast|lut|ale, -l squelch, -F 0|9, -E deemp|adc, -r.  What the device path does not cover
+ * (-o post_downsample, -E rdc, -L level printing) prints to stderr and exit(1): there is no CPU fallback. */
 void rxgpu_full_demod(struct demod_state *d);
 
 /* Replaces rtlsdr_callback(buf, len, ctx) at rtl_fm.c:899 (definition 828-863):
  * mute-zero, CS16 -> 8-bit-range scale, rotate16_90 unless offset tuning, hand-off into
  * s->demod_target->lowpassed under d->rw, signal d->ready.  len = int16 count. */
 void rxgpu_callback(int16_t *buf, uint32_t len, void *ctx);
+
+/* full_demod dispatches on d->mode_demod, a pointer into the reference's own code (rtl_fm.c:154, 808-809).
+ * The drop-in cannot know those addresses: tell it once, e.g.
+ *   rxgpu_set_demod_functions(&fm_demod, &am_demod, &usb_demod, &lsb_demod, &raw_demod);
+ * Without this call every demod_state is taken to be in fm mode. */
+void rxgpu_set_demod_functions(void *fm, void *am, void *usb, void *lsb, void *raw);
 
 /* side-car for the de-emphasis accumulator of a given demod_state */
 int *rxgpu_deemph_state(const struct demod_state *d);
@@ -84,14 +90,21 @@ typedef struct rxgpu_fm_params {
 	int downsample;          /* low_pass boxcar length when downsample_passes == 0 */
 	int downsample_passes;   /* > 0: fifth_order cascade (the -F path) */
 	int comp_fir_size;       /* 9: cic_9_tables droop compensation after the cascade */
-	int custom_atan;         /* 0 = libm atan2 discriminator, 1 = fast_atan2 (-A fast) */
+	int custom_atan;         /* -A: 0 std (libm atan2), 1 fast (fast_atan2), 2 lut (polar_disc_lut), 3 ale (esbensen) */
 	int deemph;              /* deemph_filter on/off */
 	int deemph_a;
 	int rate_out;            /* low_pass_real input rate */
 	int rate_out2;           /* low_pass_real output rate; <= 0 disables it */
 	int offset_tuning;       /* != 0: no rotate16_90 */
 	int prescaled;           /* != 0: input is already lowpassed[] (skip scale + rotate) */
+	int mode;                /* -M: RXGPU_MODE_FM/AM/USB/LSB/RAW = fm_demod/am_demod/usb_demod/lsb_demod/raw_demod (rtl_fm.c:584-665) */
+	int output_scale;        /* demod_state.output_scale (rtl_fm.c:988-992); 0 is taken as 1 */
+	int squelch_level;       /* -l: power squelch on the decimated block (rtl_fm.c:781-790); 0 = off */
+	int dc_block_audio;      /* -E adc: dc_block_audio_filter (rtl_fm.c:684-697, 818) */
+	int adc_block_const;     /* its averaging constant (default 9, rtl_fm.c:1106) */
 } rxgpu_fm_params;
+
+enum { RXGPU_MODE_FM = 0, RXGPU_MODE_AM = 1, RXGPU_MODE_USB = 2, RXGPU_MODE_LSB = 3, RXGPU_MODE_RAW = 4 };
 
 /* Every value the chain carries from one call to the next (SURVEY.md section 8b contract) */
 typedef struct rxgpu_fm_carry {
@@ -101,6 +114,8 @@ typedef struct rxgpu_fm_carry {
 	int16_t droop_i_hist[9], droop_q_hist[9];     /* generic_fir  rtl_fm.c:133-134 */
 	int deemph_avg;                          /* deemph_filter's static, rtl_fm.c:669 */
 	int now_lpr, prev_lpr_index;             /* low_pass_real     rtl_fm.c:150-151 */
+	int squelch_hits;                        /* power squelch     rtl_fm.c:145 */
+	int dc_avg;                              /* dc_block_audio    rtl_fm.c:152 */
 } rxgpu_fm_carry;
 
 typedef struct rxgpu_fm_stream rxgpu_fm_stream;

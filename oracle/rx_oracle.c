@@ -161,6 +161,97 @@ int rxo_polar_discriminant(int ar, int aj, int br, int bj)
 	return (int)(angle / 3.14159 * (1 << 14));
 }
 
+/* rtl_fm.c:515-526: atan_lut[i] = (int)(atan(i / 2^8) / 3.14159 * 2^14), 131072 entries */
+static int *lut_table(void)
+{
+	static int *lut;
+	if (!lut) {
+		lut = malloc(131072 * sizeof(int));
+		for (int i = 0; i < 131072; i++)
+			lut[i] = (int)(atan((double)i / (1 << 8)) / 3.14159 * (1 << 14));
+	}
+	return lut;
+}
+
+/* rtl_fm.c:528-564 */
+int rxo_polar_disc_lut(int ar, int aj, int br, int bj)
+{
+	int cr, cj, x, xa;
+	const int *lut = lut_table();
+	mul_conj(ar, aj, br, bj, &cr, &cj);
+	if (cr == 0 || cj == 0) {
+		if (cr == 0 && cj == 0) return 0;
+		if (cr == 0 && cj > 0) return 1 << 13;
+		if (cr == 0 && cj < 0) return -(1 << 13);
+		if (cj == 0 && cr > 0) return 0;
+		if (cj == 0 && cr < 0) return 1 << 14;
+	}
+	x = (int)((unsigned)cj << 8) / cr;
+	xa = x < 0 ? -x : x;
+	if (xa >= 131072)
+		return cj > 0 ? 1 << 13 : -(1 << 13);
+	if (x > 0)
+		return cj > 0 ? lut[x] : lut[x] - (1 << 14);
+	return cj > 0 ? (1 << 14) - lut[-x] : -lut[-x];
+}
+
+/* rtl_fm.c:566-582 */
+int rxo_esbensen(int ar, int aj, int br, int bj)
+{
+	int dr = (int)(((unsigned)br - (unsigned)ar) * 2u);
+	int dj = (int)(((unsigned)bj - (unsigned)aj) * 2u);
+	int cj = (int)((unsigned)bj * (unsigned)dr - (unsigned)br * (unsigned)dj);
+	int den = (int)((unsigned)ar * (unsigned)ar + (unsigned)aj * (unsigned)aj + 1u);
+	return (int)(2608u * (unsigned)cj) / den;
+}
+
+/* rtl_fm.c:739-757 */
+int rxo_rms(const int16_t *samples, int len, int step)
+{
+	long p = 0, t = 0;
+	for (int i = 0; i < len; i += step) {
+		long s = samples[i];
+		t += s;
+		p += s * s;
+	}
+	double dc = (double)(t * step) / (double)len;
+	double err = (double)(t * 2) * dc - dc * dc * len;
+	return (int)sqrt(((double)p - err) / len);
+}
+
+/* rtl_fm.c:617-665 */
+int rxo_simple_demod(int mode, const int16_t *lp, int lp_len, int output_scale, int16_t *result)
+{
+	if (mode == 4) {
+		memcpy(result, lp, (size_t)lp_len * sizeof(int16_t));
+		return lp_len;
+	}
+	for (int i = 0; i < lp_len; i += 2) {
+		int pcm;
+		if (mode == 1) {
+			pcm = lp[i] * lp[i] + lp[i + 1] * lp[i + 1];
+			result[i / 2] = wrap16((int16_t)sqrt(pcm) * output_scale);
+		} else {
+			pcm = mode == 2 ? lp[i] + lp[i + 1] : lp[i] - lp[i + 1];
+			result[i / 2] = wrap16((int16_t)pcm * output_scale);
+		}
+	}
+	return lp_len / 2;
+}
+
+/* rtl_fm.c:684-697 */
+void rxo_dc_block_audio(int16_t *result, int n, int adc_block_const, int *dc_avg)
+{
+	int64_t sum = 0;
+	for (int i = 0; i < n; i++)
+		sum += result[i];
+	int avg = (int)(sum / n);
+	avg = (avg + *dc_avg * adc_block_const) / (adc_block_const + 1);
+	for (int i = 0; i < n; i++)
+		result[i] = wrap16(result[i] - avg);
+	*dc_avg = avg;
+}
+
 /* rtl_fm.c:584-615 -- sample 0 of every call goes through the libm discriminator
  * against the carried previous sample; the rest use the selected one (only 0 and 1 are
  * on the path this oracle covers).  pre_r/pre_j <- last sample. */
@@ -168,9 +259,10 @@ int rxo_fm_demod(const int16_t *lp, int lp_len, int custom_atan, int *pre_r, int
 {
 	result[0] = wrap16(rxo_polar_discriminant(lp[0], lp[1], *pre_r, *pre_j));
 	for (int i = 2; i < lp_len - 1; i += 2) {
-		int pcm = custom_atan == 1
-			? rxo_polar_disc_fast(lp[i], lp[i + 1], lp[i - 2], lp[i - 1])
-			: rxo_polar_discriminant(lp[i], lp[i + 1], lp[i - 2], lp[i - 1]);
+		int pcm = custom_atan == 1 ? rxo_polar_disc_fast(lp[i], lp[i + 1], lp[i - 2], lp[i - 1])
+		        : custom_atan == 2 ? rxo_polar_disc_lut(lp[i], lp[i + 1], lp[i - 2], lp[i - 1])
+		        : custom_atan == 3 ? rxo_esbensen(lp[i], lp[i + 1], lp[i - 2], lp[i - 1])
+		        : rxo_polar_discriminant(lp[i], lp[i + 1], lp[i - 2], lp[i - 1]);
 		result[i / 2] = wrap16(pcm);
 	}
 	*pre_r = lp[lp_len - 2];
@@ -229,9 +321,25 @@ int rxo_fm_full_demod(rxo_fm_state *st, int16_t *lp, int *lp_len, int16_t *out)
 	} else {
 		*lp_len = rxo_low_pass(lp, *lp_len, st->downsample, &st->now_r, &st->now_j, &st->prev_index);
 	}
-	n = rxo_fm_demod(lp, *lp_len, st->custom_atan, &st->pre_r, &st->pre_j, out);
+	if (st->squelch_level) {                                           /* rtl_fm.c:781-790 */
+		if (rxo_rms(lp, *lp_len, 1) < st->squelch_level) {
+			st->squelch_hits++;
+			memset(lp, 0, (size_t)*lp_len * sizeof(int16_t));
+		} else {
+			st->squelch_hits = 0;
+		}
+	}
+	if (st->mode == 0) {
+		n = rxo_fm_demod(lp, *lp_len, st->custom_atan, &st->pre_r, &st->pre_j, out);
+	} else {
+		n = rxo_simple_demod(st->mode, lp, *lp_len, st->output_scale, out);
+		if (st->mode == 4)
+			return n;                                                  /* rtl_fm.c:809-811 */
+	}
 	if (st->deemph)
 		rxo_deemph(out, n, st->deemph_a, &st->deemph_avg);
+	if (st->dc_block_audio)
+		rxo_dc_block_audio(out, n, st->adc_block_const, &st->dc_avg);
 	if (st->rate_out2 > 0)
 		n = rxo_low_pass_real(out, n, st->rate_out, st->rate_out2, &st->now_lpr, &st->prev_lpr_index);
 	return n;

@@ -35,6 +35,10 @@ typedef struct rxo_fm_state {
 	int rate_out, rate_out2; /* low_pass_real ratio; rate_out2 <= 0 disables it */
 	int offset_tuning;       /* !=0: skip rotate16_90 (rtl_fm.c:854) */
 	int mute;                /* zero this many leading int16 of the next block (839-843) */
+	int mode;                /* 0 fm_demod, 1 am_demod, 2 usb_demod, 3 lsb_demod, 4 raw_demod (rtl_fm.c:584-665) */
+	int output_scale;        /* rtl_fm.c:988-992 */
+	int squelch_level;       /* rtl_fm.c:781-790 */
+	int dc_block_audio, adc_block_const;   /* rtl_fm.c:684-697, 818 */
 	/* carries */
 	int now_r, now_j, prev_index;
 	int pre_r, pre_j;
@@ -42,6 +46,8 @@ typedef struct rxo_fm_state {
 	int16_t droop_i_hist[9], droop_q_hist[9];
 	int deemph_avg;          /* the function-static `avg` of deemph_filter (669) */
 	int now_lpr, prev_lpr_index;
+	int squelch_hits;
+	int dc_avg;
 } rxo_fm_state;
 
 /* rtl_fm.c:845-848: CS16 -> 8-bit-range int16 through fp64 */
@@ -60,6 +66,15 @@ const int *rxo_cic9_table(int passes);
 int rxo_fast_atan2(int y, int x);
 int rxo_polar_disc_fast(int ar, int aj, int br, int bj);
 int rxo_polar_discriminant(int ar, int aj, int br, int bj);
+/* rtl_fm.c:515-564 (table from atan_lut_init with the same libm), 566-582 */
+int rxo_polar_disc_lut(int ar, int aj, int br, int bj);
+int rxo_esbensen(int ar, int aj, int br, int bj);
+/* rtl_fm.c:739-757 */
+int rxo_rms(const int16_t *samples, int len, int step);
+/* rtl_fm.c:617-665: mode 1 am, 2 usb, 3 lsb, 4 raw; returns result_len */
+int rxo_simple_demod(int mode, const int16_t *lp, int lp_len, int output_scale, int16_t *result);
+/* rtl_fm.c:684-697 */
+void rxo_dc_block_audio(int16_t *result, int n, int adc_block_const, int *dc_avg);
 /* rtl_fm.c:584-615; returns result_len */
 int rxo_fm_demod(const int16_t *lp, int lp_len, int custom_atan, int *pre_r, int *pre_j, int16_t *result);
 /* rtl_fm.c:667-682 */

@@ -16,7 +16,7 @@ _lib = None
 EXPORTS = [
     "rxgpu_init", "rxgpu_shutdown", "rxgpu_device_count", "rxgpu_last_error", "rxgpu_stream", "rxgpu_sync",
     "rxgpu_prof_enable", "rxgpu_prof_reset", "rxgpu_prof_get",
-    "rxgpu_full_demod", "rxgpu_callback", "rxgpu_deemph_state",
+    "rxgpu_full_demod", "rxgpu_callback", "rxgpu_deemph_state", "rxgpu_set_demod_functions",
     "rxgpu_fm_stream_create", "rxgpu_fm_stream_destroy", "rxgpu_fm_stream_set_carry", "rxgpu_fm_stream_get_carry",
     "rxgpu_fm_stream_run", "rxgpu_fm_stream_run_async", "rxgpu_fm_stream_wait", "rxgpu_fm_stream_run_host",
     "rxgpu_fm_stream_host_fixups",
@@ -68,6 +68,7 @@ def lib():
         L.rxgpu_scan.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.rxgpu_csv_dbm.argtypes = [C.c_void_p, C.c_void_p]
         L.rxgpu_full_demod.argtypes = [C.c_void_p]
+        L.rxgpu_set_demod_functions.argtypes = [C.c_void_p] * 5
         L.rxgpu_callback.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         _lib = L
     return _lib

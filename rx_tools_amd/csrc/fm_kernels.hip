@@ -248,6 +248,35 @@ __device__ __forceinline__ int fast_atan2_dev(int y, int x)
 	return y < 0 ? -ang : ang;
 }
 
+// rtl_fm.c:528-564 on the already multiplied (cr, cj); atan_lut from atan_lut_init (515-526, host libm)
+__device__ __forceinline__ int polar_disc_lut_dev(int cr, int cj, const int *__restrict__ lut)
+{
+	if (cr == 0 || cj == 0) {
+		if (cr == 0 && cj == 0) return 0;
+		if (cr == 0 && cj > 0) return 1 << 13;
+		if (cr == 0 && cj < 0) return -(1 << 13);
+		if (cj == 0 && cr > 0) return 0;
+		return 1 << 14;
+	}
+	const int x = (int)((unsigned)cj << 8) / cr;
+	const int xa = x < 0 ? -x : x;
+	if (xa >= 131072)
+		return cj > 0 ? 1 << 13 : -(1 << 13);
+	if (x > 0)
+		return cj > 0 ? lut[x] : lut[x] - (1 << 14);
+	return cj > 0 ? (1 << 14) - lut[-x] : -lut[-x];
+}
+
+// rtl_fm.c:566-582, wrapping like -fwrapv
+__device__ __forceinline__ int esbensen_dev(int ar, int aj, int br, int bj)
+{
+	const int dr = (int)(((unsigned)br - (unsigned)ar) * 2u);
+	const int dj = (int)(((unsigned)bj - (unsigned)aj) * 2u);
+	const int cj = (int)((unsigned)bj * (unsigned)dr - (unsigned)br * (unsigned)dj);
+	const int den = (int)((unsigned)ar * (unsigned)ar + (unsigned)aj * (unsigned)aj + 1u);
+	return (int)(2608u * (unsigned)cj) / den;
+}
+
 __device__ __forceinline__ uint32_t lp_final(u64 m, int ds, int p0, int seams, const uint32_t *lp_raw,
                                              const uint32_t *head, const uint32_t *tail, uint32_t carry)
 {
@@ -270,7 +299,7 @@ __global__ __launch_bounds__(256) void k_fm_disc(
 	const uint32_t *lp_raw, const uint32_t *__restrict__ head, const uint32_t *__restrict__ tail,
 	uint32_t *lp /* may alias lp_raw: seam entries are finished in place */, u64 M, int first_mode, u64 uniform_k, int custom_atan, int do_tail,
 	int16_t *__restrict__ pcm, rxk_fm_dev *__restrict__ dev, u64 *__restrict__ flag_list, unsigned out_blocks,
-	int sparse, u64 n_wg, u64 n_blocks)
+	int sparse, u64 n_wg, u64 n_blocks, const int *__restrict__ atan_lut)
 {
 	if (blockIdx.x >= out_blocks) {
 		// ---- low_pass carry: exact int32 sums of the samples after the last complete window
@@ -319,6 +348,10 @@ __global__ __launch_bounds__(256) void k_fm_disc(
 	const uint32_t a = lp_final(m, ds, p0, seams, lp_raw, head, tail, carry);
 	if (seams)
 		lp[m] = a;
+	if (!pcm) {                                  // lp_only: squelch / another demodulator comes next
+		if (m == M - 1) { dev->out_pre_r = dev->in_pre_r; dev->out_pre_j = dev->in_pre_j; }
+		return;
+	}
 	int br, bj;
 	if (m) {
 		const uint32_t b = lp_final(m - 1, ds, p0, seams, lp_raw, head, tail, carry);
@@ -353,14 +386,141 @@ __global__ __launch_bounds__(256) void k_fm_disc(
 			if (idx < RXK_FLAG_CAP)
 				flag_list[idx] = m;
 		}
-	} else {
+	} else if (custom_atan == 1) {
 		out = fast_atan2_dev(cj, cr);
+	} else if (custom_atan == 2) {
+		out = polar_disc_lut_dev(cr, cj, atan_lut);
+	} else {
+		out = esbensen_dev(ar, aj, br, bj);
 	}
 	pcm[m] = (int16_t)out;
 	if (m == M - 1) {
 		dev->out_pre_r = ar;
 		dev->out_pre_j = aj;
 	}
+}
+
+// ------------------------------------------------------------------ squelch, am/usb/lsb, dc block
+
+__device__ __forceinline__ void block_range(const rxk_fm_blocks &g, u64 b, u64 &m0, u64 &m1)
+{
+	if (g.first_mode == RXK_FIRST_UNIFORM) {
+		m0 = b * g.k; m1 = m0 + g.k;
+	} else {
+		m0 = (b * g.n + (u64)g.p0) / (u64)g.ds;
+		m1 = ((b + 1) * g.n + (u64)g.p0) / (u64)g.ds;
+	}
+}
+
+// floor(sqrt(v)) for v >= 0, exact whatever the last bit of the device sqrt does
+__device__ __forceinline__ i64 isqrt_floor(double v)
+{
+	i64 r = (i64)sqrt(v);
+	while (r > 0 && (double)(r * r) > v) r--;
+	while ((double)((r + 1) * (r + 1)) <= v) r++;
+	return r;
+}
+
+// rtl_fm.c:781-790 with rms() 739-757 (step 1, over both components): one workgroup per callback block
+__global__ __launch_bounds__(256) void k_fm_squelch(uint32_t *__restrict__ lp, rxk_fm_blocks g, int level, int *__restrict__ below)
+{
+	__shared__ i64 red[8];
+	__shared__ int quiet;
+	const u64 b = blockIdx.x;
+	u64 m0, m1;
+	block_range(g, b, m0, m1);
+	i64 t = 0, p = 0;
+	for (u64 m = m0 + threadIdx.x; m < m1; m += 256) {
+		const uint32_t w = lp[m];
+		const i64 i = lo16(w), q = hi16(w);
+		t += i + q;
+		p += i * i + q * q;
+	}
+	for (int off = 32; off; off >>= 1) { t += __shfl_down(t, off); p += __shfl_down(p, off); }
+	if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = t; red[4 + (threadIdx.x >> 6)] = p; }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		t = red[0] + red[1] + red[2] + red[3];
+		p = red[4] + red[5] + red[6] + red[7];
+		const int len = (int)(2 * (m1 - m0));
+		const double dc = (double)t / (double)len;          // (double)(t*step)/(double)len, step == 1
+		const double lhs = (double)(t * 2) * dc;
+		const double rhs = dc * dc * (double)len;
+		const double v = ((double)p - (lhs - rhs)) / (double)len;
+		const int sr = v >= 0.0 ? (int)isqrt_floor(v) : 0;
+		quiet = sr < level;
+		below[b] = quiet;
+	}
+	__syncthreads();
+	if (quiet)
+		for (u64 m = m0 + threadIdx.x; m < m1; m += 256)
+			lp[m] = 0;
+}
+
+// am_demod / usb_demod / lsb_demod, rtl_fm.c:617-656
+__global__ void k_fm_simple_demod(const uint32_t *__restrict__ lp, u64 M, int mode, int output_scale, int16_t *__restrict__ pcm)
+{
+	const u64 m = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (m >= M)
+		return;
+	const uint32_t w = lp[m];
+	const int i = lo16(w), q = hi16(w);
+	int v;
+	if (mode == 1) {
+		const int pw = (int)((unsigned)(i * i) + (unsigned)(q * q));    // may wrap at full scale, like the reference's int
+		// (int16_t)sqrt(pcm): sqrt of a negative int is NaN, which the x86 conversion turns into 0
+		v = pw < 0 ? 0 : (int)(short)isqrt_floor((double)pw);
+	} else {
+		v = (int)(short)(mode == 2 ? i + q : i - q);
+	}
+	pcm[m] = (int16_t)(v * output_scale);
+}
+
+// dc_block_audio_filter, rtl_fm.c:684-697: sum per block ...
+__global__ __launch_bounds__(256) void k_fm_dc_sums(const int16_t *__restrict__ y, rxk_fm_blocks g, i64 *__restrict__ sums)
+{
+	__shared__ i64 red[4];
+	u64 m0, m1;
+	block_range(g, blockIdx.x, m0, m1);
+	i64 t = 0;
+	for (u64 m = m0 + threadIdx.x; m < m1; m += 256)
+		t += y[m];
+	for (int off = 32; off; off >>= 1) t += __shfl_down(t, off);
+	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+	__syncthreads();
+	if (threadIdx.x == 0)
+		sums[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// ... the recursion avg = (sum/len + dc_avg*c) / (c+1) block after block (C truncating divisions) ...
+__global__ void k_fm_dc_scan(const i64 *__restrict__ sums, rxk_fm_blocks g, int c, int *__restrict__ avgs, rxk_fm_dev *__restrict__ dev)
+{
+	if (threadIdx.x || blockIdx.x)
+		return;
+	int dc = dev->in_dc_avg;
+	for (u64 b = 0; b < g.n_blocks; b++) {
+		u64 m0, m1;
+		block_range(g, b, m0, m1);
+		int avg = (int)(sums[b] / (i64)(int)(m1 - m0));
+		avg = (int)((unsigned)avg + (unsigned)dc * (unsigned)c) / (c + 1);
+		avgs[b] = avg;
+		dc = avg;
+	}
+	dev->out_dc_avg = dc;
+}
+
+// ... and the subtraction with int16 wrap
+__global__ void k_fm_dc_apply(int16_t *__restrict__ y, u64 M, rxk_fm_blocks g, const int *__restrict__ avgs)
+{
+	const u64 m = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (m >= M)
+		return;
+	u64 b;
+	if (g.first_mode == RXK_FIRST_UNIFORM)
+		b = m / g.k;
+	else
+		b = ((m + 1) * (u64)g.ds - (u64)g.p0 - 1) / g.n;
+	y[m] = (int16_t)(y[m] - avgs[b]);
 }
 
 // ------------------------------------------------------------------ F8 de-emphasis
@@ -642,6 +802,7 @@ __global__ void k_fm_carry_advance(rxk_fm_dev *dev)
 	dev->in_pre_r = dev->out_pre_r; dev->in_pre_j = dev->out_pre_j;
 	dev->in_deemph_avg = dev->out_deemph_avg;
 	dev->in_now_lpr = dev->out_now_lpr; dev->in_prev_lpr_index = dev->out_prev_lpr_index;
+	dev->in_dc_avg = dev->out_dc_avg;
 }
 
 __global__ void k_fm_passthrough_carry(rxk_fm_dev *dev, int deemph_off, int resample_off)
@@ -1015,7 +1176,7 @@ extern "C" int rxk_fm_decimate_generic(void *stream, const int16_t *iq, u64 T, i
 extern "C" int rxk_fm_disc(void *stream, const int16_t *iq, u64 T, int ds, int p0, u64 n_per_block, int prescaled,
                            int rotate, int seams, const uint32_t *lp_raw, const uint32_t *head, const uint32_t *tail,
                            uint32_t *lp, u64 M, int first_mode, u64 uniform_k, int custom_atan, int do_tail,
-                           int16_t *pcm, rxk_fm_dev *dev, u64 *flag_list, int sparse, u64 n_blocks)
+                           int16_t *pcm, rxk_fm_dev *dev, u64 *flag_list, int sparse, u64 n_blocks, const int *atan_lut)
 {
 	const u64 n_wg = (T + RXK_DEC_SPAN - 1) / RXK_DEC_SPAN;
 	const unsigned out_blocks = sparse ? (unsigned)((2 * n_wg + n_blocks + 1 + 255) / 256) : (unsigned)((M + 255) / 256);
@@ -1025,10 +1186,10 @@ extern "C" int rxk_fm_disc(void *stream, const int16_t *iq, u64 T, int ds, int p
 	hipStream_t s = (hipStream_t)stream;
 	if (prescaled)
 		hipLaunchKernelGGL((k_fm_disc<true>), dim3(grid), dim3(256), 0, s, (const uint32_t *)iq, T, ds, p0, n_per_block, 0, seams,
-		                   lp_raw, head, tail, lp, M, first_mode, uniform_k, custom_atan, do_tail, pcm, dev, flag_list, out_blocks, sparse, n_wg, n_blocks);
+		                   lp_raw, head, tail, lp, M, first_mode, uniform_k, custom_atan, do_tail, pcm, dev, flag_list, out_blocks, sparse, n_wg, n_blocks, atan_lut);
 	else
 		hipLaunchKernelGGL((k_fm_disc<false>), dim3(grid), dim3(256), 0, s, (const uint32_t *)iq, T, ds, p0, n_per_block, rotate, seams,
-		                   lp_raw, head, tail, lp, M, first_mode, uniform_k, custom_atan, do_tail, pcm, dev, flag_list, out_blocks, sparse, n_wg, n_blocks);
+		                   lp_raw, head, tail, lp, M, first_mode, uniform_k, custom_atan, do_tail, pcm, dev, flag_list, out_blocks, sparse, n_wg, n_blocks, atan_lut);
 	LAUNCH_RET();
 }
 
@@ -1189,5 +1350,29 @@ extern "C" int rxk_fm_fifth_fused(void *stream, const int16_t *iq, int rotate, u
 		else hipLaunchKernelGGL((k_fm_fifth_fused<F, false>), dim3(grid), dim3(256), 0, s, p, n, tiles, seams, out); } while (0)
 	if (fuse == 1) GO(1); else if (fuse == 2) GO(2); else GO(3);
 #undef GO
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_fm_squelch(void *stream, uint32_t *lp, rxk_fm_blocks blk, int level, int *below)
+{
+	hipLaunchKernelGGL(k_fm_squelch, dim3((unsigned)blk.n_blocks), dim3(256), 0, (hipStream_t)stream, lp, blk, level, below);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_fm_simple_demod(void *stream, const uint32_t *lp, u64 M, int mode, int output_scale, int16_t *pcm)
+{
+	if (!M)
+		return 0;
+	hipLaunchKernelGGL(k_fm_simple_demod, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, lp, M, mode, output_scale, pcm);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_fm_dc_block(void *stream, int16_t *y, u64 M, rxk_fm_blocks blk, int adc_block_const, long long *sums,
+                               int *avgs, rxk_fm_dev *dev)
+{
+	hipStream_t s = (hipStream_t)stream;
+	hipLaunchKernelGGL(k_fm_dc_sums, dim3((unsigned)blk.n_blocks), dim3(256), 0, s, y, blk, (i64 *)sums);
+	hipLaunchKernelGGL(k_fm_dc_scan, dim3(1), dim3(64), 0, s, (const i64 *)sums, blk, adc_block_const, avgs, dev);
+	hipLaunchKernelGGL(k_fm_dc_apply, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, y, M, blk, avgs);
 	LAUNCH_RET();
 }

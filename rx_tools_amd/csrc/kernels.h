@@ -26,17 +26,25 @@ typedef struct rxk_fm_dev {
 	int in_pre_r, in_pre_j;
 	int in_deemph_avg;
 	int in_now_lpr, in_prev_lpr_index;
+	int in_dc_avg;
 	/* carry out (kernels fill) */
 	int out_now_r, out_now_j, out_prev_index;
 	int out_pre_r, out_pre_j;
 	int out_deemph_avg;
 	int out_now_lpr, out_prev_lpr_index;
+	int out_dc_avg;
 	/* status */
 	int flag_cnt;          /* libm-discriminator samples needing host re-evaluation */
 	int reserved;
 	int err;               /* != 0: device-side invariant violated */
-	int pad;
 } rxk_fm_dev;
+
+/* which decimated samples belong to which callback block */
+typedef struct rxk_fm_blocks {
+	int first_mode;                /* RXK_FIRST_LOWPASS: block b owns lp[(b*n+p0)/ds .. ((b+1)*n+p0)/ds); UNIFORM: lp[b*k .. (b+1)*k) */
+	int ds, p0;
+	unsigned long long n, k, n_blocks;
+} rxk_fm_blocks;
 
 #define RXK_FLAG_CAP 4096
 
@@ -63,7 +71,8 @@ int rxk_fm_disc(void *stream, const int16_t *iq, unsigned long long T, int ds, i
                 const uint32_t *lp_raw, const uint32_t *head, const uint32_t *tail,
                 uint32_t *lp, unsigned long long M, int first_mode, unsigned long long uniform_k,
                 int custom_atan, int do_tail, int16_t *pcm, rxk_fm_dev *dev, unsigned long long *flag_list,
-                int sparse, unsigned long long n_blocks);
+                int sparse, unsigned long long n_blocks, const int *atan_lut);
+/* pcm == NULL: only finish lp[] (+ the low_pass carry); the discriminator runs later on the final lp[] */
 /* sparse != 0 (after rxk_fm_decimate with pcm): only the two seam outputs of every span, each block's
  * first (libm) output and the last output are processed */
 
@@ -87,6 +96,13 @@ int rxk_fm_deemph_serial(void *stream, const int16_t *pcm, unsigned long long M,
 /* F9 low_pass_real (rtl_fm.c:389-409): J outputs from n inputs, closed-form windows */
 int rxk_fm_resample(void *stream, const int16_t *y, unsigned long long n, int fast, int slow,
                     unsigned long long J, int16_t *out, rxk_fm_dev *dev);
+/* power squelch (rtl_fm.c:781-790, rms 739-757) per callback block: below[b] = rms < level, and such blocks are zeroed */
+int rxk_fm_squelch(void *stream, uint32_t *lp, rxk_fm_blocks blk, int level, int *below);
+/* am/usb/lsb_demod (rtl_fm.c:617-656) on the final decimated IQ */
+int rxk_fm_simple_demod(void *stream, const uint32_t *lp, unsigned long long M, int mode, int output_scale, int16_t *pcm);
+/* dc_block_audio_filter (rtl_fm.c:684-697): per-block mean, first-order recursion across blocks, subtract */
+int rxk_fm_dc_block(void *stream, int16_t *y, unsigned long long M, rxk_fm_blocks blk, int adc_block_const,
+                    long long *sums, int *avgs, rxk_fm_dev *dev);
 /* chained runs: carries-out -> carries-in on the device */
 int rxk_fm_carry_advance(void *stream, rxk_fm_dev *dev);
 /* carries when a stage is disabled */

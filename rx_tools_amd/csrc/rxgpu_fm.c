@@ -40,6 +40,11 @@ struct rxgpu_fm_stream {
 	int *lvl_tab, *lvl_lo, *lvl_gap, *lvl_start;   /* levels >= 1, packed back to back */
 	size_t lvl_cap;
 	unsigned long long *flag_list;
+	int *atan_lut;                       /* -A lut table (rtl_fm.c:515-526), only when custom_atan == 2 */
+	int *below;                          /* squelch verdict per block */
+	long long *dc_sums;                  /* dc_block_audio: per-block sums and means */
+	int *dc_avgs;
+	int *below_host;
 	rxk_fm_dev *dev;
 	int16_t *hist_dev;                   /* [10][12] cascade hist in, [10][12] out, [18] droop in, [18] out */
 	int *fir_dev;                        /* 10 ints */
@@ -64,6 +69,8 @@ struct rxgpu_fm_stream {
 	rxgpu_fm_carry carry_at_enqueue;     /* for rolling a pipelined sequence back */
 	struct run_geom last;
 	int16_t *last_out;
+	rxk_fm_blocks blk;                   /* block ownership of the run in hand */
+	size_t last_n_blocks;
 };
 
 /* rtl_fm.c:288-300 */
@@ -93,8 +100,12 @@ static int validate_params(const rxgpu_fm_params *p)
 		return rxgpu_fail(RXGPU_EINVAL, "downsample_passes %d outside 0..10", p->downsample_passes);
 	if (!p->downsample_passes && p->downsample < 1)
 		return rxgpu_fail(RXGPU_EINVAL, "downsample %d < 1", p->downsample);
-	if (p->custom_atan != 0 && p->custom_atan != 1)
-		return rxgpu_fail(RXGPU_EUNSUPPORTED, "custom_atan %d: only std (0) and fast (1) run on the device", p->custom_atan);
+	if (p->custom_atan < 0 || p->custom_atan > 3)
+		return rxgpu_fail(RXGPU_EINVAL, "custom_atan %d outside 0..3", p->custom_atan);
+	if (p->mode < RXGPU_MODE_FM || p->mode > RXGPU_MODE_RAW)
+		return rxgpu_fail(RXGPU_EINVAL, "mode %d outside 0..4", p->mode);
+	if (p->dc_block_audio && p->adc_block_const < 0)
+		return rxgpu_fail(RXGPU_EINVAL, "adc_block_const %d < 0", p->adc_block_const);
 	if (p->deemph && p->deemph_a < 1)
 		return rxgpu_fail(RXGPU_EINVAL, "deemph_a %d < 1", p->deemph_a);
 	if (p->rate_out2 > 0 && (p->rate_out < p->rate_out2 || p->rate_out <= 0))
@@ -142,6 +153,8 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 	if (!s)
 		return rxgpu_fail(RXGPU_ENOMEM, "out of host memory");
 	s->p = *params;
+	if (!s->p.output_scale)
+		s->p.output_scale = 1;
 	{
 		const char *e = getenv("RXGPU_DEEMPH_TOPCAP");
 		s->topcap_override = (e && atoi(e) > 0) ? atoi(e) : 0;
@@ -151,6 +164,8 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 	s->max_T = max_blocks * (block_len / 2);
 	if (params->downsample_passes)
 		s->max_M = max_blocks * (((block_len / 2) >> params->downsample_passes) + 1);
+	else if (params->downsample < 1)
+		s->max_M = s->max_T + 2;
 	else
 		s->max_M = s->max_T / (size_t)params->downsample + 2;
 	size_t n_wg = (s->max_T + RXK_DEC_SPAN - 1) / RXK_DEC_SPAN + 1;
@@ -179,6 +194,20 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 	DMALLOC(s->lvl_gap, s->lvl_cap * 4);
 	DMALLOC(s->lvl_start, s->lvl_cap * 4);
 	DMALLOC(s->flag_list, RXK_FLAG_CAP * 8);
+	DMALLOC(s->below, (max_blocks + 1) * 4);
+	DMALLOC(s->dc_sums, (max_blocks + 1) * 8);
+	DMALLOC(s->dc_avgs, (max_blocks + 1) * 4);
+	if (params->custom_atan == 2) {
+		/* atan_lut_init, rtl_fm.c:515-526, with the host libm the reference uses */
+		int *lut = malloc(131072 * sizeof(int));
+		if (!lut) { rxgpu_fm_stream_destroy(s); return rxgpu_fail(RXGPU_ENOMEM, "out of host memory"); }
+		for (int i = 0; i < 131072; i++)
+			lut[i] = (int)(atan((double)i / (1 << 8)) / 3.14159 * (1 << 14));
+		DMALLOC(s->atan_lut, 131072 * sizeof(int));
+		hipError_t e = hipMemcpy(s->atan_lut, lut, 131072 * sizeof(int), hipMemcpyHostToDevice);
+		free(lut);
+		if (e != hipSuccess) { rxgpu_fm_stream_destroy(s); return rxgpu_fail(RXGPU_ENODEV, "atan table upload failed"); }
+	}
 	DMALLOC(s->dev, sizeof(rxk_fm_dev));
 	DMALLOC(s->hist_dev, HIST_TOTAL * 2);
 	DMALLOC(s->fir_dev, 10 * 4);
@@ -190,7 +219,8 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 	}
 	if (hipHostMalloc((void **)&s->dev_host, sizeof(rxk_fm_dev), 0) != hipSuccess ||
 	    hipHostMalloc((void **)&s->hist_host, HIST_TOTAL * 2, 0) != hipSuccess ||
-	    hipHostMalloc((void **)&s->flag_host, RXK_FLAG_CAP * 8, 0) != hipSuccess) {
+	    hipHostMalloc((void **)&s->flag_host, RXK_FLAG_CAP * 8, 0) != hipSuccess ||
+	    hipHostMalloc((void **)&s->below_host, (max_blocks + 1) * 4, 0) != hipSuccess) {
 		rxgpu_fm_stream_destroy(s);
 		return rxgpu_fail(RXGPU_ENOMEM, "hipHostMalloc failed");
 	}
@@ -216,6 +246,8 @@ void rxgpu_fm_stream_destroy(rxgpu_fm_stream *s)
 	hipFree(s->pcm_buf[0]); hipFree(s->pcm_buf[1]); hipFree(s->y);
 	hipFree(s->pre);
 	hipFree(s->lvl_tab); hipFree(s->lvl_lo); hipFree(s->lvl_gap); hipFree(s->lvl_start);
+	hipFree(s->atan_lut); hipFree(s->below); hipFree(s->dc_sums); hipFree(s->dc_avgs);
+	if (s->below_host) hipHostFree(s->below_host);
 	hipFree(s->flag_list); hipFree(s->dev); hipFree(s->hist_dev); hipFree(s->fir_dev);
 	if (s->dev_host) hipHostFree(s->dev_host);
 	if (s->hist_host) hipHostFree(s->hist_host);
@@ -301,12 +333,23 @@ static int run_audio_stages(rxgpu_fm_stream *s, hipStream_t st, unsigned long lo
 		rxgpu_prof_end_on("fm_deemph", st);
 		audio = deemph_dst;
 	}
+	if (p->dc_block_audio && M) {
+		/* rtl_fm.c:818: in place on whatever holds the audio now */
+		int16_t *dst = (int16_t *)audio;
+		if (audio == s->pcm) {
+			/* pcm[] stays pristine (a host fix-up may have to redo these stages) */
+			dst = resample ? s->y : d_out;
+			RX_HIP(hipMemcpyAsync(dst, s->pcm, M * 2, hipMemcpyDeviceToDevice, st));
+		}
+		RX_K(rxk_fm_dc_block(st, dst, M, s->blk, p->adc_block_const, s->dc_sums, s->dc_avgs, s->dev));
+		audio = dst;
+	}
 	if (resample) {
 		rxgpu_prof_begin_on("fm_resample", st);
 		RX_K(rxk_fm_resample(st, audio, M, p->rate_out, p->rate_out2, J, d_out, s->dev));
 		rxgpu_prof_end_on("fm_resample", st);
-	} else if (!(p->deemph && M) && M) {
-		/* neither stage: the discriminator output is the result */
+	} else if (audio == s->pcm && M) {
+		/* no stage wrote d_out yet: the demodulator output is the result */
 		RX_HIP(hipMemcpyAsync(d_out, s->pcm, M * 2, hipMemcpyDeviceToDevice, st));
 	}
 	if (!(p->deemph && M) || !resample)
@@ -348,7 +391,9 @@ static int run_geometry(rxgpu_fm_stream *s, size_t n_blocks, size_t block_len, s
 	if (!g->M)
 		return rxgpu_fail(RXGPU_EUNSUPPORTED, "run produces no decimated sample");
 	g->J = g->M;
-	if (p->rate_out2 > 0) {
+	if (p->mode == RXGPU_MODE_RAW) {
+		g->J = 2 * g->M;                         /* raw_demod: result = lowpassed, rtl_fm.c:658-665, 809-811 */
+	} else if (p->rate_out2 > 0) {
 		if (g->pr0 < 0 || g->pr0 >= p->rate_out)
 			return rxgpu_fail(RXGPU_EINVAL, "prev_lpr_index %d outside [0,rate_out)", g->pr0);
 		g->J = ((unsigned long long)g->pr0 + g->M * (unsigned long long)p->rate_out2) / (unsigned long long)p->rate_out;
@@ -364,7 +409,8 @@ static void block_lengths(const rxgpu_fm_stream *s, const struct run_geom *g, si
 	unsigned long long j_prev = 0;
 	for (size_t b = 0; b < n_blocks; b++) {
 		unsigned long long cum = g->passes ? g->K * (b + 1) : ((unsigned long long)g->p0 + g->n * (b + 1)) / (unsigned long long)g->ds;
-		unsigned long long jj = p->rate_out2 > 0 ? ((unsigned long long)g->pr0 + cum * (unsigned long long)p->rate_out2) / (unsigned long long)p->rate_out : cum;
+		unsigned long long jj = p->mode == RXGPU_MODE_RAW ? 2 * cum
+			: p->rate_out2 > 0 ? ((unsigned long long)g->pr0 + cum * (unsigned long long)p->rate_out2) / (unsigned long long)p->rate_out : cum;
 		block_out_len[b] = (int)(jj - j_prev);
 		j_prev = jj;
 	}
@@ -390,7 +436,9 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks,
 		h->in_pre_r = s->carry.pre_r; h->in_pre_j = s->carry.pre_j;
 		h->in_deemph_avg = s->carry.deemph_avg;
 		h->in_now_lpr = s->carry.now_lpr; h->in_prev_lpr_index = s->carry.prev_lpr_index;
+		h->in_dc_avg = s->carry.dc_avg;
 		h->out_now_r = h->in_now_r; h->out_now_j = h->in_now_j; h->out_prev_index = h->in_prev_index;
+		h->out_pre_r = h->in_pre_r; h->out_pre_j = h->in_pre_j; h->out_dc_avg = h->in_dc_avg;
 		RX_HIP(hipMemcpyAsync(s->dev, h, sizeof(*h), hipMemcpyHostToDevice, sb));
 		if (g->passes) {
 			int16_t *hh = s->hist_host;
@@ -414,8 +462,13 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks,
 
 	s->lp_final = s->lp;
 	s->pcm = s->pcm_buf[0];
+	s->blk.first_mode = g->passes ? RXK_FIRST_UNIFORM : RXK_FIRST_LOWPASS;
+	s->blk.ds = g->ds; s->blk.p0 = g->p0; s->blk.n = g->n; s->blk.k = g->K; s->blk.n_blocks = n_blocks;
+	s->last_n_blocks = n_blocks;
+	/* squelch and the non-fm demodulators need the finished lowpassed[] before anything is demodulated */
+	const int split = p->squelch_level != 0 || p->mode != RXGPU_MODE_FM;
 	if (!g->passes) {
-		const int fused_disc = g->fast && p->custom_atan == 1;
+		const int fused_disc = g->fast && p->custom_atan == 1 && !split;
 		if (g->fast) {
 			s->pcm = s->pcm_buf[db];
 			s->lp_final = s->lp_raw[db];
@@ -437,7 +490,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks,
 		/* fast path: lp_raw is finished in place (only seam entries change) and becomes the final decimated IQ */
 		RX_K(rxk_fm_disc(sb, d_iq, g->T, g->ds, g->p0, g->n, p->prescaled, g->rotate, g->fast, g->fast ? s->lp_raw[db] : s->lp,
 		                 s->head[db], s->tail[db], g->fast ? s->lp_raw[db] : s->lp, g->M, RXK_FIRST_LOWPASS, 0, p->custom_atan, 1,
-		                 s->pcm, s->dev, s->flag_list, fused_disc, n_blocks));
+		                 split ? NULL : s->pcm, s->dev, s->flag_list, fused_disc, n_blocks, s->atan_lut));
 		rxgpu_prof_end_on("fm_disc", sb);
 	} else {
 		/* F3: cascade (first passes fused where the input is raw), F12 optional; all on stream B */
@@ -474,14 +527,35 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks,
 			rxgpu_prof_end_on("fm_droop", sb);
 			s->lp_final = s->lp;
 		}
-		rxgpu_prof_begin_on("fm_disc", sb);
-		RX_K(rxk_fm_disc(sb, d_iq, g->T, 1, 0, g->n, p->prescaled, g->rotate, 0, s->lp_final, NULL, NULL, NULL, g->M,
-		                 RXK_FIRST_UNIFORM, g->K, p->custom_atan, 0, s->pcm, s->dev, s->flag_list, 0, n_blocks));
-		rxgpu_prof_end_on("fm_disc", sb);
+		if (!split) {
+			rxgpu_prof_begin_on("fm_disc", sb);
+			RX_K(rxk_fm_disc(sb, d_iq, g->T, 1, 0, g->n, p->prescaled, g->rotate, 0, s->lp_final, NULL, NULL, NULL, g->M,
+			                 RXK_FIRST_UNIFORM, g->K, p->custom_atan, 0, s->pcm, s->dev, s->flag_list, 0, n_blocks, s->atan_lut));
+			rxgpu_prof_end_on("fm_disc", sb);
+		}
 	}
-	int rc = run_audio_stages(s, sb, g->M, g->J, d_out);
+	int rc;
+	if (split) {
+		uint32_t *lpw = (uint32_t *)s->lp_final;             /* every producer of lp_final owns it writable */
+		if (p->squelch_level)
+			RX_K(rxk_fm_squelch(sb, lpw, s->blk, p->squelch_level, s->below));
+		if (p->mode == RXGPU_MODE_FM) {
+			rxgpu_prof_begin_on("fm_disc", sb);
+			RX_K(rxk_fm_disc(sb, d_iq, g->T, g->ds, g->p0, g->n, p->prescaled, g->rotate, 0, lpw, NULL, NULL, NULL, g->M,
+			                 s->blk.first_mode, g->K, p->custom_atan, 0, s->pcm, s->dev, s->flag_list, 0, n_blocks, s->atan_lut));
+			rxgpu_prof_end_on("fm_disc", sb);
+		} else if (p->mode == RXGPU_MODE_RAW) {
+			RX_HIP(hipMemcpyAsync(d_out, lpw, g->M * 4, hipMemcpyDeviceToDevice, sb));
+			RX_K(rxk_fm_passthrough_carry(sb, s->dev, 1, 1));
+		} else {
+			RX_K(rxk_fm_simple_demod(sb, lpw, g->M, p->mode, p->output_scale, s->pcm));
+		}
+	}
+	rc = p->mode == RXGPU_MODE_RAW ? RXGPU_OK : run_audio_stages(s, sb, g->M, g->J, d_out);
 	if (rc != RXGPU_OK)
 		return rc;
+	if (p->squelch_level)
+		RX_HIP(hipMemcpyAsync(s->below_host, s->below, n_blocks * 4, hipMemcpyDeviceToHost, sb));
 	if (!g->passes && g->fast) {
 		RX_HIP(hipEventRecord(s->ev_small[db], sb));
 		s->ev_small_valid[db] = 1;
@@ -490,7 +564,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks,
 	/* what the next run needs from this one on the host side is closed-form */
 	if (!g->passes)
 		s->h_prev_index = (int)(((unsigned long long)g->p0 + g->T) - g->M * (unsigned long long)g->ds);
-	if (p->rate_out2 > 0)
+	if (p->rate_out2 > 0 && p->mode != RXGPU_MODE_RAW)
 		s->h_prev_lpr_index = (int)((unsigned long long)g->pr0 + g->M * (unsigned long long)p->rate_out2 - g->J * (unsigned long long)p->rate_out);
 	s->chained = 1;
 	s->pending++;
@@ -574,6 +648,10 @@ static int finish_runs(rxgpu_fm_stream *s)
 	s->carry.pre_r = h->out_pre_r; s->carry.pre_j = h->out_pre_j;
 	s->carry.deemph_avg = h->out_deemph_avg;
 	s->carry.now_lpr = h->out_now_lpr; s->carry.prev_lpr_index = h->out_prev_lpr_index;
+	s->carry.dc_avg = h->out_dc_avg;
+	if (p->squelch_level)                                    /* rtl_fm.c:783-789, block after block */
+		for (size_t b = 0; b < s->last_n_blocks; b++)
+			s->carry.squelch_hits = s->below_host[b] ? s->carry.squelch_hits + 1 : 0;
 	s->h_prev_index = s->carry.prev_index;
 	s->h_prev_lpr_index = s->carry.prev_lpr_index;
 	return RXGPU_OK;
@@ -601,6 +679,8 @@ int rxgpu_fm_stream_run_async(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_
 		*out_len = (size_t)g.J;
 	if (block_out_len)
 		block_lengths(s, &g, n_blocks, block_out_len);
+	if (s->p.squelch_level)
+		return finish_runs(s);               /* squelch_hits is counted on the host, run by run */
 	return RXGPU_OK;
 }
 
@@ -660,6 +740,13 @@ int rxgpu_fm_stream_run_host(rxgpu_fm_stream *s, const int16_t *h_iq, size_t n_b
 
 /* ------------------------------------------------------------------ drop-in entry points */
 
+static void *g_fn_fm, *g_fn_am, *g_fn_usb, *g_fn_lsb, *g_fn_raw;
+
+void rxgpu_set_demod_functions(void *fm, void *am, void *usb, void *lsb, void *raw)
+{
+	g_fn_fm = fm; g_fn_am = am; g_fn_usb = usb; g_fn_lsb = lsb; g_fn_raw = raw;
+}
+
 #define SIDECARS 16
 static struct { const struct demod_state *d; int avg; rxgpu_fm_stream *s; rxgpu_fm_params p; } g_side[SIDECARS];
 static int16_t *g_cb_in, *g_cb_out;          /* device staging for the callback */
@@ -697,10 +784,22 @@ void rxgpu_full_demod(struct demod_state *d)
 		rxgpu_fail(RXGPU_ECAPACITY, "more than %d demod_state objects", SIDECARS);
 		die("rxgpu_full_demod");
 	}
-	if (d->squelch_level || d->post_downsample > 1 || d->dc_block_audio) {
-		rxgpu_fail(RXGPU_EUNSUPPORTED, "squelch / -o / adc are not on the device path (squelch_level=%d post_downsample=%d dc_block_audio=%d)",
-		           d->squelch_level, d->post_downsample, d->dc_block_audio);
+	if (d->post_downsample > 1) {
+		rxgpu_fail(RXGPU_EUNSUPPORTED, "-o (post_downsample=%d) is not on the device path", d->post_downsample);
 		die("rxgpu_full_demod");
+	}
+	int mode = RXGPU_MODE_FM;
+	if (g_fn_fm) {
+		void *fn = (void *)d->mode_demod;
+		if (fn == g_fn_fm) mode = RXGPU_MODE_FM;
+		else if (fn == g_fn_am) mode = RXGPU_MODE_AM;
+		else if (fn == g_fn_usb) mode = RXGPU_MODE_USB;
+		else if (fn == g_fn_lsb) mode = RXGPU_MODE_LSB;
+		else if (fn == g_fn_raw) mode = RXGPU_MODE_RAW;
+		else {
+			rxgpu_fail(RXGPU_EUNSUPPORTED, "mode_demod %p is none of the registered demodulators", fn);
+			die("rxgpu_full_demod");
+		}
 	}
 	rxgpu_fm_params p;
 	memset(&p, 0, sizeof(p));
@@ -713,6 +812,11 @@ void rxgpu_full_demod(struct demod_state *d)
 	p.rate_out = d->rate_out;
 	p.rate_out2 = d->rate_out2;
 	p.prescaled = 1;                       /* lowpassed[] is already scaled + rotated by the callback */
+	p.mode = mode;
+	p.output_scale = d->output_scale;
+	p.squelch_level = d->squelch_level;
+	p.dc_block_audio = d->dc_block_audio;
+	p.adc_block_const = d->adc_block_const;
 	if (!g_side[slot].s || memcmp(&p, &g_side[slot].p, sizeof(p))) {
 		if (g_side[slot].s)
 			rxgpu_fm_stream_destroy(g_side[slot].s);
@@ -732,6 +836,7 @@ void rxgpu_full_demod(struct demod_state *d)
 	memcpy(c.droop_q_hist, d->droop_q_hist, sizeof(c.droop_q_hist));
 	c.deemph_avg = g_side[slot].avg;
 	c.now_lpr = d->now_lpr; c.prev_lpr_index = d->prev_lpr_index;
+	c.squelch_hits = d->squelch_hits; c.dc_avg = d->dc_avg;
 	rxgpu_fm_stream_set_carry(s, &c);
 	const int c_in_prev_index = c.prev_index;
 	size_t got = 0;
@@ -759,6 +864,7 @@ void rxgpu_full_demod(struct demod_state *d)
 	memcpy(d->droop_q_hist, c.droop_q_hist, sizeof(c.droop_q_hist));
 	g_side[slot].avg = c.deemph_avg;
 	d->now_lpr = c.now_lpr; d->prev_lpr_index = c.prev_lpr_index;
+	d->squelch_hits = c.squelch_hits; d->dc_avg = c.dc_avg;
 }
 
 void rxgpu_callback(int16_t *buf, uint32_t len, void *ctx)

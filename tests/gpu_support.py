@@ -20,7 +20,7 @@ def to_dev(a):
 
 def carry_from_oracle_state(st):
     c = R.FmCarry()
-    for f in ("now_r", "now_j", "prev_index", "pre_r", "pre_j", "deemph_avg", "now_lpr", "prev_lpr_index"):
+    for f in ("now_r", "now_j", "prev_index", "pre_r", "pre_j", "deemph_avg", "now_lpr", "prev_lpr_index", "squelch_hits", "dc_avg"):
         setattr(c, f, getattr(st, f))
     C.memmove(C.addressof(c.lp_i_hist), C.addressof(st.lp_i_hist), C.sizeof(c.lp_i_hist))
     C.memmove(C.addressof(c.lp_q_hist), C.addressof(st.lp_q_hist), C.sizeof(c.lp_q_hist))
@@ -44,6 +44,8 @@ def gpu_fm_stream(iq, block_len, n_runs=1, carry=None, pipelined=False, **params
     n_blocks = len(iq) // block_len
     per = (n_blocks + n_runs - 1) // n_runs
     s = R.FmStream(p, per, block_len)
+    if carry is None and "squelch_hits" in params:
+        carry = R.FmCarry()
     if carry is not None:
         s.set_carry(carry)
     d_iq = to_dev(iq)

@@ -41,11 +41,14 @@ class FmState(C.Structure):
         ("downsample", C.c_int), ("downsample_passes", C.c_int), ("comp_fir_size", C.c_int),
         ("custom_atan", C.c_int), ("deemph", C.c_int), ("deemph_a", C.c_int),
         ("rate_out", C.c_int), ("rate_out2", C.c_int), ("offset_tuning", C.c_int), ("mute", C.c_int),
+        ("mode", C.c_int), ("output_scale", C.c_int), ("squelch_level", C.c_int),
+        ("dc_block_audio", C.c_int), ("adc_block_const", C.c_int),
         ("now_r", C.c_int), ("now_j", C.c_int), ("prev_index", C.c_int),
         ("pre_r", C.c_int), ("pre_j", C.c_int),
         ("lp_i_hist", (C.c_int16 * 6) * 10), ("lp_q_hist", (C.c_int16 * 6) * 10),
         ("droop_i_hist", C.c_int16 * 9), ("droop_q_hist", C.c_int16 * 9),
         ("deemph_avg", C.c_int), ("now_lpr", C.c_int), ("prev_lpr_index", C.c_int),
+        ("squelch_hits", C.c_int), ("dc_avg", C.c_int),
     ]
 
 
@@ -149,16 +152,23 @@ def ref_fm_reset(L, **params):
     d.downsample = params.get("downsample", 6)
     d.downsample_passes = params.get("downsample_passes", 0)
     d.comp_fir_size = params.get("comp_fir_size", 0)
-    d.squelch_level = 0
+    d.squelch_level = params.get("squelch_level", 0)
+    d.squelch_hits = params.get("squelch_hits", 11)          # demod_init, rtl_fm.c:1091
     d.post_downsample = 1
-    d.output_scale = 1
+    d.output_scale = params.get("output_scale", 1)
+    d.dc_block_audio = params.get("dc_block_audio", 0)
+    d.adc_block_const = params.get("adc_block_const", 9)
+    d.dc_avg = 0
+    if d.custom_atan == 2:
+        L.atan_lut_init()
     d.prev_index = d.now_r = d.now_j = d.pre_r = d.pre_j = 0
     d.now_lpr = d.prev_lpr_index = 0
     C.memset(C.addressof(d.lp_i_hist), 0, C.sizeof(d.lp_i_hist))
     C.memset(C.addressof(d.lp_q_hist), 0, C.sizeof(d.lp_q_hist))
     C.memset(C.addressof(d.droop_i_hist), 0, C.sizeof(d.droop_i_hist))
     C.memset(C.addressof(d.droop_q_hist), 0, C.sizeof(d.droop_q_hist))
-    d.mode_demod = L.ref_fm_fn(0)
+    # oracle/librxgpu mode numbers (0 fm, 1 am, 2 usb, 3 lsb, 4 raw) -> ref_fm_fn's (0 fm, 1 raw, 2 am, 3 usb, 4 lsb)
+    d.mode_demod = L.ref_fm_fn({0: 0, 1: 2, 2: 3, 3: 4, 4: 1}[params.get("mode", 0)])
     s.offset_tuning = params.get("offset_tuning", 0)
     s.mute = params.get("mute", 0)
     assert L.ref_fm_deemph_force(params.get("deemph_avg", 0)) == params.get("deemph_avg", 0)
@@ -178,6 +188,12 @@ def oracle_fm_state(**params):
     st.offset_tuning = params.get("offset_tuning", 0)
     st.mute = params.get("mute", 0)
     st.deemph_avg = params.get("deemph_avg", 0)
+    st.mode = params.get("mode", 0)
+    st.output_scale = params.get("output_scale", 1)
+    st.squelch_level = params.get("squelch_level", 0)
+    st.squelch_hits = params.get("squelch_hits", 11)
+    st.dc_block_audio = params.get("dc_block_audio", 0)
+    st.adc_block_const = params.get("adc_block_const", 9)
     return st
 
 

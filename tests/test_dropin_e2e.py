@@ -116,7 +116,8 @@ def run_power_main(mode, data, plan, tmp_path, extra):
     return [line.split(", ", 2)[2] for line in open(out_path).read().splitlines()], p.stderr.decode()
 
 
-POWER_ARGS = ("88M:108M:125k", "hamming", (1, 0, 0), ["-f", "88M:108M:125k", "-w", "hamming", "-i", "1", "-1"])
+# -i 2: the reference ticks on whole seconds of time(NULL) (rtl_power.c:1029,1041-1043); 2 s leaves >= 1 s for the three passes
+POWER_ARGS = ("88M:108M:125k", "hamming", (1, 0, 0), ["-f", "88M:108M:125k", "-w", "hamming", "-i", "2", "-1"])
 
 
 @pytest.mark.ref

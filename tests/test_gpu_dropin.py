@@ -24,6 +24,10 @@ def fresh_demod(**kw):
     d.comp_fir_size = kw.get("comp_fir_size", 0)
     d.post_downsample = 1
     d.output_scale = 1
+    d.squelch_level = kw.get("squelch_level", 0)
+    d.squelch_hits = 11
+    d.dc_block_audio = kw.get("dc_block_audio", 0)
+    d.adc_block_const = 9
     libc = C.CDLL(None)
     libc.pthread_rwlock_init(C.byref(d, DemodState.rw.offset), None)
     libc.pthread_cond_init(C.byref(d, DemodState.ready.offset), None)
@@ -32,7 +36,8 @@ def fresh_demod(**kw):
 
 
 @pytest.mark.parametrize("kw", [dict(downsample=6), dict(downsample=118), dict(downsample_passes=3, comp_fir_size=9),
-                                dict(downsample=9, custom_atan=0, deemph=0, rate_out2=-1)])
+                                dict(downsample=9, custom_atan=0, deemph=0, rate_out2=-1),
+                                dict(downsample=6, squelch_level=30, dc_block_audio=1)])
 def test_full_demod_and_callback_dropin(kw):
     """rxgpu_callback + rxgpu_full_demod, block after block on a struct demod_state, == the oracle's
     rtlsdr_callback pre-stage + full_demod, including lowpassed[], lp_len and every carry"""
@@ -67,6 +72,7 @@ def test_full_demod_and_callback_dropin(kw):
         assert bytes(d.lp_i_hist) == bytes(st.lp_i_hist) and bytes(d.lp_q_hist) == bytes(st.lp_q_hist)
         assert bytes(d.droop_i_hist) == bytes(st.droop_i_hist) and bytes(d.droop_q_hist) == bytes(st.droop_q_hist)
         assert L.rxgpu_deemph_state(C.addressof(d)).contents.value == st.deemph_avg
+        assert (d.squelch_hits, d.dc_avg) == (st.squelch_hits, st.dc_avg)
 
 
 @pytest.mark.parametrize("rng,flags,window", [("24M:60M:1k", (1, 0, 0), "hamming"), ("100M:105M:1M", (1, 0, 1), "rectangle"),

@@ -129,6 +129,40 @@ def test_deemph_multi_level_tree(topcap, monkeypatch):
         _check(iq, 16384, downsample=4, deemph_a=33)
 
 
+@pytest.mark.parametrize("params", [
+    dict(downsample=6, mode=1, output_scale=3, deemph=0),             # -M am
+    dict(downsample=6, mode=2, output_scale=2),                       # -M usb (+deemph, resample)
+    dict(downsample=6, mode=3, deemph=0, rate_out2=-1),               # -M lsb
+    dict(downsample=6, mode=4),                                       # -M raw
+    dict(downsample=118, mode=4),
+    dict(downsample=10, custom_atan=2),                               # -A lut
+    dict(downsample=10, custom_atan=3),                               # -A ale
+    dict(downsample=6, squelch_level=40),                             # -l
+    dict(downsample=6, squelch_level=2000),
+    dict(downsample=118, squelch_level=900),
+    dict(downsample=6, dc_block_audio=1),                             # -E adc
+    dict(downsample=118, dc_block_audio=1, deemph=0),
+    dict(downsample=118, dc_block_audio=1, deemph=0, rate_out2=-1),
+    dict(downsample_passes=3, dc_block_audio=1, squelch_level=100, mode=1, output_scale=1),
+    dict(downsample_passes=3, comp_fir_size=9, mode=4),
+])
+@pytest.mark.parametrize("n_runs", [1, 3])
+def test_other_demodulators_and_filters(params, n_runs):
+    """-M am|usb|lsb|raw, -A lut|ale, -l squelch, -E adc: SURVEY section 8(f) rank 3, same parity bar"""
+    from gpu_support import gpu_fm_stream
+    import rx_tools_amd as R
+    for iq in (sig_fm(9 * 8192, seed=31), sig_noise(9 * 16384, seed=32), sig_noise(9 * 16384, seed=33, amp=300),
+               np.zeros(9 * 16384, np.int16)):
+        want, want_lens, st = oracle_fm_stream(iq, 16384, **params)
+        c0 = R.FmCarry()
+        c0.squelch_hits = 11                                            # demod_init, rtl_fm.c:1091
+        got, got_lens, carry, _ = gpu_fm_stream(iq, 16384, n_runs=n_runs, carry=c0, **params)
+        assert len(got) == len(want) and np.array_equal(got, want)
+        assert np.array_equal(got_lens, want_lens)
+        assert (carry.squelch_hits, carry.dc_avg, carry.now_lpr, carry.prev_lpr_index, carry.pre_r, carry.pre_j) == \
+            (st.squelch_hits, st.dc_avg, st.now_lpr, st.prev_lpr_index, st.pre_r, st.pre_j)
+
+
 def test_scale_formula_exhaustive_on_device():
     """F0 on the device for all 65536 int16 values == the reference's fp64 expression"""
     from gpu_support import gpu_fm_stream
