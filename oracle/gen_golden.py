@@ -66,6 +66,15 @@ FM_CASES = [
     ("std_atan", "fm", 3, 4096, dict(downsample=10, custom_atan=0)),
     ("odd_block", "fm", 5, 4096 + 8, dict(downsample=7)),
     ("no_deemph_no_resample", "noise", 3, 4096, dict(downsample=6, deemph=0, rate_out2=-1)),
+    # the other demodulators and filters
+    ("am", "fm", 3, 8192, dict(downsample=6, mode=1, output_scale=3, deemph=0)),
+    ("usb", "noise", 3, 8192, dict(downsample=6, mode=2, output_scale=2)),
+    ("lsb", "fm", 3, 8192, dict(downsample=6, mode=3, deemph=0, rate_out2=-1)),
+    ("raw", "fm", 3, 8192, dict(downsample=6, mode=4)),
+    ("atan_lut", "fm", 3, 8192, dict(downsample=10, custom_atan=2)),
+    ("atan_ale", "noise", 3, 8192, dict(downsample=10, custom_atan=3)),
+    ("squelch", "fm", 4, 8192, dict(downsample=6, squelch_level=2000)),
+    ("adc", "noise", 4, 8192, dict(downsample=6, dc_block_audio=1)),
 ]
 
 

@@ -15,6 +15,11 @@ pytestmark = [pytest.mark.ref, pytest.mark.skipif(not have_ref(), reason="oracle
     dict(downsample=6), dict(downsample=118), dict(downsample=5, rate_out=240000, deemph_a=19),
     dict(downsample_passes=3), dict(downsample_passes=3, comp_fir_size=9), dict(downsample_passes=7),
     dict(downsample=9, custom_atan=0), dict(downsample=118, offset_tuning=1), dict(downsample=6, mute=4096),
+    dict(downsample=6, mode=1, output_scale=3, deemph=0), dict(downsample=6, mode=2, output_scale=2),
+    dict(downsample=6, mode=3, deemph=0, rate_out2=-1), dict(downsample=6, mode=4),
+    dict(downsample=10, custom_atan=2), dict(downsample=10, custom_atan=3),
+    dict(downsample=6, squelch_level=40), dict(downsample=6, squelch_level=2000), dict(downsample=6, dc_block_audio=1),
+    dict(downsample_passes=3, dc_block_audio=1, squelch_level=100, mode=1, output_scale=1),
 ])
 def test_fm_stream_matches_reference(params):
     L = ref_fm()
@@ -26,8 +31,8 @@ def test_fm_stream_matches_reference(params):
             a, la, d = ref_fm_stream(L, iq, bl, **params)
             b, lb, st = oracle_fm_stream(iq, bl, **params)
             assert np.array_equal(a, b) and np.array_equal(la, lb)
-            assert (d.now_r, d.now_j, d.prev_index, d.pre_r, d.pre_j, d.now_lpr, d.prev_lpr_index) == \
-                (st.now_r, st.now_j, st.prev_index, st.pre_r, st.pre_j, st.now_lpr, st.prev_lpr_index)
+            assert (d.now_r, d.now_j, d.prev_index, d.pre_r, d.pre_j, d.now_lpr, d.prev_lpr_index, d.squelch_hits, d.dc_avg) == \
+                (st.now_r, st.now_j, st.prev_index, st.pre_r, st.pre_j, st.now_lpr, st.prev_lpr_index, st.squelch_hits, st.dc_avg)
 
 
 def test_struct_layout_matches_reference():
