@@ -115,7 +115,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--blocks", type=int, default=8192, help="rx_fm blocks of 131072 complex samples per step (8192 = 4 GiB of cs16)")
     ap.add_argument("--passes", type=int, default=512, help="rx_power scanner() passes per step (one report interval)")
-    ap.add_argument("--workload", default="both", choices=["both", "rx_fm", "rx_power"])
+    ap.add_argument("--workload", default="both", choices=["both", "rx_fm", "rx_power", "chan"])
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU baseline budget per path (0 = skip)")
     ap.add_argument("--prof-level", type=int, default=1)
     args = ap.parse_args()
@@ -280,6 +280,44 @@ def main():
                            "data": "synthetic"})
         else:
             result["rx_power"] = pw
+
+    # ------------------------------------------------------------------ channeliser (extension, configs[4])
+    if args.workload in ("both", "chan"):
+        block_len, bin_e, n_ch = 2 * 131072, 10, 256
+        n_blocks = max(8, args.blocks // 8)                       # 1024 blocks = 512 MiB per step by default
+        base = R.synth.sig_fm(8 * 131072, seed=4242 + rank, amp=600.0)
+        d_iq = torch.from_numpy(base).to(dev).repeat(n_blocks // 8 + 1)[: n_blocks * block_len].contiguous()
+        T = n_blocks * (block_len // 2)
+        windows = T >> bin_e
+        d_out = torch.zeros((n_ch, windows), dtype=torch.int16, device=dev)
+        ch = R.Channeliser(R.ChanParams(bin_e, 384, n_ch, 1), n_blocks, block_len, R.sine_table(bin_e))
+        steps = max(5, args.steps // 5)
+        for _ in range(max(1, args.warmup // 3)):
+            ch.run(d_iq.data_ptr(), n_blocks, block_len, d_out.data_ptr(), windows)
+        L.rxgpu_prof_reset()
+        L.rxgpu_prof_enable(args.prof_level)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ch.run(d_iq.data_ptr(), n_blocks, block_len, d_out.data_ptr(), windows)
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        L.rxgpu_prof_enable(0)
+        ms, launches = prof("ch_fft")
+        ch.close()
+        achieved = (4.0 * T) / (ms / launches * 1e-3) / 1e9 if launches else 0.0
+        result["channeliser"] = {
+            "metric": "256-channel NBFM channeliser, capture MSample/s (extension: fix_fft per 1024-sample window + fm_demod per channel)",
+            "value": world * T * steps / dt / 1e6, "unit": "MSample/s", "n_gpus": world, "steps": steps,
+            "ms_per_step": dt / steps * 1e3, "dtype": "int16/int32",
+            "config": {"workload": "BASELINE configs[4]: 256 channels x 19.5 kHz from one 20 Msps capture, N=1024, -A fast",
+                       "blocks_per_step": n_blocks, "parallelism": "replicas x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "k_ch_fft", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": 4 * T,
+                         "avg_launch_ms": (ms / launches) if launches else None,
+                         "note": "integer-VALU/LDS bound like k_pw_fft (radix-2 per barrier in LDS); first version"},
+        }
+        del d_iq, d_out
 
     if world > 1:
         dist.barrier()

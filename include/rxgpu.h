@@ -158,6 +158,39 @@ int rxgpu_fm_stream_run_host(rxgpu_fm_stream *s, const int16_t *h_iq, size_t n_b
  * the last run (device fp64 atan2 result too close to an integer boundary to trust). */
 long rxgpu_fm_stream_host_fixups(const rxgpu_fm_stream *s);
 
+/* ------------------------------------------------- rx_fm: channeliser (extension)
+ *
+ * BASELINE configs[4] / SURVEY.md section 8(f) rank 2.  NOT a reference feature: rx_tools has a single
+ * demod_state ("multiple of these, eventually", rtl_fm.c:189) and no mixer beyond rotate16_90.  It is
+ * specified from reference primitives only, so that its oracle is made of functions already pinned against
+ * the reference: every window of N = 2^bin_e capture samples goes through fix_fft (rtl_power.c:264-320) --
+ * the bank of "mix by k*fs/N, boxcar-sum N samples" channels, i.e. low_pass (rtl_fm.c:351-371) at ds = N for
+ * every offset at once, in the reference's fixed-point scaling -- and bin first_bin+c of successive windows
+ * is channel c's lowpassed[] stream, demodulated by fm_demod (rtl_fm.c:584-615; each callback block's
+ * first sample through libm atan2, the rest per custom_atan) with per-channel carried pre_r/pre_j.
+ * Channel spacing = channel sample rate = fs/N (20 Msps, N=1024: 19.5 kHz NBFM channels). */
+typedef struct rxgpu_chan_params {
+	int bin_e;               /* window length 2^bin_e complex samples (1..15) */
+	int first_bin;           /* channel c = FFT bin (first_bin + c) mod N */
+	int n_channels;
+	int custom_atan;         /* 0 std, 1 fast */
+} rxgpu_chan_params;
+
+typedef struct rxgpu_chan rxgpu_chan;
+
+/* sinewave: rxgpu_sine_table(bin_e).  block_len (int16) must hold a whole number of windows. */
+int rxgpu_chan_create(rxgpu_chan **out, const rxgpu_chan_params *p, size_t max_blocks, size_t block_len,
+                      const int16_t *sinewave);
+void rxgpu_chan_destroy(rxgpu_chan *s);
+/* pre: n_channels pairs (pre_r, pre_j) */
+int rxgpu_chan_set_carry(rxgpu_chan *s, const int *pre);
+int rxgpu_chan_get_carry(rxgpu_chan *s, int *pre);
+/* d_iq: DEVICE, n_blocks * block_len int16.  d_out: DEVICE, [n_channels][out_stride] int16; channel c's
+ * demodulated samples (one per window) at d_out[c*out_stride .. + windows).  Synchronous. */
+int rxgpu_chan_run(rxgpu_chan *s, const int16_t *d_iq, size_t n_blocks, size_t block_len, int16_t *d_out,
+                   size_t out_stride, size_t *windows_out);
+long rxgpu_chan_host_fixups(const rxgpu_chan *s);
+
 /* --------------------------------------------------------- rx_power: drop-in */
 
 /* Replaces scanner(channel)'s per-tune compute at rtl_power.c:709-770 for tunes whose

@@ -635,3 +635,26 @@ int rxo_csv_row(char *dst, size_t cap, int64_t freq, int rate, int bin_e, int do
 	*samples = 0;
 	return (int)pos;
 }
+
+/* =============================================================== channeliser (extension, see rx_oracle.h) */
+
+void rxo_chan_block(const rxo_chan_cfg *cfg, const int16_t *in, int len, int *pre, int16_t *out, size_t out_stride)
+{
+	const int n = 1 << cfg->bin_e, windows = len / 2 / n;
+	int16_t *win = malloc((size_t)2 * n * sizeof(int16_t));
+	int16_t *lp = malloc((size_t)cfg->n_channels * 2 * windows * sizeof(int16_t));
+	for (int w = 0; w < windows; w++) {
+		memcpy(win, in + (size_t)w * 2 * n, (size_t)2 * n * sizeof(int16_t));
+		rxo_fix_fft(win, cfg->bin_e, cfg->sinewave);
+		for (int c = 0; c < cfg->n_channels; c++) {
+			int bin = (cfg->first_bin + c) & (n - 1);
+			lp[((size_t)c * windows + w) * 2] = win[2 * bin];
+			lp[((size_t)c * windows + w) * 2 + 1] = win[2 * bin + 1];
+		}
+	}
+	for (int c = 0; c < cfg->n_channels; c++)
+		rxo_fm_demod(lp + (size_t)c * windows * 2, 2 * windows, cfg->custom_atan, &pre[2 * c], &pre[2 * c + 1],
+		             out + (size_t)c * out_stride);
+	free(win);
+	free(lp);
+}

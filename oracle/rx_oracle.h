@@ -93,6 +93,25 @@ int rxo_fm_full_demod(rxo_fm_state *st, int16_t *lp, int *lp_len, int16_t *out);
 long rxo_fm_stream(rxo_fm_state *st, const int16_t *in, size_t n_blocks, int block_len,
                    int16_t *out, int *per_block_len);
 
+/* ------------------------------------------------- rx_fm channeliser (extension)
+ * BASELINE configs[4] / SURVEY section 8(f) rank 2.  NOT in the reference, which has a single demod_state
+ * ("multiple of these, eventually", rtl_fm.c:189) and no mixer beyond rotate16_90.  Specified here
+ * entirely from reference primitives: every window of N = 2^bin_e capture samples goes through the
+ * reference's integer FFT fix_fft (rtl_power.c:264-320) -- mathematically the bank of "mix by k*fs/N,
+ * boxcar-sum N samples" channels, i.e. rx_fm's low_pass at ds = N for every offset at once -- and bin
+ * first_bin+c of successive windows is channel c's lowpassed[] stream, demodulated by fm_demod
+ * (rtl_fm.c:584-615) with its own carried pre_r/pre_j, callback block after callback block. */
+typedef struct rxo_chan_cfg {
+	int bin_e;               /* window = 1<<bin_e complex samples; channel spacing fs/N, channel rate fs/N */
+	int first_bin;           /* channel c is FFT bin (first_bin + c) mod N */
+	int n_channels;
+	int custom_atan;         /* 0 std, 1 fast (as -A) */
+	const int16_t *sinewave; /* rxo_sine_table(bin_e) */
+} rxo_chan_cfg;
+/* one callback block of len int16 (len/2 % N == 0): out[c * out_stride + w] for its len/2/N windows;
+ * pre[2*c], pre[2*c+1] = the channel's carried pre_r, pre_j; work: 2*N int16 + n_channels*2*windows int16 */
+void rxo_chan_block(const rxo_chan_cfg *cfg, const int16_t *in, int len, int *pre, int16_t *out, size_t out_stride);
+
 /* --------------------------------------------------------------- rx_power */
 
 typedef struct rxo_power_cfg {

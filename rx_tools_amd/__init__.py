@@ -5,6 +5,6 @@ this package is only the ctypes plumbing that tests and bench.py drive it with. 
 no CPU implementation here: without librxgpu.so and a HIP device every call fails.
 """
 from ._lib import lib, RxGpuError, check          # noqa: F401
-from .fm import FmParams, FmCarry, FmStream        # noqa: F401
+from .fm import FmParams, FmCarry, FmStream, ChanParams, Channeliser        # noqa: F401
 from .power import PowerParams, PowerPlan, PowerScan, plan_range, sine_table, window_coefs  # noqa: F401
 from . import synth  # noqa: F401

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernels.h"
+#include "fft_device.h"
 
 typedef unsigned long long u64;
 typedef long long i64;
@@ -1136,6 +1137,87 @@ __global__ void k_fm_prestage(const uint32_t *__restrict__ in, unsigned n, int r
 	out[i] = pack_iq(ri, rq);
 }
 
+// ------------------------------------------------------------------ channeliser (extension)
+
+// BASELINE configs[4] / SURVEY section 8(f) rank 2 -- not in the reference; specified from its primitives
+// (include/rxgpu.h, "rx_fm: channeliser"): every window of N capture samples through fix_fft
+// (rtl_power.c:264-320), bin first_bin+c of successive windows = channel c's lowpassed[] stream.
+// One workgroup transforms `wpg` consecutive windows side by side in LDS (the stage index maths
+// of the radix-2 network does not care that the array holds several aligned windows) and writes
+// the selected bins as [channel][window], wpg windows contiguous per channel.
+__global__ __launch_bounds__(256) void k_ch_fft(const uint32_t *__restrict__ iq, u64 total_windows, int bin_e, int wpg,
+                                                const uint32_t *__restrict__ twiddle, int first_bin, int n_channels,
+                                                uint32_t *__restrict__ chan_lp)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t x[];
+	const int n = 1 << bin_e, tot = wpg << bin_e;
+	const u64 w0 = (u64)blockIdx.x * wpg;
+	for (int e = threadIdx.x; e < tot; e += 256) {
+		const int win = e >> bin_e, j = e & (n - 1);
+		const uint32_t v = (w0 + win < total_windows) ? iq[((w0 + win) << bin_e) + j] : 0u;
+		x[(win << bin_e) + (int)(__brev((unsigned)j) >> (32 - bin_e))] = v;      // rtl_power.c:275-290
+	}
+	__syncthreads();
+	for (int s = 0; s < bin_e; s++) {                                             // rtl_power.c:291-318
+		const int half = 1 << s;
+		for (int b = threadIdx.x; b < tot / 2; b += 256) {
+			const int t = b & (half - 1);
+			const int lo_i = ((b >> s) << (s + 1)) | t;
+			uint32_t lo = x[lo_i], hi = x[lo_i + half];
+			butterfly(lo, hi, twiddle[t << (bin_e - 1 - s)]);
+			x[lo_i] = lo;
+			x[lo_i + half] = hi;
+		}
+		__syncthreads();
+	}
+	for (int idx = threadIdx.x; idx < n_channels * wpg; idx += 256) {
+		const int c = idx / wpg, win = idx - c * wpg;
+		if (w0 + win < total_windows)
+			chan_lp[(u64)c * total_windows + w0 + win] = x[(win << bin_e) + ((first_bin + c) & (n - 1))];
+	}
+}
+
+// fm_demod (rtl_fm.c:584-615) per channel: thread (c, t); the first window of every callback block
+// goes through the libm discriminator like every block's first sample does in rx_fm
+__global__ void k_ch_demod(const uint32_t *__restrict__ chan_lp, u64 total_windows, u64 wpb, int n_channels, int custom_atan,
+                           const int *__restrict__ pre_in, int *__restrict__ pre_out, int16_t *__restrict__ out, u64 out_stride,
+                           rxk_fm_dev *__restrict__ dev, u64 *__restrict__ flag_list)
+{
+	const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (gid >= (u64)n_channels * total_windows)
+		return;
+	const u64 c = gid / total_windows, t = gid - c * total_windows;
+	const uint32_t a = chan_lp[gid];
+	int br, bj;
+	if (t) {
+		const uint32_t b = chan_lp[gid - 1];
+		br = lo16(b); bj = hi16(b);
+	} else {
+		br = pre_in[2 * c]; bj = pre_in[2 * c + 1];
+	}
+	const int ar = lo16(a), aj = hi16(a);
+	const int cr = (int)((unsigned)ar * (unsigned)br + (unsigned)aj * (unsigned)bj);
+	const int cj = (int)((unsigned)aj * (unsigned)br - (unsigned)ar * (unsigned)bj);
+	int v;
+	if (custom_atan == 0 || (t % wpb) == 0) {
+		const double ang = atan2((double)cj, (double)cr);
+		const double r = ang / 3.14159 * 16384.0;
+		v = (int)r;
+		if (r != 0.0 && fabs(r - rint(r)) < 1e-6) {
+			const int idx = atomicAdd(&dev->flag_cnt, 1);
+			if (idx < RXK_FLAG_CAP)
+				flag_list[idx] = gid;
+		}
+	} else {
+		v = fast_atan2_dev(cj, cr);
+	}
+	out[c * out_stride + t] = (int16_t)v;
+	if (t == total_windows - 1) {
+		pre_out[2 * c] = ar;
+		pre_out[2 * c + 1] = aj;
+	}
+}
+
 // ------------------------------------------------------------------ launchers
 
 #define LAUNCH_RET() return (int)hipGetLastError()
@@ -1374,5 +1456,34 @@ extern "C" int rxk_fm_dc_block(void *stream, int16_t *y, u64 M, rxk_fm_blocks bl
 	hipLaunchKernelGGL(k_fm_dc_sums, dim3((unsigned)blk.n_blocks), dim3(256), 0, s, y, blk, (i64 *)sums);
 	hipLaunchKernelGGL(k_fm_dc_scan, dim3(1), dim3(64), 0, s, (const i64 *)sums, blk, adc_block_const, avgs, dev);
 	hipLaunchKernelGGL(k_fm_dc_apply, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, y, M, blk, avgs);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_ch_fft(void *stream, const int16_t *iq, u64 total_windows, int bin_e, const uint32_t *twiddle,
+                          int first_bin, int n_channels, uint32_t *chan_lp)
+{
+	if (!total_windows)
+		return 0;
+	int wpg = bin_e >= 13 ? 1 : (8192 >> bin_e);
+	const size_t shm = ((size_t)wpg << bin_e) * 4;
+	static size_t allowed = 64 * 1024;
+	if (shm > allowed) {
+		(void)hipFuncSetAttribute((const void *)k_ch_fft, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+		allowed = 144 * 1024;
+	}
+	const unsigned grid = (unsigned)((total_windows + wpg - 1) / wpg);
+	hipLaunchKernelGGL(k_ch_fft, dim3(grid), dim3(256), shm, (hipStream_t)stream, (const uint32_t *)iq, total_windows, bin_e, wpg,
+	                   twiddle, first_bin, n_channels, chan_lp);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_ch_demod(void *stream, const uint32_t *chan_lp, u64 total_windows, u64 wpb, int n_channels, int custom_atan,
+                            const int *pre_in, int *pre_out, int16_t *out, u64 out_stride, rxk_fm_dev *dev, u64 *flag_list)
+{
+	const u64 total = (u64)n_channels * total_windows;
+	if (!total)
+		return 0;
+	hipLaunchKernelGGL(k_ch_demod, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, chan_lp, total_windows, wpb,
+	                   n_channels, custom_atan, pre_in, pre_out, out, out_stride, dev, flag_list);
 	LAUNCH_RET();
 }

@@ -128,6 +128,13 @@ int rxk_fm_droop(void *stream, const uint32_t *in, unsigned long long M, const i
 /* rtlsdr_callback's scale + rotate alone (rtl_fm.c:845-857), n_complex samples */
 int rxk_fm_prestage(void *stream, const int16_t *in, unsigned n_complex, int rotate, int16_t *out);
 
+/* channeliser (extension): fix_fft per window, selected bins as [channel][window]; then fm_demod per channel */
+int rxk_ch_fft(void *stream, const int16_t *iq, unsigned long long total_windows, int bin_e, const uint32_t *twiddle,
+               int first_bin, int n_channels, uint32_t *chan_lp);
+int rxk_ch_demod(void *stream, const uint32_t *chan_lp, unsigned long long total_windows, unsigned long long wpb, int n_channels,
+                 int custom_atan, const int *pre_in, int *pre_out, int16_t *out, unsigned long long out_stride,
+                 rxk_fm_dev *dev, unsigned long long *flag_list);
+
 /* ------------------------------------------------------------- rx_power */
 
 /* P1,P4-P8 fused (rtl_power.c:715-720, 744-770) for ds == 1 or pre-downsampled input:

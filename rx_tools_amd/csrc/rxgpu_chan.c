@@ -1,0 +1,177 @@
+/* rxgpu_chan.c -- host side of the rx_fm channeliser (extension; BASELINE configs[4]).
+ *
+ * The reference has one demod_state ("multiple of these, eventually", rtl_fm.c:189) and no mixer beyond
+ * rotate16_90.  The channeliser is specified entirely from reference primitives: every window of
+ * N = 2^bin_e capture samples through fix_fft (rtl_power.c:264-320) -- the bank of "mix by k*fs/N and
+ * boxcar-sum N samples" channels, i.e. low_pass (rtl_fm.c:351-371) at ds = N for every offset at once,
+ * with the reference's own fixed-point scaling -- and fm_demod (rtl_fm.c:584-615) per channel with its
+ * own carried pre_r/pre_j, callback block after callback block.
+ */
+#include "rxgpu_internal.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+struct rxgpu_chan {
+	rxgpu_chan_params p;
+	size_t max_windows;
+	uint32_t *twiddle_dev, *chan_lp;
+	int *pre_dev[2];                 /* carried (pre_r, pre_j) per channel: in / out */
+	int *pre_host;
+	rxk_fm_dev *dev, *dev_host;
+	unsigned long long *flag_list, *flag_host;
+	long fixups;
+};
+
+int rxgpu_chan_create(rxgpu_chan **out, const rxgpu_chan_params *p, size_t max_blocks, size_t block_len, const int16_t *sinewave)
+{
+	int rc;
+	rxgpu_chan *s;
+	if (!out || !p || !sinewave || !max_blocks || block_len < 2 || (block_len & 1))
+		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_chan_create: bad arguments");
+	if (p->bin_e < 1 || p->bin_e > 15)
+		return rxgpu_fail(RXGPU_EUNSUPPORTED, "window of 2^%d samples outside 2^1..2^15", p->bin_e);
+	const size_t n = (size_t)1 << p->bin_e;
+	if ((block_len / 2) % n)
+		return rxgpu_fail(RXGPU_EUNSUPPORTED, "block of %zu samples is not a whole number of %zu-sample windows", block_len / 2, n);
+	if (p->n_channels < 1 || (size_t)p->n_channels > n || p->first_bin < 0 || (size_t)p->first_bin >= n)
+		return rxgpu_fail(RXGPU_EINVAL, "channels [%d, %d) do not fit %zu bins", p->first_bin, p->first_bin + p->n_channels, n);
+	if (p->custom_atan != 0 && p->custom_atan != 1)
+		return rxgpu_fail(RXGPU_EUNSUPPORTED, "channeliser: -A std or fast only");
+	if ((rc = rxgpu_ensure_init()) != RXGPU_OK)
+		return rc;
+	s = calloc(1, sizeof(*s));
+	if (!s)
+		return rxgpu_fail(RXGPU_ENOMEM, "out of host memory");
+	s->p = *p;
+	s->max_windows = max_blocks * (block_len / 2 / n);
+	uint32_t *tw = malloc((n / 2 + 1) * 4);
+	if (!tw) { free(s); return rxgpu_fail(RXGPU_ENOMEM, "out of host memory"); }
+	for (size_t j = 0; j < n / 2; j++) {              /* rtl_power.c:297-301: halve AFTER negating */
+		int16_t wr = sinewave[j + n / 4];
+		int16_t wi = (int16_t)(-sinewave[j]);
+		wr >>= 1;
+		wi >>= 1;
+		tw[j] = ((uint32_t)(uint16_t)wr) | ((uint32_t)(uint16_t)wi << 16);
+	}
+	const size_t nc = (size_t)p->n_channels;
+	if (hipMalloc((void **)&s->twiddle_dev, (n / 2 + 1) * 4) != hipSuccess ||
+	    hipMalloc((void **)&s->chan_lp, nc * s->max_windows * 4) != hipSuccess ||
+	    hipMalloc((void **)&s->pre_dev[0], nc * 8) != hipSuccess || hipMalloc((void **)&s->pre_dev[1], nc * 8) != hipSuccess ||
+	    hipMalloc((void **)&s->dev, sizeof(rxk_fm_dev)) != hipSuccess ||
+	    hipMalloc((void **)&s->flag_list, RXK_FLAG_CAP * 8) != hipSuccess ||
+	    hipHostMalloc((void **)&s->dev_host, sizeof(rxk_fm_dev), 0) != hipSuccess ||
+	    hipHostMalloc((void **)&s->flag_host, RXK_FLAG_CAP * 8, 0) != hipSuccess ||
+	    hipHostMalloc((void **)&s->pre_host, nc * 8, 0) != hipSuccess ||
+	    hipMemcpy(s->twiddle_dev, tw, (n / 2) * 4, hipMemcpyHostToDevice) != hipSuccess) {
+		free(tw);
+		rxgpu_chan_destroy(s);
+		return rxgpu_fail(RXGPU_ENOMEM, "channeliser workspace allocation failed");
+	}
+	free(tw);
+	memset(s->pre_host, 0, nc * 8);
+	*out = s;
+	return RXGPU_OK;
+}
+
+void rxgpu_chan_destroy(rxgpu_chan *s)
+{
+	if (!s)
+		return;
+	hipFree(s->twiddle_dev); hipFree(s->chan_lp); hipFree(s->pre_dev[0]); hipFree(s->pre_dev[1]);
+	hipFree(s->dev); hipFree(s->flag_list);
+	if (s->dev_host) hipHostFree(s->dev_host);
+	if (s->flag_host) hipHostFree(s->flag_host);
+	if (s->pre_host) hipHostFree(s->pre_host);
+	free(s);
+}
+
+int rxgpu_chan_set_carry(rxgpu_chan *s, const int *pre)
+{
+	if (!s || !pre)
+		return rxgpu_fail(RXGPU_EINVAL, "null argument");
+	memcpy(s->pre_host, pre, (size_t)s->p.n_channels * 8);
+	return RXGPU_OK;
+}
+
+int rxgpu_chan_get_carry(rxgpu_chan *s, int *pre)
+{
+	if (!s || !pre)
+		return rxgpu_fail(RXGPU_EINVAL, "null argument");
+	memcpy(pre, s->pre_host, (size_t)s->p.n_channels * 8);
+	return RXGPU_OK;
+}
+
+long rxgpu_chan_host_fixups(const rxgpu_chan *s) { return s ? s->fixups : 0; }
+
+static int disc_host(int ar, int aj, int br, int bj)
+{
+	int cr = (int)((unsigned)ar * (unsigned)br + (unsigned)aj * (unsigned)bj);
+	int cj = (int)((unsigned)aj * (unsigned)br - (unsigned)ar * (unsigned)bj);
+	return (int)(atan2((double)cj, (double)cr) / 3.14159 * (1 << 14));
+}
+
+int rxgpu_chan_run(rxgpu_chan *s, const int16_t *d_iq, size_t n_blocks, size_t block_len, int16_t *d_out, size_t out_stride,
+                   size_t *windows_out)
+{
+	if (!s || !d_iq || !d_out || !n_blocks)
+		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_chan_run: bad arguments");
+	hipStream_t st = rxgpu_hip_stream();
+	const size_t n = (size_t)1 << s->p.bin_e;
+	if (block_len < 2 || (block_len & 1) || (block_len / 2) % n)
+		return rxgpu_fail(RXGPU_EUNSUPPORTED, "block of %zu samples is not a whole number of %zu-sample windows", block_len / 2, n);
+	const unsigned long long wpb = block_len / 2 / n, total = wpb * n_blocks;
+	if (total > s->max_windows)
+		return rxgpu_fail(RXGPU_ECAPACITY, "channeliser created for %zu windows, run asks %llu", s->max_windows, total);
+	if (out_stride < total)
+		return rxgpu_fail(RXGPU_ECAPACITY, "out_stride %zu shorter than %llu windows", out_stride, total);
+	const size_t nc = (size_t)s->p.n_channels;
+	rxk_fm_dev *h = s->dev_host;
+	memset(h, 0, sizeof(*h));
+	RX_HIP(hipMemcpyAsync(s->dev, h, sizeof(*h), hipMemcpyHostToDevice, st));
+	RX_HIP(hipMemcpyAsync(s->pre_dev[0], s->pre_host, nc * 8, hipMemcpyHostToDevice, st));
+	rxgpu_prof_begin("ch_fft");
+	RX_K(rxk_ch_fft(st, d_iq, total, s->p.bin_e, s->twiddle_dev, s->p.first_bin, s->p.n_channels, s->chan_lp));
+	rxgpu_prof_end("ch_fft");
+	rxgpu_prof_begin("ch_demod");
+	RX_K(rxk_ch_demod(st, s->chan_lp, total, wpb, s->p.n_channels, s->p.custom_atan, s->pre_dev[0], s->pre_dev[1], d_out, out_stride,
+	                  s->dev, s->flag_list));
+	rxgpu_prof_end("ch_demod");
+	RX_HIP(hipMemcpyAsync(h, s->dev, sizeof(*h), hipMemcpyDeviceToHost, st));
+	int *pre_in_copy = malloc(nc * 8);
+	if (!pre_in_copy)
+		return rxgpu_fail(RXGPU_ENOMEM, "out of host memory");
+	memcpy(pre_in_copy, s->pre_host, nc * 8);
+	RX_HIP(hipMemcpyAsync(s->pre_host, s->pre_dev[1], nc * 8, hipMemcpyDeviceToHost, st));
+	RX_HIP(hipStreamSynchronize(st));
+	rxgpu_prof_collect();
+	s->fixups = 0;
+	if (h->flag_cnt) {
+		/* libm samples the device could not decide: host libm, like rxgpu_fm.c */
+		int cnt = h->flag_cnt;
+		if (cnt > RXK_FLAG_CAP) {
+			free(pre_in_copy);
+			return rxgpu_fail(RXGPU_EUNSUPPORTED, "%d undecided libm discriminator samples (cap %d)", cnt, RXK_FLAG_CAP);
+		}
+		RX_HIP(hipMemcpy(s->flag_host, s->flag_list, (size_t)cnt * 8, hipMemcpyDeviceToHost));
+		for (int i = 0; i < cnt; i++) {
+			unsigned long long gid = s->flag_host[i], c = gid / total, t = gid - c * total;
+			uint32_t a, b;
+			int br, bj;
+			RX_HIP(hipMemcpy(&a, s->chan_lp + gid, 4, hipMemcpyDeviceToHost));
+			if (t) {
+				RX_HIP(hipMemcpy(&b, s->chan_lp + gid - 1, 4, hipMemcpyDeviceToHost));
+				br = (int16_t)(b & 0xffff); bj = (int16_t)(b >> 16);
+			} else {
+				br = pre_in_copy[2 * c]; bj = pre_in_copy[2 * c + 1];
+			}
+			int16_t v = (int16_t)disc_host((int16_t)(a & 0xffff), (int16_t)(a >> 16), br, bj);
+			RX_HIP(hipMemcpy(d_out + c * out_stride + t, &v, 2, hipMemcpyHostToDevice));
+		}
+		s->fixups = cnt;
+	}
+	free(pre_in_copy);
+	if (windows_out)
+		*windows_out = (size_t)total;
+	return RXGPU_OK;
+}

@@ -137,7 +137,7 @@ static int prof_wanted(const char *name)
 {
 	if (g_prof_on >= 2)
 		return 1;
-	return !strcmp(name, "fm_decimate") || !strcmp(name, "pw_fft") || !strcmp(name, "fm_fifth");
+	return !strcmp(name, "fm_decimate") || !strcmp(name, "pw_fft") || !strcmp(name, "fm_fifth") || !strcmp(name, "ch_fft");
 }
 
 void rxgpu_prof_begin_on(const char *name, hipStream_t st)

@@ -87,3 +87,48 @@ class FmStream:
     @property
     def host_fixups(self):
         return lib().rxgpu_fm_stream_host_fixups(self._h)
+
+
+class ChanParams(C.Structure):
+    """struct rxgpu_chan_params (channeliser extension, include/rxgpu.h)"""
+    _fields_ = [(n, C.c_int) for n in ("bin_e", "first_bin", "n_channels", "custom_atan")]
+
+
+class Channeliser:
+    """rxgpu_chan: fix_fft per window + fm_demod per channel, capture resident in HBM."""
+
+    def __init__(self, params, max_blocks, block_len, sinewave):
+        import numpy as np
+        self._h = C.c_void_p()
+        self.params = params
+        sw = np.ascontiguousarray(sinewave, dtype=np.int16)
+        check(lib().rxgpu_chan_create(C.byref(self._h), C.byref(params), max_blocks, block_len, sw.ctypes.data))
+
+    def close(self):
+        if self._h:
+            lib().rxgpu_chan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_carry(self, pre):
+        check(lib().rxgpu_chan_set_carry(self._h, pre.ctypes.data))
+
+    def get_carry(self):
+        import numpy as np
+        pre = np.zeros(2 * self.params.n_channels, dtype=np.int32)
+        check(lib().rxgpu_chan_get_carry(self._h, pre.ctypes.data))
+        return pre
+
+    def run(self, d_iq_ptr, n_blocks, block_len, d_out_ptr, out_stride):
+        n = C.c_size_t(0)
+        check(lib().rxgpu_chan_run(self._h, d_iq_ptr, n_blocks, block_len, d_out_ptr, out_stride, C.byref(n)))
+        return n.value
+
+    @property
+    def host_fixups(self):
+        return lib().rxgpu_chan_host_fixups(self._h)

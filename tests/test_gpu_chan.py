@@ -1,0 +1,105 @@
+"""-m gpu: the 256-channel NBFM channeliser (BASELINE configs[4], an extension specified from reference
+primitives: fix_fft per window + fm_demod per channel) against its oracle, through the C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import rx_tools_amd as R
+from support import oracle, sig_fm, sig_noise, ptr16, i16p, intp
+
+pytestmark = pytest.mark.gpu
+
+
+class ChanCfg(C.Structure):
+    _fields_ = [("bin_e", C.c_int), ("first_bin", C.c_int), ("n_channels", C.c_int), ("custom_atan", C.c_int), ("sinewave", i16p)]
+
+
+def oracle_chan(iq, block_len, bin_e, first_bin, n_channels, custom_atan, pre=None):
+    O = oracle()
+    O.rxo_chan_block.argtypes = [C.POINTER(ChanCfg), i16p, C.c_int, intp, i16p, C.c_size_t]
+    sw = R.sine_table(bin_e)
+    cfg = ChanCfg(bin_e, first_bin, n_channels, custom_atan, ptr16(sw))
+    n = 1 << bin_e
+    n_blocks = len(iq) // block_len
+    wpb = block_len // 2 // n
+    total = wpb * n_blocks
+    out = np.zeros((n_channels, total), np.int16)
+    pre = np.zeros(2 * n_channels, np.int32) if pre is None else pre.copy()
+    tmp = np.zeros((n_channels, wpb), np.int16)
+    for b in range(n_blocks):
+        blk = np.ascontiguousarray(iq[b * block_len:(b + 1) * block_len])
+        O.rxo_chan_block(C.byref(cfg), ptr16(blk), block_len, pre.ctypes.data_as(intp), ptr16(tmp), wpb)
+        out[:, b * wpb:(b + 1) * wpb] = tmp
+    return out, pre
+
+
+def gpu_chan(iq, block_len, bin_e, first_bin, n_channels, custom_atan, n_runs=1):
+    from gpu_support import to_dev, torch_cuda
+    torch = torch_cuda()
+    n = 1 << bin_e
+    n_blocks = len(iq) // block_len
+    wpb = block_len // 2 // n
+    per = (n_blocks + n_runs - 1) // n_runs
+    ch = R.Channeliser(R.ChanParams(bin_e, first_bin, n_channels, custom_atan), per, block_len, R.sine_table(bin_e))
+    d_iq = to_dev(iq)
+    outs = []
+    b = 0
+    while b < n_blocks:
+        nb = min(per, n_blocks - b)
+        d_out = torch.zeros((n_channels, nb * wpb), dtype=torch.int16, device="cuda")
+        w = ch.run(d_iq.data_ptr() + b * block_len * 2, nb, block_len, d_out.data_ptr(), nb * wpb)
+        assert w == nb * wpb
+        outs.append(d_out.cpu().numpy())
+        b += nb
+    pre = ch.get_carry()
+    fix = ch.host_fixups
+    ch.close()
+    return np.concatenate(outs, axis=1), pre, fix
+
+
+@pytest.mark.parametrize("bin_e,first_bin,n_channels,block_len,n_blocks", [
+    (10, 384, 256, 2 * 131072, 3),        # configs[4]: 256 channels of a 1024-bin bank, callback blocks of 131072
+    (10, 900, 256, 2 * 8192, 5),          # channel range wrapping through bin 0
+    (8, 0, 256, 2 * 4096, 4),             # every bin
+    (12, 100, 7, 2 * 8192, 6),            # two windows per block
+    (5, 3, 20, 2 * 1024, 3),
+])
+@pytest.mark.parametrize("custom_atan", [1, 0])
+def test_channeliser_bit_exact(bin_e, first_bin, n_channels, block_len, n_blocks, custom_atan):
+    for iq in (sig_fm(n_blocks * block_len // 2, seed=70, amp=9000), sig_noise(n_blocks * block_len, seed=71)):
+        want, want_pre = oracle_chan(iq, block_len, bin_e, first_bin, n_channels, custom_atan)
+        got, pre, _ = gpu_chan(iq, block_len, bin_e, first_bin, n_channels, custom_atan)
+        assert got.shape == want.shape
+        bad = np.argwhere(got != want)
+        assert bad.size == 0, "first mismatch at %s: got %d want %d (%d bad)" % (bad[0], got[tuple(bad[0])], want[tuple(bad[0])], len(bad))
+        assert np.array_equal(pre, want_pre)
+
+
+def test_channeliser_carry_across_runs():
+    iq = sig_noise(8 * 2 * 8192, seed=72, amp=6000)
+    want, want_pre = oracle_chan(iq, 2 * 8192, 10, 10, 64, 1)
+    got, pre, _ = gpu_chan(iq, 2 * 8192, 10, 10, 64, 1, n_runs=4)
+    assert np.array_equal(got, want) and np.array_equal(pre, want_pre)
+
+
+def test_channeliser_finds_the_carrier():
+    """sanity of the specification itself: an unmodulated carrier at bin k*fs/N shows up in channel k only"""
+    n, k = 1024, 300
+    t = np.arange(64 * n)
+    ph = 2 * np.pi * k / n * t
+    iq = np.empty(2 * len(t), np.int16)
+    # amplitude 500: above ~724 the reference's fast_atan2 wraps in int32 (rtl_fm.c:498), by design reproduced
+    iq[0::2] = np.rint(500 * np.cos(ph))
+    iq[1::2] = np.rint(500 * np.sin(ph))
+    from gpu_support import to_dev, torch_cuda
+    torch = torch_cuda()
+    ch = R.Channeliser(R.ChanParams(10, 0, 1024, 1), 1, len(iq), R.sine_table(10))
+    d_out = torch.zeros((1024, 64), dtype=torch.int16, device="cuda")
+    ch.run(to_dev(iq).data_ptr(), 1, len(iq), d_out.data_ptr(), 64)
+    ch.close()
+    # the decimated IQ of channel k is a constant phasor -> discriminator output 0 after the first window
+    out = d_out.cpu().numpy()
+    assert np.all(np.abs(out[k, 1:]) <= 40), out[k, :8]
+    # and next to nothing leaks into far-away channels: their bins stay (near) zero
+    assert np.count_nonzero(out[(k + 512) % 1024]) == 0
