@@ -26,4 +26,138 @@ __device__ __forceinline__ void butterfly(uint32_t &lo, uint32_t &hi, uint32_t t
 }
 
 
+typedef short pw_s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pw_pk_add(uint32_t a, uint32_t b)
+{
+	pw_s16x2 r = __builtin_bit_cast(pw_s16x2, a) + __builtin_bit_cast(pw_s16x2, b);
+	return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pw_pk_sub(uint32_t a, uint32_t b)
+{
+	pw_s16x2 r = __builtin_bit_cast(pw_s16x2, a) - __builtin_bit_cast(pw_s16x2, b);
+	return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pw_pk_mul(uint32_t a, uint32_t b)
+{
+	pw_s16x2 r = __builtin_bit_cast(pw_s16x2, a) * __builtin_bit_cast(pw_s16x2, b);   // low 16 bits: the int16 wrap
+	return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pw_pk_half(uint32_t a)
+{
+	pw_s16x2 r = __builtin_bit_cast(pw_s16x2, a) >> (pw_s16x2)(1);
+	return __builtin_bit_cast(uint32_t, r);
+}
+
+// the same butterfly as `butterfly` above on packed registers: only the low 16 bits of tr/ti
+// survive the int16 stores, so the per-product truncations can be dropped (truncation to int16
+// is a ring homomorphism) and the halves are combined with one v_perm
+__device__ __forceinline__ void bfly_pk(uint32_t &lo, uint32_t &hi, uint32_t tw)
+{
+	const int wr = pw_lo(tw), wi = pw_hi(tw);
+	const int xr = pw_lo(hi), xi = pw_hi(hi);
+	const int tr = ((wr * xr + 16384) >> 15) - ((wi * xi + 16384) >> 15);
+	const int ti = ((wr * xi + 16384) >> 15) + ((wi * xr + 16384) >> 15);
+	const uint32_t t = __builtin_amdgcn_perm((uint32_t)ti, (uint32_t)tr, 0x05040100u);
+	const uint32_t q = pw_pk_half(lo);
+	hi = pw_pk_sub(q, t);
+	lo = pw_pk_add(q, t);
+}
+
+template <int BITS> __device__ __forceinline__ constexpr int crev(int v)
+{
+	int r = 0;
+	for (int i = 0; i < BITS; i++) r |= ((v >> i) & 1) << (BITS - 1 - i);
+	return r;
+}
+
+
+// ------------------------------------------------------------------ register-blocked fix_fft, N = 2^M
+
+// The reference runs its DIT stages on the bit-reversed array (rtl_power.c:275-318).  Here the data
+// stay in natural order: stage s pairs n with n + 2^(M-1-s) and its twiddle index is
+// rev_s(top s bits of n) << (M-1-s).  A thread holds the 16 values of one 4-bit field of n, does up to
+// four stages in registers, then the workgroup transposes through LDS to the next field.  Fields
+// are taken from the top; when M is not a multiple of 4 the last field (bits 3..0) overlaps the
+// previous one and only its remaining stages run.  N/16 threads per transform.
+template <int M> struct fft_geom {
+	static constexpr int P = (M + 3) / 4;                       // passes
+	static constexpr int N = 1 << M;
+	static constexpr int TPF = N / 16;                          // threads per transform
+	static constexpr int ROW = 20;                              // 16 data dwords + 4 pad per LDS row
+	__host__ __device__ static constexpr int f(int p) { return (M - 4 * (p + 1)) > 0 ? (M - 4 * (p + 1)) : 0; }   // field's low bit
+	__host__ __device__ static constexpr int u(int p) { return M - 4 - f(p); }                                    // bits above the field
+	__host__ __device__ static constexpr int sp0(int p) { return (p == P - 1) ? (4 * P - M) : 0; }                // stages already done
+};
+
+template <int M, int PASS>
+__device__ __forceinline__ void fft_pass(uint32_t (&v)[16], const uint32_t *__restrict__ tw, unsigned tq)
+{
+	typedef fft_geom<M> G;
+	constexpr int F = G::f(PASS), U = G::u(PASS), SH = M - 1 - U;
+	const unsigned base = U ? (__brev(tq >> F) >> (32 - (U ? U : 1))) : 0u;     // rev_U of the bits above the field
+#pragma unroll
+	for (int sp = G::sp0(PASS); sp < 4; sp++) {
+		const int d = 8 >> sp;
+#pragma unroll
+		for (int g = 0; g < (1 << sp); g++) {
+			const unsigned j = (U ? (base << (SH - sp)) : 0u) + ((unsigned)crev<4>(g << (4 - sp)) << (M - 1 - sp));
+			const uint32_t w = tw[j];
+#pragma unroll
+			for (int q = 0; q < d; q++) {
+				const int r = g * 2 * d + q;
+				bfly_pk(v[r], v[r + d], w);
+			}
+		}
+	}
+}
+
+// LDS transpose between the layouts of pass PASS and PASS+1 (rows of 20 dwords: ds_read_b128 conflict-free)
+template <int M, int PASS>
+__device__ __forceinline__ void fft_exchange(uint32_t (&v)[16], uint32_t *__restrict__ lds, unsigned tq)
+{
+	typedef fft_geom<M> G;
+	constexpr int F = G::f(PASS), F2 = G::f(PASS + 1);
+#pragma unroll
+	for (int r = 0; r < 16; r++) {
+		const unsigned n = ((tq >> F) << (F + 4)) | ((unsigned)r << F) | (tq & ((1u << F) - 1u));
+		const unsigned row = ((n >> (F2 + 4)) << F2) | (n & ((1u << F2) - 1u));
+		const unsigned col = (n >> F2) & 15u;
+		lds[row * G::ROW + col] = v[r];
+	}
+	__syncthreads();
+#pragma unroll
+	for (int c = 0; c < 4; c++) {
+		const uint4 t4 = *reinterpret_cast<const uint4 *>(&lds[tq * G::ROW + 4 * c]);
+		v[4 * c] = t4.x; v[4 * c + 1] = t4.y; v[4 * c + 2] = t4.z; v[4 * c + 3] = t4.w;
+	}
+}
+
+// in:  v[r] = x[tq + r * N/16]  (natural order)          out: v[r] = X[rev_M((tq << 4) | r)]
+// lds_a/lds_b: this transform's transpose areas (N/16 rows of 20 dwords each); if they are the same
+// buffer the caller's DOUBLE must be false and a barrier separates reuse.
+template <int M, bool DOUBLE>
+__device__ __forceinline__ void fft_reg(uint32_t (&v)[16], unsigned tq, uint32_t *lds_a, uint32_t *lds_b,
+                                        const uint32_t *__restrict__ tw)
+{
+	typedef fft_geom<M> G;
+	// the previous transform's last reads of lds_a must be over before this one's first writes
+	if (!DOUBLE || (G::P % 2) == 0)
+		__syncthreads();
+	fft_pass<M, 0>(v, tw, tq);
+	if constexpr (G::P > 1) {
+		fft_exchange<M, 0>(v, lds_a, tq);
+		fft_pass<M, 1>(v, tw, tq);
+	}
+	if constexpr (G::P > 2) {
+		if (!DOUBLE) __syncthreads();
+		fft_exchange<M, 1>(v, DOUBLE ? lds_b : lds_a, tq);
+		fft_pass<M, 2>(v, tw, tq);
+	}
+	if constexpr (G::P > 3) {
+		if (!DOUBLE) __syncthreads();
+		fft_exchange<M, 2>(v, lds_a, tq);
+		fft_pass<M, 3>(v, tw, tq);
+	}
+}
+
 #endif

@@ -1177,6 +1177,47 @@ __global__ __launch_bounds__(256) void k_ch_fft(const uint32_t *__restrict__ iq,
 	}
 }
 
+// The same with the register-blocked transform (fft_device.h), N = 2^M, M = 8..12: N/16 threads per
+// window, 256/(N/16) windows side by side, CH_WPG windows per workgroup so that every channel's
+// outputs leave as one contiguous segment.
+#define CH_WPG 16
+template <int M>
+__global__ __launch_bounds__(256) void k_ch_fftR(const uint32_t *__restrict__ iq, u64 total_windows,
+                                                 const uint32_t *__restrict__ twiddle, int first_bin, int n_channels,
+                                                 uint32_t *__restrict__ chan_lp)
+{
+	typedef fft_geom<M> G;
+	constexpr int N = G::N, TPF = G::TPF, FPW = 256 / TPF;
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+	uint32_t *xa = lds, *xb = lds + 256 * G::ROW;
+	uint32_t *outt = lds + 2 * 256 * G::ROW;                 // [n_channels][CH_WPG]
+	const int tid = threadIdx.x, fid = tid / TPF;
+	const unsigned tq = tid % TPF;
+	const u64 w0 = (u64)blockIdx.x * CH_WPG;
+	for (int it = 0; it < CH_WPG; it += FPW) {
+		const u64 w = w0 + it + fid;
+		const bool live = w < total_windows;
+		uint32_t v[16];
+#pragma unroll
+		for (int r = 0; r < 16; r++)
+			v[r] = live ? iq[(w << M) + tq + r * TPF] : 0u;
+		fft_reg<M, true>(v, tq, xa + fid * TPF * G::ROW, xb + fid * TPF * G::ROW, twiddle);
+#pragma unroll
+		for (int r = 0; r < 16; r++) {
+			const unsigned bin = __brev((tq << 4) | (unsigned)r) >> (32 - M);
+			const unsigned c = (bin - (unsigned)first_bin) & (N - 1);
+			if (c < (unsigned)n_channels)
+				outt[c * CH_WPG + it + fid] = v[r];
+		}
+	}
+	__syncthreads();
+	for (int idx = tid; idx < n_channels * CH_WPG; idx += 256) {
+		const int c = idx / CH_WPG, k = idx - c * CH_WPG;
+		if (w0 + k < total_windows)
+			chan_lp[(u64)c * total_windows + w0 + k] = outt[idx];
+	}
+}
+
 // fm_demod (rtl_fm.c:584-615) per channel: thread (c, t); the first window of every callback block
 // goes through the libm discriminator like every block's first sample does in rx_fm
 __global__ void k_ch_demod(const uint32_t *__restrict__ chan_lp, u64 total_windows, u64 wpb, int n_channels, int custom_atan,
@@ -1464,6 +1505,19 @@ extern "C" int rxk_ch_fft(void *stream, const int16_t *iq, u64 total_windows, in
 {
 	if (!total_windows)
 		return 0;
+	if (bin_e >= 8 && bin_e <= 12) {
+		const size_t shm = (size_t)(2 * 256 * 20 + n_channels * CH_WPG) * 4;
+		const unsigned grid = (unsigned)((total_windows + CH_WPG - 1) / CH_WPG);
+		hipStream_t s = (hipStream_t)stream;
+		const uint32_t *p = (const uint32_t *)iq;
+#define GOC(MM) do { if (shm > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_ch_fftR<MM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+		hipLaunchKernelGGL((k_ch_fftR<MM>), dim3(grid), dim3(256), shm, s, p, total_windows, twiddle, first_bin, n_channels, chan_lp); } while (0)
+		switch (bin_e) {
+		case 8: GOC(8); break; case 9: GOC(9); break; case 10: GOC(10); break; case 11: GOC(11); break; default: GOC(12); break;
+		}
+#undef GOC
+		LAUNCH_RET();
+	}
 	int wpg = bin_e >= 13 ? 1 : (8192 >> bin_e);
 	const size_t shm = ((size_t)wpg << bin_e) * 4;
 	static size_t allowed = 64 * 1024;

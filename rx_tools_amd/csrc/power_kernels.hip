@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernels.h"
+#include <stdlib.h>
 
 typedef unsigned long long u64;
 typedef long long i64;
@@ -129,50 +130,6 @@ __global__ __launch_bounds__(256) void k_pw_fft(
 }
 
 // ------------------------------------------------------------------ P4-P8, N = 4096, register-blocked
-
-typedef short pw_s16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pw_pk_add(uint32_t a, uint32_t b)
-{
-	pw_s16x2 r = __builtin_bit_cast(pw_s16x2, a) + __builtin_bit_cast(pw_s16x2, b);
-	return __builtin_bit_cast(uint32_t, r);
-}
-__device__ __forceinline__ uint32_t pw_pk_sub(uint32_t a, uint32_t b)
-{
-	pw_s16x2 r = __builtin_bit_cast(pw_s16x2, a) - __builtin_bit_cast(pw_s16x2, b);
-	return __builtin_bit_cast(uint32_t, r);
-}
-__device__ __forceinline__ uint32_t pw_pk_mul(uint32_t a, uint32_t b)
-{
-	pw_s16x2 r = __builtin_bit_cast(pw_s16x2, a) * __builtin_bit_cast(pw_s16x2, b);   // low 16 bits: the int16 wrap
-	return __builtin_bit_cast(uint32_t, r);
-}
-__device__ __forceinline__ uint32_t pw_pk_half(uint32_t a)
-{
-	pw_s16x2 r = __builtin_bit_cast(pw_s16x2, a) >> (pw_s16x2)(1);
-	return __builtin_bit_cast(uint32_t, r);
-}
-
-// the same butterfly as `butterfly` above on packed registers: only the low 16 bits of tr/ti
-// survive the int16 stores, so the per-product truncations can be dropped (truncation to int16
-// is a ring homomorphism) and the halves are combined with one v_perm
-__device__ __forceinline__ void bfly_pk(uint32_t &lo, uint32_t &hi, uint32_t tw)
-{
-	const int wr = pw_lo(tw), wi = pw_hi(tw);
-	const int xr = pw_lo(hi), xi = pw_hi(hi);
-	const int tr = ((wr * xr + 16384) >> 15) - ((wi * xi + 16384) >> 15);
-	const int ti = ((wr * xi + 16384) >> 15) + ((wi * xr + 16384) >> 15);
-	const uint32_t t = __builtin_amdgcn_perm((uint32_t)ti, (uint32_t)tr, 0x05040100u);
-	const uint32_t q = pw_pk_half(lo);
-	hi = pw_pk_sub(q, t);
-	lo = pw_pk_add(q, t);
-}
-
-template <int BITS> __device__ __forceinline__ constexpr int crev(int v)
-{
-	int r = 0;
-	for (int i = 0; i < BITS; i++) r |= ((v >> i) & 1) << (BITS - 1 - i);
-	return r;
-}
 
 // Four consecutive radix-2 stages on 16 registers.  The reference runs its DIT stages on the
 // bit-reversed array; on the natural-order index n stage s pairs n with n + 2^(11-s) and its
@@ -300,6 +257,95 @@ __global__ __launch_bounds__(256) void k_pw_fft4096(
 		const unsigned bin = base_c + 256u * (unsigned)crev<4>(r);
 		if (PEAK) atomicMax((long long *)&avg_t[bin], acc[r]);
 		else atomicAdd((unsigned long long *)&avg_t[bin], (unsigned long long)acc[r]);
+	}
+}
+
+// ------------------------------------------------------------------ P4-P8, N = 2^M (M = 8..13), register-blocked
+
+// Same structure as k_pw_fft4096 for any power of two: N/16 threads per transform, 256/(N/16) transforms
+// side by side in a 256-thread workgroup for N < 4096.  remove_dc needs the whole tune first, so a pass
+// starts with a reduction over the tune buffer and the blocks are then re-read (L2) group by group.
+template <int M, bool PEAK>
+__global__ __launch_bounds__(((1 << M) / 16 > 256) ? (1 << M) / 16 : 256) void k_pw_fftR(
+	const int16_t *__restrict__ in, size_t tune_stride, size_t pass_stride, int passes, int nb_total,
+	const int *__restrict__ window, const uint32_t *__restrict__ twiddle, int ppg, i64 *__restrict__ avg)
+{
+	typedef fft_geom<M> G;
+	constexpr int N = G::N, TPF = G::TPF, T = TPF > 256 ? TPF : 256, FPW = T / TPF;
+	constexpr bool DB = M <= 12;
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+	uint32_t *xa = lds, *xb = DB ? lds + T * G::ROW : lds;
+	i64 *red = (i64 *)(lds + (DB ? 2 : 1) * T * G::ROW);
+	const int tid = threadIdx.x, fid = tid / TPF;
+	const unsigned tq = tid % TPF;
+	const int tune = blockIdx.x;
+	const int p_begin = blockIdx.y * ppg, p_end = min(passes, p_begin + ppg);
+	constexpr bool WREG = M <= 12;                         // 1024-thread workgroups are capped at 128 VGPRs: reload instead
+	uint32_t wcoef[WREG ? 16 : 1];
+	if (WREG) {
+#pragma unroll
+		for (int r = 0; r < 16; r++) {
+			const uint32_t c = (uint32_t)window[tq + r * TPF] & 0xffffu;
+			wcoef[r] = c | (c << 16);
+		}
+	}
+	i64 acc[16];
+#pragma unroll
+	for (int r = 0; r < 16; r++)
+		acc[r] = 0;
+	const int total = nb_total * N;                        // complex samples of the tune buffer that take part
+
+	for (int pass = p_begin; pass < p_end; pass++) {
+		const uint32_t *buf = (const uint32_t *)(in + (size_t)pass * pass_stride + (size_t)tune * tune_stride);
+		i64 si = 0, sq = 0;
+		for (int c = tid; c < total; c += T) {
+			const uint32_t w = buf[c];
+			si += pw_lo(w);
+			sq += pw_hi(w);
+		}
+		for (int off = 32; off; off >>= 1) { si += __shfl_down(si, off); sq += __shfl_down(sq, off); }
+		__syncthreads();
+		if ((tid & 63) == 0) { red[tid >> 6] = si; red[16 + (tid >> 6)] = sq; }
+		__syncthreads();
+		si = 0; sq = 0;
+#pragma unroll
+		for (int w = 0; w < T / 64; w++) { si += red[w]; sq += red[16 + w]; }
+		const i64 L = 2 * (i64)total;
+		const uint32_t ave = pw_pack((int)(short)(si / L), (int)(short)(sq / (L - 1)));   // rtl_power.c:609-624 via 744-745
+
+		for (int g = 0; g < nb_total; g += FPW) {
+			const int blk = g + fid;
+			const bool live = blk < nb_total;
+			uint32_t v[16];
+#pragma unroll
+			for (int r = 0; r < 16; r++) {
+				const uint32_t w = live ? buf[blk * N + tq + r * TPF] : 0u;
+				uint32_t wc;
+				if (WREG) {
+					wc = wcoef[r];
+				} else {
+					const uint32_t c = (uint32_t)window[tq + r * TPF] & 0xffffu;
+					wc = c | (c << 16);
+				}
+				v[r] = pw_pk_mul(pw_pk_sub(w, ave), wc);                       // window, rtl_power.c:749-758
+			}
+			fft_reg<M, DB>(v, tq, xa + fid * TPF * G::ROW, xb + fid * TPF * G::ROW, twiddle);
+			if (live) {
+#pragma unroll
+				for (int r = 0; r < 16; r++) {
+					const int re = pw_lo(v[r]), im = pw_hi(v[r]);
+					const i64 pw = (i64)(uint32_t)(re * re + im * im);
+					acc[r] = PEAK ? (pw > acc[r] ? pw : acc[r]) : acc[r] + pw;
+				}
+			}
+		}
+	}
+	i64 *avg_t = avg + (size_t)tune * N;
+#pragma unroll
+	for (int r = 0; r < 16; r++) {
+		const unsigned bin = __brev((tq << 4) | (unsigned)r) >> (32 - M);
+		if (PEAK) atomicMax((long long *)&avg_t[bin], acc[r]);
+		else if (acc[r]) atomicAdd((unsigned long long *)&avg_t[bin], (unsigned long long)acc[r]);
 	}
 }
 
@@ -474,12 +520,30 @@ extern "C" int rxk_pw_fft(void *stream, const int16_t *in, size_t tune_stride, s
 	const int groups = (passes + passes_per_group - 1) / passes_per_group;
 	dim3 grid((unsigned)tunes, (unsigned)groups);
 	hipStream_t s = (hipStream_t)stream;
-	if (bin_e == 12 && (eff_len == 8192 || eff_len == 16384 || eff_len == 32768)) {
+	if (bin_e == 12 && (eff_len == 8192 || eff_len == 16384 || eff_len == 32768) && !getenv("RXGPU_FFT_GENERIC")) {
 		const int nb = eff_len / 8192;
 #define GO4K(NB) do { if (peak_hold) hipLaunchKernelGGL((k_pw_fft4096<NB, true>), grid, dim3(256), 0, s, in, tune_stride, pass_stride, passes, window, twiddle, passes_per_group, (i64 *)avg); \
 		else hipLaunchKernelGGL((k_pw_fft4096<NB, false>), grid, dim3(256), 0, s, in, tune_stride, pass_stride, passes, window, twiddle, passes_per_group, (i64 *)avg); } while (0)
 		if (nb == 1) GO4K(1); else if (nb == 2) GO4K(2); else GO4K(4);
 #undef GO4K
+		LAUNCH_RET();
+	}
+	if (bin_e >= 8 && bin_e <= 13 && eff_len % (2 * n) == 0) {
+		/* register-blocked kernel for every power of two from 256 to 8192 (16384 would spill at 1024 threads) */
+		const int nb_total = eff_len / (2 * n);
+		const int T = (n / 16 > 256) ? n / 16 : 256;
+		const size_t lds_bytes = (size_t)(bin_e <= 12 ? 2 : 1) * T * 20 * 4 + 32 * 8;
+#define GOR(MM) do { \
+		if (lds_bytes > 64 * 1024) { \
+			(void)hipFuncSetAttribute((const void *)k_pw_fftR<MM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+			(void)hipFuncSetAttribute((const void *)k_pw_fftR<MM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); } \
+		if (peak_hold) hipLaunchKernelGGL((k_pw_fftR<MM, true>), grid, dim3(T), lds_bytes, s, in, tune_stride, pass_stride, passes, nb_total, window, twiddle, passes_per_group, (i64 *)avg); \
+		else hipLaunchKernelGGL((k_pw_fftR<MM, false>), grid, dim3(T), lds_bytes, s, in, tune_stride, pass_stride, passes, nb_total, window, twiddle, passes_per_group, (i64 *)avg); } while (0)
+		switch (bin_e) {
+		case 8: GOR(8); break; case 9: GOR(9); break; case 10: GOR(10); break; case 11: GOR(11); break;
+		case 12: GOR(12); break; default: GOR(13); break;
+		}
+#undef GOR
 		LAUNCH_RET();
 	}
 #define GO(A) do { \

@@ -56,6 +56,11 @@ CASES = [
     ("100M:100.1M:10", 0.0, "youssef", (0, 0, 0), 2000, 2, 1),      # fifth_order ds=16
     ("100M:100.1M:10", 0.0, "hann-poisson", (0, 9, 0), 30000, 1, 1),    # + droop FIR
     ("100M:100.3M:100", 0.0, "rectangle", (1, 0, 0), 9000, 2, 1),   # boxcar, odd ds
+    ("100M:102M:5k", 0.0, "hamming", (1, 0, 0), 20000, 2, 1),       # N=512
+    ("100M:102M:10k", 0.0, "rectangle", (1, 0, 1), 9000, 3, 1),     # N=256
+    ("100M:102.5M:600", 0.0, "blackman", (1, 0, 0), 32768, 2, 1),   # N=8192
+    ("100M:102M:2k", 0.0, "bartlett", (1, 0, 0), 12000, 2, 1),      # N=1024
+    ("100M:102M:1500", 0.0, "rectangle", (1, 0, 0), 12000, 2, 1),   # N=2048
     ("100M:110M:1M", 0.0, "rectangle", (1, 0, 0), 5000, 3, 10),     # rms_power path
     ("100M:110M:1M", 0.0, "rectangle", (1, 0, 1), 5000, 3, 10),
 ]
