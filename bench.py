@@ -82,30 +82,49 @@ def cpu_baseline_fm(block_len, budget_s):
 
 
 def cpu_baseline_power(plan, budget_s):
+    """scanner()'s per-tune chain on one host core: the reference's own scanner() over all 599 tunes
+    (oracle/_ref) where that prebuilt object exists, else the oracle port."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import support
     import rx_tools_amd as R
-    tunes = 64
     n = 1 << plan.bin_e
-    data = R.synth.sig_noise(tunes * plan.buf_len, seed=777, amp=100)
-    O = support.oracle()
-    wc, sw = R.window_coefs("rectangle", n), R.sine_table(plan.bin_e)
-    cfg = support.PowerCfg(plan.bin_e, plan.buf_len, 1, 0, 1, 0, 0, support.ptr32(wc), support.ptr16(sw))
-    avg = np.zeros(n, np.int64)
-    work = np.zeros(plan.buf_len, np.int16)
-    smp = C.c_int(0)
-    done, t0 = 0, time.perf_counter()
-    while True:
-        for t in range(tunes):
-            O.rxo_power_tune(C.byref(cfg), support.ptr16(data[t * plan.buf_len:(t + 1) * plan.buf_len]),
-                             support.ptr16(work), support.ptr64(avg), C.byref(smp))
-        done += tunes
-        dt = time.perf_counter() - t0
-        if dt >= budget_s:
-            break
+    if support.have_ref():
+        P = support.ref_power()
+        P.ref_power_set_flags(1, 0, 0)
+        P.ref_power_scan_tuned.argtypes = [support.i16p, C.c_int]
+        tunes = P.ref_power_setup(b"24M:1.7G:1k", 0.0, b"rectangle")
+        data = R.synth.sig_noise(tunes * plan.buf_len, seed=777, amp=100)
+        done, t0 = 0, time.perf_counter()
+        while True:
+            P.ref_power_scan_tuned(support.ptr16(data), 1)     # scanner() without retune()'s settle sleep
+            done += tunes
+            dt = time.perf_counter() - t0
+            if dt >= budget_s:
+                break
+        kind = "reference"
+    else:
+        tunes = 64
+        data = R.synth.sig_noise(tunes * plan.buf_len, seed=777, amp=100)
+        O = support.oracle()
+        wc, sw = R.window_coefs("rectangle", n), R.sine_table(plan.bin_e)
+        cfg = support.PowerCfg(plan.bin_e, plan.buf_len, 1, 0, 1, 0, 0, support.ptr32(wc), support.ptr16(sw))
+        avg = np.zeros(n, np.int64)
+        work = np.zeros(plan.buf_len, np.int16)
+        smp = C.c_int(0)
+        done, t0 = 0, time.perf_counter()
+        while True:
+            for t in range(tunes):
+                O.rxo_power_tune(C.byref(cfg), support.ptr16(data[t * plan.buf_len:(t + 1) * plan.buf_len]),
+                                 support.ptr16(work), support.ptr64(avg), C.byref(smp))
+            done += tunes
+            dt = time.perf_counter() - t0
+            if dt >= budget_s:
+                break
+        kind = "port"
     bins = done * (plan.buf_len // 2)
-    return {"value": bins / dt / 1e6, "unit": "Mbins/s", "cores": 1, "kind": "port",
-            "sample": "%d tune buffers of %d int16 (N=%d), scanner() per-tune chain, %.1f s on 1 thread" % (done, plan.buf_len, n, dt)}
+    return {"value": bins / dt / 1e6, "unit": "Mbins/s", "cores": 1, "kind": kind,
+            "sample": "%d tune buffers of %d int16 (N=%d), scanner() per-tune chain, %.1f s on 1 thread (%s)"
+                      % (done, plan.buf_len, n, dt, cpu_model())}
 
 
 def main():

@@ -14,6 +14,7 @@
 
 void soapy_fake_set_source(const int16_t *iq, size_t n_complex, size_t max_chunk);
 void soapy_fake_set_discard_buffer(const void *p);
+void soapy_fake_set_freq_script(const double *f, size_t n);
 
 size_t ref_power_sizeof_tuning_state(void) { return sizeof(struct tuning_state); }
 struct tuning_state *ref_power_tunes(void) { return tunes; }
@@ -70,6 +71,20 @@ void ref_power_scan(const int16_t *in, int passes)
 	soapy_fake_set_source(in, (size_t)passes * (size_t)tune_count * buf_len / 2, buf_len / 2);
 	for (int p = 0; p < passes; p++)
 		scanner(0);
+}
+
+/* The same with the tuner already "on frequency" for every tune, so that scanner() skips retune()
+ * (its 5 ms settle sleep and flush read are device I/O, not the compute chain being timed). */
+void ref_power_scan_tuned(const int16_t *in, int passes)
+{
+	static double *freqs;
+	free(freqs);
+	freqs = malloc(sizeof(double) * (size_t)tune_count);
+	for (int i = 0; i < tune_count; i++)
+		freqs[i] = (double)tunes[i].freq;
+	soapy_fake_set_freq_script(freqs, (size_t)tune_count);
+	ref_power_scan(in, passes);
+	soapy_fake_set_freq_script(NULL, 0);
 }
 
 /* csv_dbm() (rtl_power.c:774) for every tune into a caller-named file, without the

@@ -28,6 +28,8 @@ static size_t g_max_chunk;        /* 0 = hand out whatever is asked for */
 static void (*g_eos_hook)(void);
 static void (*g_pace_hook)(void); /* called before every data read but the first */
 static size_t g_reads;
+static const double *g_freq_script;   /* getFrequency answers from this list, round robin (no retune needed) */
+static size_t g_freq_n, g_freq_pos;
 static const void *g_discard;     /* reads into this buffer are flush reads: zero-fill, consume nothing */
 
 void soapy_fake_set_source(const int16_t *iq, size_t n_complex, size_t max_chunk)
@@ -35,6 +37,7 @@ void soapy_fake_set_source(const int16_t *iq, size_t n_complex, size_t max_chunk
 	g_src = iq; g_src_len = n_complex; g_src_pos = 0; g_max_chunk = max_chunk;
 }
 void soapy_fake_set_discard_buffer(const void *p) { g_discard = p; }
+void soapy_fake_set_freq_script(const double *f, size_t n) { g_freq_script = f; g_freq_n = n; g_freq_pos = 0; }
 void soapy_fake_set_eos_hook(void (*fn)(void)) { g_eos_hook = fn; }
 void soapy_fake_set_pace_hook(void (*fn)(void)) { g_pace_hook = fn; g_reads = 0; }
 size_t soapy_fake_position(void) { return g_src_pos; }
@@ -100,7 +103,13 @@ int SoapySDRDevice_setGainMode(SoapySDRDevice *d, const int dir, const size_t ch
 int SoapySDRDevice_setGain(SoapySDRDevice *d, const int dir, const size_t ch, const double v) { (void)d; (void)dir; (void)ch; (void)v; return 0; }
 int SoapySDRDevice_setGainElement(SoapySDRDevice *d, const int dir, const size_t ch, const char *n, const double v) { (void)d; (void)dir; (void)ch; (void)n; (void)v; return 0; }
 int SoapySDRDevice_setFrequency(SoapySDRDevice *d, const int dir, const size_t ch, const double f, const SoapySDRKwargs *a) { (void)dir; (void)ch; (void)a; d->freq = f; return 0; }
-double SoapySDRDevice_getFrequency(const SoapySDRDevice *d, const int dir, const size_t ch) { (void)dir; (void)ch; return d->freq; }
+double SoapySDRDevice_getFrequency(const SoapySDRDevice *d, const int dir, const size_t ch)
+{
+	(void)dir; (void)ch;
+	if (g_freq_script && g_freq_n)
+		return g_freq_script[g_freq_pos++ % g_freq_n];
+	return d->freq;
+}
 char **SoapySDRDevice_listFrequencies(const SoapySDRDevice *d, const int dir, const size_t ch, size_t *l) { (void)d; (void)dir; (void)ch; return empty_list(l); }
 int SoapySDRDevice_setFrequencyCorrection(SoapySDRDevice *d, const int dir, const size_t ch, const double v) { (void)d; (void)dir; (void)ch; (void)v; return 0; }
 int SoapySDRDevice_setSampleRate(SoapySDRDevice *d, const int dir, const size_t ch, const double r) { (void)dir; (void)ch; d->rate = r; return 0; }
