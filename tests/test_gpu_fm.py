@@ -193,3 +193,62 @@ def test_full_size_block_and_properties():
     T = n_blocks * 131072
     assert carry.prev_index == T % 118
     assert carry.prev_lpr_index == ((T // 118) * 32000) % 170000
+
+
+def test_config1_ragged_last_block():
+    """BASELINE config 1 exactly: 1.2 M samples = 9 callback blocks of 131072 + one of 20352 (what a 1 s capture
+    at 1.2 Msps delivers), -M wbfm -s 240000 -> 32000 int16; two runs because the last block is shorter"""
+    import ctypes as C
+    import rx_tools_amd as R
+    from gpu_support import to_dev, torch_cuda
+    from support import oracle, oracle_fm_state, ptr16
+    torch = torch_cuda()
+    iq = sig_fm(1200000, seed=5)
+    kw = dict(downsample=5, rate_out=240000, deemph_a=19)
+    O, st = oracle(), oracle_fm_state(**kw)
+    lp, res, want = np.zeros(262144, np.int16), np.zeros(131072, np.int16), []
+    pos = 0
+    for n in [131072] * 9 + [20352]:
+        blk = np.ascontiguousarray(iq[2 * pos:2 * (pos + n)])
+        k = O.rxo_fm_block(C.byref(st), ptr16(blk), 2 * n, ptr16(lp), None, ptr16(res))
+        want.append(res[:k].copy())
+        pos += n
+    want = np.concatenate(want)
+    assert len(want) == 32000
+    p = R.FmParams.wbfm(**kw)
+    s = R.FmStream(p, 9, 2 * 131072)
+    d_iq = to_dev(iq)
+    d_out = torch.zeros(40000, dtype=torch.int16, device="cuda")
+    n1, _ = s.run(d_iq.data_ptr(), 9, 2 * 131072, d_out.data_ptr(), 40000)
+    n2, _ = s.run(d_iq.data_ptr() + 9 * 131072 * 4, 1, 2 * 20352, d_out.data_ptr() + 2 * n1, 40000 - n1)
+    got = d_out[:n1 + n2].cpu().numpy()
+    assert n1 + n2 == 32000 and np.array_equal(got, want)
+    c = s.get_carry()
+    assert (c.prev_index, c.now_r, c.now_j, c.now_lpr, c.prev_lpr_index) == (st.prev_index, st.now_r, st.now_j, st.now_lpr, st.prev_lpr_index)
+    s.close()
+
+
+def test_error_codes():
+    """bad geometry fails loudly with the documented codes, never silently"""
+    import rx_tools_amd as R
+    from gpu_support import torch_cuda
+    torch = torch_cuda()
+    L = R.lib()
+    d_iq = torch.zeros(4 * 16384, dtype=torch.int16, device="cuda")
+    d_out = torch.zeros(16384, dtype=torch.int16, device="cuda")
+    s = R.FmStream(R.FmParams.wbfm(downsample=6), 4, 16384)
+    for args, code in [((d_iq.data_ptr(), 0, 16384, d_out.data_ptr(), 16384), -2),        # no blocks: EINVAL
+                       ((d_iq.data_ptr(), 8, 16384, d_out.data_ptr(), 16384), -5),        # more than the stream holds: ECAPACITY
+                       ((d_iq.data_ptr(), 4, 16384, d_out.data_ptr(), 10), -5),           # output too small: ECAPACITY
+                       ((d_iq.data_ptr(), 4, 8, d_out.data_ptr(), 16384), -3)]:           # block shorter than the boxcar: EUNSUPPORTED
+        n = __import__("ctypes").c_size_t(0)
+        assert L.rxgpu_fm_stream_run(s._h, *args, __import__("ctypes").byref(n), None) == code, L.rxgpu_last_error()
+    s.close()
+    s = R.FmStream(R.FmParams.wbfm(downsample_passes=5), 4, 16384)
+    n = __import__("ctypes").c_size_t(0)
+    assert L.rxgpu_fm_stream_run(s._h, d_iq.data_ptr(), 4, 2 * 1000, d_out.data_ptr(), 16384, __import__("ctypes").byref(n), None) == -3
+    s.close()
+    with pytest.raises(R.RxGpuError):
+        R.FmStream(R.FmParams.wbfm(custom_atan=7), 4, 16384)
+    with pytest.raises(R.RxGpuError):
+        R.PowerScan(R.PowerParams(16, 1 << 18, 1, 0, 1, 0, 0), 1, np.ones(1 << 16, np.int32), np.zeros(3 << 14, np.int16))   # FFT too large for LDS
