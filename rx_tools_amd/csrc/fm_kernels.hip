@@ -981,103 +981,137 @@ __global__ void k_fm_fifth_seams(const uint32_t *__restrict__ iq, u64 n_blocks, 
 	}
 }
 
-// four outputs i..i+3 of one pass from the 16 inputs 2i-8 .. 2i+7
-__device__ __forceinline__ uint4 fifth_quad(const uint32_t *__restrict__ src)
+// Every level lives in LDS de-interleaved: E[k] = V[2k], O[k] = V[2k+1] (relative to the tile's base at
+// that level), because output i of a pass needs V[2i-5..2i] = O[i-3], E[i-2], O[i-2], E[i-1], O[i-1], E[i]:
+// consecutive outputs read consecutive words of each array, so a lane's four outputs come from two
+// aligned b128 reads per array with no bank conflict (a stride-8-dword layout was 8-way conflicted).
+// ev/od point at E[i-2] and O[i-3] for the quad's first output i.
+__device__ __forceinline__ uint4 fifth_quad_eo(const uint32_t *__restrict__ ev, const uint32_t *__restrict__ od)
 {
-	const uint4 w0 = *reinterpret_cast<const uint4 *>(src), w1 = *reinterpret_cast<const uint4 *>(src + 4);
-	const uint4 w2 = *reinterpret_cast<const uint4 *>(src + 8), w3 = *reinterpret_cast<const uint4 *>(src + 12);
-	uint4 o;
-	o.x = fifth_pk(w0.w, w1.x, w1.y, w1.z, w1.w, w2.x);     // inputs 3..8
-	o.y = fifth_pk(w1.y, w1.z, w1.w, w2.x, w2.y, w2.z);     // 5..10
-	o.z = fifth_pk(w1.w, w2.x, w2.y, w2.z, w2.w, w3.x);     // 7..12
-	o.w = fifth_pk(w2.y, w2.z, w2.w, w3.x, w3.y, w3.z);     // 9..14
-	return o;
+	const uint4 e0 = *reinterpret_cast<const uint4 *>(ev), e1 = *reinterpret_cast<const uint4 *>(ev + 4);
+	const uint4 o0 = *reinterpret_cast<const uint4 *>(od), o1 = *reinterpret_cast<const uint4 *>(od + 4);
+	uint4 r;
+	r.x = fifth_pk(o0.x, e0.x, o0.y, e0.y, o0.z, e0.z);
+	r.y = fifth_pk(o0.y, e0.y, o0.z, e0.z, o0.w, e0.w);
+	r.z = fifth_pk(o0.z, e0.z, o0.w, e0.w, o1.x, e1.x);
+	r.w = fifth_pk(o0.w, e0.w, o1.x, e1.x, o1.y, e1.y);
+	return r;
 }
+
+// LDS word offsets: level L keeps E_L[k] at le[k + FE_L] and O_L[k] at lo[k + FO_L]; chosen so that the quads
+// (first output -16+4q, -8+4q, 4q at levels 1, 2, 3) read 16-byte aligned and the E pairs are written 8-byte aligned
+#define FE0 18
+#define FO0 19
+#define FE1 10
+#define FO1 11
+#define FE2 6
+#define FO2 7
 
 template <int FUSE, bool ROTATE>
 __global__ __launch_bounds__(256) void k_fm_fifth_fused(
-	const uint32_t *__restrict__ iq, unsigned n, unsigned tiles_per_block, const uint32_t *__restrict__ seams,
+	const uint32_t *__restrict__ iq, unsigned n, unsigned tiles_per_block, unsigned tpw, const uint32_t *__restrict__ seams,
 	uint32_t *__restrict__ out)
 {
-	// l0[j] = V0[t0 + j - 40], l1[j] = V1[t0/2 + j - 24], l2[j] = V2[t0/4 + j - 8]
-	__shared__ __attribute__((aligned(16))) uint32_t l0[FF_RAW + 40];
-	__shared__ __attribute__((aligned(16))) uint32_t l1[FF_RAW / 2 + 24 + 8];
-	__shared__ __attribute__((aligned(16))) uint32_t l2[FF_RAW / 4 + 8 + 8];
-	const u64 blk = blockIdx.x / tiles_per_block;
-	const unsigned tile = blockIdx.x % tiles_per_block;
-	const unsigned t0 = tile * FF_RAW;
-	const bool first = tile == 0;
+	__shared__ __attribute__((aligned(16))) uint32_t le0[FF_RAW / 2 + FE0 + 14], lo0[FF_RAW / 2 + FO0 + 13];
+	__shared__ __attribute__((aligned(16))) uint32_t le1[FF_RAW / 4 + FE1 + 14], lo1[FF_RAW / 4 + FO1 + 13];
+	__shared__ __attribute__((aligned(16))) uint32_t le2[FF_RAW / 8 + FE2 + 10], lo2[FF_RAW / 8 + FO2 + 9];
+	const unsigned wgs_per_block = tiles_per_block / tpw;
+	const u64 blk = blockIdx.x / wgs_per_block;
+	const unsigned tile0 = (blockIdx.x % wgs_per_block) * tpw;
 	const uint32_t *braw = iq + blk * (u64)n;
 	const uint32_t *sm = seams + blk * 15;
 	const int tid = threadIdx.x;
+	constexpr int NV = (FF_RAW + 36) / 4;                  // 521 vectors of 4 samples: the tile + 36 of left halo
 
-	// level 0: FF_RAW samples + 36 of halo, 4 per lane per load; all loads issued before any is used
-	{
-		constexpr int NV = (FF_RAW + 36) / 4;              // 521 vectors
-		u32x4 w[3];
+	// a workgroup walks `tpw` consecutive tiles; the next tile's samples are in flight while this one is computed
+	u32x4 w[3];
+#pragma unroll
+	for (int u = 0; u < 3; u++) {
+		const int v4 = tid + 256 * u;
+		const int rel = 4 * v4 - 36;
+		const bool on = v4 < NV && !(tile0 == 0 && rel < 0);
+		w[u] = on ? __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(braw + tile0 * FF_RAW + rel)) : (u32x4)(0u);
+	}
+	for (unsigned tt = 0; tt < tpw; tt++) {
+		const unsigned tile = tile0 + tt, t0 = tile * FF_RAW;
+		const bool first = tile == 0;
+		// level 0: scale + rotate (t0 + rel is a multiple of 4: phases 0..3), de-interleaved into LDS.
+		// vector v4 holds V0[rel..rel+3], rel = 4 v4 - 36: E_0[2 v4 - 18 + {0,1}], O_0[2 v4 - 18 + {0,1}]
 #pragma unroll
 		for (int u = 0; u < 3; u++) {
 			const int v4 = tid + 256 * u;
 			const int rel = 4 * v4 - 36;
-			const bool on = v4 < NV && !(first && rel < 0);
-			w[u] = on ? __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(braw + t0 + rel)) : (u32x4)(0u);
-		}
-#pragma unroll
-		for (int u = 0; u < 3; u++) {
-			const int v4 = tid + 256 * u;
-			const int rel = 4 * v4 - 36;                   // relative to t0; t0 + rel is a multiple of 4: phases 0..3
 			if (v4 < NV && !(first && rel < 0)) {
-				uint4 o;
-				o.x = raw_scaled<ROTATE>(w[u].x, 0u); o.y = raw_scaled<ROTATE>(w[u].y, 1u);
-				o.z = raw_scaled<ROTATE>(w[u].z, 2u); o.w = raw_scaled<ROTATE>(w[u].w, 3u);
-				*reinterpret_cast<uint4 *>(&l0[rel + 40]) = o;
+				const uint32_t s0 = raw_scaled<ROTATE>(w[u].x, 0u), s1 = raw_scaled<ROTATE>(w[u].y, 1u);
+				const uint32_t s2 = raw_scaled<ROTATE>(w[u].z, 2u), s3 = raw_scaled<ROTATE>(w[u].w, 3u);
+				*reinterpret_cast<uint2 *>(&le0[2 * v4 - 18 + FE0]) = make_uint2(s0, s2);
+				lo0[2 * v4 - 18 + FO0] = s1;
+				lo0[2 * v4 - 17 + FO0] = s3;
 			}
 		}
-	}
-	if (first && tid < 5)
-		l0[35 + tid] = sm[tid];                            // V0[-5..-1]
-	__syncthreads();
-
-	// pass 0: V1[t0/2 + i], i = -16 + 4q
-	for (int q = tid; q < FF_RAW / 8 + 4; q += 256) {
-		if (first && q < 4)
-			continue;
-		const uint4 o = fifth_quad(&l0[8 * q]);
-		if (FUSE == 1) {
-			if (q >= 4)
-				*reinterpret_cast<uint4 *>(out + blk * (u64)(n >> 1) + t0 / 2 + 4 * (q - 4)) = o;
-		} else {
-			*reinterpret_cast<uint4 *>(&l1[8 + 4 * q]) = o;
+		if (tt + 1 < tpw) {
+#pragma unroll
+			for (int u = 0; u < 3; u++) {
+				const int v4 = tid + 256 * u;
+				const int rel = 4 * v4 - 36;
+				w[u] = v4 < NV ? __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(braw + t0 + FF_RAW + rel)) : (u32x4)(0u);
+			}
 		}
-	}
-	if (FUSE == 1)
-		return;
-	if (first && tid < 5)
-		l1[19 + tid] = sm[5 + tid];                        // V1[-5..-1]
-	__syncthreads();
-
-	// pass 1: V2[t0/4 + i], i = -8 + 4q
-	for (int q = tid; q < FF_RAW / 16 + 2; q += 256) {
-		if (first && q < 2)
-			continue;
-		const uint4 o = fifth_quad(&l1[8 * q]);
-		if (FUSE == 2) {
-			if (q >= 2)
-				*reinterpret_cast<uint4 *>(out + blk * (u64)(n >> 2) + t0 / 4 + 4 * (q - 2)) = o;
-		} else {
-			*reinterpret_cast<uint4 *>(&l2[4 * q]) = o;
+		if (first && tid == 0) {                           // V0[-5..-1] = O[-3], E[-2], O[-2], E[-1], O[-1]
+			lo0[-3 + FO0] = sm[0]; le0[-2 + FE0] = sm[1]; lo0[-2 + FO0] = sm[2]; le0[-1 + FE0] = sm[3]; lo0[-1 + FO0] = sm[4];
 		}
-	}
-	if (FUSE == 2)
-		return;
-	if (first && tid < 5)
-		l2[3 + tid] = sm[10 + tid];                        // V2[-5..-1]
-	__syncthreads();
+		__syncthreads();
 
-	// pass 2: V3[t0/8 + i], i = 4q
-	if (tid < FF_RAW / 32) {
-		const uint4 o = fifth_quad(&l2[8 * tid]);
-		*reinterpret_cast<uint4 *>(out + blk * (u64)(n >> 3) + t0 / 8 + 4 * tid) = o;
+		// pass 0: outputs V1[i..i+3], i = -16 + 4q; they are E_1[i/2], O_1[i/2], E_1[i/2+1], O_1[i/2+1]
+		for (int q = tid; q < FF_RAW / 8 + 4; q += 256) {
+			if (first && q < 4)
+				continue;
+			const int i = -16 + 4 * q;
+			const uint4 o = fifth_quad_eo(&le0[i - 2 + FE0], &lo0[i - 3 + FO0]);
+			if (FUSE == 1) {
+				if (i >= 0)                                    // halo outputs belong to the previous tile
+					*reinterpret_cast<uint4 *>(out + blk * (u64)(n >> 1) + t0 / 2 + i) = o;
+			} else {
+				*reinterpret_cast<uint2 *>(&le1[i / 2 + FE1]) = make_uint2(o.x, o.z);
+				lo1[i / 2 + FO1] = o.y;
+				lo1[i / 2 + 1 + FO1] = o.w;
+			}
+		}
+		if (FUSE >= 2) {
+			if (first && tid == 0) {
+				lo1[-3 + FO1] = sm[5]; le1[-2 + FE1] = sm[6]; lo1[-2 + FO1] = sm[7]; le1[-1 + FE1] = sm[8]; lo1[-1 + FO1] = sm[9];
+			}
+			__syncthreads();
+			// pass 1: outputs V2[i..i+3], i = -8 + 4q
+			for (int q = tid; q < FF_RAW / 16 + 2; q += 256) {
+				if (first && q < 2)
+					continue;
+				const int i = -8 + 4 * q;
+				const uint4 o = fifth_quad_eo(&le1[i - 2 + FE1], &lo1[i - 3 + FO1]);
+				if (FUSE == 2) {
+					if (i >= 0)
+						*reinterpret_cast<uint4 *>(out + blk * (u64)(n >> 2) + t0 / 4 + i) = o;
+				} else {
+					*reinterpret_cast<uint2 *>(&le2[i / 2 + FE2]) = make_uint2(o.x, o.z);
+					lo2[i / 2 + FO2] = o.y;
+					lo2[i / 2 + 1 + FO2] = o.w;
+				}
+			}
+		}
+		if (FUSE >= 3) {
+			if (first && tid == 0) {
+				lo2[-3 + FO2] = sm[10]; le2[-2 + FE2] = sm[11]; lo2[-2 + FO2] = sm[12]; le2[-1 + FE2] = sm[13]; lo2[-1 + FO2] = sm[14];
+			}
+			__syncthreads();
+			// pass 2: outputs V3[i..i+3], i = 4q
+			if (tid < FF_RAW / 32) {
+				const int i = 4 * tid;
+				const uint4 o = fifth_quad_eo(&le2[i - 2 + FE2], &lo2[i - 3 + FO2]);
+				*reinterpret_cast<uint4 *>(out + blk * (u64)(n >> 3) + t0 / 8 + i) = o;
+			}
+		}
+		if (FUSE == 1)
+			__syncthreads();                               // level 0 is rewritten at the top of the next turn
 	}
 }
 
@@ -1462,15 +1496,16 @@ extern "C" int rxk_fm_fifth_fused(void *stream, const int16_t *iq, int rotate, u
 {
 	hipStream_t s = (hipStream_t)stream;
 	const unsigned tiles = n / FF_RAW;
+	const unsigned tpw = tiles % 8 == 0 ? 8 : tiles % 4 == 0 ? 4 : tiles % 2 == 0 ? 2 : 1;   // tiles one workgroup walks
 	const u64 seam_threads = (n_blocks + 1) * 16;
-	const unsigned grid = (unsigned)(n_blocks * tiles);
+	const unsigned grid = (unsigned)(n_blocks * (tiles / tpw));
 	const uint32_t *p = (const uint32_t *)iq;
 	if (rotate)
 		hipLaunchKernelGGL((k_fm_fifth_seams<true>), dim3((unsigned)((seam_threads + 255) / 256)), dim3(256), 0, s, p, n_blocks, n, fuse, hist_in, seams, hist_out);
 	else
 		hipLaunchKernelGGL((k_fm_fifth_seams<false>), dim3((unsigned)((seam_threads + 255) / 256)), dim3(256), 0, s, p, n_blocks, n, fuse, hist_in, seams, hist_out);
-#define GO(F) do { if (rotate) hipLaunchKernelGGL((k_fm_fifth_fused<F, true>), dim3(grid), dim3(256), 0, s, p, n, tiles, seams, out); \
-		else hipLaunchKernelGGL((k_fm_fifth_fused<F, false>), dim3(grid), dim3(256), 0, s, p, n, tiles, seams, out); } while (0)
+#define GO(F) do { if (rotate) hipLaunchKernelGGL((k_fm_fifth_fused<F, true>), dim3(grid), dim3(256), 0, s, p, n, tiles, tpw, seams, out); \
+		else hipLaunchKernelGGL((k_fm_fifth_fused<F, false>), dim3(grid), dim3(256), 0, s, p, n, tiles, tpw, seams, out); } while (0)
 	if (fuse == 1) GO(1); else if (fuse == 2) GO(2); else GO(3);
 #undef GO
 	LAUNCH_RET();
