@@ -917,6 +917,19 @@ __device__ __forceinline__ uint32_t fifth_pk(uint32_t a, uint32_t b, uint32_t c,
 	return __builtin_bit_cast(uint32_t, sum >> (ff_s16x2)(4));
 }
 
+// the same window in the reference's int arithmetic (rtl_fm.c:423/431), for levels whose sums exceed int16
+__device__ __forceinline__ uint32_t fifth_pk32(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t e, uint32_t f)
+{
+	const int si = (lo16(a) + (lo16(b) + lo16(e)) * 5 + (lo16(c) + lo16(d)) * 10 + lo16(f)) >> 4;
+	const int sq = (hi16(a) + (hi16(b) + hi16(e)) * 5 + (hi16(c) + hi16(d)) * 10 + hi16(f)) >> 4;
+	return pack_iq(si, sq);
+}
+template <bool WIDE>
+__device__ __forceinline__ uint32_t fifth_any(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t e, uint32_t f)
+{
+	return WIDE ? fifth_pk32(a, b, c, d, e, f) : fifth_pk(a, b, c, d, e, f);
+}
+
 template <bool ROTATE>
 __device__ __forceinline__ uint32_t raw_scaled(uint32_t w, unsigned idx)
 {
@@ -931,23 +944,30 @@ __device__ __forceinline__ uint32_t raw_scaled(uint32_t w, unsigned idx)
 	}
 }
 
+// the fused kernel's input element: raw cs16 (scale + rotate) in stage 1, an already packed level sample in stage 2
+template <bool ROTATE, bool STAGE2>
+__device__ __forceinline__ uint32_t leaf(uint32_t w, unsigned idx)
+{
+	return STAGE2 ? w : raw_scaled<ROTATE>(w, idx);
+}
+
 // level-P sample idx (>= 0, far enough from the block start that no tap is negative)
-template <int P, bool ROTATE>
+template <int P, bool ROTATE, bool STAGE2>
 __device__ uint32_t level_val(const uint32_t *__restrict__ blk_raw, int idx)
 {
 	if constexpr (P == 0) {
-		return raw_scaled<ROTATE>(blk_raw[idx], (unsigned)idx);
+		return leaf<ROTATE, STAGE2>(blk_raw[idx], (unsigned)idx);
 	} else {
 		uint32_t t[6];
 #pragma unroll
 		for (int k = 0; k < 6; k++)
-			t[k] = level_val<P - 1, ROTATE>(blk_raw, 2 * idx - 5 + k);
-		return fifth_pk(t[0], t[1], t[2], t[3], t[4], t[5]);
+			t[k] = level_val<P - 1, ROTATE, STAGE2>(blk_raw, 2 * idx - 5 + k);
+		return fifth_any<STAGE2>(t[0], t[1], t[2], t[3], t[4], t[5]);
 	}
 }
 
 // seams[b][p][q] = V_p(b, -5+q), p < 3, q < 5; plus the carried-out histories of the fused passes
-template <bool ROTATE>
+template <bool ROTATE, bool STAGE2>
 __global__ void k_fm_fifth_seams(const uint32_t *__restrict__ iq, u64 n_blocks, unsigned n, int fuse,
                                  const int16_t *__restrict__ hist_in, uint32_t *__restrict__ seams,
                                  int16_t *__restrict__ hist_out)
@@ -963,7 +983,7 @@ __global__ void k_fm_fifth_seams(const uint32_t *__restrict__ iq, u64 n_blocks, 
 		} else {
 			const uint32_t *prev = iq + (b - 1) * (u64)n;
 			const int idx = (int)(n >> p) - 6 + q;          // s[-5+q] = previous block's sample n_p-1+(-5+q)
-			v = p == 0 ? level_val<0, ROTATE>(prev, idx) : p == 1 ? level_val<1, ROTATE>(prev, idx) : level_val<2, ROTATE>(prev, idx);
+			v = p == 0 ? level_val<0, ROTATE, STAGE2>(prev, idx) : p == 1 ? level_val<1, ROTATE, STAGE2>(prev, idx) : level_val<2, ROTATE, STAGE2>(prev, idx);
 		}
 		seams[(b * 3 + p) * 5 + q] = v;
 	}
@@ -973,7 +993,7 @@ __global__ void k_fm_fifth_seams(const uint32_t *__restrict__ iq, u64 n_blocks, 
 			const uint32_t *last = iq + (n_blocks - 1) * (u64)n;
 			for (int t = q; t < 6; t += 5) {
 				const int idx = (int)(n >> p) - 7 + t;
-				const uint32_t v = p == 0 ? level_val<0, ROTATE>(last, idx) : p == 1 ? level_val<1, ROTATE>(last, idx) : level_val<2, ROTATE>(last, idx);
+				const uint32_t v = p == 0 ? level_val<0, ROTATE, STAGE2>(last, idx) : p == 1 ? level_val<1, ROTATE, STAGE2>(last, idx) : level_val<2, ROTATE, STAGE2>(last, idx);
 				hist_out[p * 12 + t] = (int16_t)lo16(v);
 				hist_out[p * 12 + 6 + t] = (int16_t)hi16(v);
 			}
@@ -986,15 +1006,16 @@ __global__ void k_fm_fifth_seams(const uint32_t *__restrict__ iq, u64 n_blocks, 
 // consecutive outputs read consecutive words of each array, so a lane's four outputs come from two
 // aligned b128 reads per array with no bank conflict (a stride-8-dword layout was 8-way conflicted).
 // ev/od point at E[i-2] and O[i-3] for the quad's first output i.
+template <bool WIDE>
 __device__ __forceinline__ uint4 fifth_quad_eo(const uint32_t *__restrict__ ev, const uint32_t *__restrict__ od)
 {
 	const uint4 e0 = *reinterpret_cast<const uint4 *>(ev), e1 = *reinterpret_cast<const uint4 *>(ev + 4);
 	const uint4 o0 = *reinterpret_cast<const uint4 *>(od), o1 = *reinterpret_cast<const uint4 *>(od + 4);
 	uint4 r;
-	r.x = fifth_pk(o0.x, e0.x, o0.y, e0.y, o0.z, e0.z);
-	r.y = fifth_pk(o0.y, e0.y, o0.z, e0.z, o0.w, e0.w);
-	r.z = fifth_pk(o0.z, e0.z, o0.w, e0.w, o1.x, e1.x);
-	r.w = fifth_pk(o0.w, e0.w, o1.x, e1.x, o1.y, e1.y);
+	r.x = fifth_any<WIDE>(o0.x, e0.x, o0.y, e0.y, o0.z, e0.z);
+	r.y = fifth_any<WIDE>(o0.y, e0.y, o0.z, e0.z, o0.w, e0.w);
+	r.z = fifth_any<WIDE>(o0.z, e0.z, o0.w, e0.w, o1.x, e1.x);
+	r.w = fifth_any<WIDE>(o0.w, e0.w, o1.x, e1.x, o1.y, e1.y);
 	return r;
 }
 
@@ -1007,7 +1028,7 @@ __device__ __forceinline__ uint4 fifth_quad_eo(const uint32_t *__restrict__ ev, 
 #define FE2 6
 #define FO2 7
 
-template <int FUSE, bool ROTATE>
+template <int FUSE, bool ROTATE, bool STAGE2>
 __global__ __launch_bounds__(256) void k_fm_fifth_fused(
 	const uint32_t *__restrict__ iq, unsigned n, unsigned tiles_per_block, unsigned tpw, const uint32_t *__restrict__ seams,
 	uint32_t *__restrict__ out)
@@ -1042,8 +1063,8 @@ __global__ __launch_bounds__(256) void k_fm_fifth_fused(
 			const int v4 = tid + 256 * u;
 			const int rel = 4 * v4 - 36;
 			if (v4 < NV && !(first && rel < 0)) {
-				const uint32_t s0 = raw_scaled<ROTATE>(w[u].x, 0u), s1 = raw_scaled<ROTATE>(w[u].y, 1u);
-				const uint32_t s2 = raw_scaled<ROTATE>(w[u].z, 2u), s3 = raw_scaled<ROTATE>(w[u].w, 3u);
+				const uint32_t s0 = leaf<ROTATE, STAGE2>(w[u].x, 0u), s1 = leaf<ROTATE, STAGE2>(w[u].y, 1u);
+				const uint32_t s2 = leaf<ROTATE, STAGE2>(w[u].z, 2u), s3 = leaf<ROTATE, STAGE2>(w[u].w, 3u);
 				*reinterpret_cast<uint2 *>(&le0[2 * v4 - 18 + FE0]) = make_uint2(s0, s2);
 				lo0[2 * v4 - 18 + FO0] = s1;
 				lo0[2 * v4 - 17 + FO0] = s3;
@@ -1067,7 +1088,7 @@ __global__ __launch_bounds__(256) void k_fm_fifth_fused(
 			if (first && q < 4)
 				continue;
 			const int i = -16 + 4 * q;
-			const uint4 o = fifth_quad_eo(&le0[i - 2 + FE0], &lo0[i - 3 + FO0]);
+			const uint4 o = fifth_quad_eo<STAGE2>(&le0[i - 2 + FE0], &lo0[i - 3 + FO0]);
 			if (FUSE == 1) {
 				if (i >= 0)                                    // halo outputs belong to the previous tile
 					*reinterpret_cast<uint4 *>(out + blk * (u64)(n >> 1) + t0 / 2 + i) = o;
@@ -1087,7 +1108,7 @@ __global__ __launch_bounds__(256) void k_fm_fifth_fused(
 				if (first && q < 2)
 					continue;
 				const int i = -8 + 4 * q;
-				const uint4 o = fifth_quad_eo(&le1[i - 2 + FE1], &lo1[i - 3 + FO1]);
+				const uint4 o = fifth_quad_eo<STAGE2>(&le1[i - 2 + FE1], &lo1[i - 3 + FO1]);
 				if (FUSE == 2) {
 					if (i >= 0)
 						*reinterpret_cast<uint4 *>(out + blk * (u64)(n >> 2) + t0 / 4 + i) = o;
@@ -1106,7 +1127,7 @@ __global__ __launch_bounds__(256) void k_fm_fifth_fused(
 			// pass 2: outputs V3[i..i+3], i = 4q
 			if (tid < FF_RAW / 32) {
 				const int i = 4 * tid;
-				const uint4 o = fifth_quad_eo(&le2[i - 2 + FE2], &lo2[i - 3 + FO2]);
+				const uint4 o = fifth_quad_eo<STAGE2>(&le2[i - 2 + FE2], &lo2[i - 3 + FO2]);
 				*reinterpret_cast<uint4 *>(out + blk * (u64)(n >> 3) + t0 / 8 + i) = o;
 			}
 		}
@@ -1490,24 +1511,27 @@ extern "C" int rxk_fm_prestage(void *stream, const int16_t *in, unsigned n_compl
 	LAUNCH_RET();
 }
 
-// first min(passes,3) fifth_order passes fused; returns the number of passes done through *fused
-extern "C" int rxk_fm_fifth_fused(void *stream, const int16_t *iq, int rotate, u64 n_blocks, unsigned n, int fuse,
+// `fuse` (1..3) fifth_order passes in one LDS-tiled launch.  stage2 == 0: raw cs16 in (scale + rotate, packed int16
+// arithmetic); stage2 != 0: packed level samples in (int arithmetic), hist_* already offset to the first pass done
+extern "C" int rxk_fm_fifth_fused(void *stream, const void *in, int stage2, int rotate, u64 n_blocks, unsigned n, int fuse,
                                   const int16_t *hist_in, int16_t *hist_out, uint32_t *seams, uint32_t *out)
 {
 	hipStream_t s = (hipStream_t)stream;
 	const unsigned tiles = n / FF_RAW;
 	const unsigned tpw = tiles % 8 == 0 ? 8 : tiles % 4 == 0 ? 4 : tiles % 2 == 0 ? 2 : 1;   // tiles one workgroup walks
 	const u64 seam_threads = (n_blocks + 1) * 16;
+	const unsigned sgrid = (unsigned)((seam_threads + 255) / 256);
 	const unsigned grid = (unsigned)(n_blocks * (tiles / tpw));
-	const uint32_t *p = (const uint32_t *)iq;
-	if (rotate)
-		hipLaunchKernelGGL((k_fm_fifth_seams<true>), dim3((unsigned)((seam_threads + 255) / 256)), dim3(256), 0, s, p, n_blocks, n, fuse, hist_in, seams, hist_out);
-	else
-		hipLaunchKernelGGL((k_fm_fifth_seams<false>), dim3((unsigned)((seam_threads + 255) / 256)), dim3(256), 0, s, p, n_blocks, n, fuse, hist_in, seams, hist_out);
-#define GO(F) do { if (rotate) hipLaunchKernelGGL((k_fm_fifth_fused<F, true>), dim3(grid), dim3(256), 0, s, p, n, tiles, tpw, seams, out); \
-		else hipLaunchKernelGGL((k_fm_fifth_fused<F, false>), dim3(grid), dim3(256), 0, s, p, n, tiles, tpw, seams, out); } while (0)
-	if (fuse == 1) GO(1); else if (fuse == 2) GO(2); else GO(3);
+	const uint32_t *p = (const uint32_t *)in;
+#define SEAMS(RT, S2) hipLaunchKernelGGL((k_fm_fifth_seams<RT, S2>), dim3(sgrid), dim3(256), 0, s, p, n_blocks, n, fuse, hist_in, seams, hist_out)
+#define FUSED(F, RT, S2) hipLaunchKernelGGL((k_fm_fifth_fused<F, RT, S2>), dim3(grid), dim3(256), 0, s, p, n, tiles, tpw, seams, out)
+#define GO(RT, S2) do { SEAMS(RT, S2); if (fuse == 1) FUSED(1, RT, S2); else if (fuse == 2) FUSED(2, RT, S2); else FUSED(3, RT, S2); } while (0)
+	if (stage2) GO(false, true);
+	else if (rotate) GO(true, false);
+	else GO(false, false);
 #undef GO
+#undef FUSED
+#undef SEAMS
 	LAUNCH_RET();
 }
 

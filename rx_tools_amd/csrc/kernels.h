@@ -116,10 +116,12 @@ int rxk_fm_passthrough_carry(void *stream, rxk_fm_dev *dev, int deemph_off, int 
 int rxk_fm_fifth_pass(void *stream, const void *in, int in_is_raw, int prescaled, int rotate,
                       unsigned long long n_blocks, unsigned n_in, unsigned in_stride, uint32_t *out,
                       unsigned out_stride, const int16_t *hist_in, int16_t *hist_out);
-/* the first `fuse` (1..3) passes of the cascade in one LDS-tiled launch, raw cs16 input only
- * (packed-int16 arithmetic is exact there); n % RXK_FIFTH_TILE == 0.  seams: n_blocks*15 dwords. */
+/* `fuse` (1..3) passes of the cascade in one LDS-tiled launch; n % RXK_FIFTH_TILE == 0.
+ * stage2 == 0: raw cs16 input (scale + rotate on the fly; packed-int16 arithmetic is exact through three
+ * passes from raw).  stage2 != 0: packed level samples in, the reference's int arithmetic; hist_in/hist_out
+ * point at the first pass of the group.  seams: n_blocks*15 dwords of scratch. */
 #define RXK_FIFTH_TILE 2048
-int rxk_fm_fifth_fused(void *stream, const int16_t *iq, int rotate, unsigned long long n_blocks, unsigned n, int fuse,
+int rxk_fm_fifth_fused(void *stream, const void *in, int stage2, int rotate, unsigned long long n_blocks, unsigned n, int fuse,
                        const int16_t *hist_in, int16_t *hist_out, uint32_t *seams, uint32_t *out);
 /* F12 generic_fir droop compensation (rtl_fm.c:442-465, 771-776) over the concatenated stream */
 int rxk_fm_droop(void *stream, const uint32_t *in, unsigned long long M, const int *fir,

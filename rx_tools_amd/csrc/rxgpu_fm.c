@@ -215,7 +215,7 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 		/* pass 0 output is half the input, later passes shrink further: two buffers suffice */
 		DMALLOC(s->cas[0], (s->max_T / 2 + max_blocks) * 4);
 		DMALLOC(s->cas[1], (s->max_T / 4 + max_blocks) * 4);
-		DMALLOC(s->seams, (max_blocks + 1) * 15 * 4);
+		DMALLOC(s->seams, 2 * (max_blocks + 1) * 15 * 4);
 	}
 	if (hipHostMalloc((void **)&s->dev_host, sizeof(rxk_fm_dev), 0) != hipSuccess ||
 	    hipHostMalloc((void **)&s->hist_host, HIST_TOTAL * 2, 0) != hipSuccess ||
@@ -502,12 +502,23 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks,
 		if (!p->prescaled && (g->n % RXK_FIFTH_TILE) == 0) {
 			const int fuse = passes < 3 ? passes : 3;
 			uint32_t *dst = s->cas[(fuse - 1) & 1];
-			RX_K(rxk_fm_fifth_fused(sb, d_iq, g->rotate, n_blocks, (unsigned)g->n, fuse, s->hist_dev + HIST_CAS_IN,
+			RX_K(rxk_fm_fifth_fused(sb, d_iq, 0, g->rotate, n_blocks, (unsigned)g->n, fuse, s->hist_dev + HIST_CAS_IN,
 			                        s->hist_dev + HIST_CAS_OUT, s->seams, dst));
 			src = dst;
 			n_in = (unsigned)(g->n >> fuse);
 			in_stride = n_in;
 			first_pass = fuse;
+			/* a second fused group on the 1/8-rate stream (3 passes, or 1 so that the ping-pong buffers stay distinct) */
+			if (fuse == 3 && passes > 3 && (n_in % RXK_FIFTH_TILE) == 0) {
+				const int fuse2 = passes - 3 >= 3 ? 3 : 1;
+				uint32_t *dst2 = s->cas[(3 + fuse2 - 1) & 1];
+				RX_K(rxk_fm_fifth_fused(sb, src, 1, 0, n_blocks, n_in, fuse2, s->hist_dev + HIST_CAS_IN + 3 * 12,
+				                        s->hist_dev + HIST_CAS_OUT + 3 * 12, s->seams + (s->max_blocks + 1) * 15, dst2));
+				src = dst2;
+				n_in >>= fuse2;
+				in_stride = n_in;
+				first_pass = 3 + fuse2;
+			}
 		}
 		for (int i = first_pass; i < passes; i++) {
 			uint32_t *dst = s->cas[i & 1];

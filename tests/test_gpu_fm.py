@@ -114,6 +114,18 @@ def test_fifth_order_chain_bit_exact(passes, fir, sig):
         assert got[10] == want[10] and got[11] == want[11]
 
 
+@pytest.mark.parametrize("passes,fir,n", [(7, 0, 16384), (7, 9, 32768), (6, 0, 32768), (5, 9, 16384), (4, 0, 32768)])
+def test_fifth_order_two_fused_stages(passes, fir, n):
+    """blocks long enough for the second fused group (passes 4-6 on the 1/8-rate stream, int arithmetic)"""
+    from gpu_support import carry_tuple, carry_from_oracle_state
+    for iq in (sig_fm(3 * n, seed=55), sig_noise(6 * n, seed=56), np.full(6 * n, 32767, np.int16)):
+        carry, st = _check(iq, 2 * n, downsample_passes=passes, comp_fir_size=fir)
+        want, got = carry_tuple(carry_from_oracle_state(st)), carry_tuple(carry)
+        assert got[8][:12 * passes] == want[8][:12 * passes] and got[9][:12 * passes] == want[9][:12 * passes]
+    iq = sig_noise(8 * n, seed=57, amp=30000)
+    _check(iq, 2 * n, n_runs=2, pipelined=True, downsample_passes=passes, comp_fir_size=fir, offset_tuning=1)
+
+
 def test_fifth_order_carry_across_runs():
     iq = sig_noise(12 * 16384, seed=21, amp=20000)
     _check(iq, 16384, n_runs=3, downsample_passes=3, comp_fir_size=9)
