@@ -566,62 +566,186 @@ __device__ __forceinline__ int deemph_step_b(int avg, int xb, int x, unsigned ma
 //   k_fm_deemph_apply  every chunk replayed once from its exact start state -> output
 #define DEEMPH_FAN 16
 
-template <int GS, bool EVEN>
-__global__ __launch_bounds__(DEEMPH_FAN * GS) void k_fm_deemph_scan(
-	const int16_t *__restrict__ pcm, u64 M, int a, unsigned magic, int bias, int chunk, int warm, int lo0, int hi0,
-	int *__restrict__ pre, int *__restrict__ l1_tab, int *__restrict__ l1_lo, int *__restrict__ l1_gap,
-	rxk_fm_dev *__restrict__ dev)
+// Division by a: D24 (5 <= a < 256, dividend < 2^18) takes two full-rate 24-bit multiplies,
+// floor(u/a) = ((u << 6) * (2^26/a + 1)) >> 32 exactly because u*a < 2^26; otherwise the 32-bit magic.
+template <bool D24>
+__device__ __forceinline__ unsigned deemph_div(unsigned t, unsigned magic)
 {
-	extern __shared__ __attribute__((aligned(16))) int xs[];      // per group: warm + chunk biased samples
-	__shared__ int tabs[DEEMPH_FAN][GS];
-	__shared__ int los[DEEMPH_FAN], gaps[DEEMPH_FAN];
-	const int grp = threadIdx.x / GS, k = threadIdx.x % GS;
-	const u64 n_chunks = (M + chunk - 1) / chunk;
-	const u64 c = (u64)blockIdx.x * DEEMPH_FAN + grp;
-	if (c < n_chunks) {
-		int *buf = xs + (size_t)grp * (warm + chunk);
-		const u64 c0 = c * (u64)chunk;
-		const bool exact = c0 <= (u64)warm;           // the run's carried state is in reach
-		const u64 ws = exact ? 0 : c0 - warm;
-		const u64 c1 = (c0 + chunk < M) ? c0 + chunk : M;
-		const int nw = (int)(c0 - ws), nc = (int)(c1 - c0);
-		const int xoff = a / 2 + bias * a;
-		for (int i = k; i < nw + nc; i += GS)
-			buf[i] = (int)pcm[ws + i] + xoff;
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		int s = exact ? dev->in_deemph_avg : (k == 0 ? lo0 : hi0);
-		for (int i = 0; i < nw; i++)
-			s = deemph_step_b<EVEN>(s, buf[i], buf[i] - xoff, magic, bias);
-		const int base = (threadIdx.x & 63) - (GS == 64 ? (int)(threadIdx.x & 63) : k);   // group's first lane in its wave
-		const int lo = __shfl(s, base), hi = __shfl(s, base + 1);
-		int gap = exact ? 0 : hi - lo;
-		if (gap >= GS) {                              // excluded by `warm` (rxgpu_fm.c); checked anyway
-			if (k == 0) atomicExch(&dev->err, 1);
-			gap = GS - 1;
-		}
-		s = lo + (k < gap ? k : gap);
-		for (int i = 0; i < nc; i++)
-			s = deemph_step_b<EVEN>(s, buf[nw + i], buf[nw + i] - xoff, magic, bias);
-		tabs[grp][k] = s;
-		if (k == 0) { los[grp] = lo; gaps[grp] = gap; }
+	if (D24)
+		return (unsigned)(((unsigned long long)((t << 6) & 0xffffffu) * (unsigned long long)(magic & 0xffffffu)) >> 32);
+	return __umulhi(t, magic);
+}
+template <bool D24>
+__device__ __forceinline__ unsigned deemph_mul(unsigned q, unsigned a)
+{
+	if (D24) {
+		unsigned r;
+		asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(q), "v"(a));
+		return r;
 	}
+	return q * a;
+}
+template <bool EVEN, bool D24>
+__device__ __forceinline__ int deemph_step_d(int avg, int xb, int x, unsigned magic, int bias)
+{
+	unsigned t = (unsigned)(xb - avg);
+	if (EVEN)
+		t -= (x <= avg) ? 1u : 0u;
+	return avg + (int)deemph_div<D24>(t, magic) - bias;
+}
+
+// One LANE per chunk.  The still-possible start states of a chunk are consecutive integers lo..lo+g and
+// stay consecutive (slope 0 or 1), and per sample at most ONE adjacent pair of them merges: the pair
+// (v, v+1) collapses iff x - v sits on an edge of the rounding, i.e. (odd a) iff v == x - a/2 - 1 (mod a).
+// So instead of carrying every candidate through the chunk, the lane carries the lowest one plus a
+// bit mask of which original neighbours are still distinct: T[k] = lo_end + popcount(mask & ((1<<k)-1)).
+// The warm-up before the chunk tracks just the two extreme trajectories.
+template <int GS> struct deemph_mask { typedef u64 type; };
+template <> struct deemph_mask<16> { typedef uint32_t type; };
+__device__ __forceinline__ int deemph_popc(u64 v) { return __popcll(v); }
+__device__ __forceinline__ int deemph_popc(uint32_t v) { return __popc(v); }
+
+template <bool EVEN, bool D24, typename MASK>
+__device__ __forceinline__ void deemph_track(int &lo, int &cnt, MASK &mask, int x, int a, int xoff, unsigned magic, int bias)
+{
+	const unsigned u = (unsigned)(x + xoff - lo);                  // x - lo + a/2 + bias*a  >= 0
+	unsigned q = deemph_div<D24>(u, magic);
+	const unsigned r1 = u - deemph_mul<D24>(q, (unsigned)a);       // u mod a
+	int r;
+	if (!EVEN) {
+		// a = 2h+1: (x - h - 1 - lo) == u (mod a)
+		r = (int)r1 + 1 < cnt ? (int)r1 : -1;
+	} else {
+		// a = 2h: edges at D == h (mod a) for D > 0 and D == h+1 (mod a) for D <= 0, D = x - v;
+		// (x - h - lo) == u and (x - h - 1 - lo) == u - 1 (mod a)
+		const unsigned r2 = r1 ? r1 - 1 : (unsigned)a - 1;
+		r = -1;
+		if ((int)r1 + 2 <= cnt && x - lo - (int)r1 > 0)
+			r = (int)r1;
+		else if ((int)r2 + 2 <= cnt && x - lo - (int)r2 <= 0)
+			r = (int)r2;
+		if (x <= lo && r1 == 0)
+			q--;                                                   // the lowest candidate divides u - 1
+	}
+	if (__builtin_expect(r >= 0, 0)) {
+		// distinct values r and r+1 become one: clear the r-th set bit of the mask
+		MASK m2 = mask;
+		for (int i = 0; i < r; i++)
+			m2 &= m2 - 1;
+		mask &= ~(m2 & (~m2 + 1));
+		cnt--;
+	}
+	lo += (int)q - bias;
+}
+
+// Stage 64 consecutive chunks (+ the `warm` samples before the first) of pcm into LDS, coalesced; row r holds
+// chunk first-1+r, rows are chunk/8+1 sixteen-byte units apart (odd: lane-per-row b128 reads hit every bank once).
+__device__ __forceinline__ void deemph_stage(const int16_t *__restrict__ pcm, u64 M, int chunk_l2, int warm, u64 first,
+                                             uint4 *lds, int lane)
+{
+	const int row_u = (1 << (chunk_l2 - 3)) + 1, ul2 = chunk_l2 - 3;
+	const u64 p0 = first ? (first << chunk_l2) - (u64)warm : 0;
+	u64 p1 = (first + 64) << chunk_l2;
+	if (p1 > M)
+		p1 = M;
+	const uint4 *src = reinterpret_cast<const uint4 *>(pcm + p0);
+	const unsigned nfull = (unsigned)((p1 - p0) >> 3);                    // whole 16-byte units; p0 % 8 == 0
+	const unsigned u0 = (unsigned)((p0 >> 3) - ((first ? first - 1 : 0) << ul2));   // unit index of p0 counted from row 0 (row 1 if first == 0)
+	const unsigned rbase = first ? 0 : 1;
+	for (unsigned base = 0; base < nfull; base += 8 * 64) {
+		uint4 w[8];
+		unsigned g[8];
+#pragma unroll
+		for (int j = 0; j < 8; j++) {                                     // eight loads in flight per lane
+			unsigned u = base + j * 64 + lane;
+			u = u < nfull ? u : nfull - 1;                                // past the end: repeat the last unit (same data, same slot)
+			w[j] = src[u];
+			g[j] = u + u0;
+		}
+#pragma unroll
+		for (int j = 0; j < 8; j++)
+			lds[((g[j] >> ul2) + rbase) * row_u + (g[j] & ((1u << ul2) - 1))] = w[j];
+	}
+	const unsigned tail = (unsigned)((p1 - p0) & 7);
+	if (tail && lane == 0) {                                              // the ragged end of the run
+		uint32_t ww[4] = {0, 0, 0, 0};
+		const u64 p = p0 + ((u64)nfull << 3);
+		for (unsigned k = 0; k < tail; k++)
+			ww[k >> 1] |= (uint32_t)(uint16_t)pcm[p + k] << ((k & 1) * 16);
+		const unsigned g = nfull + u0;
+		lds[((g >> ul2) + rbase) * row_u + (g & ((1u << ul2) - 1))] = make_uint4(ww[0], ww[1], ww[2], ww[3]);
+	}
+}
+
+template <int GS, bool EVEN, bool D24>
+__global__ __launch_bounds__(64) void k_fm_deemph_scan(
+	const int16_t *__restrict__ pcm, u64 M, int a, unsigned magic, int bias, int chunk_l2, int warm, int lo0, int hi0,
+	int *__restrict__ tab, int *__restrict__ lo_arr, int *__restrict__ gap_arr, rxk_fm_dev *__restrict__ dev)
+{
+	extern __shared__ uint4 de_lds[];
+	const int lane = threadIdx.x, chunk = 1 << chunk_l2, row_u = chunk / 8 + 1;
+	const u64 n_chunks = (M + chunk - 1) >> chunk_l2;
+	const u64 first = (u64)blockIdx.x * 64;
+	deemph_stage(pcm, M, chunk_l2, warm, first, de_lds, lane);
 	__syncthreads();
-	if (threadIdx.x < GS) {
-		// level 1: composite of this workgroup's chunks on the first chunk's candidates; on the way,
-		// pre[c][k] = state at the start of chunk c for candidate k (what k_fm_deemph_apply needs)
-		const u64 first = (u64)blockIdx.x * DEEMPH_FAN;
-		const int cnt = (int)((n_chunks - first) < DEEMPH_FAN ? (n_chunks - first) : DEEMPH_FAN);
-		const int g0 = gaps[0];
-		int v = los[0] + ((int)threadIdx.x < g0 ? (int)threadIdx.x : g0);
-		for (int i = 0; i < cnt; i++) {
-			pre[(first + i) * GS + threadIdx.x] = v;
-			v = tabs[i][v - los[i]];
+	const u64 c = first + lane;
+	if (c >= n_chunks)
+		return;
+	const u64 c0 = c << chunk_l2;
+	const int n = (int)((M - c0) < (u64)chunk ? (M - c0) : (u64)chunk);
+	const int xoff = a / 2 + bias * a;
+	int lo, hi;
+	if (c == 0) {                                     // the run's carried state (warm <= chunk/2)
+		lo = hi = dev->in_deemph_avg;
+	} else {
+		lo = lo0;
+		hi = hi0;
+		const uint4 *row = de_lds + lane * row_u;
+		uint4 w = row[(chunk - warm) >> 3];
+		for (int u = (chunk - warm) >> 3; u < (chunk >> 3); u++) {
+			const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+			w = row[u + 1];
+#pragma unroll
+			for (int k = 0; k < 8; k++) {
+				const int x = (k & 1) ? hi16(ww[k >> 1]) : lo16(ww[k >> 1]);
+				lo = deemph_step_d<EVEN, D24>(lo, x + xoff, x, magic, bias);
+				hi = deemph_step_d<EVEN, D24>(hi, x + xoff, x, magic, bias);
+			}
 		}
-		l1_tab[(u64)blockIdx.x * GS + threadIdx.x] = v;
-		if (threadIdx.x == 0) { l1_lo[blockIdx.x] = los[0]; l1_gap[blockIdx.x] = g0; }
 	}
+	int gap = hi - lo;
+	if (gap >= GS) {                                  // excluded by `warm` (rxgpu_fm.c); checked anyway
+		atomicExch(&dev->err, 1);
+		gap = GS - 1;
+	}
+	typedef typename deemph_mask<GS>::type MASK;
+	const int lo_start = lo;
+	int cnt = gap + 1;                                // a lone candidate never passes the merge test: no special case
+	MASK mask = (MASK)(((MASK)1 << gap) - 1);
+	const uint4 *row = de_lds + (lane + 1) * row_u;
+	const int nu = n >> 3;
+	uint4 w = row[0];
+	for (int u = 0; u < nu; u++) {
+		const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+		w = row[u + 1];                               // next unit (the pad unit after the last) while this one is walked
+#pragma unroll
+		for (int k = 0; k < 8; k++) {
+			const int x = (k & 1) ? hi16(ww[k >> 1]) : lo16(ww[k >> 1]);
+			deemph_track<EVEN, D24>(lo, cnt, mask, x, a, xoff, magic, bias);
+		}
+	}
+	if (n & 7) {                                      // the ragged end of the run
+		const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+		for (int k = 0; k < (n & 7); k++) {
+			const int x = (k & 1) ? hi16(ww[k >> 1]) : lo16(ww[k >> 1]);
+			deemph_track<EVEN, D24>(lo, cnt, mask, x, a, xoff, magic, bias);
+		}
+	}
+	int *t = tab + c * GS;
+	for (int k = 0; k <= gap; k++)
+		t[k] = lo + deemph_popc((MASK)(mask & (MASK)(((MASK)1 << k) - 1)));
+	lo_arr[c] = lo_start;
+	gap_arr[c] = gap;
 }
 
 // one thread group of gs lanes per parent table: walk DEEMPH_FAN children (global, dependent)
@@ -705,37 +829,57 @@ __global__ void k_fm_deemph_down(u64 n_child, int gs, const int *__restrict__ ta
 	}
 }
 
-// every chunk replayed from its exact start state; workgroup = the same DEEMPH_FAN chunks as in
-// the scan, staged through LDS so that global traffic stays coalesced
-template <bool EVEN>
-__global__ __launch_bounds__(256) void k_fm_deemph_apply(
-	const int16_t *__restrict__ pcm, u64 M, int a, unsigned magic, int bias, int gs, int chunk,
-	const int *__restrict__ pre, const int *__restrict__ l1_lo, const int *__restrict__ l1_start,
-	int16_t *__restrict__ y)
+// every chunk replayed once from its exact start state: staged like the scan, filtered in place in LDS by
+// one lane per chunk, written back coalesced
+template <bool EVEN, bool D24>
+__global__ __launch_bounds__(64) void k_fm_deemph_apply(
+	const int16_t *__restrict__ pcm, u64 M, int a, unsigned magic, int bias, int chunk_l2,
+	const int *__restrict__ start, int16_t *__restrict__ y)
 {
-	extern __shared__ __attribute__((aligned(16))) int xs[];          // DEEMPH_FAN * chunk samples
-	const u64 n_chunks = (M + chunk - 1) / chunk;
-	const u64 first = (u64)blockIdx.x * DEEMPH_FAN;
-	const int cnt = (int)((n_chunks - first) < DEEMPH_FAN ? (n_chunks - first) : DEEMPH_FAN);
-	const u64 s0 = first * (u64)chunk;
-	const u64 s1 = (s0 + (u64)DEEMPH_FAN * chunk < M) ? s0 + (u64)DEEMPH_FAN * chunk : M;
-	const int n = (int)(s1 - s0);
-	const int xoff = a / 2 + bias * a;
-	for (int i = threadIdx.x; i < n; i += 256)
-		xs[i] = (int)pcm[s0 + i] + xoff;
+	extern __shared__ uint4 de_lds[];
+	const int lane = threadIdx.x, chunk = 1 << chunk_l2, row_u = chunk / 8 + 1;
+	const u64 n_chunks = (M + chunk - 1) >> chunk_l2;
+	const u64 first = (u64)blockIdx.x * 64;
+	deemph_stage(pcm, M, chunk_l2, 0, first, de_lds, lane);
 	__syncthreads();
-	if ((int)threadIdx.x < cnt) {
-		int s = pre[(first + threadIdx.x) * gs + (l1_start[blockIdx.x] - l1_lo[blockIdx.x])];
-		int *buf = xs + threadIdx.x * chunk;
-		const int nc = min(chunk, n - (int)threadIdx.x * chunk);
-		for (int i = 0; i < nc; i++) {
-			s = deemph_step_b<EVEN>(s, buf[i], buf[i] - xoff, magic, bias);
-			buf[i] = s;
+	const u64 c = first + lane;
+	if (c < n_chunks) {
+		const u64 c0 = c << chunk_l2;
+		const int n = (int)((M - c0) < (u64)chunk ? (M - c0) : (u64)chunk);
+		const int xoff = a / 2 + bias * a;
+		int s = start[c];
+		uint4 *row = de_lds + (lane + 1) * row_u;
+		for (int u = 0; u * 8 < n; u++) {               // past-the-end samples of the last unit are never stored
+			const uint4 w = row[u];
+			const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+			uint32_t o[4];
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const int x0 = lo16(ww[k]), x1 = hi16(ww[k]);
+				s = deemph_step_d<EVEN, D24>(s, x0 + xoff, x0, magic, bias);
+				const int y0 = s;
+				s = deemph_step_d<EVEN, D24>(s, x1 + xoff, x1, magic, bias);
+				o[k] = pack_iq(y0, s);
+			}
+			row[u] = make_uint4(o[0], o[1], o[2], o[3]);
 		}
 	}
 	__syncthreads();
-	for (int i = threadIdx.x; i < n; i += 256)
-		y[s0 + i] = (int16_t)xs[i];
+	const u64 p0 = first << chunk_l2;
+	u64 p1 = (first + 64) << chunk_l2;
+	if (p1 > M)
+		p1 = M;
+	const unsigned nfull = (unsigned)((p1 - p0) >> 3), ul2 = chunk_l2 - 3;
+	uint4 *dst = reinterpret_cast<uint4 *>(y + p0);
+	for (unsigned u = lane; u < nfull; u += 64)
+		dst[u] = de_lds[((u >> ul2) + 1) * row_u + (u & ((1u << ul2) - 1))];
+	const unsigned tail = (unsigned)((p1 - p0) & 7);
+	if (tail && lane == 0) {
+		const uint4 w = de_lds[((nfull >> ul2) + 1) * row_u + (nfull & ((1u << ul2) - 1))];
+		const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+		for (unsigned k = 0; k < tail; k++)
+			y[p0 + ((u64)nfull << 3) + k] = (int16_t)((k & 1) ? hi16(ww[k >> 1]) : lo16(ww[k >> 1]));
+	}
 }
 
 __global__ void k_fm_deemph_serial(const int16_t *__restrict__ pcm, u64 M, int a, int16_t *__restrict__ y,
@@ -1375,23 +1519,37 @@ static unsigned magic_for(int a) { return a > 1 ? (unsigned)((1ull << 32) / (uns
 
 static int bias_for(int a) { return 65536 / a + 2; }
 
+static bool deemph_d24(int a) { return a >= 5 && a < 256; }
+static unsigned deemph_magic(int a) { return deemph_d24(a) ? (1u << 26) / (unsigned)a + 1 : magic_for(a); }
+static int ilog2(int v) { int l = 0; while ((1 << l) < v) l++; return l; }
+
+template <typename K>
+static void deemph_lds_attr(K kernel, size_t lds)
+{
+	if (lds > 48 * 1024)
+		(void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
 extern "C" int rxk_fm_deemph_scan(void *stream, const int16_t *pcm, u64 M, int a, int group, int chunk, int warm,
-                                  int lo0, int hi0, int *pre, int *l1_tab, int *l1_lo, int *l1_gap, rxk_fm_dev *dev)
+                                  int lo0, int hi0, int *tab, int *lo_arr, int *gap_arr, rxk_fm_dev *dev)
 {
 	if (!M)
 		return 0;
 	const u64 n_chunks = (M + chunk - 1) / chunk;
-	const unsigned grid = (unsigned)((n_chunks + DEEMPH_FAN - 1) / DEEMPH_FAN);
-	const size_t shm = (size_t)DEEMPH_FAN * (warm + chunk) * sizeof(int);
+	const unsigned grid = (unsigned)((n_chunks + 63) / 64);
+	const size_t lds = 65 * (size_t)(chunk / 8 + 1) * 16;
 	hipStream_t s = (hipStream_t)stream;
-	const unsigned mg = magic_for(a);
-	const int bias = bias_for(a);
-#define GO(GS, EV) do { \
-		if (shm > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_fm_deemph_scan<GS, EV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
-		hipLaunchKernelGGL((k_fm_deemph_scan<GS, EV>), dim3(grid), dim3(DEEMPH_FAN * GS), shm, s, pcm, M, a, mg, bias, chunk, warm, \
-		                   lo0, hi0, pre, l1_tab, l1_lo, l1_gap, dev); } while (0)
-	if (group == 16) { if (a & 1) GO(16, false); else GO(16, true); }
-	else { if (a & 1) GO(64, false); else GO(64, true); }
+	const unsigned mg = deemph_magic(a);
+	const int bias = bias_for(a), l2 = ilog2(chunk);
+#define GO(GS, EV, D) do { deemph_lds_attr(k_fm_deemph_scan<GS, EV, D>, lds); \
+		hipLaunchKernelGGL((k_fm_deemph_scan<GS, EV, D>), dim3(grid), dim3(64), lds, s, pcm, M, a, mg, bias, l2, warm, \
+		                   lo0, hi0, tab, lo_arr, gap_arr, dev); } while (0)
+	if (group == 16) {
+		if (deemph_d24(a)) { if (a & 1) GO(16, false, true); else GO(16, true, true); }
+		else { if (a & 1) GO(16, false, false); else GO(16, true, false); }
+	} else {
+		if (a & 1) GO(64, false, true); else GO(64, true, true);
+	}
 #undef GO
 	LAUNCH_RET();
 }
@@ -1431,20 +1589,21 @@ extern "C" int rxk_fm_deemph_down(void *stream, u64 n_child, int group, const in
 	LAUNCH_RET();
 }
 
-extern "C" int rxk_fm_deemph_apply(void *stream, const int16_t *pcm, u64 M, int a, int group, int chunk, const int *pre,
-                                   const int *l1_lo, const int *l1_start, int16_t *y)
+extern "C" int rxk_fm_deemph_apply(void *stream, const int16_t *pcm, u64 M, int a, int chunk, const int *start, int16_t *y)
 {
 	if (!M)
 		return 0;
 	const u64 n_chunks = (M + chunk - 1) / chunk;
-	const unsigned grid = (unsigned)((n_chunks + DEEMPH_FAN - 1) / DEEMPH_FAN);
-	const size_t shm = (size_t)DEEMPH_FAN * chunk * sizeof(int);
-	if (a & 1)
-		hipLaunchKernelGGL((k_fm_deemph_apply<false>), dim3(grid), dim3(256), shm, (hipStream_t)stream, pcm, M, a, magic_for(a),
-		                   bias_for(a), group, chunk, pre, l1_lo, l1_start, y);
-	else
-		hipLaunchKernelGGL((k_fm_deemph_apply<true>), dim3(grid), dim3(256), shm, (hipStream_t)stream, pcm, M, a, magic_for(a),
-		                   bias_for(a), group, chunk, pre, l1_lo, l1_start, y);
+	const unsigned grid = (unsigned)((n_chunks + 63) / 64);
+	const size_t lds = 65 * (size_t)(chunk / 8 + 1) * 16;
+	hipStream_t s = (hipStream_t)stream;
+	const unsigned mg = deemph_magic(a);
+	const int bias = bias_for(a), l2 = ilog2(chunk);
+#define GO(EV, D) do { deemph_lds_attr(k_fm_deemph_apply<EV, D>, lds); \
+		hipLaunchKernelGGL((k_fm_deemph_apply<EV, D>), dim3(grid), dim3(64), lds, s, pcm, M, a, mg, bias, l2, start, y); } while (0)
+	if (deemph_d24(a)) { if (a & 1) GO(false, true); else GO(true, true); }
+	else { if (a & 1) GO(false, false); else GO(true, false); }
+#undef GO
 	LAUNCH_RET();
 }
 

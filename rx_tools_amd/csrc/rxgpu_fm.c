@@ -12,7 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define DEEMPH_CHUNK 512
+#define DEEMPH_CHUNK_MIN 256           /* chunk = power of two >= 2*warm: one lane per chunk, 64 chunks per workgroup */
 #define DEEMPH_LEVELS 8
 /* tables the single-workgroup top walk stages in LDS.  Kept small (<= 16 KiB of LDS, 256 threads) so that
  * the workgroup finds a slot on a CU that the pipelined decimator of the next run is saturating. */
@@ -36,7 +36,6 @@ struct rxgpu_fm_stream {
 	uint32_t *cas[2];                    /* fifth_order ping-pong */
 	uint32_t *seams;                     /* per block: 3 levels x 5 history samples for the fused passes */
 	int16_t *pcm_buf[2], *pcm, *y;       /* pcm: the buffer the run in hand uses (double-buffered like lp_raw) */
-	int *pre;                             /* level 0: per chunk, start state for each candidate of its level-1 parent */
 	int *lvl_tab, *lvl_lo, *lvl_gap, *lvl_start;   /* levels >= 1, packed back to back */
 	size_t lvl_cap;
 	unsigned long long *flag_list;
@@ -57,6 +56,7 @@ struct rxgpu_fm_stream {
 	size_t stage_in_cap, stage_out_cap;
 	/* de-emphasis geometry */
 	int group, warm, lo0, hi0;
+	int chunk;                           /* de-emphasis scan: samples per chunk */
 	int topcap_override;                 /* $RXGPU_DEEMPH_TOPCAP: forces the multi-level scan (tests) */
 	long fixups;
 	/* pipelining state */
@@ -134,9 +134,12 @@ static void deemph_geometry(rxgpu_fm_stream *s)
 	s->group = a <= 16 ? 16 : (a <= 64 ? 64 : 0);
 	if (a < 2 || avg < -32768 || avg > 32767)
 		s->group = 0;                 /* a == 1 or a carried state outside int16: the serial kernel */
-	s->warm = s->group ? deemph_warm(a, (long long)s->hi0 - s->lo0) : 0;
-	if (s->warm > 8192)
-		s->group = 0;                 /* absurd carried state: take the serial kernel */
+	s->warm = s->group ? (deemph_warm(a, (long long)s->hi0 - s->lo0) + 7) / 8 * 8 : 0;   /* whole 16-byte reads */
+	s->chunk = DEEMPH_CHUNK_MIN;
+	while (s->chunk < 2 * s->warm)
+		s->chunk *= 2;
+	if (s->chunk > 1024)
+		s->group = 0;                 /* cannot happen for a <= 64 and an int16 state; the serial kernel if it does */
 }
 
 int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params, size_t max_blocks, size_t block_len)
@@ -169,7 +172,7 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 	else
 		s->max_M = s->max_T / (size_t)params->downsample + 2;
 	size_t n_wg = (s->max_T + RXK_DEC_SPAN - 1) / RXK_DEC_SPAN + 1;
-	size_t n_chunks = (s->max_M + DEEMPH_CHUNK - 1) / DEEMPH_CHUNK + 1;
+	size_t n_chunks = (s->max_M + DEEMPH_CHUNK_MIN - 1) / DEEMPH_CHUNK_MIN + 1;   /* the smallest chunk = the most tables */
 #define DMALLOC(ptr, bytes) do { if (hipMalloc((void **)&(ptr), (bytes)) != hipSuccess) { \
 	rxgpu_fm_stream_destroy(s); return rxgpu_fail(RXGPU_ENOMEM, "hipMalloc(%zu) failed", (size_t)(bytes)); } } while (0)
 	for (int i = 0; i < 2; i++) {
@@ -187,8 +190,7 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 	DMALLOC(s->pcm_buf[1], s->max_M * 2);
 	s->pcm = s->pcm_buf[0];
 	DMALLOC(s->y, s->max_M * 2);
-	DMALLOC(s->pre, n_chunks * 64 * 4);
-	s->lvl_cap = n_chunks / RXK_DEEMPH_FAN + n_chunks / (RXK_DEEMPH_FAN * (RXK_DEEMPH_FAN - 1)) + 2 * DEEMPH_LEVELS + 2;
+	s->lvl_cap = n_chunks + n_chunks / (RXK_DEEMPH_FAN - 1) + 2 * DEEMPH_LEVELS + 2;     /* level 0 + all composites */
 	DMALLOC(s->lvl_tab, s->lvl_cap * 64 * 4);
 	DMALLOC(s->lvl_lo, s->lvl_cap * 4);
 	DMALLOC(s->lvl_gap, s->lvl_cap * 4);
@@ -244,7 +246,7 @@ void rxgpu_fm_stream_destroy(rxgpu_fm_stream *s)
 	hipFree(s->lp);
 	hipFree(s->cas[0]); hipFree(s->cas[1]); hipFree(s->seams);
 	hipFree(s->pcm_buf[0]); hipFree(s->pcm_buf[1]); hipFree(s->y);
-	hipFree(s->pre);
+	
 	hipFree(s->lvl_tab); hipFree(s->lvl_lo); hipFree(s->lvl_gap); hipFree(s->lvl_start);
 	hipFree(s->atan_lut); hipFree(s->below); hipFree(s->dc_sums); hipFree(s->dc_avgs);
 	if (s->below_host) hipHostFree(s->below_host);
@@ -305,12 +307,11 @@ static int run_audio_stages(rxgpu_fm_stream *s, hipStream_t st, unsigned long lo
 			/* tree scan over chunk maps: level 0 = chunks, level l+1 = composites of RXK_DEEMPH_FAN level-l tables */
 			const int g = s->group;
 			unsigned long long cnt[DEEMPH_LEVELS + 1], off[DEEMPH_LEVELS + 1];
-			int top = 1;
-			cnt[0] = (M + DEEMPH_CHUNK - 1) / DEEMPH_CHUNK;
-			cnt[1] = (cnt[0] + RXK_DEEMPH_FAN - 1) / RXK_DEEMPH_FAN;
-			off[1] = 0;
-			RX_K(rxk_fm_deemph_scan(st, s->pcm, M, p->deemph_a, g, DEEMPH_CHUNK, s->warm, s->lo0, s->hi0,
-			                        s->pre, s->lvl_tab, s->lvl_lo, s->lvl_gap, s->dev));
+			int top = 0;
+			cnt[0] = (M + s->chunk - 1) / s->chunk;
+			off[0] = 0;
+			RX_K(rxk_fm_deemph_scan(st, s->pcm, M, p->deemph_a, g, s->chunk, s->warm, s->lo0, s->hi0,
+			                        s->lvl_tab, s->lvl_lo, s->lvl_gap, s->dev));
 			const unsigned long long topcap = s->topcap_override ? (unsigned long long)s->topcap_override : (unsigned long long)DEEMPH_TOPCAP(g);
 			while (cnt[top] > topcap) {
 				if (top == DEEMPH_LEVELS)
@@ -323,10 +324,10 @@ static int run_audio_stages(rxgpu_fm_stream *s, hipStream_t st, unsigned long lo
 			}
 			RX_K(rxk_fm_deemph_top(st, (int)cnt[top], g, s->lvl_tab + off[top] * g, s->lvl_lo + off[top], s->lvl_gap + off[top],
 			                       s->lvl_start + off[top], s->dev));
-			for (int l = top; l > 1; l--)
+			for (int l = top; l > 0; l--)
 				RX_K(rxk_fm_deemph_down(st, cnt[l - 1], g, s->lvl_tab + off[l - 1] * g, s->lvl_lo + off[l - 1],
 				                        s->lvl_start + off[l], s->lvl_start + off[l - 1]));
-			RX_K(rxk_fm_deemph_apply(st, s->pcm, M, p->deemph_a, g, DEEMPH_CHUNK, s->pre, s->lvl_lo, s->lvl_start, deemph_dst));
+			RX_K(rxk_fm_deemph_apply(st, s->pcm, M, p->deemph_a, s->chunk, s->lvl_start, deemph_dst));
 		} else {
 			RX_K(rxk_fm_deemph_serial(st, s->pcm, M, p->deemph_a, deemph_dst, s->dev));
 		}
