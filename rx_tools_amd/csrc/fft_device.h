@@ -48,19 +48,38 @@ __device__ __forceinline__ uint32_t pw_pk_half(uint32_t a)
 	return __builtin_bit_cast(uint32_t, r);
 }
 
-// the same butterfly as `butterfly` above on packed registers: only the low 16 bits of tr/ti
-// survive the int16 stores, so the per-product truncations can be dropped (truncation to int16
-// is a ring homomorphism) and the halves are combined with one v_perm
-__device__ __forceinline__ void bfly_pk(uint32_t &lo, uint32_t &hi, uint32_t tw)
+// The same butterfly as `butterfly` above on packed registers, 10 VALU operations.
+// FIX_MPY(w, x) = (w*x + 16384) >> 15 = HIGH HALF of (2w)*x + 32768, and 2w fits an int16 because the
+// reference halves its twiddles first (wr = Sinewave[..] >> 1, rtl_power.c:300-301).  So with the twiddle
+// register doubled (pw_tw2) each product is one v_mad_i32_i16 that picks its int16 operands with op_sel,
+// tr = A1 - A2 and ti = A3 + A4 are packed ops reading the high halves, and only the low 16 bits of
+// either survive the int16 stores (truncation to int16 is a ring homomorphism).
+__device__ __forceinline__ uint32_t pw_tw2(uint32_t tw) { return pw_pk_add(tw, tw); }
+
+// lo, hi: packed (re, im); tw2: packed (2*wr, 2*wi).  One asm block: none of these write a partial
+// register, so no wait states are needed between them (the compiler pads every separate asm statement).
+__device__ __forceinline__ void bfly_pk(uint32_t &lo, uint32_t &hi, uint32_t tw2)
 {
-	const int wr = pw_lo(tw), wi = pw_hi(tw);
-	const int xr = pw_lo(hi), xi = pw_hi(hi);
-	const int tr = ((wr * xr + 16384) >> 15) - ((wi * xi + 16384) >> 15);
-	const int ti = ((wr * xi + 16384) >> 15) + ((wi * xr + 16384) >> 15);
-	const uint32_t t = __builtin_amdgcn_perm((uint32_t)ti, (uint32_t)tr, 0x05040100u);
-	const uint32_t q = pw_pk_half(lo);
-	hi = pw_pk_sub(q, t);
-	lo = pw_pk_add(q, t);
+	uint32_t p1, p2, p3, p4, q;
+	asm("v_mad_i32_i16 %[p1], %[w], %[hi], %[c]\n\t"                              // 2wr*xr + 32768
+	    "v_mad_i32_i16 %[p2], %[w], %[hi], %[c] op_sel:[1,1,0,0]\n\t"             // 2wi*xi
+	    "v_mad_i32_i16 %[p3], %[w], %[hi], %[c] op_sel:[0,1,0,0]\n\t"             // 2wr*xi
+	    "v_mad_i32_i16 %[p4], %[w], %[hi], %[c] op_sel:[1,0,0,0]\n\t"             // 2wi*xr
+	    "v_pk_ashrrev_i16 %[q], 1, %[lo] op_sel_hi:[0,1]\n\t"                     // qr, qi
+	    "v_pk_sub_i16 %[p1], %[p1], %[p2] op_sel:[1,1] op_sel_hi:[1,1]\n\t"       // tr (both halves)
+	    "v_pk_add_u16 %[p3], %[p3], %[p4] op_sel:[1,1] op_sel_hi:[1,1]\n\t"       // ti (both halves)
+	    "v_bfi_b32 %[p1], %[m], %[p1], %[p3]\n\t"                                 // (tr, ti)
+	    "v_pk_sub_i16 %[hi], %[q], %[p1]\n\t"
+	    "v_pk_add_u16 %[lo], %[q], %[p1]"
+	    : [lo] "+v"(lo), [hi] "+v"(hi), [p1] "=&v"(p1), [p2] "=&v"(p2), [p3] "=&v"(p3), [p4] "=&v"(p4), [q] "=&v"(q)
+	    : [w] "v"(tw2), [c] "s"(32768), [m] "s"(0xffff));
+}
+
+// re^2 + im^2 of a packed bin as one v_dot2: at most 2^31, which the uint32 holds (rtl_power.c:664-668)
+__device__ __forceinline__ uint32_t pw_norm(uint32_t v)
+{
+	const pw_s16x2 a = __builtin_bit_cast(pw_s16x2, v);
+	return (uint32_t)__builtin_amdgcn_sdot2(a, a, 0, false);
 }
 
 template <int BITS> __device__ __forceinline__ constexpr int crev(int v)
@@ -101,7 +120,7 @@ __device__ __forceinline__ void fft_pass(uint32_t (&v)[16], const uint32_t *__re
 #pragma unroll
 		for (int g = 0; g < (1 << sp); g++) {
 			const unsigned j = (U ? (base << (SH - sp)) : 0u) + ((unsigned)crev<4>(g << (4 - sp)) << (M - 1 - sp));
-			const uint32_t w = tw[j];
+			const uint32_t w = pw_tw2(tw[j]);
 #pragma unroll
 			for (int q = 0; q < d; q++) {
 				const int r = g * 2 * d + q;

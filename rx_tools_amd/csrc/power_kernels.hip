@@ -146,7 +146,7 @@ __device__ __forceinline__ void radix16_pass(uint32_t (&v)[16], const uint32_t *
 #pragma unroll
 		for (int g = 0; g < (1 << sp); g++) {
 			const unsigned j = (FIRST ? 0u : (base << (SH - sp))) + ((unsigned)crev<4>(g << (4 - sp)) << (11 - sp));
-			const uint32_t w = tw[j];
+			const uint32_t w = pw_tw2(tw[j]);
 #pragma unroll
 			for (int q = 0; q < d; q++) {
 				const int r = g * 2 * d + q;
@@ -245,8 +245,7 @@ __global__ __launch_bounds__(256) void k_pw_fft4096(
 			// real_conj + accumulate, rtl_power.c:664-668, 760-768; re^2+im^2 <= 2^31 fits u32
 #pragma unroll
 			for (int r = 0; r < 16; r++) {
-				const int re = pw_lo(v[r]), im = pw_hi(v[r]);
-				const i64 pw = (i64)(uint32_t)(re * re + im * im);
+				const i64 pw = (i64)pw_norm(v[r]);
 				acc[r] = PEAK ? (pw > acc[r] ? pw : acc[r]) : acc[r] + pw;
 			}
 		}
@@ -333,8 +332,7 @@ __global__ __launch_bounds__(((1 << M) / 16 > 256) ? (1 << M) / 16 : 256) void k
 			if (live) {
 #pragma unroll
 				for (int r = 0; r < 16; r++) {
-					const int re = pw_lo(v[r]), im = pw_hi(v[r]);
-					const i64 pw = (i64)(uint32_t)(re * re + im * im);
+					const i64 pw = (i64)pw_norm(v[r]);
 					acc[r] = PEAK ? (pw > acc[r] ? pw : acc[r]) : acc[r] + pw;
 				}
 			}
