@@ -51,10 +51,9 @@ __device__ __forceinline__ uint32_t pw_pk_half(uint32_t a)
 // The same butterfly as `butterfly` above on packed registers, 10 VALU operations.
 // FIX_MPY(w, x) = (w*x + 16384) >> 15 = HIGH HALF of (2w)*x + 32768, and 2w fits an int16 because the
 // reference halves its twiddles first (wr = Sinewave[..] >> 1, rtl_power.c:300-301).  So with the twiddle
-// register doubled (pw_tw2) each product is one v_mad_i32_i16 that picks its int16 operands with op_sel,
+// table doubled (second half of rxgpu_twiddle_table) each product is one v_mad_i32_i16 that picks its int16 operands with op_sel,
 // tr = A1 - A2 and ti = A3 + A4 are packed ops reading the high halves, and only the low 16 bits of
 // either survive the int16 stores (truncation to int16 is a ring homomorphism).
-__device__ __forceinline__ uint32_t pw_tw2(uint32_t tw) { return pw_pk_add(tw, tw); }
 
 // lo, hi: packed (re, im); tw2: packed (2*wr, 2*wi).  One asm block: none of these write a partial
 // register, so no wait states are needed between them (the compiler pads every separate asm statement).
@@ -80,6 +79,12 @@ __device__ __forceinline__ uint32_t pw_norm(uint32_t v)
 {
 	const pw_s16x2 a = __builtin_bit_cast(pw_s16x2, v);
 	return (uint32_t)__builtin_amdgcn_sdot2(a, a, 0, false);
+}
+
+// acc + a.lo*b.lo + a.hi*b.hi (v_dot2c_i32_i16); with b = (1,0) / (0,1) it adds one half of a packed sample
+__device__ __forceinline__ int pw_dot(uint32_t a, uint32_t b, int acc)
+{
+	return __builtin_amdgcn_sdot2(__builtin_bit_cast(pw_s16x2, a), __builtin_bit_cast(pw_s16x2, b), acc, false);
 }
 
 template <int BITS> __device__ __forceinline__ constexpr int crev(int v)
@@ -120,7 +125,7 @@ __device__ __forceinline__ void fft_pass(uint32_t (&v)[16], const uint32_t *__re
 #pragma unroll
 		for (int g = 0; g < (1 << sp); g++) {
 			const unsigned j = (U ? (base << (SH - sp)) : 0u) + ((unsigned)crev<4>(g << (4 - sp)) << (M - 1 - sp));
-			const uint32_t w = pw_tw2(tw[j]);
+			const uint32_t w = tw[j];                                      // doubled table (rxgpu_twiddle_table)
 #pragma unroll
 			for (int q = 0; q < d; q++) {
 				const int r = g * 2 * d + q;

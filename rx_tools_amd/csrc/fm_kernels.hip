@@ -1729,7 +1729,7 @@ extern "C" int rxk_ch_fft(void *stream, const int16_t *iq, u64 total_windows, in
 		hipStream_t s = (hipStream_t)stream;
 		const uint32_t *p = (const uint32_t *)iq;
 #define GOC(MM) do { if (shm > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_ch_fftR<MM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
-		hipLaunchKernelGGL((k_ch_fftR<MM>), dim3(grid), dim3(256), shm, s, p, total_windows, twiddle, first_bin, n_channels, chan_lp); } while (0)
+		hipLaunchKernelGGL((k_ch_fftR<MM>), dim3(grid), dim3(256), shm, s, p, total_windows, twiddle + (1 << (MM - 1)), first_bin, n_channels, chan_lp); } while (0)
 		switch (bin_e) {
 		case 8: GOC(8); break; case 9: GOC(9); break; case 10: GOC(10); break; case 11: GOC(11); break; default: GOC(12); break;
 		}

@@ -146,7 +146,7 @@ __device__ __forceinline__ void radix16_pass(uint32_t (&v)[16], const uint32_t *
 #pragma unroll
 		for (int g = 0; g < (1 << sp); g++) {
 			const unsigned j = (FIRST ? 0u : (base << (SH - sp))) + ((unsigned)crev<4>(g << (4 - sp)) << (11 - sp));
-			const uint32_t w = pw_tw2(tw[j]);
+			const uint32_t w = tw[j];                                      // doubled table
 #pragma unroll
 			for (int q = 0; q < d; q++) {
 				const int r = g * 2 * d + q;
@@ -198,8 +198,8 @@ __global__ __launch_bounds__(256) void k_pw_fft4096(
 #pragma unroll
 			for (int r = 0; r < 16; r++) {
 				d[b][r] = buf[b * 4096 + tid + 256 * r];
-				si += pw_lo(d[b][r]);
-				sq += pw_hi(d[b][r]);
+				si = pw_dot(d[b][r], 0x00000001u, si);           // += I
+				sq = pw_dot(d[b][r], 0x00010000u, sq);           // += Q
 			}
 		// remove_dc, rtl_power.c:609-624 via 744-745 (L = 2*4096*NB int16, both halves complete)
 		for (int off = 32; off; off >>= 1) { si += __shfl_down(si, off); sq += __shfl_down(sq, off); }
@@ -520,8 +520,8 @@ extern "C" int rxk_pw_fft(void *stream, const int16_t *in, size_t tune_stride, s
 	hipStream_t s = (hipStream_t)stream;
 	if (bin_e == 12 && (eff_len == 8192 || eff_len == 16384 || eff_len == 32768) && !getenv("RXGPU_FFT_GENERIC")) {
 		const int nb = eff_len / 8192;
-#define GO4K(NB) do { if (peak_hold) hipLaunchKernelGGL((k_pw_fft4096<NB, true>), grid, dim3(256), 0, s, in, tune_stride, pass_stride, passes, window, twiddle, passes_per_group, (i64 *)avg); \
-		else hipLaunchKernelGGL((k_pw_fft4096<NB, false>), grid, dim3(256), 0, s, in, tune_stride, pass_stride, passes, window, twiddle, passes_per_group, (i64 *)avg); } while (0)
+#define GO4K(NB) do { if (peak_hold) hipLaunchKernelGGL((k_pw_fft4096<NB, true>), grid, dim3(256), 0, s, in, tune_stride, pass_stride, passes, window, twiddle + 2048, passes_per_group, (i64 *)avg); \
+		else hipLaunchKernelGGL((k_pw_fft4096<NB, false>), grid, dim3(256), 0, s, in, tune_stride, pass_stride, passes, window, twiddle + 2048, passes_per_group, (i64 *)avg); } while (0)
 		if (nb == 1) GO4K(1); else if (nb == 2) GO4K(2); else GO4K(4);
 #undef GO4K
 		LAUNCH_RET();
@@ -535,8 +535,8 @@ extern "C" int rxk_pw_fft(void *stream, const int16_t *in, size_t tune_stride, s
 		if (lds_bytes > 64 * 1024) { \
 			(void)hipFuncSetAttribute((const void *)k_pw_fftR<MM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
 			(void)hipFuncSetAttribute((const void *)k_pw_fftR<MM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); } \
-		if (peak_hold) hipLaunchKernelGGL((k_pw_fftR<MM, true>), grid, dim3(T), lds_bytes, s, in, tune_stride, pass_stride, passes, nb_total, window, twiddle, passes_per_group, (i64 *)avg); \
-		else hipLaunchKernelGGL((k_pw_fftR<MM, false>), grid, dim3(T), lds_bytes, s, in, tune_stride, pass_stride, passes, nb_total, window, twiddle, passes_per_group, (i64 *)avg); } while (0)
+		if (peak_hold) hipLaunchKernelGGL((k_pw_fftR<MM, true>), grid, dim3(T), lds_bytes, s, in, tune_stride, pass_stride, passes, nb_total, window, twiddle + (1 << (MM - 1)), passes_per_group, (i64 *)avg); \
+		else hipLaunchKernelGGL((k_pw_fftR<MM, false>), grid, dim3(T), lds_bytes, s, in, tune_stride, pass_stride, passes, nb_total, window, twiddle + (1 << (MM - 1)), passes_per_group, (i64 *)avg); } while (0)
 		switch (bin_e) {
 		case 8: GOR(8); break; case 9: GOR(9); break; case 10: GOR(10); break; case 11: GOR(11); break;
 		case 12: GOR(12); break; default: GOR(13); break;

@@ -45,17 +45,11 @@ int rxgpu_chan_create(rxgpu_chan **out, const rxgpu_chan_params *p, size_t max_b
 		return rxgpu_fail(RXGPU_ENOMEM, "out of host memory");
 	s->p = *p;
 	s->max_windows = max_blocks * (block_len / 2 / n);
-	uint32_t *tw = malloc((n / 2 + 1) * 4);
+	uint32_t *tw = malloc((n + 2) * 4);
 	if (!tw) { free(s); return rxgpu_fail(RXGPU_ENOMEM, "out of host memory"); }
-	for (size_t j = 0; j < n / 2; j++) {              /* rtl_power.c:297-301: halve AFTER negating */
-		int16_t wr = sinewave[j + n / 4];
-		int16_t wi = (int16_t)(-sinewave[j]);
-		wr >>= 1;
-		wi >>= 1;
-		tw[j] = ((uint32_t)(uint16_t)wr) | ((uint32_t)(uint16_t)wi << 16);
-	}
+	rxgpu_twiddle_table(sinewave, (int)n, tw);
 	const size_t nc = (size_t)p->n_channels;
-	if (hipMalloc((void **)&s->twiddle_dev, (n / 2 + 1) * 4) != hipSuccess ||
+	if (hipMalloc((void **)&s->twiddle_dev, (n + 2) * 4) != hipSuccess ||
 	    hipMalloc((void **)&s->chan_lp, nc * s->max_windows * 4) != hipSuccess ||
 	    hipMalloc((void **)&s->pre_dev[0], nc * 8) != hipSuccess || hipMalloc((void **)&s->pre_dev[1], nc * 8) != hipSuccess ||
 	    hipMalloc((void **)&s->dev, sizeof(rxk_fm_dev)) != hipSuccess ||
@@ -63,7 +57,7 @@ int rxgpu_chan_create(rxgpu_chan **out, const rxgpu_chan_params *p, size_t max_b
 	    hipHostMalloc((void **)&s->dev_host, sizeof(rxk_fm_dev), 0) != hipSuccess ||
 	    hipHostMalloc((void **)&s->flag_host, RXK_FLAG_CAP * 8, 0) != hipSuccess ||
 	    hipHostMalloc((void **)&s->pre_host, nc * 8, 0) != hipSuccess ||
-	    hipMemcpy(s->twiddle_dev, tw, (n / 2) * 4, hipMemcpyHostToDevice) != hipSuccess) {
+	    hipMemcpy(s->twiddle_dev, tw, (n + 2) * 4, hipMemcpyHostToDevice) != hipSuccess) {
 		free(tw);
 		rxgpu_chan_destroy(s);
 		return rxgpu_fail(RXGPU_ENOMEM, "channeliser workspace allocation failed");

@@ -24,6 +24,9 @@ hipStream_t rxgpu_hip_stream2(void);   /* second stream: the latency-bound tail 
 #define RX_K(call) do { int e_ = (call); if (e_ != 0) \
 	return rxgpu_fail(RXGPU_ENODEV, "%s launch failed: %s (%s:%d)", #call, hipGetErrorString((hipError_t)e_), __FILE__, __LINE__); } while (0)
 
+/* fix_fft twiddles for the device: n/2 plain + n/2 doubled entries (rxgpu_power.c); tw holds n + 2 */
+void rxgpu_twiddle_table(const int16_t *sinewave, int n, uint32_t *tw);
+
 /* kernel timing: bracket launches with events when profiling is on */
 void rxgpu_prof_begin_on(const char *name, hipStream_t st);
 void rxgpu_prof_end_on(const char *name, hipStream_t st);

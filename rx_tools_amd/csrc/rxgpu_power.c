@@ -200,6 +200,22 @@ static const int cic_9_tables[11][10] = {
 
 #define PW_MAX_BIN_E 15       /* 2^15 complex samples = 128 KiB of the 160 KiB LDS */
 
+/* tw[0 .. n/2): the twiddles exactly as fix_fft forms them, rtl_power.c:297-301 (halve AFTER negating), packed
+ * (wr, wi); tw[n/2 .. n): the same doubled, (2wr, 2wi) -- what the packed butterfly multiplies by
+ * (fft_device.h); both still fit an int16 because of the halving.  n + 2 entries are allocated by the callers. */
+void rxgpu_twiddle_table(const int16_t *sinewave, int n, uint32_t *tw)
+{
+	for (int j = 0; j < n / 2; j++) {
+		int16_t wr = sinewave[j + n / 4];
+		int16_t wi = (int16_t)(-sinewave[j]);
+		wr >>= 1;
+		wi >>= 1;
+		tw[j] = ((uint32_t)(uint16_t)wr) | ((uint32_t)(uint16_t)wi << 16);
+		tw[n / 2 + j] = ((uint32_t)(uint16_t)(wr * 2)) | ((uint32_t)(uint16_t)(wi * 2) << 16);
+	}
+	tw[n] = tw[n + 1] = 0;
+}
+
 int rxgpu_power_scan_create(rxgpu_power_scan **out, const rxgpu_power_params *p, int max_tunes,
                             const int *window_coefs, const int16_t *sinewave)
 {
@@ -224,21 +240,14 @@ int rxgpu_power_scan_create(rxgpu_power_scan **out, const rxgpu_power_params *p,
 	s->max_tunes = max_tunes;
 	if (p->bin_e > 0) {
 		const int n = 1 << p->bin_e;
-		uint32_t *tw = malloc((size_t)(n / 2 + 1) * 4);
+		uint32_t *tw = malloc((size_t)(n + 2) * 4);
 		if (!tw) { free(s); return rxgpu_fail(RXGPU_ENOMEM, "out of host memory"); }
-		/* twiddles exactly as fix_fft forms them, rtl_power.c:297-301: halve AFTER negating */
-		for (int j = 0; j < n / 2; j++) {
-			int16_t wr = sinewave[j + n / 4];
-			int16_t wi = (int16_t)(-sinewave[j]);
-			wr >>= 1;
-			wi >>= 1;
-			tw[j] = ((uint32_t)(uint16_t)wr) | ((uint32_t)(uint16_t)wi << 16);
-		}
+		rxgpu_twiddle_table(sinewave, n, tw);
 		if (hipMalloc((void **)&s->window_dev, (size_t)n * 4) != hipSuccess ||
-		    hipMalloc((void **)&s->twiddle_dev, (size_t)(n / 2 + 1) * 4) != hipSuccess ||
+		    hipMalloc((void **)&s->twiddle_dev, (size_t)(n + 2) * 4) != hipSuccess ||
 		    hipMalloc((void **)&s->fir_dev, 10 * 4) != hipSuccess ||
 		    hipMemcpy(s->window_dev, window_coefs, (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess ||
-		    hipMemcpy(s->twiddle_dev, tw, (size_t)(n / 2 + (n < 2)) * 4, hipMemcpyHostToDevice) != hipSuccess ||
+		    hipMemcpy(s->twiddle_dev, tw, (size_t)(n + 2) * 4, hipMemcpyHostToDevice) != hipSuccess ||
 		    hipMemcpy(s->fir_dev, cic_9_tables[p->downsample_passes <= 10 ? p->downsample_passes : 0], 40, hipMemcpyHostToDevice) != hipSuccess) {
 			free(tw);
 			rxgpu_power_scan_destroy(s);
