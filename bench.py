@@ -134,7 +134,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--blocks", type=int, default=8192, help="rx_fm blocks of 131072 complex samples per step (8192 = 4 GiB of cs16)")
     ap.add_argument("--passes", type=int, default=512, help="rx_power scanner() passes per step (one report interval)")
-    ap.add_argument("--workload", default="both", choices=["both", "rx_fm", "rx_power", "chan"])
+    ap.add_argument("--workload", default="both", choices=["both", "rx_fm", "rx_power", "chan", "sdr"])
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU baseline budget per path (0 = skip)")
     ap.add_argument("--prof-level", type=int, default=1)
     args = ap.parse_args()
@@ -334,9 +334,39 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_ch_fft", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": 4 * T,
                          "avg_launch_ms": (ms / launches) if launches else None,
-                         "note": "integer-VALU/LDS bound like k_pw_fft (radix-2 per barrier in LDS); first version"},
+                         "note": "integer-VALU bound like k_pw_fft (register-blocked radix-16 passes, packed butterfly)"},
         }
         del d_iq, d_out
+
+    # ------------------------------------------------------------------ rx_sdr -F conversions
+    if args.workload in ("both", "sdr") and world == 1:
+        n_elems = 1 << 28                                         # 1 GiB of CS16
+        g = torch.Generator(device=dev).manual_seed(99)
+        d16 = torch.randint(-32768, 32768, (2 * n_elems,), dtype=torch.int16, device=dev, generator=g)
+        d12 = torch.randint(0, 256, (3 * n_elems,), dtype=torch.uint8, device=dev, generator=g)
+        torch.cuda.synchronize()
+        legs = {}
+        for fmt in ("CU8", "CS8", "CF32", "CS16"):
+            conv = R.SDR_CONVERSIONS[fmt][0]
+            src = d12 if fmt == "CS16" else d16
+            out = R.sdr_convert(fmt, src)
+            L.rxgpu_prof_reset()
+            L.rxgpu_prof_enable(2)
+            reps = 10
+            for _ in range(reps):
+                R.sdr_convert(fmt, src, out)
+            R.check(L.rxgpu_sync())
+            L.rxgpu_prof_enable(0)
+            ms, launches = prof("sdr_convert")
+            nbytes = L.rxgpu_sdr_in_bytes(conv, n_elems) + L.rxgpu_sdr_out_bytes(conv, n_elems)
+            gbs = nbytes / (ms / launches * 1e-3) / 1e9 if launches else 0.0
+            legs[("CS12->" if fmt == "CS16" else "CS16->") + fmt] = {
+                "MSample/s": n_elems / (ms / launches * 1e-3) / 1e6 if launches else 0.0,
+                "GB/s": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "bytes_per_element": nbytes / n_elems}
+            del out
+        result["sdr_convert"] = {"metric": "rx_sdr -F output conversions, complex MSample/s and HBM GB/s (read + write), 2^28 elements per launch",
+                                 "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "legs": legs}
+        del d16, d12
 
     if world > 1:
         dist.barrier()

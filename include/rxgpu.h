@@ -236,6 +236,37 @@ void rxgpu_power_scan_destroy(rxgpu_power_scan *s);
 int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, int tunes,
                          int64_t *d_avg, int32_t *d_samples);
 
+/* ------------------------------------------------------------------ rx_sdr output formats
+ *
+ * rx_sdr reads CS16 (or CS12) from the device and writes the stream in the format asked with -F; the
+ * conversions are inline loops in its main() (rtl_sdr.c:354-391).  They are replaced by one call per read:
+ *
+ *   RXGPU_SDR_CS16_TO_CU8    buf8[i] = (uint8)(x / 32767.0 * 128.0 + 127.4)     rtl_sdr.c:376-378
+ *   RXGPU_SDR_CS16_TO_CS8    buf8[i] = (int8) (x / 32767.0 * 128.0 + 0.4)       rtl_sdr.c:368-370
+ *                            (x >= 32665 gives 128, stored as -128 like the reference build)
+ *   RXGPU_SDR_CS16_TO_CF32   fbuf[i] = x * 1.0f / SHRT_MAX                        rtl_sdr.c:384-386
+ *   RXGPU_SDR_CS12_TO_CS16   3 packed bytes -> (b1<<12)|(b0<<4), (b2<<8)|(b1&0xf0) rtl_sdr.c:356-363
+ *
+ * n_elems counts complex elements (one I/Q pair), like readStream's return value. */
+enum {
+	RXGPU_SDR_CS16_TO_CU8 = 0,
+	RXGPU_SDR_CS16_TO_CS8 = 1,
+	RXGPU_SDR_CS16_TO_CF32 = 2,
+	RXGPU_SDR_CS12_TO_CS16 = 3
+};
+/* bytes read / written for n_elems elements of a conversion (0 for an unknown conversion) */
+size_t rxgpu_sdr_in_bytes(int conversion, size_t n_elems);
+size_t rxgpu_sdr_out_bytes(int conversion, size_t n_elems);
+/* device pointers (16-byte aligned), asynchronous on rxgpu_stream() */
+int rxgpu_sdr_convert(int conversion, const void *d_in, size_t n_elems, void *d_out);
+/* host pointers: what rx_sdr's read loop calls instead of its for-loops; synchronous.
+ * Replaces rtl_sdr.c:354-391 (the fwrite that follows stays). */
+int rxgpu_sdr_convert_host(int conversion, const void *in, size_t n_elems, void *out);
+
+/* rx_fm -E wav: the 44 header bytes generate_header() writes (rtl_fm.c:1174-1206); raw_mode != 0 is the
+ * two-channel header used with -M raw.  Host only. */
+void rxgpu_wav_header(int rate, int raw_mode, unsigned char out[44]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2,7 +2,7 @@
 """Generate tests/golden/*.npz by EXECUTING THE REFERENCE ITSELF (oracle/_ref).
 
 TEST INFRASTRUCTURE.  Needs /root/reference (this container): `make -C oracle ref` compiles
-rtl_fm.c / rtl_power.c where they lie, unmodified; this script drives those objects through
+rtl_fm.c / rtl_power.c / rtl_sdr.c where they lie, unmodified; this script drives those objects through
 ctypes and stores inputs + outputs.  The fixtures pin oracle/rx_oracle.c (test_oracle_golden.py)
 and, on the GPU box where /root/reference does not exist, the HIP path (test_gpu_golden.py).
 
@@ -164,6 +164,29 @@ def plans():
     np.savez_compressed(os.path.join(OUT, "plans.npz"), rows=np.array([repr(r) for r in rows]))
 
 
+def sdr_cases():
+    """rx_sdr -F conversions through the reference's own main(): every int16 value once, a packed CS12 stream,
+    and the WAV headers of rx_fm -E wav"""
+    x = np.arange(-32768, 32768, dtype=np.int16)
+    out = {}
+    for fmt in ("CU8", "CS8", "CF32"):
+        out["all_" + fmt] = support.ref_sdr_convert(fmt, x)
+    cs12 = np.random.default_rng(1212).integers(0, 256, size=3 * 4099, dtype=np.uint8)
+    out["cs12_in"] = cs12
+    out["cs12_out"] = support.ref_sdr_convert("CS16", cs12, chunk=777)
+    F = support.ref_fm()
+    hdr_args = [(32000, 0), (48000, 1), (170000, 0), (24000, 0), (1000000, 1)]
+    hdrs = np.zeros((len(hdr_args), 44), dtype=np.uint8)
+    for i, (rate, raw) in enumerate(hdr_args):
+        buf = (C.c_ubyte * 64)()
+        n = F.ref_fm_wav_header(rate, raw, buf, 64)
+        assert n == 44
+        hdrs[i] = np.frombuffer(bytes(buf)[:44], dtype=np.uint8)
+    out["wav_args"] = np.array(hdr_args, dtype=np.int64)
+    out["wav_headers"] = hdrs
+    np.savez_compressed(os.path.join(OUT, "sdr_cases.npz"), **out)
+
+
 if __name__ == "__main__":
     if not support.have_ref():
         raise SystemExit("oracle/_ref is missing: run `make -C oracle ref` where /root/reference exists")
@@ -172,7 +195,7 @@ if __name__ == "__main__":
     saved = os.dup(2)
     os.dup2(devnull, 2)          # the reference's frequency_range reports on stderr
     try:
-        kats(); fm_cases(); power_cases(); plans()
+        kats(); fm_cases(); power_cases(); plans(); sdr_cases()
     finally:
         os.dup2(saved, 2)
     for f in sorted(os.listdir(OUT)):

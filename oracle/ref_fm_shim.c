@@ -121,3 +121,25 @@ long ref_fm_run_blocks(const int16_t *iq, size_t n_blocks_in_buf, size_t block_l
 	}
 	return produced;
 }
+
+/* generate_header (rtl_fm.c:1174-1206) into a caller buffer; raw_mode selects mode_demod == &raw_demod */
+int ref_fm_wav_header(int rate, int raw_mode, unsigned char *out, size_t cap)
+{
+	char *mem = NULL;
+	size_t len = 0;
+	void (*saved)(struct demod_state *) = demod.mode_demod;
+	FILE *saved_file = output.file;
+	int saved_rate = output.rate;
+	output.file = open_memstream(&mem, &len);
+	output.rate = rate;
+	demod.mode_demod = raw_mode ? &raw_demod : &fm_demod;
+	generate_header(&demod, &output);
+	fclose(output.file);
+	output.file = saved_file;
+	output.rate = saved_rate;
+	demod.mode_demod = saved;
+	if (len > cap) len = cap;
+	memcpy(out, mem, len);
+	free(mem);
+	return (int)len;
+}

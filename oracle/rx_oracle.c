@@ -658,3 +658,62 @@ void rxo_chan_block(const rxo_chan_cfg *cfg, const int16_t *in, int len, int *pr
 	free(win);
 	free(lp);
 }
+
+/* =============================================================== rx_sdr output formats, rx_fm WAV header */
+
+/* rtl_sdr.c:368-370.  The fp64 sum reaches 128 for x >= 32665, which an int8 cannot hold; the reference
+ * build (gcc, x86-64) truncates the converted integer to its low byte (-128), stated here explicitly. */
+void rxo_sdr_cs16_to_cs8(const int16_t *in, size_t n, int8_t *out)
+{
+	for (size_t i = 0; i < n; i++)
+		out[i] = (int8_t)(uint8_t)(int)(in[i] / 32767.0 * 128.0 + 0.4);
+}
+
+/* rtl_sdr.c:376-378 */
+void rxo_sdr_cs16_to_cu8(const int16_t *in, size_t n, uint8_t *out)
+{
+	for (size_t i = 0; i < n; i++)
+		out[i] = (uint8_t)(in[i] / 32767.0 * 128.0 + 127.4);
+}
+
+/* rtl_sdr.c:384-386 */
+void rxo_sdr_cs16_to_cf32(const int16_t *in, size_t n, float *out)
+{
+	for (size_t i = 0; i < n; i++)
+		out[i] = in[i] * 1.0f / 32767;
+}
+
+/* rtl_sdr.c:356-363 */
+void rxo_sdr_cs12_to_cs16(const uint8_t *in, size_t n_elems, int16_t *out)
+{
+	for (size_t i = 0; i < n_elems; i++) {
+		uint8_t b0 = in[3 * i], b1 = in[3 * i + 1], b2 = in[3 * i + 2];
+		out[2 * i] = (int16_t)((b1 << 12) | (b0 << 4));
+		out[2 * i + 1] = (int16_t)((b2 << 8) | (b1 & 0xf0));
+	}
+}
+
+/* rtl_fm.c:1174-1206 */
+void rxo_wav_header(int rate, int raw_mode, uint8_t out[44])
+{
+	int b_rate = rate * 2, channels = 1, align = 2;
+	if (raw_mode) {
+		channels = 2;
+		align = 4;
+		b_rate *= 2;
+	}
+	uint8_t *p = out;
+	memcpy(p, "RIFF", 4); p += 4;
+	memset(p, 0xFF, 4); p += 4;
+	memcpy(p, "WAVE", 4); p += 4;
+	memcpy(p, "fmt ", 4); p += 4;
+	*p++ = 0x10; *p++ = 0; *p++ = 0; *p++ = 0;
+	*p++ = 1; *p++ = 0;
+	*p++ = (uint8_t)channels; *p++ = 0;
+	for (int i = 0; i < 4; i++) *p++ = (uint8_t)((rate >> (8 * i)) & 0xFF);
+	for (int i = 0; i < 4; i++) *p++ = (uint8_t)((b_rate >> (8 * i)) & 0xFF);
+	*p++ = (uint8_t)align; *p++ = 0;
+	*p++ = 0x10; *p++ = 0;
+	memcpy(p, "data", 4); p += 4;
+	memset(p, 0xFF, 4);
+}

@@ -149,6 +149,17 @@ void rxo_power_tune(const rxo_power_cfg *cfg, const int16_t *buf16, int16_t *wor
 int rxo_csv_row(char *dst, size_t cap, int64_t freq, int rate, int bin_e, int downsample, double crop,
                 int64_t *avg, int *samples);
 
+/* ------------------------------------------------- rx_sdr output formats (rtl_sdr.c), rx_fm WAV header */
+
+/* rtl_sdr.c:368-370, 376-378, 384-386: n int16 values (2 per element) */
+void rxo_sdr_cs16_to_cs8(const int16_t *in, size_t n, int8_t *out);
+void rxo_sdr_cs16_to_cu8(const int16_t *in, size_t n, uint8_t *out);
+void rxo_sdr_cs16_to_cf32(const int16_t *in, size_t n, float *out);
+/* rtl_sdr.c:356-363: n_elems packed 3-byte elements -> n_elems (I,Q) int16 pairs */
+void rxo_sdr_cs12_to_cs16(const uint8_t *in, size_t n_elems, int16_t *out);
+/* rtl_fm.c:1174-1206: raw_mode = (mode_demod == &raw_demod) */
+void rxo_wav_header(int rate, int raw_mode, uint8_t out[44]);
+
 #ifdef __cplusplus
 }
 #endif

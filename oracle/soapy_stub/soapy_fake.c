@@ -25,6 +25,7 @@ static const int16_t *g_src;      /* interleaved I,Q */
 static size_t g_src_len;          /* complex samples */
 static size_t g_src_pos;
 static size_t g_max_chunk;        /* 0 = hand out whatever is asked for */
+static size_t g_elem = 4;         /* bytes per element of the source (cs16 = 4, cs12 = 3) */
 static void (*g_eos_hook)(void);
 static void (*g_pace_hook)(void); /* called before every data read but the first */
 static size_t g_reads;
@@ -36,6 +37,7 @@ void soapy_fake_set_source(const int16_t *iq, size_t n_complex, size_t max_chunk
 {
 	g_src = iq; g_src_len = n_complex; g_src_pos = 0; g_max_chunk = max_chunk;
 }
+void soapy_fake_set_elem_size(size_t bytes) { g_elem = bytes ? bytes : 4; }
 void soapy_fake_set_discard_buffer(const void *p) { g_discard = p; }
 void soapy_fake_set_freq_script(const double *f, size_t n) { g_freq_script = f; g_freq_n = n; g_freq_pos = 0; }
 void soapy_fake_set_eos_hook(void (*fn)(void)) { g_eos_hook = fn; }
@@ -44,13 +46,14 @@ size_t soapy_fake_position(void) { return g_src_pos; }
 
 size_t SoapySDR_formatToSize(const char *format)
 {
-	/* bytes per element: complex formats carry two components */
+	/* bytes per element the way libSoapySDR counts them: all digits form the bit width of one component,
+	 * doubled for complex formats, divided by 8 (CS16 -> 4, CS12 -> 3, CU8 -> 2, CF32 -> 8) */
 	size_t bits = 0, is_complex = 0;
-	const char *p = format;
-	if (*p == 'C') { is_complex = 1; p++; }
-	if (*p) p++;                     /* F / S / U */
-	bits = (size_t)atoi(p);
-	return (is_complex ? 2 : 1) * ((bits + 7) / 8);
+	for (const char *p = format; *p; p++) {
+		if (*p == 'C') is_complex = 1;
+		if (*p >= '0' && *p <= '9') bits = bits * 10 + (size_t)(*p - '0');
+	}
+	return (is_complex ? 2 : 1) * bits / 8;
 }
 
 SoapySDRKwargs SoapySDRKwargs_fromString(const char *markup) { SoapySDRKwargs k = {0, NULL, NULL}; (void)markup; return k; }
@@ -90,7 +93,7 @@ int SoapySDRDevice_readStream(SoapySDRDevice *d, SoapySDRStream *s, void * const
 	}
 	if (g_max_chunk && n > g_max_chunk) n = g_max_chunk;
 	if (n > g_src_len - g_src_pos) n = g_src_len - g_src_pos;
-	memcpy(buffs[0], g_src + 2 * g_src_pos, n * 2 * sizeof(int16_t));
+	memcpy(buffs[0], (const char *)g_src + g_elem * g_src_pos, n * g_elem);
 	g_src_pos += n;
 	return (int)n;
 }

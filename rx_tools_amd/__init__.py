@@ -7,4 +7,5 @@ no CPU implementation here: without librxgpu.so and a HIP device every call fail
 from ._lib import lib, RxGpuError, check          # noqa: F401
 from .fm import FmParams, FmCarry, FmStream, ChanParams, Channeliser        # noqa: F401
 from .power import PowerParams, PowerPlan, PowerScan, plan_range, sine_table, window_coefs  # noqa: F401
+from .sdr import sdr_convert, sdr_convert_host, wav_header, SDR_CONVERSIONS      # noqa: F401
 from . import synth  # noqa: F401

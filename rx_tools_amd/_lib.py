@@ -24,6 +24,7 @@ EXPORTS = [
     "rxgpu_chan_host_fixups",
     "rxgpu_scan", "rxgpu_csv_dbm", "rxgpu_power_plan_range", "rxgpu_sine_table", "rxgpu_window_coefs",
     "rxgpu_power_scan_create", "rxgpu_power_scan_destroy", "rxgpu_power_scan_run",
+    "rxgpu_sdr_in_bytes", "rxgpu_sdr_out_bytes", "rxgpu_sdr_convert", "rxgpu_sdr_convert_host", "rxgpu_wav_header",
 ]
 
 
@@ -79,6 +80,14 @@ def lib():
         L.rxgpu_full_demod.argtypes = [C.c_void_p]
         L.rxgpu_set_demod_functions.argtypes = [C.c_void_p] * 5
         L.rxgpu_callback.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.rxgpu_sdr_in_bytes.restype = C.c_size_t
+        L.rxgpu_sdr_in_bytes.argtypes = [C.c_int, C.c_size_t]
+        L.rxgpu_sdr_out_bytes.restype = C.c_size_t
+        L.rxgpu_sdr_out_bytes.argtypes = [C.c_int, C.c_size_t]
+        L.rxgpu_sdr_convert.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.rxgpu_sdr_convert_host.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.rxgpu_wav_header.restype = None
+        L.rxgpu_wav_header.argtypes = [C.c_int, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 

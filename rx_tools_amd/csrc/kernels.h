@@ -162,6 +162,11 @@ int rxk_pw_rms_sums(void *stream, const int16_t *in, size_t n_bufs, int buf_len,
 int rxk_pw_rms_apply(void *stream, const long long *t, const long long *p, int passes, int tunes, int buf_len,
                      int peak_hold, long long *avg, int *samples);
 
+/* ---- rx_sdr output converters (sdr_kernels.hip), rtl_sdr.c:354-391; n16 = int16 count, device pointers */
+int rxk_sdr_cs16_to_8(void *stream, const int16_t *in, unsigned long long n16, int is_unsigned, uint8_t *out);
+int rxk_sdr_cs16_to_cf32(void *stream, const int16_t *in, unsigned long long n16, float *out);
+int rxk_sdr_cs12_to_cs16(void *stream, const uint8_t *in, unsigned long long n_elems, int16_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,17 +90,74 @@ def oracle():
         L.rxo_power_tune.argtypes = [C.POINTER(PowerCfg), i16p, i16p, i64p, intp]
         L.rxo_csv_row.argtypes = [C.c_char_p, C.c_size_t, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, i64p, intp]
         L.rxo_rms_power.argtypes = [i16p, C.c_int, C.c_int, i64p, intp]
+        u8p = C.POINTER(C.c_uint8)
+        L.rxo_sdr_cs16_to_cs8.argtypes = [i16p, C.c_size_t, C.POINTER(C.c_int8)]
+        L.rxo_sdr_cs16_to_cu8.argtypes = [i16p, C.c_size_t, u8p]
+        L.rxo_sdr_cs16_to_cf32.argtypes = [i16p, C.c_size_t, C.POINTER(C.c_float)]
+        L.rxo_sdr_cs12_to_cs16.argtypes = [u8p, C.c_size_t, i16p]
+        L.rxo_wav_header.argtypes = [C.c_int, C.c_int, u8p]
         _oracle = L
     return _oracle
 
 
+SDR_FORMATS = {"CU8": (0, np.uint8), "CS8": (1, np.int8), "CF32": (2, np.float32), "CS16": (3, np.int16)}
+
+
+def oracle_sdr_convert(fmt, data):
+    """data: int16 array (CU8/CS8/CF32) or uint8 array of packed CS12 elements (fmt "CS16")"""
+    L = oracle()
+    if fmt == "CS16":
+        n = data.size // 3
+        out = np.zeros(2 * n, dtype=np.int16)
+        L.rxo_sdr_cs12_to_cs16(data.ctypes.data_as(C.POINTER(C.c_uint8)), n, ptr16(out))
+        return out
+    out = np.zeros(data.size, dtype=SDR_FORMATS[fmt][1])
+    fn = {"CU8": L.rxo_sdr_cs16_to_cu8, "CS8": L.rxo_sdr_cs16_to_cs8, "CF32": L.rxo_sdr_cs16_to_cf32}[fmt]
+    fn(ptr16(data), data.size, C.cast(out.ctypes.data, fn.argtypes[2]))
+    return out
+
+
 def have_ref():
-    return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libref_fm.so")) and \
-        os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libref_power.so"))
+    return all(os.path.exists(os.path.join(ORACLE_DIR, "_ref", f))
+               for f in ("libref_fm.so", "libref_power.so", "libref_sdr.so"))
 
 
 _ref_fm = None
 _ref_power = None
+_ref_sdr = None
+
+
+def ref_sdr():
+    """oracle/_ref/libref_sdr.so -- the reference's own rtl_sdr.c, compiled unmodified."""
+    global _ref_sdr
+    if _ref_sdr is None:
+        L = C.CDLL(os.path.join(ORACLE_DIR, "_ref", "libref_sdr.so"))
+        L.ref_sdr_run.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
+        _ref_sdr = L
+    return _ref_sdr
+
+
+def ref_sdr_convert(fmt, data, chunk=1000):
+    """Run the reference's rx_sdr main() over `data` (int16 CS16, or uint8 packed CS12 when fmt == "CS16")
+    and return what it wrote with -F fmt."""
+    import tempfile
+    L = ref_sdr()
+    in_fmt = b"CS12" if fmt == "CS16" else b"CS16"
+    n_elems = data.size // (3 if fmt == "CS16" else 2)
+    data = np.ascontiguousarray(data)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "out.bin")
+        devnull = os.open(os.devnull, os.O_WRONLY)
+        saved = os.dup(2)
+        os.dup2(devnull, 2)
+        try:
+            rc = L.ref_sdr_run(data.ctypes.data, n_elems, in_fmt, fmt.encode(), path.encode(), chunk)
+        finally:
+            os.dup2(saved, 2)
+            os.close(devnull)
+            os.close(saved)
+        assert rc == 0
+        return np.fromfile(path, dtype=SDR_FORMATS[fmt][1])
 
 
 def ref_fm():
