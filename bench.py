@@ -127,6 +127,33 @@ def cpu_baseline_power(plan, budget_s):
                       % (done, plan.buf_len, n, dt, cpu_model())}
 
 
+def cpu_all_cores(which, budget_s):
+    """one independent replica of the single-thread baseline per hardware thread (the reference has
+    one demod thread / a single-threaded scanner, and keeps its state in globals, hence processes not threads)."""
+    import subprocess
+    n = os.cpu_count() or 1
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", which, "--cpu-seconds", "%g" % budget_s]
+    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for _ in range(n)]
+    total, ok = 0.0, 0
+    for p in procs:
+        out, _ = p.communicate()
+        try:
+            total += json.loads(out.decode().strip().splitlines()[-1])["value"]
+            ok += 1
+        except (ValueError, IndexError, KeyError):
+            pass
+    return {"value": total, "cores": ok, "note": "%d concurrent single-thread replicas, %.0f s each" % (ok, budget_s)}
+
+
+def cpu_worker(which, budget_s):
+    if which == "fm":
+        r = cpu_baseline_fm(2 * 131072, budget_s)
+    else:
+        import types
+        r = cpu_baseline_power(types.SimpleNamespace(bin_e=12, buf_len=16384), budget_s)   # -f 24M:1.7G:1k geometry
+    print(json.dumps(r))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,7 +164,11 @@ def main():
     ap.add_argument("--workload", default="both", choices=["both", "rx_fm", "rx_power", "chan", "sdr"])
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU baseline budget per path (0 = skip)")
     ap.add_argument("--prof-level", type=int, default=1)
+    ap.add_argument("--cpu-worker", default=None, choices=["fm", "power"], help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker:
+        cpu_worker(args.cpu_worker, args.cpu_seconds)
+        return
 
     import torch
     import torch.distributed as dist
@@ -234,6 +265,7 @@ def main():
         })
         if rank == 0 and args.cpu_seconds > 0 and world == 1:
             result["cpu_baseline"] = cpu_baseline_fm(block_len, args.cpu_seconds)
+            result["cpu_baseline"]["all_cores"] = cpu_all_cores("fm", min(4.0, args.cpu_seconds))
 
     # ------------------------------------------------------------------ rx_power
     if args.workload in ("both", "rx_power"):
@@ -292,6 +324,7 @@ def main():
         }
         if rank == 0 and args.cpu_seconds > 0 and world == 1:
             pw["cpu_baseline"] = cpu_baseline_power(plan, args.cpu_seconds / 2)
+            pw["cpu_baseline"]["all_cores"] = cpu_all_cores("power", min(4.0, args.cpu_seconds / 2))
         ps.close()
         if args.workload == "rx_power":
             result.update(pw)
