@@ -30,7 +30,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define DEC_THREADS 256
 #define DEC_WAVE_SPAN (RXK_DEC_SPAN / 4)     // samples per wave
 #define DEC_TILE 256                         // samples per wave load (64 lanes x 4)
-#define DEC_TILES (DEC_WAVE_SPAN / DEC_TILE) // 16
+#define DEC_TILES (DEC_WAVE_SPAN / DEC_TILE)
+#define DEC_BATCH 8
 
 // ------------------------------------------------------------------ small helpers
 
@@ -76,6 +77,73 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
 	return v;
 }
 
+// The same scan as ONE 32-bit add per step (v_add_u32_dpp) for values whose low halves are small and non-negative:
+// with the callback's scaling (values in [-127, 128]) a lane's I sum lies in [-510, 510] when rotated and in
+// [-508, 512] when not; biased by 511 every low half is positive and the 64 of them add up to at most 65 472, so no
+// carry ever reaches the Q half and the packed sum is exact.  The caller removes 511*(lane+1).
+__device__ __forceinline__ uint32_t wave_scan_incl_biased(uint32_t v)
+{
+	uint32_t t;
+	t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); v += t;
+	t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); v += t;
+	t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); v += t;
+	t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); v += t;
+	// rows keep their value where the mask excludes them: dst = dst + dpp(dst) in place
+	asm("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+	    "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
+	return v;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// two cs16 components through F0 (scale_cs16) with the signs of rotate16_90 folded in -- trunc(-r) == -trunc(r) --
+// packed as int16 pair (lo from a, hi from b): v_cvt_f32_i32 (SDWA) x2, one v_pk_fma_f32, v_cvt_i32_f32 x2, v_cvt_pk_i16_i32
+template <int SA, int SB>
+__device__ __forceinline__ uint32_t scale_pk(int a, int b)
+{
+	const f32x2 x = {(float)a, (float)b};
+	const f32x2 cc = {(float)(128.0 / 32767.0), (float)(128.0 / 32767.0)}, hh = {0.4f, 0.4f};
+	f32x2 r;
+	// the sign pairs are source modifiers of the one constant pair (the compiler would materialise four)
+	if (SA > 0 && SB > 0)
+		asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(cc), "v"(hh));
+	else if (SA < 0 && SB > 0)
+		asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,1,1]" : "=v"(r) : "v"(x), "v"(cc), "v"(hh));
+	else if (SA > 0 && SB < 0)
+		asm("v_pk_fma_f32 %0, %1, %2, %3 neg_hi:[0,1,1]" : "=v"(r) : "v"(x), "v"(cc), "v"(hh));
+	else
+		asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,1,1] neg_hi:[0,1,1]" : "=v"(r) : "v"(x), "v"(cc), "v"(hh));
+	return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16((int)r.x, (int)r.y));
+}
+
+// a lane's four samples as packed (I,Q) contributions to the running sums: rotate16_90 (rtl_fm.c:309-327) multiplies
+// sample n of the block by j^n, and a lane's samples sit at phases 0..3
+template <bool PRESCALED, bool ROTATE>
+__device__ __forceinline__ void dec_contrib(const u32x4 v, uint32_t &s0, uint32_t &s1, uint32_t &s2, uint32_t &s3)
+{
+	if (!PRESCALED) {
+		s0 = scale_pk<1, 1>(lo16(v.x), hi16(v.x));
+		if (ROTATE) {
+			s1 = scale_pk<-1, 1>(hi16(v.y), lo16(v.y));            // (-q1,  i1)
+			s2 = scale_pk<-1, -1>(lo16(v.z), hi16(v.z));           // (-i2, -q2)
+			s3 = scale_pk<1, -1>(hi16(v.w), lo16(v.w));            // ( q3, -i3)
+		} else {
+			s1 = scale_pk<1, 1>(lo16(v.y), hi16(v.y));
+			s2 = scale_pk<1, 1>(lo16(v.z), hi16(v.z));
+			s3 = scale_pk<1, 1>(lo16(v.w), hi16(v.w));
+		}
+	} else {
+		s0 = v.x;
+		if (ROTATE) {
+			s1 = pack_iq(-hi16(v.y), lo16(v.y));
+			s2 = pk_sub(0u, v.z);
+			s3 = pack_iq(hi16(v.w), -lo16(v.w));
+		} else {
+			s1 = v.y; s2 = v.z; s3 = v.w;
+		}
+	}
+}
+
 // ------------------------------------------------------------------ F0+F1+F2 fused
 
 // One workgroup = RXK_DEC_SPAN consecutive complex samples of the stream, 4 waves of
@@ -89,17 +157,21 @@ __device__ __forceinline__ int fast_atan2_dev(int y, int x);
 // DISC: also run the -A fast discriminator (F5/F6) for every output whose predecessor was completed
 // by this workgroup too (all but its first two), while the sums are still in LDS/registers; the
 // two seam outputs per workgroup and each block's libm sample are left to k_fm_disc.
-template <bool PRESCALED, bool ROTATE, bool DISC>
+template <bool PRESCALED, bool ROTATE, bool DISC, bool DIV24>
 __global__ __launch_bounds__(DEC_THREADS) void k_fm_decimate(
-	const u32x4 *__restrict__ iq, u64 T, int ds, int p0, unsigned magic,
+	const u32x4 *__restrict__ iq, u64 T, int ds, int p0, unsigned magic, unsigned magic24,
 	uint32_t *__restrict__ lp_raw, uint32_t *__restrict__ head, uint32_t *__restrict__ tail, unsigned slot_cap,
-	int16_t *__restrict__ pcm)
+	int lp_sparse, int16_t *__restrict__ pcm)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 	uint32_t *slot = lds;
 	uint32_t *wtot = lds + slot_cap;
 
-	const u64 wg0 = (u64)blockIdx.x * RXK_DEC_SPAN;
+	// workgroup b runs on XCD b % 8 (observed placement): give every XCD one contiguous eighth of the stream so that
+	// the partial output lines of neighbouring spans meet in the same L2 instead of being written back one by one
+	const unsigned per = gridDim.x >> 3;
+	const unsigned wgi = (gridDim.x & 7) ? blockIdx.x : (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+	const u64 wg0 = (u64)wgi * RXK_DEC_SPAN;
 	const u64 left = T - wg0;
 	const unsigned span = left < (u64)RXK_DEC_SPAN ? (unsigned)left : (unsigned)RXK_DEC_SPAN;
 	const u64 t0 = wg0 + (unsigned)p0;
@@ -109,39 +181,41 @@ __global__ __launch_bounds__(DEC_THREADS) void k_fm_decimate(
 	const u32x4 *src = iq + (wg0 >> 2);
 
 	uint32_t run = 0;                                       // wave-uniform running prefix
+	const uint32_t unbias = 511u * (lane + 1);              // what the biased scan added to this lane's I prefix (< 2^16)
 #pragma unroll
-	for (int half = 0; half < 2; half++) {
-		u32x4 v[DEC_TILES / 2];
+	for (int half = 0; half < DEC_TILES / DEC_BATCH; half++) {      // DEC_BATCH loads in flight per lane
+		u32x4 v[DEC_BATCH];
 #pragma unroll
-		for (int u = 0; u < DEC_TILES / 2; u++) {
-			unsigned rel = wave * DEC_WAVE_SPAN + (half * (DEC_TILES / 2) + u) * DEC_TILE + lane * 4;
+		for (int u = 0; u < DEC_BATCH; u++) {
+			unsigned rel = wave * DEC_WAVE_SPAN + (half * DEC_BATCH + u) * DEC_TILE + lane * 4;
 			v[u] = rel < span ? __builtin_nontemporal_load(src + (rel >> 2)) : (u32x4)(0u);
 		}
 #pragma unroll
-		for (int u = 0; u < DEC_TILES / 2; u++) {
-			const unsigned rel = wave * DEC_WAVE_SPAN + (half * (DEC_TILES / 2) + u) * DEC_TILE + lane * 4;
-			int i0 = lo16(v[u].x), q0 = hi16(v[u].x), i1 = lo16(v[u].y), q1 = hi16(v[u].y);
-			int i2 = lo16(v[u].z), q2 = hi16(v[u].z), i3 = lo16(v[u].w), q3 = hi16(v[u].w);
-			if (!PRESCALED) {
-				i0 = scale_cs16(i0); q0 = scale_cs16(q0); i1 = scale_cs16(i1); q1 = scale_cs16(q1);
-				i2 = scale_cs16(i2); q2 = scale_cs16(q2); i3 = scale_cs16(i3); q3 = scale_cs16(q3);
-			}
-			// rotate16_90: sample n of the block times j^n; a lane's 4 samples sit at phases 0..3
-			int c1i = i0, c1q = q0;
-			int c2i = c1i + (ROTATE ? -q1 : i1), c2q = c1q + (ROTATE ? i1 : q1);
-			int c3i = c2i + (ROTATE ? -i2 : i2), c3q = c2q + (ROTATE ? -q2 : q2);
-			int c4i = c3i + (ROTATE ? q3 : i3), c4q = c3q + (ROTATE ? -i3 : q3);
-			const uint32_t tot = pack_iq(c4i, c4q);
-			const uint32_t incl = wave_scan_incl(tot);
-			// does a window end inside this lane?  windows end (exclusive) at (j+1)*ds - ph
+		for (int u = 0; u < DEC_BATCH; u++) {
+			const unsigned rel = wave * DEC_WAVE_SPAN + (half * DEC_BATCH + u) * DEC_TILE + lane * 4;
+			uint32_t s0, s1, s2, s3;
+			dec_contrib<PRESCALED, ROTATE>(v[u], s0, s1, s2, s3);
+			const uint32_t c1 = s0, c2 = pk_add(c1, s1), c3 = pk_add(c2, s2), c4 = pk_add(c3, s3);
+			uint32_t incl;
+			if (!PRESCALED)
+				incl = pk_sub(wave_scan_incl_biased(pk_add(c4, 511u)), unbias);
+			else
+				incl = wave_scan_incl(c4);
+			// does a window end inside this lane?  windows end (exclusive) at (j+1)*ds - ph:
+			// k = floor(qn / ds) windows end at or before this lane's last sample, the k-th after cnt of its samples
 			const unsigned qn = rel + 4 + ph;
-			const unsigned k = __umulhi(qn, magic);         // floor(qn / ds)
-			const unsigned e = k * (unsigned)ds - ph;
-			if (k >= 1 && e > rel && rel < span) {
-				const unsigned cnt = e - rel;               // 1..4 samples of this lane belong to it
-				const int si = cnt == 1 ? c1i : cnt == 2 ? c2i : cnt == 3 ? c3i : c4i;
-				const int sq = cnt == 1 ? c1q : cnt == 2 ? c2q : cnt == 3 ? c3q : c4q;
-				slot[k - 1] = pk_add(pk_add(run, pk_sub(incl, tot)), pack_iq(si, sq));
+			unsigned k;
+			int cnt;
+			if (DIV24) {                                    // qn * ds < 2^24: two full-rate 24-bit multiplies
+				k = (unsigned)(((unsigned long long)((qn << 8) & 0xffffffu) * (unsigned long long)(magic24 & 0xffffffu)) >> 32);
+				asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(cnt) : "v"(k), "s"(ds), "v"(4u - qn));
+			} else {
+				k = __umulhi(qn, magic);
+				cnt = (int)(k * (unsigned)ds + 4u - qn);
+			}
+			if (cnt > 0 && rel < span) {                    // cnt = 1..4 samples of this lane belong to window k-1
+				const uint32_t sel = cnt == 1 ? c1 : cnt == 2 ? c2 : cnt == 3 ? c3 : c4;
+				slot[k - 1] = pk_add(pk_add(run, pk_sub(incl, c4)), sel);
 			}
 			run = pk_add(run, (uint32_t)__builtin_amdgcn_readlane((int)incl, 63));
 		}
@@ -158,12 +232,13 @@ __global__ __launch_bounds__(DEC_THREADS) void k_fm_decimate(
 		const unsigned wv = (e - 1) / DEC_WAVE_SPAN;
 		const uint32_t pj = pk_add(slot[j], wv == 0 ? 0u : wv == 1 ? b1 : wv == 2 ? b2 : b3);
 		if (j == 0) {
-			head[blockIdx.x] = pj;
+			head[wgi] = pj;
 		} else {
 			const unsigned wq = (e - (unsigned)ds - 1) / DEC_WAVE_SPAN;
 			const uint32_t pm = pk_add(slot[j - 1], wq == 0 ? 0u : wq == 1 ? b1 : wq == 2 ? b2 : b3);
 			const uint32_t a = pk_sub(pj, pm);
-			lp_raw[m_base + j] = a;
+			if (!lp_sparse || j == 1 || j == n_b - 1)
+				lp_raw[m_base + j] = a;
 			if (DISC && j >= 2) {
 				const unsigned wr = (e - 2 * (unsigned)ds - 1) / DEC_WAVE_SPAN;
 				const uint32_t pmm = pk_add(slot[j - 2], wr == 0 ? 0u : wr == 1 ? b1 : wr == 2 ? b2 : b3);
@@ -183,9 +258,9 @@ __global__ __launch_bounds__(DEC_THREADS) void k_fm_decimate(
 			const unsigned wv = (e - 1) / DEC_WAVE_SPAN;
 			last = pk_add(slot[n_b - 1], wv == 0 ? 0u : wv == 1 ? b1 : wv == 2 ? b2 : b3);
 		} else {
-			head[blockIdx.x] = 0;
+			head[wgi] = 0;
 		}
-		tail[blockIdx.x] = pk_sub(total, last);
+		tail[wgi] = pk_sub(total, last);
 	}
 }
 
@@ -236,16 +311,12 @@ __device__ __forceinline__ int fast_atan2_dev(int y, int x)
 		return 0;
 	const unsigned ux = (unsigned)x;
 	const unsigned ay = y < 0 ? 0u - (unsigned)y : (unsigned)y;
-	int ang;
-	if (x >= 0) {
-		const int num = (int)(4096u * (ux - ay));
-		const int den = (int)(ux + ay);
-		ang = 4096 - num / den;
-	} else {
-		const int num = (int)(4096u * (ux + ay));
-		const int den = (int)(ay - ux);
-		ang = 12288 - num / den;
-	}
+	// x >= 0: pi/4 - pi/4 * (x - |y|) / (x + |y|);  x < 0: 3pi/4 - pi/4 * (x + |y|) / (|y| - x)  -- one division site,
+	// so lanes of both kinds do not walk the (long) division expansion twice
+	const bool neg = x < 0;
+	const int num = (int)(4096u * (neg ? ux + ay : ux - ay));
+	const int den = (int)(neg ? ay - ux : ux + ay);
+	const int ang = (neg ? 12288 : 4096) - num / den;
 	return y < 0 ? -ang : ang;
 }
 
@@ -278,9 +349,30 @@ __device__ __forceinline__ int esbensen_dev(int ar, int aj, int br, int bj)
 	return (int)(2608u * (unsigned)cj) / den;
 }
 
-__device__ __forceinline__ uint32_t lp_final(u64 m, int ds, int p0, int seams, const uint32_t *lp_raw,
-                                             const uint32_t *head, const uint32_t *tail, uint32_t carry)
+// window m = stream samples [m*ds - p0, (m+1)*ds - p0), summed again from the capture (exact int, then int16 like low_pass's
+// store); only for windows that lie completely inside this run
+template <bool PRESCALED>
+__device__ __forceinline__ uint32_t lp_brute(const uint32_t *iq, u64 m, int ds, int p0, u64 n_per_block, int rotate)
 {
+	const u64 start = m * (u64)ds - (u64)p0;
+	u64 inblk = start % n_per_block;
+	int si = 0, sq = 0;
+	for (u64 pos = start; pos < start + (u64)ds; pos++) {
+		int ri, rq;
+		load_rot<PRESCALED>(iq, pos, rotate ? (unsigned)inblk : 0u, ri, rq);
+		si += ri; sq += rq;
+		if (++inblk == n_per_block) inblk = 0;
+	}
+	return pack_iq(si, sq);
+}
+
+// stored != 0: lp_raw[m] is known to have been written; otherwise (lp_sparse) the window is summed again
+template <bool PRESCALED>
+__device__ __forceinline__ uint32_t lp_final(u64 m, int ds, int p0, int seams, const uint32_t *lp_raw,
+                                             const uint32_t *head, const uint32_t *tail, uint32_t carry,
+                                             int stored, const uint32_t *iq, u64 n_per_block, int rotate, bool *brute)
+{
+	*brute = false;
 	if (!seams)
 		return lp_raw[m];
 	// window m covers stream samples [m*ds - p0, (m+1)*ds - p0); it is the one the decimator left
@@ -290,7 +382,10 @@ __device__ __forceinline__ uint32_t lp_final(u64 m, int ds, int p0, int seams, c
 	const u64 g = ((u64)(w0 + ds - 1)) >> RXK_DEC_SPAN_LOG2;
 	if (w0 <= (i64)(g << RXK_DEC_SPAN_LOG2))
 		return pk_add(g ? tail[g - 1] : carry, head[g]);
-	return lp_raw[m];
+	if (stored)
+		return lp_raw[m];
+	*brute = true;
+	return lp_brute<PRESCALED>(iq, m, ds, p0, n_per_block, rotate);
 }
 
 // grid: ceil(M/256) blocks for the outputs (+1 block for the exact low_pass tail sums)
@@ -300,7 +395,7 @@ __global__ __launch_bounds__(256) void k_fm_disc(
 	const uint32_t *lp_raw, const uint32_t *__restrict__ head, const uint32_t *__restrict__ tail,
 	uint32_t *lp /* may alias lp_raw: seam entries are finished in place */, u64 M, int first_mode, u64 uniform_k, int custom_atan, int do_tail,
 	int16_t *__restrict__ pcm, rxk_fm_dev *__restrict__ dev, u64 *__restrict__ flag_list, unsigned out_blocks,
-	int sparse, u64 n_wg, u64 n_blocks, const int *__restrict__ atan_lut)
+	int sparse, u64 n_wg, u64 n_blocks, const int *__restrict__ atan_lut, int lp_sparse)
 {
 	if (blockIdx.x >= out_blocks) {
 		// ---- low_pass carry: exact int32 sums of the samples after the last complete window
@@ -326,6 +421,7 @@ __global__ __launch_bounds__(256) void k_fm_disc(
 		return;
 	}
 	u64 m = (u64)blockIdx.x * 256 + threadIdx.x;
+	int a_stored = !lp_sparse, b_stored = !lp_sparse;    // lp_sparse: only a span's second and last outputs are in lp_raw
 	if (sparse) {
 		// only what k_fm_decimate<DISC> could not finish: the first two windows ending in each
 		// workgroup span, the first window of each callback block (libm), and the very last one (carry)
@@ -335,6 +431,8 @@ __global__ __launch_bounds__(256) void k_fm_disc(
 			m = ((g << RXK_DEC_SPAN_LOG2) + (u64)p0) / (u64)ds + (t & 1);
 			if (m >= M || (((m + 1) * (u64)ds - (u64)p0 - 1) >> RXK_DEC_SPAN_LOG2) != g)
 				return;
+			a_stored = 1;                            // t odd: the span's second output; t even: head/tail form
+			b_stored = 1;                            // t odd: head/tail form; t even: the previous span's last output
 		} else if (t < 2 * n_wg + n_blocks) {
 			m = ((t - 2 * n_wg) * n_per_block + (u64)p0) / (u64)ds;
 		} else if (t == 2 * n_wg + n_blocks) {
@@ -346,7 +444,8 @@ __global__ __launch_bounds__(256) void k_fm_disc(
 	if (m >= M)
 		return;
 	const uint32_t carry = pack_iq(dev->in_now_r, dev->in_now_j);
-	const uint32_t a = lp_final(m, ds, p0, seams, lp_raw, head, tail, carry);
+	bool brute;
+	const uint32_t a = lp_final<PRESCALED>(m, ds, p0, seams, lp_raw, head, tail, carry, a_stored, iq, n_per_block, rotate, &brute);
 	if (seams)
 		lp[m] = a;
 	if (!pcm) {                                  // lp_only: squelch / another demodulator comes next
@@ -355,7 +454,9 @@ __global__ __launch_bounds__(256) void k_fm_disc(
 	}
 	int br, bj;
 	if (m) {
-		const uint32_t b = lp_final(m - 1, ds, p0, seams, lp_raw, head, tail, carry);
+		const uint32_t b = lp_final<PRESCALED>(m - 1, ds, p0, seams, lp_raw, head, tail, carry, b_stored, iq, n_per_block, rotate, &brute);
+		if (brute)
+			lp[m - 1] = b;                           // the host re-reads both for a flagged libm sample
 		br = lo16(b); bj = hi16(b);
 	} else {
 		br = dev->in_pre_r; bj = dev->in_pre_j;
@@ -1463,21 +1564,28 @@ __global__ void k_ch_demod(const uint32_t *__restrict__ chan_lp, u64 total_windo
 #define LAUNCH_RET() return (int)hipGetLastError()
 
 extern "C" int rxk_fm_decimate(void *stream, const int16_t *iq, u64 T, int ds, int p0, int prescaled, int rotate,
-                               uint32_t *lp_raw, uint32_t *head, uint32_t *tail, int16_t *pcm)
+                               uint32_t *lp_raw, uint32_t *head, uint32_t *tail, int lp_sparse, int16_t *pcm)
 {
+	if (!pcm || ds > RXK_LP_SPARSE_MAX_DS)
+		lp_sparse = 0;
 	const unsigned grid = (unsigned)((T + RXK_DEC_SPAN - 1) / RXK_DEC_SPAN);
 	const unsigned magic = (unsigned)((1ull << 32) / (unsigned)ds + 1);
+	/* floor(q / ds) = (q << 8) * magic24 >> 32 is exact while q * ds < 2^24; q <= span + 4 + ds */
+	const unsigned magic24 = ((u64)(RXK_DEC_SPAN + 4 + ds) * (u64)ds < (1ull << 24)) ? (1u << 24) / (unsigned)ds + 1 : 0u;
 	const unsigned slot_cap = (RXK_DEC_SPAN + ds) / ds + 4;
 	const size_t shm = (size_t)(slot_cap + 4) * sizeof(uint32_t);
 	hipStream_t s = (hipStream_t)stream;
 	const u32x4 *p = (const u32x4 *)iq;
+#define GO3(PS, RT, DC, D24) hipLaunchKernelGGL((k_fm_decimate<PS, RT, DC, D24>), dim3(grid), dim3(DEC_THREADS), shm, s, p, T, ds, p0, \
+		magic, magic24, lp_raw, head, tail, slot_cap, lp_sparse, pcm)
 #define GO(PS, RT) do { \
-		if (pcm) hipLaunchKernelGGL((k_fm_decimate<PS, RT, true>), dim3(grid), dim3(DEC_THREADS), shm, s, p, T, ds, p0, magic, lp_raw, head, tail, slot_cap, pcm); \
-		else hipLaunchKernelGGL((k_fm_decimate<PS, RT, false>), dim3(grid), dim3(DEC_THREADS), shm, s, p, T, ds, p0, magic, lp_raw, head, tail, slot_cap, pcm); } while (0)
+		if (pcm) { if (magic24) GO3(PS, RT, true, true); else GO3(PS, RT, true, false); } \
+		else { if (magic24) GO3(PS, RT, false, true); else GO3(PS, RT, false, false); } } while (0)
 	if (prescaled) GO(true, false);
 	else if (rotate) GO(false, true);
 	else GO(false, false);
 #undef GO
+#undef GO3
 	LAUNCH_RET();
 }
 
@@ -1498,8 +1606,10 @@ extern "C" int rxk_fm_decimate_generic(void *stream, const int16_t *iq, u64 T, i
 extern "C" int rxk_fm_disc(void *stream, const int16_t *iq, u64 T, int ds, int p0, u64 n_per_block, int prescaled,
                            int rotate, int seams, const uint32_t *lp_raw, const uint32_t *head, const uint32_t *tail,
                            uint32_t *lp, u64 M, int first_mode, u64 uniform_k, int custom_atan, int do_tail,
-                           int16_t *pcm, rxk_fm_dev *dev, u64 *flag_list, int sparse, u64 n_blocks, const int *atan_lut)
+                           int16_t *pcm, rxk_fm_dev *dev, u64 *flag_list, int sparse, u64 n_blocks, const int *atan_lut, int lp_sparse)
 {
+	if (!sparse || !seams)
+		lp_sparse = 0;
 	const u64 n_wg = (T + RXK_DEC_SPAN - 1) / RXK_DEC_SPAN;
 	const unsigned out_blocks = sparse ? (unsigned)((2 * n_wg + n_blocks + 1 + 255) / 256) : (unsigned)((M + 255) / 256);
 	const unsigned grid = out_blocks + (do_tail ? 1 : 0);
@@ -1508,10 +1618,10 @@ extern "C" int rxk_fm_disc(void *stream, const int16_t *iq, u64 T, int ds, int p
 	hipStream_t s = (hipStream_t)stream;
 	if (prescaled)
 		hipLaunchKernelGGL((k_fm_disc<true>), dim3(grid), dim3(256), 0, s, (const uint32_t *)iq, T, ds, p0, n_per_block, 0, seams,
-		                   lp_raw, head, tail, lp, M, first_mode, uniform_k, custom_atan, do_tail, pcm, dev, flag_list, out_blocks, sparse, n_wg, n_blocks, atan_lut);
+		                   lp_raw, head, tail, lp, M, first_mode, uniform_k, custom_atan, do_tail, pcm, dev, flag_list, out_blocks, sparse, n_wg, n_blocks, atan_lut, lp_sparse);
 	else
 		hipLaunchKernelGGL((k_fm_disc<false>), dim3(grid), dim3(256), 0, s, (const uint32_t *)iq, T, ds, p0, n_per_block, rotate, seams,
-		                   lp_raw, head, tail, lp, M, first_mode, uniform_k, custom_atan, do_tail, pcm, dev, flag_list, out_blocks, sparse, n_wg, n_blocks, atan_lut);
+		                   lp_raw, head, tail, lp, M, first_mode, uniform_k, custom_atan, do_tail, pcm, dev, flag_list, out_blocks, sparse, n_wg, n_blocks, atan_lut, lp_sparse);
 	LAUNCH_RET();
 }
 

@@ -54,9 +54,12 @@ enum { RXK_FIRST_LOWPASS = 0, RXK_FIRST_UNIFORM = 1 };
  * boxcar sums.  T complex samples (T % 4 == 0), 4 <= ds <= RXK_DEC_MAX_DS.
  * lp_raw[m] valid for outputs completed strictly inside one workgroup span, head/tail
  * hold the per-workgroup partial sums at the seams (packed int16 I | Q<<16, mod 2^16). */
-/* pcm != NULL: also the -A fast discriminator for every output but the first two of each span */
+/* pcm != NULL: also the -A fast discriminator for every output but the first two of each span.
+ * lp_sparse != 0 (with pcm, ds <= RXK_LP_SPARSE_MAX_DS): lowpassed[] is only an intermediate then, and only the
+ * entries rxk_fm_disc(sparse) will read are stored (the second and the last output of every span). */
+#define RXK_LP_SPARSE_MAX_DS 512
 int rxk_fm_decimate(void *stream, const int16_t *iq, unsigned long long T, int ds, int p0,
-                    int prescaled, int rotate, uint32_t *lp_raw, uint32_t *head, uint32_t *tail, int16_t *pcm);
+                    int prescaled, int rotate, uint32_t *lp_raw, uint32_t *head, uint32_t *tail, int lp_sparse, int16_t *pcm);
 
 /* same maths, one thread per output, any ds >= 1 and any block length; writes final lp[] */
 int rxk_fm_decimate_generic(void *stream, const int16_t *iq, unsigned long long T, int ds, int p0,
@@ -71,7 +74,9 @@ int rxk_fm_disc(void *stream, const int16_t *iq, unsigned long long T, int ds, i
                 const uint32_t *lp_raw, const uint32_t *head, const uint32_t *tail,
                 uint32_t *lp, unsigned long long M, int first_mode, unsigned long long uniform_k,
                 int custom_atan, int do_tail, int16_t *pcm, rxk_fm_dev *dev, unsigned long long *flag_list,
-                int sparse, unsigned long long n_blocks, const int *atan_lut);
+                int sparse, unsigned long long n_blocks, const int *atan_lut, int lp_sparse);
+/* lp_sparse: lp_raw[] holds only what rxk_fm_decimate(lp_sparse) stored; any other window this kernel needs (a
+ * block's first output and its predecessor, the last two outputs) is summed again from iq and stored into lp[] */
 /* pcm == NULL: only finish lp[] (+ the low_pass carry); the discriminator runs later on the final lp[] */
 /* sparse != 0 (after rxk_fm_decimate with pcm): only the two seam outputs of every span, each block's
  * first (libm) output and the last output are processed */

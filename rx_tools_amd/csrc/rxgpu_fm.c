@@ -470,6 +470,9 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks,
 	const int split = p->squelch_level != 0 || p->mode != RXGPU_MODE_FM;
 	if (!g->passes) {
 		const int fused_disc = g->fast && p->custom_atan == 1 && !split;
+		/* lowpassed[] is an intermediate of the fused chain: keep only the entries the seam kernel reads
+		 * (the drop-in, which must hand lowpassed[] back, runs prescaled) */
+		const int lp_sparse = fused_disc && !p->prescaled && g->ds <= RXK_LP_SPARSE_MAX_DS;
 		if (g->fast) {
 			s->pcm = s->pcm_buf[db];
 			s->lp_final = s->lp_raw[db];
@@ -478,7 +481,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks,
 				RX_HIP(hipStreamWaitEvent(sa, s->ev_small[db], 0));
 			rxgpu_prof_begin_on("fm_decimate", sa);
 			RX_K(rxk_fm_decimate(sa, d_iq, g->T, g->ds, g->p0, p->prescaled, g->rotate, s->lp_raw[db], s->head[db], s->tail[db],
-			                     fused_disc ? s->pcm : NULL));
+			                     lp_sparse, fused_disc ? s->pcm : NULL));
 			rxgpu_prof_end_on("fm_decimate", sa);
 			RX_HIP(hipEventRecord(s->ev_dec[db], sa));
 			RX_HIP(hipStreamWaitEvent(sb, s->ev_dec[db], 0));
@@ -491,7 +494,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks,
 		/* fast path: lp_raw is finished in place (only seam entries change) and becomes the final decimated IQ */
 		RX_K(rxk_fm_disc(sb, d_iq, g->T, g->ds, g->p0, g->n, p->prescaled, g->rotate, g->fast, g->fast ? s->lp_raw[db] : s->lp,
 		                 s->head[db], s->tail[db], g->fast ? s->lp_raw[db] : s->lp, g->M, RXK_FIRST_LOWPASS, 0, p->custom_atan, 1,
-		                 split ? NULL : s->pcm, s->dev, s->flag_list, fused_disc, n_blocks, s->atan_lut));
+		                 split ? NULL : s->pcm, s->dev, s->flag_list, fused_disc, n_blocks, s->atan_lut, g->fast ? lp_sparse : 0));
 		rxgpu_prof_end_on("fm_disc", sb);
 	} else {
 		/* F3: cascade (first passes fused where the input is raw), F12 optional; all on stream B */
@@ -542,7 +545,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks,
 		if (!split) {
 			rxgpu_prof_begin_on("fm_disc", sb);
 			RX_K(rxk_fm_disc(sb, d_iq, g->T, 1, 0, g->n, p->prescaled, g->rotate, 0, s->lp_final, NULL, NULL, NULL, g->M,
-			                 RXK_FIRST_UNIFORM, g->K, p->custom_atan, 0, s->pcm, s->dev, s->flag_list, 0, n_blocks, s->atan_lut));
+			                 RXK_FIRST_UNIFORM, g->K, p->custom_atan, 0, s->pcm, s->dev, s->flag_list, 0, n_blocks, s->atan_lut, 0));
 			rxgpu_prof_end_on("fm_disc", sb);
 		}
 	}
@@ -554,7 +557,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks,
 		if (p->mode == RXGPU_MODE_FM) {
 			rxgpu_prof_begin_on("fm_disc", sb);
 			RX_K(rxk_fm_disc(sb, d_iq, g->T, g->ds, g->p0, g->n, p->prescaled, g->rotate, 0, lpw, NULL, NULL, NULL, g->M,
-			                 s->blk.first_mode, g->K, p->custom_atan, 0, s->pcm, s->dev, s->flag_list, 0, n_blocks, s->atan_lut));
+			                 s->blk.first_mode, g->K, p->custom_atan, 0, s->pcm, s->dev, s->flag_list, 0, n_blocks, s->atan_lut, 0));
 			rxgpu_prof_end_on("fm_disc", sb);
 		} else if (p->mode == RXGPU_MODE_RAW) {
 			RX_HIP(hipMemcpyAsync(d_out, lpw, g->M * 4, hipMemcpyDeviceToDevice, sb));
