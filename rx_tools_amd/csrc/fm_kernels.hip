@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void k_fm_disc(
 	const uint32_t *lp_raw, const uint32_t *__restrict__ head, const uint32_t *__restrict__ tail,
 	uint32_t *lp /* may alias lp_raw: seam entries are finished in place */, u64 M, int first_mode, u64 uniform_k, int custom_atan, int do_tail,
 	int16_t *__restrict__ pcm, rxk_fm_dev *__restrict__ dev, u64 *__restrict__ flag_list, unsigned out_blocks,
-	int sparse, u64 n_wg, u64 n_blocks, const int *__restrict__ atan_lut, int lp_sparse)
+	int sparse, u64 n_wg, u64 n_blocks, const int *__restrict__ atan_lut, int lp_sparse, int flag_all)
 {
 	if (blockIdx.x >= out_blocks) {
 		// ---- low_pass carry: exact int32 sums of the samples after the last complete window
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256) void k_fm_disc(
 		const double ang = atan2((double)cj, (double)cr);
 		const double v = ang / 3.14159 * 16384.0;
 		out = (int)v;
-		if (v != 0.0 && fabs(v - rint(v)) < 1e-6) {
+		if (v != 0.0 && (flag_all || fabs(v - rint(v)) < 1e-6)) {
 			const int idx = atomicAdd(&dev->flag_cnt, 1);
 			if (idx < RXK_FLAG_CAP)
 				flag_list[idx] = m;
@@ -1606,7 +1606,7 @@ extern "C" int rxk_fm_decimate_generic(void *stream, const int16_t *iq, u64 T, i
 extern "C" int rxk_fm_disc(void *stream, const int16_t *iq, u64 T, int ds, int p0, u64 n_per_block, int prescaled,
                            int rotate, int seams, const uint32_t *lp_raw, const uint32_t *head, const uint32_t *tail,
                            uint32_t *lp, u64 M, int first_mode, u64 uniform_k, int custom_atan, int do_tail,
-                           int16_t *pcm, rxk_fm_dev *dev, u64 *flag_list, int sparse, u64 n_blocks, const int *atan_lut, int lp_sparse)
+                           int16_t *pcm, rxk_fm_dev *dev, u64 *flag_list, int sparse, u64 n_blocks, const int *atan_lut, int lp_sparse, int flag_all)
 {
 	if (!sparse || !seams)
 		lp_sparse = 0;
@@ -1618,10 +1618,10 @@ extern "C" int rxk_fm_disc(void *stream, const int16_t *iq, u64 T, int ds, int p
 	hipStream_t s = (hipStream_t)stream;
 	if (prescaled)
 		hipLaunchKernelGGL((k_fm_disc<true>), dim3(grid), dim3(256), 0, s, (const uint32_t *)iq, T, ds, p0, n_per_block, 0, seams,
-		                   lp_raw, head, tail, lp, M, first_mode, uniform_k, custom_atan, do_tail, pcm, dev, flag_list, out_blocks, sparse, n_wg, n_blocks, atan_lut, lp_sparse);
+		                   lp_raw, head, tail, lp, M, first_mode, uniform_k, custom_atan, do_tail, pcm, dev, flag_list, out_blocks, sparse, n_wg, n_blocks, atan_lut, lp_sparse, flag_all);
 	else
 		hipLaunchKernelGGL((k_fm_disc<false>), dim3(grid), dim3(256), 0, s, (const uint32_t *)iq, T, ds, p0, n_per_block, rotate, seams,
-		                   lp_raw, head, tail, lp, M, first_mode, uniform_k, custom_atan, do_tail, pcm, dev, flag_list, out_blocks, sparse, n_wg, n_blocks, atan_lut, lp_sparse);
+		                   lp_raw, head, tail, lp, M, first_mode, uniform_k, custom_atan, do_tail, pcm, dev, flag_list, out_blocks, sparse, n_wg, n_blocks, atan_lut, lp_sparse, flag_all);
 	LAUNCH_RET();
 }
 

@@ -74,7 +74,8 @@ int rxk_fm_disc(void *stream, const int16_t *iq, unsigned long long T, int ds, i
                 const uint32_t *lp_raw, const uint32_t *head, const uint32_t *tail,
                 uint32_t *lp, unsigned long long M, int first_mode, unsigned long long uniform_k,
                 int custom_atan, int do_tail, int16_t *pcm, rxk_fm_dev *dev, unsigned long long *flag_list,
-                int sparse, unsigned long long n_blocks, const int *atan_lut, int lp_sparse);
+                int sparse, unsigned long long n_blocks, const int *atan_lut, int lp_sparse, int flag_all);
+/* flag_all: report EVERY libm sample as undecided (test hook: the host then re-evaluates all of them) */
 /* lp_sparse: lp_raw[] holds only what rxk_fm_decimate(lp_sparse) stored; any other window this kernel needs (a
  * block's first output and its predecessor, the last two outputs) is summed again from iq and stored into lp[] */
 /* pcm == NULL: only finish lp[] (+ the low_pass carry); the discriminator runs later on the final lp[] */

@@ -58,6 +58,7 @@ struct rxgpu_fm_stream {
 	int group, warm, lo0, hi0;
 	int chunk;                           /* de-emphasis scan: samples per chunk */
 	int topcap_override;                 /* $RXGPU_DEEMPH_TOPCAP: forces the multi-level scan (tests) */
+	int flag_all;                        /* $RXGPU_FLAG_ALL: every libm discriminator sample goes through the host re-evaluation (tests) */
 	long fixups;
 	/* pipelining state */
 	hipEvent_t ev_dec[2], ev_small[2];
@@ -161,6 +162,8 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 	{
 		const char *e = getenv("RXGPU_DEEMPH_TOPCAP");
 		s->topcap_override = (e && atoi(e) > 0) ? atoi(e) : 0;
+		e = getenv("RXGPU_FLAG_ALL");
+		s->flag_all = (e && atoi(e) > 0) ? 1 : 0;
 	}
 	s->max_blocks = max_blocks;
 	s->block_len = block_len;
@@ -494,7 +497,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks,
 		/* fast path: lp_raw is finished in place (only seam entries change) and becomes the final decimated IQ */
 		RX_K(rxk_fm_disc(sb, d_iq, g->T, g->ds, g->p0, g->n, p->prescaled, g->rotate, g->fast, g->fast ? s->lp_raw[db] : s->lp,
 		                 s->head[db], s->tail[db], g->fast ? s->lp_raw[db] : s->lp, g->M, RXK_FIRST_LOWPASS, 0, p->custom_atan, 1,
-		                 split ? NULL : s->pcm, s->dev, s->flag_list, fused_disc, n_blocks, s->atan_lut, g->fast ? lp_sparse : 0));
+		                 split ? NULL : s->pcm, s->dev, s->flag_list, fused_disc, n_blocks, s->atan_lut, g->fast ? lp_sparse : 0, s->flag_all));
 		rxgpu_prof_end_on("fm_disc", sb);
 	} else {
 		/* F3: cascade (first passes fused where the input is raw), F12 optional; all on stream B */
@@ -545,7 +548,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks,
 		if (!split) {
 			rxgpu_prof_begin_on("fm_disc", sb);
 			RX_K(rxk_fm_disc(sb, d_iq, g->T, 1, 0, g->n, p->prescaled, g->rotate, 0, s->lp_final, NULL, NULL, NULL, g->M,
-			                 RXK_FIRST_UNIFORM, g->K, p->custom_atan, 0, s->pcm, s->dev, s->flag_list, 0, n_blocks, s->atan_lut, 0));
+			                 RXK_FIRST_UNIFORM, g->K, p->custom_atan, 0, s->pcm, s->dev, s->flag_list, 0, n_blocks, s->atan_lut, 0, s->flag_all));
 			rxgpu_prof_end_on("fm_disc", sb);
 		}
 	}
@@ -557,7 +560,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks,
 		if (p->mode == RXGPU_MODE_FM) {
 			rxgpu_prof_begin_on("fm_disc", sb);
 			RX_K(rxk_fm_disc(sb, d_iq, g->T, g->ds, g->p0, g->n, p->prescaled, g->rotate, 0, lpw, NULL, NULL, NULL, g->M,
-			                 s->blk.first_mode, g->K, p->custom_atan, 0, s->pcm, s->dev, s->flag_list, 0, n_blocks, s->atan_lut, 0));
+			                 s->blk.first_mode, g->K, p->custom_atan, 0, s->pcm, s->dev, s->flag_list, 0, n_blocks, s->atan_lut, 0, s->flag_all));
 			rxgpu_prof_end_on("fm_disc", sb);
 		} else if (p->mode == RXGPU_MODE_RAW) {
 			RX_HIP(hipMemcpyAsync(d_out, lpw, g->M * 4, hipMemcpyDeviceToDevice, sb));

@@ -131,6 +131,23 @@ def test_fifth_order_carry_across_runs():
     _check(iq, 16384, n_runs=3, downsample_passes=3, comp_fir_size=9)
 
 
+@pytest.mark.parametrize("ds,block_len,std", [(118, 16384, 0), (118, 2 * 131072, 0), (6, 4096 + 8, 0), (20, 2 * 5000, 0), (118, 16384, 1)])
+def test_host_reevaluation_of_libm_samples(ds, block_len, std, monkeypatch):
+    """RXGPU_FLAG_ALL reports every libm discriminator sample as undecided, so each one is re-evaluated by the host
+    (polar_discriminant with glibc's atan2) from the stored lowpassed[] pair and the audio stages are redone:
+    same output, and the fix-up path -- incl. the windows the seam kernel sums again when lowpassed[] is kept
+    sparse -- is exercised"""
+    from gpu_support import gpu_fm_stream
+    monkeypatch.setenv("RXGPU_FLAG_ALL", "1")
+    n_blocks = 4 if block_len > 100000 else 12
+    iq = sig_fm(n_blocks * block_len // 2, seed=31)
+    params = dict(downsample=ds, custom_atan=0 if std else 1)
+    want, want_lens, st = oracle_fm_stream(iq, block_len, **params)
+    got, got_lens, carry, fixups = gpu_fm_stream(iq, block_len, **params)
+    assert np.array_equal(got, want)
+    assert fixups >= n_blocks - 1                       # an exactly zero angle is never flagged
+
+
 @pytest.mark.parametrize("topcap", ["1", "3"])
 def test_deemph_multi_level_tree(topcap, monkeypatch):
     """forces the up/down levels of the de-emphasis tree scan (normally only for >4M audio samples)"""
