@@ -355,22 +355,36 @@ template <bool PRESCALED>
 __device__ __forceinline__ uint32_t lp_brute(const uint32_t *iq, u64 m, int ds, int p0, u64 n_per_block, int rotate)
 {
 	const u64 start = m * (u64)ds - (u64)p0;
-	u64 inblk = start % n_per_block;
 	int si = 0, sq = 0;
-	for (u64 pos = start; pos < start + (u64)ds; pos++) {
+#pragma unroll 8
+	for (int i = 0; i < ds; i++) {                            // independent loads: eight in flight
 		int ri, rq;
-		load_rot<PRESCALED>(iq, pos, rotate ? (unsigned)inblk : 0u, ri, rq);
+		// the fast decimator only takes blocks of a multiple of 4 samples, so the rotation phase (position in the
+		// block, rtl_fm.c:315) is the stream position mod 4
+		load_rot<PRESCALED>(iq, start + (u64)i, rotate ? (unsigned)(start + (u64)i) : 0u, ri, rq);
 		si += ri; sq += rq;
-		if (++inblk == n_per_block) inblk = 0;
 	}
 	return pack_iq(si, sq);
 }
 
-// stored != 0: lp_raw[m] is known to have been written; otherwise (lp_sparse) the window is summed again
+// Is window m one of the two entries per span that rxk_fm_decimate(lp_sparse) stored -- the second window ending in
+// its span, or the last one?  (The first is in head/tail form, handled before this is asked.)
+__device__ __forceinline__ bool lp_sparse_stored(u64 m, int ds, int p0, u64 M)
+{
+	const u64 e1 = (m + 1) * (u64)ds - (u64)p0 - 1;                   // last sample of the window
+	const u64 g = e1 >> RXK_DEC_SPAN_LOG2;
+	const u64 m_g = ((g << RXK_DEC_SPAN_LOG2) + (u64)p0) / (u64)ds;   // the window holding the span's first sample
+	u64 m_next = (((g + 1) << RXK_DEC_SPAN_LOG2) + (u64)p0) / (u64)ds;
+	if (m_next > M)
+		m_next = M;
+	return m == m_g + 1 || m + 1 == m_next;
+}
+
+// stored: lp_raw[m] is known to have been written (< 0: find out); otherwise (lp_sparse) the window is summed again
 template <bool PRESCALED>
 __device__ __forceinline__ uint32_t lp_final(u64 m, int ds, int p0, int seams, const uint32_t *lp_raw,
                                              const uint32_t *head, const uint32_t *tail, uint32_t carry,
-                                             int stored, const uint32_t *iq, u64 n_per_block, int rotate, bool *brute)
+                                             int stored, u64 M, const uint32_t *iq, u64 n_per_block, int rotate, bool *brute)
 {
 	*brute = false;
 	if (!seams)
@@ -382,7 +396,7 @@ __device__ __forceinline__ uint32_t lp_final(u64 m, int ds, int p0, int seams, c
 	const u64 g = ((u64)(w0 + ds - 1)) >> RXK_DEC_SPAN_LOG2;
 	if (w0 <= (i64)(g << RXK_DEC_SPAN_LOG2))
 		return pk_add(g ? tail[g - 1] : carry, head[g]);
-	if (stored)
+	if (stored > 0 || (stored < 0 && lp_sparse_stored(m, ds, p0, M)))
 		return lp_raw[m];
 	*brute = true;
 	return lp_brute<PRESCALED>(iq, m, ds, p0, n_per_block, rotate);
@@ -421,7 +435,7 @@ __global__ __launch_bounds__(256) void k_fm_disc(
 		return;
 	}
 	u64 m = (u64)blockIdx.x * 256 + threadIdx.x;
-	int a_stored = !lp_sparse, b_stored = !lp_sparse;    // lp_sparse: only a span's second and last outputs are in lp_raw
+	int a_stored = lp_sparse ? -1 : 1, b_stored = a_stored;  // lp_sparse: only a span's second and last outputs are in lp_raw (-1: look)
 	if (sparse) {
 		// only what k_fm_decimate<DISC> could not finish: the first two windows ending in each
 		// workgroup span, the first window of each callback block (libm), and the very last one (carry)
@@ -445,7 +459,7 @@ __global__ __launch_bounds__(256) void k_fm_disc(
 		return;
 	const uint32_t carry = pack_iq(dev->in_now_r, dev->in_now_j);
 	bool brute;
-	const uint32_t a = lp_final<PRESCALED>(m, ds, p0, seams, lp_raw, head, tail, carry, a_stored, iq, n_per_block, rotate, &brute);
+	const uint32_t a = lp_final<PRESCALED>(m, ds, p0, seams, lp_raw, head, tail, carry, a_stored, M, iq, n_per_block, rotate, &brute);
 	if (seams)
 		lp[m] = a;
 	if (!pcm) {                                  // lp_only: squelch / another demodulator comes next
@@ -454,7 +468,7 @@ __global__ __launch_bounds__(256) void k_fm_disc(
 	}
 	int br, bj;
 	if (m) {
-		const uint32_t b = lp_final<PRESCALED>(m - 1, ds, p0, seams, lp_raw, head, tail, carry, b_stored, iq, n_per_block, rotate, &brute);
+		const uint32_t b = lp_final<PRESCALED>(m - 1, ds, p0, seams, lp_raw, head, tail, carry, b_stored, M, iq, n_per_block, rotate, &brute);
 		if (brute)
 			lp[m - 1] = b;                           // the host re-reads both for a flagged libm sample
 		br = lo16(b); bj = hi16(b);
