@@ -792,75 +792,93 @@ __device__ __forceinline__ void deemph_stage(const int16_t *__restrict__ pcm, u6
 	}
 }
 
+#define DEEMPH_WG_CHUNKS 64          // chunks per workgroup of scan/apply = fan of the first tree level
+
 template <int GS, bool EVEN, bool D24>
 __global__ __launch_bounds__(64) void k_fm_deemph_scan(
 	const int16_t *__restrict__ pcm, u64 M, int a, unsigned magic, int bias, int chunk_l2, int warm, int lo0, int hi0,
-	int *__restrict__ tab, int *__restrict__ lo_arr, int *__restrict__ gap_arr, rxk_fm_dev *__restrict__ dev)
+	int *__restrict__ pre, int *__restrict__ p_tab, int *__restrict__ p_lo, int *__restrict__ p_gap,
+	rxk_fm_dev *__restrict__ dev)
 {
 	extern __shared__ uint4 de_lds[];
 	const int lane = threadIdx.x, chunk = 1 << chunk_l2, row_u = chunk / 8 + 1;
+	int *ltab = reinterpret_cast<int *>(de_lds + 65 * row_u);        // this workgroup's 64 chunk tables, then lo and gap
+	int *llo = ltab + 64 * GS, *lgap = llo + 64;
 	const u64 n_chunks = (M + chunk - 1) >> chunk_l2;
 	const u64 first = (u64)blockIdx.x * 64;
 	deemph_stage(pcm, M, chunk_l2, warm, first, de_lds, lane);
 	__syncthreads();
 	const u64 c = first + lane;
-	if (c >= n_chunks)
-		return;
-	const u64 c0 = c << chunk_l2;
-	const int n = (int)((M - c0) < (u64)chunk ? (M - c0) : (u64)chunk);
-	const int xoff = a / 2 + bias * a;
-	int lo, hi;
-	if (c == 0) {                                     // the run's carried state (warm <= chunk/2)
-		lo = hi = dev->in_deemph_avg;
-	} else {
-		lo = lo0;
-		hi = hi0;
-		const uint4 *row = de_lds + lane * row_u;
-		uint4 w = row[(chunk - warm) >> 3];
-		for (int u = (chunk - warm) >> 3; u < (chunk >> 3); u++) {
+	if (c < n_chunks) {
+		const u64 c0 = c << chunk_l2;
+		const int n = (int)((M - c0) < (u64)chunk ? (M - c0) : (u64)chunk);
+		const int xoff = a / 2 + bias * a;
+		int lo, hi;
+		if (c == 0) {                                     // the run's carried state (warm <= chunk/2)
+			lo = hi = dev->in_deemph_avg;
+		} else {
+			lo = lo0;
+			hi = hi0;
+			const uint4 *row = de_lds + lane * row_u;
+			uint4 w = row[(chunk - warm) >> 3];
+			for (int u = (chunk - warm) >> 3; u < (chunk >> 3); u++) {
+				const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+				w = row[u + 1];
+#pragma unroll
+				for (int k = 0; k < 8; k++) {
+					const int x = (k & 1) ? hi16(ww[k >> 1]) : lo16(ww[k >> 1]);
+					lo = deemph_step_d<EVEN, D24>(lo, x + xoff, x, magic, bias);
+					hi = deemph_step_d<EVEN, D24>(hi, x + xoff, x, magic, bias);
+				}
+			}
+		}
+		int gap = hi - lo;
+		if (gap >= GS) {                                  // excluded by `warm` (rxgpu_fm.c); checked anyway
+			atomicExch(&dev->err, 1);
+			gap = GS - 1;
+		}
+		typedef typename deemph_mask<GS>::type MASK;
+		const int lo_start = lo;
+		int cnt = gap + 1;                                // a lone candidate never passes the merge test: no special case
+		MASK mask = (MASK)(((MASK)1 << gap) - 1);
+		const uint4 *row = de_lds + (lane + 1) * row_u;
+		const int nu = n >> 3;
+		uint4 w = row[0];
+		for (int u = 0; u < nu; u++) {
 			const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-			w = row[u + 1];
+			w = row[u + 1];                               // next unit (the pad unit after the last) while this one is walked
 #pragma unroll
 			for (int k = 0; k < 8; k++) {
 				const int x = (k & 1) ? hi16(ww[k >> 1]) : lo16(ww[k >> 1]);
-				lo = deemph_step_d<EVEN, D24>(lo, x + xoff, x, magic, bias);
-				hi = deemph_step_d<EVEN, D24>(hi, x + xoff, x, magic, bias);
+				deemph_track<EVEN, D24>(lo, cnt, mask, x, a, xoff, magic, bias);
 			}
 		}
-	}
-	int gap = hi - lo;
-	if (gap >= GS) {                                  // excluded by `warm` (rxgpu_fm.c); checked anyway
-		atomicExch(&dev->err, 1);
-		gap = GS - 1;
-	}
-	typedef typename deemph_mask<GS>::type MASK;
-	const int lo_start = lo;
-	int cnt = gap + 1;                                // a lone candidate never passes the merge test: no special case
-	MASK mask = (MASK)(((MASK)1 << gap) - 1);
-	const uint4 *row = de_lds + (lane + 1) * row_u;
-	const int nu = n >> 3;
-	uint4 w = row[0];
-	for (int u = 0; u < nu; u++) {
-		const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-		w = row[u + 1];                               // next unit (the pad unit after the last) while this one is walked
-#pragma unroll
-		for (int k = 0; k < 8; k++) {
-			const int x = (k & 1) ? hi16(ww[k >> 1]) : lo16(ww[k >> 1]);
-			deemph_track<EVEN, D24>(lo, cnt, mask, x, a, xoff, magic, bias);
+		if (n & 7) {                                      // the ragged end of the run
+			const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+			for (int k = 0; k < (n & 7); k++) {
+				const int x = (k & 1) ? hi16(ww[k >> 1]) : lo16(ww[k >> 1]);
+				deemph_track<EVEN, D24>(lo, cnt, mask, x, a, xoff, magic, bias);
+			}
 		}
+		for (int k = 0; k <= gap; k++)
+			ltab[lane * GS + k] = lo + deemph_popc((MASK)(mask & (MASK)(((MASK)1 << k) - 1)));
+		llo[lane] = lo_start;
+		lgap[lane] = gap;
 	}
-	if (n & 7) {                                      // the ragged end of the run
-		const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-		for (int k = 0; k < (n & 7); k++) {
-			const int x = (k & 1) ? hi16(ww[k >> 1]) : lo16(ww[k >> 1]);
-			deemph_track<EVEN, D24>(lo, cnt, mask, x, a, xoff, magic, bias);
+	__syncthreads();
+	// first tree level: the composite of this workgroup's chunk tables, one lane per candidate of the first chunk;
+	// on the way, every chunk's start state for each of those candidates (k_fm_deemph_apply picks one)
+	const int nc = (int)((n_chunks - first) < 64 ? (n_chunks - first) : 64);
+	for (int k = lane; k < GS; k += 64) {
+		const int g0 = lgap[0];
+		int v = llo[0] + (k < g0 ? k : g0);
+		for (int i = 0; i < nc; i++) {
+			pre[(first + i) * GS + k] = v;
+			v = ltab[i * GS + (v - llo[i])];
 		}
+		p_tab[(u64)blockIdx.x * GS + k] = v;
+		if (k == 0) { p_lo[blockIdx.x] = llo[0]; p_gap[blockIdx.x] = g0; }
 	}
-	int *t = tab + c * GS;
-	for (int k = 0; k <= gap; k++)
-		t[k] = lo + deemph_popc((MASK)(mask & (MASK)(((MASK)1 << k) - 1)));
-	lo_arr[c] = lo_start;
-	gap_arr[c] = gap;
 }
 
 // one thread group of gs lanes per parent table: walk DEEMPH_FAN children (global, dependent)
@@ -948,13 +966,14 @@ __global__ void k_fm_deemph_down(u64 n_child, int gs, const int *__restrict__ ta
 // one lane per chunk, written back coalesced
 template <bool EVEN, bool D24>
 __global__ __launch_bounds__(64) void k_fm_deemph_apply(
-	const int16_t *__restrict__ pcm, u64 M, int a, unsigned magic, int bias, int chunk_l2,
-	const int *__restrict__ start, int16_t *__restrict__ y)
+	const int16_t *__restrict__ pcm, u64 M, int a, unsigned magic, int bias, int chunk_l2, int gs,
+	const int *__restrict__ pre, const int *__restrict__ p_lo, const int *__restrict__ p_start, int16_t *__restrict__ y)
 {
 	extern __shared__ uint4 de_lds[];
 	const int lane = threadIdx.x, chunk = 1 << chunk_l2, row_u = chunk / 8 + 1;
 	const u64 n_chunks = (M + chunk - 1) >> chunk_l2;
 	const u64 first = (u64)blockIdx.x * 64;
+	const int cand = p_start[blockIdx.x] - p_lo[blockIdx.x];         // which candidate of the workgroup's first chunk was the true state
 	deemph_stage(pcm, M, chunk_l2, 0, first, de_lds, lane);
 	__syncthreads();
 	const u64 c = first + lane;
@@ -962,7 +981,7 @@ __global__ __launch_bounds__(64) void k_fm_deemph_apply(
 		const u64 c0 = c << chunk_l2;
 		const int n = (int)((M - c0) < (u64)chunk ? (M - c0) : (u64)chunk);
 		const int xoff = a / 2 + bias * a;
-		int s = start[c];
+		int s = pre[c * gs + cand];
 		uint4 *row = de_lds + (lane + 1) * row_u;
 		for (int u = 0; u * 8 < n; u++) {               // past-the-end samples of the last unit are never stored
 			const uint4 w = row[u];
@@ -1655,19 +1674,19 @@ static void deemph_lds_attr(K kernel, size_t lds)
 }
 
 extern "C" int rxk_fm_deemph_scan(void *stream, const int16_t *pcm, u64 M, int a, int group, int chunk, int warm,
-                                  int lo0, int hi0, int *tab, int *lo_arr, int *gap_arr, rxk_fm_dev *dev)
+                                  int lo0, int hi0, int *pre, int *p_tab, int *p_lo, int *p_gap, rxk_fm_dev *dev)
 {
 	if (!M)
 		return 0;
 	const u64 n_chunks = (M + chunk - 1) / chunk;
 	const unsigned grid = (unsigned)((n_chunks + 63) / 64);
-	const size_t lds = 65 * (size_t)(chunk / 8 + 1) * 16;
+	const size_t lds = 65 * (size_t)(chunk / 8 + 1) * 16 + (size_t)(64 * group + 128) * 4;
 	hipStream_t s = (hipStream_t)stream;
 	const unsigned mg = deemph_magic(a);
 	const int bias = bias_for(a), l2 = ilog2(chunk);
 #define GO(GS, EV, D) do { deemph_lds_attr(k_fm_deemph_scan<GS, EV, D>, lds); \
 		hipLaunchKernelGGL((k_fm_deemph_scan<GS, EV, D>), dim3(grid), dim3(64), lds, s, pcm, M, a, mg, bias, l2, warm, \
-		                   lo0, hi0, tab, lo_arr, gap_arr, dev); } while (0)
+		                   lo0, hi0, pre, p_tab, p_lo, p_gap, dev); } while (0)
 	if (group == 16) {
 		if (deemph_d24(a)) { if (a & 1) GO(16, false, true); else GO(16, true, true); }
 		else { if (a & 1) GO(16, false, false); else GO(16, true, false); }
@@ -1713,7 +1732,8 @@ extern "C" int rxk_fm_deemph_down(void *stream, u64 n_child, int group, const in
 	LAUNCH_RET();
 }
 
-extern "C" int rxk_fm_deemph_apply(void *stream, const int16_t *pcm, u64 M, int a, int chunk, const int *start, int16_t *y)
+extern "C" int rxk_fm_deemph_apply(void *stream, const int16_t *pcm, u64 M, int a, int group, int chunk, const int *pre,
+                                   const int *p_lo, const int *p_start, int16_t *y)
 {
 	if (!M)
 		return 0;
@@ -1724,7 +1744,7 @@ extern "C" int rxk_fm_deemph_apply(void *stream, const int16_t *pcm, u64 M, int 
 	const unsigned mg = deemph_magic(a);
 	const int bias = bias_for(a), l2 = ilog2(chunk);
 #define GO(EV, D) do { deemph_lds_attr(k_fm_deemph_apply<EV, D>, lds); \
-		hipLaunchKernelGGL((k_fm_deemph_apply<EV, D>), dim3(grid), dim3(64), lds, s, pcm, M, a, mg, bias, l2, start, y); } while (0)
+		hipLaunchKernelGGL((k_fm_deemph_apply<EV, D>), dim3(grid), dim3(64), lds, s, pcm, M, a, mg, bias, l2, group, pre, p_lo, p_start, y); } while (0)
 	if (deemph_d24(a)) { if (a & 1) GO(false, true); else GO(true, true); }
 	else { if (a & 1) GO(false, false); else GO(true, false); }
 #undef GO

@@ -85,17 +85,22 @@ int rxk_fm_disc(void *stream, const int16_t *iq, unsigned long long T, int ds, i
 /* F8 de-emphasis (rtl_fm.c:667-682) as a tree scan over chunk maps (see fm_kernels.hip).
  * group = 16 or 64 candidate lanes; RXK_DEEMPH_FAN tables compose into one per level. */
 #define RXK_DEEMPH_FAN 16
-/* level 0: one table per chunk (chunk % 8 == 0, warm % 8 == 0) */
+/* per workgroup of RXK_DEEMPH_WG_CHUNKS consecutive chunks: the composite of their tables = level 0 of the tree
+ * (p_tab, p_lo, p_gap) and, per chunk, its start state for every candidate of the workgroup's first chunk (pre,
+ * `group` ints per chunk: rxk_fm_deemph_apply picks one); chunk = 2^k >= 256, warm % 8 == 0 */
+#define RXK_DEEMPH_WG_CHUNKS 64
 int rxk_fm_deemph_scan(void *stream, const int16_t *pcm, unsigned long long M, int a, int group,
-                       int chunk, int warm, int lo0, int hi0, int *tab, int *lo_arr, int *gap_arr, rxk_fm_dev *dev);
+                       int chunk, int warm, int lo0, int hi0, int *pre, int *p_tab, int *p_lo, int *p_gap,
+                       rxk_fm_dev *dev);
 int rxk_fm_deemph_up(void *stream, unsigned long long n_child, int group, const int *tab, const int *lo,
                      const int *gap, int *p_tab, int *p_lo, int *p_gap);
 int rxk_fm_deemph_top(void *stream, int n, int group, const int *tab, const int *lo, const int *gap,
                       int *start, rxk_fm_dev *dev);
 int rxk_fm_deemph_down(void *stream, unsigned long long n_child, int group, const int *tab, const int *lo,
                        const int *p_start, int *start);
-int rxk_fm_deemph_apply(void *stream, const int16_t *pcm, unsigned long long M, int a, int chunk,
-                        const int *start, int16_t *y);
+/* p_start: the exact start state of every workgroup of chunks (level 0 of the tree, walked down) */
+int rxk_fm_deemph_apply(void *stream, const int16_t *pcm, unsigned long long M, int a, int group, int chunk,
+                        const int *pre, const int *p_lo, const int *p_start, int16_t *y);
 /* any a, any state: one lane, serial (degenerate fallback, still on the device) */
 int rxk_fm_deemph_serial(void *stream, const int16_t *pcm, unsigned long long M, int a, int16_t *y, rxk_fm_dev *dev);
 

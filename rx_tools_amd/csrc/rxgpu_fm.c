@@ -36,7 +36,8 @@ struct rxgpu_fm_stream {
 	uint32_t *cas[2];                    /* fifth_order ping-pong */
 	uint32_t *seams;                     /* per block: 3 levels x 5 history samples for the fused passes */
 	int16_t *pcm_buf[2], *pcm, *y;       /* pcm: the buffer the run in hand uses (double-buffered like lp_raw) */
-	int *lvl_tab, *lvl_lo, *lvl_gap, *lvl_start;   /* levels >= 1, packed back to back */
+	int *chunk_pre;                                /* per chunk: its start state for each candidate of its workgroup (scan -> apply) */
+	int *lvl_tab, *lvl_lo, *lvl_gap, *lvl_start;   /* tree levels, packed back to back */
 	size_t lvl_cap;
 	unsigned long long *flag_list;
 	int *atan_lut;                       /* -A lut table (rtl_fm.c:515-526), only when custom_atan == 2 */
@@ -193,7 +194,9 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 	DMALLOC(s->pcm_buf[1], s->max_M * 2);
 	s->pcm = s->pcm_buf[0];
 	DMALLOC(s->y, s->max_M * 2);
-	s->lvl_cap = n_chunks + n_chunks / (RXK_DEEMPH_FAN - 1) + 2 * DEEMPH_LEVELS + 2;     /* level 0 + all composites */
+	const size_t n_l0 = n_chunks / RXK_DEEMPH_WG_CHUNKS + 2;
+	s->lvl_cap = n_l0 + n_l0 / (RXK_DEEMPH_FAN - 1) + 2 * DEEMPH_LEVELS + 2;             /* level 0 + all composites */
+	DMALLOC(s->chunk_pre, n_chunks * 64 * 4);
 	DMALLOC(s->lvl_tab, s->lvl_cap * 64 * 4);
 	DMALLOC(s->lvl_lo, s->lvl_cap * 4);
 	DMALLOC(s->lvl_gap, s->lvl_cap * 4);
@@ -250,7 +253,7 @@ void rxgpu_fm_stream_destroy(rxgpu_fm_stream *s)
 	hipFree(s->cas[0]); hipFree(s->cas[1]); hipFree(s->seams);
 	hipFree(s->pcm_buf[0]); hipFree(s->pcm_buf[1]); hipFree(s->y);
 	
-	hipFree(s->lvl_tab); hipFree(s->lvl_lo); hipFree(s->lvl_gap); hipFree(s->lvl_start);
+	hipFree(s->lvl_tab); hipFree(s->lvl_lo); hipFree(s->lvl_gap); hipFree(s->lvl_start); hipFree(s->chunk_pre);
 	hipFree(s->atan_lut); hipFree(s->below); hipFree(s->dc_sums); hipFree(s->dc_avgs);
 	if (s->below_host) hipHostFree(s->below_host);
 	hipFree(s->flag_list); hipFree(s->dev); hipFree(s->hist_dev); hipFree(s->fir_dev);
@@ -307,14 +310,16 @@ static int run_audio_stages(rxgpu_fm_stream *s, hipStream_t st, unsigned long lo
 	if (p->deemph && M) {
 		rxgpu_prof_begin_on("fm_deemph", st);
 		if (s->group) {
-			/* tree scan over chunk maps: level 0 = chunks, level l+1 = composites of RXK_DEEMPH_FAN level-l tables */
+			/* tree scan over chunk maps: level 0 = composites of RXK_DEEMPH_WG_CHUNKS chunk tables (made by the scan
+			 * kernel itself), level l+1 = composites of RXK_DEEMPH_FAN level-l tables */
 			const int g = s->group;
 			unsigned long long cnt[DEEMPH_LEVELS + 1], off[DEEMPH_LEVELS + 1];
 			int top = 0;
-			cnt[0] = (M + s->chunk - 1) / s->chunk;
+			const unsigned long long n_chunks = (M + s->chunk - 1) / s->chunk;
+			cnt[0] = (n_chunks + RXK_DEEMPH_WG_CHUNKS - 1) / RXK_DEEMPH_WG_CHUNKS;
 			off[0] = 0;
 			RX_K(rxk_fm_deemph_scan(st, s->pcm, M, p->deemph_a, g, s->chunk, s->warm, s->lo0, s->hi0,
-			                        s->lvl_tab, s->lvl_lo, s->lvl_gap, s->dev));
+			                        s->chunk_pre, s->lvl_tab, s->lvl_lo, s->lvl_gap, s->dev));
 			const unsigned long long topcap = s->topcap_override ? (unsigned long long)s->topcap_override : (unsigned long long)DEEMPH_TOPCAP(g);
 			while (cnt[top] > topcap) {
 				if (top == DEEMPH_LEVELS)
@@ -330,7 +335,7 @@ static int run_audio_stages(rxgpu_fm_stream *s, hipStream_t st, unsigned long lo
 			for (int l = top; l > 0; l--)
 				RX_K(rxk_fm_deemph_down(st, cnt[l - 1], g, s->lvl_tab + off[l - 1] * g, s->lvl_lo + off[l - 1],
 				                        s->lvl_start + off[l], s->lvl_start + off[l - 1]));
-			RX_K(rxk_fm_deemph_apply(st, s->pcm, M, p->deemph_a, s->chunk, s->lvl_start, deemph_dst));
+			RX_K(rxk_fm_deemph_apply(st, s->pcm, M, p->deemph_a, g, s->chunk, s->chunk_pre, s->lvl_lo, s->lvl_start, deemph_dst));
 		} else {
 			RX_K(rxk_fm_deemph_serial(st, s->pcm, M, p->deemph_a, deemph_dst, s->dev));
 		}
