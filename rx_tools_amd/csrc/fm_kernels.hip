@@ -814,7 +814,7 @@ __global__ __launch_bounds__(64) void k_fm_deemph_scan(
 		const int n = (int)((M - c0) < (u64)chunk ? (M - c0) : (u64)chunk);
 		const int xoff = a / 2 + bias * a;
 		int lo, hi;
-		if (c == 0) {                                     // the run's carried state (warm <= chunk/2)
+		if (c == 0) {                                     // the run's carried state
 			lo = hi = dev->in_deemph_avg;
 		} else {
 			lo = lo0;

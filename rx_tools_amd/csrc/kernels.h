@@ -87,7 +87,7 @@ int rxk_fm_disc(void *stream, const int16_t *iq, unsigned long long T, int ds, i
 #define RXK_DEEMPH_FAN 16
 /* per workgroup of RXK_DEEMPH_WG_CHUNKS consecutive chunks: the composite of their tables = level 0 of the tree
  * (p_tab, p_lo, p_gap) and, per chunk, its start state for every candidate of the workgroup's first chunk (pre,
- * `group` ints per chunk: rxk_fm_deemph_apply picks one); chunk = 2^k >= 256, warm % 8 == 0 */
+ * `group` ints per chunk: rxk_fm_deemph_apply picks one); chunk = 2^k >= max(128, warm), warm % 8 == 0 */
 #define RXK_DEEMPH_WG_CHUNKS 64
 int rxk_fm_deemph_scan(void *stream, const int16_t *pcm, unsigned long long M, int a, int group,
                        int chunk, int warm, int lo0, int hi0, int *pre, int *p_tab, int *p_lo, int *p_gap,

@@ -12,7 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define DEEMPH_CHUNK_MIN 256           /* chunk = power of two >= 2*warm: one lane per chunk, 64 chunks per workgroup */
+#define DEEMPH_CHUNK_MIN 128           /* chunk = power of two >= warm: one lane per chunk, 64 chunks per workgroup */
 #define DEEMPH_LEVELS 8
 /* tables the single-workgroup top walk stages in LDS.  Kept small (<= 16 KiB of LDS, 256 threads) so that
  * the workgroup finds a slot on a CU that the pipelined decimator of the next run is saturating. */
@@ -138,7 +138,7 @@ static void deemph_geometry(rxgpu_fm_stream *s)
 		s->group = 0;                 /* a == 1 or a carried state outside int16: the serial kernel */
 	s->warm = s->group ? (deemph_warm(a, (long long)s->hi0 - s->lo0) + 7) / 8 * 8 : 0;   /* whole 16-byte reads */
 	s->chunk = DEEMPH_CHUNK_MIN;
-	while (s->chunk < 2 * s->warm)
+	while (s->chunk < s->warm)
 		s->chunk *= 2;
 	if (s->chunk > 1024)
 		s->group = 0;                 /* cannot happen for a <= 64 and an int16 state; the serial kernel if it does */
@@ -196,7 +196,7 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 	DMALLOC(s->y, s->max_M * 2);
 	const size_t n_l0 = n_chunks / RXK_DEEMPH_WG_CHUNKS + 2;
 	s->lvl_cap = n_l0 + n_l0 / (RXK_DEEMPH_FAN - 1) + 2 * DEEMPH_LEVELS + 2;             /* level 0 + all composites */
-	DMALLOC(s->chunk_pre, n_chunks * 64 * 4);
+	DMALLOC(s->chunk_pre, n_chunks * (size_t)(params->deemph_a <= 16 ? 16 : 64) * 4);
 	DMALLOC(s->lvl_tab, s->lvl_cap * 64 * 4);
 	DMALLOC(s->lvl_lo, s->lvl_cap * 4);
 	DMALLOC(s->lvl_gap, s->lvl_cap * 4);
