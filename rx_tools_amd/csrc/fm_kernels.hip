@@ -792,6 +792,53 @@ __device__ __forceinline__ void deemph_stage(const int16_t *__restrict__ pcm, u6
 	}
 }
 
+// Fast form of the step for odd a in 5..255 (the D24 range): the state is kept as N = ((a/2 - avg) << 6) + 32, so that
+//   t6 = ((x - avg + a/2) << 6) + 32          one v_mad_i32_i16 straight from the packed sample (x * 64 + N),
+//   q  = floor((x - avg + a/2) / a)            one signed 24-bit multiply-high, (t6 * (2^26/a + 1)) >> 32 -- the +32 (half
+//                                              a unit) keeps it exact for negative dividends: |t6| < 2^23, error < 2^-9 < 1/(2a),
+//   N' = N - 64 q                              one v_mad_i32_i24,
+// and, for the scan, r6 = t6 - q * 64a = ((x - avg + a/2) mod a) * 64 + 32 -- the merge test's remainder.  For odd a
+// the reference's truncating (d +- a/2) / a is floor((d + a/2) / a) for either sign of d (rtl_fm.c:675-679).
+__device__ __forceinline__ int de_state(int avg, int h) { return ((h - avg) << 6) + 32; }
+__device__ __forceinline__ int de_avg(int N, int h) { return h - (N >> 6); }
+
+template <int HALF>
+__device__ __forceinline__ void de_step(uint32_t w, int &N, unsigned m, int n64)
+{
+	int t, q;
+	if (HALF == 0)
+		asm("v_mad_i32_i16 %[t], %[w], 64, %[N]\n\tv_mul_hi_i32_i24 %[q], %[t], %[m]\n\tv_mad_i32_i24 %[N], %[q], %[n64], %[N]"
+		    : [N] "+v"(N), [t] "=&v"(t), [q] "=&v"(q) : [w] "v"(w), [m] "s"(m), [n64] "s"(n64));
+	else
+		asm("v_mad_i32_i16 %[t], %[w], 64, %[N] op_sel:[1,0,0,0]\n\tv_mul_hi_i32_i24 %[q], %[t], %[m]\n\tv_mad_i32_i24 %[N], %[q], %[n64], %[N]"
+		    : [N] "+v"(N), [t] "=&v"(t), [q] "=&v"(q) : [w] "v"(w), [m] "s"(m), [n64] "s"(n64));
+}
+
+template <int HALF>
+__device__ __forceinline__ int de_step_r(uint32_t w, int &N, unsigned m, int n64, int na6)
+{
+	int t, q, r;
+	if (HALF == 0)
+		asm("v_mad_i32_i16 %[t], %[w], 64, %[N]\n\tv_mul_hi_i32_i24 %[q], %[t], %[m]\n\tv_mad_i32_i24 %[N], %[q], %[n64], %[N]\n\t"
+		    "v_mad_i32_i24 %[r], %[q], %[na6], %[t]"
+		    : [N] "+v"(N), [t] "=&v"(t), [q] "=&v"(q), [r] "=&v"(r) : [w] "v"(w), [m] "s"(m), [n64] "s"(n64), [na6] "s"(na6));
+	else
+		asm("v_mad_i32_i16 %[t], %[w], 64, %[N] op_sel:[1,0,0,0]\n\tv_mul_hi_i32_i24 %[q], %[t], %[m]\n\tv_mad_i32_i24 %[N], %[q], %[n64], %[N]\n\t"
+		    "v_mad_i32_i24 %[r], %[q], %[na6], %[t]"
+		    : [N] "+v"(N), [t] "=&v"(t), [q] "=&v"(q), [r] "=&v"(r) : [w] "v"(w), [m] "s"(m), [n64] "s"(n64), [na6] "s"(na6));
+	return r;
+}
+
+// distinct candidates r and r+1 have become one: clear the r-th set bit of the mask
+template <typename MASK>
+__device__ __forceinline__ void de_merge(MASK &mask, int r)
+{
+	MASK m2 = mask;
+	for (int i = 0; i < r; i++)
+		m2 &= m2 - 1;
+	mask &= ~(m2 & (~m2 + 1));
+}
+
 #define DEEMPH_WG_CHUNKS 64          // chunks per workgroup of scan/apply = fan of the first tree level
 
 template <int GS, bool EVEN, bool D24>
@@ -801,6 +848,7 @@ __global__ __launch_bounds__(64) void k_fm_deemph_scan(
 	rxk_fm_dev *__restrict__ dev)
 {
 	extern __shared__ uint4 de_lds[];
+	constexpr bool FAST = !EVEN && D24;                                 // odd a in 5..255: the three-instruction step
 	const int lane = threadIdx.x, chunk = 1 << chunk_l2, row_u = chunk / 8 + 1;
 	int *ltab = reinterpret_cast<int *>(de_lds + 65 * row_u);        // this workgroup's 64 chunk tables, then lo and gap
 	int *llo = ltab + 64 * GS, *lgap = llo + 64;
@@ -821,14 +869,29 @@ __global__ __launch_bounds__(64) void k_fm_deemph_scan(
 			hi = hi0;
 			const uint4 *row = de_lds + lane * row_u;
 			uint4 w = row[(chunk - warm) >> 3];
-			for (int u = (chunk - warm) >> 3; u < (chunk >> 3); u++) {
-				const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-				w = row[u + 1];
+			if (FAST) {
+				int nl = de_state(lo, a / 2), nh = de_state(hi, a / 2);
+				for (int u = (chunk - warm) >> 3; u < (chunk >> 3); u++) {
+					const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+					w = row[u + 1];
 #pragma unroll
-				for (int k = 0; k < 8; k++) {
-					const int x = (k & 1) ? hi16(ww[k >> 1]) : lo16(ww[k >> 1]);
-					lo = deemph_step_d<EVEN, D24>(lo, x + xoff, x, magic, bias);
-					hi = deemph_step_d<EVEN, D24>(hi, x + xoff, x, magic, bias);
+					for (int k = 0; k < 4; k++) {
+						de_step<0>(ww[k], nl, magic, -64); de_step<0>(ww[k], nh, magic, -64);
+						de_step<1>(ww[k], nl, magic, -64); de_step<1>(ww[k], nh, magic, -64);
+					}
+				}
+				lo = de_avg(nl, a / 2);
+				hi = de_avg(nh, a / 2);
+			} else {
+				for (int u = (chunk - warm) >> 3; u < (chunk >> 3); u++) {
+					const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+					w = row[u + 1];
+#pragma unroll
+					for (int k = 0; k < 8; k++) {
+						const int x = (k & 1) ? hi16(ww[k >> 1]) : lo16(ww[k >> 1]);
+						lo = deemph_step_d<EVEN, D24>(lo, x + xoff, x, magic, bias);
+						hi = deemph_step_d<EVEN, D24>(hi, x + xoff, x, magic, bias);
+					}
 				}
 			}
 		}
@@ -844,20 +907,44 @@ __global__ __launch_bounds__(64) void k_fm_deemph_scan(
 		const uint4 *row = de_lds + (lane + 1) * row_u;
 		const int nu = n >> 3;
 		uint4 w = row[0];
-		for (int u = 0; u < nu; u++) {
-			const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-			w = row[u + 1];                               // next unit (the pad unit after the last) while this one is walked
+		if (FAST) {
+			int N = de_state(lo, a / 2), cm6 = gap << 6;  // r6 < cm6  <=>  remainder + 1 < number of distinct candidates
+			const int na6 = -(a << 6);
+			for (int u = 0; u < nu; u++) {
+				const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+				w = row[u + 1];                           // next unit (the pad unit after the last) while this one is walked
 #pragma unroll
-			for (int k = 0; k < 8; k++) {
-				const int x = (k & 1) ? hi16(ww[k >> 1]) : lo16(ww[k >> 1]);
-				deemph_track<EVEN, D24>(lo, cnt, mask, x, a, xoff, magic, bias);
+				for (int k = 0; k < 4; k++) {
+					int r6 = de_step_r<0>(ww[k], N, magic, -64, na6);
+					if (__builtin_expect(r6 < cm6, 0)) { de_merge(mask, r6 >> 6); cm6 -= 64; }
+					r6 = de_step_r<1>(ww[k], N, magic, -64, na6);
+					if (__builtin_expect(r6 < cm6, 0)) { de_merge(mask, r6 >> 6); cm6 -= 64; }
+				}
 			}
-		}
-		if (n & 7) {                                      // the ragged end of the run
-			const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-			for (int k = 0; k < (n & 7); k++) {
-				const int x = (k & 1) ? hi16(ww[k >> 1]) : lo16(ww[k >> 1]);
-				deemph_track<EVEN, D24>(lo, cnt, mask, x, a, xoff, magic, bias);
+			if (n & 7) {                                  // the ragged end of the run
+				const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+				for (int k = 0; k < (n & 7); k++) {
+					const int r6 = (k & 1) ? de_step_r<1>(ww[k >> 1], N, magic, -64, na6) : de_step_r<0>(ww[k >> 1], N, magic, -64, na6);
+					if (r6 < cm6) { de_merge(mask, r6 >> 6); cm6 -= 64; }
+				}
+			}
+			lo = de_avg(N, a / 2);
+		} else {
+			for (int u = 0; u < nu; u++) {
+				const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+				w = row[u + 1];
+#pragma unroll
+				for (int k = 0; k < 8; k++) {
+					const int x = (k & 1) ? hi16(ww[k >> 1]) : lo16(ww[k >> 1]);
+					deemph_track<EVEN, D24>(lo, cnt, mask, x, a, xoff, magic, bias);
+				}
+			}
+			if (n & 7) {                                  // the ragged end of the run
+				const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+				for (int k = 0; k < (n & 7); k++) {
+					const int x = (k & 1) ? hi16(ww[k >> 1]) : lo16(ww[k >> 1]);
+					deemph_track<EVEN, D24>(lo, cnt, mask, x, a, xoff, magic, bias);
+				}
 			}
 		}
 		for (int k = 0; k <= gap; k++)
@@ -983,19 +1070,38 @@ __global__ __launch_bounds__(64) void k_fm_deemph_apply(
 		const int xoff = a / 2 + bias * a;
 		int s = pre[c * gs + cand];
 		uint4 *row = de_lds + (lane + 1) * row_u;
-		for (int u = 0; u * 8 < n; u++) {               // past-the-end samples of the last unit are never stored
-			const uint4 w = row[u];
-			const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-			uint32_t o[4];
+		if (!EVEN && D24) {
+			int N = de_state(s, a / 2);
+			const uint32_t hh = (uint32_t)(a / 2) * 0x00010001u;
+			for (int u = 0; u * 8 < n; u++) {           // past-the-end samples of the last unit are never stored
+				const uint4 w = row[u];
+				const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+				uint32_t o[4];
 #pragma unroll
-			for (int k = 0; k < 4; k++) {
-				const int x0 = lo16(ww[k]), x1 = hi16(ww[k]);
-				s = deemph_step_d<EVEN, D24>(s, x0 + xoff, x0, magic, bias);
-				const int y0 = s;
-				s = deemph_step_d<EVEN, D24>(s, x1 + xoff, x1, magic, bias);
-				o[k] = pack_iq(y0, s);
+				for (int k = 0; k < 4; k++) {
+					de_step<0>(ww[k], N, magic, -64);
+					const int z0 = N >> 6;                 // a/2 - avg
+					de_step<1>(ww[k], N, magic, -64);
+					const int z1 = N >> 6;
+					o[k] = pk_sub(hh, __builtin_amdgcn_perm((uint32_t)z1, (uint32_t)z0, 0x05040100u));
+				}
+				row[u] = make_uint4(o[0], o[1], o[2], o[3]);
 			}
-			row[u] = make_uint4(o[0], o[1], o[2], o[3]);
+		} else {
+			for (int u = 0; u * 8 < n; u++) {
+				const uint4 w = row[u];
+				const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+				uint32_t o[4];
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					const int x0 = lo16(ww[k]), x1 = hi16(ww[k]);
+					s = deemph_step_d<EVEN, D24>(s, x0 + xoff, x0, magic, bias);
+					const int y0 = s;
+					s = deemph_step_d<EVEN, D24>(s, x1 + xoff, x1, magic, bias);
+					o[k] = pack_iq(y0, s);
+				}
+				row[u] = make_uint4(o[0], o[1], o[2], o[3]);
+			}
 		}
 	}
 	__syncthreads();
