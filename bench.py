@@ -281,17 +281,27 @@ def main():
         g = torch.Generator(device=dev)
         g.manual_seed(777 + rank)
         d_in = torch.randint(-100, 101, (passes, max(mine, 1), plan.buf_len), dtype=torch.int16, device=dev, generator=g)
-        d_avg = torch.zeros((per, n), dtype=torch.int64, device=dev)        # padded to `per` rows for the gather
+        # two report-interval buffers: the gather of interval k (RCCL, torch's stream) overlaps the scan of interval k+1
+        d_avgs = [torch.zeros((per, n), dtype=torch.int64, device=dev) for _ in range(2)]   # padded to `per` rows for the gather
         d_smp = torch.zeros(per, dtype=torch.int32, device=dev)
-        gbuf = shard.gather_buffers(d_avg, dst=0) if world > 1 else None
+        gbuf = shard.gather_buffers(d_avgs[0], dst=0) if world > 1 else None
+        gathered = [None, None]          # event after the gather that last read buffer b
+        state = {"k": 0}
 
         def step():
+            b = state["k"] & 1
+            state["k"] += 1
+            if gathered[b] is not None:
+                gathered[b].synchronize()
             if mine:
-                ps.run(d_in.data_ptr(), passes, mine, d_avg.data_ptr(), d_smp.data_ptr())
+                ps.run(d_in.data_ptr(), passes, mine, d_avgs[b].data_ptr(), d_smp.data_ptr())
             if world > 1:
                 # order the gather (torch's stream) after the scan (librxgpu's stream)
                 L.rxgpu_sync()
-                shard.gather_rows(d_avg, dst=0, out=gbuf)
+                shard.gather_rows(d_avgs[b], dst=0, out=gbuf)
+                ev = torch.cuda.Event()
+                ev.record()
+                gathered[b] = ev
 
         for _ in range(args.warmup):
             step()
