@@ -102,6 +102,11 @@ typedef struct rxgpu_fm_params {
 	int squelch_level;       /* -l: power squelch on the decimated block (rtl_fm.c:781-790); 0 = off */
 	int dc_block_audio;      /* -E adc: dc_block_audio_filter (rtl_fm.c:684-697, 818) */
 	int adc_block_const;     /* its averaging constant (default 9, rtl_fm.c:1106) */
+	int post_downsample;     /* -o: low_pass_simple on the demodulated block (rtl_fm.c:373-387, 814-815); 0/1 = off.
+	                          * Every block's demodulated length must be a multiple of it (the reference's own
+	                          * precondition; it reads stale data otherwise) -- RXGPU_EUNSUPPORTED if not */
+	int dc_block_raw;        /* -E rdc: dc_block_raw_filter on the scaled capture, in the callback (rtl_fm.c:699-721, 850-852) */
+	int rdc_block_const;     /* its averaging constant (default 9, rtl_fm.c:1110) */
 } rxgpu_fm_params;
 
 enum { RXGPU_MODE_FM = 0, RXGPU_MODE_AM = 1, RXGPU_MODE_USB = 2, RXGPU_MODE_LSB = 3, RXGPU_MODE_RAW = 4 };
@@ -116,6 +121,7 @@ typedef struct rxgpu_fm_carry {
 	int now_lpr, prev_lpr_index;             /* low_pass_real     rtl_fm.c:150-151 */
 	int squelch_hits;                        /* power squelch     rtl_fm.c:145 */
 	int dc_avg;                              /* dc_block_audio    rtl_fm.c:152 */
+	int dc_avgI, dc_avgQ;                    /* dc_block_raw      rtl_fm.c:153 */
 } rxgpu_fm_carry;
 
 typedef struct rxgpu_fm_stream rxgpu_fm_stream;

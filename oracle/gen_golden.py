@@ -75,6 +75,8 @@ FM_CASES = [
     ("atan_ale", "noise", 3, 8192, dict(downsample=10, custom_atan=3)),
     ("squelch", "fm", 4, 8192, dict(downsample=6, squelch_level=2000)),
     ("adc", "noise", 4, 8192, dict(downsample=6, dc_block_audio=1)),
+    ("post4", "fm", 4, 8192, dict(downsample=4, post_downsample=4)),
+    ("rdc", "noise", 5, 8192, dict(downsample=6, dc_block_raw=1, rdc_block_const=3)),
 ]
 
 

@@ -336,6 +336,8 @@ int rxo_fm_full_demod(rxo_fm_state *st, int16_t *lp, int *lp_len, int16_t *out)
 		if (st->mode == 4)
 			return n;                                                  /* rtl_fm.c:809-811 */
 	}
+	if (st->post_downsample > 1)
+		n = rxo_low_pass_simple(out, n, st->post_downsample);              /* rtl_fm.c:814-815 */
 	if (st->deemph)
 		rxo_deemph(out, n, st->deemph_a, &st->deemph_avg);
 	if (st->dc_block_audio)
@@ -345,13 +347,51 @@ int rxo_fm_full_demod(rxo_fm_state *st, int16_t *lp, int *lp_len, int16_t *out)
 	return n;
 }
 
-/* rtlsdr_callback pre-stage, rtl_fm.c:839-857 (dc_block_raw off), then full_demod */
+/* rtl_fm.c:373-387.  `len` must be a multiple of `step` (the reference says so and reads past the end otherwise);
+ * the write of signal2[len/step + 1] is kept. */
+int rxo_low_pass_simple(int16_t *signal2, int len, int step)
+{
+	int i, i2, sum;
+	for (i = 0; i < len; i += step) {
+		sum = 0;
+		for (i2 = 0; i2 < step; i2++)
+			sum += (int)signal2[i + i2];
+		signal2[i / step] = (int16_t)sum;
+	}
+	signal2[i / step + 1] = signal2[i / step];
+	return len / step;
+}
+
+/* rtl_fm.c:699-721 */
+void rxo_dc_block_raw(int16_t *buf, int len, int rdc_block_const, int *dc_avgI, int *dc_avgQ)
+{
+	int64_t sumI = 0, sumQ = 0;
+	int avgI, avgQ;
+	for (int i = 0; i < len; i += 2) {
+		sumI += buf[i];
+		sumQ += buf[i + 1];
+	}
+	avgI = (int)(sumI / (len / 2));
+	avgQ = (int)(sumQ / (len / 2));
+	avgI = (avgI + *dc_avgI * rdc_block_const) / (rdc_block_const + 1);
+	avgQ = (avgQ + *dc_avgQ * rdc_block_const) / (rdc_block_const + 1);
+	for (int i = 0; i < len; i += 2) {
+		buf[i] = (int16_t)(buf[i] - avgI);
+		buf[i + 1] = (int16_t)(buf[i + 1] - avgQ);
+	}
+	*dc_avgI = avgI;
+	*dc_avgQ = avgQ;
+}
+
+/* rtlsdr_callback pre-stage, rtl_fm.c:839-857, then full_demod */
 int rxo_fm_block(rxo_fm_state *st, const int16_t *in, int len, int16_t *lp, int *lp_len_out, int16_t *out)
 {
 	int lp_len = len, n;
 	for (int i = 0; i < len; i++)
 		lp[i] = rxo_scale_sample((st->mute && i < st->mute) ? 0 : in[i]);
 	st->mute = 0;
+	if (st->dc_block_raw)                                                  /* rtl_fm.c:850-852 */
+		rxo_dc_block_raw(lp, len, st->rdc_block_const, &st->dc_avgI, &st->dc_avgQ);
 	if (!st->offset_tuning)
 		rxo_rotate_90(lp, (uint32_t)len);
 	n = rxo_fm_full_demod(st, lp, &lp_len, out);

@@ -39,6 +39,8 @@ typedef struct rxo_fm_state {
 	int output_scale;        /* rtl_fm.c:988-992 */
 	int squelch_level;       /* rtl_fm.c:781-790 */
 	int dc_block_audio, adc_block_const;   /* rtl_fm.c:684-697, 818 */
+	int post_downsample;     /* -o: low_pass_simple on the demodulated block, rtl_fm.c:814-815 (0/1 = off) */
+	int dc_block_raw, rdc_block_const;     /* -E rdc: dc_block_raw_filter in the callback, rtl_fm.c:699-721, 850-852 */
 	/* carries */
 	int now_r, now_j, prev_index;
 	int pre_r, pre_j;
@@ -48,6 +50,7 @@ typedef struct rxo_fm_state {
 	int now_lpr, prev_lpr_index;
 	int squelch_hits;
 	int dc_avg;
+	int dc_avgI, dc_avgQ;    /* dc_block_raw_filter */
 } rxo_fm_state;
 
 /* rtl_fm.c:845-848: CS16 -> 8-bit-range int16 through fp64 */
@@ -75,6 +78,10 @@ int rxo_rms(const int16_t *samples, int len, int step);
 int rxo_simple_demod(int mode, const int16_t *lp, int lp_len, int output_scale, int16_t *result);
 /* rtl_fm.c:684-697 */
 void rxo_dc_block_audio(int16_t *result, int n, int adc_block_const, int *dc_avg);
+/* rtl_fm.c:373-387 (len % step == 0); returns the new length */
+int rxo_low_pass_simple(int16_t *signal2, int len, int step);
+/* rtl_fm.c:699-721: one callback block of len int16 */
+void rxo_dc_block_raw(int16_t *buf, int len, int rdc_block_const, int *dc_avgI, int *dc_avgQ);
 /* rtl_fm.c:584-615; returns result_len */
 int rxo_fm_demod(const int16_t *lp, int lp_len, int custom_atan, int *pre_r, int *pre_j, int16_t *result);
 /* rtl_fm.c:667-682 */

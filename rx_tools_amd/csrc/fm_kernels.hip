@@ -526,6 +526,10 @@ __device__ __forceinline__ void block_range(const rxk_fm_blocks &g, u64 b, u64 &
 		m0 = (b * g.n + (u64)g.p0) / (u64)g.ds;
 		m1 = ((b + 1) * g.n + (u64)g.p0) / (u64)g.ds;
 	}
+	if (g.post > 1) {                  // after low_pass_simple: every block's count is a multiple of post
+		m0 /= (u64)g.post;
+		m1 /= (u64)g.post;
+	}
 }
 
 // floor(sqrt(v)) for v >= 0, exact whatever the last bit of the device sqrt does
@@ -631,11 +635,12 @@ __global__ void k_fm_dc_apply(int16_t *__restrict__ y, u64 M, rxk_fm_blocks g, c
 	const u64 m = (u64)blockIdx.x * blockDim.x + threadIdx.x;
 	if (m >= M)
 		return;
+	const u64 md = g.post > 1 ? m * (u64)g.post : m;        // after -o: sample m came from demodulated samples md .. md+post-1
 	u64 b;
 	if (g.first_mode == RXK_FIRST_UNIFORM)
-		b = m / g.k;
+		b = md / g.k;
 	else
-		b = ((m + 1) * (u64)g.ds - (u64)g.p0 - 1) / g.n;
+		b = ((md + 1) * (u64)g.ds - (u64)g.p0 - 1) / g.n;
 	y[m] = (int16_t)(y[m] - avgs[b]);
 }
 
@@ -1576,6 +1581,89 @@ __global__ void k_fm_prestage(const uint32_t *__restrict__ in, unsigned n, int r
 	out[i] = pack_iq(ri, rq);
 }
 
+// ------------------------------------------------------------------ -E rdc and -o
+
+// dc_block_raw_filter (rtl_fm.c:699-721), the callback's DC blocker on the scaled capture, as a pre-pass:
+//   k_fm_rdc_sums   per callback block, the int64 sums of the scaled I and Q samples (RDC_PARTS partial workgroups)
+//   k_fm_rdc_scan   one thread: block after block, avg = (sum / n + avg_prev * c) / (c + 1) in the reference's int arithmetic
+//   k_fm_rdc_apply  scaled sample minus its block's averages (int16 wrap), then rotate16_90 -- what the callback leaves
+//                   in lowpassed[]; the rest of the chain runs on that as `prescaled` input
+#define RDC_PARTS 16
+
+__global__ __launch_bounds__(256) void k_fm_rdc_sums(const uint32_t *__restrict__ iq, u64 n_per_block, int prescaled, i64 *__restrict__ sums)
+{
+	__shared__ i64 red[2][4];
+	const u64 b = blockIdx.x / RDC_PARTS;
+	const unsigned part = blockIdx.x % RDC_PARTS;
+	const u64 per = (n_per_block + RDC_PARTS - 1) / RDC_PARTS;
+	const u64 lo = (u64)part * per, hi = lo + per < n_per_block ? lo + per : n_per_block;
+	i64 si = 0, sq = 0;
+	for (u64 i = lo + threadIdx.x; i < hi; i += 256) {
+		const uint32_t w = iq[b * n_per_block + i];
+		si += prescaled ? lo16(w) : scale_cs16(lo16(w));
+		sq += prescaled ? hi16(w) : scale_cs16(hi16(w));
+	}
+	for (int off = 32; off; off >>= 1) { si += __shfl_down(si, off); sq += __shfl_down(sq, off); }
+	if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = si; red[1][threadIdx.x >> 6] = sq; }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		atomicAdd((unsigned long long *)&sums[2 * b], (unsigned long long)(red[0][0] + red[0][1] + red[0][2] + red[0][3]));
+		atomicAdd((unsigned long long *)&sums[2 * b + 1], (unsigned long long)(red[1][0] + red[1][1] + red[1][2] + red[1][3]));
+	}
+}
+
+__global__ void k_fm_rdc_scan(const i64 *__restrict__ sums, u64 n_blocks, int n_per_block, int c, int *__restrict__ state,
+                              int *__restrict__ avg)
+{
+	if (blockIdx.x || threadIdx.x)
+		return;
+	int aI = state[0], aQ = state[1];
+	for (u64 b = 0; b < n_blocks; b++) {
+		int vI = (int)(sums[2 * b] / n_per_block), vQ = (int)(sums[2 * b + 1] / n_per_block);     // rtl_fm.c:711-712: len / 2 = samples
+		aI = (vI + aI * c) / (c + 1);
+		aQ = (vQ + aQ * c) / (c + 1);
+		avg[2 * b] = aI;
+		avg[2 * b + 1] = aQ;
+	}
+	state[0] = aI;
+	state[1] = aQ;
+}
+
+__global__ __launch_bounds__(256) void k_fm_rdc_apply(const uint32_t *__restrict__ iq, u64 T, u64 n_per_block, int prescaled, int rotate,
+                                                      const int *__restrict__ avg, uint32_t *__restrict__ out)
+{
+	const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+	if (i >= T)
+		return;
+	const u64 b = i / n_per_block;
+	const unsigned inblk = (unsigned)(i - b * n_per_block);
+	const uint32_t w = iq[i];
+	int vi = prescaled ? lo16(w) : scale_cs16(lo16(w)), vq = prescaled ? hi16(w) : scale_cs16(hi16(w));
+	vi = (int)(int16_t)(vi - avg[2 * b]);
+	vq = (int)(int16_t)(vq - avg[2 * b + 1]);
+	int ri, rq;
+	switch (rotate ? (inblk & 3) : 0) {
+	case 0: ri = vi; rq = vq; break;
+	case 1: ri = -vq; rq = vi; break;
+	case 2: ri = -vi; rq = -vq; break;
+	default: ri = vq; rq = -vi; break;
+	}
+	out[i] = pack_iq(ri, rq);
+}
+
+// low_pass_simple (rtl_fm.c:373-387) on whole blocks whose lengths are multiples of `step`: groups never straddle a
+// block, so the run's demodulated samples are one array; the sum is stored as int16 like the reference's
+__global__ void k_fm_post_downsample(const int16_t *__restrict__ in, u64 n_out, int step, int16_t *__restrict__ out)
+{
+	const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= n_out)
+		return;
+	int sum = 0;
+	for (int i = 0; i < step; i++)
+		sum += in[j * (u64)step + i];
+	out[j] = (int16_t)sum;
+}
+
 // ------------------------------------------------------------------ channeliser (extension)
 
 // BASELINE configs[4] / SURVEY section 8(f) rank 2 -- not in the reference; specified from its primitives
@@ -1908,6 +1996,31 @@ extern "C" int rxk_fm_droop(void *stream, const uint32_t *in, u64 M, const int *
 	if (!M)
 		return 0;
 	hipLaunchKernelGGL(k_fm_droop, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, M, fir, hist_in, hist_out, out);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_fm_rdc(void *stream, const int16_t *iq, u64 n_blocks, u64 n_per_block, int prescaled, int rotate,
+                          int rdc_block_const, int *state, long long *sums, int *avg, int16_t *out)
+{
+	if (!n_blocks || !n_per_block)
+		return 0;
+	hipStream_t s = (hipStream_t)stream;
+	const u64 T = n_blocks * n_per_block;
+	hipError_t e = hipMemsetAsync(sums, 0, (size_t)n_blocks * 16, s);
+	if (e != hipSuccess)
+		return (int)e;
+	hipLaunchKernelGGL(k_fm_rdc_sums, dim3((unsigned)(n_blocks * RDC_PARTS)), dim3(256), 0, s, (const uint32_t *)iq, n_per_block, prescaled, (i64 *)sums);
+	hipLaunchKernelGGL(k_fm_rdc_scan, dim3(1), dim3(64), 0, s, (const i64 *)sums, n_blocks, (int)n_per_block, rdc_block_const, state, avg);
+	hipLaunchKernelGGL(k_fm_rdc_apply, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, (const uint32_t *)iq, T, n_per_block, prescaled, rotate,
+	                   avg, (uint32_t *)out);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_fm_post_downsample(void *stream, const int16_t *in, u64 n_out, int step, int16_t *out)
+{
+	if (!n_out)
+		return 0;
+	hipLaunchKernelGGL(k_fm_post_downsample, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, n_out, step, out);
 	LAUNCH_RET();
 }
 

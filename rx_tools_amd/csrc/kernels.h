@@ -44,6 +44,7 @@ typedef struct rxk_fm_blocks {
 	int first_mode;                /* RXK_FIRST_LOWPASS: block b owns lp[(b*n+p0)/ds .. ((b+1)*n+p0)/ds); UNIFORM: lp[b*k .. (b+1)*k) */
 	int ds, p0;
 	unsigned long long n, k, n_blocks;
+	int post;                      /* > 1: the ranges are asked in samples after low_pass_simple (-o) */
 } rxk_fm_blocks;
 
 #define RXK_FLAG_CAP 4096
@@ -172,6 +173,14 @@ int rxk_pw_droop(void *stream, const int16_t *in, int16_t *out, size_t n_bufs, i
 int rxk_pw_rms_sums(void *stream, const int16_t *in, size_t n_bufs, int buf_len, long long *t, long long *p);
 int rxk_pw_rms_apply(void *stream, const long long *t, const long long *p, int passes, int tunes, int buf_len,
                      int peak_hold, long long *avg, int *samples);
+
+/* -E rdc, dc_block_raw_filter (rtl_fm.c:699-721, 850-852): per block sums -> one-thread recursion over the blocks
+ * (state[2] = dc_avgI, dc_avgQ, read and written on the device) -> out = rotate16_90(scaled - avg) as int16 pairs.
+ * sums: 2 int64 per block, avg: 2 int per block (workspace). */
+int rxk_fm_rdc(void *stream, const int16_t *iq, unsigned long long n_blocks, unsigned long long n_per_block, int prescaled,
+               int rotate, int rdc_block_const, int *state, long long *sums, int *avg, int16_t *out);
+/* -o, low_pass_simple (rtl_fm.c:373-387): out[j] = (int16) sum of in[j*step .. j*step+step) */
+int rxk_fm_post_downsample(void *stream, const int16_t *in, unsigned long long n_out, int step, int16_t *out);
 
 /* ---- rx_sdr output converters (sdr_kernels.hip), rtl_sdr.c:354-391; n16 = int16 count, device pointers */
 int rxk_sdr_cs16_to_8(void *stream, const int16_t *in, unsigned long long n16, int is_unsigned, uint8_t *out);

@@ -21,7 +21,7 @@
 /* geometry of one run, everything the host can know without the device */
 struct run_geom {
 	unsigned long long n, T, M, K, J;
-	int passes, ds, p0, pr0, rotate, fast;
+	int passes, ds, p0, pr0, rotate, fast, post;
 };
 
 struct rxgpu_fm_stream {
@@ -36,6 +36,10 @@ struct rxgpu_fm_stream {
 	uint32_t *cas[2];                    /* fifth_order ping-pong */
 	uint32_t *seams;                     /* per block: 3 levels x 5 history samples for the fused passes */
 	int16_t *pcm_buf[2], *pcm, *y;       /* pcm: the buffer the run in hand uses (double-buffered like lp_raw) */
+	int16_t *rdc_buf, *pcm_post;         /* -E rdc: the corrected, rotated capture; -o: pcm after low_pass_simple */
+	long long *rdc_sums;
+	int *rdc_avg, *rdc_state;
+	hipEvent_t ev_rdc;
 	int *chunk_pre;                                /* per chunk: its start state for each candidate of its workgroup (scan -> apply) */
 	int *lvl_tab, *lvl_lo, *lvl_gap, *lvl_start;   /* tree levels, packed back to back */
 	size_t lvl_cap;
@@ -108,6 +112,12 @@ static int validate_params(const rxgpu_fm_params *p)
 		return rxgpu_fail(RXGPU_EINVAL, "mode %d outside 0..4", p->mode);
 	if (p->dc_block_audio && p->adc_block_const < 0)
 		return rxgpu_fail(RXGPU_EINVAL, "adc_block_const %d < 0", p->adc_block_const);
+	if (p->post_downsample < 0 || p->post_downsample > 16)                 /* MAXIMUM_OVERSAMPLE, rtl_fm.c:79 */
+		return rxgpu_fail(RXGPU_EINVAL, "post_downsample %d outside 0..16", p->post_downsample);
+	if (p->dc_block_raw && p->rdc_block_const < 0)
+		return rxgpu_fail(RXGPU_EINVAL, "rdc_block_const %d < 0", p->rdc_block_const);
+	if (p->dc_block_raw && p->prescaled)
+		return rxgpu_fail(RXGPU_EINVAL, "dc_block_raw works on the raw capture (it is part of the callback), not on prescaled input");
 	if (p->deemph && p->deemph_a < 1)
 		return rxgpu_fail(RXGPU_EINVAL, "deemph_a %d < 1", p->deemph_a);
 	if (p->rate_out2 > 0 && (p->rate_out < p->rate_out2 || p->rate_out <= 0))
@@ -197,6 +207,18 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 	const size_t n_l0 = n_chunks / RXK_DEEMPH_WG_CHUNKS + 2;
 	s->lvl_cap = n_l0 + n_l0 / (RXK_DEEMPH_FAN - 1) + 2 * DEEMPH_LEVELS + 2;             /* level 0 + all composites */
 	DMALLOC(s->chunk_pre, n_chunks * (size_t)(params->deemph_a <= 16 ? 16 : 64) * 4);
+	if (params->dc_block_raw) {
+		DMALLOC(s->rdc_buf, s->max_T * 4);
+		DMALLOC(s->rdc_sums, max_blocks * 16);
+		DMALLOC(s->rdc_avg, max_blocks * 8);
+		DMALLOC(s->rdc_state, 8);
+		if (hipEventCreateWithFlags(&s->ev_rdc, hipEventDisableTiming) != hipSuccess) {
+			rxgpu_fm_stream_destroy(s);
+			return rxgpu_fail(RXGPU_ENOMEM, "hipEventCreate failed");
+		}
+	}
+	if (params->post_downsample > 1)
+		DMALLOC(s->pcm_post, s->max_M * 2);
 	DMALLOC(s->lvl_tab, s->lvl_cap * 64 * 4);
 	DMALLOC(s->lvl_lo, s->lvl_cap * 4);
 	DMALLOC(s->lvl_gap, s->lvl_cap * 4);
@@ -254,6 +276,8 @@ void rxgpu_fm_stream_destroy(rxgpu_fm_stream *s)
 	hipFree(s->pcm_buf[0]); hipFree(s->pcm_buf[1]); hipFree(s->y);
 	
 	hipFree(s->lvl_tab); hipFree(s->lvl_lo); hipFree(s->lvl_gap); hipFree(s->lvl_start); hipFree(s->chunk_pre);
+	hipFree(s->rdc_buf); hipFree(s->pcm_post); hipFree(s->rdc_sums); hipFree(s->rdc_avg); hipFree(s->rdc_state);
+	if (s->ev_rdc) hipEventDestroy(s->ev_rdc);
 	hipFree(s->atan_lut); hipFree(s->below); hipFree(s->dc_sums); hipFree(s->dc_avgs);
 	if (s->below_host) hipHostFree(s->below_host);
 	hipFree(s->flag_list); hipFree(s->dev); hipFree(s->hist_dev); hipFree(s->fir_dev);
@@ -306,7 +330,14 @@ static int run_audio_stages(rxgpu_fm_stream *s, hipStream_t st, unsigned long lo
 	const rxgpu_fm_params *p = &s->p;
 	const int resample = p->rate_out2 > 0;
 	int16_t *deemph_dst = resample ? s->y : d_out;
-	const int16_t *audio = s->pcm;
+	const int16_t *pcm = s->pcm;
+	if (p->post_downsample > 1) {
+		/* rtl_fm.c:814-815; run_geometry made sure every block's length is a multiple of the step */
+		M /= (unsigned long long)p->post_downsample;
+		RX_K(rxk_fm_post_downsample(st, s->pcm, M, p->post_downsample, s->pcm_post));
+		pcm = s->pcm_post;
+	}
+	const int16_t *audio = pcm;
 	if (p->deemph && M) {
 		rxgpu_prof_begin_on("fm_deemph", st);
 		if (s->group) {
@@ -318,7 +349,7 @@ static int run_audio_stages(rxgpu_fm_stream *s, hipStream_t st, unsigned long lo
 			const unsigned long long n_chunks = (M + s->chunk - 1) / s->chunk;
 			cnt[0] = (n_chunks + RXK_DEEMPH_WG_CHUNKS - 1) / RXK_DEEMPH_WG_CHUNKS;
 			off[0] = 0;
-			RX_K(rxk_fm_deemph_scan(st, s->pcm, M, p->deemph_a, g, s->chunk, s->warm, s->lo0, s->hi0,
+			RX_K(rxk_fm_deemph_scan(st, pcm, M, p->deemph_a, g, s->chunk, s->warm, s->lo0, s->hi0,
 			                        s->chunk_pre, s->lvl_tab, s->lvl_lo, s->lvl_gap, s->dev));
 			const unsigned long long topcap = s->topcap_override ? (unsigned long long)s->topcap_override : (unsigned long long)DEEMPH_TOPCAP(g);
 			while (cnt[top] > topcap) {
@@ -335,9 +366,9 @@ static int run_audio_stages(rxgpu_fm_stream *s, hipStream_t st, unsigned long lo
 			for (int l = top; l > 0; l--)
 				RX_K(rxk_fm_deemph_down(st, cnt[l - 1], g, s->lvl_tab + off[l - 1] * g, s->lvl_lo + off[l - 1],
 				                        s->lvl_start + off[l], s->lvl_start + off[l - 1]));
-			RX_K(rxk_fm_deemph_apply(st, s->pcm, M, p->deemph_a, g, s->chunk, s->chunk_pre, s->lvl_lo, s->lvl_start, deemph_dst));
+			RX_K(rxk_fm_deemph_apply(st, pcm, M, p->deemph_a, g, s->chunk, s->chunk_pre, s->lvl_lo, s->lvl_start, deemph_dst));
 		} else {
-			RX_K(rxk_fm_deemph_serial(st, s->pcm, M, p->deemph_a, deemph_dst, s->dev));
+			RX_K(rxk_fm_deemph_serial(st, pcm, M, p->deemph_a, deemph_dst, s->dev));
 		}
 		rxgpu_prof_end_on("fm_deemph", st);
 		audio = deemph_dst;
@@ -345,21 +376,23 @@ static int run_audio_stages(rxgpu_fm_stream *s, hipStream_t st, unsigned long lo
 	if (p->dc_block_audio && M) {
 		/* rtl_fm.c:818: in place on whatever holds the audio now */
 		int16_t *dst = (int16_t *)audio;
-		if (audio == s->pcm) {
+		if (audio == pcm) {
 			/* pcm[] stays pristine (a host fix-up may have to redo these stages) */
 			dst = resample ? s->y : d_out;
-			RX_HIP(hipMemcpyAsync(dst, s->pcm, M * 2, hipMemcpyDeviceToDevice, st));
+			RX_HIP(hipMemcpyAsync(dst, pcm, M * 2, hipMemcpyDeviceToDevice, st));
 		}
-		RX_K(rxk_fm_dc_block(st, dst, M, s->blk, p->adc_block_const, s->dc_sums, s->dc_avgs, s->dev));
+		rxk_fm_blocks blk = s->blk;
+		blk.post = p->post_downsample;
+		RX_K(rxk_fm_dc_block(st, dst, M, blk, p->adc_block_const, s->dc_sums, s->dc_avgs, s->dev));
 		audio = dst;
 	}
 	if (resample) {
 		rxgpu_prof_begin_on("fm_resample", st);
 		RX_K(rxk_fm_resample(st, audio, M, p->rate_out, p->rate_out2, J, d_out, s->dev));
 		rxgpu_prof_end_on("fm_resample", st);
-	} else if (audio == s->pcm && M) {
+	} else if (audio == pcm && M) {
 		/* no stage wrote d_out yet: the demodulator output is the result */
-		RX_HIP(hipMemcpyAsync(d_out, s->pcm, M * 2, hipMemcpyDeviceToDevice, st));
+		RX_HIP(hipMemcpyAsync(d_out, pcm, M * 2, hipMemcpyDeviceToDevice, st));
 	}
 	if (!(p->deemph && M) || !resample)
 		RX_K(rxk_fm_passthrough_carry(st, s->dev, !(p->deemph && M), !resample));
@@ -377,7 +410,7 @@ static int run_geometry(rxgpu_fm_stream *s, size_t n_blocks, size_t block_len, s
 	g->ds = g->passes ? 1 : p->downsample;
 	g->p0 = g->passes ? 0 : s->h_prev_index;
 	g->pr0 = s->h_prev_lpr_index;
-	g->rotate = !p->prescaled && !p->offset_tuning;
+	g->rotate = !p->prescaled && !p->offset_tuning && !p->dc_block_raw;   /* the -E rdc pre-pass rotates */
 	g->K = 0;
 	g->fast = 0;
 	if (g->passes) {
@@ -400,12 +433,23 @@ static int run_geometry(rxgpu_fm_stream *s, size_t n_blocks, size_t block_len, s
 	if (!g->M)
 		return rxgpu_fail(RXGPU_EUNSUPPORTED, "run produces no decimated sample");
 	g->J = g->M;
+	g->post = (p->post_downsample > 1 && p->mode != RXGPU_MODE_RAW) ? p->post_downsample : 1;
+	if (g->post > 1) {
+		/* low_pass_simple needs every block's demodulated length to be a multiple of the step (rtl_fm.c:374) */
+		const unsigned long long per = g->passes ? g->K : g->n / (unsigned long long)g->ds;
+		if ((!g->passes && g->n % (unsigned long long)g->ds) || per % (unsigned long long)g->post)
+			return rxgpu_fail(RXGPU_EUNSUPPORTED, "-o %d needs every block's demodulated length to be a multiple of it "
+			                  "(block of %llu samples, downsample %d)", g->post, g->n, g->ds);
+		g->J = g->M / (unsigned long long)g->post;
+	}
+	if (p->dc_block_raw && (g->n % 4))
+		return rxgpu_fail(RXGPU_EUNSUPPORTED, "-E rdc needs blocks of a multiple of 4 samples");
 	if (p->mode == RXGPU_MODE_RAW) {
 		g->J = 2 * g->M;                         /* raw_demod: result = lowpassed, rtl_fm.c:658-665, 809-811 */
 	} else if (p->rate_out2 > 0) {
 		if (g->pr0 < 0 || g->pr0 >= p->rate_out)
 			return rxgpu_fail(RXGPU_EINVAL, "prev_lpr_index %d outside [0,rate_out)", g->pr0);
-		g->J = ((unsigned long long)g->pr0 + g->M * (unsigned long long)p->rate_out2) / (unsigned long long)p->rate_out;
+		g->J = ((unsigned long long)g->pr0 + g->J * (unsigned long long)p->rate_out2) / (unsigned long long)p->rate_out;
 	}
 	if (g->J > out_cap)
 		return rxgpu_fail(RXGPU_ECAPACITY, "output needs %llu int16, capacity %zu", g->J, out_cap);
@@ -418,6 +462,8 @@ static void block_lengths(const rxgpu_fm_stream *s, const struct run_geom *g, si
 	unsigned long long j_prev = 0;
 	for (size_t b = 0; b < n_blocks; b++) {
 		unsigned long long cum = g->passes ? g->K * (b + 1) : ((unsigned long long)g->p0 + g->n * (b + 1)) / (unsigned long long)g->ds;
+		if (p->mode != RXGPU_MODE_RAW)
+			cum /= (unsigned long long)g->post;
 		unsigned long long jj = p->mode == RXGPU_MODE_RAW ? 2 * cum
 			: p->rate_out2 > 0 ? ((unsigned long long)g->pr0 + cum * (unsigned long long)p->rate_out2) / (unsigned long long)p->rate_out : cum;
 		block_out_len[b] = (int)(jj - j_prev);
@@ -428,11 +474,24 @@ static void block_lengths(const rxgpu_fm_stream *s, const struct run_geom *g, si
 /* Enqueue one run.  The HBM-bound decimator goes on stream A, everything after it (1/ds of the
  * data, latency-bound) on stream B behind an event, so that the next run's decimator overlaps
  * this run's audio stages.  Carries stay on the device between chained runs. */
-static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks, size_t block_len,
+static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_blocks, size_t block_len,
                        int16_t *d_out, const struct run_geom *g)
 {
 	hipStream_t sa = rxgpu_hip_stream(), sb = rxgpu_hip_stream2();
 	const rxgpu_fm_params *p = &s->p;
+	const int16_t *d_iq = d_iq_in;
+	int prescaled = p->prescaled;
+	if (p->dc_block_raw) {
+		/* -E rdc: what the callback does before it hands lowpassed[] over (rtl_fm.c:845-857): scale, dc_block_raw_filter,
+		 * rotate16_90 -- written out once, the chain then runs on it as prescaled input */
+		RX_HIP(hipMemcpyAsync(s->rdc_state, &s->carry.dc_avgI, 8, hipMemcpyHostToDevice, sa));
+		RX_K(rxk_fm_rdc(sa, d_iq_in, n_blocks, g->n, 0, !p->offset_tuning, p->rdc_block_const, s->rdc_state, s->rdc_sums,
+		                s->rdc_avg, s->rdc_buf));
+		RX_HIP(hipEventRecord(s->ev_rdc, sa));
+		RX_HIP(hipStreamWaitEvent(sb, s->ev_rdc, 0));
+		d_iq = s->rdc_buf;
+		prescaled = 1;
+	}
 	const int db = s->db;
 	rxk_fm_dev *h = s->dev_host;
 	if (p->deemph)
@@ -480,7 +539,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks,
 		const int fused_disc = g->fast && p->custom_atan == 1 && !split;
 		/* lowpassed[] is an intermediate of the fused chain: keep only the entries the seam kernel reads
 		 * (the drop-in, which must hand lowpassed[] back, runs prescaled) */
-		const int lp_sparse = fused_disc && !p->prescaled && g->ds <= RXK_LP_SPARSE_MAX_DS;
+		const int lp_sparse = fused_disc && !prescaled && g->ds <= RXK_LP_SPARSE_MAX_DS;
 		if (g->fast) {
 			s->pcm = s->pcm_buf[db];
 			s->lp_final = s->lp_raw[db];
@@ -488,19 +547,19 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks,
 			if (s->ev_small_valid[db])
 				RX_HIP(hipStreamWaitEvent(sa, s->ev_small[db], 0));
 			rxgpu_prof_begin_on("fm_decimate", sa);
-			RX_K(rxk_fm_decimate(sa, d_iq, g->T, g->ds, g->p0, p->prescaled, g->rotate, s->lp_raw[db], s->head[db], s->tail[db],
+			RX_K(rxk_fm_decimate(sa, d_iq, g->T, g->ds, g->p0, prescaled, g->rotate, s->lp_raw[db], s->head[db], s->tail[db],
 			                     lp_sparse, fused_disc ? s->pcm : NULL));
 			rxgpu_prof_end_on("fm_decimate", sa);
 			RX_HIP(hipEventRecord(s->ev_dec[db], sa));
 			RX_HIP(hipStreamWaitEvent(sb, s->ev_dec[db], 0));
 		} else {
 			rxgpu_prof_begin_on("fm_decimate_generic", sb);
-			RX_K(rxk_fm_decimate_generic(sb, d_iq, g->T, g->ds, g->p0, g->n, p->prescaled, g->rotate, s->dev, s->lp, g->M));
+			RX_K(rxk_fm_decimate_generic(sb, d_iq, g->T, g->ds, g->p0, g->n, prescaled, g->rotate, s->dev, s->lp, g->M));
 			rxgpu_prof_end_on("fm_decimate_generic", sb);
 		}
 		rxgpu_prof_begin_on("fm_disc", sb);
 		/* fast path: lp_raw is finished in place (only seam entries change) and becomes the final decimated IQ */
-		RX_K(rxk_fm_disc(sb, d_iq, g->T, g->ds, g->p0, g->n, p->prescaled, g->rotate, g->fast, g->fast ? s->lp_raw[db] : s->lp,
+		RX_K(rxk_fm_disc(sb, d_iq, g->T, g->ds, g->p0, g->n, prescaled, g->rotate, g->fast, g->fast ? s->lp_raw[db] : s->lp,
 		                 s->head[db], s->tail[db], g->fast ? s->lp_raw[db] : s->lp, g->M, RXK_FIRST_LOWPASS, 0, p->custom_atan, 1,
 		                 split ? NULL : s->pcm, s->dev, s->flag_list, fused_disc, n_blocks, s->atan_lut, g->fast ? lp_sparse : 0, s->flag_all));
 		rxgpu_prof_end_on("fm_disc", sb);
@@ -511,7 +570,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks,
 		const void *src = d_iq;
 		unsigned n_in = (unsigned)g->n, in_stride = (unsigned)g->n;
 		int first_pass = 0;
-		if (!p->prescaled && (g->n % RXK_FIFTH_TILE) == 0) {
+		if (!prescaled && (g->n % RXK_FIFTH_TILE) == 0) {
 			const int fuse = passes < 3 ? passes : 3;
 			uint32_t *dst = s->cas[(fuse - 1) & 1];
 			RX_K(rxk_fm_fifth_fused(sb, d_iq, 0, g->rotate, n_blocks, (unsigned)g->n, fuse, s->hist_dev + HIST_CAS_IN,
@@ -535,7 +594,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks,
 		for (int i = first_pass; i < passes; i++) {
 			uint32_t *dst = s->cas[i & 1];
 			unsigned n_out = n_in / 2;
-			RX_K(rxk_fm_fifth_pass(sb, src, i == 0, p->prescaled, g->rotate, n_blocks, n_in, in_stride, dst, n_out,
+			RX_K(rxk_fm_fifth_pass(sb, src, i == 0, prescaled, g->rotate, n_blocks, n_in, in_stride, dst, n_out,
 			                       s->hist_dev + HIST_CAS_IN + i * 12, s->hist_dev + HIST_CAS_OUT + i * 12));
 			src = dst;
 			n_in = n_out;
@@ -552,7 +611,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks,
 		}
 		if (!split) {
 			rxgpu_prof_begin_on("fm_disc", sb);
-			RX_K(rxk_fm_disc(sb, d_iq, g->T, 1, 0, g->n, p->prescaled, g->rotate, 0, s->lp_final, NULL, NULL, NULL, g->M,
+			RX_K(rxk_fm_disc(sb, d_iq, g->T, 1, 0, g->n, prescaled, g->rotate, 0, s->lp_final, NULL, NULL, NULL, g->M,
 			                 RXK_FIRST_UNIFORM, g->K, p->custom_atan, 0, s->pcm, s->dev, s->flag_list, 0, n_blocks, s->atan_lut, 0, s->flag_all));
 			rxgpu_prof_end_on("fm_disc", sb);
 		}
@@ -564,7 +623,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks,
 			RX_K(rxk_fm_squelch(sb, lpw, s->blk, p->squelch_level, s->below));
 		if (p->mode == RXGPU_MODE_FM) {
 			rxgpu_prof_begin_on("fm_disc", sb);
-			RX_K(rxk_fm_disc(sb, d_iq, g->T, g->ds, g->p0, g->n, p->prescaled, g->rotate, 0, lpw, NULL, NULL, NULL, g->M,
+			RX_K(rxk_fm_disc(sb, d_iq, g->T, g->ds, g->p0, g->n, prescaled, g->rotate, 0, lpw, NULL, NULL, NULL, g->M,
 			                 s->blk.first_mode, g->K, p->custom_atan, 0, s->pcm, s->dev, s->flag_list, 0, n_blocks, s->atan_lut, 0, s->flag_all));
 			rxgpu_prof_end_on("fm_disc", sb);
 		} else if (p->mode == RXGPU_MODE_RAW) {
@@ -672,6 +731,8 @@ static int finish_runs(rxgpu_fm_stream *s)
 	s->carry.deemph_avg = h->out_deemph_avg;
 	s->carry.now_lpr = h->out_now_lpr; s->carry.prev_lpr_index = h->out_prev_lpr_index;
 	s->carry.dc_avg = h->out_dc_avg;
+	if (p->dc_block_raw)
+		RX_HIP(hipMemcpy(&s->carry.dc_avgI, s->rdc_state, 8, hipMemcpyDeviceToHost));
 	if (p->squelch_level)                                    /* rtl_fm.c:783-789, block after block */
 		for (size_t b = 0; b < s->last_n_blocks; b++)
 			s->carry.squelch_hits = s->below_host[b] ? s->carry.squelch_hits + 1 : 0;
@@ -702,8 +763,8 @@ int rxgpu_fm_stream_run_async(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_
 		*out_len = (size_t)g.J;
 	if (block_out_len)
 		block_lengths(s, &g, n_blocks, block_out_len);
-	if (s->p.squelch_level)
-		return finish_runs(s);               /* squelch_hits is counted on the host, run by run */
+	if (s->p.squelch_level || s->p.dc_block_raw)
+		return finish_runs(s);               /* squelch_hits is counted on the host, the -E rdc buffer is reused: run by run */
 	return RXGPU_OK;
 }
 
@@ -773,6 +834,7 @@ void rxgpu_set_demod_functions(void *fm, void *am, void *usb, void *lsb, void *r
 #define SIDECARS 16
 static struct { const struct demod_state *d; int avg; rxgpu_fm_stream *s; rxgpu_fm_params p; } g_side[SIDECARS];
 static int16_t *g_cb_in, *g_cb_out;          /* device staging for the callback */
+static int *g_cb_rdc;                        /* -E rdc in the callback: dc_avgI/Q, the block averages, the int64 sums */
 
 static int side_slot(const struct demod_state *d)
 {
@@ -807,10 +869,6 @@ void rxgpu_full_demod(struct demod_state *d)
 		rxgpu_fail(RXGPU_ECAPACITY, "more than %d demod_state objects", SIDECARS);
 		die("rxgpu_full_demod");
 	}
-	if (d->post_downsample > 1) {
-		rxgpu_fail(RXGPU_EUNSUPPORTED, "-o (post_downsample=%d) is not on the device path", d->post_downsample);
-		die("rxgpu_full_demod");
-	}
 	int mode = RXGPU_MODE_FM;
 	if (g_fn_fm) {
 		void *fn = (void *)d->mode_demod;
@@ -840,6 +898,7 @@ void rxgpu_full_demod(struct demod_state *d)
 	p.squelch_level = d->squelch_level;
 	p.dc_block_audio = d->dc_block_audio;
 	p.adc_block_const = d->adc_block_const;
+	p.post_downsample = d->post_downsample;             /* -o; -E rdc already happened in the callback */
 	if (!g_side[slot].s || memcmp(&p, &g_side[slot].p, sizeof(p))) {
 		if (g_side[slot].s)
 			rxgpu_fm_stream_destroy(g_side[slot].s);
@@ -899,10 +958,6 @@ void rxgpu_callback(int16_t *buf, uint32_t len, void *ctx)
 	d = s->demod_target;
 	if (rxgpu_ensure_init() != RXGPU_OK)
 		die("rxgpu_callback");
-	if (d->dc_block_raw) {
-		rxgpu_fail(RXGPU_EUNSUPPORTED, "-E rdc is not on the device path");
-		die("rxgpu_callback");
-	}
 	if (len > RXGPU_MAXIMUM_BUF_LENGTH || (len & 1)) {
 		rxgpu_fail(RXGPU_EINVAL, "callback length %u", len);
 		die("rxgpu_callback");
@@ -914,16 +969,35 @@ void rxgpu_callback(int16_t *buf, uint32_t len, void *ctx)
 	}
 	if (!g_cb_in) {
 		if (hipMalloc((void **)&g_cb_in, RXGPU_MAXIMUM_BUF_LENGTH * 2) != hipSuccess ||
+		    hipMalloc((void **)&g_cb_rdc, 64) != hipSuccess ||
 		    hipMalloc((void **)&g_cb_out, RXGPU_MAXIMUM_BUF_LENGTH * 2) != hipSuccess) {
 			rxgpu_fail(RXGPU_ENOMEM, "hipMalloc failed");
 			die("rxgpu_callback");
 		}
 	}
 	hipStream_t st = rxgpu_hip_stream();
-	if (hipMemcpyAsync(g_cb_in, buf, (size_t)len * 2, hipMemcpyHostToDevice, st) != hipSuccess ||
-	    rxk_fm_prestage(st, g_cb_in, len / 2, !s->offset_tuning, g_cb_out) != 0 ||
-	    hipMemcpyAsync(s->buf16, g_cb_out, (size_t)len * 2, hipMemcpyDeviceToHost, st) != hipSuccess ||
-	    hipStreamSynchronize(st) != hipSuccess) {
+	int ok = hipMemcpyAsync(g_cb_in, buf, (size_t)len * 2, hipMemcpyHostToDevice, st) == hipSuccess;
+	if (ok && d->dc_block_raw) {
+		/* rtl_fm.c:850-852: scale, dc_block_raw_filter, rotate; g_cb_rdc = state[2] | avg[2] | sums[2] */
+		int state[2] = { d->dc_avgI, d->dc_avgQ };
+		if ((len / 2) % 4) {
+			rxgpu_fail(RXGPU_EUNSUPPORTED, "-E rdc needs blocks of a multiple of 4 samples (got %u)", len / 2);
+			die("rxgpu_callback");
+		}
+		ok = hipMemcpyAsync(g_cb_rdc, state, 8, hipMemcpyHostToDevice, st) == hipSuccess &&
+		     rxk_fm_rdc(st, g_cb_in, 1, len / 2, 0, !s->offset_tuning, d->rdc_block_const, g_cb_rdc, (long long *)(g_cb_rdc + 4),
+		                g_cb_rdc + 2, g_cb_out) == 0 &&
+		     hipMemcpyAsync(state, g_cb_rdc, 8, hipMemcpyDeviceToHost, st) == hipSuccess &&
+		     hipMemcpyAsync(s->buf16, g_cb_out, (size_t)len * 2, hipMemcpyDeviceToHost, st) == hipSuccess &&
+		     hipStreamSynchronize(st) == hipSuccess;
+		d->dc_avgI = state[0];
+		d->dc_avgQ = state[1];
+	} else if (ok) {
+		ok = rxk_fm_prestage(st, g_cb_in, len / 2, !s->offset_tuning, g_cb_out) == 0 &&
+		     hipMemcpyAsync(s->buf16, g_cb_out, (size_t)len * 2, hipMemcpyDeviceToHost, st) == hipSuccess &&
+		     hipStreamSynchronize(st) == hipSuccess;
+	}
+	if (!ok) {
 		rxgpu_fail(RXGPU_ENODEV, "device pre-stage failed: %s", hipGetErrorString(hipGetLastError()));
 		die("rxgpu_callback");
 	}

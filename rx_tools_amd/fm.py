@@ -9,14 +9,16 @@ class FmParams(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "downsample", "downsample_passes", "comp_fir_size", "custom_atan", "deemph", "deemph_a",
         "rate_out", "rate_out2", "offset_tuning", "prescaled",
-        "mode", "output_scale", "squelch_level", "dc_block_audio", "adc_block_const")]
+        "mode", "output_scale", "squelch_level", "dc_block_audio", "adc_block_const",
+        "post_downsample", "dc_block_raw", "rdc_block_const")]
 
     @classmethod
     def wbfm(cls, downsample=6, **kw):
         """`-M wbfm` defaults, rtl_fm.c:1331-1341 (deemph_a for 75 us at 170 kHz, 1410-1412)."""
         p = cls(downsample=downsample, downsample_passes=0, comp_fir_size=0, custom_atan=1, deemph=1,
                 deemph_a=13, rate_out=170000, rate_out2=32000, offset_tuning=0, prescaled=0,
-                mode=0, output_scale=1, squelch_level=0, dc_block_audio=0, adc_block_const=9)
+                mode=0, output_scale=1, squelch_level=0, dc_block_audio=0, adc_block_const=9,
+                post_downsample=1, dc_block_raw=0, rdc_block_const=9)
         for k, v in kw.items():
             setattr(p, k, v)
         return p
@@ -30,7 +32,7 @@ class FmCarry(C.Structure):
         ("lp_i_hist", (C.c_int16 * 6) * 10), ("lp_q_hist", (C.c_int16 * 6) * 10),
         ("droop_i_hist", C.c_int16 * 9), ("droop_q_hist", C.c_int16 * 9),
         ("deemph_avg", C.c_int), ("now_lpr", C.c_int), ("prev_lpr_index", C.c_int),
-        ("squelch_hits", C.c_int), ("dc_avg", C.c_int),
+        ("squelch_hits", C.c_int), ("dc_avg", C.c_int), ("dc_avgI", C.c_int), ("dc_avgQ", C.c_int),
     ]
 
 

@@ -20,7 +20,7 @@ def to_dev(a):
 
 def carry_from_oracle_state(st):
     c = R.FmCarry()
-    for f in ("now_r", "now_j", "prev_index", "pre_r", "pre_j", "deemph_avg", "now_lpr", "prev_lpr_index", "squelch_hits", "dc_avg"):
+    for f in ("now_r", "now_j", "prev_index", "pre_r", "pre_j", "deemph_avg", "now_lpr", "prev_lpr_index", "squelch_hits", "dc_avg", "dc_avgI", "dc_avgQ"):
         setattr(c, f, getattr(st, f))
     C.memmove(C.addressof(c.lp_i_hist), C.addressof(st.lp_i_hist), C.sizeof(c.lp_i_hist))
     C.memmove(C.addressof(c.lp_q_hist), C.addressof(st.lp_q_hist), C.sizeof(c.lp_q_hist))

@@ -43,12 +43,13 @@ class FmState(C.Structure):
         ("rate_out", C.c_int), ("rate_out2", C.c_int), ("offset_tuning", C.c_int), ("mute", C.c_int),
         ("mode", C.c_int), ("output_scale", C.c_int), ("squelch_level", C.c_int),
         ("dc_block_audio", C.c_int), ("adc_block_const", C.c_int),
+        ("post_downsample", C.c_int), ("dc_block_raw", C.c_int), ("rdc_block_const", C.c_int),
         ("now_r", C.c_int), ("now_j", C.c_int), ("prev_index", C.c_int),
         ("pre_r", C.c_int), ("pre_j", C.c_int),
         ("lp_i_hist", (C.c_int16 * 6) * 10), ("lp_q_hist", (C.c_int16 * 6) * 10),
         ("droop_i_hist", C.c_int16 * 9), ("droop_q_hist", C.c_int16 * 9),
         ("deemph_avg", C.c_int), ("now_lpr", C.c_int), ("prev_lpr_index", C.c_int),
-        ("squelch_hits", C.c_int), ("dc_avg", C.c_int),
+        ("squelch_hits", C.c_int), ("dc_avg", C.c_int), ("dc_avgI", C.c_int), ("dc_avgQ", C.c_int),
     ]
 
 
@@ -211,7 +212,11 @@ def ref_fm_reset(L, **params):
     d.comp_fir_size = params.get("comp_fir_size", 0)
     d.squelch_level = params.get("squelch_level", 0)
     d.squelch_hits = params.get("squelch_hits", 11)          # demod_init, rtl_fm.c:1091
-    d.post_downsample = 1
+    d.post_downsample = params.get("post_downsample", 1)
+    d.dc_block_raw = params.get("dc_block_raw", 0)
+    d.rdc_block_const = params.get("rdc_block_const", 9)
+    d.dc_avgI = params.get("dc_avgI", 0)
+    d.dc_avgQ = params.get("dc_avgQ", 0)
     d.output_scale = params.get("output_scale", 1)
     d.dc_block_audio = params.get("dc_block_audio", 0)
     d.adc_block_const = params.get("adc_block_const", 9)
@@ -251,6 +256,11 @@ def oracle_fm_state(**params):
     st.squelch_hits = params.get("squelch_hits", 11)
     st.dc_block_audio = params.get("dc_block_audio", 0)
     st.adc_block_const = params.get("adc_block_const", 9)
+    st.post_downsample = params.get("post_downsample", 1)
+    st.dc_block_raw = params.get("dc_block_raw", 0)
+    st.rdc_block_const = params.get("rdc_block_const", 9)
+    st.dc_avgI = params.get("dc_avgI", 0)
+    st.dc_avgQ = params.get("dc_avgQ", 0)
     return st
 
 

@@ -29,7 +29,7 @@ def test_struct_sizes_match_header():
     """the C structs the library is compiled against == the ctypes mirrors the tests use"""
     from rx_tools_amd.structs import DemodState, SIZEOF_DEMOD_STATE
     assert C.sizeof(DemodState) == SIZEOF_DEMOD_STATE
-    assert C.sizeof(R.FmCarry) == 316 and C.sizeof(R.FmParams) == 60
+    assert C.sizeof(R.FmCarry) == 324 and C.sizeof(R.FmParams) == 72
     assert C.sizeof(R.PowerParams) == 28
 
 

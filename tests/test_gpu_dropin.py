@@ -22,7 +22,9 @@ def fresh_demod(**kw):
     d.downsample = kw.get("downsample", 6)
     d.downsample_passes = kw.get("downsample_passes", 0)
     d.comp_fir_size = kw.get("comp_fir_size", 0)
-    d.post_downsample = 1
+    d.post_downsample = kw.get("post_downsample", 1)
+    d.dc_block_raw = kw.get("dc_block_raw", 0)
+    d.rdc_block_const = kw.get("rdc_block_const", 9)
     d.output_scale = 1
     d.squelch_level = kw.get("squelch_level", 0)
     d.squelch_hits = 11
@@ -37,7 +39,9 @@ def fresh_demod(**kw):
 
 @pytest.mark.parametrize("kw", [dict(downsample=6), dict(downsample=118), dict(downsample_passes=3, comp_fir_size=9),
                                 dict(downsample=9, custom_atan=0, deemph=0, rate_out2=-1),
-                                dict(downsample=6, squelch_level=30, dc_block_audio=1)])
+                                dict(downsample=6, squelch_level=30, dc_block_audio=1),
+                                dict(downsample=8, post_downsample=4), dict(downsample=118, dc_block_raw=1),
+                                dict(downsample_passes=3, dc_block_raw=1, rdc_block_const=2, post_downsample=2)])
 def test_full_demod_and_callback_dropin(kw):
     """rxgpu_callback + rxgpu_full_demod, block after block on a struct demod_state, == the oracle's
     rtlsdr_callback pre-stage + full_demod, including lowpassed[], lp_len and every carry"""
@@ -72,7 +76,7 @@ def test_full_demod_and_callback_dropin(kw):
         assert bytes(d.lp_i_hist) == bytes(st.lp_i_hist) and bytes(d.lp_q_hist) == bytes(st.lp_q_hist)
         assert bytes(d.droop_i_hist) == bytes(st.droop_i_hist) and bytes(d.droop_q_hist) == bytes(st.droop_q_hist)
         assert L.rxgpu_deemph_state(C.addressof(d)).contents.value == st.deemph_avg
-        assert (d.squelch_hits, d.dc_avg) == (st.squelch_hits, st.dc_avg)
+        assert (d.squelch_hits, d.dc_avg, d.dc_avgI, d.dc_avgQ) == (st.squelch_hits, st.dc_avg, st.dc_avgI, st.dc_avgQ)
 
 
 @pytest.mark.parametrize("rng,flags,window", [("24M:60M:1k", (1, 0, 0), "hamming"), ("100M:105M:1M", (1, 0, 1), "rectangle"),

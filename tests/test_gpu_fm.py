@@ -4,6 +4,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
+import rx_tools_amd as R
+
 from support import (oracle_fm_stream, oracle_fm_state, sig_fm, sig_noise, sig_alternating, oracle)
 
 pytestmark = pytest.mark.gpu
@@ -146,6 +148,37 @@ def test_host_reevaluation_of_libm_samples(ds, block_len, std, monkeypatch):
     got, got_lens, carry, fixups = gpu_fm_stream(iq, block_len, **params)
     assert np.array_equal(got, want)
     assert fixups >= n_blocks - 1                       # an exactly zero angle is never flagged
+
+
+@pytest.mark.parametrize("params,block_len", [
+    (dict(downsample=4, post_downsample=4), 16384),                   # -o 4
+    (dict(downsample=8, post_downsample=2, deemph=0, rate_out2=-1), 16384),
+    (dict(downsample=2, post_downsample=4, dc_block_audio=1), 8192),  # the reference's own -o geometry (ds=2, generic decimator)
+    (dict(downsample_passes=3, post_downsample=4), 16384),
+    (dict(downsample=6, mode=1, output_scale=2, post_downsample=2), 2 * 6 * 512),   # am + -o
+    (dict(downsample=118, dc_block_raw=1), 16384),                    # -E rdc
+    (dict(downsample=6, dc_block_raw=1, rdc_block_const=3), 2 * 6000),
+    (dict(downsample_passes=3, comp_fir_size=9, dc_block_raw=1), 16384),
+    (dict(downsample=10, dc_block_raw=1, offset_tuning=1, custom_atan=0), 8192),
+])
+def test_post_downsample_and_raw_dc_block(params, block_len):
+    """-o (low_pass_simple, rtl_fm.c:373-387) and -E rdc (dc_block_raw_filter, rtl_fm.c:699-721), several runs with
+    the dc averages carried from run to run"""
+    for sig in ("fm", "noise_full", "dc"):
+        iq = _signals(12 * block_len)[sig]
+        carry, st = _check(iq, block_len, n_runs=3, **params)
+        assert (carry.dc_avgI, carry.dc_avgQ) == (st.dc_avgI, st.dc_avgQ)
+
+
+def test_post_downsample_needs_whole_groups():
+    from gpu_support import to_dev
+    import torch
+    s = R.FmStream(R.FmParams.wbfm(downsample=6, post_downsample=4), 2, 16384)      # 8192 % 6 != 0
+    d = to_dev(np.zeros(2 * 16384, np.int16))
+    o = torch.zeros(8192, dtype=torch.int16, device="cuda")
+    with pytest.raises(R.RxGpuError, match="multiple"):
+        s.run(d.data_ptr(), 2, 16384, o.data_ptr(), o.numel())
+    s.close()
 
 
 @pytest.mark.parametrize("topcap", ["1", "3"])
