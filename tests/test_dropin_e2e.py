@@ -51,10 +51,14 @@ def expected(iq, **kw):
 
 @pytest.mark.ref
 @pytest.mark.timeout(600)
-def test_reference_main_untouched_matches_oracle(tmp_path):
+@pytest.mark.parametrize("extra,kw", [
+    (["-M", "wbfm", "-f", "100M"], dict(downsample=6)),            # optimal_settings: 1000000/170000 + 1 (rtl_fm.c:968)
+    (["-M", "wbfm", "-o", "4", "-E", "rdc", "-f", "100M"], dict(downsample=2, post_downsample=4, dc_block_raw=1)),   # rate_in x4 -> ds 2
+])
+def test_reference_main_untouched_matches_oracle(tmp_path, extra, kw):
     iq = sig_fm(4 * 131072, seed=2024)
-    got, err = run_ref_main("cpu", iq, tmp_path, ["-M", "wbfm", "-f", "100M"])
-    want = expected(iq, downsample=6)            # optimal_settings: 1000000/170000 + 1 (rtl_fm.c:968)
+    got, err = run_ref_main("cpu", iq, tmp_path, extra)
+    want = expected(iq, **kw)
     assert len(got) == len(want), err[-1500:]
     assert np.array_equal(got, want)
 
@@ -64,6 +68,7 @@ def test_reference_main_untouched_matches_oracle(tmp_path):
 @pytest.mark.parametrize("extra,kw", [
     (["-M", "wbfm", "-f", "100M"], dict(downsample=6)),
     (["-M", "wbfm", "-F", "9", "-f", "100M"], dict(downsample_passes=3, comp_fir_size=9)),
+    (["-M", "wbfm", "-o", "4", "-E", "rdc", "-f", "100M"], dict(downsample=2, post_downsample=4, dc_block_raw=1)),
 ])
 def test_reference_main_with_rxgpu_full_demod(tmp_path, extra, kw):
     iq = sig_fm(5 * 131072, seed=2025)
