@@ -677,13 +677,13 @@ __device__ __forceinline__ int deemph_step_b(int avg, int xb, int x, unsigned ma
 // after `warm` samples fewer than GS (>= a) start states remain possible for a chunk; and
 // (2) the map of a whole chunk restricted to those states is a table of <= GS entries.
 // Tables compose associatively, which turns the serial recurrence into a tree scan:
-//   k_fm_deemph_scan   chunk tables (GS candidate lanes per chunk) + the composite of every
-//                      DEEMPH_FAN consecutive chunks (level 1)
-//   k_fm_deemph_up     composite of DEEMPH_FAN tables of one level -> next level (only for very
-//                      long runs)
+//   k_fm_deemph_scan   one lane per chunk (the lowest candidate + a merge mask, see deemph_track), 64 chunks per
+//                      workgroup; the workgroup composes its 64 chunk tables (tree level 0) and stores every
+//                      chunk's start state for each candidate of the workgroup
+//   k_fm_deemph_up     composite of DEEMPH_FAN tables of one level -> next level (long runs)
 //   k_fm_deemph_top    one workgroup walks the top level from the carried state (sqrt split)
 //   k_fm_deemph_down   start state of every table one level down
-//   k_fm_deemph_apply  every chunk replayed once from its exact start state -> output
+//   k_fm_deemph_apply  picks each chunk's start state and replays the chunk once -> output
 #define DEEMPH_FAN 16
 
 // Division by a: D24 (5 <= a < 256, dividend < 2^18) takes two full-rate 24-bit multiplies,
