@@ -316,7 +316,10 @@ __device__ __forceinline__ int fast_atan2_dev(int y, int x)
 	const bool neg = x < 0;
 	const int num = (int)(4096u * (neg ? ux + ay : ux - ay));
 	const int den = (int)(neg ? ay - ux : ux + ay);
-	const int ang = (neg ? 12288 : 4096) - num / den;
+	// C's truncating int division through one correctly rounded fp64 division: for |num|, |den| < 2^31 a quotient that
+	// is not an integer lies at least 1/|den| away from the next one while the rounding error is below 2^-22/|den|,
+	// so the truncation is the same -- and the fp64 sequence is about a third of the integer expansion
+	const int ang = (neg ? 12288 : 4096) - (int)((double)num / (double)den);
 	return y < 0 ? -ang : ang;
 }
 
