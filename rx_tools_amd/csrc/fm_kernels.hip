@@ -247,7 +247,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_fm_decimate(
 				// multiply(a, conj(b)), rtl_fm.c:470-474 via 511, wrapping like -fwrapv
 				const int cr = (int)((unsigned)ar * (unsigned)br + (unsigned)aj * (unsigned)bj);
 				const int cj = (int)((unsigned)aj * (unsigned)br - (unsigned)ar * (unsigned)bj);
-				pcm[m_base + j] = (int16_t)fast_atan2_dev(cj, cr);
+				__builtin_nontemporal_store((int16_t)fast_atan2_dev(cj, cr), &pcm[m_base + j]);
 			}
 		}
 	}
