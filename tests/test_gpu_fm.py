@@ -52,6 +52,17 @@ def test_low_pass_geometries(ds, block_len):
     _check(iq, block_len, downsample=ds)
 
 
+@pytest.mark.parametrize("ds", [4, 127, 128, 512, 513, 966, 967, 1000, 4096, 8191, 8192])
+def test_low_pass_decimator_regimes(ds):
+    """the fast decimator's regimes: 24-bit / 32-bit window-edge division (switch near ds = 966), sparse / full
+    lowpassed[] (ds <= 512), one window per several lanes up to one window per half span (ds = 8192)"""
+    block_len = 2 * 32768
+    for sig, n_runs in (("fm", 1), ("noise_full", 2)):
+        iq = _signals(6 * block_len)[sig]
+        _check(iq, block_len, n_runs=n_runs, downsample=ds)
+        _check(iq, block_len, n_runs=n_runs, pipelined=True, downsample=ds, offset_tuning=1)
+
+
 def test_config1_wbfm_240k():
     """BASELINE config 1: -M wbfm -s 240000 (ds=5, deemph_a=19), 1 s = 1.2 M samples as
     9 blocks of 131072 -- through the device path (the CPU plumbing case is in test_oracle)"""
