@@ -1710,11 +1710,16 @@ __global__ __launch_bounds__(256) void k_ch_fft(const uint32_t *__restrict__ iq,
 // The same with the register-blocked transform (fft_device.h), N = 2^M, M = 8..12: N/16 threads per
 // window, 256/(N/16) windows side by side, CH_WPG windows per workgroup so that every channel's
 // outputs leave as one contiguous segment.
-#define CH_WPG 16
-template <int M>
+// windows per workgroup: 32 while the [n_channels][wpg] staging fits beside the transform buffers, else 16
+static inline int ch_wpg(int n_channels) { return n_channels <= 512 ? 32 : 16; }
+// FUSED: also fm_demod (-A fast) for every window but the workgroup's first, straight from the LDS copy of the bins; then
+// only the entries k_ch_demod(sparse) reads are stored in chan_lp (each group's first and last window).  Needs the
+// callback blocks to be whole groups of CH_WPG windows, so that a block's first (libm) window is a group's first.
+template <int M, bool FUSED>
 __global__ __launch_bounds__(256) void k_ch_fftR(const uint32_t *__restrict__ iq, u64 total_windows,
                                                  const uint32_t *__restrict__ twiddle, int first_bin, int n_channels,
-                                                 uint32_t *__restrict__ chan_lp)
+                                                 uint32_t *__restrict__ chan_lp, int16_t *__restrict__ out, u64 out_stride,
+                                                 int *__restrict__ pre_out, int CH_WPG)
 {
 	typedef fft_geom<M> G;
 	constexpr int N = G::N, TPF = G::TPF, FPW = 256 / TPF;
@@ -1742,19 +1747,47 @@ __global__ __launch_bounds__(256) void k_ch_fftR(const uint32_t *__restrict__ iq
 	}
 	__syncthreads();
 	for (int idx = tid; idx < n_channels * CH_WPG; idx += 256) {
-		const int c = idx / CH_WPG, k = idx - c * CH_WPG;
-		if (w0 + k < total_windows)
-			chan_lp[(u64)c * total_windows + w0 + k] = outt[idx];
+		const int c = idx >> (31 - __clz(CH_WPG)), k = idx & (CH_WPG - 1);       // CH_WPG is 16 or 32
+		const u64 w = w0 + k;
+		if (w >= total_windows)
+			continue;
+		const uint32_t a = outt[idx];
+		if (!FUSED) {
+			chan_lp[(u64)c * total_windows + w] = a;
+			continue;
+		}
+		if (k == 0 || k == CH_WPG - 1 || w == total_windows - 1)
+			chan_lp[(u64)c * total_windows + w] = a;
+		if (w == total_windows - 1) {                        // fm_demod's carry, rtl_fm.c:612-613
+			pre_out[2 * c] = lo16(a);
+			pre_out[2 * c + 1] = hi16(a);
+		}
+		if (k) {
+			const uint32_t b = outt[idx - 1];
+			const int ar = lo16(a), aj = hi16(a), br = lo16(b), bj = hi16(b);
+			const int cr = (int)((unsigned)ar * (unsigned)br + (unsigned)aj * (unsigned)bj);
+			const int cj = (int)((unsigned)aj * (unsigned)br - (unsigned)ar * (unsigned)bj);
+			out[(u64)c * out_stride + w] = (int16_t)fast_atan2_dev(cj, cr);
+		}
 	}
 }
 
 // fm_demod (rtl_fm.c:584-615) per channel: thread (c, t); the first window of every callback block
 // goes through the libm discriminator like every block's first sample does in rx_fm
+// sparse = group size of k_ch_fftR<FUSED> (0: dense): only the first window of every group, thread (c, group)
 __global__ void k_ch_demod(const uint32_t *__restrict__ chan_lp, u64 total_windows, u64 wpb, int n_channels, int custom_atan,
                            const int *__restrict__ pre_in, int *__restrict__ pre_out, int16_t *__restrict__ out, u64 out_stride,
-                           rxk_fm_dev *__restrict__ dev, u64 *__restrict__ flag_list)
+                           rxk_fm_dev *__restrict__ dev, u64 *__restrict__ flag_list, int sparse)
 {
-	const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	const int CH_WPG = sparse;                               // the group size of the fused FFT kernel
+	if (sparse) {
+		const u64 groups = (total_windows + CH_WPG - 1) / CH_WPG;
+		if (gid >= (u64)n_channels * groups)
+			return;
+		const u64 cc = gid / groups;
+		gid = cc * total_windows + (gid - cc * groups) * CH_WPG;
+	}
 	if (gid >= (u64)n_channels * total_windows)
 		return;
 	const u64 c = gid / total_windows, t = gid - c * total_windows;
@@ -2084,22 +2117,31 @@ extern "C" int rxk_fm_dc_block(void *stream, int16_t *y, u64 M, rxk_fm_blocks bl
 	LAUNCH_RET();
 }
 
+extern "C" int rxk_ch_fused_ok(int bin_e, u64 wpb, int custom_atan, int n_channels)
+{
+	return (bin_e >= 8 && bin_e <= 12 && custom_atan == 1 && wpb % ch_wpg(n_channels) == 0) ? ch_wpg(n_channels) : 0;
+}
+
 extern "C" int rxk_ch_fft(void *stream, const int16_t *iq, u64 total_windows, int bin_e, const uint32_t *twiddle,
-                          int first_bin, int n_channels, uint32_t *chan_lp)
+                          int first_bin, int n_channels, uint32_t *chan_lp, int fused, int16_t *out, u64 out_stride, int *pre_out)
 {
 	if (!total_windows)
 		return 0;
 	if (bin_e >= 8 && bin_e <= 12) {
+		const int CH_WPG = ch_wpg(n_channels);
 		const size_t shm = (size_t)(2 * 256 * 20 + n_channels * CH_WPG) * 4;
 		const unsigned grid = (unsigned)((total_windows + CH_WPG - 1) / CH_WPG);
 		hipStream_t s = (hipStream_t)stream;
 		const uint32_t *p = (const uint32_t *)iq;
-#define GOC(MM) do { if (shm > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_ch_fftR<MM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
-		hipLaunchKernelGGL((k_ch_fftR<MM>), dim3(grid), dim3(256), shm, s, p, total_windows, twiddle + (1 << (MM - 1)), first_bin, n_channels, chan_lp); } while (0)
+#define GOF(MM, FU) do { if (shm > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_ch_fftR<MM, FU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+		hipLaunchKernelGGL((k_ch_fftR<MM, FU>), dim3(grid), dim3(256), shm, s, p, total_windows, twiddle + (1 << (MM - 1)), first_bin, n_channels, chan_lp, \
+		                   out, out_stride, pre_out, CH_WPG); } while (0)
+#define GOC(MM) do { if (fused) GOF(MM, true); else GOF(MM, false); } while (0)
 		switch (bin_e) {
 		case 8: GOC(8); break; case 9: GOC(9); break; case 10: GOC(10); break; case 11: GOC(11); break; default: GOC(12); break;
 		}
 #undef GOC
+#undef GOF
 		LAUNCH_RET();
 	}
 	int wpg = bin_e >= 13 ? 1 : (8192 >> bin_e);
@@ -2116,12 +2158,12 @@ extern "C" int rxk_ch_fft(void *stream, const int16_t *iq, u64 total_windows, in
 }
 
 extern "C" int rxk_ch_demod(void *stream, const uint32_t *chan_lp, u64 total_windows, u64 wpb, int n_channels, int custom_atan,
-                            const int *pre_in, int *pre_out, int16_t *out, u64 out_stride, rxk_fm_dev *dev, u64 *flag_list)
+                            const int *pre_in, int *pre_out, int16_t *out, u64 out_stride, rxk_fm_dev *dev, u64 *flag_list, int sparse)
 {
-	const u64 total = (u64)n_channels * total_windows;
+	const u64 total = sparse ? (u64)n_channels * ((total_windows + sparse - 1) / sparse) : (u64)n_channels * total_windows;
 	if (!total)
 		return 0;
 	hipLaunchKernelGGL(k_ch_demod, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, chan_lp, total_windows, wpb,
-	                   n_channels, custom_atan, pre_in, pre_out, out, out_stride, dev, flag_list);
+	                   n_channels, custom_atan, pre_in, pre_out, out, out_stride, dev, flag_list, sparse);
 	LAUNCH_RET();
 }

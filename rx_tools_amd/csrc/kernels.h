@@ -143,11 +143,14 @@ int rxk_fm_droop(void *stream, const uint32_t *in, unsigned long long M, const i
 int rxk_fm_prestage(void *stream, const int16_t *in, unsigned n_complex, int rotate, int16_t *out);
 
 /* channeliser (extension): fix_fft per window, selected bins as [channel][window]; then fm_demod per channel */
+/* fused != 0 (allowed when rxk_ch_fused_ok): the FFT kernel also demodulates (-A fast) every window but the first of each
+ * group and keeps only the bins rxk_ch_demod(sparse) needs in chan_lp; out / out_stride / pre_out as for rxk_ch_demod */
+int rxk_ch_fused_ok(int bin_e, unsigned long long wpb, int custom_atan, int n_channels);   /* 0, or the group size to pass as `fused` / `sparse` */
 int rxk_ch_fft(void *stream, const int16_t *iq, unsigned long long total_windows, int bin_e, const uint32_t *twiddle,
-               int first_bin, int n_channels, uint32_t *chan_lp);
+               int first_bin, int n_channels, uint32_t *chan_lp, int fused, int16_t *out, unsigned long long out_stride, int *pre_out);
 int rxk_ch_demod(void *stream, const uint32_t *chan_lp, unsigned long long total_windows, unsigned long long wpb, int n_channels,
                  int custom_atan, const int *pre_in, int *pre_out, int16_t *out, unsigned long long out_stride,
-                 rxk_fm_dev *dev, unsigned long long *flag_list);
+                 rxk_fm_dev *dev, unsigned long long *flag_list, int sparse);
 
 /* ------------------------------------------------------------- rx_power */
 

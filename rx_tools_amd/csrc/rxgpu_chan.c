@@ -124,12 +124,15 @@ int rxgpu_chan_run(rxgpu_chan *s, const int16_t *d_iq, size_t n_blocks, size_t b
 	memset(h, 0, sizeof(*h));
 	RX_HIP(hipMemcpyAsync(s->dev, h, sizeof(*h), hipMemcpyHostToDevice, st));
 	RX_HIP(hipMemcpyAsync(s->pre_dev[0], s->pre_host, nc * 8, hipMemcpyHostToDevice, st));
+	/* -A fast with whole groups of windows per block: fm_demod runs inside the FFT kernel for all but each group's first window */
+	const int fused = rxk_ch_fused_ok(s->p.bin_e, wpb, s->p.custom_atan, s->p.n_channels);
 	rxgpu_prof_begin("ch_fft");
-	RX_K(rxk_ch_fft(st, d_iq, total, s->p.bin_e, s->twiddle_dev, s->p.first_bin, s->p.n_channels, s->chan_lp));
+	RX_K(rxk_ch_fft(st, d_iq, total, s->p.bin_e, s->twiddle_dev, s->p.first_bin, s->p.n_channels, s->chan_lp, fused, d_out, out_stride,
+	                s->pre_dev[1]));
 	rxgpu_prof_end("ch_fft");
 	rxgpu_prof_begin("ch_demod");
 	RX_K(rxk_ch_demod(st, s->chan_lp, total, wpb, s->p.n_channels, s->p.custom_atan, s->pre_dev[0], s->pre_dev[1], d_out, out_stride,
-	                  s->dev, s->flag_list));
+	                  s->dev, s->flag_list, fused));
 	rxgpu_prof_end("ch_demod");
 	RX_HIP(hipMemcpyAsync(h, s->dev, sizeof(*h), hipMemcpyDeviceToHost, st));
 	int *pre_in_copy = malloc(nc * 8);

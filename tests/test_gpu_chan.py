@@ -64,6 +64,9 @@ def gpu_chan(iq, block_len, bin_e, first_bin, n_channels, custom_atan, n_runs=1)
     (8, 0, 256, 2 * 4096, 4),             # every bin
     (12, 100, 7, 2 * 8192, 6),            # two windows per block
     (5, 3, 20, 2 * 1024, 3),
+    (9, 17, 100, 2 * 16384, 5),           # 32 windows per block: the fused demodulator, one group of 32 per block
+    (11, 2000, 96, 2 * 131072, 2),        # 64 windows per block: two groups
+    (10, 0, 1024, 2 * 16384, 3),          # every bin of a 1024 bank: groups of 16 (LDS), fused
 ])
 @pytest.mark.parametrize("custom_atan", [1, 0])
 def test_channeliser_bit_exact(bin_e, first_bin, n_channels, block_len, n_blocks, custom_atan):
@@ -80,6 +83,14 @@ def test_channeliser_carry_across_runs():
     iq = sig_noise(8 * 2 * 8192, seed=72, amp=6000)
     want, want_pre = oracle_chan(iq, 2 * 8192, 10, 10, 64, 1)
     got, pre, _ = gpu_chan(iq, 2 * 8192, 10, 10, 64, 1, n_runs=4)
+    assert np.array_equal(got, want) and np.array_equal(pre, want_pre)
+
+
+def test_channeliser_fused_carry_across_runs():
+    """the fused path (-A fast, whole groups of 32 windows per block) run by run"""
+    iq = sig_fm(6 * 32768, seed=73, amp=12000)
+    want, want_pre = oracle_chan(iq, 2 * 32768, 10, 500, 256, 1)      # 32 windows per block
+    got, pre, _ = gpu_chan(iq, 2 * 32768, 10, 500, 256, 1, n_runs=3)
     assert np.array_equal(got, want) and np.array_equal(pre, want_pre)
 
 
