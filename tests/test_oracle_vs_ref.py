@@ -20,6 +20,9 @@ pytestmark = [pytest.mark.ref, pytest.mark.skipif(not have_ref(), reason="oracle
     dict(downsample=10, custom_atan=2), dict(downsample=10, custom_atan=3),
     dict(downsample=6, squelch_level=40), dict(downsample=6, squelch_level=2000), dict(downsample=6, dc_block_audio=1),
     dict(downsample_passes=3, dc_block_audio=1, squelch_level=100, mode=1, output_scale=1),
+    dict(downsample=4, post_downsample=4), dict(downsample=2, post_downsample=2, dc_block_audio=1), dict(downsample_passes=3, post_downsample=4),
+    dict(downsample=118, dc_block_raw=1), dict(downsample=6, dc_block_raw=1, rdc_block_const=2, dc_avgI=11, dc_avgQ=-3),
+    dict(downsample_passes=3, comp_fir_size=9, dc_block_raw=1, post_downsample=2),
 ])
 def test_fm_stream_matches_reference(params):
     L = ref_fm()
@@ -28,11 +31,18 @@ def test_fm_stream_matches_reference(params):
         for bl in (8192, 16384, 4096 + 8):
             if params.get("downsample_passes") and (bl // 2) % (1 << params["downsample_passes"]):
                 continue
+            if params.get("post_downsample", 1) > 1:
+                # low_pass_simple needs whole groups (rtl_fm.c:374); it reads stale memory otherwise
+                per = (bl // 2) >> params["downsample_passes"] if params.get("downsample_passes") else (bl // 2) // params["downsample"]
+                if ((bl // 2) % params.get("downsample", 1) and not params.get("downsample_passes")) or per % params["post_downsample"]:
+                    continue
             a, la, d = ref_fm_stream(L, iq, bl, **params)
             b, lb, st = oracle_fm_stream(iq, bl, **params)
             assert np.array_equal(a, b) and np.array_equal(la, lb)
-            assert (d.now_r, d.now_j, d.prev_index, d.pre_r, d.pre_j, d.now_lpr, d.prev_lpr_index, d.squelch_hits, d.dc_avg) == \
-                (st.now_r, st.now_j, st.prev_index, st.pre_r, st.pre_j, st.now_lpr, st.prev_lpr_index, st.squelch_hits, st.dc_avg)
+            assert (d.now_r, d.now_j, d.prev_index, d.pre_r, d.pre_j, d.now_lpr, d.prev_lpr_index, d.squelch_hits, d.dc_avg,
+                    d.dc_avgI, d.dc_avgQ) == \
+                (st.now_r, st.now_j, st.prev_index, st.pre_r, st.pre_j, st.now_lpr, st.prev_lpr_index, st.squelch_hits, st.dc_avg,
+                 st.dc_avgI, st.dc_avgQ)
 
 
 def test_struct_layout_matches_reference():
