@@ -185,6 +185,12 @@ int rxk_fm_rdc(void *stream, const int16_t *iq, unsigned long long n_blocks, uns
 /* -o, low_pass_simple (rtl_fm.c:373-387): out[j] = (int16) sum of in[j*step .. j*step+step) */
 int rxk_fm_post_downsample(void *stream, const int16_t *in, unsigned long long n_out, int step, int16_t *out);
 
+/* fix_fft for 2^15 < N <= 2^21 (rtl_power.c:485): the same network on a scratch copy in HBM, one launch per stage.
+ * scratch: cap_blocks * 2^bin_e dwords; dc: 2 ints per (pass, tune) */
+int rxk_pw_fft_big(void *stream, const int16_t *in, size_t tune_stride, size_t pass_stride, int passes, int tunes,
+                   int bin_e, int eff_len, const int *window, const uint32_t *twiddle, int peak_hold,
+                   uint32_t *scratch, size_t cap_blocks, int *dc, long long *avg);
+
 /* ---- rx_sdr output converters (sdr_kernels.hip), rtl_sdr.c:354-391; n16 = int16 count, device pointers */
 int rxk_sdr_cs16_to_8(void *stream, const int16_t *in, unsigned long long n16, int is_unsigned, uint8_t *out);
 int rxk_sdr_cs16_to_cf32(void *stream, const int16_t *in, unsigned long long n16, float *out);

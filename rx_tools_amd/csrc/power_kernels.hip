@@ -508,6 +508,115 @@ __global__ void k_pw_rms_apply(const i64 *__restrict__ t_in, const i64 *__restri
 
 #define LAUNCH_RET() return (int)hipGetLastError()
 
+// ------------------------------------------------------------------ P4-P8, N > 2^15: fix_fft in global memory
+
+// The reference takes FFT lengths up to 2^21 (rtl_power.c:485); beyond 2^15 a block no longer fits LDS, so the same
+// radix-2 network (bit-reversed load, rtl_power.c:275-290, then one launch per stage, 291-318) runs on a scratch copy
+// in HBM, many blocks side by side.  Correct and plain -- these lengths are for 1-Hz-class bins on a narrow range.
+__global__ __launch_bounds__(256) void k_pwb_dc(const int16_t *__restrict__ in, size_t tune_stride, size_t pass_stride, int tunes,
+                                                int eff_len, int *__restrict__ dc)
+{
+	__shared__ i64 red[8];
+	const int tune = blockIdx.x, pass = blockIdx.y, tid = threadIdx.x;
+	const uint32_t *buf = (const uint32_t *)(in + (size_t)pass * pass_stride + (size_t)tune * tune_stride);
+	const int L = eff_len;
+	const int ci = (L + 1) / 2, cq = L / 2;
+	i64 si = 0, sq = 0;
+	for (int c = tid; c < ci; c += 256) {
+		const uint32_t w = buf[c];
+		si += pw_lo(w);
+		if (c < cq) sq += pw_hi(w);
+	}
+	for (int off = 32; off; off >>= 1) { si += __shfl_down(si, off); sq += __shfl_down(sq, off); }
+	if ((tid & 63) == 0) { red[tid >> 6] = si; red[4 + (tid >> 6)] = sq; }
+	__syncthreads();
+	if (tid == 0) {
+		si = red[0] + red[1] + red[2] + red[3];
+		sq = red[4] + red[5] + red[6] + red[7];
+		dc[2 * ((size_t)pass * tunes + tune)] = (int)(short)(si / (i64)L);                       // remove_dc, rtl_power.c:609-624
+		dc[2 * ((size_t)pass * tunes + tune) + 1] = (L > 1) ? (int)(short)(sq / (i64)(L - 1)) : 0;
+	}
+}
+
+// block q = (pass * tunes + tune) * nbpt + blk;  this launch covers blocks q0 .. q0+nq
+__global__ void k_pwb_load(const int16_t *__restrict__ in, size_t tune_stride, size_t pass_stride, int tunes, int nbpt, int bin_e,
+                           int eff_len, const int *__restrict__ window, const int *__restrict__ dc, size_t q0, size_t nq,
+                           uint32_t *__restrict__ scratch)
+{
+	const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const size_t ql = gid >> bin_e;
+	if (ql >= nq)
+		return;
+	const int n = 1 << bin_e, j = (int)(gid & (size_t)(n - 1));
+	const size_t q = q0 + ql, pt = q / (size_t)nbpt;
+	const int blk = (int)(q - pt * (size_t)nbpt);
+	const size_t pass = pt / (size_t)tunes, tune = pt - pass * (size_t)tunes;
+	const uint32_t *buf = (const uint32_t *)(in + pass * pass_stride + tune * tune_stride);
+	const int ci = (eff_len + 1) / 2, cq = eff_len / 2;
+	const int c = blk * n + j;
+	const uint32_t w = buf[c];
+	int vi = pw_lo(w), vq = pw_hi(w);
+	if (c < ci) vi = (int)(short)(vi - dc[2 * pt]);
+	if (c < cq) vq = (int)(short)(vq - dc[2 * pt + 1]);
+	const int coef = window[j];                              // rtl_power.c:749-758: int32 product, int16 truncation
+	scratch[(ql << bin_e) + (__brev((unsigned)j) >> (32 - bin_e))] = pw_pack(vi * coef, vq * coef);
+}
+
+__global__ void k_pwb_stage(uint32_t *__restrict__ scratch, size_t nq, int bin_e, int s, const uint32_t *__restrict__ twiddle)
+{
+	const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const size_t ql = gid >> (bin_e - 1);
+	if (ql >= nq)
+		return;
+	const unsigned b = (unsigned)(gid & (((size_t)1 << (bin_e - 1)) - 1));
+	const unsigned half = 1u << s, t = b & (half - 1);
+	const unsigned lo_i = ((b >> s) << (s + 1)) | t;
+	uint32_t *x = scratch + (ql << bin_e);
+	uint32_t lo = x[lo_i], hi = x[lo_i + half];
+	butterfly(lo, hi, twiddle[(size_t)t << (bin_e - 1 - s)]);
+	x[lo_i] = lo;
+	x[lo_i + half] = hi;
+}
+
+__global__ void k_pwb_acc(const uint32_t *__restrict__ scratch, int tunes, int nbpt, int bin_e, size_t q0, size_t nq, int peak_hold,
+                          i64 *__restrict__ avg)
+{
+	const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const size_t ql = gid >> bin_e;
+	if (ql >= nq)
+		return;
+	const size_t k = gid & (((size_t)1 << bin_e) - 1);
+	const size_t pt = (q0 + ql) / (size_t)nbpt, tune = pt % (size_t)tunes;
+	const uint32_t w = scratch[gid];
+	const i64 re = pw_lo(w), im = pw_hi(w);
+	const i64 pw = re * re + im * im;
+	i64 *a = avg + (tune << bin_e) + k;
+	if (peak_hold) atomicMax((long long *)a, pw);
+	else atomicAdd((unsigned long long *)a, (unsigned long long)pw);
+}
+
+// scratch: cap_blocks * 2^bin_e dwords; dc: 2 ints per (pass, tune)
+extern "C" int rxk_pw_fft_big(void *stream, const int16_t *in, size_t tune_stride, size_t pass_stride, int passes, int tunes,
+                              int bin_e, int eff_len, const int *window, const uint32_t *twiddle, int peak_hold,
+                              uint32_t *scratch, size_t cap_blocks, int *dc, long long *avg)
+{
+	hipStream_t s = (hipStream_t)stream;
+	const size_t n = (size_t)1 << bin_e;
+	const int nbpt = (int)(((size_t)eff_len + 2 * n - 1) / (2 * n));
+	const size_t total = (size_t)passes * (size_t)tunes * (size_t)nbpt;
+	hipLaunchKernelGGL(k_pwb_dc, dim3((unsigned)tunes, (unsigned)passes), dim3(256), 0, s, in, tune_stride, pass_stride, tunes, eff_len, dc);
+	for (size_t q0 = 0; q0 < total; q0 += cap_blocks) {
+		const size_t nq = total - q0 < cap_blocks ? total - q0 : cap_blocks;
+		const unsigned g_full = (unsigned)((nq * n + 255) / 256), g_half = (unsigned)((nq * (n / 2) + 255) / 256);
+		hipLaunchKernelGGL(k_pwb_load, dim3(g_full), dim3(256), 0, s, in, tune_stride, pass_stride, tunes, nbpt, bin_e, eff_len, window, dc,
+		                   q0, nq, scratch);
+		for (int st = 0; st < bin_e; st++)
+			hipLaunchKernelGGL(k_pwb_stage, dim3(g_half), dim3(256), 0, s, scratch, nq, bin_e, st, twiddle);
+		hipLaunchKernelGGL(k_pwb_acc, dim3(g_full), dim3(256), 0, s, scratch, tunes, nbpt, bin_e, q0, nq, peak_hold, (i64 *)avg);
+	}
+	LAUNCH_RET();
+}
+
 extern "C" int rxk_pw_fft(void *stream, const int16_t *in, size_t tune_stride, size_t pass_stride, int passes, int tunes,
                           int bin_e, int eff_len, int dc_len, const int *window, const uint32_t *twiddle, int peak_hold,
                           int passes_per_group, long long *avg)

@@ -181,6 +181,9 @@ struct rxgpu_power_scan {
 	size_t work_cap;
 	long long *rms_t, *rms_p;
 	size_t rms_cap;
+	uint32_t *big_scratch;     /* N > 2^15: FFT blocks in HBM */
+	int *big_dc;
+	size_t big_cap_blocks, big_dc_cap;
 };
 
 /* rtl_fm.c:288-300 == rtl_power.c:213-225 */
@@ -198,7 +201,8 @@ static const int cic_9_tables[11][10] = {
 	{9, -199, -362, 5303, -25505, 77489, -25505, 5303, -362, -199},
 };
 
-#define PW_MAX_BIN_E 15       /* 2^15 complex samples = 128 KiB of the 160 KiB LDS */
+#define PW_LDS_BIN_E 15       /* 2^15 complex samples = 128 KiB of the 160 KiB LDS */
+#define PW_MAX_BIN_E 21       /* frequency_range never asks for more, rtl_power.c:485 */
 
 /* tw[0 .. n/2): the twiddles exactly as fix_fft forms them, rtl_power.c:297-301 (halve AFTER negating), packed
  * (wr, wi); tw[n/2 .. n): the same doubled, (2wr, 2wi) -- what the packed butterfly multiplies by
@@ -226,7 +230,7 @@ int rxgpu_power_scan_create(rxgpu_power_scan **out, const rxgpu_power_params *p,
 	if (p->bin_e < 0 || p->bin_e > 21 || p->buf_len < 2 || (p->buf_len & 1) || p->downsample < 1)
 		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_power_scan_create: bad geometry");
 	if (p->bin_e > PW_MAX_BIN_E)
-		return rxgpu_fail(RXGPU_EUNSUPPORTED, "FFT of 2^%d points does not fit the LDS-resident kernel (max 2^%d)", p->bin_e, PW_MAX_BIN_E);
+		return rxgpu_fail(RXGPU_EUNSUPPORTED, "FFT of 2^%d points: the reference stops at 2^%d (rtl_power.c:485)", p->bin_e, PW_MAX_BIN_E);
 	if (p->bin_e > 0 && (!window_coefs || !sinewave))
 		return rxgpu_fail(RXGPU_EINVAL, "window and sine tables are required for bin_e > 0");
 	if (p->bin_e > 0 && p->buf_len < 2 * (1 << p->bin_e))
@@ -265,6 +269,7 @@ void rxgpu_power_scan_destroy(rxgpu_power_scan *s)
 		return;
 	hipFree(s->window_dev); hipFree(s->twiddle_dev); hipFree(s->fir_dev);
 	hipFree(s->work[0]); hipFree(s->work[1]);
+	hipFree(s->big_scratch); hipFree(s->big_dc);
 	hipFree(s->rms_t); hipFree(s->rms_p);
 	free(s);
 }
@@ -335,8 +340,29 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 	const int ppg = (passes + groups - 1) / groups;
 	const int n_blocks = (eff_len + 2 * (1 << p->bin_e) - 1) / (2 * (1 << p->bin_e));
 	rxgpu_prof_begin("pw_fft");
-	RX_K(rxk_pw_fft(st, fft_in, (size_t)buf_len, (size_t)tunes * (size_t)buf_len, passes, tunes, p->bin_e, eff_len, eff_len,
-	                s->window_dev, s->twiddle_dev, p->peak_hold, ppg, (long long *)d_avg));
+	if (p->bin_e > PW_LDS_BIN_E) {
+		const size_t total = (size_t)passes * (size_t)tunes * (size_t)n_blocks, n = (size_t)1 << p->bin_e;
+		size_t want = ((size_t)1 << 28) / n;                /* up to 1 GiB of scratch */
+		if (want > total) want = total;
+		if (want < 1) want = 1;
+		if (s->big_cap_blocks < want) {
+			hipFree(s->big_scratch);
+			s->big_scratch = NULL; s->big_cap_blocks = 0;
+			RX_HIP(hipMalloc((void **)&s->big_scratch, want * n * 4));
+			s->big_cap_blocks = want;
+		}
+		if (s->big_dc_cap < (size_t)passes * (size_t)tunes) {
+			hipFree(s->big_dc);
+			s->big_dc = NULL; s->big_dc_cap = 0;
+			RX_HIP(hipMalloc((void **)&s->big_dc, (size_t)passes * (size_t)tunes * 8));
+			s->big_dc_cap = (size_t)passes * (size_t)tunes;
+		}
+		RX_K(rxk_pw_fft_big(st, fft_in, (size_t)buf_len, (size_t)tunes * (size_t)buf_len, passes, tunes, p->bin_e, eff_len,
+		                    s->window_dev, s->twiddle_dev, p->peak_hold, s->big_scratch, s->big_cap_blocks, s->big_dc, (long long *)d_avg));
+	} else {
+		RX_K(rxk_pw_fft(st, fft_in, (size_t)buf_len, (size_t)tunes * (size_t)buf_len, passes, tunes, p->bin_e, eff_len, eff_len,
+		                s->window_dev, s->twiddle_dev, p->peak_hold, ppg, (long long *)d_avg));
+	}
 	rxgpu_prof_end("pw_fft");
 	RX_K(rxk_pw_samples(st, d_samples, tunes, n_blocks * ds * passes));   /* rtl_power.c:769 */
 	return RXGPU_OK;

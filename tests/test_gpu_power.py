@@ -61,6 +61,9 @@ CASES = [
     ("100M:102.5M:600", 0.0, "blackman", (1, 0, 0), 32768, 2, 1),   # N=8192
     ("100M:102M:2k", 0.0, "bartlett", (1, 0, 0), 12000, 2, 1),      # N=1024
     ("100M:102M:1500", 0.0, "rectangle", (1, 0, 0), 12000, 2, 1),   # N=2048
+    ("100M:102M:40", 0.0, "hamming", (1, 0, 0), 20000, 2, 1),       # N=2^16: the global-memory network (N > 2^15)
+    ("100M:102.8M:20", 0.0, "rectangle", (1, 0, 1), 32768, 2, 1),   # N=2^18, peak hold, full scale
+    ("100M:102.8M:2", 0.0, "blackman", (1, 0, 0), 3000, 1, 1),      # N=2^21, the reference's largest
     ("100M:110M:1M", 0.0, "rectangle", (1, 0, 0), 5000, 3, 10),     # rms_power path
     ("100M:110M:1M", 0.0, "rectangle", (1, 0, 1), 5000, 3, 10),
 ]
