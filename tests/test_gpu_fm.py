@@ -324,4 +324,4 @@ def test_error_codes():
     with pytest.raises(R.RxGpuError):
         R.FmStream(R.FmParams.wbfm(custom_atan=7), 4, 16384)
     with pytest.raises(R.RxGpuError):
-        R.PowerScan(R.PowerParams(16, 1 << 18, 1, 0, 1, 0, 0), 1, np.ones(1 << 16, np.int32), np.zeros(3 << 14, np.int16))   # FFT too large for LDS
+        R.PowerScan(R.PowerParams(22, 1 << 24, 1, 0, 1, 0, 0), 1, np.ones(1 << 22, np.int32), np.zeros(3 << 20, np.int16))   # beyond the reference's 2^21
