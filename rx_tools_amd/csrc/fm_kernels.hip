@@ -1171,12 +1171,35 @@ __global__ void k_fm_resample(const int16_t *__restrict__ y, u64 n, int fast, in
 	const u64 p0 = (u64)dev->in_prev_lpr_index;
 	const int ratio = fast / slow;
 	if (j < J) {
-		const u64 b = j ? lpr_end(j - 1, fast, slow, p0) : 0;
-		const u64 e = lpr_end(j, fast, slow, p0);
+		// E(j) = floor(((j+1)*fast - p0 + slow - 1) / slow).  One 64-bit division per wave (its first output), then
+		// E(j0 + l) = q0 + floor((r0 + (l+1)*fast) / slow) on 32-bit numerators through exact fp64 divisions
+		u64 b, e;
+		if (fast < (1 << 25)) {
+			const u64 j0 = j - (threadIdx.x & 63);
+			const i64 nb = (i64)(j0 * (u64)fast) - (i64)p0 + (i64)slow - 1;         // < 0 only for j0 == 0
+			i64 q0 = nb >= 0 ? (i64)div_floor((u64)nb, (u64)slow) : -(i64)div_floor((u64)(-nb) + (u64)slow - 1, (u64)slow);
+			const unsigned r0 = (unsigned)(nb - q0 * (i64)slow);
+			const unsigned l = threadIdx.x & 63;
+			const unsigned xb = r0 + l * (unsigned)fast, xe = xb + (unsigned)fast;
+			const i64 bb = q0 + (i64)(unsigned)((double)xb / (double)slow);
+			b = bb > 0 ? (u64)bb : 0;                                                // E(-1) = 0
+			e = (u64)(q0 + (i64)(unsigned)((double)xe / (double)slow));
+		} else {
+			b = j ? lpr_end(j - 1, fast, slow, p0) : 0;
+			e = lpr_end(j, fast, slow, p0);
+		}
 		int sum = j ? 0 : dev->in_now_lpr;
-		for (u64 i = b; i < e; i++)
-			sum += y[i];
-		out[j] = (int16_t)(sum / ratio);
+		for (u64 i = b; i < e; i += 8) {               // eight independent loads in flight, not one after the other
+			int v[8];
+#pragma unroll
+			for (int k = 0; k < 8; k++)
+				v[k] = i + k < e ? y[i + k] : 0;
+#pragma unroll
+			for (int k = 0; k < 8; k++)
+				sum += v[k];
+		}
+		// C's truncating division through fp64 (exact for |sum| < 2^31, see fast_atan2_dev)
+		out[j] = (int16_t)(int)((double)sum / (double)ratio);
 	}
 	if (j == J) {                                 // one extra thread: the carries
 		const u64 b = J ? lpr_end(J - 1, fast, slow, p0) : 0;
