@@ -236,7 +236,28 @@ def main():
         ms, launches = prof("fm_decimate")
         fixups = s.host_fixups
         s.close()
-        del d_iq, d_out
+        del d_out
+        # SURVEY 8(d) config 2 also names the -F variant; and the -M wbfm default decimation.  Same buffer, same
+        # pipelined loop, a few steps each; reported beside the headline, not part of `value`.
+        variants = {}
+        if world == 1:
+            for label, kw, per_in in (("-F cascade, downsample_passes=7 (ds=128)", dict(downsample_passes=7), 128),
+                                      ("-M wbfm default, downsample=6", dict(downsample=6), 6)):
+                d_o = torch.zeros(T // per_in + 64, dtype=torch.int16, device=dev)
+                sv = R.FmStream(R.FmParams.wbfm(**kw), n_blocks, block_len)
+                for _ in range(3):
+                    sv.run_async(d_iq.data_ptr(), n_blocks, block_len, d_o.data_ptr(), d_o.numel())
+                sv.wait()
+                k = max(5, args.steps // 5)
+                tv = time.perf_counter()
+                for _ in range(k):
+                    sv.run_async(d_iq.data_ptr(), n_blocks, block_len, d_o.data_ptr(), d_o.numel())
+                sv.wait()
+                tv = time.perf_counter() - tv
+                variants[label] = {"value": T * k / tv / 1e6, "unit": "MSample/s", "ms_per_step": tv / k * 1e3, "steps": k}
+                sv.close()
+                del d_o
+        del d_iq
         torch.cuda.empty_cache()
         value = world * T * args.steps / dt / 1e6
         traffic, traffic_src = None, None
@@ -259,6 +280,7 @@ def main():
                        "blocks_per_step": n_blocks, "block_complex_samples": block_len // 2,
                        "bytes_per_step": 4 * T, "parallelism": "replicas x%d (rx_fm does not shard)" % world,
                        "host_fixups_last_step": fixups},
+            "rx_fm_variants": variants,
             "roofline": {"bound": "hbm", "kernel": "k_fm_decimate (F0+F1+F2)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": 4 * T, "avg_launch_ms": (ms / launches) if launches else None},
