@@ -165,6 +165,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU baseline budget per path (0 = skip)")
     ap.add_argument("--prof-level", type=int, default=1)
     ap.add_argument("--cpu-worker", default=None, choices=["fm", "power"], help=argparse.SUPPRESS)
+    ap.add_argument("--variants", default="F", choices=["F", "all"], help="rx_fm side figures: the -F cascade (default) or also -M wbfm's ds=6")
     args = ap.parse_args()
     if args.cpu_worker:
         cpu_worker(args.cpu_worker, args.cpu_seconds)
@@ -241,8 +242,12 @@ def main():
         # pipelined loop, a few steps each; reported beside the headline, not part of `value`.
         variants = {}
         if world == 1:
-            for label, kw, per_in in (("-F cascade, downsample_passes=7 (ds=128)", dict(downsample_passes=7), 128),
-                                      ("-M wbfm default, downsample=6", dict(downsample=6), 6)):
+            # (the ds=6 variant launches the headline's own decimator kernel; it is off by default so that the rocprofv3
+            # per-kernel averages of this command describe the headline launches only)
+            todo = [("-F cascade, downsample_passes=7 (ds=128)", dict(downsample_passes=7), 128)]
+            if args.variants == "all":
+                todo.append(("-M wbfm default, downsample=6", dict(downsample=6), 6))
+            for label, kw, per_in in todo:
                 d_o = torch.zeros(T // per_in + 64, dtype=torch.int16, device=dev)
                 sv = R.FmStream(R.FmParams.wbfm(**kw), n_blocks, block_len)
                 for _ in range(3):
