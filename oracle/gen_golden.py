@@ -157,7 +157,8 @@ def plans():
     rows = []
     for rng, crop, boxcar in [("24M:1.7G:1k", 0.0, 1), ("88M:108M:125k", 0.0, 1), ("88M:108M:125k", 0.2, 1),
                               ("100M:100.1M:10", 0.0, 1), ("100M:100.1M:10", 0.0, 0), ("100M:1G:1M", 0.0, 1),
-                              ("100M:100.3M:100", 0.0, 1), ("433M:435M:500", 0.5, 0), ("50M:60M:10k", 0.3, 1)]:
+                              ("100M:100.3M:100", 0.0, 1), ("433M:435M:500", 0.5, 0), ("50M:60M:10k", 0.3, 1),
+                              ("100M:102M:40", 0.0, 1), ("100M:102.8M:20", 0.0, 1), ("100M:102.8M:2", 0.0, 1), ("100M:101M:2", 0.1, 0)]:
         P.ref_power_set_flags(boxcar, 0, 0)
         n = P.ref_power_setup(rng.encode(), crop, b"rectangle")
         t = (TuningState * n).from_address(P.ref_power_tunes())

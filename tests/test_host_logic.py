@@ -28,7 +28,7 @@ def test_config3_geometry():
 
 def test_tables_match_oracle():
     O = oracle()
-    for e in (0, 1, 3, 5, 12, 14):
+    for e in (0, 1, 3, 5, 12, 14, 17):
         n = 1 << e
         want = np.zeros(max(1, n * 3 // 4), np.int16)
         O.rxo_sine_table(e, ptr16(want))
