@@ -4,7 +4,7 @@
 Headline (`value`): complex IQ MSample/s through the rx_fm callback pre-stage + full_demod()
 chain at the "20 Msps" WBFM geometry of BASELINE config 2 (downsample=118 -> 170 ksps ->
 32 ksps audio, -A fast, de-emphasis on), blocks of 131072 complex samples, input resident in
-HBM.  One step = one rxgpu_fm_stream_run over --blocks blocks (default 8192 = 2^30 samples = 4 GiB of cs16).
+HBM.  One step = one rxgpu_fm_stream_run over --blocks blocks (default 16384 = 2^31 samples = 8 GiB of cs16).
 The same JSON line carries, under "rx_power", FFT bins/s of the scanner() chain at the
 config-3 geometry (-f 24M:1.7G:1k: 599 tunes x 16384 int16, N=4096), tunes sharded across the
 ranks with one RCCL gather of the avg[] rows to rank 0 per step.
@@ -159,7 +159,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--blocks", type=int, default=8192, help="rx_fm blocks of 131072 complex samples per step (8192 = 4 GiB of cs16)")
+    ap.add_argument("--blocks", type=int, default=16384, help="rx_fm blocks of 131072 complex samples per step (16384 = 8 GiB of cs16)")
     ap.add_argument("--passes", type=int, default=512, help="rx_power scanner() passes per step (one report interval)")
     ap.add_argument("--workload", default="both", choices=["both", "rx_fm", "rx_power", "chan", "sdr"])
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU baseline budget per path (0 = skip)")
@@ -268,7 +268,7 @@ def main():
         traffic, traffic_src = None, None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))["k_fm_decimate"]
-            # measured on the default 2^30-sample launch; bytes scale with the launch
+            # measured on 2^30-sample launches (--blocks 8192); bytes scale with the launch
             traffic = pmc["hbm_bytes_per_launch"] * (T / float(1 << 30))
             traffic_src = "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per gfx950 note)"
         except (OSError, KeyError, ValueError):
@@ -373,7 +373,7 @@ def main():
     # ------------------------------------------------------------------ channeliser (extension, configs[4])
     if args.workload in ("both", "chan"):
         block_len, bin_e, n_ch = 2 * 131072, 10, 256
-        n_blocks = max(8, args.blocks // 8)                       # 1024 blocks = 512 MiB per step by default
+        n_blocks = max(8, args.blocks // 8)                       # 2048 blocks = 1 GiB per step by default
         base = R.synth.sig_fm(8 * 131072, seed=4242 + rank, amp=600.0)
         d_iq = torch.from_numpy(base).to(dev).repeat(n_blocks // 8 + 1)[: n_blocks * block_len].contiguous()
         T = n_blocks * (block_len // 2)
