@@ -647,7 +647,8 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 	if (!g->passes)
 		s->h_prev_index = (int)(((unsigned long long)g->p0 + g->T) - g->M * (unsigned long long)g->ds);
 	if (p->rate_out2 > 0 && p->mode != RXGPU_MODE_RAW)
-		s->h_prev_lpr_index = (int)((unsigned long long)g->pr0 + g->M * (unsigned long long)p->rate_out2 - g->J * (unsigned long long)p->rate_out);
+		s->h_prev_lpr_index = (int)((unsigned long long)g->pr0 + (g->M / (unsigned long long)g->post) * (unsigned long long)p->rate_out2 -
+		                            g->J * (unsigned long long)p->rate_out);
 	s->chained = 1;
 	s->pending++;
 	s->last = *g;

@@ -181,6 +181,33 @@ def test_post_downsample_and_raw_dc_block(params, block_len):
         assert (carry.dc_avgI, carry.dc_avgQ) == (st.dc_avgI, st.dc_avgQ)
 
 
+def test_random_parameter_sweep():
+    """seeded random parameter sets -- every switch of the chain at once -- HIP against the oracle, two runs each"""
+    rng = np.random.default_rng(20260925)
+    for case in range(48):
+        passes = int(rng.choice([0, 0, 0, 1, 2, 3, 5]))
+        block = int(rng.choice([2048, 4096, 8192, 16384])) * 2
+        n = block // 2
+        ds = int(rng.choice([1, 2, 3, 4, 6, 7, 16, 118, 250]))
+        post = int(rng.choice([1, 1, 1, 2, 4]))
+        params = dict(downsample=ds, downsample_passes=passes, comp_fir_size=int(rng.choice([0, 9])),
+                      custom_atan=int(rng.integers(0, 4)), deemph=int(rng.integers(0, 2)), deemph_a=int(rng.choice([2, 3, 8, 13, 19, 40, 100])),
+                      rate_out=int(rng.choice([170000, 240000, 48000])), rate_out2=int(rng.choice([-1, 32000, 48000, 8000])),
+                      offset_tuning=int(rng.integers(0, 2)), mode=int(rng.choice([0, 0, 0, 1, 2, 3, 4])), output_scale=int(rng.integers(1, 4)),
+                      squelch_level=int(rng.choice([0, 0, 50, 3000])), dc_block_audio=int(rng.integers(0, 2)),
+                      dc_block_raw=int(rng.integers(0, 2)), rdc_block_const=int(rng.integers(1, 12)), post_downsample=post)
+        if params["rate_out2"] > params["rate_out"]:
+            params["rate_out2"] = -1
+        per = (n >> passes) if passes else n // ds
+        if post > 1 and ((not passes and n % ds) or per % post):
+            params["post_downsample"] = 1
+        iq = [sig_fm(4 * n, seed=case), sig_noise(4 * block, seed=case), sig_noise(4 * block, seed=case, amp=300)][case % 3]
+        try:
+            _check(iq, block, n_runs=2, pipelined=bool(case & 1), **params)
+        except Exception as e:
+            raise AssertionError("case %d block %d %r: %s" % (case, block, params, e))
+
+
 def test_post_downsample_needs_whole_groups():
     from gpu_support import to_dev
     import torch

@@ -45,6 +45,35 @@ def test_fm_stream_matches_reference(params):
                  st.dc_avgI, st.dc_avgQ)
 
 
+def test_fm_stream_random_parameter_sweep():
+    """seeded random parameter sets (every switch of the chain at once) through the reference and the restatement"""
+    L = ref_fm()
+    rng = np.random.default_rng(20260925)
+    for case in range(40):
+        passes = int(rng.choice([0, 0, 0, 1, 2, 3, 5]))
+        block = int(rng.choice([2048, 4096, 8192, 16384])) * 2
+        n = block // 2
+        ds = int(rng.choice([1, 2, 3, 4, 6, 7, 16, 118, 250]))
+        post = int(rng.choice([1, 1, 1, 2, 4]))
+        params = dict(downsample=ds, downsample_passes=passes, comp_fir_size=int(rng.choice([0, 9])),
+                      custom_atan=int(rng.integers(0, 4)), deemph=int(rng.integers(0, 2)), deemph_a=int(rng.choice([2, 3, 8, 13, 19, 40, 100])),
+                      rate_out=int(rng.choice([170000, 240000, 48000])), rate_out2=int(rng.choice([-1, 32000, 48000, 8000])),
+                      offset_tuning=int(rng.integers(0, 2)), mode=int(rng.choice([0, 0, 0, 1, 2, 3, 4])), output_scale=int(rng.integers(1, 4)),
+                      squelch_level=int(rng.choice([0, 0, 50, 3000])), dc_block_audio=int(rng.integers(0, 2)),
+                      dc_block_raw=int(rng.integers(0, 2)), rdc_block_const=int(rng.integers(1, 12)), post_downsample=post)
+        if params["rate_out2"] > params["rate_out"]:
+            params["rate_out2"] = -1
+        per = (n >> passes) if passes else n // ds
+        if post > 1 and ((not passes and n % ds) or per % post):
+            params["post_downsample"] = 1
+        iq = [sig_fm(3 * n, seed=case), sig_noise(3 * block, seed=case), sig_noise(3 * block, seed=case, amp=300)][case % 3]
+        a, la, d = ref_fm_stream(L, iq, block, **params)
+        b, lb, st = oracle_fm_stream(iq, block, **params)
+        assert np.array_equal(a, b) and np.array_equal(la, lb), (case, params)
+        assert (d.now_r, d.now_j, d.prev_index, d.pre_r, d.pre_j, d.now_lpr, d.prev_lpr_index, d.squelch_hits, d.dc_avg, d.dc_avgI, d.dc_avgQ) == \
+            (st.now_r, st.now_j, st.prev_index, st.pre_r, st.pre_j, st.now_lpr, st.prev_lpr_index, st.squelch_hits, st.dc_avg, st.dc_avgI, st.dc_avgQ), (case, params)
+
+
 def test_struct_layout_matches_reference():
     from rx_tools_amd.structs import DemodState, DongleState, TuningState
     L, P = ref_fm(), ref_power()
