@@ -46,6 +46,10 @@ const char *rxgpu_last_error(void);
 /* the hipStream_t (as void*) all kernels of this library are launched on */
 void *rxgpu_stream(void);
 int rxgpu_sync(void);
+/* Page-lock / release a host buffer in place (hipHostRegister), so that the host-fed entry points
+ * (rxgpu_fm_stream_run_host, the drop-ins) DMA it without a bounce.  Optional: pageable memory works too. */
+int rxgpu_pin(void *ptr, size_t bytes);
+int rxgpu_unpin(void *ptr);
 
 /* Per-kernel device timing with hipEvents on the launch stream.  level 1 brackets only the
  * kernels that dominate each path ("fm_decimate", "fm_fifth", "pw_fft"), level 2 every
@@ -64,9 +68,15 @@ int rxgpu_prof_get(const char *name, double *total_ms, long *launches);
  * droop_*_hist, now_lpr/prev_lpr_index) exactly as the CPU leaves them.  deemph_filter's
  * function-static `avg` (rtl_fm.c:669) has no field in the struct: it lives in a side-car
  * keyed by the demod_state address (rxgpu_deemph_state).  Covered: -M fm|am|usb|lsb|raw,
- * -A std|fast|lut|ale, -l squelch, -F 0|9, -E deemp|adc, -r.  What the device path does not cover
- * (-o post_downsample, -E rdc, -L level printing) prints to stderr and exit(1): there is no CPU fallback. */
+ * -A std|fast|lut|ale, -l squelch, -F 0|9, -E deemp|adc|rdc (rdc runs in rxgpu_callback), -o, -r.
+ * Not on the device path, by decision: -L level printing (file-static counters of rtl_fm.c) and -o with a block
+ * whose demodulated length is not a multiple of the step (the reference then reads stale data): those print to
+ * stderr and exit(1) -- there is no CPU fallback.
+ * If the block in d->lowpassed is the one rxgpu_callback handed over last (same demod_state, same lp_len, nobody
+ * called rxgpu_dropin_invalidate), the copy it left in HBM is used and the block does not cross PCIe a second time. */
 void rxgpu_full_demod(struct demod_state *d);
+/* a caller that edits d->lowpassed between rxgpu_callback and rxgpu_full_demod says so here */
+void rxgpu_dropin_invalidate(const struct demod_state *d);
 
 /* Replaces rtlsdr_callback(buf, len, ctx) at rtl_fm.c:899 (definition 828-863):
  * mute-zero, CS16 -> 8-bit-range scale, rotate16_90 unless offset tuning, hand-off into
@@ -111,6 +121,23 @@ typedef struct rxgpu_fm_params {
 
 enum { RXGPU_MODE_FM = 0, RXGPU_MODE_AM = 1, RXGPU_MODE_USB = 2, RXGPU_MODE_LSB = 3, RXGPU_MODE_RAW = 4 };
 
+/* Parameter derivation, host only (no device needed): what rx_fm's main() does between getopt and the first block.
+ *   rxgpu_fm_params_init   demod_init's defaults (rtl_fm.c:1086-1115) + the -M switch (1320-1341); mode is one of
+ *                          "fm" "nbfm" "nfm" "wbfm" "wfm" "am" "usb" "lsb" "raw" "iq"; *rate_in receives demod.rate_in
+ *                          (24000, or 170000 for wbfm); downsample_passes stays 0 (set it to 1, like -F does at 1306,
+ *                          with comp_fir_size = the -F argument, before planning)
+ *   rxgpu_fm_plan_settings `rate_in *= post_downsample` (1371), optimal_settings (960-997: downsample,
+ *                          downsample_passes, capture_freq/rate, output_scale) and deemph_a (1410-1415);
+ *                          reads p->downsample_passes (truthy = -F), offset_tuning, mode, deemph, rate_out,
+ *                          post_downsample; writes p->downsample, downsample_passes, output_scale, deemph_a and *plan */
+typedef struct rxgpu_fm_plan {
+	int rate_in;                 /* after the post_downsample multiplication */
+	int downsample, downsample_passes, output_scale, deemph_a;
+	uint32_t capture_freq, capture_rate;   /* dongle.freq / dongle.rate */
+} rxgpu_fm_plan;
+int rxgpu_fm_params_init(rxgpu_fm_params *p, const char *mode, int *rate_in);
+int rxgpu_fm_plan_settings(rxgpu_fm_params *p, int freq, int rate_in, int edge, int time_constant_us, rxgpu_fm_plan *plan);
+
 /* Every value the chain carries from one call to the next (SURVEY.md section 8b contract) */
 typedef struct rxgpu_fm_carry {
 	int now_r, now_j, prev_index;           /* low_pass          rtl_fm.c:139,141 */
@@ -148,20 +175,25 @@ int rxgpu_fm_stream_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks
  * latency-bound audio stages of run r on a second stream; carries are chained on the device.
  * *out_len and block_out_len are filled immediately (they are closed-form in the geometry).
  * rxgpu_fm_stream_wait() blocks until every enqueued run has finished and brings the carries
- * back; get_carry/set_carry/run wait implicitly.  If a libm-discriminator sample of a pipelined
- * sequence is undecided on the device (see host_fixups; never observed), wait() returns
- * RXGPU_EUNSUPPORTED after rolling the carries back to the start of the sequence, and the
- * caller replays those blocks with rxgpu_fm_stream_run. */
+ * back; get_carry/set_carry/run wait implicitly.  At most two runs are in flight: enqueueing run
+ * r+2 first retires run r (normally long finished).  d_iq and d_out of a run must stay valid
+ * until it is retired.  A libm-discriminator sample the device could not decide (see host_fixups:
+ * about 2e-10 of the libm samples) is settled when its run is retired: the host re-evaluates it
+ * with its own libm, patches the demodulated sample and redoes the audio stages of that run and
+ * of the one behind it -- the sequence continues, nothing is rolled back. */
 int rxgpu_fm_stream_run_async(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks, size_t block_len,
                               int16_t *d_out, size_t out_cap, size_t *out_len, int *block_out_len);
 int rxgpu_fm_stream_wait(rxgpu_fm_stream *s);
 
-/* Same with HOST input/output buffers (staged through pinned memory over PCIe). */
+/* Same with HOST input/output buffers: the capture crosses PCIe in chunks of whole blocks into two device
+ * staging buffers on a copy stream while the previous chunk is being demodulated (double-buffered; pin the
+ * buffers with rxgpu_pin for DMA without a bounce), results come back the same way.  Synchronous. */
 int rxgpu_fm_stream_run_host(rxgpu_fm_stream *s, const int16_t *h_iq, size_t n_blocks, size_t block_len,
                              int16_t *h_out, size_t out_cap, size_t *out_len, int *block_out_len);
 
-/* Number of blocks whose libm-discriminator sample had to be re-evaluated on the host in
- * the last run (device fp64 atan2 result too close to an integer boundary to trust). */
+/* Number of libm-discriminator samples re-evaluated on the host since the last wait()/run() began
+ * (device fp64 atan2 result within 2^-33 of a truncation boundary, where a last-ulp difference to
+ * glibc's atan2 could matter). */
 long rxgpu_fm_stream_host_fixups(const rxgpu_fm_stream *s);
 
 /* ------------------------------------------------- rx_fm: channeliser (extension)
@@ -241,6 +273,35 @@ void rxgpu_power_scan_destroy(rxgpu_power_scan *s);
  * Asynchronous on rxgpu_stream(); call rxgpu_sync() (or a hipStreamSynchronize) to wait. */
 int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, int tunes,
                          int64_t *d_avg, int32_t *d_samples);
+
+/* ------------------------------------------------------------ rx_power: tunes sharded over the GPUs of one node
+ *
+ * scanner()'s tunes are independent (rtl_power.c:679-771); rows only meet when main() prints them in tune order
+ * (rtl_power.c:1047-1050).  One process per GPU; rank r scans the contiguous range rxgpu_shard_tunes gives it and one
+ * ncclGather per report interval (RCCL over xGMI, enqueued on rxgpu_stream() behind the scan) brings every rank's
+ * [per][N] int64 avg block and [per] int32 samples to the root, which feeds csv_dbm.  librccl is bound at run time
+ * ($RXGPU_RCCL_LIB, else an already loaded librccl, else the loader path, else /opt/rocm/lib). */
+typedef struct rxgpu_comm rxgpu_comm;
+/* 128 bytes (ncclUniqueId): made on one rank, handed to the others by whatever launched the processes (MPI, a file,
+ * torch.distributed's store ...), then every rank calls rxgpu_comm_create -- collective, like ncclCommInitRank */
+int rxgpu_comm_unique_id(void *id128);
+int rxgpu_comm_create(rxgpu_comm **out, const void *id128, int rank, int world);
+/* or wrap an ncclComm_t the application already has (not destroyed by rxgpu_comm_destroy) */
+int rxgpu_comm_adopt(rxgpu_comm **out, void *nccl_comm, int rank, int world);
+void rxgpu_comm_destroy(rxgpu_comm *c);
+int rxgpu_comm_rank(const rxgpu_comm *c);
+int rxgpu_comm_world(const rxgpu_comm *c);
+const char *rxgpu_comm_library(void);     /* which librccl was bound (NULL: none found) */
+/* rank's tunes: [*first, *first + *count), *per = ceil(total / world) = rows of every rank's padded block */
+int rxgpu_shard_tunes(int rank, int world, int total, int *first, int *count, int *per);
+/* d_avg_local [per][n_bins] int64, d_samples_local [per] int32 (DEVICE) -> on the root d_avg_all [world][per][n_bins],
+ * d_samples_all [world][per] (ignored elsewhere).  Asynchronous on rxgpu_stream().  c == NULL: a single process. */
+int rxgpu_power_gather(rxgpu_comm *c, const int64_t *d_avg_local, const int32_t *d_samples_local, int per, int n_bins,
+                       int64_t *d_avg_all, int32_t *d_samples_all, int root);
+/* rxgpu_power_scan_run over this rank's tunes (d_in_local: [passes][count][buf_len]) followed by the gather */
+int rxgpu_power_scan_run_sharded(rxgpu_power_scan *s, rxgpu_comm *c, const int16_t *d_in_local, int passes, int total_tunes,
+                                 int64_t *d_avg_local, int32_t *d_samples_local, int n_bins,
+                                 int64_t *d_avg_all, int32_t *d_samples_all, int root);
 
 /* ------------------------------------------------------------------ rx_sdr output formats
  *

@@ -167,6 +167,40 @@ def plans():
     np.savez_compressed(os.path.join(OUT, "plans.npz"), rows=np.array([repr(r) for r in rows]))
 
 
+FM_PLAN_ARGS = [
+    ["-M", "wbfm", "-f", "100M"],
+    ["-M", "wbfm", "-f", "100M", "-F", "9"],
+    ["-M", "wbfm", "-f", "97.3M", "-c", "eu"],
+    ["-M", "wbfm", "-f", "100M", "-o", "4", "-E", "rdc"],
+    ["-M", "fm", "-f", "145.5M", "-s", "240000", "-E", "deemp"],
+    ["-M", "fm", "-f", "145.5M", "-s", "240000", "-E", "deemp", "-c", "120"],
+    ["-M", "fm", "-f", "162.55M"],
+    ["-M", "am", "-f", "118.3M", "-s", "12000"],
+    ["-M", "usb", "-f", "14.2M", "-s", "6000", "-F", "0"],
+    ["-M", "lsb", "-f", "7.1M", "-s", "6000", "-E", "edge"],
+    ["-M", "raw", "-f", "433M", "-s", "48000", "-E", "offset"],
+    ["-M", "fm", "-f", "433M", "-s", "1000000"],
+    ["-M", "fm", "-f", "433M", "-s", "2000000", "-A", "lut"],
+    ["-M", "fm", "-f", "433M", "-s", "300000", "-F", "9", "-r", "48000", "-A", "fast"],
+]
+
+
+def fm_plans():
+    """the parameters rx_fm's main() derives (getopt, demod_init, rate_in *= post_downsample, optimal_settings, deemph_a),
+    dumped from the reference's own globals after its main() ran on the fake device (tests/dropin_runner.py plan)"""
+    import json
+    import subprocess
+    import tempfile
+    rows = []
+    runner = os.path.join(ROOT, "tests", "dropin_runner.py")
+    for args in FM_PLAN_ARGS:
+        with tempfile.TemporaryDirectory() as d:
+            out = os.path.join(d, "plan.json")
+            subprocess.run([sys.executable, runner, "plan", out] + args, capture_output=True, timeout=120)
+            rows.append(json.dumps({"args": args, "state": json.load(open(out))}))
+    np.savez_compressed(os.path.join(OUT, "fm_plans.npz"), rows=np.array(rows))
+
+
 def sdr_cases():
     """rx_sdr -F conversions through the reference's own main(): every int16 value once, a packed CS12 stream,
     and the WAV headers of rx_fm -E wav"""
@@ -198,7 +232,7 @@ if __name__ == "__main__":
     saved = os.dup(2)
     os.dup2(devnull, 2)          # the reference's frequency_range reports on stderr
     try:
-        kats(); fm_cases(); power_cases(); plans(); sdr_cases()
+        kats(); fm_cases(); power_cases(); plans(); fm_plans(); sdr_cases()
     finally:
         os.dup2(saved, 2)
     for f in sorted(os.listdir(OUT)):

@@ -15,8 +15,10 @@ _lib = None
 # every symbol include/rxgpu.h declares; tests/test_abi.py checks they are all exported
 EXPORTS = [
     "rxgpu_init", "rxgpu_shutdown", "rxgpu_device_count", "rxgpu_last_error", "rxgpu_stream", "rxgpu_sync",
+    "rxgpu_pin", "rxgpu_unpin",
     "rxgpu_prof_enable", "rxgpu_prof_reset", "rxgpu_prof_get",
-    "rxgpu_full_demod", "rxgpu_callback", "rxgpu_deemph_state", "rxgpu_set_demod_functions",
+    "rxgpu_full_demod", "rxgpu_callback", "rxgpu_deemph_state", "rxgpu_set_demod_functions", "rxgpu_dropin_invalidate",
+    "rxgpu_fm_params_init", "rxgpu_fm_plan_settings",
     "rxgpu_fm_stream_create", "rxgpu_fm_stream_destroy", "rxgpu_fm_stream_set_carry", "rxgpu_fm_stream_get_carry",
     "rxgpu_fm_stream_run", "rxgpu_fm_stream_run_async", "rxgpu_fm_stream_wait", "rxgpu_fm_stream_run_host",
     "rxgpu_fm_stream_host_fixups",
@@ -24,6 +26,8 @@ EXPORTS = [
     "rxgpu_chan_host_fixups",
     "rxgpu_scan", "rxgpu_csv_dbm", "rxgpu_power_plan_range", "rxgpu_sine_table", "rxgpu_window_coefs",
     "rxgpu_power_scan_create", "rxgpu_power_scan_destroy", "rxgpu_power_scan_run",
+    "rxgpu_comm_unique_id", "rxgpu_comm_create", "rxgpu_comm_adopt", "rxgpu_comm_destroy", "rxgpu_comm_rank", "rxgpu_comm_world",
+    "rxgpu_comm_library", "rxgpu_shard_tunes", "rxgpu_power_gather", "rxgpu_power_scan_run_sharded",
     "rxgpu_sdr_in_bytes", "rxgpu_sdr_out_bytes", "rxgpu_sdr_convert", "rxgpu_sdr_convert_host", "rxgpu_wav_header",
 ]
 
@@ -86,6 +90,24 @@ def lib():
         L.rxgpu_sdr_out_bytes.argtypes = [C.c_int, C.c_size_t]
         L.rxgpu_sdr_convert.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
         L.rxgpu_sdr_convert_host.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.rxgpu_pin.argtypes = [C.c_void_p, C.c_size_t]
+        L.rxgpu_unpin.argtypes = [C.c_void_p]
+        L.rxgpu_dropin_invalidate.argtypes = [C.c_void_p]
+        L.rxgpu_dropin_invalidate.restype = None
+        L.rxgpu_fm_params_init.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]
+        L.rxgpu_fm_plan_settings.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.rxgpu_comm_unique_id.argtypes = [C.c_void_p]
+        L.rxgpu_comm_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int]
+        L.rxgpu_comm_adopt.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int]
+        L.rxgpu_comm_destroy.argtypes = [C.c_void_p]
+        L.rxgpu_comm_destroy.restype = None
+        L.rxgpu_comm_rank.argtypes = [C.c_void_p]
+        L.rxgpu_comm_world.argtypes = [C.c_void_p]
+        L.rxgpu_comm_library.restype = C.c_char_p
+        L.rxgpu_shard_tunes.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.rxgpu_power_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.rxgpu_power_scan_run_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                   C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.rxgpu_wav_header.restype = None
         L.rxgpu_wav_header.argtypes = [C.c_int, C.c_int, C.c_void_p]
         _lib = L

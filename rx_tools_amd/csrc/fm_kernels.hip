@@ -411,8 +411,8 @@ __global__ __launch_bounds__(256) void k_fm_disc(
 	const uint32_t *__restrict__ iq, u64 T, int ds, int p0, u64 n_per_block, int rotate, int seams,
 	const uint32_t *lp_raw, const uint32_t *__restrict__ head, const uint32_t *__restrict__ tail,
 	uint32_t *lp /* may alias lp_raw: seam entries are finished in place */, u64 M, int first_mode, u64 uniform_k, int custom_atan, int do_tail,
-	int16_t *__restrict__ pcm, rxk_fm_dev *__restrict__ dev, u64 *__restrict__ flag_list, unsigned out_blocks,
-	int sparse, u64 n_wg, u64 n_blocks, const int *__restrict__ atan_lut, int lp_sparse, int flag_all)
+	int16_t *__restrict__ pcm, rxk_fm_dev *__restrict__ dev, rxk_flag_rec *__restrict__ flag_list, int *__restrict__ flag_cnt,
+	unsigned out_blocks, int sparse, u64 n_wg, u64 n_blocks, const int *__restrict__ atan_lut, int lp_sparse, int flag_all)
 {
 	if (blockIdx.x >= out_blocks) {
 		// ---- low_pass carry: exact int32 sums of the samples after the last complete window
@@ -500,10 +500,15 @@ __global__ __launch_bounds__(256) void k_fm_disc(
 		const double ang = atan2((double)cj, (double)cr);
 		const double v = ang / 3.14159 * 16384.0;
 		out = (int)v;
-		if (v != 0.0 && (flag_all || fabs(v - rint(v)) < 1e-6)) {
-			const int idx = atomicAdd(&dev->flag_cnt, 1);
-			if (idx < RXK_FLAG_CAP)
-				flag_list[idx] = m;
+		if (v != 0.0 && (flag_all || fabs(v - rint(v)) < RXK_LIBM_WINDOW)) {
+			const int idx = atomicAdd(flag_cnt, 1);
+			if (idx < RXK_FLAG_CAP) {
+				rxk_flag_rec r;
+				r.m = m; r.ar = ar; r.aj = aj; r.br = br; r.bj = bj;
+				flag_list[idx] = r;
+			}
+			if (flag_all > 1)
+				out += 77;                               // test hook: only the host's re-evaluation can make this sample right
 		}
 	} else if (custom_atan == 1) {
 		out = fast_atan2_dev(cj, cr);
@@ -1211,14 +1216,29 @@ __global__ void k_fm_resample(const int16_t *__restrict__ y, u64 n, int fast, in
 	}
 }
 
-// pipelined runs: what the previous run left as carries-out is this run's carries-in
-__global__ void k_fm_carry_advance(rxk_fm_dev *dev)
+// pipelined runs: what the previous run left as carries-out is this run's carries-in; the audio-stage carries-in are
+// also kept aside so that those stages can be redone after a host fix-up of a libm sample
+__global__ void k_fm_carry_advance(rxk_fm_dev *dev, int advance, int *snap)
 {
-	dev->in_now_r = dev->out_now_r; dev->in_now_j = dev->out_now_j; dev->in_prev_index = dev->out_prev_index;
-	dev->in_pre_r = dev->out_pre_r; dev->in_pre_j = dev->out_pre_j;
-	dev->in_deemph_avg = dev->out_deemph_avg;
-	dev->in_now_lpr = dev->out_now_lpr; dev->in_prev_lpr_index = dev->out_prev_lpr_index;
-	dev->in_dc_avg = dev->out_dc_avg;
+	if (advance) {
+		dev->in_now_r = dev->out_now_r; dev->in_now_j = dev->out_now_j; dev->in_prev_index = dev->out_prev_index;
+		dev->in_pre_r = dev->out_pre_r; dev->in_pre_j = dev->out_pre_j;
+		dev->in_deemph_avg = dev->out_deemph_avg;
+		dev->in_now_lpr = dev->out_now_lpr; dev->in_prev_lpr_index = dev->out_prev_lpr_index;
+		dev->in_dc_avg = dev->out_dc_avg;
+	}
+	snap[0] = dev->in_deemph_avg; snap[1] = dev->in_now_lpr; snap[2] = dev->in_prev_lpr_index; snap[3] = dev->in_dc_avg;
+}
+
+__global__ void k_fm_audio_carry(rxk_fm_dev *dev, const int *snap)
+{
+	if (snap) {
+		dev->in_deemph_avg = snap[0]; dev->in_now_lpr = snap[1]; dev->in_prev_lpr_index = snap[2]; dev->in_dc_avg = snap[3];
+	} else {
+		dev->in_deemph_avg = dev->out_deemph_avg;
+		dev->in_now_lpr = dev->out_now_lpr; dev->in_prev_lpr_index = dev->out_prev_lpr_index;
+		dev->in_dc_avg = dev->out_dc_avg;
+	}
 }
 
 __global__ void k_fm_passthrough_carry(rxk_fm_dev *dev, int deemph_off, int resample_off)
@@ -1830,7 +1850,7 @@ __global__ void k_ch_demod(const uint32_t *__restrict__ chan_lp, u64 total_windo
 		const double ang = atan2((double)cj, (double)cr);
 		const double r = ang / 3.14159 * 16384.0;
 		v = (int)r;
-		if (r != 0.0 && fabs(r - rint(r)) < 1e-6) {
+		if (r != 0.0 && fabs(r - rint(r)) < RXK_LIBM_WINDOW) {
 			const int idx = atomicAdd(&dev->flag_cnt, 1);
 			if (idx < RXK_FLAG_CAP)
 				flag_list[idx] = gid;
@@ -1892,7 +1912,8 @@ extern "C" int rxk_fm_decimate_generic(void *stream, const int16_t *iq, u64 T, i
 extern "C" int rxk_fm_disc(void *stream, const int16_t *iq, u64 T, int ds, int p0, u64 n_per_block, int prescaled,
                            int rotate, int seams, const uint32_t *lp_raw, const uint32_t *head, const uint32_t *tail,
                            uint32_t *lp, u64 M, int first_mode, u64 uniform_k, int custom_atan, int do_tail,
-                           int16_t *pcm, rxk_fm_dev *dev, u64 *flag_list, int sparse, u64 n_blocks, const int *atan_lut, int lp_sparse, int flag_all)
+                           int16_t *pcm, rxk_fm_dev *dev, rxk_flag_rec *flag_list, int *flag_cnt, int sparse, u64 n_blocks, const int *atan_lut,
+                           int lp_sparse, int flag_all)
 {
 	if (!sparse || !seams)
 		lp_sparse = 0;
@@ -1904,10 +1925,10 @@ extern "C" int rxk_fm_disc(void *stream, const int16_t *iq, u64 T, int ds, int p
 	hipStream_t s = (hipStream_t)stream;
 	if (prescaled)
 		hipLaunchKernelGGL((k_fm_disc<true>), dim3(grid), dim3(256), 0, s, (const uint32_t *)iq, T, ds, p0, n_per_block, 0, seams,
-		                   lp_raw, head, tail, lp, M, first_mode, uniform_k, custom_atan, do_tail, pcm, dev, flag_list, out_blocks, sparse, n_wg, n_blocks, atan_lut, lp_sparse, flag_all);
+		                   lp_raw, head, tail, lp, M, first_mode, uniform_k, custom_atan, do_tail, pcm, dev, flag_list, flag_cnt, out_blocks, sparse, n_wg, n_blocks, atan_lut, lp_sparse, flag_all);
 	else
 		hipLaunchKernelGGL((k_fm_disc<false>), dim3(grid), dim3(256), 0, s, (const uint32_t *)iq, T, ds, p0, n_per_block, rotate, seams,
-		                   lp_raw, head, tail, lp, M, first_mode, uniform_k, custom_atan, do_tail, pcm, dev, flag_list, out_blocks, sparse, n_wg, n_blocks, atan_lut, lp_sparse, flag_all);
+		                   lp_raw, head, tail, lp, M, first_mode, uniform_k, custom_atan, do_tail, pcm, dev, flag_list, flag_cnt, out_blocks, sparse, n_wg, n_blocks, atan_lut, lp_sparse, flag_all);
 	LAUNCH_RET();
 }
 
@@ -2016,9 +2037,15 @@ extern "C" int rxk_fm_resample(void *stream, const int16_t *y, u64 n, int fast, 
 	LAUNCH_RET();
 }
 
-extern "C" int rxk_fm_carry_advance(void *stream, rxk_fm_dev *dev)
+extern "C" int rxk_fm_carry_advance(void *stream, rxk_fm_dev *dev, int advance, int *snap)
 {
-	hipLaunchKernelGGL(k_fm_carry_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, dev);
+	hipLaunchKernelGGL(k_fm_carry_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, dev, advance, snap);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_fm_audio_carry(void *stream, rxk_fm_dev *dev, const int *snap)
+{
+	hipLaunchKernelGGL(k_fm_audio_carry, dim3(1), dim3(1), 0, (hipStream_t)stream, dev, snap);
 	LAUNCH_RET();
 }
 

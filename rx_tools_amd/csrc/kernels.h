@@ -49,6 +49,20 @@ typedef struct rxk_fm_blocks {
 
 #define RXK_FLAG_CAP 4096
 
+/* a libm-discriminator sample the device could not decide: its index in the run's demodulated stream and the two
+ * decimated samples it is made of (a = lp[m], b = lp[m-1] or the carried pre_r/pre_j) -- all the host needs to
+ * re-evaluate it with its own libm */
+typedef struct rxk_flag_rec {
+	unsigned long long m;
+	int ar, aj, br, bj;
+} rxk_flag_rec;
+
+/* |v - rint(v)| below this flags a libm sample, v = atan2(cj,cr) / 3.14159 * 16384 (rtl_fm.c:476-483).  Device atan2
+ * (OCML, <= 2 ulp) and glibc's (<= 1 ulp) differ by <= 3 ulp(pi) = 1.33e-15; the division by 3.14159 is correctly
+ * rounded on both sides (<= 1.1e-16 each way on a quotient <= 1.0000009), the multiplication by 2^14 is exact:
+ * |v_dev - v_host| <= (1.33e-15 / 3.14159 + 2.2e-16) * 16384 = 1.06e-11 < 2^-36.  2^-33 leaves a factor 8. */
+#define RXK_LIBM_WINDOW 0x1p-33
+
 enum { RXK_FIRST_LOWPASS = 0, RXK_FIRST_UNIFORM = 1 };
 
 /* F0+F1+F2 fused (rtl_fm.c:845-848, 309-327, 351-371): cs16 -> scaled -> rotated ->
@@ -74,9 +88,10 @@ int rxk_fm_disc(void *stream, const int16_t *iq, unsigned long long T, int ds, i
                 unsigned long long n_per_block, int prescaled, int rotate, int seams,
                 const uint32_t *lp_raw, const uint32_t *head, const uint32_t *tail,
                 uint32_t *lp, unsigned long long M, int first_mode, unsigned long long uniform_k,
-                int custom_atan, int do_tail, int16_t *pcm, rxk_fm_dev *dev, unsigned long long *flag_list,
+                int custom_atan, int do_tail, int16_t *pcm, rxk_fm_dev *dev, rxk_flag_rec *flag_list, int *flag_cnt,
                 int sparse, unsigned long long n_blocks, const int *atan_lut, int lp_sparse, int flag_all);
-/* flag_all: report EVERY libm sample as undecided (test hook: the host then re-evaluates all of them) */
+/* flag_all: report EVERY libm sample as undecided (test hook: the host then re-evaluates all of them); 2: and store a
+ * deliberately wrong value for it, so that only the host fix-up + the redo of the audio stages can produce the right output */
 /* lp_sparse: lp_raw[] holds only what rxk_fm_decimate(lp_sparse) stored; any other window this kernel needs (a
  * block's first output and its predecessor, the last two outputs) is summed again from iq and stored into lp[] */
 /* pcm == NULL: only finish lp[] (+ the low_pass carry); the discriminator runs later on the final lp[] */
@@ -115,8 +130,11 @@ int rxk_fm_simple_demod(void *stream, const uint32_t *lp, unsigned long long M, 
 /* dc_block_audio_filter (rtl_fm.c:684-697): per-block mean, first-order recursion across blocks, subtract */
 int rxk_fm_dc_block(void *stream, int16_t *y, unsigned long long M, rxk_fm_blocks blk, int adc_block_const,
                     long long *sums, int *avgs, rxk_fm_dev *dev);
-/* chained runs: carries-out -> carries-in on the device */
-int rxk_fm_carry_advance(void *stream, rxk_fm_dev *dev);
+/* chained runs: carries-out -> carries-in on the device (advance != 0); either way the audio-stage carries-in of the
+ * run (deemph_avg, now_lpr, prev_lpr_index, dc_avg) are copied to snap[0..4) so that the stages can be redone later */
+int rxk_fm_carry_advance(void *stream, rxk_fm_dev *dev, int advance, int *snap);
+/* redo of audio stages: their carries-in from a snapshot (snap != NULL) or from the carries-out of the run before */
+int rxk_fm_audio_carry(void *stream, rxk_fm_dev *dev, const int *snap);
 /* carries when a stage is disabled */
 int rxk_fm_passthrough_carry(void *stream, rxk_fm_dev *dev, int deemph_off, int resample_off);
 

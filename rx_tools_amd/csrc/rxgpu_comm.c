@@ -1,0 +1,212 @@
+/* rxgpu_comm.c -- multi-GPU rx_power: tunes sharded over the ranks of one node, one RCCL gather per report
+ * interval to merge the rows on the rank that prints the CSV.
+ *
+ * scanner()'s tunes are independent units (rtl_power.c:679-771: each tuning_state has its own buf16, avg[] and
+ * samples); nothing crosses tunes until main() prints the rows in tune order (rtl_power.c:1047-1050).  So rank r
+ * scans the contiguous range [r*per, min(T,(r+1)*per)), per = ceil(T/W), and its [per][N] int64 avg block and
+ * [per] int32 samples (padded to `per` rows so that the collective is fixed-size) go to the root with ncclGather,
+ * enqueued on the library's own stream right behind the scan kernels -- no host synchronisation, no reduction
+ * (the rows are disjoint), no ring: xGMI is point to point and a gather is W-1 direct transfers into the root.
+ *
+ * librccl is bound at run time (dlopen), so librxgpu.so itself keeps loading on hosts without RCCL; the rccl.h
+ * declarations are used for the types only. */
+#include "rxgpu_internal.h"
+#include <dlfcn.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <rccl/rccl.h>
+
+struct rxgpu_comm {
+	ncclComm_t nccl;
+	int rank, world;
+	int owned;                       /* created here (destroy it) or adopted from the caller */
+};
+
+static struct {
+	void *handle;
+	ncclResult_t (*GetUniqueId)(ncclUniqueId *);
+	ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
+	ncclResult_t (*CommDestroy)(ncclComm_t);
+	ncclResult_t (*Gather)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+	ncclResult_t (*GroupStart)(void);
+	ncclResult_t (*GroupEnd)(void);
+	const char *(*GetErrorString)(ncclResult_t);
+	char path[256];
+} g_rccl;
+static pthread_mutex_t g_rccl_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static int rccl_bind(void)
+{
+	int rc = RXGPU_OK;
+	pthread_mutex_lock(&g_rccl_lock);
+	if (!g_rccl.handle) {
+		/* $RXGPU_RCCL_LIB, else a librccl this process has already loaded (one RCCL per process: a host application
+		 * that brought its own keeps using it), else the loader's search path, else ROCm's default location */
+		const char *env = getenv("RXGPU_RCCL_LIB");
+		const char *cand[] = { env, "librccl.so.1", "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so" };
+		const int flags[] = { RTLD_NOW | RTLD_LOCAL, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD, RTLD_NOW | RTLD_LOCAL, RTLD_NOW | RTLD_LOCAL, RTLD_NOW | RTLD_LOCAL };
+		for (unsigned i = 0; i < sizeof(cand) / sizeof(cand[0]) && !g_rccl.handle; i++) {
+			if (!cand[i] || !*cand[i])
+				continue;
+			g_rccl.handle = dlopen(cand[i], flags[i]);
+			if (g_rccl.handle)
+				snprintf(g_rccl.path, sizeof(g_rccl.path), "%s%s", cand[i], (flags[i] & RTLD_NOLOAD) ? " (already loaded)" : "");
+		}
+		if (!g_rccl.handle) {
+			rc = rxgpu_fail(RXGPU_ENODEV, "librccl not found (set RXGPU_RCCL_LIB): %s", dlerror());
+		} else {
+#define BIND(field, sym) do { *(void **)&g_rccl.field = dlsym(g_rccl.handle, sym); if (!g_rccl.field && rc == RXGPU_OK) \
+	rc = rxgpu_fail(RXGPU_ENODEV, "%s lacks %s", g_rccl.path, sym); } while (0)
+			BIND(GetUniqueId, "ncclGetUniqueId");
+			BIND(CommInitRank, "ncclCommInitRank");
+			BIND(CommDestroy, "ncclCommDestroy");
+			BIND(Gather, "ncclGather");
+			BIND(GroupStart, "ncclGroupStart");
+			BIND(GroupEnd, "ncclGroupEnd");
+			BIND(GetErrorString, "ncclGetErrorString");
+#undef BIND
+			if (rc != RXGPU_OK) {
+				dlclose(g_rccl.handle);
+				g_rccl.handle = NULL;
+			}
+		}
+	}
+	pthread_mutex_unlock(&g_rccl_lock);
+	return rc;
+}
+
+#define RX_NCCL(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) \
+	return rxgpu_fail(RXGPU_ENODEV, "%s failed: %s (%s:%d)", #call, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?", __FILE__, __LINE__); } while (0)
+
+const char *rxgpu_comm_library(void)
+{
+	return rccl_bind() == RXGPU_OK ? g_rccl.path : NULL;
+}
+
+int rxgpu_comm_unique_id(void *id128)
+{
+	int rc;
+	if (!id128)
+		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_comm_unique_id: null buffer");
+	if ((rc = rccl_bind()) != RXGPU_OK)
+		return rc;
+	ncclUniqueId id;
+	RX_NCCL(g_rccl.GetUniqueId(&id));
+	memcpy(id128, &id, sizeof(id));
+	return RXGPU_OK;
+}
+
+int rxgpu_comm_create(rxgpu_comm **out, const void *id128, int rank, int world)
+{
+	int rc;
+	if (!out || !id128 || world < 1 || rank < 0 || rank >= world)
+		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_comm_create: bad arguments (rank %d of %d)", rank, world);
+	if ((rc = rxgpu_ensure_init()) != RXGPU_OK)          /* the communicator binds to the device this process drives */
+		return rc;
+	if ((rc = rccl_bind()) != RXGPU_OK)
+		return rc;
+	rxgpu_comm *c = calloc(1, sizeof(*c));
+	if (!c)
+		return rxgpu_fail(RXGPU_ENOMEM, "out of host memory");
+	ncclUniqueId id;
+	memcpy(&id, id128, sizeof(id));
+	ncclResult_t r = g_rccl.CommInitRank(&c->nccl, world, id, rank);
+	if (r != ncclSuccess) {
+		free(c);
+		return rxgpu_fail(RXGPU_ENODEV, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, g_rccl.GetErrorString(r));
+	}
+	c->rank = rank;
+	c->world = world;
+	c->owned = 1;
+	*out = c;
+	return RXGPU_OK;
+}
+
+int rxgpu_comm_adopt(rxgpu_comm **out, void *nccl_comm, int rank, int world)
+{
+	int rc;
+	if (!out || !nccl_comm || world < 1 || rank < 0 || rank >= world)
+		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_comm_adopt: bad arguments");
+	if ((rc = rccl_bind()) != RXGPU_OK)
+		return rc;
+	rxgpu_comm *c = calloc(1, sizeof(*c));
+	if (!c)
+		return rxgpu_fail(RXGPU_ENOMEM, "out of host memory");
+	c->nccl = (ncclComm_t)nccl_comm;
+	c->rank = rank;
+	c->world = world;
+	c->owned = 0;
+	*out = c;
+	return RXGPU_OK;
+}
+
+void rxgpu_comm_destroy(rxgpu_comm *c)
+{
+	if (!c)
+		return;
+	if (c->owned && c->nccl && g_rccl.CommDestroy) {
+		if (rxgpu_hip_stream())
+			hipStreamSynchronize(rxgpu_hip_stream());
+		g_rccl.CommDestroy(c->nccl);
+	}
+	free(c);
+}
+
+int rxgpu_comm_rank(const rxgpu_comm *c) { return c ? c->rank : 0; }
+int rxgpu_comm_world(const rxgpu_comm *c) { return c ? c->world : 1; }
+
+/* contiguous tune ranges: rank r owns [first, first+count), every rank's block is padded to `per` rows */
+int rxgpu_shard_tunes(int rank, int world, int total, int *first, int *count, int *per)
+{
+	if (world < 1 || rank < 0 || rank >= world || total < 0)
+		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_shard_tunes: rank %d of %d, %d tunes", rank, world, total);
+	const int p = (total + world - 1) / world;
+	int lo = rank * p;
+	if (lo > total) lo = total;
+	int hi = lo + p;
+	if (hi > total) hi = total;
+	if (first) *first = lo;
+	if (count) *count = hi - lo;
+	if (per) *per = p;
+	return RXGPU_OK;
+}
+
+int rxgpu_power_gather(rxgpu_comm *c, const int64_t *d_avg_local, const int32_t *d_samples_local, int per, int n_bins,
+                       int64_t *d_avg_all, int32_t *d_samples_all, int root)
+{
+	if (!d_avg_local || !d_samples_local || per < 1 || n_bins < 1)
+		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_power_gather: bad arguments");
+	hipStream_t st = rxgpu_hip_stream();
+	const int world = c ? c->world : 1, rank = c ? c->rank : 0;
+	if (root < 0 || root >= world)
+		return rxgpu_fail(RXGPU_EINVAL, "root %d outside [0,%d)", root, world);
+	if (rank == root && (!d_avg_all || !d_samples_all))
+		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_power_gather: the root needs the receive buffers");
+	const size_t n_avg = (size_t)per * (size_t)n_bins;
+	if (!c) {                                            /* one process: the "gather" is the rank's own block */
+		if (d_avg_all != d_avg_local)
+			RX_HIP(hipMemcpyAsync(d_avg_all, d_avg_local, n_avg * 8, hipMemcpyDeviceToDevice, st));
+		if (d_samples_all != d_samples_local)
+			RX_HIP(hipMemcpyAsync(d_samples_all, d_samples_local, (size_t)per * 4, hipMemcpyDeviceToDevice, st));
+		return RXGPU_OK;
+	}
+	rxgpu_prof_begin("pw_gather");
+	RX_NCCL(g_rccl.Gather(d_avg_local, d_avg_all, n_avg, ncclInt64, root, c->nccl, st));
+	RX_NCCL(g_rccl.Gather(d_samples_local, d_samples_all, (size_t)per, ncclInt32, root, c->nccl, st));
+	rxgpu_prof_end("pw_gather");
+	return RXGPU_OK;
+}
+
+int rxgpu_power_scan_run_sharded(rxgpu_power_scan *s, rxgpu_comm *c, const int16_t *d_in_local, int passes, int total_tunes,
+                                 int64_t *d_avg_local, int32_t *d_samples_local, int n_bins,
+                                 int64_t *d_avg_all, int32_t *d_samples_all, int root)
+{
+	int rc, count = 0, per = 0;
+	if ((rc = rxgpu_shard_tunes(c ? c->rank : 0, c ? c->world : 1, total_tunes, NULL, &count, &per)) != RXGPU_OK)
+		return rc;
+	if (count > 0 && (rc = rxgpu_power_scan_run(s, d_in_local, passes, count, d_avg_local, d_samples_local)) != RXGPU_OK)
+		return rc;
+	return rxgpu_power_gather(c, d_avg_local, d_samples_local, per, n_bins, d_avg_all, d_samples_all, root);
+}

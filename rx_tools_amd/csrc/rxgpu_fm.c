@@ -8,6 +8,7 @@
 #include "rxgpu_internal.h"
 #include "rxgpu_ref_structs.h"
 #include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -43,7 +44,12 @@ struct rxgpu_fm_stream {
 	int *chunk_pre;                                /* per chunk: its start state for each candidate of its workgroup (scan -> apply) */
 	int *lvl_tab, *lvl_lo, *lvl_gap, *lvl_start;   /* tree levels, packed back to back */
 	size_t lvl_cap;
-	unsigned long long *flag_list;
+	/* libm samples the device could not decide, per run slot (seq & 1): count + records on the device, mirrors in pinned memory */
+	int *flag_cnt_dev;                   /* [2] */
+	rxk_flag_rec *flag_rec_dev;          /* [2][RXK_FLAG_CAP] */
+	int *flag_cnt_host;                  /* [2], pinned */
+	rxk_flag_rec *flag_rec_host;         /* [RXK_FLAG_CAP], pinned */
+	int *snap_dev;                       /* [2][4]: the audio-stage carries-in of the run in each slot */
 	int *atan_lut;                       /* -A lut table (rtl_fm.c:515-526), only when custom_atan == 2 */
 	int *below;                          /* squelch verdict per block */
 	long long *dc_sums;                  /* dc_block_audio: per-block sums and means */
@@ -55,26 +61,33 @@ struct rxgpu_fm_stream {
 	/* pinned host mirrors */
 	rxk_fm_dev *dev_host;
 	int16_t *hist_host;
-	unsigned long long *flag_host;
-	/* host staging for run_host */
-	int16_t *stage_in, *stage_out;
+	/* device staging for run_host: three input chunks in rotation (a chunk must stay put until its run is retired,
+	 * i.e. until the run two behind it is enqueued), one output buffer for the whole call */
+	int16_t *stage_in[3], *stage_out;
 	size_t stage_in_cap, stage_out_cap;
+	hipEvent_t ev_h2d[3];
 	/* de-emphasis geometry */
 	int group, warm, lo0, hi0;
 	int chunk;                           /* de-emphasis scan: samples per chunk */
 	int topcap_override;                 /* $RXGPU_DEEMPH_TOPCAP: forces the multi-level scan (tests) */
 	int flag_all;                        /* $RXGPU_FLAG_ALL: every libm discriminator sample goes through the host re-evaluation (tests) */
 	long fixups;
-	/* pipelining state */
-	hipEvent_t ev_dec[2], ev_small[2];
+	/* pipelining state: at most two runs in flight, run `seq` uses buffer set / slot seq & 1 */
+	hipEvent_t ev_dec[2], ev_small[2], ev_disc[2];
 	int ev_small_valid[2];
-	int db;                              /* decimator buffer set the next run uses */
+	unsigned long long seq;              /* runs enqueued so far */
 	int pending;                         /* runs enqueued and not yet waited for */
 	int chained;                         /* device carries are ahead of the host copy */
 	int h_prev_index, h_prev_lpr_index;  /* the two carries the host can track in closed form */
-	rxgpu_fm_carry carry_at_enqueue;     /* for rolling a pipelined sequence back */
+	struct run_rec {
+		int live;                        /* enqueued, not retired */
+		unsigned long long seq;
+		struct run_geom g;
+		int16_t *d_out, *pcm;
+		rxk_fm_blocks blk;
+		size_t n_blocks;
+	} rec[2];
 	struct run_geom last;
-	int16_t *last_out;
 	rxk_fm_blocks blk;                   /* block ownership of the run in hand */
 	size_t last_n_blocks;
 };
@@ -174,7 +187,7 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 		const char *e = getenv("RXGPU_DEEMPH_TOPCAP");
 		s->topcap_override = (e && atoi(e) > 0) ? atoi(e) : 0;
 		e = getenv("RXGPU_FLAG_ALL");
-		s->flag_all = (e && atoi(e) > 0) ? 1 : 0;
+		s->flag_all = (e && atoi(e) > 0) ? atoi(e) : 0;
 	}
 	s->max_blocks = max_blocks;
 	s->block_len = block_len;
@@ -194,6 +207,7 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 		DMALLOC(s->head[i], n_wg * 4);
 		DMALLOC(s->tail[i], n_wg * 4);
 		if (hipEventCreateWithFlags(&s->ev_dec[i], hipEventDisableTiming) != hipSuccess ||
+		    hipEventCreateWithFlags(&s->ev_disc[i], hipEventDisableTiming) != hipSuccess ||
 		    hipEventCreateWithFlags(&s->ev_small[i], hipEventDisableTiming) != hipSuccess) {
 			rxgpu_fm_stream_destroy(s);
 			return rxgpu_fail(RXGPU_ENODEV, "hipEventCreate failed");
@@ -223,7 +237,9 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 	DMALLOC(s->lvl_lo, s->lvl_cap * 4);
 	DMALLOC(s->lvl_gap, s->lvl_cap * 4);
 	DMALLOC(s->lvl_start, s->lvl_cap * 4);
-	DMALLOC(s->flag_list, RXK_FLAG_CAP * 8);
+	DMALLOC(s->flag_cnt_dev, 2 * sizeof(int));
+	DMALLOC(s->flag_rec_dev, 2 * RXK_FLAG_CAP * sizeof(rxk_flag_rec));
+	DMALLOC(s->snap_dev, 8 * sizeof(int));
 	DMALLOC(s->below, (max_blocks + 1) * 4);
 	DMALLOC(s->dc_sums, (max_blocks + 1) * 8);
 	DMALLOC(s->dc_avgs, (max_blocks + 1) * 4);
@@ -249,11 +265,13 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 	}
 	if (hipHostMalloc((void **)&s->dev_host, sizeof(rxk_fm_dev), 0) != hipSuccess ||
 	    hipHostMalloc((void **)&s->hist_host, HIST_TOTAL * 2, 0) != hipSuccess ||
-	    hipHostMalloc((void **)&s->flag_host, RXK_FLAG_CAP * 8, 0) != hipSuccess ||
+	    hipHostMalloc((void **)&s->flag_rec_host, RXK_FLAG_CAP * sizeof(rxk_flag_rec), 0) != hipSuccess ||
+	    hipHostMalloc((void **)&s->flag_cnt_host, 2 * sizeof(int), 0) != hipSuccess ||
 	    hipHostMalloc((void **)&s->below_host, (max_blocks + 1) * 4, 0) != hipSuccess) {
 		rxgpu_fm_stream_destroy(s);
 		return rxgpu_fail(RXGPU_ENOMEM, "hipHostMalloc failed");
 	}
+	s->flag_cnt_host[0] = s->flag_cnt_host[1] = 0;
 	*out = s;
 	return RXGPU_OK;
 }
@@ -262,14 +280,20 @@ void rxgpu_fm_stream_destroy(rxgpu_fm_stream *s)
 {
 	if (!s)
 		return;
-	if (s->pending) {
+	if (rxgpu_hip_stream()) {
 		hipStreamSynchronize(rxgpu_hip_stream());
 		hipStreamSynchronize(rxgpu_hip_stream2());
+		hipStreamSynchronize(rxgpu_hip_stream3());
 	}
 	for (int i = 0; i < 2; i++) {
 		hipFree(s->lp_raw[i]); hipFree(s->head[i]); hipFree(s->tail[i]);
 		if (s->ev_dec[i]) hipEventDestroy(s->ev_dec[i]);
 		if (s->ev_small[i]) hipEventDestroy(s->ev_small[i]);
+		if (s->ev_disc[i]) hipEventDestroy(s->ev_disc[i]);
+	}
+	for (int i = 0; i < 3; i++) {
+		hipFree(s->stage_in[i]);
+		if (s->ev_h2d[i]) hipEventDestroy(s->ev_h2d[i]);
 	}
 	hipFree(s->lp);
 	hipFree(s->cas[0]); hipFree(s->cas[1]); hipFree(s->seams);
@@ -280,11 +304,12 @@ void rxgpu_fm_stream_destroy(rxgpu_fm_stream *s)
 	if (s->ev_rdc) hipEventDestroy(s->ev_rdc);
 	hipFree(s->atan_lut); hipFree(s->below); hipFree(s->dc_sums); hipFree(s->dc_avgs);
 	if (s->below_host) hipHostFree(s->below_host);
-	hipFree(s->flag_list); hipFree(s->dev); hipFree(s->hist_dev); hipFree(s->fir_dev);
+	hipFree(s->flag_cnt_dev); hipFree(s->flag_rec_dev); hipFree(s->snap_dev);
+	hipFree(s->dev); hipFree(s->hist_dev); hipFree(s->fir_dev);
 	if (s->dev_host) hipHostFree(s->dev_host);
 	if (s->hist_host) hipHostFree(s->hist_host);
-	if (s->flag_host) hipHostFree(s->flag_host);
-	if (s->stage_in) hipFree(s->stage_in);
+	if (s->flag_rec_host) hipHostFree(s->flag_rec_host);
+	if (s->flag_cnt_host) hipHostFree(s->flag_cnt_host);
 	if (s->stage_out) hipFree(s->stage_out);
 	free(s);
 }
@@ -442,8 +467,6 @@ static int run_geometry(rxgpu_fm_stream *s, size_t n_blocks, size_t block_len, s
 			                  "(block of %llu samples, downsample %d)", g->post, g->n, g->ds);
 		g->J = g->M / (unsigned long long)g->post;
 	}
-	if (p->dc_block_raw && (g->n % 4))
-		return rxgpu_fail(RXGPU_EUNSUPPORTED, "-E rdc needs blocks of a multiple of 4 samples");
 	if (p->mode == RXGPU_MODE_RAW) {
 		g->J = 2 * g->M;                         /* raw_demod: result = lowpassed, rtl_fm.c:658-665, 809-811 */
 	} else if (p->rate_out2 > 0) {
@@ -474,6 +497,8 @@ static void block_lengths(const rxgpu_fm_stream *s, const struct run_geom *g, si
 /* Enqueue one run.  The HBM-bound decimator goes on stream A, everything after it (1/ds of the
  * data, latency-bound) on stream B behind an event, so that the next run's decimator overlaps
  * this run's audio stages.  Carries stay on the device between chained runs. */
+static int retire_slot(rxgpu_fm_stream *s, int slot);
+
 static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_blocks, size_t block_len,
                        int16_t *d_out, const struct run_geom *g)
 {
@@ -481,6 +506,12 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 	const rxgpu_fm_params *p = &s->p;
 	const int16_t *d_iq = d_iq_in;
 	int prescaled = p->prescaled;
+	int rc;
+	/* buffer set / flag slot of this run; the run that used it two enqueues ago is retired first (normally long
+	 * finished: its discriminator ran before the previous run's decimator even started) */
+	const int db = (int)(s->seq & 1);
+	if (s->rec[db].live && (rc = retire_slot(s, db)) != RXGPU_OK)
+		return rc;
 	if (p->dc_block_raw) {
 		/* -E rdc: what the callback does before it hands lowpassed[] over (rtl_fm.c:845-857): scale, dc_block_raw_filter,
 		 * rotate16_90 -- written out once, the chain then runs on it as prescaled input */
@@ -492,10 +523,10 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 		d_iq = s->rdc_buf;
 		prescaled = 1;
 	}
-	const int db = s->db;
 	rxk_fm_dev *h = s->dev_host;
 	if (p->deemph)
 		deemph_geometry(s);
+	RX_HIP(hipMemsetAsync(s->flag_cnt_dev + db, 0, sizeof(int), sb));
 
 	if (!s->chained) {
 		/* carries in from the host copy, status cleared */
@@ -518,9 +549,10 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 			memcpy(hh + HIST_DROOP_IN + 9, s->carry.droop_q_hist, 18);
 			RX_HIP(hipMemcpyAsync(s->hist_dev, hh, HIST_TOTAL * 2, hipMemcpyHostToDevice, sb));
 		}
+		RX_K(rxk_fm_carry_advance(sb, s->dev, 0, s->snap_dev + 4 * db));
 	} else {
 		/* carries out of the previous run become this run's carries in, on the device */
-		RX_K(rxk_fm_carry_advance(sb, s->dev));
+		RX_K(rxk_fm_carry_advance(sb, s->dev, 1, s->snap_dev + 4 * db));
 		if (g->passes) {
 			RX_HIP(hipMemcpyAsync(s->hist_dev + HIST_CAS_IN, s->hist_dev + HIST_CAS_OUT, 10 * 12 * 2, hipMemcpyDeviceToDevice, sb));
 			if (p->comp_fir_size == 9)
@@ -529,7 +561,9 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 	}
 
 	s->lp_final = s->lp;
-	s->pcm = s->pcm_buf[0];
+	s->pcm = s->pcm_buf[db];                 /* stays intact until the run is retired: a host fix-up patches it */
+	rxk_flag_rec *const flag_rec = s->flag_rec_dev + (size_t)db * RXK_FLAG_CAP;
+	int *const flag_cnt = s->flag_cnt_dev + db;
 	s->blk.first_mode = g->passes ? RXK_FIRST_UNIFORM : RXK_FIRST_LOWPASS;
 	s->blk.ds = g->ds; s->blk.p0 = g->p0; s->blk.n = g->n; s->blk.k = g->K; s->blk.n_blocks = n_blocks;
 	s->last_n_blocks = n_blocks;
@@ -541,7 +575,6 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 		 * (the drop-in, which must hand lowpassed[] back, runs prescaled) */
 		const int lp_sparse = fused_disc && !prescaled && g->ds <= RXK_LP_SPARSE_MAX_DS;
 		if (g->fast) {
-			s->pcm = s->pcm_buf[db];
 			s->lp_final = s->lp_raw[db];
 			/* buffer set `db` was last read by the audio chain two runs ago */
 			if (s->ev_small_valid[db])
@@ -561,7 +594,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 		/* fast path: lp_raw is finished in place (only seam entries change) and becomes the final decimated IQ */
 		RX_K(rxk_fm_disc(sb, d_iq, g->T, g->ds, g->p0, g->n, prescaled, g->rotate, g->fast, g->fast ? s->lp_raw[db] : s->lp,
 		                 s->head[db], s->tail[db], g->fast ? s->lp_raw[db] : s->lp, g->M, RXK_FIRST_LOWPASS, 0, p->custom_atan, 1,
-		                 split ? NULL : s->pcm, s->dev, s->flag_list, fused_disc, n_blocks, s->atan_lut, g->fast ? lp_sparse : 0, s->flag_all));
+		                 split ? NULL : s->pcm, s->dev, flag_rec, flag_cnt, fused_disc, n_blocks, s->atan_lut, g->fast ? lp_sparse : 0, s->flag_all));
 		rxgpu_prof_end_on("fm_disc", sb);
 	} else {
 		/* F3: cascade (first passes fused where the input is raw), F12 optional; all on stream B */
@@ -612,11 +645,10 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 		if (!split) {
 			rxgpu_prof_begin_on("fm_disc", sb);
 			RX_K(rxk_fm_disc(sb, d_iq, g->T, 1, 0, g->n, prescaled, g->rotate, 0, s->lp_final, NULL, NULL, NULL, g->M,
-			                 RXK_FIRST_UNIFORM, g->K, p->custom_atan, 0, s->pcm, s->dev, s->flag_list, 0, n_blocks, s->atan_lut, 0, s->flag_all));
+			                 RXK_FIRST_UNIFORM, g->K, p->custom_atan, 0, s->pcm, s->dev, flag_rec, flag_cnt, 0, n_blocks, s->atan_lut, 0, s->flag_all));
 			rxgpu_prof_end_on("fm_disc", sb);
 		}
 	}
-	int rc;
 	if (split) {
 		uint32_t *lpw = (uint32_t *)s->lp_final;             /* every producer of lp_final owns it writable */
 		if (p->squelch_level)
@@ -624,7 +656,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 		if (p->mode == RXGPU_MODE_FM) {
 			rxgpu_prof_begin_on("fm_disc", sb);
 			RX_K(rxk_fm_disc(sb, d_iq, g->T, g->ds, g->p0, g->n, prescaled, g->rotate, 0, lpw, NULL, NULL, NULL, g->M,
-			                 s->blk.first_mode, g->K, p->custom_atan, 0, s->pcm, s->dev, s->flag_list, 0, n_blocks, s->atan_lut, 0, s->flag_all));
+			                 s->blk.first_mode, g->K, p->custom_atan, 0, s->pcm, s->dev, flag_rec, flag_cnt, 0, n_blocks, s->atan_lut, 0, s->flag_all));
 			rxgpu_prof_end_on("fm_disc", sb);
 		} else if (p->mode == RXGPU_MODE_RAW) {
 			RX_HIP(hipMemcpyAsync(d_out, lpw, g->M * 4, hipMemcpyDeviceToDevice, sb));
@@ -633,16 +665,17 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 			RX_K(rxk_fm_simple_demod(sb, lpw, g->M, p->mode, p->output_scale, s->pcm));
 		}
 	}
+	/* every kernel that can flag a libm sample has been enqueued: the count comes back behind them, and the event
+	 * tells the host when this run's demodulated samples (and its reads of d_iq) are complete */
+	RX_HIP(hipMemcpyAsync(s->flag_cnt_host + db, flag_cnt, sizeof(int), hipMemcpyDeviceToHost, sb));
+	RX_HIP(hipEventRecord(s->ev_disc[db], sb));
 	rc = p->mode == RXGPU_MODE_RAW ? RXGPU_OK : run_audio_stages(s, sb, g->M, g->J, d_out);
 	if (rc != RXGPU_OK)
 		return rc;
 	if (p->squelch_level)
 		RX_HIP(hipMemcpyAsync(s->below_host, s->below, n_blocks * 4, hipMemcpyDeviceToHost, sb));
-	if (!g->passes && g->fast) {
-		RX_HIP(hipEventRecord(s->ev_small[db], sb));
-		s->ev_small_valid[db] = 1;
-		s->db ^= 1;
-	}
+	RX_HIP(hipEventRecord(s->ev_small[db], sb));
+	s->ev_small_valid[db] = 1;
 	/* what the next run needs from this one on the host side is closed-form */
 	if (!g->passes)
 		s->h_prev_index = (int)(((unsigned long long)g->p0 + g->T) - g->M * (unsigned long long)g->ds);
@@ -652,11 +685,74 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 	s->chained = 1;
 	s->pending++;
 	s->last = *g;
-	s->last_out = d_out;
+	s->rec[db].live = 1;
+	s->rec[db].seq = s->seq++;
+	s->rec[db].g = *g;
+	s->rec[db].d_out = d_out;
+	s->rec[db].pcm = s->pcm;
+	s->rec[db].blk = s->blk;
+	s->rec[db].n_blocks = n_blocks;
 	return RXGPU_OK;
 }
 
-/* Wait for everything enqueued, read the carries back, settle undecided libm samples. */
+/* Settle the libm samples the device left undecided in the run of `slot`, and in the run enqueued behind it (its
+ * audio stages consumed carries that are about to change): re-evaluate them with the host libm -- the one the
+ * reference uses -- patch pcm[], and redo the audio stages from the snapshot of their carries-in.  Everything else
+ * of those runs (decimated IQ, discriminator carries, the other pcm samples) is final already. */
+static int fixup_from(rxgpu_fm_stream *s, int slot)
+{
+	hipStream_t sa = rxgpu_hip_stream(), sb = rxgpu_hip_stream2();
+	int rc;
+	RX_HIP(hipStreamSynchronize(sa));
+	RX_HIP(hipStreamSynchronize(sb));
+	const int other = slot ^ 1;
+	int order[2], n = 0;
+	order[n++] = slot;
+	if (s->rec[other].live && s->rec[other].seq > s->rec[slot].seq)
+		order[n++] = other;
+	for (int i = 0; i < n; i++) {
+		const int q = order[i];
+		struct run_rec *r = &s->rec[q];
+		const int cnt = s->flag_cnt_host[q];
+		if (cnt > RXK_FLAG_CAP)
+			return rxgpu_fail(RXGPU_EUNSUPPORTED, "%d undecided libm discriminator samples in one run (at most %d are recorded)", cnt, RXK_FLAG_CAP);
+		if (cnt) {
+			RX_HIP(hipMemcpy(s->flag_rec_host, s->flag_rec_dev + (size_t)q * RXK_FLAG_CAP, (size_t)cnt * sizeof(rxk_flag_rec), hipMemcpyDeviceToHost));
+			for (int k = 0; k < cnt; k++) {
+				const rxk_flag_rec *f = &s->flag_rec_host[k];
+				const int16_t v = (int16_t)polar_discriminant_host(f->ar, f->aj, f->br, f->bj);
+				RX_HIP(hipMemcpy(r->pcm + f->m, &v, 2, hipMemcpyHostToDevice));
+			}
+			s->fixups += cnt;
+			s->flag_cnt_host[q] = 0;
+		}
+		if (s->p.mode == RXGPU_MODE_RAW)
+			continue;
+		RX_K(rxk_fm_audio_carry(sb, s->dev, i == 0 ? s->snap_dev + 4 * q : NULL));
+		s->pcm = r->pcm;
+		s->blk = r->blk;
+		if ((rc = run_audio_stages(s, sb, r->g.M, r->g.J, r->d_out)) != RXGPU_OK)
+			return rc;
+	}
+	RX_HIP(hipStreamSynchronize(sb));
+	return RXGPU_OK;
+}
+
+/* The run in `slot` leaves the pipeline: its demodulated samples are complete (ev_disc), so the count of undecided
+ * libm samples is known; nearly always zero. */
+static int retire_slot(rxgpu_fm_stream *s, int slot)
+{
+	int rc;
+	if (!s->rec[slot].live)
+		return RXGPU_OK;
+	RX_HIP(hipEventSynchronize(s->ev_disc[slot]));
+	if (s->flag_cnt_host[slot] && (rc = fixup_from(s, slot)) != RXGPU_OK)
+		return rc;
+	s->rec[slot].live = 0;
+	return RXGPU_OK;
+}
+
+/* Wait for everything enqueued, settle undecided libm samples, read the carries back. */
 static int finish_runs(rxgpu_fm_stream *s)
 {
 	hipStream_t sa = rxgpu_hip_stream(), sb = rxgpu_hip_stream2();
@@ -665,51 +761,21 @@ static int finish_runs(rxgpu_fm_stream *s)
 	int rc;
 	if (!s->pending)
 		return RXGPU_OK;
+	/* oldest first */
+	const int first = (s->rec[0].live && s->rec[1].live) ? (s->rec[0].seq < s->rec[1].seq ? 0 : 1) : (s->rec[0].live ? 0 : 1);
+	if ((rc = retire_slot(s, first)) != RXGPU_OK || (rc = retire_slot(s, first ^ 1)) != RXGPU_OK) {
+		s->pending = 0;
+		s->chained = 0;
+		return rc;
+	}
 	const struct run_geom *g = &s->last;
 	if (g->passes)
 		RX_HIP(hipMemcpyAsync(s->hist_host, s->hist_dev, HIST_TOTAL * 2, hipMemcpyDeviceToHost, sb));
 	RX_HIP(hipMemcpyAsync(h, s->dev, sizeof(*h), hipMemcpyDeviceToHost, sb));
 	RX_HIP(hipStreamSynchronize(sb));
 	RX_HIP(hipStreamSynchronize(sa));
-	const int n_pending = s->pending;
 	s->pending = 0;
 	s->chained = 0;
-	s->fixups = 0;
-	if (h->flag_cnt) {
-		/* libm-discriminator samples the device could not decide: re-evaluate them with the host libm
-		 * (the one the reference uses), patch pcm[], redo the audio stages.  Only possible when the
-		 * flagged run is the only one in flight; a pipelined sequence is rolled back instead. */
-		int cnt = h->flag_cnt;
-		if (n_pending > 1 || cnt > RXK_FLAG_CAP) {
-			s->carry = s->carry_at_enqueue;
-			s->h_prev_index = s->carry.prev_index;
-			s->h_prev_lpr_index = s->carry.prev_lpr_index;
-			return rxgpu_fail(RXGPU_EUNSUPPORTED, "%d undecided libm discriminator samples in %d pipelined runs: carries rolled back, "
-			                  "re-run these blocks one rxgpu_fm_stream_run at a time", cnt, n_pending);
-		}
-		RX_HIP(hipMemcpy(s->flag_host, s->flag_list, (size_t)cnt * 8, hipMemcpyDeviceToHost));
-		for (int i = 0; i < cnt; i++) {
-			unsigned long long m = s->flag_host[i];
-			uint32_t a, b;
-			int br, bj;
-			RX_HIP(hipMemcpy(&a, s->lp_final + m, 4, hipMemcpyDeviceToHost));
-			if (m) {
-				RX_HIP(hipMemcpy(&b, s->lp_final + m - 1, 4, hipMemcpyDeviceToHost));
-				br = (int16_t)(b & 0xffff); bj = (int16_t)(b >> 16);
-			} else {
-				br = s->carry.pre_r; bj = s->carry.pre_j;
-			}
-			int16_t v = (int16_t)polar_discriminant_host((int16_t)(a & 0xffff), (int16_t)(a >> 16), br, bj);
-			RX_HIP(hipMemcpy(s->pcm + m, &v, 2, hipMemcpyHostToDevice));
-		}
-		s->fixups = cnt;
-		h->flag_cnt = 0; h->reserved = 0;
-		RX_HIP(hipMemcpyAsync(&s->dev->flag_cnt, &h->flag_cnt, 2 * sizeof(int), hipMemcpyHostToDevice, sb));
-		if ((rc = run_audio_stages(s, sb, g->M, g->J, s->last_out)) != RXGPU_OK)
-			return rc;
-		RX_HIP(hipMemcpyAsync(h, s->dev, sizeof(*h), hipMemcpyDeviceToHost, sb));
-		RX_HIP(hipStreamSynchronize(sb));
-	}
 	rxgpu_prof_collect();
 	if (h->err)
 		return rxgpu_fail(RXGPU_ENODEV, "device-side invariant violated in the de-emphasis scan (err=%d)", h->err);
@@ -752,7 +818,7 @@ int rxgpu_fm_stream_run_async(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_
 	if ((rc = rxgpu_ensure_init()) != RXGPU_OK)
 		return rc;
 	if (!s->pending) {
-		s->carry_at_enqueue = s->carry;
+		s->fixups = 0;
 		s->h_prev_index = s->carry.prev_index;
 		s->h_prev_lpr_index = s->carry.prev_lpr_index;
 	}
@@ -787,39 +853,180 @@ int rxgpu_fm_stream_run(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_blocks
 	return finish_runs(s);
 }
 
+/* chunk of a host-fed call: whole blocks, about 64 MiB (large enough that the per-run launches vanish, small enough
+ * that the first chunk's copy -- the only one nothing overlaps -- is a small part of the call) */
+#define HOST_CHUNK_BYTES ((size_t)64 << 20)
+
+static int run_host_chunked(rxgpu_fm_stream *s, const int16_t *h_iq, size_t n_blocks, size_t block_len,
+                            int16_t *h_out, size_t out_cap, size_t *out_len, int *block_out_len)
+{
+	int rc;
+	hipStream_t sa = rxgpu_hip_stream(), sb = rxgpu_hip_stream2(), sc = rxgpu_hip_stream3();
+	size_t cb = HOST_CHUNK_BYTES / (block_len * 2);
+	if (cb < 1) cb = 1;
+	if (cb > n_blocks) cb = n_blocks;
+	if (cb > s->max_blocks) cb = s->max_blocks;
+	/* squelch and -E rdc finish run by run and count on the host: no gain from chunking, keep them whole */
+	if (s->p.squelch_level || s->p.dc_block_raw)
+		cb = n_blocks;
+	if (n_blocks > s->max_blocks && cb == n_blocks)
+		return rxgpu_fail(RXGPU_ECAPACITY, "stream created for %zu blocks, run asks %zu", s->max_blocks, n_blocks);
+	const size_t chunk_bytes = cb * block_len * 2;
+	if (s->stage_in_cap < chunk_bytes) {
+		for (int i = 0; i < 3; i++) {
+			hipFree(s->stage_in[i]);
+			s->stage_in[i] = NULL;
+		}
+		s->stage_in_cap = 0;
+		for (int i = 0; i < 3; i++) {
+			RX_HIP(hipMalloc((void **)&s->stage_in[i], chunk_bytes));
+			if (!s->ev_h2d[i])
+				RX_HIP(hipEventCreateWithFlags(&s->ev_h2d[i], hipEventDisableTiming));
+		}
+		s->stage_in_cap = chunk_bytes;
+	}
+	/* the whole call's output stays on the device until the end: raw_demod hands lowpassed[] through (2 int16 per
+	 * decimated sample), every other mode at most one per decimated sample; each chunk may round up by one */
+	const size_t n_chunks = (n_blocks + cb - 1) / cb;
+	size_t per_block_M = s->p.downsample_passes ? ((block_len / 2) >> s->p.downsample_passes) + 1
+	                                            : (block_len / 2) / (size_t)(s->p.downsample > 0 ? s->p.downsample : 1) + 2;
+	const size_t out_need = (s->p.mode == RXGPU_MODE_RAW ? 2 : 1) * (per_block_M * n_blocks + 2 * n_chunks) + 16;
+	if (s->stage_out_cap < out_need) {
+		hipFree(s->stage_out);
+		s->stage_out = NULL; s->stage_out_cap = 0;
+		RX_HIP(hipMalloc((void **)&s->stage_out, out_need * 2));
+		s->stage_out_cap = out_need;
+	}
+	size_t total = 0, done = 0;
+	for (size_t c = 0; c < n_chunks; c++) {
+		const size_t nb = n_blocks - done < cb ? n_blocks - done : cb;
+		const int slot = (int)(c % 3);
+		/* chunk c-3 used this buffer; its run was retired when run c-1 was enqueued.  The copy runs on its own stream
+		 * while the runs of the chunks before it are on the compute streams. */
+		RX_HIP(hipMemcpyAsync(s->stage_in[slot], h_iq + done * block_len, nb * block_len * 2, hipMemcpyHostToDevice, sc));
+		RX_HIP(hipEventRecord(s->ev_h2d[slot], sc));
+		/* both compute streams read the capture (decimator on A; discriminator seams, cascade and generic decimator on B) */
+		RX_HIP(hipStreamWaitEvent(sa, s->ev_h2d[slot], 0));
+		RX_HIP(hipStreamWaitEvent(sb, s->ev_h2d[slot], 0));
+		size_t got = 0;
+		rc = rxgpu_fm_stream_run_async(s, s->stage_in[slot], nb, block_len, s->stage_out + total, s->stage_out_cap - total, &got,
+		                               block_out_len ? block_out_len + done : NULL);
+		if (rc != RXGPU_OK) {
+			finish_runs(s);
+			return rc;
+		}
+		total += got;
+		done += nb;
+	}
+	if ((rc = finish_runs(s)) != RXGPU_OK)
+		return rc;
+	if (total > out_cap)
+		return rxgpu_fail(RXGPU_ECAPACITY, "output needs %zu int16, capacity %zu", total, out_cap);
+	if (total)
+		RX_HIP(hipMemcpy(h_out, s->stage_out, total * 2, hipMemcpyDeviceToHost));
+	if (out_len)
+		*out_len = total;
+	return RXGPU_OK;
+}
+
 int rxgpu_fm_stream_run_host(rxgpu_fm_stream *s, const int16_t *h_iq, size_t n_blocks, size_t block_len,
                              int16_t *h_out, size_t out_cap, size_t *out_len, int *block_out_len)
 {
 	int rc;
-	size_t got = 0;
-	if (!s || !h_iq || !h_out)
+	if (!s || !h_iq || !h_out || !n_blocks || block_len < 2 || (block_len & 1))
 		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_fm_stream_run_host: bad arguments");
 	if ((rc = rxgpu_ensure_init()) != RXGPU_OK)
 		return rc;
-	hipStream_t st = rxgpu_hip_stream();
-	size_t in_bytes = n_blocks * block_len * 2;
-	if (s->stage_in_cap < in_bytes) {
-		if (s->stage_in) hipFree(s->stage_in);
-		s->stage_in = NULL; s->stage_in_cap = 0;
-		RX_HIP(hipMalloc((void **)&s->stage_in, in_bytes));
-		s->stage_in_cap = in_bytes;
-	}
-	size_t out_bytes = (s->max_M + 16) * 2;
-	if (s->stage_out_cap < out_bytes) {
-		if (s->stage_out) hipFree(s->stage_out);
-		s->stage_out = NULL; s->stage_out_cap = 0;
-		RX_HIP(hipMalloc((void **)&s->stage_out, out_bytes));
-		s->stage_out_cap = out_bytes;
-	}
-	RX_HIP(hipMemcpyAsync(s->stage_in, h_iq, in_bytes, hipMemcpyHostToDevice, st));
-	rc = rxgpu_fm_stream_run(s, s->stage_in, n_blocks, block_len, s->stage_out, s->max_M + 16, &got, block_out_len);
-	if (rc != RXGPU_OK)
+	if (s->pending && (rc = finish_runs(s)) != RXGPU_OK)
 		return rc;
-	if (got > out_cap)
-		return rxgpu_fail(RXGPU_ECAPACITY, "output needs %zu int16, capacity %zu", got, out_cap);
-	RX_HIP(hipMemcpy(h_out, s->stage_out, got * 2, hipMemcpyDeviceToHost));
-	if (out_len)
-		*out_len = got;
+	return run_host_chunked(s, h_iq, n_blocks, block_len, h_out, out_cap, out_len, block_out_len);
+}
+
+/* ------------------------------------------------------------------ parameter derivation (host only) */
+
+/* demod_init (rtl_fm.c:1086-1115) and the -M switch (1320-1341) */
+int rxgpu_fm_params_init(rxgpu_fm_params *p, const char *mode, int *rate_in)
+{
+	if (!p || !mode)
+		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_fm_params_init: null argument");
+	memset(p, 0, sizeof(*p));
+	int rin = 24000;                         /* DEFAULT_SAMPLE_RATE, rtl_fm.c:73 */
+	p->rate_out = 24000;
+	p->rate_out2 = -1;                       /* "flag for disabled" */
+	p->post_downsample = 1;
+	p->adc_block_const = 9;
+	p->rdc_block_const = 9;
+	p->output_scale = 1;
+	p->mode = RXGPU_MODE_FM;
+	if (!strcmp(mode, "fm") || !strcmp(mode, "nbfm") || !strcmp(mode, "nfm")) {
+		p->mode = RXGPU_MODE_FM;
+	} else if (!strcmp(mode, "raw") || !strcmp(mode, "iq")) {
+		p->mode = RXGPU_MODE_RAW;
+	} else if (!strcmp(mode, "am")) {
+		p->mode = RXGPU_MODE_AM;
+	} else if (!strcmp(mode, "usb")) {
+		p->mode = RXGPU_MODE_USB;
+	} else if (!strcmp(mode, "lsb")) {
+		p->mode = RXGPU_MODE_LSB;
+	} else if (!strcmp(mode, "wbfm") || !strcmp(mode, "wfm")) {
+		p->mode = RXGPU_MODE_FM;
+		rin = 170000;
+		p->rate_out = 170000;
+		p->rate_out2 = 32000;
+		p->custom_atan = 1;
+		p->deemph = 1;
+		p->squelch_level = 0;
+	} else {
+		return rxgpu_fail(RXGPU_EINVAL, "unknown -M mode \"%s\"", mode);
+	}
+	if (rate_in)
+		*rate_in = rin;
+	return RXGPU_OK;
+}
+
+/* `rate_in *= post_downsample` (rtl_fm.c:1371), optimal_settings (960-997), deemph_a (1410-1415) */
+int rxgpu_fm_plan_settings(rxgpu_fm_params *p, int freq, int rate_in, int edge, int time_constant_us, rxgpu_fm_plan *plan)
+{
+	if (!p)
+		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_fm_plan_settings: null argument");
+	if (rate_in <= 0)
+		return rxgpu_fail(RXGPU_EINVAL, "rate_in %d <= 0", rate_in);
+	const int post = p->post_downsample > 0 ? p->post_downsample : 1;
+	rate_in *= post;
+	int downsample = (1000000 / rate_in) + 1;
+	int passes = p->downsample_passes;
+	if (passes) {
+		passes = (int)log2(downsample) + 1;
+		downsample = 1 << passes;
+	}
+	const int capture_rate = downsample * rate_in;
+	int capture_freq = freq;
+	if (!p->offset_tuning)
+		capture_freq = freq + capture_rate / 4;
+	capture_freq += edge * rate_in / 2;
+	int output_scale = (1 << 15) / (128 * downsample);
+	if (output_scale < 1)
+		output_scale = 1;
+	if (p->mode == RXGPU_MODE_FM)
+		output_scale = 1;
+	int deemph_a = p->deemph_a;
+	if (p->deemph) {
+		const double tc = (double)time_constant_us * 1e-6;
+		deemph_a = (int)round(1.0 / ((1.0 - exp(-1.0 / (p->rate_out * tc)))));
+	}
+	p->downsample = downsample;
+	p->downsample_passes = passes;
+	p->output_scale = output_scale;
+	p->deemph_a = deemph_a;
+	if (plan) {
+		plan->rate_in = rate_in;
+		plan->downsample = downsample;
+		plan->downsample_passes = passes;
+		plan->output_scale = output_scale;
+		plan->deemph_a = deemph_a;
+		plan->capture_freq = (uint32_t)capture_freq;
+		plan->capture_rate = (uint32_t)capture_rate;
+	}
 	return RXGPU_OK;
 }
 
@@ -833,22 +1040,35 @@ void rxgpu_set_demod_functions(void *fm, void *am, void *usb, void *lsb, void *r
 }
 
 #define SIDECARS 16
-static struct { const struct demod_state *d; int avg; rxgpu_fm_stream *s; rxgpu_fm_params p; } g_side[SIDECARS];
-static int16_t *g_cb_in, *g_cb_out;          /* device staging for the callback */
+/* side-car of a demod_state: deemph_filter's static accumulator, the stream object, and where the callback left the
+ * block it handed over last (slot of g_cb_pre, its length, still valid?) */
+static struct {
+	const struct demod_state *d;
+	int avg;
+	rxgpu_fm_stream *s;
+	rxgpu_fm_params p;
+	int dev_slot, dev_len, dev_valid;
+} g_side[SIDECARS];
+static int16_t *g_cb_in, *g_cb_pre[2];       /* device: the raw block; the pre-staged block, written / published in turn */
 static int *g_cb_rdc;                        /* -E rdc in the callback: dc_avgI/Q, the block averages, the int64 sums */
+static pthread_mutex_t g_side_lock = PTHREAD_MUTEX_INITIALIZER;
 
 static int side_slot(const struct demod_state *d)
 {
-	int free_slot = -1;
-	for (int i = 0; i < SIDECARS; i++) {
+	int free_slot = -1, found = -1;
+	pthread_mutex_lock(&g_side_lock);
+	for (int i = 0; i < SIDECARS && found < 0; i++) {
 		if (g_side[i].d == d)
-			return i;
-		if (!g_side[i].d && free_slot < 0)
+			found = i;
+		else if (!g_side[i].d && free_slot < 0)
 			free_slot = i;
 	}
-	if (free_slot >= 0)
+	if (found < 0 && free_slot >= 0) {
 		g_side[free_slot].d = d;
-	return free_slot;
+		found = free_slot;
+	}
+	pthread_mutex_unlock(&g_side_lock);
+	return found;
 }
 
 int *rxgpu_deemph_state(const struct demod_state *d)
@@ -857,10 +1077,37 @@ int *rxgpu_deemph_state(const struct demod_state *d)
 	return i < 0 ? NULL : &g_side[i].avg;
 }
 
+void rxgpu_dropin_invalidate(const struct demod_state *d)
+{
+	int i = side_slot(d);
+	if (i >= 0)
+		g_side[i].dev_valid = 0;
+}
+
 static void die(const char *what)
 {
 	fprintf(stderr, "rxgpu: %s: %s\n", what, rxgpu_last_error());
 	exit(1);
+}
+
+/* page-lock the struct members the drop-in DMAs from/to (SURVEY.md section 8b "Ownership"), once per address; a
+ * refusal (already registered, or the platform says no) only means the copies go through the runtime's bounce */
+static void pin_once(const void *ptr, size_t bytes)
+{
+	static const void *seen[64];
+	static int n_seen;
+	pthread_mutex_lock(&g_side_lock);
+	int known = 0;
+	for (int i = 0; i < n_seen; i++)
+		known |= seen[i] == ptr;
+	if (!known && n_seen < 64)
+		seen[n_seen++] = ptr;
+	pthread_mutex_unlock(&g_side_lock);
+	if (known)
+		return;
+	const uintptr_t lo = (uintptr_t)ptr & ~(uintptr_t)4095, hi = ((uintptr_t)ptr + bytes + 4095) & ~(uintptr_t)4095;
+	if (hipHostRegister((void *)lo, hi - lo, hipHostRegisterDefault) != hipSuccess)
+		(void)hipGetLastError();
 }
 
 void rxgpu_full_demod(struct demod_state *d)
@@ -870,6 +1117,8 @@ void rxgpu_full_demod(struct demod_state *d)
 		rxgpu_fail(RXGPU_ECAPACITY, "more than %d demod_state objects", SIDECARS);
 		die("rxgpu_full_demod");
 	}
+	if (rxgpu_ensure_init() != RXGPU_OK)
+		die("rxgpu_full_demod");
 	int mode = RXGPU_MODE_FM;
 	if (g_fn_fm) {
 		void *fn = (void *)d->mode_demod;
@@ -907,6 +1156,8 @@ void rxgpu_full_demod(struct demod_state *d)
 		if (rxgpu_fm_stream_create(&g_side[slot].s, &p, 1, RXGPU_MAXIMUM_BUF_LENGTH) != RXGPU_OK)
 			die("rxgpu_full_demod");
 		g_side[slot].p = p;
+		pin_once(d->lowpassed, sizeof(d->lowpassed));
+		pin_once(d->result, sizeof(d->result));
 	}
 	rxgpu_fm_stream *s = g_side[slot].s;
 	rxgpu_fm_carry c;
@@ -923,8 +1174,35 @@ void rxgpu_full_demod(struct demod_state *d)
 	rxgpu_fm_stream_set_carry(s, &c);
 	const int c_in_prev_index = c.prev_index;
 	size_t got = 0;
-	if (rxgpu_fm_stream_run_host(s, d->lowpassed, 1, (size_t)d->lp_len, d->result, RXGPU_MAXIMUM_BUF_LENGTH, &got, NULL) != RXGPU_OK)
+	hipStream_t st = rxgpu_hip_stream(), sb = rxgpu_hip_stream2();
+	if (g_side[slot].dev_valid && g_side[slot].dev_len == d->lp_len && g_cb_pre[g_side[slot].dev_slot]) {
+		/* the block is the one rxgpu_callback pre-staged: it is still in HBM, no second trip over PCIe.  (The caller
+		 * holds d->rw like the reference's demod thread, rtl_fm.c:922-924, so the callback cannot publish meanwhile.) */
+		const size_t cap = (size_t)RXGPU_MAXIMUM_BUF_LENGTH + 16;
+		if (s->stage_out_cap < cap) {
+			hipFree(s->stage_out);
+			s->stage_out = NULL; s->stage_out_cap = 0;
+			if (hipMalloc((void **)&s->stage_out, cap * 2) != hipSuccess) {
+				rxgpu_fail(RXGPU_ENOMEM, "hipMalloc failed");
+				die("rxgpu_full_demod");
+			}
+			s->stage_out_cap = cap;
+		}
+		if (rxgpu_fm_stream_run(s, g_cb_pre[g_side[slot].dev_slot], 1, (size_t)d->lp_len, s->stage_out, s->stage_out_cap, &got, NULL) != RXGPU_OK)
+			die("rxgpu_full_demod");
+		if (got > RXGPU_MAXIMUM_BUF_LENGTH) {
+			rxgpu_fail(RXGPU_ECAPACITY, "result needs %zu int16", got);
+			die("rxgpu_full_demod");
+		}
+		if (got && hipMemcpyAsync(d->result, s->stage_out, got * 2, hipMemcpyDeviceToHost, sb) != hipSuccess) {
+			rxgpu_fail(RXGPU_ENODEV, "copy of the result failed");
+			die("rxgpu_full_demod");
+		}
+		g_side[slot].dev_valid = 0;
+	} else if (rxgpu_fm_stream_run_host(s, d->lowpassed, 1, (size_t)d->lp_len, d->result, RXGPU_MAXIMUM_BUF_LENGTH, &got, NULL) != RXGPU_OK) {
 		die("rxgpu_full_demod");
+	}
+	(void)st;
 	rxgpu_fm_stream_get_carry(s, &c);
 	/* decimated IQ back into lowpassed[], like the CPU's in-place stages leave it */
 	{
@@ -932,7 +1210,7 @@ void rxgpu_full_demod(struct demod_state *d)
 		unsigned long long n = (unsigned long long)d->lp_len / 2;
 		unsigned long long M = passes ? (n >> passes) : ((unsigned long long)c_in_prev_index + n) / (unsigned long long)d->downsample;
 		const uint32_t *src = s->lp_final;
-		if (hipMemcpy(d->lowpassed, src, M * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+		if (hipMemcpyAsync(d->lowpassed, src, M * 4, hipMemcpyDeviceToHost, sb) != hipSuccess || hipStreamSynchronize(sb) != hipSuccess) {
 			rxgpu_fail(RXGPU_ENODEV, "copy of decimated IQ failed");
 			die("rxgpu_full_demod");
 		}
@@ -963,6 +1241,11 @@ void rxgpu_callback(int16_t *buf, uint32_t len, void *ctx)
 		rxgpu_fail(RXGPU_EINVAL, "callback length %u", len);
 		die("rxgpu_callback");
 	}
+	const int side = side_slot(d);
+	if (side < 0) {
+		rxgpu_fail(RXGPU_ECAPACITY, "more than %d demod_state objects", SIDECARS);
+		die("rxgpu_callback");
+	}
 	if (s->mute) {                                   /* rtl_fm.c:839-843 */
 		for (int i = 0; i < s->mute && i < (int)len; i++)
 			buf[i] = 0;
@@ -971,31 +1254,33 @@ void rxgpu_callback(int16_t *buf, uint32_t len, void *ctx)
 	if (!g_cb_in) {
 		if (hipMalloc((void **)&g_cb_in, RXGPU_MAXIMUM_BUF_LENGTH * 2) != hipSuccess ||
 		    hipMalloc((void **)&g_cb_rdc, 64) != hipSuccess ||
-		    hipMalloc((void **)&g_cb_out, RXGPU_MAXIMUM_BUF_LENGTH * 2) != hipSuccess) {
+		    hipMalloc((void **)&g_cb_pre[0], RXGPU_MAXIMUM_BUF_LENGTH * 2) != hipSuccess ||
+		    hipMalloc((void **)&g_cb_pre[1], RXGPU_MAXIMUM_BUF_LENGTH * 2) != hipSuccess) {
 			rxgpu_fail(RXGPU_ENOMEM, "hipMalloc failed");
 			die("rxgpu_callback");
 		}
+		pin_once(s->buf16, sizeof(s->buf16));
 	}
-	hipStream_t st = rxgpu_hip_stream();
-	int ok = hipMemcpyAsync(g_cb_in, buf, (size_t)len * 2, hipMemcpyHostToDevice, st) == hipSuccess;
-	if (ok && d->dc_block_raw) {
+	/* write the slot that is NOT published: full_demod may be reading the published one right now (it runs under
+	 * d->rw; the publication below happens under d->rw too) */
+	const int w = g_side[side].dev_valid ? g_side[side].dev_slot ^ 1 : 0;
+	int16_t *pre = g_cb_pre[w];
+	hipStream_t st = rxgpu_hip_stream3();            /* its own stream: the demod thread's runs use the other two */
+	int ok = !len || hipMemcpyAsync(g_cb_in, buf, (size_t)len * 2, hipMemcpyHostToDevice, st) == hipSuccess;
+	if (ok && len && d->dc_block_raw) {
 		/* rtl_fm.c:850-852: scale, dc_block_raw_filter, rotate; g_cb_rdc = state[2] | avg[2] | sums[2] */
 		int state[2] = { d->dc_avgI, d->dc_avgQ };
-		if ((len / 2) % 4) {
-			rxgpu_fail(RXGPU_EUNSUPPORTED, "-E rdc needs blocks of a multiple of 4 samples (got %u)", len / 2);
-			die("rxgpu_callback");
-		}
 		ok = hipMemcpyAsync(g_cb_rdc, state, 8, hipMemcpyHostToDevice, st) == hipSuccess &&
 		     rxk_fm_rdc(st, g_cb_in, 1, len / 2, 0, !s->offset_tuning, d->rdc_block_const, g_cb_rdc, (long long *)(g_cb_rdc + 4),
-		                g_cb_rdc + 2, g_cb_out) == 0 &&
+		                g_cb_rdc + 2, pre) == 0 &&
 		     hipMemcpyAsync(state, g_cb_rdc, 8, hipMemcpyDeviceToHost, st) == hipSuccess &&
-		     hipMemcpyAsync(s->buf16, g_cb_out, (size_t)len * 2, hipMemcpyDeviceToHost, st) == hipSuccess &&
+		     hipMemcpyAsync(s->buf16, pre, (size_t)len * 2, hipMemcpyDeviceToHost, st) == hipSuccess &&
 		     hipStreamSynchronize(st) == hipSuccess;
 		d->dc_avgI = state[0];
 		d->dc_avgQ = state[1];
-	} else if (ok) {
-		ok = rxk_fm_prestage(st, g_cb_in, len / 2, !s->offset_tuning, g_cb_out) == 0 &&
-		     hipMemcpyAsync(s->buf16, g_cb_out, (size_t)len * 2, hipMemcpyDeviceToHost, st) == hipSuccess &&
+	} else if (ok && len) {
+		ok = rxk_fm_prestage(st, g_cb_in, len / 2, !s->offset_tuning, pre) == 0 &&
+		     hipMemcpyAsync(s->buf16, pre, (size_t)len * 2, hipMemcpyDeviceToHost, st) == hipSuccess &&
 		     hipStreamSynchronize(st) == hipSuccess;
 	}
 	if (!ok) {
@@ -1005,6 +1290,9 @@ void rxgpu_callback(int16_t *buf, uint32_t len, void *ctx)
 	pthread_rwlock_wrlock(&d->rw);                   /* rtl_fm.c:858-862 */
 	memcpy(d->lowpassed, s->buf16, 2 * (size_t)len);
 	d->lp_len = (int)len;
+	g_side[side].dev_slot = w;
+	g_side[side].dev_len = (int)len;
+	g_side[side].dev_valid = len > 0;
 	pthread_rwlock_unlock(&d->rw);
 	pthread_mutex_lock(&d->ready_m);
 	pthread_cond_signal(&d->ready);

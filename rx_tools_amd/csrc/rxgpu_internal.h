@@ -18,6 +18,7 @@ int rxgpu_fail(int code, const char *fmt, ...);
 int rxgpu_ensure_init(void);
 hipStream_t rxgpu_hip_stream(void);
 hipStream_t rxgpu_hip_stream2(void);   /* second stream: the latency-bound tail of a pipelined rx_fm run */
+hipStream_t rxgpu_hip_stream3(void);   /* third stream: host <-> device copies of the host-fed entry points */
 
 #define RX_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
 	return rxgpu_fail(RXGPU_ENODEV, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)

@@ -11,6 +11,7 @@
 #include "rxgpu_internal.h"
 #include "rxgpu_ref_structs.h"
 #include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -370,17 +371,38 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 
 /* ------------------------------------------------------------------ drop-ins */
 
-int rxgpu_scan(struct tuning_state *tunes, int tune_count, const int *window_coefs,
-               const int16_t *sinewave, int boxcar, int comp_fir_size, int peak_hold)
+/* scanner() is called once per sweep for the life of the process with the same geometry and tables (rtl_power.c:1040-1046):
+ * the scan object, its device tables and the three device buffers are kept between calls and only rebuilt when the
+ * geometry or a table changes. */
+static struct {
+	rxgpu_power_scan *s;
+	rxgpu_power_params p;
+	int tune_cap;
+	int *window_copy;
+	int16_t *sine_copy;
+	int16_t *d_in;
+	int64_t *d_avg;
+	int32_t *d_samples;
+	int64_t *h_avg;                  /* pinned staging: tunes[i].avg are separate mallocs of the caller */
+	int16_t *h_in;
+} g_scan;
+static pthread_mutex_t g_scan_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static void scan_cache_drop(void)
+{
+	rxgpu_power_scan_destroy(g_scan.s);
+	free(g_scan.window_copy); free(g_scan.sine_copy);
+	hipFree(g_scan.d_in); hipFree(g_scan.d_avg); hipFree(g_scan.d_samples);
+	if (g_scan.h_avg) hipHostFree(g_scan.h_avg);
+	if (g_scan.h_in) hipHostFree(g_scan.h_in);
+	memset(&g_scan, 0, sizeof(g_scan));
+}
+
+static int scan_locked(struct tuning_state *tunes, int tune_count, const int *window_coefs,
+                       const int16_t *sinewave, int boxcar, int comp_fir_size, int peak_hold)
 {
 	int rc;
-	rxgpu_power_scan *s = NULL;
 	rxgpu_power_params p;
-	int16_t *d_in = NULL;
-	int64_t *d_avg = NULL;
-	int32_t *d_samples = NULL;
-	if (!tunes || tune_count < 1)
-		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_scan: no tunes");
 	/* scanner() uses tunes[0]'s geometry for every tune, rtl_power.c:676-678 */
 	memset(&p, 0, sizeof(p));
 	p.bin_e = tunes[0].bin_e;
@@ -390,76 +412,109 @@ int rxgpu_scan(struct tuning_state *tunes, int tune_count, const int *window_coe
 	p.boxcar = boxcar;
 	p.comp_fir_size = comp_fir_size;
 	p.peak_hold = peak_hold;
-	if ((rc = rxgpu_power_scan_create(&s, &p, tune_count, window_coefs, sinewave)) != RXGPU_OK)
-		return rc;
 	const size_t n = (size_t)1 << p.bin_e;
-	const size_t in_bytes = (size_t)tune_count * p.buf_len * 2;
-	rc = RXGPU_ENOMEM;
-	if (hipMalloc((void **)&d_in, in_bytes) != hipSuccess || hipMalloc((void **)&d_avg, (size_t)tune_count * n * 8) != hipSuccess ||
-	    hipMalloc((void **)&d_samples, (size_t)tune_count * 4) != hipSuccess) {
-		rxgpu_fail(RXGPU_ENOMEM, "rxgpu_scan: hipMalloc failed");
-		goto done;
+	const size_t n_sine = n * 3 / 4 ? n * 3 / 4 : 1;
+	int same = g_scan.s && !memcmp(&p, &g_scan.p, sizeof(p)) && tune_count <= g_scan.tune_cap;
+	if (same && p.bin_e > 0)
+		same = window_coefs && sinewave && !memcmp(g_scan.window_copy, window_coefs, n * sizeof(int)) &&
+		       !memcmp(g_scan.sine_copy, sinewave, n_sine * sizeof(int16_t));
+	if (!same) {
+		scan_cache_drop();
+		if ((rc = rxgpu_power_scan_create(&g_scan.s, &p, tune_count, window_coefs, sinewave)) != RXGPU_OK)
+			return rc;
+		g_scan.p = p;
+		g_scan.tune_cap = tune_count;
+		if (p.bin_e > 0) {
+			g_scan.window_copy = malloc(n * sizeof(int));
+			g_scan.sine_copy = malloc(n_sine * sizeof(int16_t));
+			if (!g_scan.window_copy || !g_scan.sine_copy) {
+				scan_cache_drop();
+				return rxgpu_fail(RXGPU_ENOMEM, "out of host memory");
+			}
+			memcpy(g_scan.window_copy, window_coefs, n * sizeof(int));
+			memcpy(g_scan.sine_copy, sinewave, n_sine * sizeof(int16_t));
+		}
+		if (hipMalloc((void **)&g_scan.d_in, (size_t)tune_count * p.buf_len * 2) != hipSuccess ||
+		    hipMalloc((void **)&g_scan.d_avg, (size_t)tune_count * n * 8) != hipSuccess ||
+		    hipMalloc((void **)&g_scan.d_samples, (size_t)tune_count * 4 + 4) != hipSuccess ||
+		    hipHostMalloc((void **)&g_scan.h_avg, (size_t)tune_count * n * 8 + (size_t)tune_count * 4, 0) != hipSuccess ||
+		    hipHostMalloc((void **)&g_scan.h_in, (size_t)tune_count * p.buf_len * 2, 0) != hipSuccess) {
+			scan_cache_drop();
+			return rxgpu_fail(RXGPU_ENOMEM, "rxgpu_scan: buffer allocation failed");
+		}
 	}
 	hipStream_t st = rxgpu_hip_stream();
+	/* gather the caller's scattered buffers into the pinned staging, then three copies instead of 3 per tune */
+	int32_t *h_samples = (int32_t *)(g_scan.h_avg + (size_t)tune_count * n);
 	for (int i = 0; i < tune_count; i++) {
-		hipMemcpyAsync(d_in + (size_t)i * p.buf_len, tunes[i].buf16, (size_t)p.buf_len * 2, hipMemcpyHostToDevice, st);
-		hipMemcpyAsync(d_avg + (size_t)i * n, tunes[i].avg, n * 8, hipMemcpyHostToDevice, st);
-		hipMemcpyAsync(d_samples + i, &tunes[i].samples, 4, hipMemcpyHostToDevice, st);
+		memcpy(g_scan.h_in + (size_t)i * p.buf_len, tunes[i].buf16, (size_t)p.buf_len * 2);
+		memcpy(g_scan.h_avg + (size_t)i * n, tunes[i].avg, n * 8);
+		h_samples[i] = tunes[i].samples;
 	}
-	if ((rc = rxgpu_power_scan_run(s, d_in, 1, tune_count, d_avg, d_samples)) != RXGPU_OK)
-		goto done;
+	RX_HIP(hipMemcpyAsync(g_scan.d_in, g_scan.h_in, (size_t)tune_count * p.buf_len * 2, hipMemcpyHostToDevice, st));
+	RX_HIP(hipMemcpyAsync(g_scan.d_avg, g_scan.h_avg, (size_t)tune_count * n * 8, hipMemcpyHostToDevice, st));
+	RX_HIP(hipMemcpyAsync(g_scan.d_samples, h_samples, (size_t)tune_count * 4, hipMemcpyHostToDevice, st));
+	if ((rc = rxgpu_power_scan_run(g_scan.s, g_scan.d_in, 1, tune_count, g_scan.d_avg, g_scan.d_samples)) != RXGPU_OK)
+		return rc;
+	RX_HIP(hipMemcpyAsync(g_scan.h_avg, g_scan.d_avg, (size_t)tune_count * n * 8, hipMemcpyDeviceToHost, st));
+	RX_HIP(hipMemcpyAsync(h_samples, g_scan.d_samples, (size_t)tune_count * 4, hipMemcpyDeviceToHost, st));
+	RX_HIP(hipStreamSynchronize(st));
 	for (int i = 0; i < tune_count; i++) {
-		hipMemcpyAsync(tunes[i].avg, d_avg + (size_t)i * n, n * 8, hipMemcpyDeviceToHost, st);
-		hipMemcpyAsync(&tunes[i].samples, d_samples + i, 4, hipMemcpyDeviceToHost, st);
-	}
-	if (hipStreamSynchronize(st) != hipSuccess) {
-		rc = rxgpu_fail(RXGPU_ENODEV, "rxgpu_scan: %s", hipGetErrorString(hipGetLastError()));
-		goto done;
+		memcpy(tunes[i].avg, g_scan.h_avg + (size_t)i * n, n * 8);
+		tunes[i].samples = h_samples[i];
 	}
 	rxgpu_prof_collect();
-	rc = RXGPU_OK;
-done:
-	hipFree(d_in); hipFree(d_avg); hipFree(d_samples);
-	rxgpu_power_scan_destroy(s);
+	return RXGPU_OK;
+}
+
+int rxgpu_scan(struct tuning_state *tunes, int tune_count, const int *window_coefs,
+               const int16_t *sinewave, int boxcar, int comp_fir_size, int peak_hold)
+{
+	int rc;
+	if (!tunes || tune_count < 1)
+		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_scan: no tunes");
+	if ((rc = rxgpu_ensure_init()) != RXGPU_OK)
+		return rc;
+	pthread_mutex_lock(&g_scan_lock);
+	rc = scan_locked(tunes, tune_count, window_coefs, sinewave, boxcar, comp_fir_size, peak_hold);
+	pthread_mutex_unlock(&g_scan_lock);
 	return rc;
 }
 
-/* csv_dbm, rtl_power.c:774-817 (host; fed with bit-exact avg[] it prints the same text) */
+/* One CSV row for a tuning_state, byte for byte what csv_dbm prints (rtl_power.c:774-817) -- a restatement, because
+ * the text has to be identical: the bins are read through the index map the reference's in-place edits amount to
+ * (bin 0 takes bin 1's value, then the two halves trade places), every floating-point expression keeps the
+ * reference's operation order (two successive divisions per bin, one division by the product for the trailing
+ * column), and like the reference the row's accumulators are cleared afterwards. */
+static int64_t csv_bin(const struct tuning_state *ts, int len, int i)
+{
+	if (ts->bin_e == 0)
+		return ts->avg[i];
+	int src = i + len / 2;
+	if (src >= len)
+		src -= len;
+	return ts->avg[src == 0 ? 1 : src];
+}
+
 void rxgpu_csv_dbm(struct tuning_state *ts, void *file)
 {
 	FILE *f = (FILE *)file;
-	int i, len, ds, i1, i2, bw2, bin_count;
-	int64_t tmp;
-	double dbm;
-	len = 1 << ts->bin_e;
-	ds = ts->downsample;
-	if (ts->bin_e > 0) {
-		ts->avg[0] = ts->avg[1];                           /* nuke DC (784) */
-		for (i = 0; i < len / 2; i++) {                    /* half swap (786-790) */
-			tmp = ts->avg[i];
-			ts->avg[i] = ts->avg[i + len / 2];
-			ts->avg[i + len / 2] = tmp;
-		}
-	}
-	bin_count = (int)((double)len * (1.0 - ts->crop));
-	bw2 = (int)(((double)ts->rate * (double)bin_count) / (len * 2 * ds));
-	fprintf(f, "%lli, %lli, %.2f, %i, ", (long long)ts->freq - bw2, (long long)ts->freq + bw2,
+	const int len = 1 << ts->bin_e, ds = ts->downsample;
+	const int kept = (int)((double)len * (1.0 - ts->crop));
+	const int half_bw = (int)(((double)ts->rate * (double)kept) / (len * 2 * ds));
+	const int skip = (int)((double)len * ts->crop * 0.5);
+	const int first = skip, last = (len - 1) - skip;
+	fprintf(f, "%lli, %lli, %.2f, %i, ", (long long)ts->freq - half_bw, (long long)ts->freq + half_bw,
 	        (double)ts->rate / (double)(len * ds), ts->samples);
-	i1 = 0 + (int)((double)len * ts->crop * 0.5);
-	i2 = (len - 1) - (int)((double)len * ts->crop * 0.5);
-	for (i = i1; i <= i2; i++) {
-		dbm = (double)ts->avg[i];
-		dbm /= (double)ts->rate;
-		dbm /= (double)ts->samples;
-		dbm = 10 * log10(dbm);
-		fprintf(f, "%.2f, ", dbm);
+	for (int i = first; i <= last; i++) {
+		double v = (double)csv_bin(ts, len, i);
+		v /= (double)ts->rate;
+		v /= (double)ts->samples;
+		fprintf(f, "%.2f, ", 10 * log10(v));
 	}
-	dbm = (double)ts->avg[i2] / ((double)ts->rate * (double)ts->samples);
-	if (ts->bin_e == 0)
-		dbm = ((double)ts->avg[0] / ((double)ts->rate * (double)ts->samples));
-	dbm = 10 * log10(dbm);
-	fprintf(f, "%.2f\n", dbm);
-	for (i = 0; i < len; i++)
-		ts->avg[i] = 0L;
+	/* the trailing column repeats the last bin with the other operation order (rtl_power.c:808-813) */
+	const double tail = (double)csv_bin(ts, len, ts->bin_e == 0 ? 0 : last) / ((double)ts->rate * (double)ts->samples);
+	fprintf(f, "%.2f\n", 10 * log10(tail));
+	memset(ts->avg, 0, (size_t)len * sizeof(ts->avg[0]));
 	ts->samples = 0;
 }

@@ -1,13 +1,19 @@
 /* rxgpu_rt.c -- runtime of librxgpu: device binding, the launch stream, error text and
  * per-kernel event timing.  Plain C over the HIP C API. */
 #include "rxgpu_internal.h"
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 static int g_device = -1;
-static hipStream_t g_stream, g_stream2;
-static char g_err[512];
+static hipStream_t g_stream, g_stream2, g_stream3;
+/* The drop-in is entered from two threads of the reference (rtlsdr_callback on the dongle thread, full_demod on the
+ * demod thread, rtl_fm.c:899/923): the error text and the "this thread is bound to the device" flag are per thread,
+ * initialisation is serialised. */
+static __thread char g_err[512];
+static __thread int t_bound_device = -1;
+static pthread_mutex_t g_init_lock = PTHREAD_MUTEX_INITIALIZER;
 
 int rxgpu_fail(int code, const char *fmt, ...)
 {
@@ -28,7 +34,17 @@ int rxgpu_device_count(void)
 	return n;
 }
 
+static int init_locked(int device);
+
 int rxgpu_init(int device)
+{
+	pthread_mutex_lock(&g_init_lock);
+	int rc = init_locked(device);
+	pthread_mutex_unlock(&g_init_lock);
+	return rc;
+}
+
+static int init_locked(int device)
 {
 	int n = 0;
 	if (device < 0) {
@@ -37,8 +53,14 @@ int rxgpu_init(int device)
 			e = getenv("LOCAL_RANK");
 		device = (e && *e) ? atoi(e) : 0;
 	}
-	if (g_device == device)
+	if (g_device == device) {
+		/* hipSetDevice is per thread: bind the caller too */
+		if (t_bound_device != device) {
+			RX_HIP(hipSetDevice(device));
+			t_bound_device = device;
+		}
 		return RXGPU_OK;
+	}
 	if (g_device >= 0)
 		rxgpu_shutdown();
 	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
@@ -46,7 +68,9 @@ int rxgpu_init(int device)
 	if (device >= n)
 		return rxgpu_fail(RXGPU_ENODEV, "device %d requested but only %d visible", device, n);
 	RX_HIP(hipSetDevice(device));
+	t_bound_device = device;
 	RX_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+	RX_HIP(hipStreamCreateWithFlags(&g_stream3, hipStreamNonBlocking));
 	{
 		/* the tail stream carries many small kernels behind a saturating one: give it the high priority */
 		int lo_p = 0, hi_p = 0;
@@ -67,19 +91,42 @@ void rxgpu_shutdown(void)
 	rxgpu_prof_reset();
 	hipStreamDestroy(g_stream);
 	hipStreamDestroy(g_stream2);
-	g_stream = g_stream2 = NULL;
+	hipStreamDestroy(g_stream3);
+	g_stream = g_stream2 = g_stream3 = NULL;
 	g_device = -1;
 }
 
 int rxgpu_ensure_init(void)
 {
-	if (g_device >= 0)
+	/* fast path: initialised, and this thread already talks to the right device */
+	if (g_device >= 0 && t_bound_device == g_device)
 		return RXGPU_OK;
-	return rxgpu_init(-1);
+	return rxgpu_init(g_device >= 0 ? g_device : -1);
 }
 
 hipStream_t rxgpu_hip_stream(void) { return g_stream; }
 hipStream_t rxgpu_hip_stream2(void) { return g_stream2; }
+hipStream_t rxgpu_hip_stream3(void) { return g_stream3; }
+
+/* Host buffers the caller wants DMA'd without a bounce (SURVEY.md section 8b "Ownership"): page-lock them in place. */
+int rxgpu_pin(void *ptr, size_t bytes)
+{
+	int rc;
+	if (!ptr || !bytes)
+		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_pin: bad arguments");
+	if ((rc = rxgpu_ensure_init()) != RXGPU_OK)
+		return rc;
+	RX_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+	return RXGPU_OK;
+}
+
+int rxgpu_unpin(void *ptr)
+{
+	if (!ptr)
+		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_unpin: null pointer");
+	RX_HIP(hipHostUnregister(ptr));
+	return RXGPU_OK;
+}
 void *rxgpu_stream(void) { return (void *)g_stream; }
 
 int rxgpu_sync(void)
@@ -88,6 +135,7 @@ int rxgpu_sync(void)
 		return rxgpu_fail(RXGPU_ENODEV, "rxgpu_sync before rxgpu_init");
 	RX_HIP(hipStreamSynchronize(g_stream));
 	RX_HIP(hipStreamSynchronize(g_stream2));
+	RX_HIP(hipStreamSynchronize(g_stream3));
 	rxgpu_prof_collect();
 	return RXGPU_OK;
 }
@@ -101,6 +149,7 @@ struct prof_total { char name[24]; double ms; long n; };
 struct prof_pair { int slot; hipEvent_t a, b; };
 
 static int g_prof_on;
+static pthread_mutex_t g_prof_lock = PTHREAD_MUTEX_INITIALIZER;   /* begin/end pairs come from one thread at a time per stream object; the tables are shared */
 static struct prof_total g_tot[PROF_NAMES];
 static int g_ntot;
 static struct prof_pair g_pend[PROF_PENDING];
@@ -137,39 +186,57 @@ static int prof_wanted(const char *name)
 {
 	if (g_prof_on >= 2)
 		return 1;
-	return !strcmp(name, "fm_decimate") || !strcmp(name, "pw_fft") || !strcmp(name, "fm_fifth") || !strcmp(name, "ch_fft");
+	return !strcmp(name, "fm_decimate") || !strcmp(name, "pw_fft") || !strcmp(name, "fm_fifth") || !strcmp(name, "ch_fft") ||
+	       !strcmp(name, "pw_gather");
 }
+
+/* the begin of a pair waits in a per-thread slot; the shared tables are only touched under the lock */
+static __thread struct prof_pair t_cur = { -1, NULL, NULL };
 
 void rxgpu_prof_begin_on(const char *name, hipStream_t st)
 {
-	if (!g_prof_on || g_npend == PROF_PENDING || !prof_wanted(name))
+	if (!g_prof_on || !prof_wanted(name))
 		return;
-	struct prof_pair *p = &g_pend[g_npend];
-	p->slot = prof_slot(name);
-	if (p->slot < 0)
-		return;
-	p->a = prof_event();
-	p->b = NULL;
-	hipEventRecord(p->a, st);
+	pthread_mutex_lock(&g_prof_lock);
+	t_cur.slot = g_npend < PROF_PENDING ? prof_slot(name) : -1;
+	t_cur.a = t_cur.slot >= 0 ? prof_event() : NULL;
+	pthread_mutex_unlock(&g_prof_lock);
+	if (t_cur.a)
+		hipEventRecord(t_cur.a, st);
 }
 
 void rxgpu_prof_end_on(const char *name, hipStream_t st)
 {
-	if (!g_prof_on || g_npend == PROF_PENDING || !prof_wanted(name))
+	if (!g_prof_on || !prof_wanted(name) || t_cur.slot < 0 || !t_cur.a)
 		return;
-	struct prof_pair *p = &g_pend[g_npend];
-	if (p->slot < 0 || !p->a)
-		return;
-	p->b = prof_event();
-	hipEventRecord(p->b, st);
-	g_npend++;
+	pthread_mutex_lock(&g_prof_lock);
+	t_cur.b = prof_event();
+	pthread_mutex_unlock(&g_prof_lock);
+	hipEventRecord(t_cur.b, st);
+	pthread_mutex_lock(&g_prof_lock);
 	if (g_npend < PROF_PENDING) {
-		g_pend[g_npend].a = NULL;
-		g_pend[g_npend].slot = -1;
+		g_pend[g_npend++] = t_cur;
+	} else {
+		g_free[g_nfree++] = t_cur.a;
+		g_free[g_nfree++] = t_cur.b;
 	}
+	pthread_mutex_unlock(&g_prof_lock);
+	t_cur.slot = -1;
+	t_cur.a = NULL;
 }
 
+static void prof_collect_locked(void);
+
 void rxgpu_prof_collect(void)
+{
+	if (!g_npend)
+		return;
+	pthread_mutex_lock(&g_prof_lock);
+	prof_collect_locked();
+	pthread_mutex_unlock(&g_prof_lock);
+}
+
+static void prof_collect_locked(void)
 {
 	for (int i = 0; i < g_npend; i++) {
 		float ms = 0;
@@ -182,8 +249,6 @@ void rxgpu_prof_collect(void)
 		g_free[g_nfree++] = p->b;
 	}
 	g_npend = 0;
-	g_pend[0].a = NULL;
-	g_pend[0].slot = -1;
 }
 
 void rxgpu_prof_reset(void)

@@ -13,15 +13,42 @@ class FmParams(C.Structure):
         "post_downsample", "dc_block_raw", "rdc_block_const")]
 
     @classmethod
-    def wbfm(cls, downsample=6, **kw):
-        """`-M wbfm` defaults, rtl_fm.c:1331-1341 (deemph_a for 75 us at 170 kHz, 1410-1412)."""
-        p = cls(downsample=downsample, downsample_passes=0, comp_fir_size=0, custom_atan=1, deemph=1,
-                deemph_a=13, rate_out=170000, rate_out2=32000, offset_tuning=0, prescaled=0,
-                mode=0, output_scale=1, squelch_level=0, dc_block_audio=0, adc_block_const=9,
-                post_downsample=1, dc_block_raw=0, rdc_block_const=9)
+    def for_mode(cls, mode, freq=100000000, rate_in=None, fifth_order=None, edge=0, time_constant_us=75, **kw):
+        """What rx_fm's main() derives for `-M mode [-s rate_in] [-F fifth_order] ...`: demod_init + the -M switch
+        (rxgpu_fm_params_init), then optimal_settings and deemph_a (rxgpu_fm_plan_settings).  kw: fields set between the
+        two, like command-line flags (post_downsample, offset_tuning, deemph ...).  Returns (params, plan)."""
+        p = cls()
+        rin = C.c_int(0)
+        check(lib().rxgpu_fm_params_init(C.byref(p), mode.encode(), C.byref(rin)))
+        if rate_in is not None:                     # -s sets both, rtl_fm.c:1255-1258
+            rin.value = rate_in
+            p.rate_out = rate_in
+        if fifth_order is not None:                 # -F, rtl_fm.c:1305-1308
+            p.downsample_passes = 1
+            p.comp_fir_size = fifth_order
+        for k, v in kw.items():
+            setattr(p, k, v)
+        plan = FmPlan()
+        check(lib().rxgpu_fm_plan_settings(C.byref(p), freq, rin.value, edge, time_constant_us, C.byref(plan)))
+        return p, plan
+
+    @classmethod
+    def wbfm(cls, downsample=None, **kw):
+        """`-M wbfm` as main() leaves it (rtl_fm.c:1331-1341, 960-997, 1410-1415: downsample 6, deemph_a 13 for 75 us at
+        170 kHz); `downsample` / `downsample_passes` / any other field can then be overridden, e.g. the 20 Msps geometry
+        of BASELINE configs[1] is downsample=118."""
+        p, _ = cls.for_mode("wbfm")
+        if downsample is not None:
+            p.downsample = downsample
         for k, v in kw.items():
             setattr(p, k, v)
         return p
+
+
+class FmPlan(C.Structure):
+    """struct rxgpu_fm_plan: what optimal_settings (rtl_fm.c:960-997) and the deemph_a formula (1410-1415) decide."""
+    _fields_ = [("rate_in", C.c_int), ("downsample", C.c_int), ("downsample_passes", C.c_int), ("output_scale", C.c_int),
+                ("deemph_a", C.c_int), ("capture_freq", C.c_uint32), ("capture_rate", C.c_uint32)]
 
 
 class FmCarry(C.Structure):

@@ -1,5 +1,9 @@
 """Multi-GPU rx_power: contiguous tune ranges per rank and the one gather that merges them.
 
+The product path is librxgpu's own (rxgpu_comm_*, rxgpu_power_gather in rxgpu_comm.c: ncclGather from librccl on the
+library's stream, right behind the scan kernels); `Comm` binds it.  The torch.distributed helpers below it are what the
+CPU tests (gloo) and bench.py's fallback use.
+
 scanner()'s tunes are independent units (rtl_power.c:679-771: own buf16, avg, samples); nothing
 crosses tunes until csv_dbm prints rows in tune order (1047-1050).  So rank r scans tunes
 [r*per, min(T,(r+1)*per)) with per = ceil(T/W), and once per report interval every rank's
@@ -9,12 +13,62 @@ no reduction, no ring.  rx_fm does not shard (one stream, sequential carries).
 """
 
 
+import ctypes as C
+
+from ._lib import lib, check
+
+
 def tune_range(rank, world, total):
-    """(first, count, per) of the tunes rank `rank` of `world` owns."""
-    per = (total + world - 1) // world
-    lo = min(total, rank * per)
-    hi = min(total, lo + per)
-    return lo, hi - lo, per
+    """(first, count, per) of the tunes rank `rank` of `world` owns (rxgpu_shard_tunes)."""
+    first, count, per = C.c_int(0), C.c_int(0), C.c_int(0)
+    check(lib().rxgpu_shard_tunes(rank, world, total, C.byref(first), C.byref(count), C.byref(per)))
+    return first.value, count.value, per.value
+
+
+class Comm:
+    """rxgpu_comm: an RCCL communicator owned by librxgpu (one rank per process / GPU)."""
+
+    def __init__(self, unique_id, rank, world):
+        self._h = C.c_void_p()
+        self.rank, self.world = rank, world
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        check(lib().rxgpu_comm_create(C.byref(self._h), buf, rank, world))
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        check(lib().rxgpu_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def from_torch_distributed(cls):
+        """Rank 0 makes the ncclUniqueId, torch.distributed (any backend) hands it round, every rank joins."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(), dist.get_world_size()
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return cls(box[0], rank, world)
+
+    @staticmethod
+    def library():
+        p = lib().rxgpu_comm_library()
+        return p.decode() if p else None
+
+    def gather(self, d_avg_local, d_samples_local, per, n_bins, d_avg_all=0, d_samples_all=0, root=0):
+        """device addresses; asynchronous on the library's stream"""
+        check(lib().rxgpu_power_gather(self._h, d_avg_local, d_samples_local, per, n_bins, d_avg_all or None,
+                                       d_samples_all or None, root))
+
+    def close(self):
+        if self._h:
+            lib().rxgpu_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def gather_buffers(local, dst=0):

@@ -60,3 +60,65 @@ def test_csv_dbm_matches_reference_rows(tmp_path):
             assert ts.samples == 0 and not avg[t].any()
         libc.fclose(f)
         assert open(path).read().splitlines() == [str(r) for r in z[name + "__csv"]], name
+
+
+def _atofs(s):
+    mult = {"k": 1e3, "K": 1e3, "M": 1e6, "m": 1e6, "G": 1e9, "g": 1e9}.get(s[-1])
+    return float(s[:-1]) * mult if mult else float(s)
+
+
+def test_fm_plan_matches_reference_main():
+    """rxgpu_fm_params_init + rxgpu_fm_plan_settings == the state rx_fm's own main() derives for the same flags
+    (golden: the reference's globals after its main() ran, oracle/gen_golden.py fm_plans)"""
+    import json
+    rows = np.load(os.path.join(GOLDEN_DIR, "fm_plans.npz"))["rows"]
+    assert len(rows) >= 12
+    mode_fn = {R.fm.FmParams.for_mode(m)[0].mode: fn for m, fn in (("fm", 0), ("raw", 1), ("am", 2), ("usb", 3), ("lsb", 4))}
+    for r in rows:
+        row = json.loads(str(r))
+        a, st = row["args"], row["state"]
+        opt = {a[i]: [] for i in range(0, len(a), 2)}
+        for i in range(0, len(a), 2):
+            opt[a[i]].append(a[i + 1])
+        mode = opt["-M"][0]
+        kw = {}
+        for e in opt.get("-E", []):
+            kw.update({"rdc": dict(dc_block_raw=1), "deemp": dict(deemph=1), "offset": dict(offset_tuning=1), "edge": {},
+                       "adc": dict(dc_block_audio=1)}[e])
+        if "-o" in opt:
+            kw["post_downsample"] = int(opt["-o"][0])
+        if "-r" in opt:
+            kw["rate_out2"] = int(_atofs(opt["-r"][0]))
+        if "-A" in opt:
+            kw["custom_atan"] = {"std": 0, "fast": 1, "lut": 2, "ale": 3}[opt["-A"][0]]
+        tc = {"us": 75, "eu": 50}.get(opt.get("-c", ["us"])[0]) or int(float(opt["-c"][0]))
+        freq = int(_atofs(opt["-f"][0])) + (16000 if mode in ("wbfm", "wfm") else 0)     # controller_thread_fn, rtl_fm.c:1006-1009
+        p, plan = R.fm.FmParams.for_mode(mode, freq=freq, rate_in=int(_atofs(opt["-s"][0])) if "-s" in opt else None,
+                                          fifth_order=int(opt["-F"][0]) if "-F" in opt else None,
+                                          edge=1 if "edge" in opt.get("-E", []) else 0, time_constant_us=tc, **kw)
+        got = dict(rate_in=plan.rate_in, rate_out=p.rate_out, rate_out2=p.rate_out2, downsample=p.downsample,
+                   post_downsample=p.post_downsample, output_scale=p.output_scale, downsample_passes=p.downsample_passes,
+                   comp_fir_size=p.comp_fir_size, custom_atan=p.custom_atan, deemph=p.deemph, deemph_a=p.deemph_a,
+                   squelch_level=p.squelch_level, dc_block_audio=p.dc_block_audio, dc_block_raw=p.dc_block_raw,
+                   adc_block_const=p.adc_block_const, rdc_block_const=p.rdc_block_const, mode_fn=mode_fn[p.mode],
+                   capture_freq=plan.capture_freq, capture_rate=plan.capture_rate, offset_tuning=p.offset_tuning)
+        assert got == st, (a, {k: (got[k], st[k]) for k in st if got[k] != st[k]})
+
+
+def test_wbfm_defaults_are_derived():
+    p = R.FmParams.wbfm()
+    assert (p.downsample, p.downsample_passes, p.deemph, p.deemph_a, p.rate_out, p.rate_out2, p.custom_atan, p.output_scale,
+            p.post_downsample, p.adc_block_const, p.rdc_block_const) == (6, 0, 1, 13, 170000, 32000, 1, 1, 1, 9, 9)
+    assert R.FmParams.wbfm(downsample=118).downsample == 118
+
+
+def test_shard_tunes_cover_every_tune_once():
+    from rx_tools_amd import shard
+    for total in (1, 7, 599, 600, 4096):
+        for world in (1, 2, 3, 4, 8):
+            seen = []
+            for r in range(world):
+                lo, cnt, per = shard.tune_range(r, world, total)
+                assert per == -(-total // world) and cnt <= per
+                seen += list(range(lo, lo + cnt))
+            assert seen == list(range(total))
