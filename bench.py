@@ -2,21 +2,32 @@
 """bench.py -- the rx_tools hot path on MI355X, measured the way BASELINE.json asks.
 
 Headline (`value`): complex IQ MSample/s through the rx_fm callback pre-stage + full_demod()
-chain at the "20 Msps" WBFM geometry of BASELINE config 2 (downsample=118 -> 170 ksps ->
+chain at the "20 Msps" WBFM geometry of BASELINE configs[1] (downsample=118 -> 170 ksps ->
 32 ksps audio, -A fast, de-emphasis on), blocks of 131072 complex samples, input resident in
 HBM.  One step = one rxgpu_fm_stream_run over --blocks blocks (default 16384 = 2^31 samples = 8 GiB of cs16).
-The same JSON line carries, under "rx_power", FFT bins/s of the scanner() chain at the
-config-3 geometry (-f 24M:1.7G:1k: 599 tunes x 16384 int16, N=4096), tunes sharded across the
-ranks with one RCCL gather of the avg[] rows to rank 0 per step.
+The capture is generated on the device, seeded and NON-REPEATING (signal (A): FM carrier at -fs/4, 1 kHz tone,
+75 kHz deviation, +-128 LSB of noise on every sample), and after the timed loop the same 2^31 samples -- plus a
+chained second run, the way the timed loop chains them -- go through the CPU reference (oracle/_ref, the reference's
+own rtlsdr_callback + full_demod) and every output sample and carry of the pipelined GPU sequence is compared:
+`parity_checked_samples` in the JSON line.
 
-  python bench.py --gpus 1 --steps 100 --warmup 10      (the defaults; about 10 s incl. the CPU baselines)
+The same line carries:
+  rx_fm_variants   the small-decimation chains (-M wbfm default ds=6; BASELINE configs[0] ds=5 / 240 kHz) and the -F cascade
+  host_fed         rxgpu_fm_stream_run_host from pinned host memory (PCIe-inclusive; never `value`) and the drop-in's
+                   per-block latency (rxgpu_callback + rxgpu_full_demod on a struct demod_state)
+  rx_power         FFT bins/s of the scanner() chain at the configs[2] geometry (-f 24M:1.7G:1k: 599 tunes x 16384 int16,
+                   N=4096), tunes sharded across the ranks with ONE ncclGather per step issued by librxgpu itself
+                   (rxgpu_power_scan_run_sharded), plus two more geometries (full-scale/hamming; N=16384 with -F 9)
+  channeliser, sdr_convert   the extension and the rx_sdr converters
+
+  python bench.py --gpus 1 --steps 100 --warmup 10      (the defaults)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
 rx_fm does not shard (one stream, sequential carries): N>1 runs N independent replicas
 ("replicas only", weak scaling).  rx_power shards by tune (strong scaling of one sweep).
-torch is used for device buffers and torch.distributed only; every sample is processed by
-librxgpu.so through its C ABI.
+torch is used for device buffers, the synthetic capture and torch.distributed's rendezvous only; every sample is
+processed by librxgpu.so through its C ABI.  oracle/ is used as the checker and as the timed CPU baseline, nothing else.
 """
 import argparse
 import ctypes as C
@@ -31,6 +42,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+PCIE_PEAK_GBS = 63.0           # MI355X_MICROARCH.md: PCIe Gen5 x16
+# integer VALU issue: one wave64 instruction per quad-cycle per SIMD (the packed 16-bit / mad ops of the FFT butterfly each
+# count one SQ_ACTIVE_INST_VALU quad-cycle): 256 CUs x 4 SIMDs x 2.4 GHz / 4
+VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4.0
 
 
 def cpu_model():
@@ -43,64 +58,93 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline_fm(block_len, budget_s):
-    """The reference's own callback + full_demod (oracle/_ref, gcc -O2) -- or, where that
-    prebuilt object is absent, the oracle port -- on one host core, config-2 parameters."""
+def _timed_reps(fn, budget_s, reps=3):
+    """fn(seconds) -> (units, seconds); `reps` repetitions sharing the budget: best and median rate"""
+    rates = []
+    for _ in range(reps):
+        units, dt = fn(budget_s / reps)
+        rates.append(units / dt)
+    rates.sort()
+    return rates[-1], rates[len(rates) // 2], rates
+
+
+def cpu_baseline_fm(block_len, budget_s, lib_name="libref_fm.so", ds=118):
+    """The reference's own callback + full_demod (oracle/_ref, gcc -O2) -- or, where that prebuilt object is absent, the
+    oracle port -- on one host core, config-2 parameters; 3 repetitions, best and median."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import support
     import rx_tools_amd as R
     n_buf = 16
     iq = R.synth.sig_fm(n_buf * block_len // 2, seed=12345)
-    if support.have_ref():
-        L = support.ref_fm()
-        support.ref_fm_reset(L, downsample=118)
+    path = os.path.join(support.ORACLE_DIR, "_ref", lib_name)
+    if os.path.exists(path):
+        if lib_name == "libref_fm.so":
+            L = support.ref_fm()
+        else:
+            L = C.CDLL(path)
+            L.ref_fm_demod.restype = C.c_void_p
+            L.ref_fm_dongle.restype = C.c_void_p
+            L.ref_fm_fn.restype = C.c_void_p
+            L.ref_fm_run_blocks.restype = C.c_long
+            L.ref_fm_run_blocks.argtypes = [support.i16p, C.c_size_t, C.c_size_t, C.c_size_t, support.i16p, support.i16p, C.c_size_t]
+            L.ref_fm_init()
+        support.ref_fm_reset(L, downsample=ds)
         scratch = np.zeros(block_len, np.int16)
-        calls, t0 = 0, time.perf_counter()
-        while True:
-            L.ref_fm_run_blocks(support.ptr16(iq), n_buf, block_len, 64, support.ptr16(scratch), None, 0)
-            calls += 64
-            dt = time.perf_counter() - t0
-            if dt >= budget_s:
-                break
+
+        def rep(seconds):
+            calls, t0 = 0, time.perf_counter()
+            while True:
+                L.ref_fm_run_blocks(support.ptr16(iq), n_buf, block_len, 64, support.ptr16(scratch), None, 0)
+                calls += 64
+                dt = time.perf_counter() - t0
+                if dt >= seconds:
+                    return calls * (block_len // 2), dt
         kind = "reference"
     else:
         O = support.oracle()
-        st = support.oracle_fm_state(downsample=118)
+        st = support.oracle_fm_state(downsample=ds)
         out = np.zeros(n_buf * block_len // 2, np.int16)
-        calls, t0 = 0, time.perf_counter()
-        while True:
-            O.rxo_fm_stream(C.byref(st), support.ptr16(iq), n_buf, block_len, support.ptr16(out), None)
-            calls += n_buf
-            dt = time.perf_counter() - t0
-            if dt >= budget_s:
-                break
+
+        def rep(seconds):
+            calls, t0 = 0, time.perf_counter()
+            while True:
+                O.rxo_fm_stream(C.byref(st), support.ptr16(iq), n_buf, block_len, support.ptr16(out), None)
+                calls += n_buf
+                dt = time.perf_counter() - t0
+                if dt >= seconds:
+                    return calls * (block_len // 2), dt
         kind = "port"
-    samples = calls * (block_len // 2)
-    return {"value": samples / dt / 1e6, "unit": "MSample/s", "cores": 1, "kind": kind,
-            "sample": "%d blocks of %d complex samples, rtlsdr_callback+full_demod, ds=118 wbfm, %.1f s on 1 thread (%s)"
-                      % (calls, block_len // 2, dt, cpu_model())}
+    rep(0.2)                                            # pre-fault, warm caches
+    best, median, rates = _timed_reps(rep, budget_s)
+    return {"value": best / 1e6, "median": median / 1e6, "unit": "MSample/s", "cores": 1, "kind": kind,
+            "sample": "3 repetitions of %.1f s over blocks of %d complex samples, rtlsdr_callback+full_demod, ds=%d wbfm, 1 thread, %s (%s)"
+                      % (budget_s / 3, block_len // 2, ds, "gcc -O0 (the reference's default build)" if "O0" in lib_name else "gcc -O2", cpu_model())}
 
 
-def cpu_baseline_power(plan, budget_s):
+def cpu_baseline_power(plan, budget_s, lib_name="libref_power.so"):
     """scanner()'s per-tune chain on one host core: the reference's own scanner() over all 599 tunes
-    (oracle/_ref) where that prebuilt object exists, else the oracle port."""
+    (oracle/_ref) where that prebuilt object exists, else the oracle port; 3 repetitions, best and median."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import support
     import rx_tools_amd as R
     n = 1 << plan.bin_e
-    if support.have_ref():
-        P = support.ref_power()
+    path = os.path.join(support.ORACLE_DIR, "_ref", lib_name)
+    if os.path.exists(path):
+        P = support.ref_power() if lib_name == "libref_power.so" else C.CDLL(path)
+        P.ref_power_setup.argtypes = [C.c_char_p, C.c_double, C.c_char_p]
         P.ref_power_set_flags(1, 0, 0)
         P.ref_power_scan_tuned.argtypes = [support.i16p, C.c_int]
         tunes = P.ref_power_setup(b"24M:1.7G:1k", 0.0, b"rectangle")
         data = R.synth.sig_noise(tunes * plan.buf_len, seed=777, amp=100)
-        done, t0 = 0, time.perf_counter()
-        while True:
-            P.ref_power_scan_tuned(support.ptr16(data), 1)     # scanner() without retune()'s settle sleep
-            done += tunes
-            dt = time.perf_counter() - t0
-            if dt >= budget_s:
-                break
+
+        def rep(seconds):
+            done, t0 = 0, time.perf_counter()
+            while True:
+                P.ref_power_scan_tuned(support.ptr16(data), 1)     # scanner() without retune()'s settle sleep
+                done += tunes
+                dt = time.perf_counter() - t0
+                if dt >= seconds:
+                    return done * (plan.buf_len // 2), dt
         kind = "reference"
     else:
         tunes = 64
@@ -111,20 +155,33 @@ def cpu_baseline_power(plan, budget_s):
         avg = np.zeros(n, np.int64)
         work = np.zeros(plan.buf_len, np.int16)
         smp = C.c_int(0)
-        done, t0 = 0, time.perf_counter()
-        while True:
-            for t in range(tunes):
-                O.rxo_power_tune(C.byref(cfg), support.ptr16(data[t * plan.buf_len:(t + 1) * plan.buf_len]),
-                                 support.ptr16(work), support.ptr64(avg), C.byref(smp))
-            done += tunes
-            dt = time.perf_counter() - t0
-            if dt >= budget_s:
-                break
+
+        def rep(seconds):
+            done, t0 = 0, time.perf_counter()
+            while True:
+                for t in range(tunes):
+                    O.rxo_power_tune(C.byref(cfg), support.ptr16(data[t * plan.buf_len:(t + 1) * plan.buf_len]),
+                                     support.ptr16(work), support.ptr64(avg), C.byref(smp))
+                done += tunes
+                dt = time.perf_counter() - t0
+                if dt >= seconds:
+                    return done * (plan.buf_len // 2), dt
         kind = "port"
-    bins = done * (plan.buf_len // 2)
-    return {"value": bins / dt / 1e6, "unit": "Mbins/s", "cores": 1, "kind": kind,
-            "sample": "%d tune buffers of %d int16 (N=%d), scanner() per-tune chain, %.1f s on 1 thread (%s)"
-                      % (done, plan.buf_len, n, dt, cpu_model())}
+    best, median, rates = _timed_reps(rep, budget_s)
+    return {"value": best / 1e6, "median": median / 1e6, "unit": "Mbins/s", "cores": 1, "kind": kind,
+            "sample": "3 repetitions of %.1f s over tune buffers of %d int16 (N=%d), scanner() per-tune chain, 1 thread, %s (%s)"
+                      % (budget_s / 3, plan.buf_len, n, "gcc -O0 (the reference's default build)" if "O0" in lib_name else "gcc -O2", cpu_model())}
+
+
+def cpu_subprocess(which, budget_s, lib=""):
+    """one baseline in a process of its own (the -O0 objects define the same globals as the -O2 ones)"""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", which, "--cpu-seconds", "%g" % budget_s, "--cpu-lib", lib]
+    try:
+        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=120).stdout
+        return json.loads(out.decode().strip().splitlines()[-1])
+    except Exception as e:                                       # noqa: BLE001 -- a missing baseline must not sink the bench
+        return {"error": repr(e)}
 
 
 def cpu_all_cores(which, budget_s):
@@ -138,20 +195,98 @@ def cpu_all_cores(which, budget_s):
     for p in procs:
         out, _ = p.communicate()
         try:
-            total += json.loads(out.decode().strip().splitlines()[-1])["value"]
+            total += json.loads(out.decode().strip().splitlines()[-1])["median"]
             ok += 1
         except (ValueError, IndexError, KeyError):
             pass
-    return {"value": total, "cores": ok, "note": "%d concurrent single-thread replicas, %.0f s each" % (ok, budget_s)}
+    return {"value": total, "cores": ok, "note": "%d concurrent single-thread replicas, %.0f s each (sum of medians)" % (ok, budget_s)}
 
 
-def cpu_worker(which, budget_s):
+def cpu_worker(which, budget_s, lib):
     if which == "fm":
-        r = cpu_baseline_fm(2 * 131072, budget_s)
+        r = cpu_baseline_fm(2 * 131072, budget_s, lib or "libref_fm.so")
     else:
         import types
-        r = cpu_baseline_power(types.SimpleNamespace(bin_e=12, buf_len=16384), budget_s)   # -f 24M:1.7G:1k geometry
+        r = cpu_baseline_power(types.SimpleNamespace(bin_e=12, buf_len=16384), budget_s, lib or "libref_power.so")   # -f 24M:1.7G:1k geometry
     print(json.dumps(r))
+
+
+def device_capture(torch, dev, n_complex, seed, fs=20.06e6, amp=20000.0, tone=1000.0, devi=75e3, noise=128, chunk=1 << 25):
+    """Signal (A) of SURVEY 8(d) on the device, seeded, any length, never repeating: FM carrier at -fs/4 (rotate16_90 brings it
+    to DC), 1 kHz tone at 75 kHz deviation, plus uniform noise of +-128 LSB drawn per sample from a seeded generator.
+    (rx_tools_amd.synth.sig_fm is the same signal from a host LCG; tiling a few of its blocks -- what round 1 did --
+    repeats every first-sample value.)"""
+    out = torch.empty(2 * n_complex, dtype=torch.int16, device=dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    two_pi = 2.0 * np.pi
+    for lo in range(0, n_complex, chunk):
+        m = min(chunk, n_complex - lo)
+        t = torch.arange(lo, lo + m, dtype=torch.float64, device=dev)
+        # carrier phase -2*pi*t/4 taken modulo one turn before the multiply; the tone argument stays below 2^31 * 3e-4
+        phase = (torch.remainder(t, 4.0) * (-0.25 * two_pi)) + (devi / tone) * torch.sin((two_pi * tone / fs) * t)
+        nz = torch.randint(-noise, noise + 1, (2 * m,), dtype=torch.int32, device=dev, generator=g)
+        i = torch.round(amp * torch.cos(phase)).to(torch.int32) + nz[0::2]
+        q = torch.round(amp * torch.sin(phase)).to(torch.int32) + nz[1::2]
+        v = out[2 * lo:2 * (lo + m)]
+        v[0::2] = i.clamp_(-32768, 32767).to(torch.int16)
+        v[1::2] = q.clamp_(-32768, 32767).to(torch.int16)
+        del t, phase, nz, i, q
+    return out
+
+
+def check_against_cpu(torch, R, L, d_iq, n_blocks, block_len, tail_blocks, params_kw):
+    """The pipelined GPU sequence [all n_blocks][the first tail_blocks again, carries chained] against the CPU reference
+    (oracle/_ref: the reference's own rtlsdr_callback + full_demod; the oracle port where the prebuilt object is absent)
+    over the very same samples: every int16 of output, every carry the struct exposes."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import support
+    from rx_tools_amd.structs import DemodState
+    T = n_blocks * (block_len // 2)
+    ds = params_kw["downsample"]
+    d_out = torch.zeros((T + tail_blocks * (block_len // 2)) // ds + 128, dtype=torch.int16, device=d_iq.device)
+    s = R.FmStream(R.FmParams.wbfm(**params_kw), n_blocks, block_len)
+    t0 = time.perf_counter()
+    n1, _ = s.run_async(d_iq.data_ptr(), n_blocks, block_len, d_out.data_ptr(), d_out.numel())
+    n2, _ = s.run_async(d_iq.data_ptr(), tail_blocks, block_len, d_out.data_ptr() + 2 * n1, d_out.numel() - n1)
+    s.wait()
+    gpu_s = time.perf_counter() - t0
+    got = d_out[:n1 + n2].cpu().numpy()
+    carry = s.get_carry()
+    fix = s.host_fixups
+    s.close()
+    h_iq = d_iq.cpu().numpy()
+    calls = n_blocks + tail_blocks
+    want = np.zeros(n1 + n2 + 4096, np.int16)
+    t0 = time.perf_counter()
+    if support.have_ref():
+        F = support.ref_fm()
+        d, _ = support.ref_fm_reset(F, **params_kw)
+        scratch = np.zeros(block_len, np.int16)
+        produced = F.ref_fm_run_blocks(support.ptr16(h_iq), n_blocks, block_len, calls, support.ptr16(scratch), support.ptr16(want), want.size)
+        d = DemodState.from_address(F.ref_fm_demod())
+        ref_carry = (d.now_r, d.now_j, d.prev_index, d.pre_r, d.pre_j, d.now_lpr, d.prev_lpr_index)
+        kind = "reference"
+    else:
+        O = support.oracle()
+        st = support.oracle_fm_state(**params_kw)
+        produced = O.rxo_fm_stream(C.byref(st), support.ptr16(h_iq), n_blocks, block_len, support.ptr16(want), None)
+        produced += O.rxo_fm_stream(C.byref(st), support.ptr16(h_iq), tail_blocks, block_len, support.ptr16(want[produced:]), None)
+        ref_carry = (st.now_r, st.now_j, st.prev_index, st.pre_r, st.pre_j, st.now_lpr, st.prev_lpr_index)
+        kind = "port"
+    cpu_s = time.perf_counter() - t0
+    gpu_carry = (carry.now_r, carry.now_j, carry.prev_index, carry.pre_r, carry.pre_j, carry.now_lpr, carry.prev_lpr_index)
+    ok = produced == n1 + n2 and np.array_equal(got, want[:produced]) and gpu_carry == ref_carry
+    res = {"parity_checked_samples": calls * (block_len // 2), "parity_ok": bool(ok), "parity_outputs_compared": int(produced),
+           "parity_checker": kind, "parity_cpu_seconds": cpu_s, "parity_gpu_seconds": gpu_s, "parity_host_fixups": int(fix),
+           "parity_sequence": "2 pipelined runs (%d + %d blocks), carries chained on the device; output and now_r/now_j/prev_index/"
+                              "pre_r/pre_j/now_lpr/prev_lpr_index compared" % (n_blocks, tail_blocks)}
+    if not ok:
+        bad = np.nonzero(got[:min(len(got), produced)] != want[:min(len(got), produced)])[0]
+        res["parity_first_mismatch"] = int(bad[0]) if bad.size else -1
+        res["parity_carries"] = {"gpu": gpu_carry, "cpu": ref_carry, "gpu_len": int(n1 + n2), "cpu_len": int(produced)}
+    del h_iq
+    return res
 
 
 def main():
@@ -162,18 +297,23 @@ def main():
     ap.add_argument("--blocks", type=int, default=16384, help="rx_fm blocks of 131072 complex samples per step (16384 = 8 GiB of cs16)")
     ap.add_argument("--passes", type=int, default=512, help="rx_power scanner() passes per step (one report interval)")
     ap.add_argument("--workload", default="both", choices=["both", "rx_fm", "rx_power", "chan", "sdr"])
-    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU baseline budget per path (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=9.0, help="CPU baseline budget per path (0 = skip)")
     ap.add_argument("--prof-level", type=int, default=1)
     ap.add_argument("--cpu-worker", default=None, choices=["fm", "power"], help=argparse.SUPPRESS)
-    ap.add_argument("--variants", default="F", choices=["F", "all"], help="rx_fm side figures: the -F cascade (default) or also -M wbfm's ds=6")
+    ap.add_argument("--cpu-lib", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--variants", default="all", choices=["all", "none"],
+                    help="rx_fm side figures (ds=6, ds=5/240k, -F cascade, host-fed); `none` keeps the per-kernel averages of a "
+                         "rocprofv3 run of this command to the headline launches (the ds=6 chain launches the same decimator kernel)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the full-size comparison with the CPU reference")
     args = ap.parse_args()
     if args.cpu_worker:
-        cpu_worker(args.cpu_worker, args.cpu_seconds)
+        cpu_worker(args.cpu_worker, args.cpu_seconds, args.cpu_lib)
         return
 
     import torch
     import torch.distributed as dist
     import rx_tools_amd as R
+    from rx_tools_amd import shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -207,19 +347,26 @@ def main():
         L.rxgpu_prof_get(name.encode(), C.byref(ms), C.byref(n))
         return ms.value, n.value
 
+    def pmc_summary():
+        for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+            try:
+                return json.load(open(os.path.join(ROOT, "profiles", name))), "profiles/" + name
+            except (OSError, ValueError):
+                continue
+        return {}, None
+
     result = {}
 
     # ------------------------------------------------------------------ rx_fm (headline)
     if args.workload in ("both", "rx_fm"):
         block_len = 2 * 131072
         n_blocks = args.blocks
-        base = R.synth.sig_fm(8 * 131072, seed=12345 + rank)          # 8 blocks of signal (A)
-        d_base = torch.from_numpy(base).to(dev)
-        d_iq = d_base.repeat(n_blocks // 8 + 1)[: n_blocks * block_len].contiguous()
-        del d_base
         T = n_blocks * (block_len // 2)
+        d_iq = device_capture(torch, dev, T, seed=12345 + rank)
+        torch.cuda.synchronize()
         d_out = torch.zeros(T // 118 + 64, dtype=torch.int16, device=dev)
-        s = R.FmStream(R.FmParams.wbfm(downsample=118), n_blocks, block_len)
+        hp = dict(downsample=118)
+        s = R.FmStream(R.FmParams.wbfm(**hp), n_blocks, block_len)
         for _ in range(args.warmup):
             s.run_async(d_iq.data_ptr(), n_blocks, block_len, d_out.data_ptr(), d_out.numel())
         s.wait()
@@ -238,40 +385,112 @@ def main():
         fixups = s.host_fixups
         s.close()
         del d_out
-        # SURVEY 8(d) config 2 also names the -F variant; and the -M wbfm default decimation.  Same buffer, same
-        # pipelined loop, a few steps each; reported beside the headline, not part of `value`.
+        parity = {}
+        if world == 1 and not args.no_parity:
+            parity = check_against_cpu(torch, R, L, d_iq, n_blocks, block_len, max(1, n_blocks // 16), hp)
+        # SURVEY 8(d) config 2 also names the -F variant; and the -M wbfm default decimation; BASELINE configs[0] is ds=5 at 240 kHz.
+        # Same buffer, same pipelined loop, a few steps each; reported beside the headline, not part of `value`.
         variants = {}
-        if world == 1:
-            # (the ds=6 variant launches the headline's own decimator kernel; it is off by default so that the rocprofv3
-            # per-kernel averages of this command describe the headline launches only)
-            todo = [("-F cascade, downsample_passes=7 (ds=128)", dict(downsample_passes=7), 128)]
-            if args.variants == "all":
-                todo.append(("-M wbfm default, downsample=6", dict(downsample=6), 6))
+        if world == 1 and args.variants == "all":
+            todo = [("-M wbfm default, downsample=6", dict(downsample=6), 6),
+                    ("BASELINE configs[0] geometry: -s 240000, downsample=5, deemph_a=19", dict(downsample=5, rate_out=240000, deemph_a=19), 5),
+                    ("-F cascade, downsample_passes=7 (ds=128)", dict(downsample_passes=7), 128),
+                    ("-F 9 cascade as -M wbfm -F 9 sets it: downsample_passes=3 (ds=8) + droop FIR", dict(downsample_passes=3, comp_fir_size=9), 8)]
             for label, kw, per_in in todo:
                 d_o = torch.zeros(T // per_in + 64, dtype=torch.int16, device=dev)
                 sv = R.FmStream(R.FmParams.wbfm(**kw), n_blocks, block_len)
-                for _ in range(3):
+                for _ in range(2):
                     sv.run_async(d_iq.data_ptr(), n_blocks, block_len, d_o.data_ptr(), d_o.numel())
                 sv.wait()
                 k = max(5, args.steps // 5)
+                L.rxgpu_prof_reset()
+                L.rxgpu_prof_enable(2)
                 tv = time.perf_counter()
                 for _ in range(k):
                     sv.run_async(d_iq.data_ptr(), n_blocks, block_len, d_o.data_ptr(), d_o.numel())
                 sv.wait()
                 tv = time.perf_counter() - tv
-                variants[label] = {"value": T * k / tv / 1e6, "unit": "MSample/s", "ms_per_step": tv / k * 1e3, "steps": k}
+                L.rxgpu_prof_enable(0)
+                stages = {}
+                for nm in ("fm_decimate", "fm_fifth", "fm_droop", "fm_disc", "fm_deemph", "fm_resample"):
+                    sms, sn = prof(nm)
+                    if sn:
+                        stages[nm] = round(sms / sn * 1e3, 1)
+                variants[label] = {"value": T * k / tv / 1e6, "unit": "MSample/s", "ms_per_step": tv / k * 1e3, "steps": k,
+                                   "frac_of_hbm_peak": 4.0 * T * k / tv / 1e9 / HBM_PEAK_GBS, "stage_us_per_step": stages,
+                                   "host_fixups": int(sv.host_fixups)}
                 sv.close()
                 del d_o
+        # ---- host-fed leg (PCIe-inclusive, never `value`) and the drop-in's per-block latency
+        host_fed = {}
+        if world == 1 and args.variants == "all":
+            hb = min(n_blocks, 4096)                                  # 2 GiB of capture from host memory
+            h_iq = d_iq[: hb * block_len].cpu().numpy()
+            h_out = np.zeros(hb * (block_len // 2) // 118 + 4096, np.int16)
+            sh = R.FmStream(R.FmParams.wbfm(**hp), hb, block_len)
+            legs = {}
+            for label, pin in (("pinned (rxgpu_pin)", True), ("pageable", False)):
+                if pin:
+                    R.check(L.rxgpu_pin(h_iq.ctypes.data, h_iq.nbytes))
+                try:
+                    sh.run_host(h_iq.ctypes.data, hb, block_len, h_out.ctypes.data, h_out.size)        # staging allocated, pages touched
+                    t0 = time.perf_counter()
+                    reps = 3
+                    for _ in range(reps):
+                        sh.run_host(h_iq.ctypes.data, hb, block_len, h_out.ctypes.data, h_out.size)
+                    th = (time.perf_counter() - t0) / reps
+                finally:
+                    if pin:
+                        R.check(L.rxgpu_unpin(h_iq.ctypes.data))
+                gbs = h_iq.nbytes / th / 1e9
+                legs[label] = {"GS/s": hb * (block_len // 2) / th / 1e9, "GB/s": gbs, "frac_of_pcie": gbs / PCIE_PEAK_GBS, "ms": th * 1e3}
+            sh.close()
+            host_fed = {"metric": "rxgpu_fm_stream_run_host: %d blocks (%.1f GiB) from host memory, 64 MiB chunks, H2D on a copy stream "
+                                  "overlapped with the demodulation of the previous chunk, results copied back" % (hb, h_iq.nbytes / 2 ** 30),
+                        "pcie_peak_GBs": PCIE_PEAK_GBS, "legs": legs}
+            del h_iq
+            # drop-in: rxgpu_callback + rxgpu_full_demod on the reference's own structs, block after block
+            from rx_tools_amd.structs import DemodState, DongleState
+            d = DemodState()
+            d.rate_in = d.rate_out = 170000
+            d.rate_out2, d.custom_atan, d.deemph, d.deemph_a, d.downsample = 32000, 1, 1, 13, 118
+            d.post_downsample, d.output_scale, d.squelch_hits, d.adc_block_const, d.rdc_block_const = 1, 1, 11, 9, 9
+            libc = C.CDLL(None)
+            libc.pthread_rwlock_init(C.byref(d, DemodState.rw.offset), None)
+            libc.pthread_cond_init(C.byref(d, DemodState.ready.offset), None)
+            libc.pthread_mutex_init(C.byref(d, DemodState.ready_m.offset), None)
+            g = DongleState()
+            g.demod_target = C.pointer(d)
+            blk = d_iq[:block_len].cpu().numpy().copy()
+            for _ in range(5):
+                L.rxgpu_callback(blk.ctypes.data, block_len, C.addressof(g))
+                L.rxgpu_full_demod(C.addressof(d))
+            nb = 200
+            t0 = time.perf_counter()
+            for _ in range(nb):
+                L.rxgpu_callback(blk.ctypes.data, block_len, C.addressof(g))
+            t_cb = (time.perf_counter() - t0) / nb
+            t0 = time.perf_counter()
+            for _ in range(nb):
+                L.rxgpu_callback(blk.ctypes.data, block_len, C.addressof(g))
+                L.rxgpu_full_demod(C.addressof(d))
+            t_both = (time.perf_counter() - t0) / nb
+            host_fed["dropin_block_us"] = {"callback": t_cb * 1e6, "callback+full_demod": t_both * 1e6,
+                                           "block_complex_samples": block_len // 2,
+                                           "MSample/s": (block_len // 2) / t_both / 1e6,
+                                           "note": "one 1 MiB block per call pair: H2D raw, pre-stage kernel, D2H into buf16/lowpassed[]; "
+                                                   "full_demod consumes the copy left in HBM, D2H of lowpassed[]/result[] only"}
         del d_iq
         torch.cuda.empty_cache()
         value = world * T * args.steps / dt / 1e6
         traffic, traffic_src = None, None
+        pmc, pmc_src = pmc_summary()
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))["k_fm_decimate"]
+            k = pmc["k_fm_decimate"]
             # measured on 2^30-sample launches (--blocks 8192); bytes scale with the launch
-            traffic = pmc["hbm_bytes_per_launch"] * (T / float(1 << 30))
-            traffic_src = "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per gfx950 note)"
-        except (OSError, KeyError, ValueError):
+            traffic = k["hbm_bytes_per_launch"] * (T / float(1 << 30))
+            traffic_src = pmc_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per gfx950 note)"
+        except (KeyError, TypeError):
             pass
         achieved = (4.0 * T) / (ms / launches * 1e-3) / 1e9 if launches else 0.0
         result.update({
@@ -284,22 +503,25 @@ def main():
                                    "polar_disc_fast, deemph a=13, low_pass_real (BASELINE configs[1])",
                        "blocks_per_step": n_blocks, "block_complex_samples": block_len // 2,
                        "bytes_per_step": 4 * T, "parallelism": "replicas x%d (rx_fm does not shard)" % world,
-                       "host_fixups_last_step": fixups},
+                       "capture": "non-repeating, generated on the device (seeded): FM carrier at -fs/4, 1 kHz tone, 75 kHz deviation, +-128 LSB noise",
+                       "host_fixups_timed_loop": int(fixups)},
             "rx_fm_variants": variants,
+            "host_fed": host_fed,
             "roofline": {"bound": "hbm", "kernel": "k_fm_decimate (F0+F1+F2)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": 4 * T, "avg_launch_ms": (ms / launches) if launches else None},
         })
+        result.update(parity)
         if rank == 0 and args.cpu_seconds > 0 and world == 1:
             result["cpu_baseline"] = cpu_baseline_fm(block_len, args.cpu_seconds)
-            result["cpu_baseline"]["all_cores"] = cpu_all_cores("fm", min(4.0, args.cpu_seconds))
+            result["cpu_baseline"]["reference_default_build_O0"] = cpu_subprocess("fm", min(3.0, args.cpu_seconds), "libref_fm_O0.so")
+            result["cpu_baseline"]["all_cores"] = cpu_all_cores("fm", min(3.0, args.cpu_seconds))
 
     # ------------------------------------------------------------------ rx_power
     if args.workload in ("both", "rx_power"):
         plan = R.plan_range("24M:1.7G:1k", 0.0, 1)
         n = 1 << plan.bin_e
         total_tunes = plan.tune_count
-        from rx_tools_amd import shard
         lo, mine, per = shard.tune_range(rank, world, total_tunes)   # contiguous tune ranges, SURVEY section 8(e)
         passes = args.passes
         wc, sw = R.window_coefs("rectangle", n), R.sine_table(plan.bin_e)
@@ -308,34 +530,50 @@ def main():
         g = torch.Generator(device=dev)
         g.manual_seed(777 + rank)
         d_in = torch.randint(-100, 101, (passes, max(mine, 1), plan.buf_len), dtype=torch.int16, device=dev, generator=g)
-        # two report-interval buffers: the gather of interval k (RCCL, torch's stream) overlaps the scan of interval k+1
+        # two report-interval buffers: the gather of interval k (behind the scan on the library's stream) never waits for the host
         d_avgs = [torch.zeros((per, n), dtype=torch.int64, device=dev) for _ in range(2)]   # padded to `per` rows for the gather
-        d_smp = torch.zeros(per, dtype=torch.int32, device=dev)
-        gbuf = shard.gather_buffers(d_avgs[0], dst=0) if world > 1 else None
-        gathered = [None, None]          # event after the gather that last read buffer b
+        d_smps = [torch.zeros(per, dtype=torch.int32, device=dev) for _ in range(2)]
+        d_avg_all = torch.zeros((world, per, n), dtype=torch.int64, device=dev) if rank == 0 else None
+        d_smp_all = torch.zeros((world, per), dtype=torch.int32, device=dev) if rank == 0 else None
+        comm, gather_impl, comm_err = None, "single process (no collective)", None
+        if world > 1:
+            try:
+                comm = shard.Comm.from_torch_distributed()
+                gather_impl = "librxgpu rxgpu_power_gather: ncclGather(avg int64) + ncclGather(samples int32) from %s on the library's stream" % shard.Comm.library()
+            except Exception as e:                               # noqa: BLE001 -- say so in the line and fall back to torch.distributed
+                comm_err = repr(e)
+                gather_impl = "torch.distributed.gather (backend nccl = RCCL); librxgpu's own communicator failed: " + comm_err
+            ok = torch.tensor([1 if comm is not None else 0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and comm is not None:          # all ranks or none
+                comm.close()
+                comm = None
+                gather_impl = "torch.distributed.gather (backend nccl = RCCL); librxgpu's communicator failed on another rank"
+        gbuf = shard.gather_buffers(d_avgs[0], dst=0) if (world > 1 and comm is None) else None
+        sbuf = shard.gather_buffers(d_smps[0], dst=0) if (world > 1 and comm is None) else None
         state = {"k": 0}
 
         def step():
             b = state["k"] & 1
             state["k"] += 1
-            if gathered[b] is not None:
-                gathered[b].synchronize()
-            if mine:
-                ps.run(d_in.data_ptr(), passes, mine, d_avgs[b].data_ptr(), d_smp.data_ptr())
-            if world > 1:
-                # order the gather (torch's stream) after the scan (librxgpu's stream)
-                L.rxgpu_sync()
+            if comm is not None or world == 1:
+                R.check(L.rxgpu_power_scan_run_sharded(ps._h, comm._h if comm is not None else None, d_in.data_ptr(), passes, total_tunes,
+                                                       d_avgs[b].data_ptr(), d_smps[b].data_ptr(), n,
+                                                       d_avg_all.data_ptr() if rank == 0 else None,
+                                                       d_smp_all.data_ptr() if rank == 0 else None, 0))
+            else:
+                if mine:
+                    ps.run(d_in.data_ptr(), passes, mine, d_avgs[b].data_ptr(), d_smps[b].data_ptr())
+                L.rxgpu_sync()                                   # order torch's stream behind the library's
                 shard.gather_rows(d_avgs[b], dst=0, out=gbuf)
-                ev = torch.cuda.Event()
-                ev.record()
-                gathered[b] = ev
+                shard.gather_rows(d_smps[b], dst=0, out=sbuf)
 
         for _ in range(args.warmup):
             step()
+        L.rxgpu_sync()
         L.rxgpu_prof_reset()
         L.rxgpu_prof_enable(args.prof_level)
         barrier()
-        L.rxgpu_sync()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
@@ -344,25 +582,75 @@ def main():
         dt = max_over_ranks(time.perf_counter() - t0)
         L.rxgpu_prof_enable(0)
         ms, launches = prof("pw_fft")
+        gms, gl = prof("pw_gather")
         bins_per_step_all = passes * total_tunes * (plan.buf_len // 2)
         bins_local = passes * mine * (plan.buf_len // 2)
-        achieved = (4.0 * bins_local) / (ms / launches * 1e-3) / 1e9 if launches else 0.0
+        hbm_achieved = (4.0 * bins_local) / (ms / launches * 1e-3) / 1e9 if launches else 0.0
+        pmc, pmc_src = pmc_summary()
+        valu = None
+        try:
+            k = pmc["k_pw_fft4096"]
+            # counted on a 512-pass, 599-tune launch; instructions scale with the bins of the launch
+            instr = k["SQ_INSTS_VALU"] * (bins_local / float(512 * 599 * 8192))
+            valu = instr / (ms / launches * 1e-3) / 1e9
+        except (KeyError, TypeError, ZeroDivisionError):
+            pass
         pw = {
             "metric": "rx_power FFT bins/s (scanner() chain, -f 24M:1.7G:1k geometry)",
             "value": bins_per_step_all * args.steps / dt / 1e6, "unit": "Mbins/s", "n_gpus": world,
             "ms_per_step": dt / args.steps * 1e3, "scaling": "strong", "dtype": "int16/int32/int64",
             "config": {"workload": "599 tunes x 16384 int16, N=4096, 2 FFT blocks/tune/pass, rectangle window (BASELINE configs[2]/[3])",
-                       "passes_per_step": passes, "tunes_this_rank": mine,
-                       "parallelism": "tunes sharded x%d, one RCCL gather of avg[] to rank 0 per step" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_pw_fft (P4-P8)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": 4 * bins_local,
-                         "avg_launch_ms": (ms / launches) if launches else None,
-                         "note": "integer-VALU/LDS bound on paper (SURVEY section 8d); HBM fraction reported as asked"},
+                       "passes_per_step": passes, "tunes_this_rank": mine, "tunes_per_rank_padded": per, "rccl_ranks": world,
+                       "parallelism": "tunes sharded x%d, one gather of avg[] + samples to rank 0 per step" % world,
+                       "gather": gather_impl, "gather_us_per_step_rank0": (gms / gl * 1e3) if gl else None,
+                       "gather_bytes_per_rank": per * n * 8 + per * 4},
+            "roofline": {"bound": "valu", "kernel": "k_pw_fft4096 (P4-P8)",
+                         "achieved": valu, "peak": VALU_PEAK_GINSTR * 1e0, "unit": "G wave-instr/s",
+                         "frac": (valu / VALU_PEAK_GINSTR) if valu else None,
+                         "valu_source": (pmc_src + " (rocprofv3 --pmc SQ_INSTS_VALU per launch) / live launch time; peak = 1024 SIMDs x 2.4 GHz / 4 "
+                                         "(one wave64 integer instruction per quad-cycle)") if valu else None,
+                         "hbm_achieved": hbm_achieved, "hbm_peak": HBM_PEAK_GBS, "hbm_unit": "GB/s", "hbm_frac": hbm_achieved / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes_per_launch": 4 * bins_local,
+                         "avg_launch_ms": (ms / launches) if launches else None},
         }
+        ps.close()
+        del d_in
+        # two more geometries of SURVEY 8(d) config 3, one launch shape each, rank 0 only (not part of `value`)
+        more = {}
+        if world == 1 and args.variants == "all":
+            for label, rng, boxcar, window, amp, fir, npasses in (
+                    ("full-scale input, hamming window (every int16 wrap of the window product and the butterflies)", "24M:1.7G:1k", 1, "hamming", 32767, 0, passes),
+                    ("-f 100M:100.1M:10 -F 9: N=16384, fifth_order x4 (ds=16) + droop FIR, one tune", "100M:100.1M:10", 0, "rectangle", 2000, 9, 4096),
+                    ("-f 100M:100.1M:10 (boxcar ds=28), N=16384, one tune", "100M:100.1M:10", 1, "rectangle", 2000, 0, 4096)):
+                pl = R.plan_range(rng, 0.0, boxcar)
+                nn = 1 << pl.bin_e
+                p2 = R.PowerScan(R.PowerParams(pl.bin_e, pl.buf_len, pl.downsample, pl.downsample_passes, boxcar, fir, 0), pl.tune_count,
+                                 R.window_coefs(window, nn), R.sine_table(pl.bin_e))
+                di = torch.randint(-amp, amp + 1, (npasses, pl.tune_count, pl.buf_len), dtype=torch.int16, device=dev, generator=g)
+                da = torch.zeros((pl.tune_count, nn), dtype=torch.int64, device=dev)
+                dsm = torch.zeros(pl.tune_count, dtype=torch.int32, device=dev)
+                for _ in range(2):
+                    p2.run(di.data_ptr(), npasses, pl.tune_count, da.data_ptr(), dsm.data_ptr())
+                L.rxgpu_sync()
+                reps = 5
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    p2.run(di.data_ptr(), npasses, pl.tune_count, da.data_ptr(), dsm.data_ptr())
+                L.rxgpu_sync()
+                t2 = (time.perf_counter() - t0) / reps
+                in_samples = npasses * pl.tune_count * (pl.buf_len // 2)
+                more[label] = {"Mbins/s": in_samples / pl.downsample / t2 / 1e6, "input MSample/s": in_samples / t2 / 1e6,
+                               "GB/s_in": 4.0 * in_samples / t2 / 1e9, "frac_of_hbm_peak": 4.0 * in_samples / t2 / 1e9 / HBM_PEAK_GBS,
+                               "N": nn, "downsample": pl.downsample, "tunes": pl.tune_count, "passes": npasses, "ms": t2 * 1e3}
+                p2.close()
+                del di, da, dsm
+        pw["other_geometries"] = more
         if rank == 0 and args.cpu_seconds > 0 and world == 1:
             pw["cpu_baseline"] = cpu_baseline_power(plan, args.cpu_seconds / 2)
-            pw["cpu_baseline"]["all_cores"] = cpu_all_cores("power", min(4.0, args.cpu_seconds / 2))
-        ps.close()
+            pw["cpu_baseline"]["reference_default_build_O0"] = cpu_subprocess("power", min(3.0, args.cpu_seconds / 2), "libref_power_O0.so")
+            pw["cpu_baseline"]["all_cores"] = cpu_all_cores("power", min(3.0, args.cpu_seconds / 2))
+        if comm is not None:
+            comm.close()
         if args.workload == "rx_power":
             result.update(pw)
             result.update({"steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
@@ -374,9 +662,8 @@ def main():
     if args.workload in ("both", "chan"):
         block_len, bin_e, n_ch = 2 * 131072, 10, 256
         n_blocks = max(8, args.blocks // 8)                       # 2048 blocks = 1 GiB per step by default
-        base = R.synth.sig_fm(8 * 131072, seed=4242 + rank, amp=600.0)
-        d_iq = torch.from_numpy(base).to(dev).repeat(n_blocks // 8 + 1)[: n_blocks * block_len].contiguous()
         T = n_blocks * (block_len // 2)
+        d_iq = device_capture(torch, dev, T, seed=4242 + rank, amp=600.0)
         windows = T >> bin_e
         d_out = torch.zeros((n_ch, windows), dtype=torch.int16, device=dev)
         ch = R.Channeliser(R.ChanParams(bin_e, 384, n_ch, 1), n_blocks, block_len, R.sine_table(bin_e))
@@ -393,6 +680,7 @@ def main():
         dt = max_over_ranks(time.perf_counter() - t0)
         L.rxgpu_prof_enable(0)
         ms, launches = prof("ch_fft")
+        chan_fix = ch.host_fixups
         ch.close()
         achieved = (4.0 * T) / (ms / launches * 1e-3) / 1e9 if launches else 0.0
         result["channeliser"] = {
@@ -400,7 +688,7 @@ def main():
             "value": world * T * steps / dt / 1e6, "unit": "MSample/s", "n_gpus": world, "steps": steps,
             "ms_per_step": dt / steps * 1e3, "dtype": "int16/int32",
             "config": {"workload": "BASELINE configs[4]: 256 channels x 19.5 kHz from one 20 Msps capture, N=1024, -A fast",
-                       "blocks_per_step": n_blocks, "parallelism": "replicas x%d" % world},
+                       "blocks_per_step": n_blocks, "parallelism": "replicas x%d" % world, "host_fixups_last_step": int(chan_fix)},
             "roofline": {"bound": "hbm", "kernel": "k_ch_fft", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": 4 * T,
                          "avg_launch_ms": (ms / launches) if launches else None,
@@ -443,6 +731,9 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
+        if result.get("parity_ok") is False:
+            sys.stderr.write("bench.py: the pipelined GPU output differs from the CPU reference at bench size\n")
+            sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -862,7 +862,13 @@ static int run_host_chunked(rxgpu_fm_stream *s, const int16_t *h_iq, size_t n_bl
 {
 	int rc;
 	hipStream_t sa = rxgpu_hip_stream(), sb = rxgpu_hip_stream2(), sc = rxgpu_hip_stream3();
-	size_t cb = HOST_CHUNK_BYTES / (block_len * 2);
+	size_t chunk_target = HOST_CHUNK_BYTES;
+	{
+		const char *e = getenv("RXGPU_HOST_CHUNK");      /* bytes; tests use it to get many chunks out of a small capture */
+		if (e && atol(e) > 0)
+			chunk_target = (size_t)atol(e);
+	}
+	size_t cb = chunk_target / (block_len * 2);
 	if (cb < 1) cb = 1;
 	if (cb > n_blocks) cb = n_blocks;
 	if (cb > s->max_blocks) cb = s->max_blocks;

@@ -44,9 +44,17 @@ class Comm:
     def from_torch_distributed(cls):
         """Rank 0 makes the ncclUniqueId, torch.distributed (any backend) hands it round, every rank joins."""
         import torch.distributed as dist
+        from ._lib import RxGpuError
         rank, world = dist.get_rank(), dist.get_world_size()
-        box = [cls.unique_id() if rank == 0 else None]
+        box = [None]
+        if rank == 0:
+            try:
+                box[0] = cls.unique_id()
+            except RxGpuError as e:                     # the others are waiting in the broadcast: tell them
+                box[0] = "rank 0: %s" % e
         dist.broadcast_object_list(box, src=0)
+        if not isinstance(box[0], bytes):
+            raise RxGpuError("no ncclUniqueId (%s)" % box[0])
         return cls(box[0], rank, world)
 
     @staticmethod

@@ -121,3 +121,36 @@ def test_scan_and_csv_dropin(rng, flags, window, tmp_path):
         L.rxgpu_csv_dbm(C.byref(arr[t]), f)
     libc.fclose(f)
     assert open(str(tmp_path / "o.csv")).read() == "".join(rows)
+
+
+def test_dropin_handoff_stays_on_the_device_unless_invalidated():
+    """rxgpu_callback leaves the pre-staged block in HBM and rxgpu_full_demod uses that copy; a caller that edits
+    d->lowpassed in between says so with rxgpu_dropin_invalidate and gets the edited block demodulated"""
+    L, O = R.lib(), oracle()
+    R.check(L.rxgpu_init(0))
+    block_len = 16384
+    iq = sig_fm(2 * block_len // 2, seed=43)
+    kw = dict(downsample=6)
+    for edit in (False, True):
+        d = fresh_demod(**kw)
+        s = DongleState()
+        s.demod_target = C.pointer(d)
+        st = oracle_fm_state(**kw)
+        L.rxgpu_deemph_state(C.addressof(d)).contents.value = 0
+        lp = np.zeros(block_len, np.int16)
+        want = np.zeros(block_len, np.int16)
+        for b in range(2):
+            blk = np.ascontiguousarray(iq[b * block_len:(b + 1) * block_len])
+            L.rxgpu_callback(blk.copy().ctypes.data, block_len, C.addressof(s))
+            pre = np.ctypeslib.as_array(d.lowpassed)[:block_len].copy()
+            if edit:
+                pre[100:200] = 0
+                np.ctypeslib.as_array(d.lowpassed)[:block_len] = pre
+                L.rxgpu_dropin_invalidate(C.addressof(d))
+            lp[:block_len] = pre
+            lp_len = C.c_int(block_len)
+            n_want = O.rxo_fm_full_demod(C.byref(st), ptr16(lp), C.byref(lp_len), ptr16(want))
+            L.rxgpu_full_demod(C.addressof(d))
+            assert d.result_len == n_want
+            assert np.array_equal(np.ctypeslib.as_array(d.result)[:n_want], want[:n_want])
+            assert d.lp_len == lp_len.value and np.array_equal(np.ctypeslib.as_array(d.lowpassed)[:d.lp_len], lp[:lp_len.value])

@@ -352,3 +352,107 @@ def test_error_codes():
         R.FmStream(R.FmParams.wbfm(custom_atan=7), 4, 16384)
     with pytest.raises(R.RxGpuError):
         R.PowerScan(R.PowerParams(22, 1 << 24, 1, 0, 1, 0, 0), 1, np.ones(1 << 22, np.int32), np.zeros(3 << 20, np.int16))   # beyond the reference's 2^21
+
+
+# ----------------------------------------------------------------------------- round 2: libm fix-ups inside the pipeline
+
+@pytest.mark.parametrize("params,block_len,n_runs", [
+    (dict(downsample=118), 16384, 5),
+    (dict(downsample=6), 8192, 6),
+    (dict(downsample=20, custom_atan=0), 2 * 5000, 4),               # -A std: every sample is a libm sample
+    (dict(downsample_passes=3, comp_fir_size=9), 16384, 4),
+    (dict(downsample=10, post_downsample=2, dc_block_audio=1), 2 * 10 * 400, 5),
+    (dict(downsample=7, mode=0, deemph=0, rate_out2=-1), 2 * 7 * 300 + 2, 3),   # generic decimator (n % 4 != 0), no audio stages
+])
+def test_pipelined_fixups_redo_audio_stages(params, block_len, n_runs, monkeypatch):
+    """RXGPU_FLAG_ALL=2: the device flags every libm sample AND stores a wrong value for it, in a pipelined sequence
+    (two runs in flight).  Only the host's re-evaluation, the patch of pcm[] and the redo of the audio stages of the
+    flagged run and of the run behind it -- from the snapshot of their carries-in -- can give the oracle's output and
+    carries.  Nothing is rolled back."""
+    monkeypatch.setenv("RXGPU_FLAG_ALL", "2")
+    from gpu_support import gpu_fm_stream, carry_tuple, carry_from_oracle_state
+    n_blocks = 4 * n_runs
+    iq = sig_fm(n_blocks * block_len // 2, seed=77)
+    want, want_lens, st = oracle_fm_stream(iq, block_len, **params)
+    got, got_lens, carry, fixups = gpu_fm_stream(iq, block_len, n_runs=n_runs, pipelined=True, **params)
+    assert np.array_equal(got, want)
+    assert np.array_equal(got_lens, want_lens)
+    assert carry_tuple(carry)[:8] == carry_tuple(carry_from_oracle_state(st))[:8]
+    assert fixups >= n_blocks - 1
+
+
+def test_libm_flag_rate_on_a_million_distinct_blocks():
+    """2^20 callback blocks of 16 noise samples (every block's first decimated sample is a libm sample, all of them
+    different) through a pipelined sequence: bit-exact, and the number of samples the device could not decide stays
+    at the 2 * 2^-33 per sample the window predicts (expected 2.4e-4 here; 1e-6 -- the old window -- would be ~2)."""
+    from gpu_support import gpu_fm_stream
+    n_blocks, block_len = 1 << 20, 32
+    iq = sig_noise(n_blocks * block_len, seed=2026, amp=20000)
+    params = dict(downsample=4)
+    want, want_lens, st = oracle_fm_stream(iq, block_len, **params)
+    got, got_lens, carry, fixups = gpu_fm_stream(iq, block_len, n_runs=4, pipelined=True, **params)
+    assert np.array_equal(got, want)
+    assert fixups <= 1
+    # -A std: 2^22 libm samples in one go
+    iq = sig_noise(2 * (1 << 22) * 4, seed=2027, amp=3000)
+    params = dict(downsample=4, custom_atan=0, deemph=0, rate_out2=-1)
+    want, _, _ = oracle_fm_stream(iq, 2 * 65536, **params)
+    got, _, _, fixups = gpu_fm_stream(iq, 2 * 65536, n_runs=2, pipelined=True, **params)
+    assert np.array_equal(got, want)
+    assert fixups <= 1
+
+
+@pytest.mark.parametrize("params,block_len,n_blocks", [
+    (dict(downsample=118), 16384, 40),
+    (dict(downsample=6), 8192, 37),
+    (dict(downsample_passes=3, comp_fir_size=9), 16384, 19),
+    (dict(downsample=5, mode=4, deemph=0, rate_out2=-1), 8192, 21),      # raw_demod: 2 int16 per decimated sample
+    (dict(downsample=6, squelch_level=40), 8192, 9),                     # squelch: one chunk
+])
+def test_run_host_chunked(params, block_len, n_blocks, monkeypatch):
+    """rxgpu_fm_stream_run_host with a capture of many chunks (RXGPU_HOST_CHUNK shrinks them): H2D of chunk c+1 on the
+    copy stream while chunk c is demodulated, three staging buffers in rotation, outputs concatenated == the oracle."""
+    monkeypatch.setenv("RXGPU_HOST_CHUNK", str(4 * block_len * 2))
+    from gpu_support import carry_tuple, carry_from_oracle_state
+    iq = sig_fm(n_blocks * block_len // 2, seed=99)
+    want, want_lens, st = oracle_fm_stream(iq, block_len, **params)
+    p = R.FmParams.wbfm()
+    for k, v in params.items():
+        setattr(p, k, v)
+    s = R.FmStream(p, n_blocks, block_len)
+    if "squelch_level" in params:
+        s.set_carry(R.FmCarry(squelch_hits=11))
+    out = np.zeros(len(iq) + 64, np.int16)
+    R.check(R.lib().rxgpu_pin(iq.ctypes.data, iq.nbytes))
+    try:
+        n, lens = s.run_host(iq.ctypes.data, n_blocks, block_len, out.ctypes.data, out.size, True)
+    finally:
+        R.check(R.lib().rxgpu_unpin(iq.ctypes.data))
+    assert n == len(want) and np.array_equal(out[:n], want)
+    assert np.array_equal(np.array(lens, np.int32), want_lens)
+    assert carry_tuple(s.get_carry())[:8] == carry_tuple(carry_from_oracle_state(st))[:8]
+    s.close()
+
+
+def test_raw_mode_full_capacity_block_through_run_host():
+    """-M raw hands lowpassed[] through: 2 int16 per decimated sample.  A block that fills the stream's capacity
+    (what dongle_thread_fn delivers: 131072 complex samples) must fit the host-fed path's staging."""
+    block_len = 2 * 131072
+    iq = sig_fm(block_len // 2, seed=3)
+    params = dict(downsample=1, mode=4, deemph=0, rate_out2=-1)
+    want, _, _ = oracle_fm_stream(iq, block_len, **params)
+    p = R.FmParams.wbfm()
+    for k, v in params.items():
+        setattr(p, k, v)
+    s = R.FmStream(p, 1, block_len)
+    out = np.zeros(block_len + 64, np.int16)
+    n, _ = s.run_host(iq.ctypes.data, 1, block_len, out.ctypes.data, out.size)
+    assert n == len(want) == block_len and np.array_equal(out[:n], want)
+    s.close()
+
+
+@pytest.mark.parametrize("block_len", [2 * 6001, 2 * 4098, 2 * 777])
+def test_raw_dc_block_any_block_length(block_len):
+    """-E rdc no longer needs blocks of a multiple of 4 samples (readStream may return any count)"""
+    iq = sig_fm(7 * block_len // 2, seed=8)
+    _check(iq, block_len, downsample=6, dc_block_raw=1, rdc_block_const=4)

@@ -100,3 +100,46 @@ def test_scan_linearity_in_passes_full_geometry():
     # and a few tunes against the oracle
     want, _ = oracle_scan(one[:3 * plan.buf_len], 1, 3, plan, wc, sw, 1, 0, 0)
     assert np.array_equal(a1[:3], want)
+
+
+def _run_rccl_world(world, tmp_path):
+    import os
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(__file__), "rccl_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(world)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+    assert (tmp_path / "ok").exists()
+    return (tmp_path / "ok").read_text()
+
+
+@pytest.mark.timeout(900)
+def test_sharded_sweep_through_librxgpu_rccl_world1(tmp_path):
+    """product scan -> ncclGather issued by librxgpu itself (rxgpu_power_scan_run_sharded, librccl bound at run time)
+    -> rxgpu_csv_dbm on the root == the oracle's CSV.  One rank: what a 1-GPU box can run."""
+    assert "world=1" in _run_rccl_world(1, tmp_path)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_sweep_through_librxgpu_rccl_multi_gpu(world, tmp_path):
+    """the same with one process per GPU over xGMI; needs that many GPUs"""
+    import torch
+    if torch.cuda.device_count() < world:
+        pytest.skip("needs %d GPUs, %d visible" % (world, torch.cuda.device_count()))
+    assert ("world=%d" % world) in _run_rccl_world(world, tmp_path)
+
+
+def test_gather_without_a_communicator_is_a_copy():
+    from gpu_support import torch_cuda
+    torch = torch_cuda()
+    L = R.lib()
+    R.check(L.rxgpu_init(0))
+    a = torch.arange(3 * 8, dtype=torch.int64, device="cuda").reshape(3, 8)
+    s = torch.arange(3, dtype=torch.int32, device="cuda")
+    a2, s2 = torch.zeros_like(a), torch.zeros_like(s)
+    R.check(L.rxgpu_power_gather(None, a.data_ptr(), s.data_ptr(), 3, 8, a2.data_ptr(), s2.data_ptr(), 0))
+    R.check(L.rxgpu_sync())
+    assert torch.equal(a, a2) and torch.equal(s, s2)
