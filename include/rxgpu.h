@@ -77,6 +77,11 @@ int rxgpu_prof_get(const char *name, double *total_ms, long *launches);
 void rxgpu_full_demod(struct demod_state *d);
 /* a caller that edits d->lowpassed between rxgpu_callback and rxgpu_full_demod says so here */
 void rxgpu_dropin_invalidate(const struct demod_state *d);
+/* Optional, once at start-up: page-lock lowpassed[]..result[] of *d and buf16[] of *s so that the drop-in's copies are
+ * DMA'd in place (SURVEY.md section 8b "Ownership").  The structs must outlive the registration -- the reference's are
+ * globals (rtl_fm.c:190-191); rxgpu_dropin_unpin before freeing heap-allocated ones.  Either pointer may be NULL. */
+int rxgpu_dropin_pin(struct demod_state *d, struct dongle_state *s);
+int rxgpu_dropin_unpin(struct demod_state *d, struct dongle_state *s);
 
 /* Replaces rtlsdr_callback(buf, len, ctx) at rtl_fm.c:899 (definition 828-863):
  * mute-zero, CS16 -> 8-bit-range scale, rotate16_90 unless offset tuning, hand-off into

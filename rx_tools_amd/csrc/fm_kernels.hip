@@ -49,6 +49,18 @@ __device__ __forceinline__ uint32_t pack_iq(int i, int q) { return ((uint32_t)i 
 __device__ __forceinline__ int lo16(uint32_t w) { return (int)(short)(w & 0xffffu); }
 __device__ __forceinline__ int hi16(uint32_t w) { return (int)w >> 16; }
 
+// Tiled layout of the demodulated stream for the lane-per-chunk audio kernels (k_fm_deemph_scan_t / _apply_rs_t):
+// a tile is 64 chunks of CH = 2^chl2 samples; inside a tile the 16-byte unit u (8 samples) of chunk c sits at unit
+// u*64 + c, so that 64 lanes walking 64 consecutive chunks read 1 KiB contiguous per instruction -- no LDS transpose,
+// no staging, full occupancy.  Sample m = tile*64*CH + c*CH + k  ->  tile*64*CH + (k/8)*512 + c*8 + k%8.  chl2 == 0: linear.
+__device__ __forceinline__ u64 pcm_index(u64 m, int chl2)
+{
+	if (!chl2)
+		return m;
+	const unsigned k = (unsigned)m & ((1u << chl2) - 1u), c = (unsigned)(m >> chl2) & 63u;
+	return (m & ~(((u64)64 << chl2) - 1)) | ((u64)(k >> 3) << 9) | (c << 3) | (k & 7u);
+}
+
 // F0, rtl_fm.c:846: (int16)(x / 32767.0 * 128.0 + 0.4) in double, truncated.  One fp32
 // fma reproduces it for all 65536 inputs (checked exhaustively in tests/test_scale.py and
 // on the device in tests/test_gpu_fm.py): the result is never closer than 6.0e-6 to an
@@ -153,6 +165,19 @@ __device__ __forceinline__ void dec_contrib(const u32x4 v, uint32_t &s0, uint32_
 // barrier, output j = slot[j] - slot[j-1].  The window that straddles the workgroup start
 // is finished by rxk_fm_disc from head[]/tail[].
 __device__ __forceinline__ int fast_atan2_dev(int y, int x);
+__device__ __forceinline__ void mul_conj_pk(uint32_t a, uint32_t b, int &cr, int &cj);
+
+// the packed prefix up to the end of window j of a span: slot[j] plus the totals of the waves before the one that wrote it
+// (b1, b2, b3 = totals of waves 0, 0..1, 0..2); the window's last sample, span-relative, names the writer.  Range tests on
+// the position, not a switch on the wave number: the compiler turns the latter into a table in scratch memory.
+__device__ __forceinline__ uint32_t dec_prefix(const uint32_t *slot, unsigned j, unsigned ds, unsigned e_off, uint32_t b1, uint32_t b2, uint32_t b3)
+{
+	const unsigned e1 = __umul24(j, ds) + e_off;             // j < 2^13, ds < 2^14
+	uint32_t base = e1 >= DEC_WAVE_SPAN ? b1 : 0u;
+	base = e1 >= 2 * DEC_WAVE_SPAN ? b2 : base;
+	base = e1 >= 3 * DEC_WAVE_SPAN ? b3 : base;
+	return pk_add(slot[j], base);
+}
 
 // DISC: also run the -A fast discriminator (F5/F6) for every output whose predecessor was completed
 // by this workgroup too (all but its first two), while the sums are still in LDS/registers; the
@@ -161,7 +186,7 @@ template <bool PRESCALED, bool ROTATE, bool DISC, bool DIV24>
 __global__ __launch_bounds__(DEC_THREADS) void k_fm_decimate(
 	const u32x4 *__restrict__ iq, u64 T, int ds, int p0, unsigned magic, unsigned magic24,
 	uint32_t *__restrict__ lp_raw, uint32_t *__restrict__ head, uint32_t *__restrict__ tail, unsigned slot_cap,
-	int lp_sparse, int16_t *__restrict__ pcm)
+	int lp_sparse, int16_t *__restrict__ pcm, int pcm_chl2)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 	uint32_t *slot = lds;
@@ -227,42 +252,59 @@ __global__ __launch_bounds__(DEC_THREADS) void k_fm_decimate(
 	const uint32_t b1 = wtot[0], b2 = pk_add(b1, wtot[1]), b3 = pk_add(b2, wtot[2]);
 	const uint32_t total = pk_add(b3, wtot[3]);
 	const unsigned n_b = (span + ph) / (unsigned)ds;
-	for (unsigned j = threadIdx.x; j < n_b; j += DEC_THREADS) {
-		const unsigned e = (j + 1) * (unsigned)ds - ph;
-		const unsigned wv = (e - 1) / DEC_WAVE_SPAN;
-		const uint32_t pj = pk_add(slot[j], wv == 0 ? 0u : wv == 1 ? b1 : wv == 2 ? b2 : b3);
+	// P(j): the packed prefix up to the end of window j = slot[j] + the totals of the waves before the one that wrote it
+	// (the window's last sample, span-relative e1 = j*ds + ds - ph - 1, names that wave)
+	const unsigned e_off = (unsigned)ds - ph - 1u;
+#define PREFIX_AT(J) dec_prefix(slot, (J), (unsigned)ds, e_off, b1, b2, b3)
+	// Every wave takes a contiguous quarter of the outputs, 64 consecutive ones per turn: output j = P(j) - P(j-1) and the
+	// discriminator also wants P(j-2) -- both sit in the neighbouring lanes (two wave-wide DPP shifts), the two values
+	// that cross a turn travel in SGPRs.  One LDS read and one prefix selection per output instead of three.
+	const unsigned per_wave = (n_b + 3) / 4;
+	const unsigned j_lo = wave * per_wave, j_hi = min(n_b, j_lo + per_wave);
+	uint32_t c1 = 0, c2 = 0;                                 // P(j-1), P(j-2) for the turn's first lane
+	if (j_lo < j_hi) {
+		if (j_lo >= 1) c1 = PREFIX_AT(j_lo - 1);
+		if (j_lo >= 2) c2 = PREFIX_AT(j_lo - 2);
+	}
+	for (unsigned j0 = j_lo; j0 < j_hi; j0 += 64) {
+		const unsigned j = j0 + lane;
+		const bool live = j < j_hi;
+		const uint32_t pj = PREFIX_AT(live ? j : j_hi - 1);
+		const uint32_t pm = (uint32_t)__builtin_amdgcn_update_dpp((int)c1, (int)pj, 0x138, 0xf, 0xf, false);    // wave_shr:1, lane 0 keeps c1
+		const uint32_t pmm = (uint32_t)__builtin_amdgcn_update_dpp((int)c2, (int)pm, 0x138, 0xf, 0xf, false);
+		c1 = (uint32_t)__builtin_amdgcn_readlane((int)pj, 63);
+		c2 = (uint32_t)__builtin_amdgcn_readlane((int)pj, 62);
+		if (!live)
+			continue;
 		if (j == 0) {
 			head[wgi] = pj;
-		} else {
-			const unsigned wq = (e - (unsigned)ds - 1) / DEC_WAVE_SPAN;
-			const uint32_t pm = pk_add(slot[j - 1], wq == 0 ? 0u : wq == 1 ? b1 : wq == 2 ? b2 : b3);
-			const uint32_t a = pk_sub(pj, pm);
-			if (!lp_sparse || j == 1 || j == n_b - 1)
-				lp_raw[m_base + j] = a;
-			if (DISC && j >= 2) {
-				const unsigned wr = (e - 2 * (unsigned)ds - 1) / DEC_WAVE_SPAN;
-				const uint32_t pmm = pk_add(slot[j - 2], wr == 0 ? 0u : wr == 1 ? b1 : wr == 2 ? b2 : b3);
-				const uint32_t b = pk_sub(pm, pmm);
-				const int ar = lo16(a), aj = hi16(a), br = lo16(b), bj = hi16(b);
-				// multiply(a, conj(b)), rtl_fm.c:470-474 via 511, wrapping like -fwrapv
-				const int cr = (int)((unsigned)ar * (unsigned)br + (unsigned)aj * (unsigned)bj);
-				const int cj = (int)((unsigned)aj * (unsigned)br - (unsigned)ar * (unsigned)bj);
-				__builtin_nontemporal_store((int16_t)fast_atan2_dev(cj, cr), &pcm[m_base + j]);
-			}
+			continue;
+		}
+		const uint32_t a = pk_sub(pj, pm);
+		if (!lp_sparse || j == 1 || j == n_b - 1)
+			lp_raw[m_base + j] = a;
+		if (DISC && j >= 2) {
+			int cr, cj;
+			mul_conj_pk(a, pk_sub(pm, pmm), cr, cj);
+			const int16_t v = (int16_t)fast_atan2_dev(cj, cr);
+			if (pcm_chl2)
+				pcm[pcm_index(m_base + j, pcm_chl2)] = v;        // 16-byte pieces of a line arrive from different turns: let L2 merge them
+			else
+				__builtin_nontemporal_store(v, &pcm[m_base + j]);
 		}
 	}
 	if (threadIdx.x == 0) {
 		uint32_t last = 0;
 		if (n_b) {
-			const unsigned e = n_b * (unsigned)ds - ph;
-			const unsigned wv = (e - 1) / DEC_WAVE_SPAN;
-			last = pk_add(slot[n_b - 1], wv == 0 ? 0u : wv == 1 ? b1 : wv == 2 ? b2 : b3);
+			last = PREFIX_AT(n_b - 1);
 		} else {
 			head[wgi] = 0;
 		}
 		tail[wgi] = pk_sub(total, last);
 	}
 }
+
+#undef PREFIX_AT
 
 // One sample, scaled and rotated by its position in its block (exact int)
 template <bool PRESCALED>
@@ -304,6 +346,24 @@ __global__ void k_fm_decimate_generic(const uint32_t *__restrict__ iq, u64 T, in
 
 // ------------------------------------------------------------------ F5/F6 discriminator
 
+// C's truncating int32 division.  Fast path: the quotient from one fp32 reciprocal (v_rcp_f32, 1 ulp) is within 2^-21
+// relative of the true one, so for |quotient| < 2^20 its truncation is off by at most one, which the exact 32-bit
+// remainder settles (|den| < 2^30 keeps that remainder inside an int32).  Anything else -- quotients the int32 wrap of
+// fast_atan2's numerator can produce -- takes one correctly rounded fp64 division: a non-integer quotient of two int32
+// lies at least 1/|den| away from the next integer while the rounding error is below 2^-22/|den|.
+__device__ __forceinline__ int div_trunc(int num, int den)
+{
+	const unsigned un = num < 0 ? 0u - (unsigned)num : (unsigned)num;
+	const unsigned ud = den < 0 ? 0u - (unsigned)den : (unsigned)den;
+	const float fq = (float)un * __builtin_amdgcn_rcpf((float)ud);
+	if (__builtin_expect(ud >= (1u << 30) || !(fq < 1048576.0f), 0))
+		return (int)((double)num / (double)den);
+	unsigned q = (unsigned)fq;
+	const int r = (int)(un - q * ud);
+	q = r < 0 ? q - 1 : ((unsigned)r >= ud ? q + 1 : q);
+	return ((num ^ den) < 0) ? -(int)q : (int)q;
+}
+
 // rtl_fm.c:485-506 with the int32 wrap of `pi4 * (x -/+ yabs)` and C's truncating division
 __device__ __forceinline__ int fast_atan2_dev(int y, int x)
 {
@@ -312,15 +372,22 @@ __device__ __forceinline__ int fast_atan2_dev(int y, int x)
 	const unsigned ux = (unsigned)x;
 	const unsigned ay = y < 0 ? 0u - (unsigned)y : (unsigned)y;
 	// x >= 0: pi/4 - pi/4 * (x - |y|) / (x + |y|);  x < 0: 3pi/4 - pi/4 * (x + |y|) / (|y| - x)  -- one division site,
-	// so lanes of both kinds do not walk the (long) division expansion twice
+	// so lanes of both kinds do not walk the division twice
 	const bool neg = x < 0;
 	const int num = (int)(4096u * (neg ? ux + ay : ux - ay));
 	const int den = (int)(neg ? ay - ux : ux + ay);
-	// C's truncating int division through one correctly rounded fp64 division: for |num|, |den| < 2^31 a quotient that
-	// is not an integer lies at least 1/|den| away from the next one while the rounding error is below 2^-22/|den|,
-	// so the truncation is the same -- and the fp64 sequence is about a third of the integer expansion
-	const int ang = (neg ? 12288 : 4096) - (int)((double)num / (double)den);
+	const int ang = (neg ? 12288 : 4096) - div_trunc(num, den);
 	return y < 0 ? -ang : ang;
+}
+
+// multiply(a, conj(b)) on packed (re, im) int16 pairs, rtl_fm.c:470-474 via 480/511, wrapping like -fwrapv:
+// cr = ar*br + aj*bj is one v_dot2_i32_i16, cj = aj*br - ar*bj two v_mad_i32_i16 (op_sel picks the halves) and a subtraction
+__device__ __forceinline__ void mul_conj_pk(uint32_t a, uint32_t b, int &cr, int &cj)
+{
+	cr = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), 0, false);
+	int t, u;
+	asm("v_mad_i32_i16 %0, %2, %3, 0 op_sel:[1,0,0,0]\n\tv_mad_i32_i16 %1, %2, %3, 0 op_sel:[0,1,0,0]" : "=&v"(t), "=&v"(u) : "v"(a), "v"(b));
+	cj = (int)((unsigned)t - (unsigned)u);
 }
 
 // rtl_fm.c:528-564 on the already multiplied (cr, cj); atan_lut from atan_lut_init (515-526, host libm)
@@ -412,7 +479,7 @@ __global__ __launch_bounds__(256) void k_fm_disc(
 	const uint32_t *lp_raw, const uint32_t *__restrict__ head, const uint32_t *__restrict__ tail,
 	uint32_t *lp /* may alias lp_raw: seam entries are finished in place */, u64 M, int first_mode, u64 uniform_k, int custom_atan, int do_tail,
 	int16_t *__restrict__ pcm, rxk_fm_dev *__restrict__ dev, rxk_flag_rec *__restrict__ flag_list, int *__restrict__ flag_cnt,
-	unsigned out_blocks, int sparse, u64 n_wg, u64 n_blocks, const int *__restrict__ atan_lut, int lp_sparse, int flag_all)
+	unsigned out_blocks, int sparse, u64 n_wg, u64 n_blocks, const int *__restrict__ atan_lut, int lp_sparse, int flag_all, int pcm_chl2)
 {
 	if (blockIdx.x >= out_blocks) {
 		// ---- low_pass carry: exact int32 sums of the samples after the last complete window
@@ -479,7 +546,7 @@ __global__ __launch_bounds__(256) void k_fm_disc(
 		br = dev->in_pre_r; bj = dev->in_pre_j;
 	}
 	const int ar = lo16(a), aj = hi16(a);
-	// multiply(a, conj(b)), rtl_fm.c:470-474 via 480/511, wrapping like -fwrapv
+	// multiply(a, conj(b)), rtl_fm.c:470-474 via 480/511, wrapping like -fwrapv (pre_r/pre_j are full ints: plain products)
 	const int cr = (int)((unsigned)ar * (unsigned)br + (unsigned)aj * (unsigned)bj);
 	const int cj = (int)((unsigned)aj * (unsigned)br - (unsigned)ar * (unsigned)bj);
 
@@ -517,7 +584,7 @@ __global__ __launch_bounds__(256) void k_fm_disc(
 	} else {
 		out = esbensen_dev(ar, aj, br, bj);
 	}
-	pcm[m] = (int16_t)out;
+	pcm[pcm_index(m, pcm_chl2)] = (int16_t)out;
 	if (m == M - 1) {
 		dev->out_pre_r = ar;
 		dev->out_pre_j = aj;
@@ -1148,6 +1215,256 @@ __global__ void k_fm_deemph_serial(const int16_t *__restrict__ pcm, u64 M, int a
 		y[i] = (int16_t)s;
 	}
 	dev->out_deemph_avg = s;
+}
+
+
+// ------------------------------------------------------------------ F8 + F9 on the tiled stream (the small-decimation chain)
+
+// With -M wbfm's default decimation (ds = 6; ds = 5 for BASELINE configs[0]) the audio stages see a sixth of the capture
+// rate and the LDS-staged kernels above -- one 64-lane workgroup per 16 KiB of staging, two waves per SIMD, loads, compute
+// and stores one after the other -- are latency-bound at a fraction of the VALU rate.  Here the decimator hands the
+// demodulated samples over in the tiled layout (pcm_index), every lane streams its chunk with coalesced 16-byte loads
+// straight into registers, there is no LDS staging and no barrier, eight waves per SIMD:
+//   k_fm_deemph_scan_t     per chunk: warm-up on the previous chunk's tail (two extreme trajectories), then the lowest
+//                          candidate + merge mask (deemph_track's idea, three-instruction step) -> a COMPACT chunk table
+//                          {lo_start, lo_end | gap << 16, mask} of 16 bytes
+//   k_fm_deemph_up0/down0  the tree's first level on compact tables (16 chunks per parent); the levels above are the
+//                          kernels of the LDS-staged path (k_fm_deemph_up / _top / _down)
+//   k_fm_deemph_apply_rs_t every chunk replayed from its exact start state, and low_pass_real (rtl_fm.c:389-409) run
+//                          INLINE on the filtered samples: de-emphasised audio never goes to HBM.  A lane owns the
+//                          resampler windows that START in its chunk and walks on into the next chunk to finish the last
+//                          one; outputs are staged per wave in a few KiB of LDS and leave coalesced.
+// Odd a in 5..255 only (the three-instruction step), 2 <= rate_out / rate_out2 <= 32; everything else keeps the other path.
+
+__device__ __forceinline__ const uint4 *tile_unit(const int16_t *pcm_t, u64 chunk, int chl2)
+{
+	return reinterpret_cast<const uint4 *>(pcm_t + ((chunk >> 6) << (6 + chl2))) + (chunk & 63);
+}
+
+__device__ __forceinline__ int ctab_apply(const uint4 t, int v)
+{
+	const int idx = v - (int)t.x;                                  // 0 .. gap
+	const u64 mask = (u64)t.z | ((u64)t.w << 32);
+	const u64 below = idx >= 64 ? ~0ull : (((u64)1 << idx) - 1);
+	return (int)(short)(t.y & 0xffffu) + __popcll(mask & below);
+}
+
+template <int GS, int CHL2>
+__global__ __launch_bounds__(256) void k_fm_deemph_scan_t(
+	const int16_t *__restrict__ pcm_t, u64 M, int a, unsigned magic, int warm, int lo0, int hi0,
+	uint4 *__restrict__ ctab, rxk_fm_dev *__restrict__ dev)
+{
+	constexpr int CH = 1 << CHL2, UPC = CH / 8;
+	const u64 c = ((u64)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + (threadIdx.x & 63);
+	const u64 n_chunks = (M + CH - 1) >> CHL2;
+	if (c >= n_chunks)
+		return;
+	const u64 c0 = c << CHL2;
+	const int n = (int)((M - c0) < (u64)CH ? (M - c0) : (u64)CH);
+	const int h = a / 2;
+	int lo, hi;
+	if (c == 0) {                                             // the run's carried state
+		lo = hi = dev->in_deemph_avg;
+	} else {
+		const uint4 *row = tile_unit(pcm_t, c - 1, CHL2);
+		int nl = de_state(lo0, h), nh = de_state(hi0, h);
+		const int u0 = (CH - warm) >> 3;
+		uint4 w = row[(size_t)u0 * 64];
+		for (int u = u0; u < UPC; u++) {
+			const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+			if (u + 1 < UPC)
+				w = row[(size_t)(u + 1) * 64];
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				de_step<0>(ww[k], nl, magic, -64); de_step<0>(ww[k], nh, magic, -64);
+				de_step<1>(ww[k], nl, magic, -64); de_step<1>(ww[k], nh, magic, -64);
+			}
+		}
+		lo = de_avg(nl, h);
+		hi = de_avg(nh, h);
+	}
+	int gap = hi - lo;
+	if (gap >= GS) {                                          // excluded by `warm` (rxgpu_fm.c); checked anyway
+		atomicExch(&dev->err, 1);
+		gap = GS - 1;
+	}
+	typedef typename deemph_mask<GS>::type MASK;
+	const int lo_start = lo;
+	MASK mask = (MASK)(((MASK)1 << gap) - 1);
+	const uint4 *row = tile_unit(pcm_t, c, CHL2);
+	int N = de_state(lo, h), cm6 = gap << 6;                  // r6 < cm6  <=>  remainder + 1 < number of distinct candidates
+	const int na6 = -(a << 6);
+	const int nu = n >> 3;
+	uint4 w = row[0];
+	for (int u = 0; u < nu; u++) {
+		const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+		if (u + 1 < UPC)
+			w = row[(size_t)(u + 1) * 64];                    // the next unit (or the ragged one) while this one is walked
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			int r6 = de_step_r<0>(ww[k], N, magic, -64, na6);
+			if (__builtin_expect(r6 < cm6, 0)) { de_merge(mask, r6 >> 6); cm6 -= 64; }
+			r6 = de_step_r<1>(ww[k], N, magic, -64, na6);
+			if (__builtin_expect(r6 < cm6, 0)) { de_merge(mask, r6 >> 6); cm6 -= 64; }
+		}
+	}
+	if (n & 7) {                                              // the ragged end of the run
+		const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+		for (int k = 0; k < (n & 7); k++) {
+			const int r6 = (k & 1) ? de_step_r<1>(ww[k >> 1], N, magic, -64, na6) : de_step_r<0>(ww[k >> 1], N, magic, -64, na6);
+			if (r6 < cm6) { de_merge(mask, r6 >> 6); cm6 -= 64; }
+		}
+	}
+	const int lo_end = de_avg(N, h);
+	const u64 m64 = (u64)mask;
+	ctab[c] = make_uint4((uint32_t)lo_start, ((uint32_t)lo_end & 0xffffu) | ((uint32_t)gap << 16), (uint32_t)m64, (uint32_t)(m64 >> 32));
+}
+
+// first tree level on compact tables: thread (parent, k) walks the parent's 16 chunk tables
+__global__ void k_fm_deemph_up0(u64 n_chunks, int gs, const uint4 *__restrict__ ctab, int *__restrict__ p_tab, int *__restrict__ p_lo,
+                                int *__restrict__ p_gap)
+{
+	const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	const u64 parent = gid / gs;
+	const int k = (int)(gid % gs);
+	const u64 first = parent * DEEMPH_FAN;
+	if (first >= n_chunks)
+		return;
+	const int cnt = (int)((n_chunks - first) < DEEMPH_FAN ? (n_chunks - first) : DEEMPH_FAN);
+	const uint4 t0 = ctab[first];
+	const int g0 = (int)(t0.y >> 16);
+	int v = (int)t0.x + (k < g0 ? k : g0);
+	for (int i = 0; i < cnt; i++)
+		v = ctab_apply(ctab[first + i], v);
+	p_tab[parent * gs + k] = v;
+	if (k == 0) { p_lo[parent] = (int)t0.x; p_gap[parent] = g0; }
+}
+
+// ... and back down: the exact start state of every chunk
+__global__ void k_fm_deemph_down0(u64 n_chunks, const uint4 *__restrict__ ctab, const int *__restrict__ p_start, int *__restrict__ start)
+{
+	const u64 parent = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	const u64 first = parent * DEEMPH_FAN;
+	if (first >= n_chunks)
+		return;
+	const int cnt = (int)((n_chunks - first) < DEEMPH_FAN ? (n_chunks - first) : DEEMPH_FAN);
+	int s = p_start[parent];
+	for (int i = 0; i < cnt; i++) {
+		start[first + i] = s;
+		s = ctab_apply(ctab[first + i], s);
+	}
+}
+
+// floor(num / den) for num < 2^52 (declared with the resampler below)
+__device__ __forceinline__ u64 div_floor(u64 num, u64 den);
+
+// One sample of low_pass_real run inline behind the de-emphasis step: y joins the window if this lane owns it, the
+// phase advances, and a completed window leaves as (int16)(sum / ratio) -- the truncating division through one fp32
+// multiply by a reciprocal rounded up (exact for |sum| <= 34 * 32768 and ratio <= 32, checked exhaustively on the host).
+// Branch-free: lanes are at different phases, some lane of the wave emits at nearly every sample.
+__device__ __forceinline__ void lpr_step(int y, int &own, int &acc, int &p, int &slot, int fast, int slow, float rinv, int16_t *stage)
+{
+	own |= p < slow ? 1 : 0;                                  // a window starts at this sample
+	acc += own ? y : 0;
+	p += slow;
+	const bool emit = p >= fast;
+	const int q = (int)((float)acc * rinv);
+	if (emit && own)
+		stage[slot] = (int16_t)q;
+	slot += (emit && own) ? 1 : 0;
+	acc = emit ? 0 : acc;
+	p -= emit ? fast : 0;
+}
+
+template <int CHL2>
+__global__ __launch_bounds__(256) void k_fm_deemph_apply_rs_t(
+	const int16_t *__restrict__ pcm_t, u64 M, int a, unsigned magic, const int *__restrict__ start,
+	int fast, int slow, float rinv, int wcap, int16_t *__restrict__ out, rxk_fm_dev *__restrict__ dev)
+{
+	constexpr int CH = 1 << CHL2, UPC = CH / 8;
+	extern __shared__ int16_t stage_all[];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	int16_t *stage = stage_all + (size_t)wave * wcap;
+	const u64 cw = ((u64)blockIdx.x * 4 + wave) * 64;         // the wave's first chunk
+	const u64 c = cw + lane;
+	const u64 n_chunks = (M + CH - 1) >> CHL2;
+	if (cw >= n_chunks)
+		return;
+	const bool valid = c < n_chunks;
+	const int h = a / 2;
+	const u64 p_in = (u64)dev->in_prev_lpr_index;
+	// outputs completed before this chunk, and the resampler phase at its first sample (rtl_fm.c:397-399)
+	const u64 c0 = valid ? c << CHL2 : M;
+	const u64 num = p_in + c0 * (u64)slow;
+	const u64 e0 = div_floor(num, (u64)fast);
+	int p = (int)(num - e0 * (u64)fast);
+	int own = (c == 0) ? 1 : 0;                               // the run's first lane continues the carried window
+	int acc = (c == 0) ? dev->in_now_lpr : 0;
+	// first output this lane will write: e0 if a window starts exactly here (or it is the run's first lane), else the one after
+	const u64 j_first = e0 + ((c == 0 || p < slow) ? 0 : 1);
+	const u64 jw0 = (u64)__builtin_amdgcn_readfirstlane((int)(unsigned)j_first) | ((u64)__builtin_amdgcn_readfirstlane((int)(unsigned)(j_first >> 32)) << 32);
+	int slot = (int)(j_first - jw0);
+	if (valid) {
+		const int n = (int)((M - c0) < (u64)CH ? (M - c0) : (u64)CH);
+		int N = de_state(start[c], h);
+		const uint4 *row = tile_unit(pcm_t, c, CHL2);
+		const int nu = n >> 3;
+		uint4 w = row[0];
+		for (int u = 0; u < nu; u++) {
+			const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+			if (u + 1 < UPC)
+				w = row[(size_t)(u + 1) * 64];
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				de_step<0>(ww[k], N, magic, -64);
+				lpr_step(h - (N >> 6), own, acc, p, slot, fast, slow, rinv, stage);
+				de_step<1>(ww[k], N, magic, -64);
+				lpr_step(h - (N >> 6), own, acc, p, slot, fast, slow, rinv, stage);
+			}
+		}
+		if (n & 7) {
+			const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+			for (int k = 0; k < (n & 7); k++) {
+				if (k & 1) de_step<1>(ww[k >> 1], N, magic, -64); else de_step<0>(ww[k >> 1], N, magic, -64);
+				lpr_step(h - (N >> 6), own, acc, p, slot, fast, slow, rinv, stage);
+			}
+		}
+		const u64 end = c0 + (u64)n;
+		if (end == M) {
+			// the run's last chunk: what is left is the carry (rtl_fm.c:150-151).  A window still open belongs either to
+			// this lane (own) or to an earlier lane that walks on to M below and writes it; no window open: zero.
+			if (own)
+				dev->out_now_lpr = acc;
+			else if (p < slow)
+				dev->out_now_lpr = 0;
+			dev->out_prev_lpr_index = p;
+		} else if (own && p >= slow) {
+			// a window this lane owns is still open: walk on into the following chunk(s) until it completes
+			u64 i = end;
+			bool open = true;
+			while (open && i < M) {
+				const uint4 wv = tile_unit(pcm_t, i >> CHL2, CHL2)[(size_t)((unsigned)(i & (CH - 1)) >> 3) * 64];
+				const uint32_t ww[4] = {wv.x, wv.y, wv.z, wv.w};
+				for (int k = (int)(i & 7); k < 8 && open && i < M; k++, i++) {
+					if (k & 1) de_step<1>(ww[k >> 1], N, magic, -64); else de_step<0>(ww[k >> 1], N, magic, -64);
+					const int before = slot;
+					lpr_step(h - (N >> 6), own, acc, p, slot, fast, slow, rinv, stage);
+					open = slot == before;
+				}
+			}
+			if (open)
+				dev->out_now_lpr = acc;                       // ran into the end of the run: this partial window is the carry
+		}
+	}
+	// the wave's outputs [jw0, jw0 + cnt) leave coalesced; lanes own ascending, contiguous ranges
+	int cnt = valid ? slot : 0;
+	for (int off = 32; off; off >>= 1)
+		cnt = max(cnt, __shfl_xor(cnt, off));
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	for (int idx = lane; idx < cnt; idx += 64)
+		out[jw0 + (u64)idx] = stage[idx];
 }
 
 // ------------------------------------------------------------------ F9 low_pass_real
@@ -1870,7 +2187,7 @@ __global__ void k_ch_demod(const uint32_t *__restrict__ chan_lp, u64 total_windo
 #define LAUNCH_RET() return (int)hipGetLastError()
 
 extern "C" int rxk_fm_decimate(void *stream, const int16_t *iq, u64 T, int ds, int p0, int prescaled, int rotate,
-                               uint32_t *lp_raw, uint32_t *head, uint32_t *tail, int lp_sparse, int16_t *pcm)
+                               uint32_t *lp_raw, uint32_t *head, uint32_t *tail, int lp_sparse, int16_t *pcm, int pcm_chl2)
 {
 	if (!pcm || ds > RXK_LP_SPARSE_MAX_DS)
 		lp_sparse = 0;
@@ -1883,7 +2200,7 @@ extern "C" int rxk_fm_decimate(void *stream, const int16_t *iq, u64 T, int ds, i
 	hipStream_t s = (hipStream_t)stream;
 	const u32x4 *p = (const u32x4 *)iq;
 #define GO3(PS, RT, DC, D24) hipLaunchKernelGGL((k_fm_decimate<PS, RT, DC, D24>), dim3(grid), dim3(DEC_THREADS), shm, s, p, T, ds, p0, \
-		magic, magic24, lp_raw, head, tail, slot_cap, lp_sparse, pcm)
+		magic, magic24, lp_raw, head, tail, slot_cap, lp_sparse, pcm, pcm_chl2)
 #define GO(PS, RT) do { \
 		if (pcm) { if (magic24) GO3(PS, RT, true, true); else GO3(PS, RT, true, false); } \
 		else { if (magic24) GO3(PS, RT, false, true); else GO3(PS, RT, false, false); } } while (0)
@@ -1913,7 +2230,7 @@ extern "C" int rxk_fm_disc(void *stream, const int16_t *iq, u64 T, int ds, int p
                            int rotate, int seams, const uint32_t *lp_raw, const uint32_t *head, const uint32_t *tail,
                            uint32_t *lp, u64 M, int first_mode, u64 uniform_k, int custom_atan, int do_tail,
                            int16_t *pcm, rxk_fm_dev *dev, rxk_flag_rec *flag_list, int *flag_cnt, int sparse, u64 n_blocks, const int *atan_lut,
-                           int lp_sparse, int flag_all)
+                           int lp_sparse, int flag_all, int pcm_chl2)
 {
 	if (!sparse || !seams)
 		lp_sparse = 0;
@@ -1925,10 +2242,10 @@ extern "C" int rxk_fm_disc(void *stream, const int16_t *iq, u64 T, int ds, int p
 	hipStream_t s = (hipStream_t)stream;
 	if (prescaled)
 		hipLaunchKernelGGL((k_fm_disc<true>), dim3(grid), dim3(256), 0, s, (const uint32_t *)iq, T, ds, p0, n_per_block, 0, seams,
-		                   lp_raw, head, tail, lp, M, first_mode, uniform_k, custom_atan, do_tail, pcm, dev, flag_list, flag_cnt, out_blocks, sparse, n_wg, n_blocks, atan_lut, lp_sparse, flag_all);
+		                   lp_raw, head, tail, lp, M, first_mode, uniform_k, custom_atan, do_tail, pcm, dev, flag_list, flag_cnt, out_blocks, sparse, n_wg, n_blocks, atan_lut, lp_sparse, flag_all, pcm_chl2);
 	else
 		hipLaunchKernelGGL((k_fm_disc<false>), dim3(grid), dim3(256), 0, s, (const uint32_t *)iq, T, ds, p0, n_per_block, rotate, seams,
-		                   lp_raw, head, tail, lp, M, first_mode, uniform_k, custom_atan, do_tail, pcm, dev, flag_list, flag_cnt, out_blocks, sparse, n_wg, n_blocks, atan_lut, lp_sparse, flag_all);
+		                   lp_raw, head, tail, lp, M, first_mode, uniform_k, custom_atan, do_tail, pcm, dev, flag_list, flag_cnt, out_blocks, sparse, n_wg, n_blocks, atan_lut, lp_sparse, flag_all, pcm_chl2);
 	LAUNCH_RET();
 }
 
@@ -2022,6 +2339,70 @@ extern "C" int rxk_fm_deemph_apply(void *stream, const int16_t *pcm, u64 M, int 
 	if (deemph_d24(a)) { if (a & 1) GO(false, true); else GO(true, true); }
 	else { if (a & 1) GO(false, false); else GO(true, false); }
 #undef GO
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_fm_deemph_tiled_ok(int a, int group, int chunk, int fast, int slow)
+{
+	if (!(a & 1) || !deemph_d24(a) || (group != 16 && group != 64) || (chunk != 128 && chunk != 256))
+		return 0;
+	if (slow <= 0 || fast < 2 * slow || fast / slow > 32)
+		return 0;
+	return chunk == 128 ? 7 : 8;
+}
+
+extern "C" int rxk_fm_deemph_scan_t(void *stream, const int16_t *pcm_t, u64 M, int a, int group, int chl2, int warm, int lo0, int hi0,
+                                    void *ctab, rxk_fm_dev *dev)
+{
+	if (!M)
+		return 0;
+	const u64 n_chunks = (M + (1u << chl2) - 1) >> chl2;
+	const unsigned grid = (unsigned)((n_chunks + 255) / 256);
+	hipStream_t s = (hipStream_t)stream;
+	const unsigned mg = deemph_magic(a);
+#define GO(GS, CL) hipLaunchKernelGGL((k_fm_deemph_scan_t<GS, CL>), dim3(grid), dim3(256), 0, s, pcm_t, M, a, mg, warm, lo0, hi0, (uint4 *)ctab, dev)
+	if (group == 16) { if (chl2 == 7) GO(16, 7); else GO(16, 8); }
+	else { if (chl2 == 7) GO(64, 7); else GO(64, 8); }
+#undef GO
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_fm_deemph_up0(void *stream, u64 n_chunks, int group, const void *ctab, int *p_tab, int *p_lo, int *p_gap)
+{
+	const u64 parents = (n_chunks + DEEMPH_FAN - 1) / DEEMPH_FAN;
+	const u64 threads = parents * group;
+	hipLaunchKernelGGL(k_fm_deemph_up0, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+	                   n_chunks, group, (const uint4 *)ctab, p_tab, p_lo, p_gap);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_fm_deemph_down0(void *stream, u64 n_chunks, const void *ctab, const int *p_start, int *start)
+{
+	const u64 parents = (n_chunks + DEEMPH_FAN - 1) / DEEMPH_FAN;
+	hipLaunchKernelGGL(k_fm_deemph_down0, dim3((unsigned)((parents + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+	                   n_chunks, (const uint4 *)ctab, p_start, start);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_fm_deemph_apply_rs_t(void *stream, const int16_t *pcm_t, u64 M, int a, int chl2, const int *start, int fast, int slow,
+                                        int16_t *out, rxk_fm_dev *dev)
+{
+	if (!M)
+		return 0;
+	const u64 n_chunks = (M + (1u << chl2) - 1) >> chl2;
+	const unsigned grid = (unsigned)((n_chunks + 255) / 256);
+	const int ratio = fast / slow;
+	// the reciprocal rounded UP: (int)((float)sum * rinv) is C's truncating sum / ratio for |sum| <= 34 * 32768, ratio <= 32
+	const float rinv = __builtin_nextafterf((float)(1.0 / (double)ratio), __builtin_inff());
+	// outputs one wave can produce: 64 chunks' worth of input, +1 window finished for a neighbour, +1 rounding
+	const int wcap = (int)((((u64)64 << chl2) * (u64)slow) / (u64)fast) + 4;
+	const size_t lds = (size_t)4 * wcap * sizeof(int16_t);
+	hipStream_t s = (hipStream_t)stream;
+	const unsigned mg = deemph_magic(a);
+	if (chl2 == 7)
+		hipLaunchKernelGGL((k_fm_deemph_apply_rs_t<7>), dim3(grid), dim3(256), lds, s, pcm_t, M, a, mg, start, fast, slow, rinv, wcap, out, dev);
+	else
+		hipLaunchKernelGGL((k_fm_deemph_apply_rs_t<8>), dim3(grid), dim3(256), lds, s, pcm_t, M, a, mg, start, fast, slow, rinv, wcap, out, dev);
 	LAUNCH_RET();
 }
 

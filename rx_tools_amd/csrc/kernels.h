@@ -74,7 +74,9 @@ enum { RXK_FIRST_LOWPASS = 0, RXK_FIRST_UNIFORM = 1 };
  * entries rxk_fm_disc(sparse) will read are stored (the second and the last output of every span). */
 #define RXK_LP_SPARSE_MAX_DS 512
 int rxk_fm_decimate(void *stream, const int16_t *iq, unsigned long long T, int ds, int p0,
-                    int prescaled, int rotate, uint32_t *lp_raw, uint32_t *head, uint32_t *tail, int lp_sparse, int16_t *pcm);
+                    int prescaled, int rotate, uint32_t *lp_raw, uint32_t *head, uint32_t *tail, int lp_sparse, int16_t *pcm, int pcm_chl2);
+/* pcm_chl2 != 0: pcm[] is written in the tiled layout of the lane-per-chunk audio kernels (chunks of 2^pcm_chl2 samples, see
+ * pcm_index in fm_kernels.hip); rxk_fm_disc takes the same argument */
 
 /* same maths, one thread per output, any ds >= 1 and any block length; writes final lp[] */
 int rxk_fm_decimate_generic(void *stream, const int16_t *iq, unsigned long long T, int ds, int p0,
@@ -89,7 +91,7 @@ int rxk_fm_disc(void *stream, const int16_t *iq, unsigned long long T, int ds, i
                 const uint32_t *lp_raw, const uint32_t *head, const uint32_t *tail,
                 uint32_t *lp, unsigned long long M, int first_mode, unsigned long long uniform_k,
                 int custom_atan, int do_tail, int16_t *pcm, rxk_fm_dev *dev, rxk_flag_rec *flag_list, int *flag_cnt,
-                int sparse, unsigned long long n_blocks, const int *atan_lut, int lp_sparse, int flag_all);
+                int sparse, unsigned long long n_blocks, const int *atan_lut, int lp_sparse, int flag_all, int pcm_chl2);
 /* flag_all: report EVERY libm sample as undecided (test hook: the host then re-evaluates all of them); 2: and store a
  * deliberately wrong value for it, so that only the host fix-up + the redo of the audio stages can produce the right output */
 /* lp_sparse: lp_raw[] holds only what rxk_fm_decimate(lp_sparse) stored; any other window this kernel needs (a
@@ -117,6 +119,17 @@ int rxk_fm_deemph_down(void *stream, unsigned long long n_child, int group, cons
 /* p_start: the exact start state of every workgroup of chunks (level 0 of the tree, walked down) */
 int rxk_fm_deemph_apply(void *stream, const int16_t *pcm, unsigned long long M, int a, int group, int chunk,
                         const int *pre, const int *p_lo, const int *p_start, int16_t *y);
+/* The same two stages on the TILED stream, for the small-decimation chains (fm_kernels.hip, "F8 + F9 on the tiled stream"):
+ * lane per chunk straight from HBM, compact 16-byte chunk tables (ctab), the tree's first level on those (up0 / down0, the
+ * levels above are rxk_fm_deemph_up/_top/_down), then replay + low_pass_real inline -> out[].  rxk_fm_deemph_tiled_ok
+ * returns 0 or the chunk log2 (7/8) to hand to the decimator as pcm_chl2. */
+int rxk_fm_deemph_tiled_ok(int a, int group, int chunk, int fast, int slow);
+int rxk_fm_deemph_scan_t(void *stream, const int16_t *pcm_t, unsigned long long M, int a, int group, int chl2, int warm, int lo0, int hi0,
+                         void *ctab, rxk_fm_dev *dev);
+int rxk_fm_deemph_up0(void *stream, unsigned long long n_chunks, int group, const void *ctab, int *p_tab, int *p_lo, int *p_gap);
+int rxk_fm_deemph_down0(void *stream, unsigned long long n_chunks, const void *ctab, const int *p_start, int *start);
+int rxk_fm_deemph_apply_rs_t(void *stream, const int16_t *pcm_t, unsigned long long M, int a, int chl2, const int *start, int fast, int slow,
+                             int16_t *out, rxk_fm_dev *dev);
 /* any a, any state: one lane, serial (degenerate fallback, still on the device) */
 int rxk_fm_deemph_serial(void *stream, const int16_t *pcm, unsigned long long M, int a, int16_t *y, rxk_fm_dev *dev);
 

@@ -42,6 +42,9 @@ struct rxgpu_fm_stream {
 	int *rdc_avg, *rdc_state;
 	hipEvent_t ev_rdc;
 	int *chunk_pre;                                /* per chunk: its start state for each candidate of its workgroup (scan -> apply) */
+	void *ctab;                                    /* tiled path: compact 16-byte chunk tables (scan_t -> up0 / down0) */
+	int *cstart;                                   /* tiled path: exact start state per chunk (down0 -> apply_rs_t) */
+	int tiled;                                     /* pcm[] of the run in hand is in the tiled layout: chunk log2, else 0 */
 	int *lvl_tab, *lvl_lo, *lvl_gap, *lvl_start;   /* tree levels, packed back to back */
 	size_t lvl_cap;
 	/* libm samples the device could not decide, per run slot (seq & 1): count + records on the device, mirrors in pinned memory */
@@ -83,6 +86,7 @@ struct rxgpu_fm_stream {
 		int live;                        /* enqueued, not retired */
 		unsigned long long seq;
 		struct run_geom g;
+		int tiled;
 		int16_t *d_out, *pcm;
 		rxk_fm_blocks blk;
 		size_t n_blocks;
@@ -214,13 +218,16 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 		}
 	}
 	DMALLOC(s->lp, s->max_M * 4);
-	DMALLOC(s->pcm_buf[0], s->max_M * 2);
-	DMALLOC(s->pcm_buf[1], s->max_M * 2);
+	const size_t pcm_cap = (s->max_M + 64 * 256 - 1) / (64 * 256) * (64 * 256) + 64 * 256;   /* whole tiles of the tiled layout */
+	DMALLOC(s->pcm_buf[0], pcm_cap * 2);
+	DMALLOC(s->pcm_buf[1], pcm_cap * 2);
 	s->pcm = s->pcm_buf[0];
 	DMALLOC(s->y, s->max_M * 2);
-	const size_t n_l0 = n_chunks / RXK_DEEMPH_WG_CHUNKS + 2;
+	const size_t n_l0 = n_chunks / RXK_DEEMPH_FAN + 2;                                    /* the tiled path's first level: 16 chunks per table */
 	s->lvl_cap = n_l0 + n_l0 / (RXK_DEEMPH_FAN - 1) + 2 * DEEMPH_LEVELS + 2;             /* level 0 + all composites */
 	DMALLOC(s->chunk_pre, n_chunks * (size_t)(params->deemph_a <= 16 ? 16 : 64) * 4);
+	DMALLOC(s->ctab, n_chunks * 16);
+	DMALLOC(s->cstart, n_chunks * 4);
 	if (params->dc_block_raw) {
 		DMALLOC(s->rdc_buf, s->max_T * 4);
 		DMALLOC(s->rdc_sums, max_blocks * 16);
@@ -300,6 +307,7 @@ void rxgpu_fm_stream_destroy(rxgpu_fm_stream *s)
 	hipFree(s->pcm_buf[0]); hipFree(s->pcm_buf[1]); hipFree(s->y);
 	
 	hipFree(s->lvl_tab); hipFree(s->lvl_lo); hipFree(s->lvl_gap); hipFree(s->lvl_start); hipFree(s->chunk_pre);
+	hipFree(s->ctab); hipFree(s->cstart);
 	hipFree(s->rdc_buf); hipFree(s->pcm_post); hipFree(s->rdc_sums); hipFree(s->rdc_avg); hipFree(s->rdc_state);
 	if (s->ev_rdc) hipEventDestroy(s->ev_rdc);
 	hipFree(s->atan_lut); hipFree(s->below); hipFree(s->dc_sums); hipFree(s->dc_avgs);
@@ -340,6 +348,15 @@ int rxgpu_fm_stream_get_carry(rxgpu_fm_stream *s, rxgpu_fm_carry *c)
 
 long rxgpu_fm_stream_host_fixups(const rxgpu_fm_stream *s) { return s ? s->fixups : 0; }
 
+/* where sample m of the demodulated stream sits in pcm[]: linear, or (chl2 != 0) the tiled layout of fm_kernels.hip's pcm_index */
+static unsigned long long pcm_index_host(unsigned long long m, int chl2)
+{
+	if (!chl2)
+		return m;
+	const unsigned k = (unsigned)m & ((1u << chl2) - 1u), c = (unsigned)(m >> chl2) & 63u;
+	return (m & ~((64ull << chl2) - 1)) | ((unsigned long long)(k >> 3) << 9) | (c << 3) | (k & 7u);
+}
+
 /* polar_discriminant with the host libm, exactly rtl_fm.c:470-483 */
 static int polar_discriminant_host(int ar, int aj, int br, int bj)
 {
@@ -356,6 +373,40 @@ static int run_audio_stages(rxgpu_fm_stream *s, hipStream_t st, unsigned long lo
 	const int resample = p->rate_out2 > 0;
 	int16_t *deemph_dst = resample ? s->y : d_out;
 	const int16_t *pcm = s->pcm;
+	if (s->tiled && M) {
+		/* the small-decimation chain: lane-per-chunk kernels on the tiled stream, de-emphasis and low_pass_real in two
+		 * passes over pcm[] with the tree on compact tables in between; the filtered audio itself never reaches HBM */
+		const int g = s->group, chl2 = s->tiled;
+		unsigned long long cnt[DEEMPH_LEVELS + 1], off[DEEMPH_LEVELS + 1];
+		int top = 0;
+		const unsigned long long n_chunks = (M + (1ull << chl2) - 1) >> chl2;
+		rxgpu_prof_begin_on("fm_deemph", st);
+		RX_K(rxk_fm_deemph_scan_t(st, pcm, M, p->deemph_a, g, chl2, s->warm, s->lo0, s->hi0, s->ctab, s->dev));
+		cnt[0] = (n_chunks + RXK_DEEMPH_FAN - 1) / RXK_DEEMPH_FAN;
+		off[0] = 0;
+		RX_K(rxk_fm_deemph_up0(st, n_chunks, g, s->ctab, s->lvl_tab, s->lvl_lo, s->lvl_gap));
+		const unsigned long long topcap = s->topcap_override ? (unsigned long long)s->topcap_override : (unsigned long long)DEEMPH_TOPCAP(g);
+		while (cnt[top] > topcap) {
+			if (top == DEEMPH_LEVELS)
+				return rxgpu_fail(RXGPU_EUNSUPPORTED, "de-emphasis scan deeper than %d levels", DEEMPH_LEVELS);
+			cnt[top + 1] = (cnt[top] + RXK_DEEMPH_FAN - 1) / RXK_DEEMPH_FAN;
+			off[top + 1] = off[top] + cnt[top];
+			RX_K(rxk_fm_deemph_up(st, cnt[top], g, s->lvl_tab + off[top] * g, s->lvl_lo + off[top], s->lvl_gap + off[top],
+			                      s->lvl_tab + off[top + 1] * g, s->lvl_lo + off[top + 1], s->lvl_gap + off[top + 1]));
+			top++;
+		}
+		RX_K(rxk_fm_deemph_top(st, (int)cnt[top], g, s->lvl_tab + off[top] * g, s->lvl_lo + off[top], s->lvl_gap + off[top],
+		                       s->lvl_start + off[top], s->dev));
+		for (int l = top; l > 0; l--)
+			RX_K(rxk_fm_deemph_down(st, cnt[l - 1], g, s->lvl_tab + off[l - 1] * g, s->lvl_lo + off[l - 1],
+			                        s->lvl_start + off[l], s->lvl_start + off[l - 1]));
+		RX_K(rxk_fm_deemph_down0(st, n_chunks, s->ctab, s->lvl_start, s->cstart));
+		rxgpu_prof_end_on("fm_deemph", st);
+		rxgpu_prof_begin_on("fm_resample", st);
+		RX_K(rxk_fm_deemph_apply_rs_t(st, pcm, M, p->deemph_a, chl2, s->cstart, p->rate_out, p->rate_out2, d_out, s->dev));
+		rxgpu_prof_end_on("fm_resample", st);
+		return RXGPU_OK;
+	}
 	if (p->post_downsample > 1) {
 		/* rtl_fm.c:814-815; run_geometry made sure every block's length is a multiple of the step */
 		M /= (unsigned long long)p->post_downsample;
@@ -561,6 +612,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 	}
 
 	s->lp_final = s->lp;
+	s->tiled = 0;
 	s->pcm = s->pcm_buf[db];                 /* stays intact until the run is retired: a host fix-up patches it */
 	rxk_flag_rec *const flag_rec = s->flag_rec_dev + (size_t)db * RXK_FLAG_CAP;
 	int *const flag_cnt = s->flag_cnt_dev + db;
@@ -574,6 +626,11 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 		/* lowpassed[] is an intermediate of the fused chain: keep only the entries the seam kernel reads
 		 * (the drop-in, which must hand lowpassed[] back, runs prescaled) */
 		const int lp_sparse = fused_disc && !prescaled && g->ds <= RXK_LP_SPARSE_MAX_DS;
+		/* small decimation: the audio stages are a sizeable share of the work -- hand them the demodulated samples in the tiled
+		 * layout their lane-per-chunk kernels stream (rxk_fm_deemph_scan_t / _apply_rs_t).  $RXGPU_NO_TILED keeps the other path. */
+		s->tiled = 0;
+		if (g->fast && fused_disc && p->deemph && s->group && p->rate_out2 > 0 && g->post == 1 && !p->dc_block_audio && !getenv("RXGPU_NO_TILED"))
+			s->tiled = rxk_fm_deemph_tiled_ok(p->deemph_a, s->group, s->chunk, p->rate_out, p->rate_out2);
 		if (g->fast) {
 			s->lp_final = s->lp_raw[db];
 			/* buffer set `db` was last read by the audio chain two runs ago */
@@ -581,7 +638,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 				RX_HIP(hipStreamWaitEvent(sa, s->ev_small[db], 0));
 			rxgpu_prof_begin_on("fm_decimate", sa);
 			RX_K(rxk_fm_decimate(sa, d_iq, g->T, g->ds, g->p0, prescaled, g->rotate, s->lp_raw[db], s->head[db], s->tail[db],
-			                     lp_sparse, fused_disc ? s->pcm : NULL));
+			                     lp_sparse, fused_disc ? s->pcm : NULL, s->tiled));
 			rxgpu_prof_end_on("fm_decimate", sa);
 			RX_HIP(hipEventRecord(s->ev_dec[db], sa));
 			RX_HIP(hipStreamWaitEvent(sb, s->ev_dec[db], 0));
@@ -594,7 +651,8 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 		/* fast path: lp_raw is finished in place (only seam entries change) and becomes the final decimated IQ */
 		RX_K(rxk_fm_disc(sb, d_iq, g->T, g->ds, g->p0, g->n, prescaled, g->rotate, g->fast, g->fast ? s->lp_raw[db] : s->lp,
 		                 s->head[db], s->tail[db], g->fast ? s->lp_raw[db] : s->lp, g->M, RXK_FIRST_LOWPASS, 0, p->custom_atan, 1,
-		                 split ? NULL : s->pcm, s->dev, flag_rec, flag_cnt, fused_disc, n_blocks, s->atan_lut, g->fast ? lp_sparse : 0, s->flag_all));
+		                 split ? NULL : s->pcm, s->dev, flag_rec, flag_cnt, fused_disc, n_blocks, s->atan_lut, g->fast ? lp_sparse : 0, s->flag_all,
+		                 (g->fast && fused_disc) ? s->tiled : 0));
 		rxgpu_prof_end_on("fm_disc", sb);
 	} else {
 		/* F3: cascade (first passes fused where the input is raw), F12 optional; all on stream B */
@@ -645,7 +703,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 		if (!split) {
 			rxgpu_prof_begin_on("fm_disc", sb);
 			RX_K(rxk_fm_disc(sb, d_iq, g->T, 1, 0, g->n, prescaled, g->rotate, 0, s->lp_final, NULL, NULL, NULL, g->M,
-			                 RXK_FIRST_UNIFORM, g->K, p->custom_atan, 0, s->pcm, s->dev, flag_rec, flag_cnt, 0, n_blocks, s->atan_lut, 0, s->flag_all));
+			                 RXK_FIRST_UNIFORM, g->K, p->custom_atan, 0, s->pcm, s->dev, flag_rec, flag_cnt, 0, n_blocks, s->atan_lut, 0, s->flag_all, 0));
 			rxgpu_prof_end_on("fm_disc", sb);
 		}
 	}
@@ -656,7 +714,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 		if (p->mode == RXGPU_MODE_FM) {
 			rxgpu_prof_begin_on("fm_disc", sb);
 			RX_K(rxk_fm_disc(sb, d_iq, g->T, g->ds, g->p0, g->n, prescaled, g->rotate, 0, lpw, NULL, NULL, NULL, g->M,
-			                 s->blk.first_mode, g->K, p->custom_atan, 0, s->pcm, s->dev, flag_rec, flag_cnt, 0, n_blocks, s->atan_lut, 0, s->flag_all));
+			                 s->blk.first_mode, g->K, p->custom_atan, 0, s->pcm, s->dev, flag_rec, flag_cnt, 0, n_blocks, s->atan_lut, 0, s->flag_all, 0));
 			rxgpu_prof_end_on("fm_disc", sb);
 		} else if (p->mode == RXGPU_MODE_RAW) {
 			RX_HIP(hipMemcpyAsync(d_out, lpw, g->M * 4, hipMemcpyDeviceToDevice, sb));
@@ -690,6 +748,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 	s->rec[db].g = *g;
 	s->rec[db].d_out = d_out;
 	s->rec[db].pcm = s->pcm;
+	s->rec[db].tiled = s->tiled;
 	s->rec[db].blk = s->blk;
 	s->rec[db].n_blocks = n_blocks;
 	return RXGPU_OK;
@@ -721,7 +780,7 @@ static int fixup_from(rxgpu_fm_stream *s, int slot)
 			for (int k = 0; k < cnt; k++) {
 				const rxk_flag_rec *f = &s->flag_rec_host[k];
 				const int16_t v = (int16_t)polar_discriminant_host(f->ar, f->aj, f->br, f->bj);
-				RX_HIP(hipMemcpy(r->pcm + f->m, &v, 2, hipMemcpyHostToDevice));
+				RX_HIP(hipMemcpy(r->pcm + pcm_index_host(f->m, r->tiled), &v, 2, hipMemcpyHostToDevice));
 			}
 			s->fixups += cnt;
 			s->flag_cnt_host[q] = 0;
@@ -731,6 +790,7 @@ static int fixup_from(rxgpu_fm_stream *s, int slot)
 		RX_K(rxk_fm_audio_carry(sb, s->dev, i == 0 ? s->snap_dev + 4 * q : NULL));
 		s->pcm = r->pcm;
 		s->blk = r->blk;
+		s->tiled = r->tiled;
 		if ((rc = run_audio_stages(s, sb, r->g.M, r->g.J, r->d_out)) != RXGPU_OK)
 			return rc;
 	}
@@ -1096,24 +1156,40 @@ static void die(const char *what)
 	exit(1);
 }
 
-/* page-lock the struct members the drop-in DMAs from/to (SURVEY.md section 8b "Ownership"), once per address; a
- * refusal (already registered, or the platform says no) only means the copies go through the runtime's bounce */
-static void pin_once(const void *ptr, size_t bytes)
+/* Page-lock the struct members the drop-in DMAs from/to (SURVEY.md section 8b "Ownership"): lowpassed[] .. result[] of
+ * the demod_state as one range, buf16[] of the dongle_state.  Explicit and optional -- the structs must outlive the
+ * registration (the reference's are globals, rtl_fm.c:190-191); without it the copies go through the runtime's
+ * own bounce buffers.  Either pointer may be NULL. */
+static int pin_range(const void *ptr, size_t bytes, int on)
 {
-	static const void *seen[64];
-	static int n_seen;
-	pthread_mutex_lock(&g_side_lock);
-	int known = 0;
-	for (int i = 0; i < n_seen; i++)
-		known |= seen[i] == ptr;
-	if (!known && n_seen < 64)
-		seen[n_seen++] = ptr;
-	pthread_mutex_unlock(&g_side_lock);
-	if (known)
-		return;
 	const uintptr_t lo = (uintptr_t)ptr & ~(uintptr_t)4095, hi = ((uintptr_t)ptr + bytes + 4095) & ~(uintptr_t)4095;
-	if (hipHostRegister((void *)lo, hi - lo, hipHostRegisterDefault) != hipSuccess)
-		(void)hipGetLastError();
+	if (on)
+		RX_HIP(hipHostRegister((void *)lo, hi - lo, hipHostRegisterDefault));
+	else
+		RX_HIP(hipHostUnregister((void *)lo));
+	return RXGPU_OK;
+}
+
+int rxgpu_dropin_pin(struct demod_state *d, struct dongle_state *s)
+{
+	int rc;
+	if ((rc = rxgpu_ensure_init()) != RXGPU_OK)
+		return rc;
+	if (d && (rc = pin_range(d->lowpassed, (size_t)((char *)(d->result + RXGPU_MAXIMUM_BUF_LENGTH) - (char *)d->lowpassed), 1)) != RXGPU_OK)
+		return rc;
+	if (s && (rc = pin_range(s->buf16, sizeof(s->buf16), 1)) != RXGPU_OK)
+		return rc;
+	return RXGPU_OK;
+}
+
+int rxgpu_dropin_unpin(struct demod_state *d, struct dongle_state *s)
+{
+	int rc = RXGPU_OK, r2;
+	if (d)
+		rc = pin_range(d->lowpassed, 0, 0);
+	if (s && (r2 = pin_range(s->buf16, 0, 0)) != RXGPU_OK)
+		rc = r2;
+	return rc;
 }
 
 void rxgpu_full_demod(struct demod_state *d)
@@ -1162,8 +1238,6 @@ void rxgpu_full_demod(struct demod_state *d)
 		if (rxgpu_fm_stream_create(&g_side[slot].s, &p, 1, RXGPU_MAXIMUM_BUF_LENGTH) != RXGPU_OK)
 			die("rxgpu_full_demod");
 		g_side[slot].p = p;
-		pin_once(d->lowpassed, sizeof(d->lowpassed));
-		pin_once(d->result, sizeof(d->result));
 	}
 	rxgpu_fm_stream *s = g_side[slot].s;
 	rxgpu_fm_carry c;
@@ -1265,7 +1339,6 @@ void rxgpu_callback(int16_t *buf, uint32_t len, void *ctx)
 			rxgpu_fail(RXGPU_ENOMEM, "hipMalloc failed");
 			die("rxgpu_callback");
 		}
-		pin_once(s->buf16, sizeof(s->buf16));
 	}
 	/* write the slot that is NOT published: full_demod may be reading the published one right now (it runs under
 	 * d->rw; the publication below happens under d->rw too) */

@@ -139,6 +139,8 @@ def test_dropin_handoff_stays_on_the_device_unless_invalidated():
         L.rxgpu_deemph_state(C.addressof(d)).contents.value = 0
         lp = np.zeros(block_len, np.int16)
         want = np.zeros(block_len, np.int16)
+        if edit:
+            R.check(L.rxgpu_dropin_pin(C.addressof(d), C.addressof(s)))       # the optional in-place DMA of the struct members
         for b in range(2):
             blk = np.ascontiguousarray(iq[b * block_len:(b + 1) * block_len])
             L.rxgpu_callback(blk.copy().ctypes.data, block_len, C.addressof(s))
@@ -154,3 +156,5 @@ def test_dropin_handoff_stays_on_the_device_unless_invalidated():
             assert d.result_len == n_want
             assert np.array_equal(np.ctypeslib.as_array(d.result)[:n_want], want[:n_want])
             assert d.lp_len == lp_len.value and np.array_equal(np.ctypeslib.as_array(d.lowpassed)[:d.lp_len], lp[:lp_len.value])
+        if edit:
+            R.check(L.rxgpu_dropin_unpin(C.addressof(d), C.addressof(s)))

@@ -456,3 +456,41 @@ def test_raw_dc_block_any_block_length(block_len):
     """-E rdc no longer needs blocks of a multiple of 4 samples (readStream may return any count)"""
     iq = sig_fm(7 * block_len // 2, seed=8)
     _check(iq, block_len, downsample=6, dc_block_raw=1, rdc_block_const=4)
+
+
+# ----------------------------------------------------------------------------- round 2: the tiled audio path
+
+@pytest.mark.parametrize("params,block_len,n_runs", [
+    (dict(downsample=6), 8192, 1),
+    (dict(downsample=6), 8192, 3),
+    (dict(downsample=5, rate_out=240000, deemph_a=19), 2 * 20000, 2),            # GS=64, chunks of 256 (BASELINE configs[0])
+    (dict(downsample=4, deemph_a=9), 2 * 4096, 2),                                # -c eu
+    (dict(downsample=12, rate_out=96000, rate_out2=48000, deemph_a=7), 2 * 12 * 700, 2),   # ratio 2
+    (dict(downsample=4, rate_out=1000000, rate_out2=32000), 2 * 65536, 2),        # ratio 31, windows of 31/32 samples
+    (dict(downsample=118), 2 * 131072, 2),
+    (dict(downsample=7, deemph_a=63), 2 * 7 * 1234 + 8, 3),                       # odd block geometry, a at the top of the GS=64 range
+])
+@pytest.mark.parametrize("tiled", [True, False])
+def test_tiled_audio_path_equals_staged_path(params, block_len, n_runs, tiled, monkeypatch):
+    """the lane-per-chunk kernels on the tiled stream (k_fm_deemph_scan_t / up0 / down0 / apply_rs_t: de-emphasis with the
+    resampler inline) and the LDS-staged kernels ($RXGPU_NO_TILED) both reproduce the oracle, sample for sample and carry
+    for carry, also pipelined across runs whose lengths are not multiples of a chunk"""
+    if not tiled:
+        monkeypatch.setenv("RXGPU_NO_TILED", "1")
+    n_blocks = 4 * n_runs + 1
+    iq = sig_fm(n_blocks * block_len // 2, seed=55, amp=9000.0, noise=900)
+    _check(iq, block_len, n_runs=n_runs, pipelined=n_runs > 1, **params)
+
+
+@pytest.mark.parametrize("sig", ["noise_full", "zeros", "dc", "alternating"])
+def test_tiled_audio_path_hostile_signals(sig):
+    """constant input (no chunk ever merges its candidates: the tree has to carry the exact state), full-scale noise (every
+    int16 wrap of the discriminator), and the multi-level tree forced by a long run"""
+    iq = _signals(40 * 8192)[sig]
+    _check(iq, 8192, n_runs=2, pipelined=True, downsample=4)
+
+
+def test_tiled_audio_path_multi_level_tree(monkeypatch):
+    monkeypatch.setenv("RXGPU_DEEMPH_TOPCAP", "3")
+    iq = sig_fm(64 * 16384 // 2, seed=66)
+    _check(iq, 16384, n_runs=2, pipelined=True, downsample=4)
