@@ -217,6 +217,10 @@ typedef struct rxgpu_chan_params {
 	int first_bin;           /* channel c = FFT bin (first_bin + c) mod N */
 	int n_channels;
 	int custom_atan;         /* 0 std, 1 fast */
+	/* per-channel audio stages, every channel with carried state of its own like a demod_state (NBFM defaults: both off,
+	 * rtl_fm.c:1086-1099): deemph_filter (rtl_fm.c:667-682) and low_pass_real (389-409) on the channel's demodulated stream */
+	int deemph, deemph_a;    /* -E deemp; deemph_a as rxgpu_fm_plan_settings derives it for the channel rate fs / N */
+	int rate_out, rate_out2; /* low_pass_real: channel rate (fs / N) -> rate_out2; rate_out2 <= 0 disables it */
 } rxgpu_chan_params;
 
 typedef struct rxgpu_chan rxgpu_chan;
@@ -228,8 +232,12 @@ void rxgpu_chan_destroy(rxgpu_chan *s);
 /* pre: n_channels pairs (pre_r, pre_j) */
 int rxgpu_chan_set_carry(rxgpu_chan *s, const int *pre);
 int rxgpu_chan_get_carry(rxgpu_chan *s, int *pre);
+/* audio: n_channels triples (deemph avg, now_lpr, prev_lpr_index) -- rtl_fm.c:669, 150-151 per channel */
+int rxgpu_chan_set_audio_carry(rxgpu_chan *s, const int *audio);
+int rxgpu_chan_get_audio_carry(rxgpu_chan *s, int *audio);
 /* d_iq: DEVICE, n_blocks * block_len int16.  d_out: DEVICE, [n_channels][out_stride] int16; channel c's
- * demodulated samples (one per window) at d_out[c*out_stride .. + windows).  Synchronous. */
+ * output at d_out[c*out_stride .. + *windows_out): one demodulated sample per window, or -- with low_pass_real on -- the
+ * resampled audio (*windows_out = samples per channel, the same for every channel).  Synchronous. */
 int rxgpu_chan_run(rxgpu_chan *s, const int16_t *d_iq, size_t n_blocks, size_t block_len, int16_t *d_out,
                    size_t out_stride, size_t *windows_out);
 long rxgpu_chan_host_fixups(const rxgpu_chan *s);

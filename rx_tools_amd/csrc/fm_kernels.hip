@@ -268,20 +268,15 @@ __global__ __launch_bounds__(DEC_THREADS) void k_fm_decimate(
 	}
 	for (unsigned j0 = j_lo; j0 < j_hi; j0 += 64) {
 		const unsigned j = j0 + lane;
-		const bool live = j < j_hi;
-		const uint32_t pj = PREFIX_AT(live ? j : j_hi - 1);
+		const uint32_t pj = PREFIX_AT(j);                                    // lanes past j_hi read slots nobody wrote: never stored
 		const uint32_t pm = (uint32_t)__builtin_amdgcn_update_dpp((int)c1, (int)pj, 0x138, 0xf, 0xf, false);    // wave_shr:1, lane 0 keeps c1
 		const uint32_t pmm = (uint32_t)__builtin_amdgcn_update_dpp((int)c2, (int)pm, 0x138, 0xf, 0xf, false);
 		c1 = (uint32_t)__builtin_amdgcn_readlane((int)pj, 63);
 		c2 = (uint32_t)__builtin_amdgcn_readlane((int)pj, 62);
-		if (!live)
+		if (j >= j_hi)
 			continue;
-		if (j == 0) {
-			head[wgi] = pj;
-			continue;
-		}
 		const uint32_t a = pk_sub(pj, pm);
-		if (!lp_sparse || j == 1 || j == n_b - 1)
+		if (!lp_sparse && j)
 			lp_raw[m_base + j] = a;
 		if (DISC && j >= 2) {
 			int cr, cj;
@@ -292,6 +287,15 @@ __global__ __launch_bounds__(DEC_THREADS) void k_fm_decimate(
 			else
 				__builtin_nontemporal_store(v, &pcm[m_base + j]);
 		}
+	}
+	// the first window ending in the span goes out in head/tail form; with a sparse lowpassed[] only the entries the seam kernel
+	// reads are kept: the span's second output and its last one
+	if (threadIdx.x == 0 && n_b)
+		head[wgi] = PREFIX_AT(0);
+	if (lp_sparse && threadIdx.x >= 64 && threadIdx.x < 66) {
+		const unsigned j = threadIdx.x == 64 ? 1u : n_b - 1;
+		if (j >= 1 && j < n_b)
+			lp_raw[m_base + j] = pk_sub(PREFIX_AT(j), PREFIX_AT(j - 1));
 	}
 	if (threadIdx.x == 0) {
 		uint32_t last = 0;
@@ -376,7 +380,20 @@ __device__ __forceinline__ int fast_atan2_dev(int y, int x)
 	const bool neg = x < 0;
 	const int num = (int)(4096u * (neg ? ux + ay : ux - ay));
 	const int den = (int)(neg ? ay - ux : ux + ay);
-	const int ang = (neg ? 12288 : 4096) - div_trunc(num, den);
+	// den = |x| + |y| is positive unless that sum wrapped: one test sends a wrapped (or huge) denominator and an oversized
+	// quotient to the exact fp64 division, everything else needs no |den| and no sign of den
+	int q;
+	const unsigned un = num < 0 ? 0u - (unsigned)num : (unsigned)num;
+	const float fq = (float)un * __builtin_amdgcn_rcpf((float)(unsigned)den);
+	if (__builtin_expect((unsigned)den >= (1u << 30) || !(fq < 1048576.0f), 0)) {
+		q = (int)((double)num / (double)den);
+	} else {
+		unsigned uq = (unsigned)fq;
+		const int r = (int)(un - uq * (unsigned)den);
+		uq = r < 0 ? uq - 1 : ((unsigned)r >= (unsigned)den ? uq + 1 : uq);
+		q = num < 0 ? -(int)uq : (int)uq;
+	}
+	const int ang = (neg ? 12288 : 4096) - q;
 	return y < 0 ? -ang : ang;
 }
 
@@ -2182,6 +2199,122 @@ __global__ void k_ch_demod(const uint32_t *__restrict__ chan_lp, u64 total_windo
 	}
 }
 
+
+// Per-channel audio stages of the channeliser: deemph_filter (rtl_fm.c:667-682) and low_pass_real (389-409) on every
+// channel's demodulated stream, each channel with its own carried state like a demod_state of its own (rtl_fm.c:189
+// "multiple of these, eventually").  One workgroup per channel.  De-emphasis: every thread takes a contiguous chunk of the
+// channel's samples, narrows the possible start states on the `warm` samples before it (two extreme trajectories), tracks
+// lowest candidate + merge mask through its chunk (deemph_track, any a up to 64), thread 0 walks the chunk tables from the
+// carried state, and every thread replays its chunk from its exact start.  a > 64, a == 1 or a carried state outside
+// int16: one thread does the whole row.  Then low_pass_real in closed form, one thread per output.
+//   audio: per channel {avg, now_lpr, prev_lpr_index} in, same out.  y: scratch row per channel (de-emphasised samples
+//   when a resampler follows, else unused); out rows: in place (no resampler) or compacted to J samples per channel.
+template <bool EVEN, bool D24>
+__global__ __launch_bounds__(256) void k_ch_audio(
+	int16_t *__restrict__ rows, u64 row_stride, u64 W, int deemph, int a, unsigned magic, int bias, int warm, int serial,
+	int fast, int slow, u64 J, const int *__restrict__ audio_in, int *__restrict__ audio_out, int16_t *__restrict__ y_rows, u64 y_stride)
+{
+	__shared__ uint4 tab[256];
+	__shared__ int start[256];
+	const int tid = threadIdx.x;
+	const u64 c = blockIdx.x;
+	int16_t *row = rows + c * row_stride;
+	int16_t *yrow = slow > 0 ? y_rows + c * y_stride : row;      // where the (de-emphasised) samples go before resampling
+	const int avg_in = audio_in[3 * c];
+	if (deemph) {
+		const int h = a / 2, xoff = h + bias * a;
+		// chunks of at least `warm` samples, multiples of 8, so that every chunk but the first has its warm-up inside the row
+		u64 chunk = (W + 255) / 256;
+		if (chunk < (u64)warm) chunk = (u64)warm;
+		chunk = (chunk + 7) & ~(u64)7;
+		const int active = serial ? 1 : (int)((W + chunk - 1) / chunk);
+		if (serial) chunk = W;
+		const u64 b = (u64)tid * chunk, e = min(W, b + chunk);
+		if (tid < active && !serial) {
+			int lo, hi;
+			if (tid == 0) {
+				lo = hi = avg_in;
+			} else {
+				lo = -32768; hi = 32767;
+				for (u64 i = b - (u64)warm; i < b; i++) {
+					const int x = row[i];
+					lo = deemph_step_d<EVEN, D24>(lo, x + xoff, x, magic, bias);
+					hi = deemph_step_d<EVEN, D24>(hi, x + xoff, x, magic, bias);
+				}
+			}
+			int gap = hi - lo;
+			if (gap > 63) gap = 63;                               // excluded by `warm`
+			const int lo_start = lo;
+			int cnt = gap + 1;
+			u64 mask = (((u64)1 << gap) - 1);
+			for (u64 i = b; i < e; i++)
+				deemph_track<EVEN, D24>(lo, cnt, mask, (int)row[i], a, xoff, magic, bias);
+			tab[tid] = make_uint4((uint32_t)lo_start, ((uint32_t)lo & 0xffffu) | ((uint32_t)gap << 16), (uint32_t)mask, (uint32_t)(mask >> 32));
+		}
+		__syncthreads();
+		if (tid == 0) {
+			int s = avg_in;
+			if (!serial)
+				for (int t = 0; t < active; t++) {
+					start[t] = s;
+					s = ctab_apply(tab[t], s);
+				}
+			else
+				start[0] = s;
+			if (!serial)
+				audio_out[3 * c] = s;
+		}
+		__syncthreads();
+		if (tid < active) {
+			int s = start[tid];
+			if (!serial) {
+				for (u64 i = b; i < e; i++) {
+					const int x = row[i];
+					s = deemph_step_d<EVEN, D24>(s, x + xoff, x, magic, bias);
+					yrow[i] = (int16_t)s;
+				}
+			} else {
+				for (u64 i = b; i < e; i++) {                 // any a, any state: the reference's own expression
+					const int d = (int)row[i] - s;
+					s += d > 0 ? (d + h) / a : (d - h) / a;
+					yrow[i] = (int16_t)s;
+				}
+				audio_out[3 * c] = s;
+			}
+		}
+		__syncthreads();
+	} else {
+		if (slow > 0)
+			for (u64 i = tid; i < W; i += 256)
+				yrow[i] = row[i];
+		if (tid == 0)
+			audio_out[3 * c] = avg_in;
+		__syncthreads();
+	}
+	if (slow > 0) {
+		const u64 p0 = (u64)audio_in[3 * c + 2];
+		const int ratio = fast / slow;
+		for (u64 j = tid; j < J; j += 256) {
+			const u64 wb = j ? lpr_end(j - 1, fast, slow, p0) : 0, we = lpr_end(j, fast, slow, p0);
+			int sum = j ? 0 : audio_in[3 * c + 1];
+			for (u64 i = wb; i < we; i++)
+				sum += yrow[i];
+			row[j] = (int16_t)(sum / ratio);
+		}
+		if (tid == 0) {
+			const u64 wb = J ? lpr_end(J - 1, fast, slow, p0) : 0;
+			int sum = J ? 0 : audio_in[3 * c + 1];
+			for (u64 i = wb; i < W; i++)
+				sum += yrow[i];
+			audio_out[3 * c + 1] = sum;
+			audio_out[3 * c + 2] = (int)(p0 + W * (u64)slow - J * (u64)fast);
+		}
+	} else if (tid == 0) {
+		audio_out[3 * c + 1] = audio_in[3 * c + 1];
+		audio_out[3 * c + 2] = audio_in[3 * c + 2];
+	}
+}
+
 // ------------------------------------------------------------------ launchers
 
 #define LAUNCH_RET() return (int)hipGetLastError()
@@ -2195,7 +2328,7 @@ extern "C" int rxk_fm_decimate(void *stream, const int16_t *iq, u64 T, int ds, i
 	const unsigned magic = (unsigned)((1ull << 32) / (unsigned)ds + 1);
 	/* floor(q / ds) = (q << 8) * magic24 >> 32 is exact while q * ds < 2^24; q <= span + 4 + ds */
 	const unsigned magic24 = ((u64)(RXK_DEC_SPAN + 4 + ds) * (u64)ds < (1ull << 24)) ? (1u << 24) / (unsigned)ds + 1 : 0u;
-	const unsigned slot_cap = (RXK_DEC_SPAN + ds) / ds + 4;
+	const unsigned slot_cap = (RXK_DEC_SPAN + ds) / ds + 4 + 64;      /* + one turn of lanes past the last output (read, never used) */
 	const size_t shm = (size_t)(slot_cap + 4) * sizeof(uint32_t);
 	hipStream_t s = (hipStream_t)stream;
 	const u32x4 *p = (const u32x4 *)iq;
@@ -2596,5 +2729,21 @@ extern "C" int rxk_ch_demod(void *stream, const uint32_t *chan_lp, u64 total_win
 		return 0;
 	hipLaunchKernelGGL(k_ch_demod, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, chan_lp, total_windows, wpb,
 	                   n_channels, custom_atan, pre_in, pre_out, out, out_stride, dev, flag_list, sparse);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_ch_audio(void *stream, int16_t *rows, u64 row_stride, u64 W, int n_channels, int deemph, int a, int warm, int serial,
+                            int fast, int slow, u64 J, const int *audio_in, int *audio_out, int16_t *y_rows, u64 y_stride)
+{
+	if (!W || !n_channels)
+		return 0;
+	hipStream_t s = (hipStream_t)stream;
+	const unsigned mg = deemph ? deemph_magic(a) : 0u;
+	const int bias = deemph ? bias_for(a) : 0;
+#define GO(EV, D) hipLaunchKernelGGL((k_ch_audio<EV, D>), dim3((unsigned)n_channels), dim3(256), 0, s, rows, row_stride, W, deemph, a, mg, bias, warm, serial, \
+		fast, slow, J, audio_in, audio_out, y_rows, y_stride)
+	if (deemph && deemph_d24(a)) { if (a & 1) GO(false, true); else GO(true, true); }
+	else { if (!deemph || (a & 1)) GO(false, false); else GO(true, false); }
+#undef GO
 	LAUNCH_RET();
 }

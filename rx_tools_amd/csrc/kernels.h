@@ -183,6 +183,13 @@ int rxk_ch_demod(void *stream, const uint32_t *chan_lp, unsigned long long total
                  int custom_atan, const int *pre_in, int *pre_out, int16_t *out, unsigned long long out_stride,
                  rxk_fm_dev *dev, unsigned long long *flag_list, int sparse);
 
+/* per-channel deemph_filter + low_pass_real on the channeliser's [channel][window] output (one workgroup per channel);
+ * audio_in/out: {avg, now_lpr, prev_lpr_index} per channel; y_rows: scratch rows when slow > 0.  warm: samples that bring any two
+ * int16 start states within 64 of each other (host: deemph_warm); serial != 0: one thread per channel does the recursion */
+int rxk_ch_audio(void *stream, int16_t *rows, unsigned long long row_stride, unsigned long long W, int n_channels, int deemph, int a,
+                 int warm, int serial, int fast, int slow, unsigned long long J, const int *audio_in, int *audio_out,
+                 int16_t *y_rows, unsigned long long y_stride);
+
 /* ------------------------------------------------------------- rx_power */
 
 /* P1,P4-P8 fused (rtl_power.c:715-720, 744-770) for ds == 1 or pre-downsampled input:

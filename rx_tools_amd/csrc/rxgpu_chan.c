@@ -18,6 +18,8 @@ struct rxgpu_chan {
 	uint32_t *twiddle_dev, *chan_lp;
 	int *pre_dev[2];                 /* carried (pre_r, pre_j) per channel: in / out */
 	int *pre_host;
+	int *audio_dev[2], *audio_host;  /* per channel {deemph avg, now_lpr, prev_lpr_index}: in / out */
+	int16_t *audio_y;                /* [n_channels][max_windows]: the de-emphasised samples in front of the resampler */
 	rxk_fm_dev *dev, *dev_host;
 	unsigned long long *flag_list, *flag_host;
 	long fixups;
@@ -38,6 +40,10 @@ int rxgpu_chan_create(rxgpu_chan **out, const rxgpu_chan_params *p, size_t max_b
 		return rxgpu_fail(RXGPU_EINVAL, "channels [%d, %d) do not fit %zu bins", p->first_bin, p->first_bin + p->n_channels, n);
 	if (p->custom_atan != 0 && p->custom_atan != 1)
 		return rxgpu_fail(RXGPU_EUNSUPPORTED, "channeliser: -A std or fast only");
+	if (p->deemph && p->deemph_a < 1)
+		return rxgpu_fail(RXGPU_EINVAL, "deemph_a %d < 1", p->deemph_a);
+	if (p->rate_out2 > 0 && (p->rate_out < p->rate_out2 || p->rate_out <= 0))
+		return rxgpu_fail(RXGPU_EUNSUPPORTED, "low_pass_real needs rate_out >= rate_out2 > 0 (got %d, %d)", p->rate_out, p->rate_out2);
 	if ((rc = rxgpu_ensure_init()) != RXGPU_OK)
 		return rc;
 	s = calloc(1, sizeof(*s));
@@ -52,6 +58,9 @@ int rxgpu_chan_create(rxgpu_chan **out, const rxgpu_chan_params *p, size_t max_b
 	if (hipMalloc((void **)&s->twiddle_dev, (n + 2) * 4) != hipSuccess ||
 	    hipMalloc((void **)&s->chan_lp, nc * s->max_windows * 4) != hipSuccess ||
 	    hipMalloc((void **)&s->pre_dev[0], nc * 8) != hipSuccess || hipMalloc((void **)&s->pre_dev[1], nc * 8) != hipSuccess ||
+	    hipMalloc((void **)&s->audio_dev[0], nc * 12) != hipSuccess || hipMalloc((void **)&s->audio_dev[1], nc * 12) != hipSuccess ||
+	    hipHostMalloc((void **)&s->audio_host, nc * 12, 0) != hipSuccess ||
+	    (p->rate_out2 > 0 && hipMalloc((void **)&s->audio_y, nc * s->max_windows * 2) != hipSuccess) ||
 	    hipMalloc((void **)&s->dev, sizeof(rxk_fm_dev)) != hipSuccess ||
 	    hipMalloc((void **)&s->flag_list, RXK_FLAG_CAP * 8) != hipSuccess ||
 	    hipHostMalloc((void **)&s->dev_host, sizeof(rxk_fm_dev), 0) != hipSuccess ||
@@ -64,6 +73,7 @@ int rxgpu_chan_create(rxgpu_chan **out, const rxgpu_chan_params *p, size_t max_b
 	}
 	free(tw);
 	memset(s->pre_host, 0, nc * 8);
+	memset(s->audio_host, 0, nc * 12);
 	*out = s;
 	return RXGPU_OK;
 }
@@ -73,6 +83,8 @@ void rxgpu_chan_destroy(rxgpu_chan *s)
 	if (!s)
 		return;
 	hipFree(s->twiddle_dev); hipFree(s->chan_lp); hipFree(s->pre_dev[0]); hipFree(s->pre_dev[1]);
+	hipFree(s->audio_dev[0]); hipFree(s->audio_dev[1]); hipFree(s->audio_y);
+	if (s->audio_host) hipHostFree(s->audio_host);
 	hipFree(s->dev); hipFree(s->flag_list);
 	if (s->dev_host) hipHostFree(s->dev_host);
 	if (s->flag_host) hipHostFree(s->flag_host);
@@ -96,7 +108,36 @@ int rxgpu_chan_get_carry(rxgpu_chan *s, int *pre)
 	return RXGPU_OK;
 }
 
+int rxgpu_chan_set_audio_carry(rxgpu_chan *s, const int *audio)
+{
+	if (!s || !audio)
+		return rxgpu_fail(RXGPU_EINVAL, "null argument");
+	memcpy(s->audio_host, audio, (size_t)s->p.n_channels * 12);
+	return RXGPU_OK;
+}
+
+int rxgpu_chan_get_audio_carry(rxgpu_chan *s, int *audio)
+{
+	if (!s || !audio)
+		return rxgpu_fail(RXGPU_EINVAL, "null argument");
+	memcpy(audio, s->audio_host, (size_t)s->p.n_channels * 12);
+	return RXGPU_OK;
+}
+
 long rxgpu_chan_host_fixups(const rxgpu_chan *s) { return s ? s->fixups : 0; }
+
+/* samples until trajectories from the two ends of the int16 range are at most 63 apart: the gap g shrinks by at least
+ * floor(g / a) per sample (k_fm_deemph_scan's argument) */
+static int chan_warm(int a)
+{
+	int n = 0;
+	long long g = 65535;
+	while (g > 63 && n < (1 << 20)) {
+		g -= g / a;
+		n++;
+	}
+	return (n + 8) / 8 * 8;
+}
 
 static int disc_host(int ar, int aj, int br, int bj)
 {
@@ -168,7 +209,33 @@ int rxgpu_chan_run(rxgpu_chan *s, const int16_t *d_iq, size_t n_blocks, size_t b
 		s->fixups = cnt;
 	}
 	free(pre_in_copy);
+	unsigned long long per_channel = total;
+	if (s->p.deemph || s->p.rate_out2 > 0) {
+		/* per-channel audio stages on the finished (and, where needed, host-corrected) demodulated rows */
+		int serial = s->p.deemph && (s->p.deemph_a < 2 || s->p.deemph_a > 64);
+		unsigned long long J = total;
+		if (s->p.rate_out2 > 0) {
+			const int p0 = s->audio_host[2];                  /* the phase advances alike in every channel */
+			for (size_t c = 0; c < nc; c++)
+				if (s->audio_host[3 * c + 2] != p0 || p0 < 0 || p0 >= s->p.rate_out)
+					return rxgpu_fail(RXGPU_EINVAL, "prev_lpr_index must be the same in [0, rate_out) for every channel");
+			J = ((unsigned long long)p0 + total * (unsigned long long)s->p.rate_out2) / (unsigned long long)s->p.rate_out;
+		}
+		for (size_t c = 0; c < nc && !serial; c++)
+			if (s->audio_host[3 * c] < -32768 || s->audio_host[3 * c] > 32767)
+				serial = 1;
+		RX_HIP(hipMemcpyAsync(s->audio_dev[0], s->audio_host, nc * 12, hipMemcpyHostToDevice, st));
+		rxgpu_prof_begin("ch_audio");
+		RX_K(rxk_ch_audio(st, d_out, out_stride, total, s->p.n_channels, s->p.deemph, s->p.deemph_a,
+		                  s->p.deemph && !serial ? chan_warm(s->p.deemph_a) : 8, serial, s->p.rate_out, s->p.rate_out2 > 0 ? s->p.rate_out2 : 0, J,
+		                  s->audio_dev[0], s->audio_dev[1], s->audio_y, s->max_windows));
+		rxgpu_prof_end("ch_audio");
+		RX_HIP(hipMemcpyAsync(s->audio_host, s->audio_dev[1], nc * 12, hipMemcpyDeviceToHost, st));
+		RX_HIP(hipStreamSynchronize(st));
+		rxgpu_prof_collect();
+		per_channel = J;
+	}
 	if (windows_out)
-		*windows_out = (size_t)total;
+		*windows_out = (size_t)per_channel;
 	return RXGPU_OK;
 }

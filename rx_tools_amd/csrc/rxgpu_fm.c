@@ -36,6 +36,8 @@ struct rxgpu_fm_stream {
 	const uint32_t *lp_final;            /* where the last run left the final decimated IQ */
 	uint32_t *cas[2];                    /* fifth_order ping-pong */
 	uint32_t *seams;                     /* per block: 3 levels x 5 history samples for the fused passes */
+	uint32_t *cas_a[2], *seams_a[2];     /* raw input: the first fused group runs on stream A like the decimator, double-buffered */
+	hipEvent_t ev_up;                    /* carries uploaded on stream B -> stream A may read the cascade history */
 	int16_t *pcm_buf[2], *pcm, *y;       /* pcm: the buffer the run in hand uses (double-buffered like lp_raw) */
 	int16_t *rdc_buf, *pcm_post;         /* -E rdc: the corrected, rotated capture; -o: pcm after low_pass_simple */
 	long long *rdc_sums;
@@ -269,6 +271,17 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 		DMALLOC(s->cas[0], (s->max_T / 2 + max_blocks) * 4);
 		DMALLOC(s->cas[1], (s->max_T / 4 + max_blocks) * 4);
 		DMALLOC(s->seams, 2 * (max_blocks + 1) * 15 * 4);
+		if (!params->prescaled) {
+			const int fuse = params->downsample_passes < 3 ? params->downsample_passes : 3;
+			for (int i = 0; i < 2; i++) {
+				DMALLOC(s->cas_a[i], ((s->max_T >> fuse) + max_blocks) * 4);
+				DMALLOC(s->seams_a[i], (max_blocks + 1) * 15 * 4);
+			}
+			if (hipEventCreateWithFlags(&s->ev_up, hipEventDisableTiming) != hipSuccess) {
+				rxgpu_fm_stream_destroy(s);
+				return rxgpu_fail(RXGPU_ENODEV, "hipEventCreate failed");
+			}
+		}
 	}
 	if (hipHostMalloc((void **)&s->dev_host, sizeof(rxk_fm_dev), 0) != hipSuccess ||
 	    hipHostMalloc((void **)&s->hist_host, HIST_TOTAL * 2, 0) != hipSuccess ||
@@ -304,6 +317,8 @@ void rxgpu_fm_stream_destroy(rxgpu_fm_stream *s)
 	}
 	hipFree(s->lp);
 	hipFree(s->cas[0]); hipFree(s->cas[1]); hipFree(s->seams);
+	hipFree(s->cas_a[0]); hipFree(s->cas_a[1]); hipFree(s->seams_a[0]); hipFree(s->seams_a[1]);
+	if (s->ev_up) hipEventDestroy(s->ev_up);
 	hipFree(s->pcm_buf[0]); hipFree(s->pcm_buf[1]); hipFree(s->y);
 	
 	hipFree(s->lvl_tab); hipFree(s->lvl_lo); hipFree(s->lvl_gap); hipFree(s->lvl_start); hipFree(s->chunk_pre);
@@ -578,6 +593,10 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 	if (p->deemph)
 		deemph_geometry(s);
 	RX_HIP(hipMemsetAsync(s->flag_cnt_dev + db, 0, sizeof(int), sb));
+	/* -F on the raw capture: the first fused group of fifth_order passes reads 8/9 of all the bytes of the run; like the
+	 * boxcar decimator it goes on stream A, so that it overlaps the later passes and the audio stages of the run before */
+	const int fuse_a = (g->passes && !prescaled && (g->n % RXK_FIFTH_TILE) == 0 && s->cas_a[0]) ? (g->passes < 3 ? g->passes : 3) : 0;
+	const int fresh = !s->chained;
 
 	if (!s->chained) {
 		/* carries in from the host copy, status cleared */
@@ -605,7 +624,9 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 		/* carries out of the previous run become this run's carries in, on the device */
 		RX_K(rxk_fm_carry_advance(sb, s->dev, 1, s->snap_dev + 4 * db));
 		if (g->passes) {
-			RX_HIP(hipMemcpyAsync(s->hist_dev + HIST_CAS_IN, s->hist_dev + HIST_CAS_OUT, 10 * 12 * 2, hipMemcpyDeviceToDevice, sb));
+			/* the histories of the passes stream A runs are advanced there (below), the others here */
+			RX_HIP(hipMemcpyAsync(s->hist_dev + HIST_CAS_IN + fuse_a * 12, s->hist_dev + HIST_CAS_OUT + fuse_a * 12, (size_t)(10 - fuse_a) * 12 * 2,
+			                      hipMemcpyDeviceToDevice, sb));
 			if (p->comp_fir_size == 9)
 				RX_HIP(hipMemcpyAsync(s->hist_dev + HIST_DROOP_IN, s->hist_dev + HIST_DROOP_OUT, 18 * 2, hipMemcpyDeviceToDevice, sb));
 		}
@@ -655,32 +676,44 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 		                 (g->fast && fused_disc) ? s->tiled : 0));
 		rxgpu_prof_end_on("fm_disc", sb);
 	} else {
-		/* F3: cascade (first passes fused where the input is raw), F12 optional; all on stream B */
+		/* F3: cascade (first passes fused where the input is raw), F12 optional */
 		const int passes = g->passes;
-		rxgpu_prof_begin_on("fm_fifth", sb);
 		const void *src = d_iq;
 		unsigned n_in = (unsigned)g->n, in_stride = (unsigned)g->n;
 		int first_pass = 0;
-		if (!prescaled && (g->n % RXK_FIFTH_TILE) == 0) {
-			const int fuse = passes < 3 ? passes : 3;
-			uint32_t *dst = s->cas[(fuse - 1) & 1];
-			RX_K(rxk_fm_fifth_fused(sb, d_iq, 0, g->rotate, n_blocks, (unsigned)g->n, fuse, s->hist_dev + HIST_CAS_IN,
-			                        s->hist_dev + HIST_CAS_OUT, s->seams, dst));
+		if (fuse_a) {
+			const int fuse = fuse_a;
+			uint32_t *dst = s->cas_a[db];
+			if (s->ev_small_valid[db])                   /* cas_a[db] was last read by the run two enqueues ago */
+				RX_HIP(hipStreamWaitEvent(sa, s->ev_small[db], 0));
+			if (fresh) {
+				RX_HIP(hipEventRecord(s->ev_up, sb));    /* the history upload above went through stream B */
+				RX_HIP(hipStreamWaitEvent(sa, s->ev_up, 0));
+			} else {
+				RX_HIP(hipMemcpyAsync(s->hist_dev + HIST_CAS_IN, s->hist_dev + HIST_CAS_OUT, (size_t)fuse * 12 * 2, hipMemcpyDeviceToDevice, sa));
+			}
+			rxgpu_prof_begin_on("fm_fifth", sa);
+			RX_K(rxk_fm_fifth_fused(sa, d_iq, 0, g->rotate, n_blocks, (unsigned)g->n, fuse, s->hist_dev + HIST_CAS_IN,
+			                        s->hist_dev + HIST_CAS_OUT, s->seams_a[db], dst));
+			rxgpu_prof_end_on("fm_fifth", sa);
+			RX_HIP(hipEventRecord(s->ev_dec[db], sa));
+			RX_HIP(hipStreamWaitEvent(sb, s->ev_dec[db], 0));
 			src = dst;
 			n_in = (unsigned)(g->n >> fuse);
 			in_stride = n_in;
 			first_pass = fuse;
+		}
+		rxgpu_prof_begin_on("fm_fifth2", sb);
+		if (fuse_a == 3 && passes > 3 && (n_in % RXK_FIFTH_TILE) == 0) {
 			/* a second fused group on the 1/8-rate stream (3 passes, or 1 so that the ping-pong buffers stay distinct) */
-			if (fuse == 3 && passes > 3 && (n_in % RXK_FIFTH_TILE) == 0) {
-				const int fuse2 = passes - 3 >= 3 ? 3 : 1;
-				uint32_t *dst2 = s->cas[(3 + fuse2 - 1) & 1];
-				RX_K(rxk_fm_fifth_fused(sb, src, 1, 0, n_blocks, n_in, fuse2, s->hist_dev + HIST_CAS_IN + 3 * 12,
-				                        s->hist_dev + HIST_CAS_OUT + 3 * 12, s->seams + (s->max_blocks + 1) * 15, dst2));
-				src = dst2;
-				n_in >>= fuse2;
-				in_stride = n_in;
-				first_pass = 3 + fuse2;
-			}
+			const int fuse2 = passes - 3 >= 3 ? 3 : 1;
+			uint32_t *dst2 = s->cas[(3 + fuse2 - 1) & 1];
+			RX_K(rxk_fm_fifth_fused(sb, src, 1, 0, n_blocks, n_in, fuse2, s->hist_dev + HIST_CAS_IN + 3 * 12,
+			                        s->hist_dev + HIST_CAS_OUT + 3 * 12, s->seams + (s->max_blocks + 1) * 15, dst2));
+			src = dst2;
+			n_in >>= fuse2;
+			in_stride = n_in;
+			first_pass = 3 + fuse2;
 		}
 		for (int i = first_pass; i < passes; i++) {
 			uint32_t *dst = s->cas[i & 1];
@@ -691,7 +724,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 			n_in = n_out;
 			in_stride = n_out;
 		}
-		rxgpu_prof_end_on("fm_fifth", sb);
+		rxgpu_prof_end_on("fm_fifth2", sb);
 		s->lp_final = (const uint32_t *)src;             /* [n_blocks][K] contiguous == M samples */
 		if (p->comp_fir_size == 9) {
 			RX_HIP(hipMemcpyAsync(s->fir_dev, cic_9_tables[passes], 10 * sizeof(int), hipMemcpyHostToDevice, sb));

@@ -120,7 +120,7 @@ class FmStream:
 
 class ChanParams(C.Structure):
     """struct rxgpu_chan_params (channeliser extension, include/rxgpu.h)"""
-    _fields_ = [(n, C.c_int) for n in ("bin_e", "first_bin", "n_channels", "custom_atan")]
+    _fields_ = [(n, C.c_int) for n in ("bin_e", "first_bin", "n_channels", "custom_atan", "deemph", "deemph_a", "rate_out", "rate_out2")]
 
 
 class Channeliser:
@@ -152,6 +152,15 @@ class Channeliser:
         pre = np.zeros(2 * self.params.n_channels, dtype=np.int32)
         check(lib().rxgpu_chan_get_carry(self._h, pre.ctypes.data))
         return pre
+
+    def set_audio_carry(self, audio):
+        check(lib().rxgpu_chan_set_audio_carry(self._h, audio.ctypes.data))
+
+    def get_audio_carry(self):
+        import numpy as np
+        a = np.zeros(3 * self.params.n_channels, dtype=np.int32)
+        check(lib().rxgpu_chan_get_audio_carry(self._h, a.ctypes.data))
+        return a
 
     def run(self, d_iq_ptr, n_blocks, block_len, d_out_ptr, out_stride):
         n = C.c_size_t(0)

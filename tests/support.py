@@ -287,7 +287,7 @@ def oracle_fm_stream(iq, block_len, **params):
     L = oracle()
     st = oracle_fm_state(**params)
     n_blocks = len(iq) // block_len
-    out = np.zeros(len(iq) // 2 + 16, dtype=np.int16)
+    out = np.zeros(len(iq) + 16, dtype=np.int16)           # raw_demod at downsample 1 hands back as many int16 as went in
     lens = np.zeros(n_blocks, dtype=np.int32)
     total = L.rxo_fm_stream(C.byref(st), ptr16(iq), n_blocks, block_len, ptr16(out), ptr32(lens))
     return out[:total].copy(), lens, st

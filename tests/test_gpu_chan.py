@@ -114,3 +114,72 @@ def test_channeliser_finds_the_carrier():
     assert np.all(np.abs(out[k, 1:]) <= 40), out[k, :8]
     # and next to nothing leaks into far-away channels: their bins stay (near) zero
     assert np.count_nonzero(out[(k + 512) % 1024]) == 0
+
+
+# ----------------------------------------------------------------------------- round 2: per-channel audio stages
+
+def oracle_chan_audio(iq, block_len, bin_e, first_bin, n_channels, custom_atan, deemph, a, rate_out, rate_out2):
+    """every channel a demod_state of its own: after fm_demod, deemph_filter and low_pass_real (the reference's functions as
+    restated and pinned in oracle/rx_oracle.c) on the channel's samples, callback block after callback block, with the
+    channel's own carried avg / now_lpr / prev_lpr_index"""
+    O = oracle()
+    O.rxo_chan_block.argtypes = [C.POINTER(ChanCfg), i16p, C.c_int, intp, i16p, C.c_size_t]
+    O.rxo_deemph.argtypes = [i16p, C.c_int, C.c_int, intp]
+    O.rxo_low_pass_real.argtypes = [i16p, C.c_int, C.c_int, C.c_int, intp, intp]
+    sw = R.sine_table(bin_e)
+    cfg = ChanCfg(bin_e, first_bin, n_channels, custom_atan, ptr16(sw))
+    n = 1 << bin_e
+    n_blocks = len(iq) // block_len
+    wpb = block_len // 2 // n
+    pre = np.zeros(2 * n_channels, np.int32)
+    state = np.zeros((n_channels, 3), np.int32)
+    outs = [[] for _ in range(n_channels)]
+    tmp = np.zeros((n_channels, wpb), np.int16)
+    for b in range(n_blocks):
+        blk = np.ascontiguousarray(iq[b * block_len:(b + 1) * block_len])
+        O.rxo_chan_block(C.byref(cfg), ptr16(blk), block_len, pre.ctypes.data_as(intp), ptr16(tmp), wpb)
+        for c in range(n_channels):
+            row = np.ascontiguousarray(tmp[c])
+            k = wpb
+            avg, now, idx = (C.c_int(int(v)) for v in state[c])
+            if deemph:
+                O.rxo_deemph(ptr16(row), k, a, C.byref(avg))
+            if rate_out2 > 0:
+                k = O.rxo_low_pass_real(ptr16(row), k, rate_out, rate_out2, C.byref(now), C.byref(idx))
+            state[c] = (avg.value, now.value, idx.value)
+            outs[c].append(row[:k].copy())
+    return np.stack([np.concatenate(o) for o in outs]), pre, state
+
+
+@pytest.mark.parametrize("bin_e,n_channels,block_len,n_blocks,deemph,a,rate_out,rate_out2,custom_atan", [
+    (10, 256, 2 * 131072, 3, 1, 2, 19531, 8000, 1),       # configs[4] bank: 75 us at 19.5 kHz gives a = 2 (even, generic step), -r 8000
+    (8, 64, 2 * 65536, 4, 1, 13, 170000, 32000, 1),       # the wbfm constants on a coarse bank: odd a, three-instruction range
+    (8, 64, 2 * 65536, 4, 1, 13, 170000, -1, 0),          # de-emphasis only, in place; -A std
+    (9, 100, 2 * 32768, 5, 0, 0, 48000, 8000, 1),         # resampler only, ratio 6
+    (8, 32, 2 * 65536, 3, 1, 64, 24000, 12000, 1),        # a at the top of the mask range
+    (8, 32, 2 * 16384, 3, 1, 200, 24000, 6000, 1),        # a > 64: one thread per channel
+    (8, 16, 2 * 1024, 6, 1, 9, 24000, 8000, 1),           # four windows per block: shorter than any warm-up
+])
+def test_channeliser_per_channel_audio_stages(bin_e, n_channels, block_len, n_blocks, deemph, a, rate_out, rate_out2, custom_atan):
+    from gpu_support import to_dev, torch_cuda
+    torch = torch_cuda()
+    iq = sig_noise(n_blocks * block_len, seed=4 + bin_e, amp=2500)
+    want, want_pre, want_state = oracle_chan_audio(iq, block_len, bin_e, 5, n_channels, custom_atan, deemph, a, rate_out, rate_out2)
+    n = 1 << bin_e
+    wpb = block_len // 2 // n
+    per = (n_blocks + 1) // 2                                  # two runs: the per-channel carries cross a run boundary
+    ch = R.Channeliser(R.ChanParams(bin_e, 5, n_channels, custom_atan, deemph, a, rate_out, rate_out2), per, block_len, R.sine_table(bin_e))
+    d_iq = to_dev(iq)
+    outs, b = [], 0
+    while b < n_blocks:
+        nb = min(per, n_blocks - b)
+        d_out = torch.zeros((n_channels, nb * wpb), dtype=torch.int16, device="cuda")
+        w = ch.run(d_iq.data_ptr() + b * block_len * 2, nb, block_len, d_out.data_ptr(), nb * wpb)
+        outs.append(d_out[:, :w].cpu().numpy())
+        b += nb
+    got = np.concatenate(outs, axis=1)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
+    assert np.array_equal(ch.get_carry(), want_pre)
+    assert np.array_equal(ch.get_audio_carry().reshape(n_channels, 3), want_state)
+    ch.close()
