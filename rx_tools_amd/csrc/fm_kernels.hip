@@ -889,7 +889,7 @@ __device__ __forceinline__ void deemph_stage(const int16_t *__restrict__ pcm, u6
 	}
 }
 
-// Fast form of the step for odd a in 5..255 (the D24 range): the state is kept as N = ((a/2 - avg) << 6) + 32, so that
+// Fast form of the step for odd a in 9..255 (the D24 range): the state is kept as N = ((a/2 - avg) << 6) + 32, so that
 //   t6 = ((x - avg + a/2) << 6) + 32          one v_mad_i32_i16 straight from the packed sample (x * 64 + N),
 //   q  = floor((x - avg + a/2) / a)            one signed 24-bit multiply-high, (t6 * (2^26/a + 1)) >> 32 -- the +32 (half
 //                                              a unit) keeps it exact for negative dividends: |t6| < 2^23, error < 2^-9 < 1/(2a),
@@ -1251,7 +1251,7 @@ __global__ void k_fm_deemph_serial(const int16_t *__restrict__ pcm, u64 M, int a
 //                          INLINE on the filtered samples: de-emphasised audio never goes to HBM.  A lane owns the
 //                          resampler windows that START in its chunk and walks on into the next chunk to finish the last
 //                          one; outputs are staged per wave in a few KiB of LDS and leave coalesced.
-// Odd a in 5..255 only (the three-instruction step), 2 <= rate_out / rate_out2 <= 32; everything else keeps the other path.
+// Odd a in 9..255 only (the three-instruction step), 2 <= rate_out / rate_out2 <= 32; everything else keeps the other path.
 
 __device__ __forceinline__ const uint4 *tile_unit(const int16_t *pcm_t, u64 chunk, int chl2)
 {
@@ -1375,20 +1375,21 @@ __global__ void k_fm_deemph_down0(u64 n_chunks, const uint4 *__restrict__ ctab, 
 // floor(num / den) for num < 2^52 (declared with the resampler below)
 __device__ __forceinline__ u64 div_floor(u64 num, u64 den);
 
-// One sample of low_pass_real run inline behind the de-emphasis step: y joins the window if this lane owns it, the
-// phase advances, and a completed window leaves as (int16)(sum / ratio) -- the truncating division through one fp32
-// multiply by a reciprocal rounded up (exact for |sum| <= 34 * 32768 and ratio <= 32, checked exhaustively on the host).
-// Branch-free: lanes are at different phases, some lane of the wave emits at nearly every sample.
-__device__ __forceinline__ void lpr_step(int y, int &own, int &acc, int &p, int &slot, int fast, int slow, float rinv, int16_t *stage)
+// One sample of low_pass_real run inline behind the de-emphasis step: y joins the running window, the phase advances, and a
+// completed window leaves as (int16)(sum / ratio) -- the truncating division through one fp32 multiply by a reciprocal
+// rounded up (exact for |sum| <= 34 * 32768 and ratio <= 32, checked exhaustively on the host).  Branch-free bookkeeping:
+// lanes are at different phases, some lane of the wave emits at nearly every sample.  A lane that starts in the middle of
+// somebody else's window emits that window's (partial, wrong) sum into the slot BEFORE its own first one: slot -1 of the
+// staging for a wave's first lane, otherwise the slot its left neighbour fills in afterwards, when it walks on past its
+// chunk to finish the window it owns -- same wave, later in program order, LDS operations retire in order.
+__device__ __forceinline__ void lpr_step(int y, int &acc, int &p, int &slot, int fast, int slow, float rinv, int16_t *stage)
 {
-	own |= p < slow ? 1 : 0;                                  // a window starts at this sample
-	acc += own ? y : 0;
+	acc += y;
 	p += slow;
 	const bool emit = p >= fast;
-	const int q = (int)((float)acc * rinv);
-	if (emit && own)
-		stage[slot] = (int16_t)q;
-	slot += (emit && own) ? 1 : 0;
+	if (emit)
+		stage[slot] = (int16_t)(int)((float)acc * rinv);
+	slot += emit ? 1 : 0;
 	acc = emit ? 0 : acc;
 	p -= emit ? fast : 0;
 }
@@ -1415,12 +1416,15 @@ __global__ __launch_bounds__(256) void k_fm_deemph_apply_rs_t(
 	const u64 num = p_in + c0 * (u64)slow;
 	const u64 e0 = div_floor(num, (u64)fast);
 	int p = (int)(num - e0 * (u64)fast);
-	int own = (c == 0) ? 1 : 0;                               // the run's first lane continues the carried window
-	int acc = (c == 0) ? dev->in_now_lpr : 0;
-	// first output this lane will write: e0 if a window starts exactly here (or it is the run's first lane), else the one after
-	const u64 j_first = e0 + ((c == 0 || p < slow) ? 0 : 1);
+	const int p_first = p;
+	int acc = (c == 0) ? dev->in_now_lpr : 0;                 // the run's first lane continues the carried window
+	// does a window start exactly at this chunk's first sample (or is this the run's first lane)?  If not, the window under way
+	// belongs to the lane on the left and completes after `skip` samples; this lane's own outputs start behind it.
+	const bool owns_first = c == 0 || p < slow;
+	const u64 j_first = e0 + (owns_first ? 0 : 1);
 	const u64 jw0 = (u64)__builtin_amdgcn_readfirstlane((int)(unsigned)j_first) | ((u64)__builtin_amdgcn_readfirstlane((int)(unsigned)(j_first >> 32)) << 32);
-	int slot = (int)(j_first - jw0);
+	int slot = (int)(j_first - jw0) - (owns_first ? 0 : 1);   // >= -1: the staging has one spare element in front
+	stage += 1;
 	if (valid) {
 		const int n = (int)((M - c0) < (u64)CH ? (M - c0) : (u64)CH);
 		int N = de_state(start[c], h);
@@ -1434,19 +1438,22 @@ __global__ __launch_bounds__(256) void k_fm_deemph_apply_rs_t(
 #pragma unroll
 			for (int k = 0; k < 4; k++) {
 				de_step<0>(ww[k], N, magic, -64);
-				lpr_step(h - (N >> 6), own, acc, p, slot, fast, slow, rinv, stage);
+				lpr_step(h - (N >> 6), acc, p, slot, fast, slow, rinv, stage);
 				de_step<1>(ww[k], N, magic, -64);
-				lpr_step(h - (N >> 6), own, acc, p, slot, fast, slow, rinv, stage);
+				lpr_step(h - (N >> 6), acc, p, slot, fast, slow, rinv, stage);
 			}
 		}
 		if (n & 7) {
 			const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
 			for (int k = 0; k < (n & 7); k++) {
 				if (k & 1) de_step<1>(ww[k >> 1], N, magic, -64); else de_step<0>(ww[k >> 1], N, magic, -64);
-				lpr_step(h - (N >> 6), own, acc, p, slot, fast, slow, rinv, stage);
+				lpr_step(h - (N >> 6), acc, p, slot, fast, slow, rinv, stage);
 			}
 		}
 		const u64 end = c0 + (u64)n;
+		// a window this lane owns has started iff the one it found under way (if any) completed inside the chunk
+		const int skip = owns_first ? 0 : (fast - p_first + slow - 1) / slow;
+		const bool own = skip < n || (owns_first && n > 0);
 		if (end == M) {
 			// the run's last chunk: what is left is the carry (rtl_fm.c:150-151).  A window still open belongs either to
 			// this lane (own) or to an earlier lane that walks on to M below and writes it; no window open: zero.
@@ -1465,7 +1472,7 @@ __global__ __launch_bounds__(256) void k_fm_deemph_apply_rs_t(
 				for (int k = (int)(i & 7); k < 8 && open && i < M; k++, i++) {
 					if (k & 1) de_step<1>(ww[k >> 1], N, magic, -64); else de_step<0>(ww[k >> 1], N, magic, -64);
 					const int before = slot;
-					lpr_step(h - (N >> 6), own, acc, p, slot, fast, slow, rinv, stage);
+					lpr_step(h - (N >> 6), acc, p, slot, fast, slow, rinv, stage);
 					open = slot == before;
 				}
 			}
@@ -1947,6 +1954,111 @@ __global__ void k_fm_droop(const uint32_t *__restrict__ in, u64 M, const int *__
 	}
 }
 
+
+// F12 + F5/F6 in one pass (the `-M wbfm -F 9` chain: three fifth_order passes leave an eighth of the capture rate, and the
+// one-thread-per-output k_fm_droop + dense k_fm_disc pair then costs more than the cascade).  A thread takes four
+// consecutive outputs t0..t0+3 of the droop FIR -- out[t] = sum over the nine samples BEFORE t, rtl_fm.c:442-465 -- from four
+// aligned 16-byte loads of the post-cascade stream (s[t0-12 .. t0+3]; the neighbours' loads hit the same lines), computes
+// out[t0-1] once more for the first product, and demodulates: fast_atan2 for ordinary samples, the libm form (with the
+// 2^-33 window and the host fix-up records) for each callback block's first sample.  lp_out != NULL also stores the FIR output
+// (the drop-in hands lowpassed[] back); pcm goes out linear or tiled.
+template <bool STORE_LP>
+__global__ __launch_bounds__(256) void k_fm_droop_disc(
+	const uint32_t *__restrict__ in, u64 M, const int *__restrict__ fir, const int16_t *__restrict__ hist_in, int16_t *__restrict__ hist_out,
+	uint32_t *__restrict__ lp_out, u64 uniform_k, int16_t *__restrict__ pcm, int pcm_chl2, rxk_fm_dev *__restrict__ dev,
+	rxk_flag_rec *__restrict__ flag_list, int *__restrict__ flag_cnt, int flag_all)
+{
+	const u64 t0 = ((u64)blockIdx.x * 256 + threadIdx.x) * 4;
+	if (t0 >= M)
+		return;
+	// s[t0-12 .. t0+3]: stream samples, the carried history (hist[0..8] = s[-9..-1]) before the run, zero before that
+	uint32_t sv[16];
+	if (t0 >= 12 && t0 + 4 <= M) {
+		const uint4 *q = reinterpret_cast<const uint4 *>(in + t0 - 12);
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const uint4 w = q[k];
+			sv[4 * k] = w.x; sv[4 * k + 1] = w.y; sv[4 * k + 2] = w.z; sv[4 * k + 3] = w.w;
+		}
+	} else {
+#pragma unroll
+		for (int k = 0; k < 16; k++) {
+			const i64 idx = (i64)t0 - 12 + k;
+			sv[k] = idx >= (i64)M ? 0u : idx >= 0 ? in[idx] : idx >= -9 ? pack_iq(hist_in[9 + idx], hist_in[18 + idx]) : 0u;
+		}
+	}
+	const int f1 = fir[1], f2 = fir[2], f3 = fir[3], f4 = fir[4], f5 = fir[5];
+	uint32_t o[5];                                            // out[t0-1 .. t0+3]; out[t] uses s[t-9 .. t-1] = sv[t-t0+3 .. t-t0+11]
+#pragma unroll
+	for (int r = 0; r < 5; r++) {
+		const int b = r + 2;
+		const int si = (lo16(sv[b]) + lo16(sv[b + 8])) * f1 + (lo16(sv[b + 1]) + lo16(sv[b + 7])) * f2 + (lo16(sv[b + 2]) + lo16(sv[b + 6])) * f3 +
+		               (lo16(sv[b + 3]) + lo16(sv[b + 5])) * f4 + lo16(sv[b + 4]) * f5;
+		const int sq = (hi16(sv[b]) + hi16(sv[b + 8])) * f1 + (hi16(sv[b + 1]) + hi16(sv[b + 7])) * f2 + (hi16(sv[b + 2]) + hi16(sv[b + 6])) * f3 +
+		               (hi16(sv[b + 3]) + hi16(sv[b + 5])) * f4 + hi16(sv[b + 4]) * f5;
+		o[r] = pack_iq(si >> 15, sq >> 15);
+	}
+	const int n = (int)((M - t0) < 4 ? (M - t0) : 4);
+	if (STORE_LP) {
+		if (n == 4)
+			*reinterpret_cast<uint4 *>(lp_out + t0) = make_uint4(o[1], o[2], o[3], o[4]);
+		else
+			for (int r = 0; r < n; r++) lp_out[t0 + r] = o[1 + r];
+	}
+	int16_t res[4];
+#pragma unroll
+	for (int r = 0; r < 4; r++) {
+		const u64 m = t0 + r;
+		if (r >= n) { res[r] = 0; continue; }
+		const uint32_t a = o[1 + r];
+		int br, bj;
+		if (m) { br = lo16(o[r]); bj = hi16(o[r]); }
+		else { br = dev->in_pre_r; bj = dev->in_pre_j; }
+		const int ar = lo16(a), aj = hi16(a);
+		const int cr = (int)((unsigned)ar * (unsigned)br + (unsigned)aj * (unsigned)bj);
+		const int cj = (int)((unsigned)aj * (unsigned)br - (unsigned)ar * (unsigned)bj);
+		const bool first = (uniform_k & (uniform_k - 1)) ? (m % uniform_k) == 0 : (m & (uniform_k - 1)) == 0;
+		int out;
+		if (__builtin_expect(first, 0)) {
+			// polar_discriminant, rtl_fm.c:476-483 (see k_fm_disc)
+			const double v = atan2((double)cj, (double)cr) / 3.14159 * 16384.0;
+			out = (int)v;
+			if (v != 0.0 && (flag_all || fabs(v - rint(v)) < RXK_LIBM_WINDOW)) {
+				const int idx = atomicAdd(flag_cnt, 1);
+				if (idx < RXK_FLAG_CAP) {
+					rxk_flag_rec rec;
+					rec.m = m; rec.ar = ar; rec.aj = aj; rec.br = br; rec.bj = bj;
+					flag_list[idx] = rec;
+				}
+				if (flag_all > 1)
+					out += 77;
+			}
+		} else {
+			out = fast_atan2_dev(cj, cr);
+		}
+		res[r] = (int16_t)out;
+		if (m == M - 1) {
+			dev->out_pre_r = ar;
+			dev->out_pre_j = aj;
+		}
+	}
+	int16_t *dst = pcm + pcm_index(t0, pcm_chl2);             // four consecutive samples stay inside one 16-byte unit of the tiled layout
+	if (n == 4)
+		*reinterpret_cast<uint2 *>(dst) = make_uint2((uint32_t)(uint16_t)res[0] | ((uint32_t)(uint16_t)res[1] << 16),
+		                                             (uint32_t)(uint16_t)res[2] | ((uint32_t)(uint16_t)res[3] << 16));
+	else
+		for (int r = 0; r < n; r++) dst[r] = res[r];
+	if (t0 + 4 >= M) {
+		// new history = the last 9 INPUT samples s[M-9 .. M-1]
+		for (int j = 0; j < 9; j++) {
+			const i64 idx = (i64)M - 9 + j;
+			const uint32_t w = idx >= 0 ? in[idx] : pack_iq(hist_in[9 + idx], hist_in[18 + idx]);
+			hist_out[j] = (int16_t)lo16(w);
+			hist_out[9 + j] = (int16_t)hi16(w);
+		}
+	}
+}
+
 // ------------------------------------------------------------------ callback pre-stage alone
 
 // rtlsdr_callback's scale + rotate (rtl_fm.c:845-857) as an elementwise pass, for the
@@ -2386,7 +2498,9 @@ static unsigned magic_for(int a) { return a > 1 ? (unsigned)((1ull << 32) / (uns
 
 static int bias_for(int a) { return 65536 / a + 2; }
 
-static bool deemph_d24(int a) { return a >= 5 && a < 256; }
+// the 24-bit forms: the unsigned division takes (2^26/a + 1) < 2^24, i.e. a >= 5; the three-instruction step multiplies by the same
+// constant with a SIGNED 24-bit multiply-high (v_mul_hi_i32_i24), so it needs 2^26/a + 1 < 2^23: a >= 9.  One predicate for both.
+static bool deemph_d24(int a) { return a >= 9 && a < 256; }
 static unsigned deemph_magic(int a) { return deemph_d24(a) ? (1u << 26) / (unsigned)a + 1 : magic_for(a); }
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) l++; return l; }
 
@@ -2528,7 +2642,7 @@ extern "C" int rxk_fm_deemph_apply_rs_t(void *stream, const int16_t *pcm_t, u64 
 	// the reciprocal rounded UP: (int)((float)sum * rinv) is C's truncating sum / ratio for |sum| <= 34 * 32768, ratio <= 32
 	const float rinv = __builtin_nextafterf((float)(1.0 / (double)ratio), __builtin_inff());
 	// outputs one wave can produce: 64 chunks' worth of input, +1 window finished for a neighbour, +1 rounding
-	const int wcap = (int)((((u64)64 << chl2) * (u64)slow) / (u64)fast) + 4;
+	const int wcap = ((int)((((u64)64 << chl2) * (u64)slow) / (u64)fast) + 6) & ~1;       /* + the spare element in front, even */
 	const size_t lds = (size_t)4 * wcap * sizeof(int16_t);
 	hipStream_t s = (hipStream_t)stream;
 	const unsigned mg = deemph_magic(a);
@@ -2745,5 +2859,22 @@ extern "C" int rxk_ch_audio(void *stream, int16_t *rows, u64 row_stride, u64 W, 
 	if (deemph && deemph_d24(a)) { if (a & 1) GO(false, true); else GO(true, true); }
 	else { if (!deemph || (a & 1)) GO(false, false); else GO(true, false); }
 #undef GO
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_fm_droop_disc(void *stream, const uint32_t *in, u64 M, const int *fir, const int16_t *hist_in, int16_t *hist_out,
+                                 uint32_t *lp_out, u64 uniform_k, int16_t *pcm, int pcm_chl2, rxk_fm_dev *dev, rxk_flag_rec *flag_list,
+                                 int *flag_cnt, int flag_all)
+{
+	if (!M)
+		return 0;
+	const unsigned grid = (unsigned)(((M + 3) / 4 + 255) / 256);
+	hipStream_t s = (hipStream_t)stream;
+	if (lp_out)
+		hipLaunchKernelGGL((k_fm_droop_disc<true>), dim3(grid), dim3(256), 0, s, in, M, fir, hist_in, hist_out, lp_out, uniform_k, pcm, pcm_chl2, dev,
+		                   flag_list, flag_cnt, flag_all);
+	else
+		hipLaunchKernelGGL((k_fm_droop_disc<false>), dim3(grid), dim3(256), 0, s, in, M, fir, hist_in, hist_out, lp_out, uniform_k, pcm, pcm_chl2, dev,
+		                   flag_list, flag_cnt, flag_all);
 	LAUNCH_RET();
 }

@@ -170,6 +170,12 @@ int rxk_fm_fifth_fused(void *stream, const void *in, int stage2, int rotate, uns
 int rxk_fm_droop(void *stream, const uint32_t *in, unsigned long long M, const int *fir,
                  const int16_t *hist_in, int16_t *hist_out, uint32_t *out);
 
+/* F12 + fm_demod (-A fast; each block's first sample through libm) in one pass over the post-cascade stream; uniform blocks of
+ * uniform_k samples.  lp_out (optional): the FIR output; pcm: linear or tiled (pcm_chl2). */
+int rxk_fm_droop_disc(void *stream, const uint32_t *in, unsigned long long M, const int *fir, const int16_t *hist_in, int16_t *hist_out,
+                      uint32_t *lp_out, unsigned long long uniform_k, int16_t *pcm, int pcm_chl2, rxk_fm_dev *dev, rxk_flag_rec *flag_list,
+                      int *flag_cnt, int flag_all);
+
 /* rtlsdr_callback's scale + rotate alone (rtl_fm.c:845-857), n_complex samples */
 int rxk_fm_prestage(void *stream, const int16_t *in, unsigned n_complex, int rotate, int16_t *out);
 

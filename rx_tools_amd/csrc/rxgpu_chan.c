@@ -126,13 +126,14 @@ int rxgpu_chan_get_audio_carry(rxgpu_chan *s, int *audio)
 
 long rxgpu_chan_host_fixups(const rxgpu_chan *s) { return s ? s->fixups : 0; }
 
-/* samples until trajectories from the two ends of the int16 range are at most 63 apart: the gap g shrinks by at least
- * floor(g / a) per sample (k_fm_deemph_scan's argument) */
+/* samples until trajectories from the two ends of the int16 range are fewer than `a` apart (then at most one adjacent pair
+ * of candidates merges per sample, which is what the mask tracking relies on): the gap g shrinks by at least floor(g / a) per
+ * sample (k_fm_deemph_scan's argument).  a <= 64, so the candidates also fit the 64-bit mask. */
 static int chan_warm(int a)
 {
 	int n = 0;
 	long long g = 65535;
-	while (g > 63 && n < (1 << 20)) {
+	while (g >= a && n < (1 << 20)) {
 		g -= g / a;
 		n++;
 	}

@@ -642,16 +642,15 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 	s->last_n_blocks = n_blocks;
 	/* squelch and the non-fm demodulators need the finished lowpassed[] before anything is demodulated */
 	const int split = p->squelch_level != 0 || p->mode != RXGPU_MODE_FM;
+	/* de-emphasis + resampler behind an fm discriminator: hand them the demodulated samples in the tiled layout their
+	 * lane-per-chunk kernels stream (rxk_fm_deemph_scan_t / _apply_rs_t).  $RXGPU_NO_TILED keeps the LDS-staged kernels. */
+	if (!split && p->deemph && s->group && p->rate_out2 > 0 && g->post == 1 && !p->dc_block_audio && !getenv("RXGPU_NO_TILED"))
+		s->tiled = rxk_fm_deemph_tiled_ok(p->deemph_a, s->group, s->chunk, p->rate_out, p->rate_out2);
 	if (!g->passes) {
 		const int fused_disc = g->fast && p->custom_atan == 1 && !split;
 		/* lowpassed[] is an intermediate of the fused chain: keep only the entries the seam kernel reads
 		 * (the drop-in, which must hand lowpassed[] back, runs prescaled) */
 		const int lp_sparse = fused_disc && !prescaled && g->ds <= RXK_LP_SPARSE_MAX_DS;
-		/* small decimation: the audio stages are a sizeable share of the work -- hand them the demodulated samples in the tiled
-		 * layout their lane-per-chunk kernels stream (rxk_fm_deemph_scan_t / _apply_rs_t).  $RXGPU_NO_TILED keeps the other path. */
-		s->tiled = 0;
-		if (g->fast && fused_disc && p->deemph && s->group && p->rate_out2 > 0 && g->post == 1 && !p->dc_block_audio && !getenv("RXGPU_NO_TILED"))
-			s->tiled = rxk_fm_deemph_tiled_ok(p->deemph_a, s->group, s->chunk, p->rate_out, p->rate_out2);
 		if (g->fast) {
 			s->lp_final = s->lp_raw[db];
 			/* buffer set `db` was last read by the audio chain two runs ago */
@@ -672,12 +671,12 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 		/* fast path: lp_raw is finished in place (only seam entries change) and becomes the final decimated IQ */
 		RX_K(rxk_fm_disc(sb, d_iq, g->T, g->ds, g->p0, g->n, prescaled, g->rotate, g->fast, g->fast ? s->lp_raw[db] : s->lp,
 		                 s->head[db], s->tail[db], g->fast ? s->lp_raw[db] : s->lp, g->M, RXK_FIRST_LOWPASS, 0, p->custom_atan, 1,
-		                 split ? NULL : s->pcm, s->dev, flag_rec, flag_cnt, fused_disc, n_blocks, s->atan_lut, g->fast ? lp_sparse : 0, s->flag_all,
-		                 (g->fast && fused_disc) ? s->tiled : 0));
+		                 split ? NULL : s->pcm, s->dev, flag_rec, flag_cnt, fused_disc, n_blocks, s->atan_lut, g->fast ? lp_sparse : 0, s->flag_all, s->tiled));
 		rxgpu_prof_end_on("fm_disc", sb);
 	} else {
 		/* F3: cascade (first passes fused where the input is raw), F12 optional */
 		const int passes = g->passes;
+		int fused_dd = 0;
 		const void *src = d_iq;
 		unsigned n_in = (unsigned)g->n, in_stride = (unsigned)g->n;
 		int first_pass = 0;
@@ -728,15 +727,27 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 		s->lp_final = (const uint32_t *)src;             /* [n_blocks][K] contiguous == M samples */
 		if (p->comp_fir_size == 9) {
 			RX_HIP(hipMemcpyAsync(s->fir_dev, cic_9_tables[passes], 10 * sizeof(int), hipMemcpyHostToDevice, sb));
-			rxgpu_prof_begin_on("fm_droop", sb);
-			RX_K(rxk_fm_droop(sb, s->lp_final, g->M, s->fir_dev, s->hist_dev + HIST_DROOP_IN, s->hist_dev + HIST_DROOP_OUT, s->lp));
-			rxgpu_prof_end_on("fm_droop", sb);
-			s->lp_final = s->lp;
+			if (!split && p->custom_atan == 1) {
+				/* the droop FIR and the discriminator in one pass; the FIR output itself is only kept where somebody reads it
+				 * back (the drop-in hands lowpassed[] to its caller) */
+				rxgpu_prof_begin_on("fm_droop", sb);
+				RX_K(rxk_fm_droop_disc(sb, s->lp_final, g->M, s->fir_dev, s->hist_dev + HIST_DROOP_IN, s->hist_dev + HIST_DROOP_OUT,
+				                       prescaled ? s->lp : NULL, g->K, s->pcm, s->tiled, s->dev, flag_rec, flag_cnt, s->flag_all));
+				rxgpu_prof_end_on("fm_droop", sb);
+				if (prescaled)
+					s->lp_final = s->lp;
+				fused_dd = 1;
+			} else {
+				rxgpu_prof_begin_on("fm_droop", sb);
+				RX_K(rxk_fm_droop(sb, s->lp_final, g->M, s->fir_dev, s->hist_dev + HIST_DROOP_IN, s->hist_dev + HIST_DROOP_OUT, s->lp));
+				rxgpu_prof_end_on("fm_droop", sb);
+				s->lp_final = s->lp;
+			}
 		}
-		if (!split) {
+		if (!split && !fused_dd) {
 			rxgpu_prof_begin_on("fm_disc", sb);
 			RX_K(rxk_fm_disc(sb, d_iq, g->T, 1, 0, g->n, prescaled, g->rotate, 0, s->lp_final, NULL, NULL, NULL, g->M,
-			                 RXK_FIRST_UNIFORM, g->K, p->custom_atan, 0, s->pcm, s->dev, flag_rec, flag_cnt, 0, n_blocks, s->atan_lut, 0, s->flag_all, 0));
+			                 RXK_FIRST_UNIFORM, g->K, p->custom_atan, 0, s->pcm, s->dev, flag_rec, flag_cnt, 0, n_blocks, s->atan_lut, 0, s->flag_all, s->tiled));
 			rxgpu_prof_end_on("fm_disc", sb);
 		}
 	}

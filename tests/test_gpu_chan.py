@@ -181,5 +181,7 @@ def test_channeliser_per_channel_audio_stages(bin_e, n_channels, block_len, n_bl
     assert got.shape == want.shape
     assert np.array_equal(got, want)
     assert np.array_equal(ch.get_carry(), want_pre)
-    assert np.array_equal(ch.get_audio_carry().reshape(n_channels, 3), want_state)
+    state = ch.get_audio_carry().reshape(n_channels, 3)
+    bad = np.argwhere(state != want_state)
+    assert bad.size == 0, "first differing carries (channel, field): %s got %s want %s" % (bad[:5].tolist(), state[bad[:5, 0]].tolist(), want_state[bad[:5, 0]].tolist())
     ch.close()

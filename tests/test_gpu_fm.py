@@ -103,6 +103,8 @@ def test_pipelined_runs(params):
     dict(downsample=20, deemph_a=200),         # serial de-emphasis kernel
     dict(downsample=20, deemph_a=1),
     dict(downsample=20, deemph_a=2),
+    dict(downsample=20, deemph_a=5),           # odd, below the signed 24-bit step's range (needs a >= 9): the generic step
+    dict(downsample=20, deemph_a=7),
     dict(downsample=8, rate_out=48000, rate_out2=48000),
 ])
 def test_stage_switches(params):
