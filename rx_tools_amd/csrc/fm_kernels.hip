@@ -1804,10 +1804,46 @@ __device__ __forceinline__ uint4 fifth_quad_eo(const uint32_t *__restrict__ ev, 
 #define FE2 6
 #define FO2 7
 
-template <int FUSE, bool ROTATE, bool STAGE2>
+// rx_power's stateless fifth_order (rtl_power.c:582-607): no history -- the first five outputs of every buffer and pass
+// come from special ease-in formulas on the pass input's samples 0..8 (k_pw_fifth has them one by one)
+__device__ __forceinline__ uint32_t ease_out(int k, const uint32_t *le, const uint32_t *lo, int fe, int fo)
+{
+	uint32_t s[9];
+#pragma unroll
+	for (int i = 0; i < 9; i++)
+		s[i] = (i & 1) ? lo[i / 2 + fo] : le[i / 2 + fe];
+	int oi, oq;
+#define EASE_K(get, o) do { \
+		const int a = get(s[0]), b_ = get(s[1]), c = get(s[2]), d = get(s[3]), e = get(s[4]), f = get(s[5]); \
+		switch (k) { \
+		case 0: o = ((a + b_) * 10 + (c + d) * 5 + d + f) >> 4; break; \
+		case 1: o = ((b_ + c) * 10 + (a + d) * 5 + e + f) >> 4; break; \
+		case 2: o = (a + (b_ + e) * 5 + (c + d) * 10 + f) >> 4; break; \
+		case 3: o = (c + (d + f) * 5 + (e + f) * 10 + get(s[6])) >> 4; break; \
+		default: o = (e + (f + get(s[7])) * 5 + (f + get(s[6])) * 10 + get(s[8])) >> 4; break; \
+		} } while (0)
+	EASE_K(lo16, oi);
+	EASE_K(hi16, oq);
+#undef EASE_K
+	return pack_iq(oi, oq);
+}
+
+// outputs i .. i+3 of a buffer's first tile: the quad that holds any of outputs 0..4 takes them from the ease-in formulas
+__device__ __forceinline__ void ease_fix(uint4 &o, int i, const uint32_t *le, const uint32_t *lo, int fe, int fo)
+{
+	if (i == 0) {
+		o.x = ease_out(0, le, lo, fe, fo); o.y = ease_out(1, le, lo, fe, fo); o.z = ease_out(2, le, lo, fe, fo); o.w = ease_out(3, le, lo, fe, fo);
+	} else if (i == 4) {
+		o.x = ease_out(4, le, lo, fe, fo);
+	}
+}
+
+// EASE: the buffers are independent and stateless (rx_power): no seams, ease-in at every buffer start; in_stride / out_stride:
+// distance between buffers in samples of the input / of the group's output
+template <int FUSE, bool ROTATE, bool STAGE2, bool EASE>
 __global__ __launch_bounds__(256) void k_fm_fifth_fused(
 	const uint32_t *__restrict__ iq, unsigned n, unsigned tiles_per_block, unsigned tpw, const uint32_t *__restrict__ seams,
-	uint32_t *__restrict__ out)
+	uint32_t *__restrict__ out, unsigned in_stride, unsigned out_stride)
 {
 	__shared__ __attribute__((aligned(16))) uint32_t le0[FF_RAW / 2 + FE0 + 14], lo0[FF_RAW / 2 + FO0 + 13];
 	__shared__ __attribute__((aligned(16))) uint32_t le1[FF_RAW / 4 + FE1 + 14], lo1[FF_RAW / 4 + FO1 + 13];
@@ -1815,8 +1851,9 @@ __global__ __launch_bounds__(256) void k_fm_fifth_fused(
 	const unsigned wgs_per_block = tiles_per_block / tpw;
 	const u64 blk = blockIdx.x / wgs_per_block;
 	const unsigned tile0 = (blockIdx.x % wgs_per_block) * tpw;
-	const uint32_t *braw = iq + blk * (u64)n;
-	const uint32_t *sm = seams + blk * 15;
+	const uint32_t *braw = iq + blk * (u64)in_stride;
+	const uint32_t *sm = EASE ? nullptr : seams + blk * 15;
+	uint32_t *bout = out + blk * (u64)out_stride;
 	const int tid = threadIdx.x;
 	constexpr int NV = (FF_RAW + 36) / 4;                  // 521 vectors of 4 samples: the tile + 36 of left halo
 
@@ -1839,8 +1876,9 @@ __global__ __launch_bounds__(256) void k_fm_fifth_fused(
 			const int v4 = tid + 256 * u;
 			const int rel = 4 * v4 - 36;
 			if (v4 < NV && !(first && rel < 0)) {
-				const uint32_t s0 = leaf<ROTATE, STAGE2>(w[u].x, 0u), s1 = leaf<ROTATE, STAGE2>(w[u].y, 1u);
-				const uint32_t s2 = leaf<ROTATE, STAGE2>(w[u].z, 2u), s3 = leaf<ROTATE, STAGE2>(w[u].w, 3u);
+				uint32_t s0, s1, s2, s3;
+				if (STAGE2) { s0 = w[u].x; s1 = w[u].y; s2 = w[u].z; s3 = w[u].w; }
+				else dec_contrib<false, ROTATE>(w[u], s0, s1, s2, s3);       // the decimator's packed scale + rotate: 24 instructions per 4 samples
 				*reinterpret_cast<uint2 *>(&le0[2 * v4 - 18 + FE0]) = make_uint2(s0, s2);
 				lo0[2 * v4 - 18 + FO0] = s1;
 				lo0[2 * v4 - 17 + FO0] = s3;
@@ -1854,7 +1892,7 @@ __global__ __launch_bounds__(256) void k_fm_fifth_fused(
 				w[u] = v4 < NV ? __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(braw + t0 + FF_RAW + rel)) : (u32x4)(0u);
 			}
 		}
-		if (first && tid == 0) {                           // V0[-5..-1] = O[-3], E[-2], O[-2], E[-1], O[-1]
+		if (!EASE && first && tid == 0) {                  // V0[-5..-1] = O[-3], E[-2], O[-2], E[-1], O[-1]
 			lo0[-3 + FO0] = sm[0]; le0[-2 + FE0] = sm[1]; lo0[-2 + FO0] = sm[2]; le0[-1 + FE0] = sm[3]; lo0[-1 + FO0] = sm[4];
 		}
 		__syncthreads();
@@ -1864,10 +1902,12 @@ __global__ __launch_bounds__(256) void k_fm_fifth_fused(
 			if (first && q < 4)
 				continue;
 			const int i = -16 + 4 * q;
-			const uint4 o = fifth_quad_eo<STAGE2>(&le0[i - 2 + FE0], &lo0[i - 3 + FO0]);
+			uint4 o = fifth_quad_eo<STAGE2>(&le0[i - 2 + FE0], &lo0[i - 3 + FO0]);
+			if (EASE && first)
+				ease_fix(o, i, le0, lo0, FE0, FO0);
 			if (FUSE == 1) {
 				if (i >= 0)                                    // halo outputs belong to the previous tile
-					*reinterpret_cast<uint4 *>(out + blk * (u64)(n >> 1) + t0 / 2 + i) = o;
+					*reinterpret_cast<uint4 *>(bout + t0 / 2 + i) = o;
 			} else {
 				*reinterpret_cast<uint2 *>(&le1[i / 2 + FE1]) = make_uint2(o.x, o.z);
 				lo1[i / 2 + FO1] = o.y;
@@ -1875,7 +1915,7 @@ __global__ __launch_bounds__(256) void k_fm_fifth_fused(
 			}
 		}
 		if (FUSE >= 2) {
-			if (first && tid == 0) {
+			if (!EASE && first && tid == 0) {
 				lo1[-3 + FO1] = sm[5]; le1[-2 + FE1] = sm[6]; lo1[-2 + FO1] = sm[7]; le1[-1 + FE1] = sm[8]; lo1[-1 + FO1] = sm[9];
 			}
 			__syncthreads();
@@ -1884,10 +1924,12 @@ __global__ __launch_bounds__(256) void k_fm_fifth_fused(
 				if (first && q < 2)
 					continue;
 				const int i = -8 + 4 * q;
-				const uint4 o = fifth_quad_eo<STAGE2>(&le1[i - 2 + FE1], &lo1[i - 3 + FO1]);
+				uint4 o = fifth_quad_eo<STAGE2>(&le1[i - 2 + FE1], &lo1[i - 3 + FO1]);
+				if (EASE && first)
+					ease_fix(o, i, le1, lo1, FE1, FO1);
 				if (FUSE == 2) {
 					if (i >= 0)
-						*reinterpret_cast<uint4 *>(out + blk * (u64)(n >> 2) + t0 / 4 + i) = o;
+						*reinterpret_cast<uint4 *>(bout + t0 / 4 + i) = o;
 				} else {
 					*reinterpret_cast<uint2 *>(&le2[i / 2 + FE2]) = make_uint2(o.x, o.z);
 					lo2[i / 2 + FO2] = o.y;
@@ -1896,15 +1938,17 @@ __global__ __launch_bounds__(256) void k_fm_fifth_fused(
 			}
 		}
 		if (FUSE >= 3) {
-			if (first && tid == 0) {
+			if (!EASE && first && tid == 0) {
 				lo2[-3 + FO2] = sm[10]; le2[-2 + FE2] = sm[11]; lo2[-2 + FO2] = sm[12]; le2[-1 + FE2] = sm[13]; lo2[-1 + FO2] = sm[14];
 			}
 			__syncthreads();
 			// pass 2: outputs V3[i..i+3], i = 4q
 			if (tid < FF_RAW / 32) {
 				const int i = 4 * tid;
-				const uint4 o = fifth_quad_eo<STAGE2>(&le2[i - 2 + FE2], &lo2[i - 3 + FO2]);
-				*reinterpret_cast<uint4 *>(out + blk * (u64)(n >> 3) + t0 / 8 + i) = o;
+				uint4 o = fifth_quad_eo<STAGE2>(&le2[i - 2 + FE2], &lo2[i - 3 + FO2]);
+				if (EASE && first)
+					ease_fix(o, i, le2, lo2, FE2, FO2);
+				*reinterpret_cast<uint4 *>(bout + t0 / 8 + i) = o;
 			}
 		}
 		if (FUSE == 1)
@@ -2760,7 +2804,7 @@ extern "C" int rxk_fm_fifth_fused(void *stream, const void *in, int stage2, int 
 	const unsigned grid = (unsigned)(n_blocks * (tiles / tpw));
 	const uint32_t *p = (const uint32_t *)in;
 #define SEAMS(RT, S2) hipLaunchKernelGGL((k_fm_fifth_seams<RT, S2>), dim3(sgrid), dim3(256), 0, s, p, n_blocks, n, fuse, hist_in, seams, hist_out)
-#define FUSED(F, RT, S2) hipLaunchKernelGGL((k_fm_fifth_fused<F, RT, S2>), dim3(grid), dim3(256), 0, s, p, n, tiles, tpw, seams, out)
+#define FUSED(F, RT, S2) hipLaunchKernelGGL((k_fm_fifth_fused<F, RT, S2, false>), dim3(grid), dim3(256), 0, s, p, n, tiles, tpw, seams, out, n, n >> F)
 #define GO(RT, S2) do { SEAMS(RT, S2); if (fuse == 1) FUSED(1, RT, S2); else if (fuse == 2) FUSED(2, RT, S2); else FUSED(3, RT, S2); } while (0)
 	if (stage2) GO(false, true);
 	else if (rotate) GO(true, false);
@@ -2876,5 +2920,22 @@ extern "C" int rxk_fm_droop_disc(void *stream, const uint32_t *in, u64 M, const 
 	else
 		hipLaunchKernelGGL((k_fm_droop_disc<false>), dim3(grid), dim3(256), 0, s, in, M, fir, hist_in, hist_out, lp_out, uniform_k, pcm, pcm_chl2, dev,
 		                   flag_list, flag_cnt, flag_all);
+	LAUNCH_RET();
+}
+
+// rx_power's downsample_iq (rtl_power.c:656-662): `fuse` (1..3) stateless fifth_order passes over n_bufs independent buffers of n
+// complex samples (n % RXK_FIFTH_TILE == 0) in one LDS-tiled launch; strides in complex samples
+extern "C" int rxk_pw_fifth_fused(void *stream, const int16_t *in, unsigned long long n_bufs, unsigned n, unsigned in_stride, int fuse,
+                                  int16_t *out, unsigned out_stride)
+{
+	hipStream_t s = (hipStream_t)stream;
+	const unsigned tiles = n / FF_RAW;
+	const unsigned tpw = tiles % 8 == 0 ? 8 : tiles % 4 == 0 ? 4 : tiles % 2 == 0 ? 2 : 1;
+	const unsigned grid = (unsigned)(n_bufs * (tiles / tpw));
+	const uint32_t *p = (const uint32_t *)in;
+	uint32_t *o = (uint32_t *)out;
+#define FUSED(F) hipLaunchKernelGGL((k_fm_fifth_fused<F, false, true, true>), dim3(grid), dim3(256), 0, s, p, n, tiles, tpw, nullptr, o, in_stride, out_stride)
+	if (fuse == 1) FUSED(1); else if (fuse == 2) FUSED(2); else FUSED(3);
+#undef FUSED
 	LAUNCH_RET();
 }

@@ -209,10 +209,17 @@ int rxk_pw_fft(void *stream, const int16_t *in, size_t tune_stride, size_t pass_
 int rxk_pw_samples(void *stream, int *samples, int tunes, int add);
 /* P2 boxcar (rtl_power.c:723-733): every buffer of buf_len int16 -> same-size buffer whose
  * complex slot k holds the wrapped sum of samples [k*ds,(k+1)*ds), zero elsewhere */
-int rxk_pw_boxcar(void *stream, const int16_t *in, int16_t *out, size_t n_bufs, int buf_len, int ds);
+int rxk_pw_boxcar(void *stream, const int16_t *in, int16_t *out, size_t n_bufs, int buf_len, int ds, int n_write);
+/* P2 through rxk_fm_decimate (prescaled, no rotation) when buffers hold whole windows: finish the per-span seam entries */
+int rxk_pw_boxcar_seams(void *stream, uint32_t *lp, const uint32_t *head, const uint32_t *tail, unsigned long long T, int ds);
+/* n_write: complex slots per buffer actually produced (what the transform will read); <= 0: all of them */
 /* P3 one stateless fifth_order pass on I and Q (rtl_power.c:582-607, 656-662): n_in complex
  * samples per buffer -> ceil(n_in/2); strides in complex samples */
 int rxk_pw_fifth(void *stream, const int16_t *in, int16_t *out, size_t n_bufs, int n_in, int in_stride, int out_stride);
+/* `fuse` (1..3) of those passes in one LDS-tiled launch (the rx_fm cascade kernel with ease-in instead of carried history);
+ * n % RXK_FIFTH_TILE == 0 */
+int rxk_pw_fifth_fused(void *stream, const int16_t *in, unsigned long long n_bufs, unsigned n, unsigned in_stride, int fuse,
+                       int16_t *out, unsigned out_stride);
 /* generic_fir (rtl_power.c:626-654) over n complex samples per buffer */
 int rxk_pw_droop(void *stream, const int16_t *in, int16_t *out, size_t n_bufs, int n, int stride, const int *fir);
 /* P9 rms_power sums: t[b] = sum s, p[b] = sum s^2 (int64, exact) per buffer, then the fp64

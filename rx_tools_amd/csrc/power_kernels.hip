@@ -279,7 +279,8 @@ __global__ __launch_bounds__(((1 << M) / 16 > 256) ? (1 << M) / 16 : 256) void k
 	const unsigned tq = tid % TPF;
 	const int tune = blockIdx.x;
 	const int p_begin = blockIdx.y * ppg, p_end = min(passes, p_begin + ppg);
-	constexpr bool WREG = M <= 12;                         // 1024-thread workgroups are capped at 128 VGPRs: reload instead
+	constexpr bool WREG = M <= 12;                         // 512- and 1024-thread workgroups are short of VGPRs: reload instead
+	constexpr bool ACCREG = M <= 13;                       // (a 1024-thread build would have no room for 16 int64 accumulators)
 	uint32_t wcoef[WREG ? 16 : 1];
 	if (WREG) {
 #pragma unroll
@@ -288,10 +289,11 @@ __global__ __launch_bounds__(((1 << M) / 16 > 256) ? (1 << M) / 16 : 256) void k
 			wcoef[r] = c | (c << 16);
 		}
 	}
-	i64 acc[16];
+	i64 acc[ACCREG ? 16 : 1];
 #pragma unroll
-	for (int r = 0; r < 16; r++)
+	for (int r = 0; r < (ACCREG ? 16 : 1); r++)
 		acc[r] = 0;
+	i64 *avg_t = avg + (size_t)tune * N;
 	const int total = nb_total * N;                        // complex samples of the tune buffer that take part
 
 	for (int pass = p_begin; pass < p_end; pass++) {
@@ -333,17 +335,24 @@ __global__ __launch_bounds__(((1 << M) / 16 > 256) ? (1 << M) / 16 : 256) void k
 #pragma unroll
 				for (int r = 0; r < 16; r++) {
 					const i64 pw = (i64)pw_norm(v[r]);
-					acc[r] = PEAK ? (pw > acc[r] ? pw : acc[r]) : acc[r] + pw;
+					if (ACCREG) {
+						acc[r] = PEAK ? (pw > acc[r] ? pw : acc[r]) : acc[r] + pw;
+					} else {
+						const unsigned bin = __brev((tq << 4) | (unsigned)r) >> (32 - M);
+						if (PEAK) atomicMax((long long *)&avg_t[bin], pw);
+						else if (pw) atomicAdd((unsigned long long *)&avg_t[bin], (unsigned long long)pw);
+					}
 				}
 			}
 		}
 	}
-	i64 *avg_t = avg + (size_t)tune * N;
+	if (ACCREG) {
 #pragma unroll
-	for (int r = 0; r < 16; r++) {
-		const unsigned bin = __brev((tq << 4) | (unsigned)r) >> (32 - M);
-		if (PEAK) atomicMax((long long *)&avg_t[bin], acc[r]);
-		else if (acc[r]) atomicAdd((unsigned long long *)&avg_t[bin], (unsigned long long)acc[r]);
+		for (int r = 0; r < 16; r++) {
+			const unsigned bin = __brev((tq << 4) | (unsigned)r) >> (32 - M);
+			if (PEAK) atomicMax((long long *)&avg_t[bin], acc[r]);
+			else if (acc[r]) atomicAdd((unsigned long long *)&avg_t[bin], (unsigned long long)acc[r]);
+		}
 	}
 }
 
@@ -359,13 +368,15 @@ __global__ void k_pw_samples(int *samples, int tunes, int add)
 // rtl_power.c:723-733.  In-place on the reference: slot k (int16 2k,2k+1) ends up holding the
 // int16-wrapped sum of complex samples [k*ds, (k+1)*ds) that exist, every other position of
 // the buffer is left zero.
-__global__ void k_pw_boxcar(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t n_bufs, int n_complex, int ds)
+// Only the first n_write slots of every buffer are produced: the transform reads eff_len / 2 of them (rounded up to whole FFT
+// blocks), the rest of the reference's zero-filled tail is never looked at again -- writing it cost as much as reading the input.
+__global__ void k_pw_boxcar(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t n_bufs, int n_complex, int ds, int n_write)
 {
 	const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (gid >= n_bufs * (u64)n_complex)
+	if (gid >= n_bufs * (u64)n_write)
 		return;
-	const u64 b = gid / (unsigned)n_complex;
-	const int k = (int)(gid - b * (unsigned)n_complex);
+	const u64 b = gid / (unsigned)n_write;
+	const int k = (int)(gid - b * (unsigned)n_write);
 	const uint32_t *src = in + b * (u64)n_complex;
 	int si = 0, sq = 0;
 	const i64 first = (i64)k * ds;
@@ -378,6 +389,28 @@ __global__ void k_pw_boxcar(const uint32_t *__restrict__ in, uint32_t *__restric
 		}
 	}
 	out[b * (u64)n_complex + k] = pw_pack(si, sq);
+}
+
+// When every buffer holds a whole number of boxcar windows, P2 over the concatenated buffers IS rx_fm's low_pass without
+// scale and rotation: the fast decimator of fm_kernels.hip (coalesced 16-byte loads, wave prefix scan) does the sums at
+// HBM rate and leaves the first window ending in each of its spans in head/tail form; this finishes those.
+__global__ void k_pw_boxcar_seams(uint32_t *__restrict__ lp, const uint32_t *__restrict__ head, const uint32_t *__restrict__ tail,
+                                  u64 n_spans, u64 M, int ds)
+{
+	const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= n_spans)
+		return;
+	const u64 m = (g << RXK_DEC_SPAN_LOG2) / (u64)ds;          // windows completed before the span = the first one ending in it
+	if (m < M)
+		lp[m] = pw_pk_add(g ? tail[g - 1] : 0u, head[g]);
+}
+
+extern "C" int rxk_pw_boxcar_seams(void *stream, uint32_t *lp, const uint32_t *head, const uint32_t *tail, unsigned long long T, int ds)
+{
+	const u64 n_spans = (T + RXK_DEC_SPAN - 1) / RXK_DEC_SPAN;
+	hipLaunchKernelGGL(k_pw_boxcar_seams, dim3((unsigned)((n_spans + 255) / 256)), dim3(256), 0, (hipStream_t)stream, lp, head, tail,
+	                   n_spans, T / (u64)ds, ds);
+	return (int)hipGetLastError();
 }
 
 // ------------------------------------------------------------------ P3 fifth_order (stateless)
@@ -635,8 +668,9 @@ extern "C" int rxk_pw_fft(void *stream, const int16_t *in, size_t tune_stride, s
 #undef GO4K
 		LAUNCH_RET();
 	}
-	if (bin_e >= 8 && bin_e <= 13 && eff_len % (2 * n) == 0) {
-		/* register-blocked kernel for every power of two from 256 to 8192 (16384 would spill at 1024 threads) */
+	if (bin_e >= 8 && bin_e <= 13 && eff_len % (2 * n) == 0 && !getenv("RXGPU_FFT_GENERIC")) {
+		/* register-blocked kernel for every power of two from 256 to 8192.  2^14 was tried (round 2): N/16 = 1024 threads leave 128
+		 * VGPRs per lane, the transform wants ~200, and the spilling build ran 3.3x slower than the LDS radix-2 kernel below */
 		const int nb_total = eff_len / (2 * n);
 		const int T = (n / 16 > 256) ? n / 16 : 256;
 		const size_t lds_bytes = (size_t)(bin_e <= 12 ? 2 : 1) * T * 20 * 4 + 32 * 8;
@@ -673,12 +707,14 @@ extern "C" int rxk_pw_samples(void *stream, int *samples, int tunes, int add)
 	LAUNCH_RET();
 }
 
-extern "C" int rxk_pw_boxcar(void *stream, const int16_t *in, int16_t *out, size_t n_bufs, int buf_len, int ds)
+extern "C" int rxk_pw_boxcar(void *stream, const int16_t *in, int16_t *out, size_t n_bufs, int buf_len, int ds, int n_write)
 {
 	const int nc = buf_len / 2;
-	const u64 total = (u64)n_bufs * nc;
+	if (n_write > nc || n_write <= 0)
+		n_write = nc;
+	const u64 total = (u64)n_bufs * n_write;
 	hipLaunchKernelGGL(k_pw_boxcar, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-	                   (const uint32_t *)in, (uint32_t *)out, n_bufs, nc, ds);
+	                   (const uint32_t *)in, (uint32_t *)out, n_bufs, nc, ds, n_write);
 	LAUNCH_RET();
 }
 

@@ -180,6 +180,8 @@ struct rxgpu_power_scan {
 	int *fir_dev;
 	int16_t *work[2];
 	size_t work_cap;
+	uint32_t *bx_head, *bx_tail;  /* boxcar through the rx_fm decimator: per-span seam partials */
+	size_t bx_cap;
 	long long *rms_t, *rms_p;
 	size_t rms_cap;
 	uint32_t *big_scratch;     /* N > 2^15: FFT blocks in HBM */
@@ -270,6 +272,7 @@ void rxgpu_power_scan_destroy(rxgpu_power_scan *s)
 		return;
 	hipFree(s->window_dev); hipFree(s->twiddle_dev); hipFree(s->fir_dev);
 	hipFree(s->work[0]); hipFree(s->work[1]);
+	hipFree(s->bx_head); hipFree(s->bx_tail);
 	hipFree(s->big_scratch); hipFree(s->big_dc);
 	hipFree(s->rms_t); hipFree(s->rms_p);
 	free(s);
@@ -302,6 +305,7 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 
 	const int16_t *fft_in = d_in;
 	int eff_len = buf_len;
+	size_t fft_tune_stride = (size_t)buf_len, fft_pass_stride = (size_t)tunes * (size_t)buf_len;
 	if (ds > 1 && (p->boxcar || ds_p)) {
 		const size_t need = n_bufs * (size_t)buf_len * 2;
 		if (s->work_cap < need) {
@@ -313,16 +317,48 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 		}
 		rxgpu_prof_begin("pw_downsample");
 		if (p->boxcar) {                                   /* rtl_power.c:723-733 */
-			RX_K(rxk_pw_boxcar(st, d_in, s->work[0], n_bufs, buf_len, ds));
+			/* slots the transform reads: eff_len / 2 rounded up to whole FFT blocks (rms_power never comes here) */
+			const int n_fft = 1 << p->bin_e, eff = buf_len / ds;
+			const int n_read = (eff + 2 * n_fft - 1) / (2 * n_fft) * n_fft;
+			const unsigned long long nc = (unsigned long long)buf_len / 2, T = (unsigned long long)n_bufs * nc;
+			if (ds >= 4 && ds <= RXK_DEC_MAX_DS && nc % (unsigned long long)ds == 0 && T % 4 == 0 && !getenv("RXGPU_BOXCAR_PLAIN")) {
+				/* whole windows per buffer: the sums over the concatenated buffers are low_pass (rtl_fm.c:351-371) on an already
+				 * scaled, unrotated stream -- the rx_fm decimator, then its per-span seam entries; output compact, eff_len per buffer */
+				const size_t n_spans = (size_t)((T + RXK_DEC_SPAN - 1) / RXK_DEC_SPAN) + 1;
+				if (s->bx_cap < n_spans) {
+					hipFree(s->bx_head); hipFree(s->bx_tail);
+					s->bx_head = s->bx_tail = NULL; s->bx_cap = 0;
+					RX_HIP(hipMalloc((void **)&s->bx_head, n_spans * 4));
+					RX_HIP(hipMalloc((void **)&s->bx_tail, n_spans * 4));
+					s->bx_cap = n_spans;
+				}
+				RX_K(rxk_fm_decimate(st, d_in, T, ds, 0, 1, 0, (uint32_t *)s->work[0], s->bx_head, s->bx_tail, 0, NULL, 0));
+				RX_K(rxk_pw_boxcar_seams(st, (uint32_t *)s->work[0], s->bx_head, s->bx_tail, T, ds));
+				fft_tune_stride = (size_t)eff;
+				fft_pass_stride = (size_t)tunes * (size_t)eff;
+			} else {
+				RX_K(rxk_pw_boxcar(st, d_in, s->work[0], n_bufs, buf_len, ds, n_read));
+			}
 			fft_in = s->work[0];
 		} else {                                           /* rtl_power.c:734-743 */
 			const int16_t *src = d_in;
 			int n_in = buf_len / 2, which = 0;
-			for (int j = 0; j < ds_p; j++) {
-				RX_K(rxk_pw_fifth(st, src, s->work[which], n_bufs, n_in, buf_len / 2, buf_len / 2));
+			for (int j = 0; j < ds_p;) {
+				/* up to three passes per launch while the pass input is whole tiles; otherwise one pass at a time */
+				int fuse = ds_p - j < 3 ? ds_p - j : 3;
+				while (fuse > 0 && (n_in % RXK_FIFTH_TILE || getenv("RXGPU_FIFTH_PLAIN")))
+					fuse = 0;
+				if (fuse) {
+					RX_K(rxk_pw_fifth_fused(st, src, n_bufs, (unsigned)n_in, (unsigned)(buf_len / 2), fuse, s->work[which], (unsigned)(buf_len / 2)));
+					n_in >>= fuse;
+					j += fuse;
+				} else {
+					RX_K(rxk_pw_fifth(st, src, s->work[which], n_bufs, n_in, buf_len / 2, buf_len / 2));
+					n_in = (n_in + 1) / 2;
+					j++;
+				}
 				src = s->work[which];
 				which ^= 1;
-				n_in = (n_in + 1) / 2;
 			}
 			if (p->comp_fir_size == 9 && ds_p <= 10) {
 				RX_K(rxk_pw_droop(st, src, s->work[which], n_bufs, (buf_len >> ds_p) / 2, buf_len / 2, s->fir_dev));
@@ -358,10 +394,10 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 			RX_HIP(hipMalloc((void **)&s->big_dc, (size_t)passes * (size_t)tunes * 8));
 			s->big_dc_cap = (size_t)passes * (size_t)tunes;
 		}
-		RX_K(rxk_pw_fft_big(st, fft_in, (size_t)buf_len, (size_t)tunes * (size_t)buf_len, passes, tunes, p->bin_e, eff_len,
+		RX_K(rxk_pw_fft_big(st, fft_in, fft_tune_stride, fft_pass_stride, passes, tunes, p->bin_e, eff_len,
 		                    s->window_dev, s->twiddle_dev, p->peak_hold, s->big_scratch, s->big_cap_blocks, s->big_dc, (long long *)d_avg));
 	} else {
-		RX_K(rxk_pw_fft(st, fft_in, (size_t)buf_len, (size_t)tunes * (size_t)buf_len, passes, tunes, p->bin_e, eff_len, eff_len,
+		RX_K(rxk_pw_fft(st, fft_in, fft_tune_stride, fft_pass_stride, passes, tunes, p->bin_e, eff_len, eff_len,
 		                s->window_dev, s->twiddle_dev, p->peak_hold, ppg, (long long *)d_avg));
 	}
 	rxgpu_prof_end("pw_fft");

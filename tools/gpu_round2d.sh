@@ -1,9 +1,9 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r2c
+O=$R/gpurun_out/r2d
 mkdir -p $O
 cd $R
-for f in test_gpu_fm test_gpu_chan test_gpu_dropin test_gpu_golden; do
+for f in test_gpu_fm test_gpu_chan test_gpu_dropin test_gpu_golden test_dropin_e2e; do
   timeout 900 python -u -m pytest tests/$f.py -m gpu -q -x -p no:cacheprovider --timeout 600 > $O/$f.log 2>&1
   echo "$f rc=$? $(tail -1 $O/$f.log)"
 done
@@ -12,7 +12,7 @@ timeout 600 python bench.py --steps 10 --warmup 3 --workload rx_fm --cpu-seconds
 echo bench rc=$?
 python - <<'P'
 import json
-d=json.load(open('gpurun_out/r2c/bench_fm.json'))
+d=json.load(open('gpurun_out/r2d/bench_fm.json'))
 print('headline', round(d['value']/1e6,3), 'TS/s dec frac', round(d['roofline']['frac'],3), 'ms', round(d['roofline']['avg_launch_ms'],3))
 for k,v in d['rx_fm_variants'].items(): print(k[:40], round(v['value']/1e6,3), v['stage_us_per_step'])
 P
