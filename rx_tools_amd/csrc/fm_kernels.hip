@@ -110,11 +110,23 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // two cs16 components through F0 (scale_cs16) with the signs of rotate16_90 folded in -- trunc(-r) == -trunc(r) --
 // packed as int16 pair (lo from a, hi from b): v_cvt_f32_i32 (SDWA) x2, one v_pk_fma_f32, v_cvt_i32_f32 x2, v_cvt_pk_i16_i32
+// the two constant pairs of the scale live in VGPRs for the whole kernel (made opaque once by scale_consts: left as literals the
+// compiler rebuilds both pairs -- two v_mov_b64 and four s_mov -- in front of every tile)
+struct scale_k { f32x2 cc, hh; };
+__device__ __forceinline__ scale_k scale_consts()
+{
+	scale_k k;
+	k.cc = (f32x2){(float)(128.0 / 32767.0), (float)(128.0 / 32767.0)};
+	k.hh = (f32x2){0.4f, 0.4f};
+	asm volatile("" : "+v"(k.cc), "+v"(k.hh));
+	return k;
+}
+
 template <int SA, int SB>
-__device__ __forceinline__ uint32_t scale_pk(int a, int b)
+__device__ __forceinline__ uint32_t scale_pk(int a, int b, const scale_k &K)
 {
 	const f32x2 x = {(float)a, (float)b};
-	const f32x2 cc = {(float)(128.0 / 32767.0), (float)(128.0 / 32767.0)}, hh = {0.4f, 0.4f};
+	const f32x2 cc = K.cc, hh = K.hh;
 	f32x2 r;
 	// the sign pairs are source modifiers of the one constant pair (the compiler would materialise four)
 	if (SA > 0 && SB > 0)
@@ -131,18 +143,18 @@ __device__ __forceinline__ uint32_t scale_pk(int a, int b)
 // a lane's four samples as packed (I,Q) contributions to the running sums: rotate16_90 (rtl_fm.c:309-327) multiplies
 // sample n of the block by j^n, and a lane's samples sit at phases 0..3
 template <bool PRESCALED, bool ROTATE>
-__device__ __forceinline__ void dec_contrib(const u32x4 v, uint32_t &s0, uint32_t &s1, uint32_t &s2, uint32_t &s3)
+__device__ __forceinline__ void dec_contrib(const u32x4 v, uint32_t &s0, uint32_t &s1, uint32_t &s2, uint32_t &s3, const scale_k &K)
 {
 	if (!PRESCALED) {
-		s0 = scale_pk<1, 1>(lo16(v.x), hi16(v.x));
+		s0 = scale_pk<1, 1>(lo16(v.x), hi16(v.x), K);
 		if (ROTATE) {
-			s1 = scale_pk<-1, 1>(hi16(v.y), lo16(v.y));            // (-q1,  i1)
-			s2 = scale_pk<-1, -1>(lo16(v.z), hi16(v.z));           // (-i2, -q2)
-			s3 = scale_pk<1, -1>(hi16(v.w), lo16(v.w));            // ( q3, -i3)
+			s1 = scale_pk<-1, 1>(hi16(v.y), lo16(v.y), K);         // (-q1,  i1)
+			s2 = scale_pk<-1, -1>(lo16(v.z), hi16(v.z), K);        // (-i2, -q2)
+			s3 = scale_pk<1, -1>(hi16(v.w), lo16(v.w), K);         // ( q3, -i3)
 		} else {
-			s1 = scale_pk<1, 1>(lo16(v.y), hi16(v.y));
-			s2 = scale_pk<1, 1>(lo16(v.z), hi16(v.z));
-			s3 = scale_pk<1, 1>(lo16(v.w), hi16(v.w));
+			s1 = scale_pk<1, 1>(lo16(v.y), hi16(v.y), K);
+			s2 = scale_pk<1, 1>(lo16(v.z), hi16(v.z), K);
+			s3 = scale_pk<1, 1>(lo16(v.w), hi16(v.w), K);
 		}
 	} else {
 		s0 = v.x;
@@ -207,6 +219,8 @@ __global__ __launch_bounds__(DEC_THREADS) void k_fm_decimate(
 
 	uint32_t run = 0;                                       // wave-uniform running prefix
 	const uint32_t unbias = 511u * (lane + 1);              // what the biased scan added to this lane's I prefix (< 2^16)
+	const scale_k K = scale_consts();
+	const unsigned dummy = slot_cap - 1;                    // where lanes without a window end put their (unused) prefix
 #pragma unroll
 	for (int half = 0; half < DEC_TILES / DEC_BATCH; half++) {      // DEC_BATCH loads in flight per lane
 		u32x4 v[DEC_BATCH];
@@ -219,7 +233,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_fm_decimate(
 		for (int u = 0; u < DEC_BATCH; u++) {
 			const unsigned rel = wave * DEC_WAVE_SPAN + (half * DEC_BATCH + u) * DEC_TILE + lane * 4;
 			uint32_t s0, s1, s2, s3;
-			dec_contrib<PRESCALED, ROTATE>(v[u], s0, s1, s2, s3);
+			dec_contrib<PRESCALED, ROTATE>(v[u], s0, s1, s2, s3, K);
 			const uint32_t c1 = s0, c2 = pk_add(c1, s1), c3 = pk_add(c2, s2), c4 = pk_add(c3, s3);
 			uint32_t incl;
 			if (!PRESCALED)
@@ -238,10 +252,11 @@ __global__ __launch_bounds__(DEC_THREADS) void k_fm_decimate(
 				k = __umulhi(qn, magic);
 				cnt = (int)(k * (unsigned)ds + 4u - qn);
 			}
-			if (cnt > 0 && rel < span) {                    // cnt = 1..4 samples of this lane belong to window k-1
-				const uint32_t sel = cnt == 1 ? c1 : cnt == 2 ? c2 : cnt == 3 ? c3 : c4;
-				slot[k - 1] = pk_add(pk_add(run, pk_sub(incl, c4)), sel);
-			}
+			// cnt = 1..4 samples of this lane belong to window k-1: the prefix up to there goes to its slot.  No branch: every lane
+			// stores (the others into one spare slot), so that the tiles of a batch form one basic block
+			const bool hit = cnt > 0 && rel < span;
+			const uint32_t sel = cnt <= 1 ? c1 : cnt == 2 ? c2 : cnt == 3 ? c3 : c4;
+			slot[hit ? k - 1 : dummy] = pk_add(pk_add(run, pk_sub(incl, c4)), sel);
 			run = pk_add(run, (uint32_t)__builtin_amdgcn_readlane((int)incl, 63));
 		}
 	}
@@ -1279,23 +1294,42 @@ __global__ __launch_bounds__(256) void k_fm_deemph_scan_t(
 	const u64 c0 = c << CHL2;
 	const int n = (int)((M - c0) < (u64)CH ? (M - c0) : (u64)CH);
 	const int h = a / 2;
+	const uint4 *row = tile_unit(pcm_t, c, CHL2);
+	// four units (64 bytes per lane, 4 KiB per wave) in flight: the walk is a dependent chain, the loads must not be
+	uint4 cur[4];
+#pragma unroll
+	for (int j = 0; j < 4; j++)
+		cur[j] = row[(size_t)j * 64];                         // UPC >= 16
 	int lo, hi;
 	if (c == 0) {                                             // the run's carried state
 		lo = hi = dev->in_deemph_avg;
 	} else {
-		const uint4 *row = tile_unit(pcm_t, c - 1, CHL2);
+		const uint4 *prow = tile_unit(pcm_t, c - 1, CHL2);
 		int nl = de_state(lo0, h), nh = de_state(hi0, h);
 		const int u0 = (CH - warm) >> 3;
-		uint4 w = row[(size_t)u0 * 64];
-		for (int u = u0; u < UPC; u++) {
-			const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-			if (u + 1 < UPC)
-				w = row[(size_t)(u + 1) * 64];
+		uint4 wq[4];
 #pragma unroll
-			for (int k = 0; k < 4; k++) {
-				de_step<0>(ww[k], nl, magic, -64); de_step<0>(ww[k], nh, magic, -64);
-				de_step<1>(ww[k], nl, magic, -64); de_step<1>(ww[k], nh, magic, -64);
+		for (int j = 0; j < 4; j++)
+			wq[j] = prow[(size_t)min(u0 + j, UPC - 1) * 64];
+		for (int ub = u0; ub < UPC; ub += 4) {
+			uint4 nx[4];
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+				nx[j] = prow[(size_t)min(ub + 4 + j, UPC - 1) * 64];
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				if (ub + j < UPC) {
+					const uint32_t ww[4] = {wq[j].x, wq[j].y, wq[j].z, wq[j].w};
+#pragma unroll
+					for (int k = 0; k < 4; k++) {
+						de_step<0>(ww[k], nl, magic, -64); de_step<0>(ww[k], nh, magic, -64);
+						de_step<1>(ww[k], nl, magic, -64); de_step<1>(ww[k], nh, magic, -64);
+					}
+				}
 			}
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+				wq[j] = nx[j];
 		}
 		lo = de_avg(nl, h);
 		hi = de_avg(nh, h);
@@ -1308,24 +1342,33 @@ __global__ __launch_bounds__(256) void k_fm_deemph_scan_t(
 	typedef typename deemph_mask<GS>::type MASK;
 	const int lo_start = lo;
 	MASK mask = (MASK)(((MASK)1 << gap) - 1);
-	const uint4 *row = tile_unit(pcm_t, c, CHL2);
 	int N = de_state(lo, h), cm6 = gap << 6;                  // r6 < cm6  <=>  remainder + 1 < number of distinct candidates
 	const int na6 = -(a << 6);
 	const int nu = n >> 3;
-	uint4 w = row[0];
-	for (int u = 0; u < nu; u++) {
-		const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-		if (u + 1 < UPC)
-			w = row[(size_t)(u + 1) * 64];                    // the next unit (or the ragged one) while this one is walked
+	for (int ub = 0; ub < nu; ub += 4) {
+		uint4 nx[4];
 #pragma unroll
-		for (int k = 0; k < 4; k++) {
-			int r6 = de_step_r<0>(ww[k], N, magic, -64, na6);
-			if (__builtin_expect(r6 < cm6, 0)) { de_merge(mask, r6 >> 6); cm6 -= 64; }
-			r6 = de_step_r<1>(ww[k], N, magic, -64, na6);
-			if (__builtin_expect(r6 < cm6, 0)) { de_merge(mask, r6 >> 6); cm6 -= 64; }
+		for (int j = 0; j < 4; j++)
+			nx[j] = row[(size_t)min(ub + 4 + j, UPC - 1) * 64];
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			if (ub + j < nu) {
+				const uint32_t ww[4] = {cur[j].x, cur[j].y, cur[j].z, cur[j].w};
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					int r6 = de_step_r<0>(ww[k], N, magic, -64, na6);
+					if (__builtin_expect(r6 < cm6, 0)) { de_merge(mask, r6 >> 6); cm6 -= 64; }
+					r6 = de_step_r<1>(ww[k], N, magic, -64, na6);
+					if (__builtin_expect(r6 < cm6, 0)) { de_merge(mask, r6 >> 6); cm6 -= 64; }
+				}
+			}
 		}
+#pragma unroll
+		for (int j = 0; j < 4; j++)
+			cur[j] = nx[j];
 	}
-	if (n & 7) {                                              // the ragged end of the run
+	if (n & 7) {                                              // the ragged end of the run: unit nu
+		const uint4 w = row[(size_t)nu * 64];
 		const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
 		for (int k = 0; k < (n & 7); k++) {
 			const int r6 = (k & 1) ? de_step_r<1>(ww[k >> 1], N, magic, -64, na6) : de_step_r<0>(ww[k >> 1], N, magic, -64, na6);
@@ -1855,6 +1898,7 @@ __global__ __launch_bounds__(256) void k_fm_fifth_fused(
 	const uint32_t *sm = EASE ? nullptr : seams + blk * 15;
 	uint32_t *bout = out + blk * (u64)out_stride;
 	const int tid = threadIdx.x;
+	const scale_k K = scale_consts();
 	constexpr int NV = (FF_RAW + 36) / 4;                  // 521 vectors of 4 samples: the tile + 36 of left halo
 
 	// a workgroup walks `tpw` consecutive tiles; the next tile's samples are in flight while this one is computed
@@ -1878,7 +1922,7 @@ __global__ __launch_bounds__(256) void k_fm_fifth_fused(
 			if (v4 < NV && !(first && rel < 0)) {
 				uint32_t s0, s1, s2, s3;
 				if (STAGE2) { s0 = w[u].x; s1 = w[u].y; s2 = w[u].z; s3 = w[u].w; }
-				else dec_contrib<false, ROTATE>(w[u], s0, s1, s2, s3);       // the decimator's packed scale + rotate: 24 instructions per 4 samples
+				else dec_contrib<false, ROTATE>(w[u], s0, s1, s2, s3, K);    // the decimator's packed scale + rotate: 24 instructions per 4 samples
 				*reinterpret_cast<uint2 *>(&le0[2 * v4 - 18 + FE0]) = make_uint2(s0, s2);
 				lo0[2 * v4 - 18 + FO0] = s1;
 				lo0[2 * v4 - 17 + FO0] = s3;
@@ -1978,9 +2022,11 @@ __global__ void k_fm_droop(const uint32_t *__restrict__ in, u64 M, const int *__
 			hq[j] = hist_in[9 + 9 + idx];
 		}
 	}
+	// sums of two int16 times cic_9_tables coefficients (|f| < 2^17): both fit 24 bits, the full-rate 24-bit multiply keeps the low
+	// 32 bits of the product -- the reference's wrapping int arithmetic
 	const int f1 = fir[1], f2 = fir[2], f3 = fir[3], f4 = fir[4], f5 = fir[5];
-	const int si = (hi[0] + hi[8]) * f1 + (hi[1] + hi[7]) * f2 + (hi[2] + hi[6]) * f3 + (hi[3] + hi[5]) * f4 + hi[4] * f5;
-	const int sq = (hq[0] + hq[8]) * f1 + (hq[1] + hq[7]) * f2 + (hq[2] + hq[6]) * f3 + (hq[3] + hq[5]) * f4 + hq[4] * f5;
+	const int si = __mul24(hi[0] + hi[8], f1) + __mul24(hi[1] + hi[7], f2) + __mul24(hi[2] + hi[6], f3) + __mul24(hi[3] + hi[5], f4) + __mul24(hi[4], f5);
+	const int sq = __mul24(hq[0] + hq[8], f1) + __mul24(hq[1] + hq[7], f2) + __mul24(hq[2] + hq[6], f3) + __mul24(hq[3] + hq[5], f4) + __mul24(hq[4], f5);
 	out[t] = pack_iq(si >> 15, sq >> 15);
 	if (t == M - 1) {
 		// new history = the last 9 INPUT samples s[M-9 .. M-1]
@@ -2036,10 +2082,11 @@ __global__ __launch_bounds__(256) void k_fm_droop_disc(
 #pragma unroll
 	for (int r = 0; r < 5; r++) {
 		const int b = r + 2;
-		const int si = (lo16(sv[b]) + lo16(sv[b + 8])) * f1 + (lo16(sv[b + 1]) + lo16(sv[b + 7])) * f2 + (lo16(sv[b + 2]) + lo16(sv[b + 6])) * f3 +
-		               (lo16(sv[b + 3]) + lo16(sv[b + 5])) * f4 + lo16(sv[b + 4]) * f5;
-		const int sq = (hi16(sv[b]) + hi16(sv[b + 8])) * f1 + (hi16(sv[b + 1]) + hi16(sv[b + 7])) * f2 + (hi16(sv[b + 2]) + hi16(sv[b + 6])) * f3 +
-		               (hi16(sv[b + 3]) + hi16(sv[b + 5])) * f4 + hi16(sv[b + 4]) * f5;
+		// 24-bit multiplies: sums of two int16 and coefficients below 2^17 (see k_fm_droop)
+		const int si = __mul24(lo16(sv[b]) + lo16(sv[b + 8]), f1) + __mul24(lo16(sv[b + 1]) + lo16(sv[b + 7]), f2) + __mul24(lo16(sv[b + 2]) + lo16(sv[b + 6]), f3) +
+		               __mul24(lo16(sv[b + 3]) + lo16(sv[b + 5]), f4) + __mul24(lo16(sv[b + 4]), f5);
+		const int sq = __mul24(hi16(sv[b]) + hi16(sv[b + 8]), f1) + __mul24(hi16(sv[b + 1]) + hi16(sv[b + 7]), f2) + __mul24(hi16(sv[b + 2]) + hi16(sv[b + 6]), f3) +
+		               __mul24(hi16(sv[b + 3]) + hi16(sv[b + 5]), f4) + __mul24(hi16(sv[b + 4]), f5);
 		o[r] = pack_iq(si >> 15, sq >> 15);
 	}
 	const int n = (int)((M - t0) < 4 ? (M - t0) : 4);

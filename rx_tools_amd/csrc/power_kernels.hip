@@ -484,8 +484,9 @@ __global__ void k_pw_droop(const uint32_t *__restrict__ in, uint32_t *__restrict
 		hi[j] = pw_lo(w); hq[j] = pw_hi(w);
 	}
 	const int f1 = fir[1], f2 = fir[2], f3 = fir[3], f4 = fir[4], f5 = fir[5];
-	const int si = (hi[0] + hi[8]) * f1 + (hi[1] + hi[7]) * f2 + (hi[2] + hi[6]) * f3 + (hi[3] + hi[5]) * f4 + hi[4] * f5;
-	const int sq = (hq[0] + hq[8]) * f1 + (hq[1] + hq[7]) * f2 + (hq[2] + hq[6]) * f3 + (hq[3] + hq[5]) * f4 + hq[4] * f5;
+	// 24-bit multiplies: sums of two int16 and cic_9_tables coefficients (< 2^17) fit; low 32 bits of the product = the wrapping int
+	const int si = __mul24(hi[0] + hi[8], f1) + __mul24(hi[1] + hi[7], f2) + __mul24(hi[2] + hi[6], f3) + __mul24(hi[3] + hi[5], f4) + __mul24(hi[4], f5);
+	const int sq = __mul24(hq[0] + hq[8], f1) + __mul24(hq[1] + hq[7], f2) + __mul24(hq[2] + hq[6], f3) + __mul24(hq[3] + hq[5], f4) + __mul24(hq[4], f5);
 	out[b * (u64)stride + t] = pw_pack(si >> 15, sq >> 15);
 }
 

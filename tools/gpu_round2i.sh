@@ -1,0 +1,18 @@
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r2i
+mkdir -p $O
+cd $R
+for f in test_gpu_fm test_gpu_power test_gpu_dropin test_dropin_e2e; do
+  timeout 900 python -u -m pytest tests/$f.py -m gpu -q -x -p no:cacheprovider --timeout 600 > $O/$f.log 2>&1
+  echo "$f rc=$? $(tail -1 $O/$f.log)"
+done
+timeout 300 python tools/ds6_probe.py 8192 > $O/ds6_probe.log 2>&1; grep tiled $O/ds6_probe.log
+timeout 600 python bench.py --steps 10 --warmup 3 --workload rx_fm --cpu-seconds 0 --no-parity > $O/bench_fm.json 2> $O/bench_fm.err
+echo bench rc=$?
+python - <<'P'
+import json
+d=json.load(open('gpurun_out/r2i/bench_fm.json'))
+print('headline', round(d['value']/1e6,3), 'TS/s dec frac', round(d['roofline']['frac'],3), 'ms', round(d['roofline']['avg_launch_ms'],3))
+for k,v in d['rx_fm_variants'].items(): print(k[:40], round(v['value']/1e6,3), v['stage_us_per_step'])
+P
