@@ -355,6 +355,13 @@ def main():
                 continue
         return {}, None
 
+    def pmc_kernel(pmc, prefix, field):
+        """the summary's entry for a kernel (template arguments included in its key), the one that has `field`"""
+        for k, v in pmc.items():
+            if k.startswith(prefix) and isinstance(v, dict) and v.get(field):
+                return v
+        raise KeyError(prefix)
+
     result = {}
 
     # ------------------------------------------------------------------ rx_fm (headline)
@@ -488,7 +495,7 @@ def main():
         traffic, traffic_src = None, None
         pmc, pmc_src = pmc_summary()
         try:
-            k = pmc["k_fm_decimate"]
+            k = pmc_kernel(pmc, "k_fm_decimate<false, true, true", "hbm_bytes_per_launch")
             # measured on 2^30-sample launches (--blocks 8192); bytes scale with the launch
             traffic = k["hbm_bytes_per_launch"] * (T / float(1 << 30))
             traffic_src = pmc_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per gfx950 note)"
@@ -591,7 +598,7 @@ def main():
         pmc, pmc_src = pmc_summary()
         valu = None
         try:
-            k = pmc["k_pw_fft4096"]
+            k = pmc_kernel(pmc, "k_pw_fft4096", "SQ_INSTS_VALU")
             # counted on a 512-pass, 599-tune launch; instructions scale with the bins of the launch
             instr = k["SQ_INSTS_VALU"] * (bins_local / float(512 * 599 * 8192))
             valu = instr / (ms / launches * 1e-3) / 1e9

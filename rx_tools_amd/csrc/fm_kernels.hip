@@ -325,6 +325,122 @@ __global__ __launch_bounds__(DEC_THREADS) void k_fm_decimate(
 
 #undef PREFIX_AT
 
+// ------------------------------------------------------------------ F0+F1+F2(+F5/F6) for small decimation, direct form
+
+// -M wbfm's own decimation is 6 (rtl_fm.c:968 with rate_in 170 kHz), BASELINE configs[0] has 5.  There the prefix-scan
+// decimator above spends as many instructions on slots, scans and prefix differences as on the samples themselves, and the
+// whole chain is bound by VALU issue (rocprofv3: 0.256 wave-instructions per SIMD-cycle at ds = 6).  For ds <= 32 a window is
+// shorter than a wave's row of samples, so: stage a span of SCALED, ROTATED samples in LDS once (same coalesced 16-byte loads,
+// same packed fp32-fma scale), then one thread per output sums its ds consecutive LDS words -- no scan, no slots, no seams:
+// a span also stages the ds samples in front of it and the ds - 1 behind it (0.2 % re-read at ds = 6), so every window that
+// STARTS in a span is complete there, and the predecessor the discriminator needs is the neighbouring lane's sum (lane 0 of a
+// wave sums it again).  What this kernel cannot know stays with k_fm_disc(sparse, seams = 2): the run's first two outputs (the
+// carried now_r/now_j and pre_r/pre_j live in a struct that a later kernel of the previous run is still writing), every
+// callback block's first output (libm) and the carries out.
+#define DSM_SPAN 4096
+#define DSM_HALO 32                                            // >= ds: whole 16-byte vectors on either side
+
+// sum of the ds staged samples from LDS word r: the reads are issued together (a loop with a run-time trip count would wait for each
+// LDS read in turn); DSK = ds for the common small values, 0 = groups of eight with a uniform bound
+template <int DSK>
+__device__ __forceinline__ uint32_t dsm_window(const uint32_t *sm, int r, int ds)
+{
+	if constexpr (DSK > 0) {
+		uint32_t v[DSK];
+#pragma unroll
+		for (int i = 0; i < DSK; i++)
+			v[i] = sm[r + i];
+		uint32_t a = v[0];
+#pragma unroll
+		for (int i = 1; i < DSK; i++)
+			a = pk_add(a, v[i]);
+		return a;
+	}
+	uint32_t a = 0;
+	for (int i0 = 0; i0 < ds; i0 += 8) {
+		uint32_t v[8];
+#pragma unroll
+		for (int i = 0; i < 8; i++)
+			v[i] = sm[r + i0 + i];                            // past the window: staged neighbours (or the pad), dropped below
+#pragma unroll
+		for (int i = 0; i < 8; i++)
+			a = pk_add(a, i0 + i < ds ? v[i] : 0u);
+	}
+	return a;
+}
+
+template <bool ROTATE, int DSK>
+__global__ __launch_bounds__(256) void k_fm_decimate_small(
+	const u32x4 *__restrict__ iq, u64 T, int ds, int p0, u64 M, int16_t *__restrict__ pcm, int pcm_chl2)
+{
+	__shared__ __attribute__((aligned(16))) uint32_t sm[DSM_HALO + DSM_SPAN + DSM_HALO + 8];    // + the generic window sum's over-read
+	const unsigned per = gridDim.x >> 3;
+	const unsigned wgi = (gridDim.x & 7) ? blockIdx.x : (blockIdx.x & 7) * per + (blockIdx.x >> 3);   // XCD-contiguous spans, like k_fm_decimate
+	const u64 wg0 = (u64)wgi * DSM_SPAN;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const scale_k K = scale_consts();
+	// stage [wg0 - HALO, wg0 + SPAN + HALO): vector v holds samples wg0 - HALO + 4v .. +3 (their rotation phases are 0..3: wg0
+	// and HALO are multiples of 4); outside the run: zeros (never used by a window that is produced here)
+	constexpr int NV = (DSM_SPAN + 2 * DSM_HALO) / 4;         // 1040 vectors
+	u32x4 w[5];
+#pragma unroll
+	for (int u = 0; u < 5; u++) {
+		const int v = tid + 256 * u;
+		const i64 pos = (i64)wg0 - DSM_HALO + 4 * (i64)v;
+		w[u] = (v < NV && pos >= 0 && (u64)pos < T) ? __builtin_nontemporal_load(iq + (pos >> 2)) : (u32x4)(0u);
+	}
+#pragma unroll
+	for (int u = 0; u < 5; u++) {
+		const int v = tid + 256 * u;
+		if (v < NV) {
+			uint32_t s0, s1, s2, s3;
+			dec_contrib<false, ROTATE>(w[u], s0, s1, s2, s3, K);
+			*reinterpret_cast<uint4 *>(&sm[4 * v]) = make_uint4(s0, s1, s2, s3);
+		}
+	}
+	__syncthreads();
+	// windows that START in this span: m*ds - p0 in [wg0, wg0 + SPAN).  All per-output arithmetic below is 32-bit, relative to the
+	// span's first window m_lo and to the tile of the output stream it falls in.
+	const u64 m_lo = (wg0 + (u64)p0 + (u64)ds - 1) / (u64)ds;
+	u64 m_hi64 = (wg0 + DSM_SPAN + (u64)p0 + (u64)ds - 1) / (u64)ds;
+	if (m_hi64 > M)
+		m_hi64 = M;
+	if (m_hi64 <= m_lo)
+		return;
+	const unsigned n_out = (unsigned)(m_hi64 - m_lo);                            // <= SPAN / ds + 1
+	const int rel0 = (int)((i64)(m_lo * (u64)ds) - (i64)p0 - (i64)wg0) + DSM_HALO;   // LDS word of window m_lo's first sample
+	const u64 tile_mask = pcm_chl2 ? (((u64)64 << pcm_chl2) - 1) : 0;
+	int16_t *const pcm_tile = pcm + (m_lo & ~tile_mask);                        // linear layout: tile_mask = 0, pcm_tile = pcm + m_lo... see below
+	const unsigned mt0 = (unsigned)(m_lo & tile_mask);
+	for (unsigned jb = (unsigned)(tid & ~63); jb < n_out; jb += 256) {           // a wave takes 64 consecutive outputs per turn
+		const unsigned j = jb + lane;
+		// lanes past the last output stay inside the staged range and are not stored
+		const int rel = rel0 + (int)__umul24(j, (unsigned)ds);
+		const int r0 = rel < DSM_SPAN + DSM_HALO ? rel : DSM_SPAN + DSM_HALO - 1;
+		const uint32_t a = dsm_window<DSK>(sm, r0, ds);
+		// the previous output: the lane on the left has it; a wave's first lane sums it again (its window starts ds samples
+		// earlier, inside the left halo at worst)
+		uint32_t b0 = 0;
+		if (lane == 0)
+			b0 = dsm_window<DSK>(sm, r0 - ds, ds);
+		b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
+		const uint32_t b = (uint32_t)__builtin_amdgcn_update_dpp((int)b0, (int)a, 0x138, 0xf, 0xf, false);   // wave_shr:1, lane 0 keeps b0
+		if (j >= n_out)
+			continue;
+		int cr, cj;
+		mul_conj_pk(a, b, cr, cj);
+		const int16_t v = (int16_t)fast_atan2_dev(cj, cr);
+		if (pcm_chl2) {
+			// 32-bit form of pcm_index: the bits above a tile pass through, so an output that runs into the next tile lands there
+			const unsigned mt = mt0 + j, k = mt & ((1u << pcm_chl2) - 1u), c = (mt >> pcm_chl2) & 63u;
+			pcm_tile[(mt & ~(unsigned)tile_mask) | ((k >> 3) << 9) | (c << 3) | (k & 7u)] = v;
+		} else {
+			__builtin_nontemporal_store(v, &pcm_tile[j]);
+		}
+	}
+}
+
+
 // One sample, scaled and rotated by its position in its block (exact int)
 template <bool PRESCALED>
 __device__ __forceinline__ void load_rot(const uint32_t *iq, u64 pos, unsigned phase, int &ri, int &rq)
@@ -491,6 +607,21 @@ __device__ __forceinline__ uint32_t lp_final(u64 m, int ds, int p0, int seams, c
 	*brute = false;
 	if (!seams)
 		return lp_raw[m];
+	if (seams == 2) {
+		// after k_fm_decimate_small with a sparse lowpassed[]: nothing is stored, every window this kernel needs is summed again;
+		// the run's first window may begin in the previous run -- those samples are the carried now_r/now_j
+		*brute = true;
+		const i64 w0 = (i64)(m * (u64)ds) - (i64)p0;
+		if (w0 >= 0)
+			return lp_brute<PRESCALED>(iq, m, ds, p0, n_per_block, rotate);
+		int si = 0, sq = 0;
+		for (i64 pos = 0; pos < w0 + ds; pos++) {
+			int ri, rq;
+			load_rot<PRESCALED>(iq, (u64)pos, rotate ? (unsigned)pos : 0u, ri, rq);
+			si += ri; sq += rq;
+		}
+		return pk_add(carry, pack_iq(si, sq));
+	}
 	// window m covers stream samples [m*ds - p0, (m+1)*ds - p0); it is the one the decimator left
 	// in head/tail form iff it is the first window ENDING inside its workgroup span, i.e. iff it
 	// starts at or before that span's first sample
@@ -2548,6 +2679,21 @@ extern "C" int rxk_fm_decimate(void *stream, const int16_t *iq, u64 T, int ds, i
 	LAUNCH_RET();
 }
 
+extern "C" int rxk_fm_decimate_small(void *stream, const int16_t *iq, u64 T, int ds, int p0, int rotate, unsigned long long M, int16_t *pcm,
+                                     int pcm_chl2)
+{
+	const unsigned grid = (unsigned)((T + DSM_SPAN - 1) / DSM_SPAN);
+	hipStream_t s = (hipStream_t)stream;
+	const u32x4 *p = (const u32x4 *)iq;
+#define GO2(RT, K) hipLaunchKernelGGL((k_fm_decimate_small<RT, K>), dim3(grid), dim3(256), 0, s, p, T, ds, p0, M, pcm, pcm_chl2)
+#define GO(RT) do { switch (ds) { case 4: GO2(RT, 4); break; case 5: GO2(RT, 5); break; case 6: GO2(RT, 6); break; \
+		case 7: GO2(RT, 7); break; case 8: GO2(RT, 8); break; default: GO2(RT, 0); break; } } while (0)
+	if (rotate) GO(true); else GO(false);
+#undef GO
+#undef GO2
+	LAUNCH_RET();
+}
+
 extern "C" int rxk_fm_decimate_generic(void *stream, const int16_t *iq, u64 T, int ds, int p0, u64 n_per_block,
                                        int prescaled, int rotate, const rxk_fm_dev *dev, uint32_t *lp, u64 M)
 {
@@ -2570,7 +2716,8 @@ extern "C" int rxk_fm_disc(void *stream, const int16_t *iq, u64 T, int ds, int p
 {
 	if (!sparse || !seams)
 		lp_sparse = 0;
-	const u64 n_wg = (T + RXK_DEC_SPAN - 1) / RXK_DEC_SPAN;
+	/* seams == 2 (after rxk_fm_decimate_small): no span seams, just the run's first two outputs */
+	const u64 n_wg = seams == 2 ? 1 : (T + RXK_DEC_SPAN - 1) / RXK_DEC_SPAN;
 	const unsigned out_blocks = sparse ? (unsigned)((2 * n_wg + n_blocks + 1 + 255) / 256) : (unsigned)((M + 255) / 256);
 	const unsigned grid = out_blocks + (do_tail ? 1 : 0);
 	if (!grid)

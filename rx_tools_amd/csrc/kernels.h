@@ -78,6 +78,14 @@ int rxk_fm_decimate(void *stream, const int16_t *iq, unsigned long long T, int d
 /* pcm_chl2 != 0: pcm[] is written in the tiled layout of the lane-per-chunk audio kernels (chunks of 2^pcm_chl2 samples, see
  * pcm_index in fm_kernels.hip); rxk_fm_disc takes the same argument */
 
+/* the direct form for small decimation (RXK_DEC_SMALL_MIN <= ds <= RXK_DEC_SMALL_MAX, raw cs16 input, T % 4 == 0): scaled samples staged
+ * in LDS once, one thread per output, no seams, -A fast discriminator for every output into pcm[] (linear or tiled); lowpassed[] is not
+ * kept.  rxk_fm_disc(sparse, seams = 2) then redoes the run's first two outputs and every block's first one and takes the carries. */
+#define RXK_DEC_SMALL_MIN 4
+#define RXK_DEC_SMALL_MAX 32
+int rxk_fm_decimate_small(void *stream, const int16_t *iq, unsigned long long T, int ds, int p0, int rotate, unsigned long long M,
+                          int16_t *pcm, int pcm_chl2);
+
 /* same maths, one thread per output, any ds >= 1 and any block length; writes final lp[] */
 int rxk_fm_decimate_generic(void *stream, const int16_t *iq, unsigned long long T, int ds, int p0,
                             unsigned long long n_per_block, int prescaled, int rotate,

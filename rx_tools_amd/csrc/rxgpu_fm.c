@@ -651,14 +651,20 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 		/* lowpassed[] is an intermediate of the fused chain: keep only the entries the seam kernel reads
 		 * (the drop-in, which must hand lowpassed[] back, runs prescaled) */
 		const int lp_sparse = fused_disc && !prescaled && g->ds <= RXK_LP_SPARSE_MAX_DS;
+		/* small decimation on the raw capture: the direct kernel (samples staged in LDS, a thread per output, no seams) */
+		const int small = g->fast && fused_disc && !prescaled && g->ds >= RXK_DEC_SMALL_MIN && g->ds <= RXK_DEC_SMALL_MAX &&
+		                  !getenv("RXGPU_NO_SMALL");
 		if (g->fast) {
 			s->lp_final = s->lp_raw[db];
 			/* buffer set `db` was last read by the audio chain two runs ago */
 			if (s->ev_small_valid[db])
 				RX_HIP(hipStreamWaitEvent(sa, s->ev_small[db], 0));
 			rxgpu_prof_begin_on("fm_decimate", sa);
-			RX_K(rxk_fm_decimate(sa, d_iq, g->T, g->ds, g->p0, prescaled, g->rotate, s->lp_raw[db], s->head[db], s->tail[db],
-			                     lp_sparse, fused_disc ? s->pcm : NULL, s->tiled));
+			if (small)
+				RX_K(rxk_fm_decimate_small(sa, d_iq, g->T, g->ds, g->p0, g->rotate, g->M, s->pcm, s->tiled));
+			else
+				RX_K(rxk_fm_decimate(sa, d_iq, g->T, g->ds, g->p0, prescaled, g->rotate, s->lp_raw[db], s->head[db], s->tail[db],
+				                     lp_sparse, fused_disc ? s->pcm : NULL, s->tiled));
 			rxgpu_prof_end_on("fm_decimate", sa);
 			RX_HIP(hipEventRecord(s->ev_dec[db], sa));
 			RX_HIP(hipStreamWaitEvent(sb, s->ev_dec[db], 0));
@@ -669,7 +675,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 		}
 		rxgpu_prof_begin_on("fm_disc", sb);
 		/* fast path: lp_raw is finished in place (only seam entries change) and becomes the final decimated IQ */
-		RX_K(rxk_fm_disc(sb, d_iq, g->T, g->ds, g->p0, g->n, prescaled, g->rotate, g->fast, g->fast ? s->lp_raw[db] : s->lp,
+		RX_K(rxk_fm_disc(sb, d_iq, g->T, g->ds, g->p0, g->n, prescaled, g->rotate, small ? 2 : g->fast, g->fast ? s->lp_raw[db] : s->lp,
 		                 s->head[db], s->tail[db], g->fast ? s->lp_raw[db] : s->lp, g->M, RXK_FIRST_LOWPASS, 0, p->custom_atan, 1,
 		                 split ? NULL : s->pcm, s->dev, flag_rec, flag_cnt, fused_disc, n_blocks, s->atan_lut, g->fast ? lp_sparse : 0, s->flag_all, s->tiled));
 		rxgpu_prof_end_on("fm_disc", sb);

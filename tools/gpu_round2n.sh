@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r2k
+O=$R/gpurun_out/r2n
 mkdir -p $O
 cd $R
 for f in test_gpu_fm test_gpu_power; do
@@ -12,7 +12,7 @@ timeout 600 python bench.py --steps 20 --warmup 5 --workload rx_fm --cpu-seconds
 echo bench rc=$?
 python - <<'P'
 import json
-d=json.load(open('gpurun_out/r2k/bench_fm.json'))
+d=json.load(open('gpurun_out/r2n/bench_fm.json'))
 print('headline', round(d['value']/1e6,3), 'TS/s dec frac', round(d['roofline']['frac'],3), 'ms', round(d['roofline']['avg_launch_ms'],3))
 for k,v in d['rx_fm_variants'].items(): print(k[:40], round(v['value']/1e6,3), v['stage_us_per_step'])
 P
