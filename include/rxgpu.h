@@ -79,7 +79,9 @@ void rxgpu_full_demod(struct demod_state *d);
 void rxgpu_dropin_invalidate(const struct demod_state *d);
 /* Optional, once at start-up: page-lock lowpassed[]..result[] of *d and buf16[] of *s so that the drop-in's copies are
  * DMA'd in place (SURVEY.md section 8b "Ownership").  The structs must outlive the registration -- the reference's are
- * globals (rtl_fm.c:190-191); rxgpu_dropin_unpin before freeing heap-allocated ones.  Either pointer may be NULL. */
+ * globals (rtl_fm.c:190-191); rxgpu_dropin_unpin before freeing heap-allocated ones.  Either pointer may be NULL.
+ * Exactly the members' bytes are registered (no rounding out to pages), so neighbouring host buffers keep resolving
+ * as pageable memory. */
 int rxgpu_dropin_pin(struct demod_state *d, struct dongle_state *s);
 int rxgpu_dropin_unpin(struct demod_state *d, struct dongle_state *s);
 

@@ -1212,11 +1212,13 @@ static void die(const char *what)
  * own bounce buffers.  Either pointer may be NULL. */
 static int pin_range(const void *ptr, size_t bytes, int on)
 {
-	const uintptr_t lo = (uintptr_t)ptr & ~(uintptr_t)4095, hi = ((uintptr_t)ptr + bytes + 4095) & ~(uintptr_t)4095;
+	/* exactly the member's bytes, NOT rounded out to pages: the runtime resolves a host pointer by the registered
+	 * ranges, and a foreign buffer that merely shares a boundary page with the struct must not resolve to this one
+	 * (its copies would then fail with hipErrorInvalidValue as soon as they run past the registration's end) */
 	if (on)
-		RX_HIP(hipHostRegister((void *)lo, hi - lo, hipHostRegisterDefault));
+		RX_HIP(hipHostRegister((void *)ptr, bytes, hipHostRegisterDefault));
 	else
-		RX_HIP(hipHostUnregister((void *)lo));
+		RX_HIP(hipHostUnregister((void *)ptr));
 	return RXGPU_OK;
 }
 

@@ -143,7 +143,8 @@ def test_dropin_handoff_stays_on_the_device_unless_invalidated():
             R.check(L.rxgpu_dropin_pin(C.addressof(d), C.addressof(s)))       # the optional in-place DMA of the struct members
         for b in range(2):
             blk = np.ascontiguousarray(iq[b * block_len:(b + 1) * block_len])
-            L.rxgpu_callback(blk.copy().ctypes.data, block_len, C.addressof(s))
+            raw = blk.copy()                                                   # the callback may zero its head (mute): not the test's copy
+            L.rxgpu_callback(raw.ctypes.data, block_len, C.addressof(s))
             pre = np.ctypeslib.as_array(d.lowpassed)[:block_len].copy()
             if edit:
                 pre[100:200] = 0
