@@ -254,7 +254,9 @@ long rxgpu_chan_host_fixups(const rxgpu_chan *s);
 int rxgpu_scan(struct tuning_state *tunes, int tune_count, const int *window_coefs,
                const int16_t *sinewave, int boxcar, int comp_fir_size, int peak_hold);
 
-/* Replaces csv_dbm(ts) (rtl_power.c:774-817), writing to `file`. Host code, unchanged math. */
+/* csv_dbm(ts) (rtl_power.c:774-817) writing to `file`.  Host code, NOT a device function: our restatement of the
+ * reference's text formatter (one index map per printed bin), tested byte-for-byte against the reference's output.
+ * Optional -- fed the bit-exact avg[] of rxgpu_scan, the reference's own csv_dbm prints the same bytes. */
 void rxgpu_csv_dbm(struct tuning_state *ts, void *file /* FILE* */);
 
 /* Host-side planners/tables with the reference's exact arithmetic (needed to size shards):
