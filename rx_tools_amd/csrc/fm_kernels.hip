@@ -109,7 +109,7 @@ __device__ __forceinline__ uint32_t wave_scan_incl_biased(uint32_t v)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // two cs16 components through F0 (scale_cs16) with the signs of rotate16_90 folded in -- trunc(-r) == -trunc(r) --
-// packed as int16 pair (lo from a, hi from b): v_cvt_f32_i32 (SDWA) x2, one v_pk_fma_f32, v_cvt_i32_f32 x2, v_cvt_pk_i16_i32
+// packed as int16 pair (lo from a, hi from b): v_cvt_f32_i32 (SDWA) x2, one v_pk_fma_f32, v_cvt_i32_f32 x2 (the second into the high half)
 // the two constant pairs of the scale live in VGPRs for the whole kernel (made opaque once by scale_consts: left as literals the
 // compiler rebuilds both pairs -- two v_mov_b64 and four s_mov -- in front of every tile)
 struct scale_k { f32x2 cc, hh; };
@@ -137,7 +137,11 @@ __device__ __forceinline__ uint32_t scale_pk(int a, int b, const scale_k &K)
 		asm("v_pk_fma_f32 %0, %1, %2, %3 neg_hi:[0,1,1]" : "=v"(r) : "v"(x), "v"(cc), "v"(hh));
 	else
 		asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,1,1] neg_hi:[0,1,1]" : "=v"(r) : "v"(x), "v"(cc), "v"(hh));
-	return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16((int)r.x, (int)r.y));
+	// |value| <= 128: the second conversion writes its low half straight into the high half of the pair (SDWA destination select),
+	// no v_cvt_pk_i16_i32
+	uint32_t out = (uint32_t)(int)r.x;
+	asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(out) : "v"(r.y));
+	return out;
 }
 
 // a lane's four samples as packed (I,Q) contributions to the running sums: rotate16_90 (rtl_fm.c:309-327) multiplies
@@ -176,6 +180,7 @@ __device__ __forceinline__ void dec_contrib(const u32x4 v, uint32_t &s0, uint32_
 // sample of a boxcar window drops the prefix at that point into an LDS slot.  After a
 // barrier, output j = slot[j] - slot[j-1].  The window that straddles the workgroup start
 // is finished by rxk_fm_disc from head[]/tail[].
+template <bool DEN24 = false>
 __device__ __forceinline__ int fast_atan2_dev(int y, int x);
 __device__ __forceinline__ void mul_conj_pk(uint32_t a, uint32_t b, int &cr, int &cj);
 
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_fm_decimate(
 // wave sums it again).  What this kernel cannot know stays with k_fm_disc(sparse, seams = 2): the run's first two outputs (the
 // carried now_r/now_j and pre_r/pre_j live in a struct that a later kernel of the previous run is still writing), every
 // callback block's first output (libm) and the carries out.
-#define DSM_SPAN 4096
+#define DSM_SPAN_MAX 4608                                       // samples of a span at most (see dsm_span)
 #define DSM_HALO 32                                            // >= ds: whole 16-byte vectors on either side
 
 // sum of the ds staged samples from LDS word r: the reads are issued together (a loop with a run-time trip count would wait for each
@@ -369,28 +374,49 @@ __device__ __forceinline__ uint32_t dsm_window(const uint32_t *sm, int r, int ds
 	return a;
 }
 
-template <bool ROTATE, int DSK>
-__global__ __launch_bounds__(256) void k_fm_decimate_small(
-	const u32x4 *__restrict__ iq, u64 T, int ds, int p0, u64 M, int16_t *__restrict__ pcm, int pcm_chl2)
+// span of a workgroup in samples: a multiple of 256 * ds (64 * ds for ds > 18) not above 4608, so that every span holds the same
+// whole number of windows -- whatever the phase p0 -- and the four waves get whole 64-output turns of them
+static inline unsigned dsm_span(int ds)
 {
-	__shared__ __attribute__((aligned(16))) uint32_t sm[DSM_HALO + DSM_SPAN + DSM_HALO + 8];    // + the generic window sum's over-read
+	const unsigned unit = (ds <= 18 ? 256u : 64u) * (unsigned)ds;
+	return (DSM_SPAN_MAX / unit) * unit;
+}
+
+// NR: rounds of 256 vectors that cover the staged range (4 or 5)
+template <bool ROTATE, int DSK, int NR>
+__global__ __launch_bounds__(256) void k_fm_decimate_small(
+	const u32x4 *__restrict__ iq, u64 T, int ds, int p0, u64 M, int16_t *__restrict__ pcm, int pcm_chl2, unsigned span, unsigned span_windows)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t dsm_sm[];   // DSM_HALO + span + DSM_HALO + 8 (the generic window sum's over-read)
+	uint32_t *const sm = dsm_sm;
+	// XCD-contiguous spans, like k_fm_decimate (neighbouring spans write pieces of the same lines of the tiled output: they have to
+	// meet in one L2); the grid is rounded up to a multiple of 8, the few workgroups past the last span leave
 	const unsigned per = gridDim.x >> 3;
-	const unsigned wgi = (gridDim.x & 7) ? blockIdx.x : (blockIdx.x & 7) * per + (blockIdx.x >> 3);   // XCD-contiguous spans, like k_fm_decimate
-	const u64 wg0 = (u64)wgi * DSM_SPAN;
-	const int tid = threadIdx.x, lane = tid & 63;
+	const unsigned wgi = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+	const u64 wg0 = (u64)wgi * span;
+	if (wg0 >= T)
+		return;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const scale_k K = scale_consts();
-	// stage [wg0 - HALO, wg0 + SPAN + HALO): vector v holds samples wg0 - HALO + 4v .. +3 (their rotation phases are 0..3: wg0
+	// stage [wg0 - HALO, wg0 + span + HALO): vector v holds samples wg0 - HALO + 4v .. +3 (their rotation phases are 0..3: wg0
 	// and HALO are multiples of 4); outside the run: zeros (never used by a window that is produced here)
-	constexpr int NV = (DSM_SPAN + 2 * DSM_HALO) / 4;         // 1040 vectors
-	u32x4 w[5];
+	const int NV = (int)(span + 2 * DSM_HALO) / 4;             // <= 1168 vectors: five rounds of 256
+	u32x4 w[NR];
+	if (wg0 >= DSM_HALO && wg0 + span + DSM_HALO <= T) {      // an inner span: no bounds to test per load
+		const u32x4 *base = iq + ((wg0 - DSM_HALO) >> 2);
 #pragma unroll
-	for (int u = 0; u < 5; u++) {
-		const int v = tid + 256 * u;
-		const i64 pos = (i64)wg0 - DSM_HALO + 4 * (i64)v;
-		w[u] = (v < NV && pos >= 0 && (u64)pos < T) ? __builtin_nontemporal_load(iq + (pos >> 2)) : (u32x4)(0u);
+		for (int u = 0; u < NR; u++)                          // all in flight: vectors past the staged range re-read its last one, unused
+			w[u] = __builtin_nontemporal_load(base + min(tid + 256 * u, NV - 1));
+	} else {
+#pragma unroll
+		for (int u = 0; u < NR; u++) {
+			const int v = tid + 256 * u;
+			const i64 pos = (i64)wg0 - DSM_HALO + 4 * (i64)v;
+			w[u] = (v < NV && pos >= 0 && (u64)pos < T) ? __builtin_nontemporal_load(iq + (pos >> 2)) : (u32x4)(0u);
+		}
 	}
 #pragma unroll
-	for (int u = 0; u < 5; u++) {
+	for (int u = 0; u < NR; u++) {
 		const int v = tid + 256 * u;
 		if (v < NV) {
 			uint32_t s0, s1, s2, s3;
@@ -399,41 +425,55 @@ __global__ __launch_bounds__(256) void k_fm_decimate_small(
 		}
 	}
 	__syncthreads();
-	// windows that START in this span: m*ds - p0 in [wg0, wg0 + SPAN).  All per-output arithmetic below is 32-bit, relative to the
-	// span's first window m_lo and to the tile of the output stream it falls in.
-	const u64 m_lo = (wg0 + (u64)p0 + (u64)ds - 1) / (u64)ds;
-	u64 m_hi64 = (wg0 + DSM_SPAN + (u64)p0 + (u64)ds - 1) / (u64)ds;
+	// windows that START in this span: m*ds - p0 in [wg0, wg0 + span).  The span is a whole number of windows (dsm_span), so the
+	// first one is wgi * (span / ds), plus one when the run starts inside a window -- no division.  All per-output arithmetic
+	// below is 32-bit, relative to the span's first window m_lo and to the tile of the output stream it falls in.
+	const unsigned wps = span_windows;
+	const u64 m_lo = (u64)wgi * wps + (p0 ? 1u : 0u);
+	u64 m_hi64 = m_lo + wps;
 	if (m_hi64 > M)
 		m_hi64 = M;
 	if (m_hi64 <= m_lo)
 		return;
-	const unsigned n_out = (unsigned)(m_hi64 - m_lo);                            // <= SPAN / ds + 1
-	const int rel0 = (int)((i64)(m_lo * (u64)ds) - (i64)p0 - (i64)wg0) + DSM_HALO;   // LDS word of window m_lo's first sample
-	const u64 tile_mask = pcm_chl2 ? (((u64)64 << pcm_chl2) - 1) : 0;
-	int16_t *const pcm_tile = pcm + (m_lo & ~tile_mask);                        // linear layout: tile_mask = 0, pcm_tile = pcm + m_lo... see below
-	const unsigned mt0 = (unsigned)(m_lo & tile_mask);
-	for (unsigned jb = (unsigned)(tid & ~63); jb < n_out; jb += 256) {           // a wave takes 64 consecutive outputs per turn
-		const unsigned j = jb + lane;
+	const unsigned n_out = (unsigned)(m_hi64 - m_lo);                            // span / ds, fewer at the end of the run
+	const int rel0 = (p0 ? ds - p0 : 0) + DSM_HALO;                              // LDS word of window m_lo's first sample
+	const int rel_max = (int)span + DSM_HALO - 1;
+	const unsigned tile_mask = pcm_chl2 ? ((64u << pcm_chl2) - 1u) : 0u;
+	int16_t *const pcm_tile = pcm + (m_lo & ~(u64)tile_mask);
+	const unsigned mt0 = (unsigned)(m_lo & (u64)tile_mask);
+	const unsigned keep = ~tile_mask | 7u;
+	// every wave takes a contiguous quarter of the span's outputs, 64 consecutive ones per turn: the previous output the
+	// discriminator needs is the neighbouring lane's sum, the one that crosses a turn travels in an SGPR, and only the wave's very
+	// first predecessor is summed again (its window starts ds samples earlier, inside the left halo at worst)
+	const unsigned per_wave = (n_out + 3) >> 2;
+	const unsigned j_lo = (unsigned)wave * per_wave, j_hi = min(n_out, j_lo + per_wave);
+	if (j_lo >= j_hi)
+		return;
+	uint32_t b0 = 0;
+	if (lane == 0)
+		b0 = dsm_window<DSK>(sm, rel0 + (int)__umul24(j_lo, (unsigned)ds) - ds, ds);
+	b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
+	for (unsigned j0 = j_lo; j0 < j_hi; j0 += 64) {
+		const unsigned j = j0 + lane;
 		// lanes past the last output stay inside the staged range and are not stored
 		const int rel = rel0 + (int)__umul24(j, (unsigned)ds);
-		const int r0 = rel < DSM_SPAN + DSM_HALO ? rel : DSM_SPAN + DSM_HALO - 1;
-		const uint32_t a = dsm_window<DSK>(sm, r0, ds);
-		// the previous output: the lane on the left has it; a wave's first lane sums it again (its window starts ds samples
-		// earlier, inside the left halo at worst)
-		uint32_t b0 = 0;
-		if (lane == 0)
-			b0 = dsm_window<DSK>(sm, r0 - ds, ds);
-		b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
+		const uint32_t a = dsm_window<DSK>(sm, min(rel, rel_max), ds);
 		const uint32_t b = (uint32_t)__builtin_amdgcn_update_dpp((int)b0, (int)a, 0x138, 0xf, 0xf, false);   // wave_shr:1, lane 0 keeps b0
-		if (j >= n_out)
+		b0 = (uint32_t)__builtin_amdgcn_readlane((int)a, 63);
+		if (j >= j_hi)
 			continue;
 		int cr, cj;
 		mul_conj_pk(a, b, cr, cj);
-		const int16_t v = (int16_t)fast_atan2_dev(cj, cr);
+		// |lowpassed| <= 128 * ds: for ds <= 16 the discriminator's denominator stays below 2^24
+		const int16_t v = (int16_t)fast_atan2_dev<(DSK > 0 && DSK <= 16)>(cj, cr);
 		if (pcm_chl2) {
-			// 32-bit form of pcm_index: the bits above a tile pass through, so an output that runs into the next tile lands there
-			const unsigned mt = mt0 + j, k = mt & ((1u << pcm_chl2) - 1u), c = (mt >> pcm_chl2) & 63u;
-			pcm_tile[(mt & ~(unsigned)tile_mask) | ((k >> 3) << 9) | (c << 3) | (k & 7u)] = v;
+			// 32-bit form of pcm_index (two bit-field moves): the bits above a tile pass through, so an output that runs into the
+			// next tile lands there
+			const unsigned mt = mt0 + j;
+			unsigned idx = mt & keep;
+			idx |= __builtin_amdgcn_ubfe(mt, 3u, (unsigned)pcm_chl2 - 3u) << 9;
+			idx |= __builtin_amdgcn_ubfe(mt, (unsigned)pcm_chl2, 6u) << 3;
+			pcm_tile[idx] = v;
 		} else {
 			__builtin_nontemporal_store(v, &pcm_tile[j]);
 		}
@@ -499,7 +539,10 @@ __device__ __forceinline__ int div_trunc(int num, int den)
 	return ((num ^ den) < 0) ? -(int)q : (int)q;
 }
 
-// rtl_fm.c:485-506 with the int32 wrap of `pi4 * (x -/+ yabs)` and C's truncating division
+// rtl_fm.c:485-506 with the int32 wrap of `pi4 * (x -/+ yabs)` and C's truncating division.  DEN24: the caller guarantees
+// |x| + |y| < 2^24 (no wrap of the denominator, and the remainder's product is one full-rate 24-bit multiply instead of the
+// quarter-rate v_mul_lo_u32)
+template <bool DEN24>
 __device__ __forceinline__ int fast_atan2_dev(int y, int x)
 {
 	if (x == 0 && y == 0)
@@ -516,11 +559,11 @@ __device__ __forceinline__ int fast_atan2_dev(int y, int x)
 	int q;
 	const unsigned un = num < 0 ? 0u - (unsigned)num : (unsigned)num;
 	const float fq = (float)un * __builtin_amdgcn_rcpf((float)(unsigned)den);
-	if (__builtin_expect((unsigned)den >= (1u << 30) || !(fq < 1048576.0f), 0)) {
+	if (__builtin_expect((!DEN24 && (unsigned)den >= (1u << 30)) || !(fq < 1048576.0f), 0)) {
 		q = (int)((double)num / (double)den);
 	} else {
 		unsigned uq = (unsigned)fq;
-		const int r = (int)(un - uq * (unsigned)den);
+		const int r = (int)(un - (DEN24 ? __umul24(uq, (unsigned)den) : uq * (unsigned)den));
 		uq = r < 0 ? uq - 1 : ((unsigned)r >= (unsigned)den ? uq + 1 : uq);
 		q = num < 0 ? -(int)uq : (int)uq;
 	}
@@ -1388,7 +1431,7 @@ __global__ void k_fm_deemph_serial(const int16_t *__restrict__ pcm, u64 M, int a
 // and stores one after the other -- are latency-bound at a fraction of the VALU rate.  Here the decimator hands the
 // demodulated samples over in the tiled layout (pcm_index), every lane streams its chunk with coalesced 16-byte loads
 // straight into registers, there is no LDS staging and no barrier, eight waves per SIMD:
-//   k_fm_deemph_scan_t     per chunk: warm-up on the previous chunk's tail (two extreme trajectories), then the lowest
+//   k_fm_deemph_scan_t     per chunk: warm-up on the previous chunk's tail (the lowest trajectory + a bound), then the lowest
 //                          candidate + merge mask (deemph_track's idea, three-instruction step) -> a COMPACT chunk table
 //                          {lo_start, lo_end | gap << 16, mask} of 16 bytes
 //   k_fm_deemph_up0/down0  the tree's first level on compact tables (16 chunks per parent); the levels above are the
@@ -1414,7 +1457,7 @@ __device__ __forceinline__ int ctab_apply(const uint4 t, int v)
 
 template <int GS, int CHL2>
 __global__ __launch_bounds__(256) void k_fm_deemph_scan_t(
-	const int16_t *__restrict__ pcm_t, u64 M, int a, unsigned magic, int warm, int lo0, int hi0,
+	const int16_t *__restrict__ pcm_t, u64 M, int a, unsigned magic, int warm, int lo0, int gap_w,
 	uint4 *__restrict__ ctab, rxk_fm_dev *__restrict__ dev)
 {
 	constexpr int CH = 1 << CHL2, UPC = CH / 8;
@@ -1431,12 +1474,18 @@ __global__ __launch_bounds__(256) void k_fm_deemph_scan_t(
 #pragma unroll
 	for (int j = 0; j < 4; j++)
 		cur[j] = row[(size_t)j * 64];                         // UPC >= 16
-	int lo, hi;
+	// Warm-up on the previous chunk's tail.  Only the LOWEST trajectory is walked: for two states g apart one step leaves them
+	// at most g - floor(g / a) apart (floor(u - v) <= floor(u) - floor(v)), a bound that does not depend on the samples and is
+	// non-decreasing in g -- so after `warm` steps from the whole state range the true state lies in [lo, lo + gap_w], gap_w < a
+	// being the host's iterate of that recurrence (rxgpu_fm.c, deemph_geometry).  Candidates the upper trajectory would have
+	// excluded are carried as candidates like any other; the merge tracking below thins them out.
+	int lo, gap;
 	if (c == 0) {                                             // the run's carried state
-		lo = hi = dev->in_deemph_avg;
+		lo = dev->in_deemph_avg;
+		gap = 0;
 	} else {
 		const uint4 *prow = tile_unit(pcm_t, c - 1, CHL2);
-		int nl = de_state(lo0, h), nh = de_state(hi0, h);
+		int nl = de_state(lo0, h);
 		const int u0 = (CH - warm) >> 3;
 		uint4 wq[4];
 #pragma unroll
@@ -1453,8 +1502,8 @@ __global__ __launch_bounds__(256) void k_fm_deemph_scan_t(
 					const uint32_t ww[4] = {wq[j].x, wq[j].y, wq[j].z, wq[j].w};
 #pragma unroll
 					for (int k = 0; k < 4; k++) {
-						de_step<0>(ww[k], nl, magic, -64); de_step<0>(ww[k], nh, magic, -64);
-						de_step<1>(ww[k], nl, magic, -64); de_step<1>(ww[k], nh, magic, -64);
+						de_step<0>(ww[k], nl, magic, -64);
+						de_step<1>(ww[k], nl, magic, -64);
 					}
 				}
 			}
@@ -1463,10 +1512,9 @@ __global__ __launch_bounds__(256) void k_fm_deemph_scan_t(
 				wq[j] = nx[j];
 		}
 		lo = de_avg(nl, h);
-		hi = de_avg(nh, h);
+		gap = gap_w;
 	}
-	int gap = hi - lo;
-	if (gap >= GS) {                                          // excluded by `warm` (rxgpu_fm.c); checked anyway
+	if (gap >= GS) {                                          // excluded by the host (gap_w < a <= GS); checked anyway
 		atomicExch(&dev->err, 1);
 		gap = GS - 1;
 	}
@@ -1549,23 +1597,24 @@ __global__ void k_fm_deemph_down0(u64 n_chunks, const uint4 *__restrict__ ctab, 
 // floor(num / den) for num < 2^52 (declared with the resampler below)
 __device__ __forceinline__ u64 div_floor(u64 num, u64 den);
 
-// One sample of low_pass_real run inline behind the de-emphasis step: y joins the running window, the phase advances, and a
-// completed window leaves as (int16)(sum / ratio) -- the truncating division through one fp32 multiply by a reciprocal
-// rounded up (exact for |sum| <= 34 * 32768 and ratio <= 32, checked exhaustively on the host).  Branch-free bookkeeping:
-// lanes are at different phases, some lane of the wave emits at nearly every sample.  A lane that starts in the middle of
-// somebody else's window emits that window's (partial, wrong) sum into the slot BEFORE its own first one: slot -1 of the
-// staging for a wave's first lane, otherwise the slot its left neighbour fills in afterwards, when it walks on past its
-// chunk to finish the window it owns -- same wave, later in program order, LDS operations retire in order.
-__device__ __forceinline__ void lpr_step(int y, int &acc, int &p, int &slot, int fast, int slow, float rinv, int16_t *stage)
+// One sample of low_pass_real run inline behind the de-emphasis step, five instructions and a masked LDS store.  The window
+// sum is kept as acc = -64 * sum: the de-emphasis state N = ((a/2 - avg) << 6) + 32 joins it as N - (64 * (a/2) + 32) = -64 * avg
+// in one v_add3.  p is the resampler phase BEFORE the sample (rtl_fm.c:397-399): the sample completes a window iff
+// p + slow >= fast, i.e. p >= thr = fast - slow, and then the phase moves by slow - fast instead of slow.  A completed window
+// leaves as its raw int32 sum; the division by the ratio happens once per OUTPUT when the wave's staging is written out.
+// Branch-free bookkeeping: lanes are at different phases, some lane of the wave emits at nearly every sample.  A lane that
+// starts in the middle of somebody else's window emits that window's (partial, wrong) sum into the slot BEFORE its own first
+// one: slot -1 of the staging for a wave's first lane, otherwise the slot its left neighbour fills in afterwards, when it
+// walks on past its chunk to finish the window it owns -- same wave, later in program order, LDS operations retire in order.
+__device__ __forceinline__ void lpr_step(int N, int nK, int &acc, int &p, int &slot, int thr, int slow, int d_emit, int *stage)
 {
-	acc += y;
-	p += slow;
-	const bool emit = p >= fast;
+	acc = acc + N + nK;
+	const bool emit = p >= thr;
 	if (emit)
-		stage[slot] = (int16_t)(int)((float)acc * rinv);
-	slot += emit ? 1 : 0;
+		*reinterpret_cast<int *>(reinterpret_cast<char *>(stage) + slot) = acc;      // slot counts bytes: the LDS address is stage + slot as it is
+	slot += emit ? 4 : 0;
 	acc = emit ? 0 : acc;
-	p -= emit ? fast : 0;
+	p += emit ? d_emit : slow;
 }
 
 template <int CHL2>
@@ -1574,10 +1623,10 @@ __global__ __launch_bounds__(256) void k_fm_deemph_apply_rs_t(
 	int fast, int slow, float rinv, int wcap, int16_t *__restrict__ out, rxk_fm_dev *__restrict__ dev)
 {
 	constexpr int CH = 1 << CHL2, UPC = CH / 8;
-	extern __shared__ int16_t stage_all[];
+	extern __shared__ int stage_all[];                         // per wave: wcap window sums (as -64 * sum)
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	int16_t *stage = stage_all + (size_t)wave * wcap;
-	const u64 cw = ((u64)blockIdx.x * 4 + wave) * 64;         // the wave's first chunk
+	int *stage = stage_all + (size_t)wave * wcap;
+	const u64 cw = ((u64)blockIdx.x * (blockDim.x >> 6) + wave) * 64;   // the wave's first chunk (1, 2 or 4 waves per workgroup)
 	const u64 c = cw + lane;
 	const u64 n_chunks = (M + CH - 1) >> CHL2;
 	if (cw >= n_chunks)
@@ -1591,13 +1640,14 @@ __global__ __launch_bounds__(256) void k_fm_deemph_apply_rs_t(
 	const u64 e0 = div_floor(num, (u64)fast);
 	int p = (int)(num - e0 * (u64)fast);
 	const int p_first = p;
-	int acc = (c == 0) ? dev->in_now_lpr : 0;                 // the run's first lane continues the carried window
+	int acc = (c == 0) ? -64 * dev->in_now_lpr : 0;           // the run's first lane continues the carried window (as -64 * sum)
+	const int nK = -(64 * h + 32), thr = fast - slow, d_emit = slow - fast;
 	// does a window start exactly at this chunk's first sample (or is this the run's first lane)?  If not, the window under way
 	// belongs to the lane on the left and completes after `skip` samples; this lane's own outputs start behind it.
 	const bool owns_first = c == 0 || p < slow;
 	const u64 j_first = e0 + (owns_first ? 0 : 1);
 	const u64 jw0 = (u64)__builtin_amdgcn_readfirstlane((int)(unsigned)j_first) | ((u64)__builtin_amdgcn_readfirstlane((int)(unsigned)(j_first >> 32)) << 32);
-	int slot = (int)(j_first - jw0) - (owns_first ? 0 : 1);   // >= -1: the staging has one spare element in front
+	int slot = 4 * ((int)(j_first - jw0) - (owns_first ? 0 : 1));   // in bytes; >= -4: the staging has one spare element in front
 	stage += 1;
 	if (valid) {
 		const int n = (int)((M - c0) < (u64)CH ? (M - c0) : (u64)CH);
@@ -1612,16 +1662,16 @@ __global__ __launch_bounds__(256) void k_fm_deemph_apply_rs_t(
 #pragma unroll
 			for (int k = 0; k < 4; k++) {
 				de_step<0>(ww[k], N, magic, -64);
-				lpr_step(h - (N >> 6), acc, p, slot, fast, slow, rinv, stage);
+				lpr_step(N, nK, acc, p, slot, thr, slow, d_emit, stage);
 				de_step<1>(ww[k], N, magic, -64);
-				lpr_step(h - (N >> 6), acc, p, slot, fast, slow, rinv, stage);
+				lpr_step(N, nK, acc, p, slot, thr, slow, d_emit, stage);
 			}
 		}
 		if (n & 7) {
 			const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
 			for (int k = 0; k < (n & 7); k++) {
 				if (k & 1) de_step<1>(ww[k >> 1], N, magic, -64); else de_step<0>(ww[k >> 1], N, magic, -64);
-				lpr_step(h - (N >> 6), acc, p, slot, fast, slow, rinv, stage);
+				lpr_step(N, nK, acc, p, slot, thr, slow, d_emit, stage);
 			}
 		}
 		const u64 end = c0 + (u64)n;
@@ -1632,7 +1682,7 @@ __global__ __launch_bounds__(256) void k_fm_deemph_apply_rs_t(
 			// the run's last chunk: what is left is the carry (rtl_fm.c:150-151).  A window still open belongs either to
 			// this lane (own) or to an earlier lane that walks on to M below and writes it; no window open: zero.
 			if (own)
-				dev->out_now_lpr = acc;
+				dev->out_now_lpr = -(acc >> 6);
 			else if (p < slow)
 				dev->out_now_lpr = 0;
 			dev->out_prev_lpr_index = p;
@@ -1646,23 +1696,23 @@ __global__ __launch_bounds__(256) void k_fm_deemph_apply_rs_t(
 				for (int k = (int)(i & 7); k < 8 && open && i < M; k++, i++) {
 					if (k & 1) de_step<1>(ww[k >> 1], N, magic, -64); else de_step<0>(ww[k >> 1], N, magic, -64);
 					const int before = slot;
-					lpr_step(h - (N >> 6), acc, p, slot, fast, slow, rinv, stage);
+					lpr_step(N, nK, acc, p, slot, thr, slow, d_emit, stage);
 					open = slot == before;
 				}
 			}
 			if (open)
-				dev->out_now_lpr = acc;                       // ran into the end of the run: this partial window is the carry
+				dev->out_now_lpr = -(acc >> 6);               // ran into the end of the run: this partial window is the carry
 		}
 	}
 	// the wave's outputs [jw0, jw0 + cnt) leave coalesced; lanes own ascending, contiguous ranges
-	int cnt = valid ? slot : 0;
+	int cnt = valid ? slot >> 2 : 0;
 	for (int off = 32; off; off >>= 1)
 		cnt = max(cnt, __shfl_xor(cnt, off));
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-	for (int idx = lane; idx < cnt; idx += 64)
-		out[jw0 + (u64)idx] = stage[idx];
+	for (int idx = lane; idx < cnt; idx += 64)                // (int16)(sum / ratio), the truncating division by the reciprocal rounded up
+		out[jw0 + (u64)idx] = (int16_t)(int)((float)(-(stage[idx] >> 6)) * rinv);
 }
 
 // ------------------------------------------------------------------ F9 low_pass_real
@@ -2682,10 +2732,14 @@ extern "C" int rxk_fm_decimate(void *stream, const int16_t *iq, u64 T, int ds, i
 extern "C" int rxk_fm_decimate_small(void *stream, const int16_t *iq, u64 T, int ds, int p0, int rotate, unsigned long long M, int16_t *pcm,
                                      int pcm_chl2)
 {
-	const unsigned grid = (unsigned)((T + DSM_SPAN - 1) / DSM_SPAN);
+	const unsigned span = dsm_span(ds);
+	const unsigned grid = ((unsigned)((T + span - 1) / span) + 7u) & ~7u;
+	const size_t lds = (size_t)(span + 2 * DSM_HALO + 8) * 4;
 	hipStream_t s = (hipStream_t)stream;
 	const u32x4 *p = (const u32x4 *)iq;
-#define GO2(RT, K) hipLaunchKernelGGL((k_fm_decimate_small<RT, K>), dim3(grid), dim3(256), 0, s, p, T, ds, p0, M, pcm, pcm_chl2)
+	const bool four = (span + 2 * DSM_HALO) / 4 <= 1024;
+#define GO2(RT, K) do { if (four) hipLaunchKernelGGL((k_fm_decimate_small<RT, K, 4>), dim3(grid), dim3(256), lds, s, p, T, ds, p0, M, pcm, pcm_chl2, span, span / (unsigned)ds); \
+		else hipLaunchKernelGGL((k_fm_decimate_small<RT, K, 5>), dim3(grid), dim3(256), lds, s, p, T, ds, p0, M, pcm, pcm_chl2, span, span / (unsigned)ds); } while (0)
 #define GO(RT) do { switch (ds) { case 4: GO2(RT, 4); break; case 5: GO2(RT, 5); break; case 6: GO2(RT, 6); break; \
 		case 7: GO2(RT, 7); break; case 8: GO2(RT, 8); break; default: GO2(RT, 0); break; } } while (0)
 	if (rotate) GO(true); else GO(false);
@@ -2836,7 +2890,7 @@ extern "C" int rxk_fm_deemph_tiled_ok(int a, int group, int chunk, int fast, int
 	return chunk == 128 ? 7 : 8;
 }
 
-extern "C" int rxk_fm_deemph_scan_t(void *stream, const int16_t *pcm_t, u64 M, int a, int group, int chl2, int warm, int lo0, int hi0,
+extern "C" int rxk_fm_deemph_scan_t(void *stream, const int16_t *pcm_t, u64 M, int a, int group, int chl2, int warm, int lo0, int gap_w,
                                     void *ctab, rxk_fm_dev *dev)
 {
 	if (!M)
@@ -2845,7 +2899,7 @@ extern "C" int rxk_fm_deemph_scan_t(void *stream, const int16_t *pcm_t, u64 M, i
 	const unsigned grid = (unsigned)((n_chunks + 255) / 256);
 	hipStream_t s = (hipStream_t)stream;
 	const unsigned mg = deemph_magic(a);
-#define GO(GS, CL) hipLaunchKernelGGL((k_fm_deemph_scan_t<GS, CL>), dim3(grid), dim3(256), 0, s, pcm_t, M, a, mg, warm, lo0, hi0, (uint4 *)ctab, dev)
+#define GO(GS, CL) hipLaunchKernelGGL((k_fm_deemph_scan_t<GS, CL>), dim3(grid), dim3(256), 0, s, pcm_t, M, a, mg, warm, lo0, gap_w, (uint4 *)ctab, dev)
 	if (group == 16) { if (chl2 == 7) GO(16, 7); else GO(16, 8); }
 	else { if (chl2 == 7) GO(64, 7); else GO(64, 8); }
 #undef GO
@@ -2875,19 +2929,26 @@ extern "C" int rxk_fm_deemph_apply_rs_t(void *stream, const int16_t *pcm_t, u64 
 	if (!M)
 		return 0;
 	const u64 n_chunks = (M + (1u << chl2) - 1) >> chl2;
-	const unsigned grid = (unsigned)((n_chunks + 255) / 256);
 	const int ratio = fast / slow;
 	// the reciprocal rounded UP: (int)((float)sum * rinv) is C's truncating sum / ratio for |sum| <= 34 * 32768, ratio <= 32
 	const float rinv = __builtin_nextafterf((float)(1.0 / (double)ratio), __builtin_inff());
 	// outputs one wave can produce: 64 chunks' worth of input, +1 window finished for a neighbour, +1 rounding
 	const int wcap = ((int)((((u64)64 << chl2) * (u64)slow) / (u64)fast) + 6) & ~1;       /* + the spare element in front, even */
-	const size_t lds = (size_t)4 * wcap * sizeof(int16_t);
+	// small workgroups: about 12 KiB of staging each (2 waves at the wbfm ratios), so that one finds room beside the
+	// decimator's workgroups of the next run, which fill most of a CU's LDS
+	int wpb = 4;
+	while (wpb > 1 && (size_t)wpb * wcap * sizeof(int) > 12800)
+		wpb >>= 1;
+	const size_t lds = (size_t)wpb * wcap * sizeof(int);
+	if (lds > 65536)
+		return -1;
+	const unsigned grid = (unsigned)((n_chunks + 64 * wpb - 1) / (64 * wpb));
 	hipStream_t s = (hipStream_t)stream;
 	const unsigned mg = deemph_magic(a);
 	if (chl2 == 7)
-		hipLaunchKernelGGL((k_fm_deemph_apply_rs_t<7>), dim3(grid), dim3(256), lds, s, pcm_t, M, a, mg, start, fast, slow, rinv, wcap, out, dev);
+		hipLaunchKernelGGL((k_fm_deemph_apply_rs_t<7>), dim3(grid), dim3(64 * wpb), lds, s, pcm_t, M, a, mg, start, fast, slow, rinv, wcap, out, dev);
 	else
-		hipLaunchKernelGGL((k_fm_deemph_apply_rs_t<8>), dim3(grid), dim3(256), lds, s, pcm_t, M, a, mg, start, fast, slow, rinv, wcap, out, dev);
+		hipLaunchKernelGGL((k_fm_deemph_apply_rs_t<8>), dim3(grid), dim3(64 * wpb), lds, s, pcm_t, M, a, mg, start, fast, slow, rinv, wcap, out, dev);
 	LAUNCH_RET();
 }
 

@@ -132,7 +132,7 @@ int rxk_fm_deemph_apply(void *stream, const int16_t *pcm, unsigned long long M, 
  * levels above are rxk_fm_deemph_up/_top/_down), then replay + low_pass_real inline -> out[].  rxk_fm_deemph_tiled_ok
  * returns 0 or the chunk log2 (7/8) to hand to the decimator as pcm_chl2. */
 int rxk_fm_deemph_tiled_ok(int a, int group, int chunk, int fast, int slow);
-int rxk_fm_deemph_scan_t(void *stream, const int16_t *pcm_t, unsigned long long M, int a, int group, int chl2, int warm, int lo0, int hi0,
+int rxk_fm_deemph_scan_t(void *stream, const int16_t *pcm_t, unsigned long long M, int a, int group, int chl2, int warm, int lo0, int gap_w,
                          void *ctab, rxk_fm_dev *dev);
 int rxk_fm_deemph_up0(void *stream, unsigned long long n_chunks, int group, const void *ctab, int *p_tab, int *p_lo, int *p_gap);
 int rxk_fm_deemph_down0(void *stream, unsigned long long n_chunks, const void *ctab, const int *p_start, int *start);

@@ -72,7 +72,7 @@ struct rxgpu_fm_stream {
 	size_t stage_in_cap, stage_out_cap;
 	hipEvent_t ev_h2d[3];
 	/* de-emphasis geometry */
-	int group, warm, lo0, hi0;
+	int group, warm, lo0, hi0, gap_w;
 	int chunk;                           /* de-emphasis scan: samples per chunk */
 	int topcap_override;                 /* $RXGPU_DEEMPH_TOPCAP: forces the multi-level scan (tests) */
 	int flag_all;                        /* $RXGPU_FLAG_ALL: every libm discriminator sample goes through the host re-evaluation (tests) */
@@ -146,7 +146,7 @@ static int validate_params(const rxgpu_fm_params *p)
 
 /* worst-case samples until trajectories from the two ends of [lo0,hi0] are < a apart:
  * the gap g shrinks by at least floor(g/a) per sample (see k_fm_deemph_scan) */
-static int deemph_warm(int a, long long range)
+static int deemph_warm(int a, long long range, int *gap_end)
 {
 	int n = 0;
 	long long g = range;
@@ -154,6 +154,8 @@ static int deemph_warm(int a, long long range)
 		g -= g / a;
 		n++;
 	}
+	if (gap_end)
+		*gap_end = (int)g;            /* < a: what the bound has come down to (k_fm_deemph_scan_t takes it as the candidate count) */
 	return n + 1;
 }
 
@@ -165,7 +167,8 @@ static void deemph_geometry(rxgpu_fm_stream *s)
 	s->group = a <= 16 ? 16 : (a <= 64 ? 64 : 0);
 	if (a < 2 || avg < -32768 || avg > 32767)
 		s->group = 0;                 /* a == 1 or a carried state outside int16: the serial kernel */
-	s->warm = s->group ? (deemph_warm(a, (long long)s->hi0 - s->lo0) + 7) / 8 * 8 : 0;   /* whole 16-byte reads */
+	s->gap_w = 0;
+	s->warm = s->group ? (deemph_warm(a, (long long)s->hi0 - s->lo0, &s->gap_w) + 7) / 8 * 8 : 0;   /* whole 16-byte reads */
 	s->chunk = DEEMPH_CHUNK_MIN;
 	while (s->chunk < s->warm)
 		s->chunk *= 2;
@@ -396,7 +399,7 @@ static int run_audio_stages(rxgpu_fm_stream *s, hipStream_t st, unsigned long lo
 		int top = 0;
 		const unsigned long long n_chunks = (M + (1ull << chl2) - 1) >> chl2;
 		rxgpu_prof_begin_on("fm_deemph", st);
-		RX_K(rxk_fm_deemph_scan_t(st, pcm, M, p->deemph_a, g, chl2, s->warm, s->lo0, s->hi0, s->ctab, s->dev));
+		RX_K(rxk_fm_deemph_scan_t(st, pcm, M, p->deemph_a, g, chl2, s->warm, s->lo0, s->gap_w, s->ctab, s->dev));
 		cnt[0] = (n_chunks + RXK_DEEMPH_FAN - 1) / RXK_DEEMPH_FAN;
 		off[0] = 0;
 		RX_K(rxk_fm_deemph_up0(st, n_chunks, g, s->ctab, s->lvl_tab, s->lvl_lo, s->lvl_gap));
@@ -645,7 +648,14 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 	/* de-emphasis + resampler behind an fm discriminator: hand them the demodulated samples in the tiled layout their
 	 * lane-per-chunk kernels stream (rxk_fm_deemph_scan_t / _apply_rs_t).  $RXGPU_NO_TILED keeps the LDS-staged kernels. */
 	if (!split && p->deemph && s->group && p->rate_out2 > 0 && g->post == 1 && !p->dc_block_audio && !getenv("RXGPU_NO_TILED"))
-		s->tiled = rxk_fm_deemph_tiled_ok(p->deemph_a, s->group, s->chunk, p->rate_out, p->rate_out2);
+	{
+		/* $RXGPU_DEEMPH_CHUNK=256 forces the larger chunk where the warm-up would fit 128 (tests of that template; measured: no
+		 * gain -- the scan's warm-up weighs less, but the resampler's per-wave staging doubles and with it the LDS a workgroup needs
+		 * to find beside the decimator's) */
+		const char *force = getenv("RXGPU_DEEMPH_CHUNK");
+		const int chunk = (force && atoi(force) == 256 && s->chunk < 256) ? 256 : s->chunk;
+		s->tiled = rxk_fm_deemph_tiled_ok(p->deemph_a, s->group, chunk, p->rate_out, p->rate_out2);
+	}
 	if (!g->passes) {
 		const int fused_disc = g->fast && p->custom_atan == 1 && !split;
 		/* lowpassed[] is an intermediate of the fused chain: keep only the entries the seam kernel reads

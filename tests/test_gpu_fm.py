@@ -492,6 +492,22 @@ def test_tiled_audio_path_hostile_signals(sig):
     _check(iq, 8192, n_runs=2, pipelined=True, downsample=4)
 
 
+@pytest.mark.parametrize("params,block_len,n_runs", [
+    (dict(downsample=6), 8192, 3),
+    (dict(downsample=4, deemph_a=9), 2 * 4096, 2),
+    (dict(downsample=12, rate_out=96000, rate_out2=48000, deemph_a=15), 2 * 12 * 700, 2),
+    (dict(downsample=118), 2 * 131072, 2),
+])
+def test_tiled_audio_path_long_run_chunks(params, block_len, n_runs, monkeypatch):
+    """runs of 2^25 and more demodulated samples take 256-sample chunks even where the warm-up would fit 128
+    (the scan's warm-up per chunk weighs half as much); $RXGPU_DEEMPH_CHUNK=256 forces that choice on a short run"""
+    monkeypatch.setenv("RXGPU_DEEMPH_CHUNK", "256")
+    n_blocks = 4 * n_runs + 1
+    iq = sig_fm(n_blocks * block_len // 2, seed=56, amp=9000.0, noise=900)
+    _check(iq, block_len, n_runs=n_runs, pipelined=n_runs > 1, **params)
+    _check(_signals(40 * 8192)["dc"], 8192, n_runs=2, pipelined=True, downsample=4)
+
+
 def test_tiled_audio_path_multi_level_tree(monkeypatch):
     monkeypatch.setenv("RXGPU_DEEMPH_TOPCAP", "3")
     iq = sig_fm(64 * 16384 // 2, seed=66)
