@@ -196,18 +196,38 @@ __device__ __forceinline__ uint32_t dec_prefix(const uint32_t *slot, unsigned j,
 	return pk_add(slot[j], base);
 }
 
+// WIDE slots: the main loop leaves the SELECTION of the prefix inside the lane (which of its four samples ends the window) to the
+// reader -- once per output instead of once per lane and tile.  A record holds X = the biased prefix through the lane's four
+// samples and the three suffix sums behind samples 0, 1, 2 of the lane; the window's last sample e1 names wave, tile, lane and
+// sample, and with them what to take off: the suffix behind that sample and the scan's bias (511 per lane, 64 * 511 per tile).
+__device__ __forceinline__ uint32_t dec_prefix_wide(const uint4 *slot4, unsigned j, unsigned ds, unsigned e_off, uint32_t b1, uint32_t b2, uint32_t b3)
+{
+	const unsigned e1 = __umul24(j, ds) + e_off;
+	uint32_t base = e1 >= DEC_WAVE_SPAN ? b1 : 0u;
+	base = e1 >= 2 * DEC_WAVE_SPAN ? b2 : base;
+	base = e1 >= 3 * DEC_WAVE_SPAN ? b3 : base;
+	const uint4 rec = slot4[j];
+	const unsigned pos = e1 & (DEC_WAVE_SPAN - 1), r = pos & 3u;
+	const unsigned unb = (511u * (((pos >> 2) & 63u) + 1u) + 32704u * (pos >> 8)) & 0xffffu;
+	uint32_t suf = r == 0 ? rec.y : r == 1 ? rec.z : rec.w;
+	suf = r == 3 ? 0u : suf;
+	return pk_add(pk_sub(pk_sub(rec.x, unb), suf), base);
+}
+
 // DISC: also run the -A fast discriminator (F5/F6) for every output whose predecessor was completed
 // by this workgroup too (all but its first two), while the sums are still in LDS/registers; the
 // two seam outputs per workgroup and each block's libm sample are left to k_fm_disc.
-template <bool PRESCALED, bool ROTATE, bool DISC, bool DIV24>
+template <bool PRESCALED, bool ROTATE, bool DISC, bool DIV24, bool WIDE = false>
 __global__ __launch_bounds__(DEC_THREADS) void k_fm_decimate(
 	const u32x4 *__restrict__ iq, u64 T, int ds, int p0, unsigned magic, unsigned magic24,
 	uint32_t *__restrict__ lp_raw, uint32_t *__restrict__ head, uint32_t *__restrict__ tail, unsigned slot_cap,
 	int lp_sparse, int16_t *__restrict__ pcm, int pcm_chl2)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+	static_assert(!(WIDE && PRESCALED), "wide slots ride on the biased scan of the raw path");
 	uint32_t *slot = lds;
-	uint32_t *wtot = lds + slot_cap;
+	uint4 *slot4 = reinterpret_cast<uint4 *>(lds);              // WIDE: 16-byte records (dec_prefix_wide)
+	uint32_t *wtot = lds + (WIDE ? 4 : 1) * slot_cap;
 
 	// workgroup b runs on XCD b % 8 (observed placement): give every XCD one contiguous eighth of the stream so that
 	// the partial output lines of neighbouring spans meet in the same L2 instead of being written back one by one
@@ -239,9 +259,12 @@ __global__ __launch_bounds__(DEC_THREADS) void k_fm_decimate(
 			const unsigned rel = wave * DEC_WAVE_SPAN + (half * DEC_BATCH + u) * DEC_TILE + lane * 4;
 			uint32_t s0, s1, s2, s3;
 			dec_contrib<PRESCALED, ROTATE>(v[u], s0, s1, s2, s3, K);
-			const uint32_t c1 = s0, c2 = pk_add(c1, s1), c3 = pk_add(c2, s2), c4 = pk_add(c3, s3);
+			const uint32_t s23 = pk_add(s2, s3), s123 = pk_add(s1, s23);           // WIDE: the suffix sums the reader selects from
+			const uint32_t c1 = s0, c2 = pk_add(c1, s1), c3 = pk_add(c2, s2), c4 = WIDE ? pk_add(s0, s123) : pk_add(c3, s3);
 			uint32_t incl;
-			if (!PRESCALED)
+			if (WIDE)
+				incl = wave_scan_incl_biased(pk_add(c4, 511u));                    // stays biased: the reader takes the bias off
+			else if (!PRESCALED)
 				incl = pk_sub(wave_scan_incl_biased(pk_add(c4, 511u)), unbias);
 			else
 				incl = wave_scan_incl(c4);
@@ -260,13 +283,17 @@ __global__ __launch_bounds__(DEC_THREADS) void k_fm_decimate(
 			// cnt = 1..4 samples of this lane belong to window k-1: the prefix up to there goes to its slot.  No branch: every lane
 			// stores (the others into one spare slot), so that the tiles of a batch form one basic block
 			const bool hit = cnt > 0 && rel < span;
-			const uint32_t sel = cnt <= 1 ? c1 : cnt == 2 ? c2 : cnt == 3 ? c3 : c4;
-			slot[hit ? k - 1 : dummy] = pk_add(pk_add(run, pk_sub(incl, c4)), sel);
+			if (WIDE) {
+				slot4[hit ? k - 1 : dummy] = make_uint4(pk_add(run, incl), s123, s23, s3);
+			} else {
+				const uint32_t sel = cnt <= 1 ? c1 : cnt == 2 ? c2 : cnt == 3 ? c3 : c4;
+				slot[hit ? k - 1 : dummy] = pk_add(pk_add(run, pk_sub(incl, c4)), sel);
+			}
 			run = pk_add(run, (uint32_t)__builtin_amdgcn_readlane((int)incl, 63));
 		}
 	}
 	if (lane == 0)
-		wtot[wave] = run;
+		wtot[wave] = WIDE ? pk_sub(run, (uint32_t)((DEC_TILES * 32704u) & 0xffffu)) : run;    // WIDE: lane 63's bias of every tile
 	__syncthreads();
 
 	const uint32_t b1 = wtot[0], b2 = pk_add(b1, wtot[1]), b3 = pk_add(b2, wtot[2]);
@@ -275,7 +302,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_fm_decimate(
 	// P(j): the packed prefix up to the end of window j = slot[j] + the totals of the waves before the one that wrote it
 	// (the window's last sample, span-relative e1 = j*ds + ds - ph - 1, names that wave)
 	const unsigned e_off = (unsigned)ds - ph - 1u;
-#define PREFIX_AT(J) dec_prefix(slot, (J), (unsigned)ds, e_off, b1, b2, b3)
+#define PREFIX_AT(J) (WIDE ? dec_prefix_wide(slot4, (J), (unsigned)ds, e_off, b1, b2, b3) : dec_prefix(slot, (J), (unsigned)ds, e_off, b1, b2, b3))
 	// Every wave takes a contiguous quarter of the outputs, 64 consecutive ones per turn: output j = P(j) - P(j-1) and the
 	// discriminator also wants P(j-2) -- both sit in the neighbouring lanes (two wave-wide DPP shifts), the two values
 	// that cross a turn travel in SGPRs.  One LDS read and one prefix selection per output instead of three.
@@ -2713,11 +2740,15 @@ extern "C" int rxk_fm_decimate(void *stream, const int16_t *iq, u64 T, int ds, i
 	/* floor(q / ds) = (q << 8) * magic24 >> 32 is exact while q * ds < 2^24; q <= span + 4 + ds */
 	const unsigned magic24 = ((u64)(RXK_DEC_SPAN + 4 + ds) * (u64)ds < (1ull << 24)) ? (1u << 24) / (unsigned)ds + 1 : 0u;
 	const unsigned slot_cap = (RXK_DEC_SPAN + ds) / ds + 4 + 64;      /* + one turn of lanes past the last output (read, never used) */
-	const size_t shm = (size_t)(slot_cap + 4) * sizeof(uint32_t);
+	/* 16-byte slot records (the prefix selection left to the reader, dec_prefix_wide) where they stay small: raw input, ds >= 64
+	 * (at most 5 KiB of LDS per workgroup); $RXGPU_DEC_NARROW keeps the 4-byte slots (A/B) */
+	const bool wide = !prescaled && ds >= 64 && !getenv("RXGPU_DEC_NARROW");
+	const size_t shm = (size_t)((wide ? 4 : 1) * slot_cap + 4) * sizeof(uint32_t);
 	hipStream_t s = (hipStream_t)stream;
 	const u32x4 *p = (const u32x4 *)iq;
-#define GO3(PS, RT, DC, D24) hipLaunchKernelGGL((k_fm_decimate<PS, RT, DC, D24>), dim3(grid), dim3(DEC_THREADS), shm, s, p, T, ds, p0, \
+#define GO4(PS, RT, DC, D24, W) hipLaunchKernelGGL((k_fm_decimate<PS, RT, DC, D24, W>), dim3(grid), dim3(DEC_THREADS), shm, s, p, T, ds, p0, \
 		magic, magic24, lp_raw, head, tail, slot_cap, lp_sparse, pcm, pcm_chl2)
+#define GO3(PS, RT, DC, D24) do { if (!PS && wide) GO4(PS, RT, DC, D24, !PS); else GO4(PS, RT, DC, D24, false); } while (0)
 #define GO(PS, RT) do { \
 		if (pcm) { if (magic24) GO3(PS, RT, true, true); else GO3(PS, RT, true, false); } \
 		else { if (magic24) GO3(PS, RT, false, true); else GO3(PS, RT, false, false); } } while (0)
@@ -2726,6 +2757,7 @@ extern "C" int rxk_fm_decimate(void *stream, const int16_t *iq, u64 T, int ds, i
 	else GO(false, false);
 #undef GO
 #undef GO3
+#undef GO4
 	LAUNCH_RET();
 }
 
