@@ -2121,28 +2121,48 @@ __global__ __launch_bounds__(256) void k_fm_fifth_fused(
 	for (unsigned tt = 0; tt < tpw; tt++) {
 		const unsigned tile = tile0 + tt, t0 = tile * FF_RAW;
 		const bool first = tile == 0;
+		// Tiles after the first of this workgroup's walk CONTINUE the stream: the five samples in front of a level are the
+		// previous tile's last five, still in LDS -- one thread moves them to the front (the thread, or a lane of the wave, that
+		// overwrites the tail later in program order), nothing of the halo is loaded, converted or filtered again, and every
+		// pass is whole rounds of the workgroup: 512 vectors, 256 / 128 / 64 quads.
+		const bool cont = tt > 0;
 		// level 0: scale + rotate (t0 + rel is a multiple of 4: phases 0..3), de-interleaved into LDS.
 		// vector v4 holds V0[rel..rel+3], rel = 4 v4 - 36: E_0[2 v4 - 18 + {0,1}], O_0[2 v4 - 18 + {0,1}]
+		if (cont) {
+			if (tid == 255) {                              // V0[-5..-1] = O[-3], E[-2], O[-2], E[-1], O[-1] <- O[1021], E[1022], O[1022], E[1023], O[1023]
+				const uint32_t a0 = lo0[FF_RAW / 2 - 3 + FO0], a1 = le0[FF_RAW / 2 - 2 + FE0], a2 = lo0[FF_RAW / 2 - 2 + FO0],
+				               a3 = le0[FF_RAW / 2 - 1 + FE0], a4 = lo0[FF_RAW / 2 - 1 + FO0];
+				lo0[-3 + FO0] = a0; le0[-2 + FE0] = a1; lo0[-2 + FO0] = a2; le0[-1 + FE0] = a3; lo0[-1 + FO0] = a4;
+			}
 #pragma unroll
-		for (int u = 0; u < 3; u++) {
-			const int v4 = tid + 256 * u;
-			const int rel = 4 * v4 - 36;
-			if (v4 < NV && !(first && rel < 0)) {
+			for (int u = 0; u < 2; u++) {
+				const int v4 = 9 + tid + 256 * u;              // rel = 4 (tid + 256 u) >= 0
 				uint32_t s0, s1, s2, s3;
 				if (STAGE2) { s0 = w[u].x; s1 = w[u].y; s2 = w[u].z; s3 = w[u].w; }
-				else dec_contrib<false, ROTATE>(w[u], s0, s1, s2, s3, K);    // the decimator's packed scale + rotate: 24 instructions per 4 samples
+				else dec_contrib<false, ROTATE>(w[u], s0, s1, s2, s3, K);
 				*reinterpret_cast<uint2 *>(&le0[2 * v4 - 18 + FE0]) = make_uint2(s0, s2);
 				lo0[2 * v4 - 18 + FO0] = s1;
 				lo0[2 * v4 - 17 + FO0] = s3;
 			}
-		}
-		if (tt + 1 < tpw) {
+		} else {
 #pragma unroll
 			for (int u = 0; u < 3; u++) {
 				const int v4 = tid + 256 * u;
 				const int rel = 4 * v4 - 36;
-				w[u] = v4 < NV ? __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(braw + t0 + FF_RAW + rel)) : (u32x4)(0u);
+				if (v4 < NV && !(first && rel < 0)) {
+					uint32_t s0, s1, s2, s3;
+					if (STAGE2) { s0 = w[u].x; s1 = w[u].y; s2 = w[u].z; s3 = w[u].w; }
+					else dec_contrib<false, ROTATE>(w[u], s0, s1, s2, s3, K);    // the decimator's packed scale + rotate: 20 instructions per 4 samples
+					*reinterpret_cast<uint2 *>(&le0[2 * v4 - 18 + FE0]) = make_uint2(s0, s2);
+					lo0[2 * v4 - 18 + FO0] = s1;
+					lo0[2 * v4 - 17 + FO0] = s3;
+				}
 			}
+		}
+		if (tt + 1 < tpw) {                                    // the next tile continues: its 512 vectors, no halo
+#pragma unroll
+			for (int u = 0; u < 2; u++)
+				w[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(braw + t0 + FF_RAW + 4 * (tid + 256 * u)));
 		}
 		if (!EASE && first && tid == 0) {                  // V0[-5..-1] = O[-3], E[-2], O[-2], E[-1], O[-1]
 			lo0[-3 + FO0] = sm[0]; le0[-2 + FE0] = sm[1]; lo0[-2 + FO0] = sm[2]; le0[-1 + FE0] = sm[3]; lo0[-1 + FO0] = sm[4];
@@ -2150,7 +2170,12 @@ __global__ __launch_bounds__(256) void k_fm_fifth_fused(
 		__syncthreads();
 
 		// pass 0: outputs V1[i..i+3], i = -16 + 4q; they are E_1[i/2], O_1[i/2], E_1[i/2+1], O_1[i/2+1]
-		for (int q = tid; q < FF_RAW / 8 + 4; q += 256) {
+		if (FUSE >= 2 && cont && tid == 255) {                 // level 1's last five to its front, before this thread's quad overwrites them
+			const uint32_t a0 = lo1[FF_RAW / 4 - 3 + FO1], a1 = le1[FF_RAW / 4 - 2 + FE1], a2 = lo1[FF_RAW / 4 - 2 + FO1],
+			               a3 = le1[FF_RAW / 4 - 1 + FE1], a4 = lo1[FF_RAW / 4 - 1 + FO1];
+			lo1[-3 + FO1] = a0; le1[-2 + FE1] = a1; lo1[-2 + FO1] = a2; le1[-1 + FE1] = a3; lo1[-1 + FO1] = a4;
+		}
+		for (int q = cont ? tid + 4 : tid; q < FF_RAW / 8 + 4; q += 256) {
 			if (first && q < 4)
 				continue;
 			const int i = -16 + 4 * q;
@@ -2172,7 +2197,12 @@ __global__ __launch_bounds__(256) void k_fm_fifth_fused(
 			}
 			__syncthreads();
 			// pass 1: outputs V2[i..i+3], i = -8 + 4q
-			for (int q = tid; q < FF_RAW / 16 + 2; q += 256) {
+			if (FUSE >= 3 && cont && tid == 127) {             // level 2's last five to its front (thread 127 writes that tail below)
+				const uint32_t a0 = lo2[FF_RAW / 8 - 3 + FO2], a1 = le2[FF_RAW / 8 - 2 + FE2], a2 = lo2[FF_RAW / 8 - 2 + FO2],
+				               a3 = le2[FF_RAW / 8 - 1 + FE2], a4 = lo2[FF_RAW / 8 - 1 + FO2];
+				lo2[-3 + FO2] = a0; le2[-2 + FE2] = a1; lo2[-2 + FO2] = a2; le2[-1 + FE2] = a3; lo2[-1 + FO2] = a4;
+			}
+			for (int q = cont ? tid + 2 : tid; q < FF_RAW / 16 + 2; q += 256) {
 				if (first && q < 2)
 					continue;
 				const int i = -8 + 4 * q;
@@ -3085,7 +3115,7 @@ extern "C" int rxk_fm_fifth_fused(void *stream, const void *in, int stage2, int 
 {
 	hipStream_t s = (hipStream_t)stream;
 	const unsigned tiles = n / FF_RAW;
-	const unsigned tpw = tiles % 8 == 0 ? 8 : tiles % 4 == 0 ? 4 : tiles % 2 == 0 ? 2 : 1;   // tiles one workgroup walks
+	const unsigned tpw = tiles % 16 == 0 ? 16 : tiles % 8 == 0 ? 8 : tiles % 4 == 0 ? 4 : tiles % 2 == 0 ? 2 : 1;   // tiles one workgroup walks
 	const u64 seam_threads = (n_blocks + 1) * 16;
 	const unsigned sgrid = (unsigned)((seam_threads + 255) / 256);
 	const unsigned grid = (unsigned)(n_blocks * (tiles / tpw));
@@ -3217,7 +3247,7 @@ extern "C" int rxk_pw_fifth_fused(void *stream, const int16_t *in, unsigned long
 {
 	hipStream_t s = (hipStream_t)stream;
 	const unsigned tiles = n / FF_RAW;
-	const unsigned tpw = tiles % 8 == 0 ? 8 : tiles % 4 == 0 ? 4 : tiles % 2 == 0 ? 2 : 1;
+	const unsigned tpw = tiles % 16 == 0 ? 16 : tiles % 8 == 0 ? 8 : tiles % 4 == 0 ? 4 : tiles % 2 == 0 ? 2 : 1;
 	const unsigned grid = (unsigned)(n_bufs * (tiles / tpw));
 	const uint32_t *p = (const uint32_t *)in;
 	uint32_t *o = (uint32_t *)out;
