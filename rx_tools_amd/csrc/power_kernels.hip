@@ -169,13 +169,22 @@ __global__ __launch_bounds__(256) void k_pw_fft4096(
 	const int *__restrict__ window, const uint32_t *__restrict__ twiddle, int ppg, i64 *__restrict__ avg)
 {
 	__shared__ __attribute__((aligned(16))) uint32_t xa[F4K_BUF];
-	__shared__ __attribute__((aligned(16))) uint32_t xb[F4K_BUF];
+	__shared__ __attribute__((aligned(16))) uint32_t xb[F4K_BUF + 16 * 16];
 	__shared__ i64 red[8];
 	const int tid = threadIdx.x;
 	const int tune = blockIdx.x;
 	const int p_begin = blockIdx.y * ppg;
 	const int p_end = min(passes, p_begin + ppg);
 	const unsigned hi4 = tid >> 4, lo4 = tid & 15;
+	// Banks of the first transpose's ds_write_b32 (row = 16 r + lo4, column = hi4, rows 20 dwords apart): the LDS serves 32 lanes per
+	// cycle from 32 banks and 20 k mod 32 takes only EIGHT values, so rows k and k + 8 of a half-wave met in one bank (rocprofv3:
+	// a third of the LDS cycles were conflicts).  Rows with bit 3 set sit 2 dwords further inside their 20: 8 x 4 different banks.
+	// Such rows are 8-byte aligned, the read side takes its 16 bytes as two 8-byte halves (ds_read2_b64).
+	const unsigned xa_w = lo4 * F4K_ROW + hi4 + 2u * ((lo4 >> 3) & 1u), xa_r = (unsigned)tid * F4K_ROW + 2u * (((unsigned)tid >> 3) & 1u);
+	// the second transpose (row = 16 hi4 + r, column = lo4) put the two 16-row groups of a half-wave on the same 16 banks:
+	// every group starts 16 dwords further than 16 rows would put it (336 g: the bank offset alternates 0, 16; rows stay 16-byte
+	// aligned for the ds_read_b128 side)
+	const unsigned xb_w = (hi4 * 16u) * F4K_ROW + lo4 + 16u * hi4, xb_r = (unsigned)tid * F4K_ROW + 16u * hi4;
 	const unsigned base_b = __brev(hi4) >> 28;           // rev4 of bits 11..8
 	const unsigned base_c = __brev((unsigned)tid) >> 24; // rev8 of bits 11..4
 	uint32_t wcoef[16];
@@ -221,23 +230,23 @@ __global__ __launch_bounds__(256) void k_pw_fft4096(
 			// transpose 1: next field is bits 7..4; row (hi4', lo4) gets the 16 values of that field
 #pragma unroll
 			for (int r = 0; r < 16; r++)
-				xa[(r * 16 + lo4) * F4K_ROW + hi4] = v[r];
+				xa[xa_w + r * 16 * F4K_ROW] = v[r];
 			__syncthreads();
 #pragma unroll
 			for (int c = 0; c < 4; c++) {
-				const uint4 t4 = *reinterpret_cast<const uint4 *>(&xa[tid * F4K_ROW + 4 * c]);
-				v[4 * c] = t4.x; v[4 * c + 1] = t4.y; v[4 * c + 2] = t4.z; v[4 * c + 3] = t4.w;
+				const uint2 ta = *reinterpret_cast<const uint2 *>(&xa[xa_r + 4 * c]), tb = *reinterpret_cast<const uint2 *>(&xa[xa_r + 4 * c + 2]);
+				v[4 * c] = ta.x; v[4 * c + 1] = ta.y; v[4 * c + 2] = tb.x; v[4 * c + 3] = tb.y;
 			}
 			// stages 4-7: n = hi4<<8 | r<<4 | lo4
 			radix16_pass<7, false>(v, twiddle, base_b);
 			// transpose 2: next field is bits 3..0; row = bits 11..4
 #pragma unroll
 			for (int r = 0; r < 16; r++)
-				xb[(hi4 * 16 + r) * F4K_ROW + lo4] = v[r];
+				xb[xb_w + r * F4K_ROW] = v[r];
 			__syncthreads();
 #pragma unroll
 			for (int c = 0; c < 4; c++) {
-				const uint4 t4 = *reinterpret_cast<const uint4 *>(&xb[tid * F4K_ROW + 4 * c]);
+				const uint4 t4 = *reinterpret_cast<const uint4 *>(&xb[xb_r + 4 * c]);
 				v[4 * c] = t4.x; v[4 * c + 1] = t4.y; v[4 * c + 2] = t4.z; v[4 * c + 3] = t4.w;
 			}
 			// stages 8-11: n = tid<<4 | r
