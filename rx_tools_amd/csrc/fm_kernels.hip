@@ -1884,12 +1884,11 @@ __global__ __launch_bounds__(256) void k_fm_fifth_pass(
 	unsigned out_stride, const int16_t *__restrict__ hist_in, int16_t *__restrict__ hist_out)
 {
 	const unsigned n_out = (n_in + 1) / 2;
-	const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
-	if (gid >= n_blocks * (u64)n_out)
+	const unsigned k = blockIdx.x * 256 + threadIdx.x;        // grid: x over a block's outputs, y over the callback blocks
+	if (k >= n_out)
 		return;
-	const u64 blk = gid / n_out;
-	const unsigned k = (unsigned)(gid - blk * n_out);
 	const unsigned kl = n_out - 1;                 // K' of any (equal-length) block
+	for (u64 blk = blockIdx.y; blk < n_blocks; blk += gridDim.y) {
 	int ti[6], tq[6];
 #pragma unroll
 	for (int t = 0; t < 6; t++) {
@@ -1921,6 +1920,7 @@ __global__ __launch_bounds__(256) void k_fm_fifth_pass(
 			hist_out[6 + t] = (int16_t)tq[t];
 		}
 	}
+	}
 }
 
 // ------------------------------------------------------------------ F3 fused: first 1-3 passes in LDS
@@ -1944,17 +1944,33 @@ __device__ __forceinline__ uint32_t fifth_pk(uint32_t a, uint32_t b, uint32_t c,
 	return __builtin_bit_cast(uint32_t, sum >> (ff_s16x2)(4));
 }
 
-// the same window in the reference's int arithmetic (rtl_fm.c:423/431), for levels whose sums exceed int16
+// the same window in the reference's int arithmetic (rtl_fm.c:423/431), for levels whose sums exceed int16.  The levels this
+// is used on hold values below 2^14 in magnitude (raw samples are at most 128 after the scale, every pass doubles at most, six
+// passes at most in front of it), so the three pair sums still fit packed int16; each component's 32-bit sum is then three
+// v_mad_i32_i16 (op_sel picks the half), and shift + pack take three more: 12 instructions instead of ~30 of unpacking
 __device__ __forceinline__ uint32_t fifth_pk32(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t e, uint32_t f)
+{
+	const uint32_t af = pk_add(a, f), be = pk_add(b, e), cd = pk_add(c, d);
+	int si, sq;
+	asm("v_mad_i32_i16 %0, %2, 1, 0\n\tv_mad_i32_i16 %1, %2, 1, 0 op_sel:[1,0,0,0]\n\t"
+	    "v_mad_i32_i16 %0, %3, 5, %0\n\tv_mad_i32_i16 %1, %3, 5, %1 op_sel:[1,0,0,0]\n\t"
+	    "v_mad_i32_i16 %0, %4, 10, %0\n\tv_mad_i32_i16 %1, %4, 10, %1 op_sel:[1,0,0,0]"
+	    : "=&v"(si), "=&v"(sq) : "v"(af), "v"(be), "v"(cd));
+	// (si >> 4) & 0xffff | (sq >> 4) << 16
+	return (uint32_t)__builtin_amdgcn_ubfe((unsigned)si, 4u, 16u) | (((unsigned)sq << 12) & 0xffff0000u);
+}
+// ... and for inputs of any magnitude (rx_power's buffers are raw int16)
+__device__ __forceinline__ uint32_t fifth_int(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t e, uint32_t f)
 {
 	const int si = (lo16(a) + (lo16(b) + lo16(e)) * 5 + (lo16(c) + lo16(d)) * 10 + lo16(f)) >> 4;
 	const int sq = (hi16(a) + (hi16(b) + hi16(e)) * 5 + (hi16(c) + hi16(d)) * 10 + hi16(f)) >> 4;
 	return pack_iq(si, sq);
 }
-template <bool WIDE>
+// MODE 0: packed int16 (sums below 2^15), 1: 32-bit sums of values below 2^14, 2: 32-bit sums of anything
+template <int MODE>
 __device__ __forceinline__ uint32_t fifth_any(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t e, uint32_t f)
 {
-	return WIDE ? fifth_pk32(a, b, c, d, e, f) : fifth_pk(a, b, c, d, e, f);
+	return MODE == 0 ? fifth_pk(a, b, c, d, e, f) : MODE == 1 ? fifth_pk32(a, b, c, d, e, f) : fifth_int(a, b, c, d, e, f);
 }
 
 template <bool ROTATE>
@@ -1989,7 +2005,7 @@ __device__ uint32_t level_val(const uint32_t *__restrict__ blk_raw, int idx)
 #pragma unroll
 		for (int k = 0; k < 6; k++)
 			t[k] = level_val<P - 1, ROTATE, STAGE2>(blk_raw, 2 * idx - 5 + k);
-		return fifth_any<STAGE2>(t[0], t[1], t[2], t[3], t[4], t[5]);
+		return fifth_any<STAGE2 ? 2 : 0>(t[0], t[1], t[2], t[3], t[4], t[5]);
 	}
 }
 
@@ -2033,7 +2049,7 @@ __global__ void k_fm_fifth_seams(const uint32_t *__restrict__ iq, u64 n_blocks, 
 // consecutive outputs read consecutive words of each array, so a lane's four outputs come from two
 // aligned b128 reads per array with no bank conflict (a stride-8-dword layout was 8-way conflicted).
 // ev/od point at E[i-2] and O[i-3] for the quad's first output i.
-template <bool WIDE>
+template <int WIDE>
 __device__ __forceinline__ uint4 fifth_quad_eo(const uint32_t *__restrict__ ev, const uint32_t *__restrict__ od)
 {
 	const uint4 e0 = *reinterpret_cast<const uint4 *>(ev), e1 = *reinterpret_cast<const uint4 *>(ev + 4);
@@ -2108,6 +2124,9 @@ __global__ __launch_bounds__(256) void k_fm_fifth_fused(
 	const int tid = threadIdx.x;
 	const scale_k K = scale_consts();
 	constexpr int NV = (FF_RAW + 36) / 4;                  // 521 vectors of 4 samples: the tile + 36 of left halo
+	// arithmetic of the passes: packed int16 on the raw stream, 32-bit sums behind it -- of bounded values in rx_fm's cascade
+	// (passes 4-6), of anything in rx_power's buffers
+	constexpr int FMODE = !STAGE2 ? 0 : (EASE ? 2 : 1);
 
 	// a workgroup walks `tpw` consecutive tiles; the next tile's samples are in flight while this one is computed
 	u32x4 w[3];
@@ -2179,7 +2198,7 @@ __global__ __launch_bounds__(256) void k_fm_fifth_fused(
 			if (first && q < 4)
 				continue;
 			const int i = -16 + 4 * q;
-			uint4 o = fifth_quad_eo<STAGE2>(&le0[i - 2 + FE0], &lo0[i - 3 + FO0]);
+			uint4 o = fifth_quad_eo<FMODE>(&le0[i - 2 + FE0], &lo0[i - 3 + FO0]);
 			if (EASE && first)
 				ease_fix(o, i, le0, lo0, FE0, FO0);
 			if (FUSE == 1) {
@@ -2206,7 +2225,7 @@ __global__ __launch_bounds__(256) void k_fm_fifth_fused(
 				if (first && q < 2)
 					continue;
 				const int i = -8 + 4 * q;
-				uint4 o = fifth_quad_eo<STAGE2>(&le1[i - 2 + FE1], &lo1[i - 3 + FO1]);
+				uint4 o = fifth_quad_eo<FMODE>(&le1[i - 2 + FE1], &lo1[i - 3 + FO1]);
 				if (EASE && first)
 					ease_fix(o, i, le1, lo1, FE1, FO1);
 				if (FUSE == 2) {
@@ -2227,7 +2246,7 @@ __global__ __launch_bounds__(256) void k_fm_fifth_fused(
 			// pass 2: outputs V3[i..i+3], i = 4q
 			if (tid < FF_RAW / 32) {
 				const int i = 4 * tid;
-				uint4 o = fifth_quad_eo<STAGE2>(&le2[i - 2 + FE2], &lo2[i - 3 + FO2]);
+				uint4 o = fifth_quad_eo<FMODE>(&le2[i - 2 + FE2], &lo2[i - 3 + FO2]);
 				if (EASE && first)
 					ease_fix(o, i, le2, lo2, FE2, FO2);
 				*reinterpret_cast<uint4 *>(bout + t0 / 8 + i) = o;
@@ -3049,19 +3068,18 @@ extern "C" int rxk_fm_fifth_pass(void *stream, const void *in, int in_is_raw, in
                                  const int16_t *hist_in, int16_t *hist_out)
 {
 	const unsigned n_out = (n_in + 1) / 2;
-	const u64 total = n_blocks * (u64)n_out;
-	if (!total)
+	if (!n_blocks || !n_out)
 		return 0;
-	const unsigned grid = (unsigned)((total + 255) / 256);
+	const dim3 grid((n_out + 255) / 256, (unsigned)(n_blocks < 65535 ? n_blocks : 65535));
 	hipStream_t s = (hipStream_t)stream;
 	if (!in_is_raw)
-		hipLaunchKernelGGL((k_fm_fifth_pass<false, true, false>), dim3(grid), dim3(256), 0, s, in, n_blocks, n_in, in_stride, out, out_stride, hist_in, hist_out);
+		hipLaunchKernelGGL((k_fm_fifth_pass<false, true, false>), grid, dim3(256), 0, s, in, n_blocks, n_in, in_stride, out, out_stride, hist_in, hist_out);
 	else if (prescaled)
-		hipLaunchKernelGGL((k_fm_fifth_pass<true, true, false>), dim3(grid), dim3(256), 0, s, in, n_blocks, n_in, in_stride, out, out_stride, hist_in, hist_out);
+		hipLaunchKernelGGL((k_fm_fifth_pass<true, true, false>), grid, dim3(256), 0, s, in, n_blocks, n_in, in_stride, out, out_stride, hist_in, hist_out);
 	else if (rotate)
-		hipLaunchKernelGGL((k_fm_fifth_pass<true, false, true>), dim3(grid), dim3(256), 0, s, in, n_blocks, n_in, in_stride, out, out_stride, hist_in, hist_out);
+		hipLaunchKernelGGL((k_fm_fifth_pass<true, false, true>), grid, dim3(256), 0, s, in, n_blocks, n_in, in_stride, out, out_stride, hist_in, hist_out);
 	else
-		hipLaunchKernelGGL((k_fm_fifth_pass<true, false, false>), dim3(grid), dim3(256), 0, s, in, n_blocks, n_in, in_stride, out, out_stride, hist_in, hist_out);
+		hipLaunchKernelGGL((k_fm_fifth_pass<true, false, false>), grid, dim3(256), 0, s, in, n_blocks, n_in, in_stride, out, out_stride, hist_in, hist_out);
 	LAUNCH_RET();
 }
 
