@@ -1614,11 +1614,17 @@ __global__ void k_fm_deemph_down0(u64 n_chunks, const uint4 *__restrict__ ctab, 
 	if (first >= n_chunks)
 		return;
 	const int cnt = (int)((n_chunks - first) < DEEMPH_FAN ? (n_chunks - first) : DEEMPH_FAN);
+	uint4 t[DEEMPH_FAN];                                    // all of the parent's tables on their way before the (dependent) walk starts
+#pragma unroll
+	for (int i = 0; i < DEEMPH_FAN; i++)
+		t[i] = ctab[first + (i < cnt ? i : cnt - 1)];
 	int s = p_start[parent];
-	for (int i = 0; i < cnt; i++) {
-		start[first + i] = s;
-		s = ctab_apply(ctab[first + i], s);
-	}
+#pragma unroll
+	for (int i = 0; i < DEEMPH_FAN; i++)
+		if (i < cnt) {
+			start[first + i] = s;
+			s = ctab_apply(t[i], s);
+		}
 }
 
 // floor(num / den) for num < 2^52 (declared with the resampler below)
