@@ -1586,6 +1586,91 @@ __global__ __launch_bounds__(256) void k_fm_deemph_scan_t(
 	ctab[c] = make_uint4((uint32_t)lo_start, ((uint32_t)lo_end & 0xffffu) | ((uint32_t)gap << 16), (uint32_t)m64, (uint32_t)(m64 >> 32));
 }
 
+// The same scan for 128-sample chunks with every byte of the stream read ONCE.  k_fm_deemph_scan_t reads a chunk's tail twice:
+// as the right-hand neighbour's warm-up and as the chunk's own samples, several microseconds apart -- at the -M wbfm rates that is
+// 0.6 GB more per 8 GiB of capture, and the kernel runs at memory speed.  Here a lane loads its chunk's 16 units into registers
+// first, and the warm-up of lane L walks the registers of lane L - 1 (one wave_shr:1 DPP move per dword).  A wave therefore
+// covers 63 chunks: its lane 0 only supplies the chunk in front of them (1.6 % of the stream is loaded by two waves).
+template <int GS>
+__global__ __launch_bounds__(256) void k_fm_deemph_scan_r(
+	const int16_t *__restrict__ pcm_t, u64 M, int a, unsigned magic, int warm, int lo0, int gap_w,
+	uint4 *__restrict__ ctab, rxk_fm_dev *__restrict__ dev)
+{
+	constexpr int CHL2 = 7, CH = 1 << CHL2, UPC = CH / 8;
+	const int lane = threadIdx.x & 63;
+	const u64 wv = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+	const u64 n_chunks = (M + CH - 1) >> CHL2;
+	if (wv * 63 >= n_chunks)
+		return;
+	const i64 cs = (i64)(wv * 63) + lane - 1;                 // lane 0: the chunk in front of the wave's 63
+	const bool valid = lane >= 1 && (u64)cs < n_chunks;
+	const u64 c = cs < 0 ? 0 : ((u64)cs < n_chunks ? (u64)cs : n_chunks - 1);      // lanes without a chunk load a neighbour's (unused)
+	const u64 c0 = c << CHL2;
+	const int n = (int)((M - c0) < (u64)CH ? (M - c0) : (u64)CH);
+	const int h = a / 2;
+	const uint4 *row = tile_unit(pcm_t, c, CHL2);
+	uint4 own[UPC];
+#pragma unroll
+	for (int u = 0; u < UPC; u++)
+		own[u] = row[(size_t)u * 64];
+	// warm-up over the previous chunk's tail: lane L - 1's registers (see k_fm_deemph_scan_t for the one-trajectory argument)
+	int nl = de_state(lo0, h);
+	const int u0 = (CH - warm) >> 3;
+#pragma unroll
+	for (int u = 0; u < UPC; u++) {
+		if (u >= u0) {
+			const uint32_t ww[4] = {
+				(uint32_t)__builtin_amdgcn_update_dpp(0, (int)own[u].x, 0x138, 0xf, 0xf, false),
+				(uint32_t)__builtin_amdgcn_update_dpp(0, (int)own[u].y, 0x138, 0xf, 0xf, false),
+				(uint32_t)__builtin_amdgcn_update_dpp(0, (int)own[u].z, 0x138, 0xf, 0xf, false),
+				(uint32_t)__builtin_amdgcn_update_dpp(0, (int)own[u].w, 0x138, 0xf, 0xf, false)};
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				de_step<0>(ww[k], nl, magic, -64);
+				de_step<1>(ww[k], nl, magic, -64);
+			}
+		}
+	}
+	int lo = de_avg(nl, h), gap = gap_w;
+	if (cs <= 0) {                                            // the run's first chunk: the carried state, no candidates
+		lo = dev->in_deemph_avg;
+		gap = 0;
+	}
+	if (gap >= GS) {                                          // excluded by the host (gap_w < a <= GS); checked anyway
+		atomicExch(&dev->err, 1);
+		gap = GS - 1;
+	}
+	typedef typename deemph_mask<GS>::type MASK;
+	const int lo_start = lo;
+	MASK mask = (MASK)(((MASK)1 << gap) - 1);
+	int N = de_state(lo, h), cm6 = gap << 6;                  // r6 < cm6  <=>  remainder + 1 < number of distinct candidates
+	const int na6 = -(a << 6);
+	const int nu = n >> 3;
+#pragma unroll
+	for (int u = 0; u < UPC; u++) {
+		const uint32_t ww[4] = {own[u].x, own[u].y, own[u].z, own[u].w};
+		if (u < nu) {
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				int r6 = de_step_r<0>(ww[k], N, magic, -64, na6);
+				if (__builtin_expect(r6 < cm6, 0)) { de_merge(mask, r6 >> 6); cm6 -= 64; }
+				r6 = de_step_r<1>(ww[k], N, magic, -64, na6);
+				if (__builtin_expect(r6 < cm6, 0)) { de_merge(mask, r6 >> 6); cm6 -= 64; }
+			}
+		} else if (u == nu && (n & 7)) {                      // the ragged end of the run
+			for (int k = 0; k < (n & 7); k++) {
+				const int r6 = (k & 1) ? de_step_r<1>(ww[k >> 1], N, magic, -64, na6) : de_step_r<0>(ww[k >> 1], N, magic, -64, na6);
+				if (r6 < cm6) { de_merge(mask, r6 >> 6); cm6 -= 64; }
+			}
+		}
+	}
+	if (!valid)
+		return;
+	const int lo_end = de_avg(N, h);
+	const u64 m64 = (u64)mask;
+	ctab[c] = make_uint4((uint32_t)lo_start, ((uint32_t)lo_end & 0xffffu) | ((uint32_t)gap << 16), (uint32_t)m64, (uint32_t)(m64 >> 32));
+}
+
 // first tree level on compact tables: thread (parent, k) walks the parent's 16 chunk tables
 __global__ void k_fm_deemph_up0(u64 n_chunks, int gs, const uint4 *__restrict__ ctab, int *__restrict__ p_tab, int *__restrict__ p_lo,
                                 int *__restrict__ p_gap)
@@ -2821,7 +2906,13 @@ extern "C" int rxk_fm_decimate_small(void *stream, const int16_t *iq, u64 T, int
 {
 	const unsigned span = dsm_span(ds);
 	const unsigned grid = ((unsigned)((T + span - 1) / span) + 7u) & ~7u;
-	const size_t lds = (size_t)(span + 2 * DSM_HALO + 8) * 4;
+	/* the staged span, padded to a fifth of the CU's LDS: five workgroups per CU (20 waves) run the kernel as fast as eight do,
+	 * and the audio stages of the previous run -- long, latency-bound waves on the other stream -- always find slots beside them
+	 * (A/B in one process at ds = 6: 2 % on the pipelined step; $RXGPU_DSM_LDS sets another floor) */
+	size_t lds = (size_t)(span + 2 * DSM_HALO + 8) * 4;
+	const size_t lds_floor = getenv("RXGPU_DSM_LDS") ? (size_t)atoi(getenv("RXGPU_DSM_LDS")) : 32000;
+	if (lds < lds_floor && lds_floor <= 65536)
+		lds = lds_floor;
 	hipStream_t s = (hipStream_t)stream;
 	const u32x4 *p = (const u32x4 *)iq;
 	const bool four = (span + 2 * DSM_HALO) / 4 <= 1024;
@@ -2986,6 +3077,15 @@ extern "C" int rxk_fm_deemph_scan_t(void *stream, const int16_t *pcm_t, u64 M, i
 	const unsigned grid = (unsigned)((n_chunks + 255) / 256);
 	hipStream_t s = (hipStream_t)stream;
 	const unsigned mg = deemph_magic(a);
+	if (chl2 == 7 && !getenv("RXGPU_SCAN_T")) {
+		/* 128-sample chunks: the chunk in registers, the warm-up from the neighbouring lane; 63 chunks per wave */
+		const unsigned rgrid = (unsigned)(((n_chunks + 62) / 63 + 3) / 4);
+		if (group == 16)
+			hipLaunchKernelGGL((k_fm_deemph_scan_r<16>), dim3(rgrid), dim3(256), 0, s, pcm_t, M, a, mg, warm, lo0, gap_w, (uint4 *)ctab, dev);
+		else
+			hipLaunchKernelGGL((k_fm_deemph_scan_r<64>), dim3(rgrid), dim3(256), 0, s, pcm_t, M, a, mg, warm, lo0, gap_w, (uint4 *)ctab, dev);
+		LAUNCH_RET();
+	}
 #define GO(GS, CL) hipLaunchKernelGGL((k_fm_deemph_scan_t<GS, CL>), dim3(grid), dim3(256), 0, s, pcm_t, M, a, mg, warm, lo0, gap_w, (uint4 *)ctab, dev)
 	if (group == 16) { if (chl2 == 7) GO(16, 7); else GO(16, 8); }
 	else { if (chl2 == 7) GO(64, 7); else GO(64, 8); }

@@ -76,7 +76,11 @@ static int init_locked(int device)
 		int lo_p = 0, hi_p = 0;
 		if (hipDeviceGetStreamPriorityRange(&lo_p, &hi_p) != hipSuccess)
 			lo_p = hi_p = 0;
-		RX_HIP(hipStreamCreateWithPriority(&g_stream2, hipStreamNonBlocking, hi_p));
+		int prio = hi_p;
+		const char *e = getenv("RXGPU_B_PRIO");                 /* experiment switch: "normal" / "low" */
+		if (e && !strcmp(e, "normal")) prio = 0;
+		if (e && !strcmp(e, "low")) prio = lo_p;
+		RX_HIP(hipStreamCreateWithPriority(&g_stream2, hipStreamNonBlocking, prio));
 	}
 	g_device = device;
 	return RXGPU_OK;

@@ -7,10 +7,11 @@ from bench import device_capture
 L = R.lib(); R.check(L.rxgpu_init(0))
 blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 switch = sys.argv[2] if len(sys.argv) > 2 else "RXGPU_DEC_NARROW"
+ds = int(sys.argv[3]) if len(sys.argv) > 3 else 118
 bl = 2 * 131072
 d_iq = device_capture(torch, torch.device("cuda"), blocks * 131072, seed=5)
-d_out = torch.zeros(blocks * 131072 // 118 + 64, dtype=torch.int16, device="cuda")
-s = R.FmStream(R.FmParams.wbfm(downsample=118), blocks, bl)
+d_out = torch.zeros(blocks * 131072 // ds + 64, dtype=torch.int16, device="cuda")
+s = R.FmStream(R.FmParams.wbfm(downsample=ds), blocks, bl)
 def dump(names):
     out = {}
     for n in names:
@@ -20,7 +21,7 @@ def dump(names):
     return out
 for rep in range(4):
     for on in (1, 0):
-        if on: os.environ[switch] = "1"
+        if on: os.environ[switch] = sys.argv[4] if len(sys.argv) > 4 else "1"
         else: os.environ.pop(switch, None)
         for _ in range(3): s.run(d_iq.data_ptr(), blocks, bl, d_out.data_ptr(), d_out.numel())
         L.rxgpu_prof_reset(); L.rxgpu_prof_enable(2)
@@ -30,5 +31,5 @@ for rep in range(4):
         s.wait()
         dt = (time.perf_counter() - t0) / k
         L.rxgpu_prof_enable(0)
-        print((switch + "=1" if on else "default").ljust(22), "us/step", round(dt * 1e6, 1), dump(["fm_decimate", "fm_disc", "fm_deemph"]),
+        print((switch + "=1" if on else "default").ljust(22), "us/step", round(dt * 1e6, 1), dump(["fm_decimate", "fm_disc", "fm_deemph", "fm_resample"]),
               "TS/s", round(blocks * 131072 / dt / 1e12, 3), flush=True)
