@@ -3245,7 +3245,11 @@ extern "C" int rxk_fm_fifth_fused(void *stream, const void *in, int stage2, int 
 	const unsigned grid = (unsigned)(n_blocks * (tiles / tpw));
 	const uint32_t *p = (const uint32_t *)in;
 #define SEAMS(RT, S2) hipLaunchKernelGGL((k_fm_fifth_seams<RT, S2>), dim3(sgrid), dim3(256), 0, s, p, n_blocks, n, fuse, hist_in, seams, hist_out)
-#define FUSED(F, RT, S2) hipLaunchKernelGGL((k_fm_fifth_fused<F, RT, S2, false>), dim3(grid), dim3(256), 0, s, p, n, tiles, tpw, seams, out, n, n >> F)
+	/* the raw stage's workgroups take a fifth of the CU's LDS each (15 KiB of tiles + this pad): with eight per CU the kernel is no
+	 * faster, and the later passes / discriminator / audio stages of the previous run on the other stream wait for wave slots
+	 * (A/B in one process, -F ds=128 pipelined: 0.92 -> 0.98 TSample/s; $RXGPU_FF_PAD sets another pad) */
+	const size_t pad = stage2 ? 0 : getenv("RXGPU_FF_PAD") ? (size_t)atoi(getenv("RXGPU_FF_PAD")) : 17000;
+#define FUSED(F, RT, S2) hipLaunchKernelGGL((k_fm_fifth_fused<F, RT, S2, false>), dim3(grid), dim3(256), pad, s, p, n, tiles, tpw, seams, out, n, n >> F)
 #define GO(RT, S2) do { SEAMS(RT, S2); if (fuse == 1) FUSED(1, RT, S2); else if (fuse == 2) FUSED(2, RT, S2); else FUSED(3, RT, S2); } while (0)
 	if (stage2) GO(false, true);
 	else if (rotate) GO(true, false);
