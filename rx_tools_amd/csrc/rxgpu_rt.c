@@ -72,15 +72,12 @@ static int init_locked(int device)
 	RX_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
 	RX_HIP(hipStreamCreateWithFlags(&g_stream3, hipStreamNonBlocking));
 	{
-		/* the tail stream carries many small kernels behind a saturating one: give it the high priority */
+		/* the tail stream carries many small kernels behind a saturating one: give it the high priority (measured: normal or
+		 * low priority changes nothing -- what those kernels wait for is wave slots, see rxk_fm_decimate_small / rxk_fm_fifth_fused) */
 		int lo_p = 0, hi_p = 0;
 		if (hipDeviceGetStreamPriorityRange(&lo_p, &hi_p) != hipSuccess)
 			lo_p = hi_p = 0;
-		int prio = hi_p;
-		const char *e = getenv("RXGPU_B_PRIO");                 /* experiment switch: "normal" / "low" */
-		if (e && !strcmp(e, "normal")) prio = 0;
-		if (e && !strcmp(e, "low")) prio = lo_p;
-		RX_HIP(hipStreamCreateWithPriority(&g_stream2, hipStreamNonBlocking, prio));
+		RX_HIP(hipStreamCreateWithPriority(&g_stream2, hipStreamNonBlocking, hi_p));
 	}
 	g_device = device;
 	return RXGPU_OK;
