@@ -43,6 +43,17 @@ def test_low_pass_chain_bit_exact(sig, ds):
     _check(iq, 16384, downsample=ds)
 
 
+@pytest.mark.parametrize("ds", [4, 8, 9, 13, 16, 17, 18, 19, 24, 25, 31, 32, 33, 48, 63, 64, 65, 100, 200, 500, 2000])
+@pytest.mark.parametrize("sig", ["fm", "noise_full"])
+def test_every_decimator_regime(ds, sig):
+    """the span geometry of the small-decimation kernel changes at ds = 18/19 (256 or 64 windows per unit of a span), the
+    discriminator's 24-bit remainder multiply stops at 16, the small kernel hands over to the prefix-scan kernel at 33 and that
+    one switches to 16-byte slot records at 64: a pipelined sequence of blocks that are no multiple of ds on each of them"""
+    block_len = 2 * 10240 + 8
+    iq = _signals(13 * block_len)[sig]
+    _check(iq, block_len, n_runs=3, pipelined=True, downsample=ds)
+
+
 @pytest.mark.parametrize("ds,block_len", [(118, 2 * 131072), (5, 2 * 20352), (7, 4096 + 8), (1, 4096), (3, 8192),
                                           (250, 8192), (118, 2 * 1180)])
 def test_low_pass_geometries(ds, block_len):
