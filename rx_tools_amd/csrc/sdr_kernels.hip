@@ -18,6 +18,7 @@
 typedef unsigned long long u64;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // x * 1.0f / 32767.0f, correctly rounded like the reference's fp32 division, in three operations: the quotient by
 // the rounded reciprocal, its exact residual, one correction (Markstein); all 65536 inputs are checked in
@@ -54,49 +55,52 @@ __device__ __forceinline__ uint32_t sdr_pack4(uint32_t a, uint32_t b)
 	       (sdr_to8<UNSIGNED>((int)(short)(b & 0xffffu)) << 16) | (sdr_to8<UNSIGNED>((int)b >> 16) << 24);
 }
 
-// n16 int16 in, n16 bytes out; one thread per 16 values
+// Every kernel below gives consecutive lanes consecutive pieces of BOTH streams: a wave instruction then reads or writes one
+// contiguous run (1 KiB for 16-byte pieces).  The first versions gave a thread 32-64 contiguous bytes of its own, i.e. two to four
+// instructions each touching every other (third, fourth) 16-byte piece of a 2-4 KiB window: 3.3-5.3 TB/s against a copy
+// ceiling of 6.3.
+
+// n16 int16 in, n16 bytes out; one thread per 8 values (16 bytes in, 8 bytes out), two units in flight
 template <bool UNSIGNED>
 __global__ __launch_bounds__(256) void k_sdr_cs16_to_8(const int16_t *__restrict__ in, u64 n16, uint8_t *__restrict__ out)
 {
-	const u64 units = n16 >> 4;
+	const u64 units = n16 >> 3;
 	const u64 stride = (u64)gridDim.x * blockDim.x;
-	for (u64 u = (u64)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += stride) {
-		const u32x4 a = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(in) + 2 * u);
-		const u32x4 b = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(in) + 2 * u + 1);
-		u32x4 o;
-		o.x = sdr_pack4<UNSIGNED>(a.x, a.y);
-		o.y = sdr_pack4<UNSIGNED>(a.z, a.w);
-		o.z = sdr_pack4<UNSIGNED>(b.x, b.y);
-		o.w = sdr_pack4<UNSIGNED>(b.z, b.w);
-		__builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(out) + u);
+	for (u64 u = (u64)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += 2 * stride) {
+		const u64 u2 = u + stride;
+		const bool two = u2 < units;
+		const u32x4 a = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(in) + u);
+		const u32x4 b = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(in) + (two ? u2 : u));
+		const u32x2 oa = {sdr_pack4<UNSIGNED>(a.x, a.y), sdr_pack4<UNSIGNED>(a.z, a.w)};
+		const u32x2 ob = {sdr_pack4<UNSIGNED>(b.x, b.y), sdr_pack4<UNSIGNED>(b.z, b.w)};
+		__builtin_nontemporal_store(oa, reinterpret_cast<u32x2 *>(out) + u);
+		if (two)
+			__builtin_nontemporal_store(ob, reinterpret_cast<u32x2 *>(out) + u2);
 	}
-	if (blockIdx.x == 0 && threadIdx.x < (n16 & 15)) {                 // ragged end
-		const u64 i = (units << 4) + threadIdx.x;
+	if (blockIdx.x == 0 && threadIdx.x < (n16 & 7)) {                  // ragged end
+		const u64 i = (units << 3) + threadIdx.x;
 		out[i] = (uint8_t)sdr_to8<UNSIGNED>(in[i]);
 	}
 }
 
-// n16 int16 in, n16 floats out; one thread per 8 values
+// n16 int16 in, n16 floats out; one thread per 4 values (8 bytes in, 16 bytes out), two units in flight
 __global__ __launch_bounds__(256) void k_sdr_cs16_to_cf32(const int16_t *__restrict__ in, u64 n16, float *__restrict__ out)
 {
-	const u64 units = n16 >> 3;
+	const u64 units = n16 >> 2;
 	const u64 stride = (u64)gridDim.x * blockDim.x;
-	for (u64 u = (u64)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += stride) {
-		const u32x4 a = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(in) + u);
-		const uint32_t w[4] = {a.x, a.y, a.z, a.w};
-		float f[8];
-#pragma unroll
-		for (int k = 0; k < 4; k++) {
-			f[2 * k] = sdr_unit((int)(short)(w[k] & 0xffffu));
-			f[2 * k + 1] = sdr_unit((int)w[k] >> 16);
-		}
-		f32x4 *o = reinterpret_cast<f32x4 *>(out) + 2 * u;
-		const f32x4 o0 = {f[0], f[1], f[2], f[3]}, o1 = {f[4], f[5], f[6], f[7]};
-		__builtin_nontemporal_store(o0, o);
-		__builtin_nontemporal_store(o1, o + 1);
+	for (u64 u = (u64)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += 2 * stride) {
+		const u64 u2 = u + stride;
+		const bool two = u2 < units;
+		const u32x2 a = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(in) + u);
+		const u32x2 b = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(in) + (two ? u2 : u));
+		const f32x4 oa = {sdr_unit((int)(short)(a.x & 0xffffu)), sdr_unit((int)a.x >> 16), sdr_unit((int)(short)(a.y & 0xffffu)), sdr_unit((int)a.y >> 16)};
+		const f32x4 ob = {sdr_unit((int)(short)(b.x & 0xffffu)), sdr_unit((int)b.x >> 16), sdr_unit((int)(short)(b.y & 0xffffu)), sdr_unit((int)b.y >> 16)};
+		__builtin_nontemporal_store(oa, reinterpret_cast<f32x4 *>(out) + u);
+		if (two)
+			__builtin_nontemporal_store(ob, reinterpret_cast<f32x4 *>(out) + u2);
 	}
-	if (blockIdx.x == 0 && threadIdx.x < (n16 & 7)) {
-		const u64 i = (units << 3) + threadIdx.x;
+	if (blockIdx.x == 0 && threadIdx.x < (n16 & 3)) {
+		const u64 i = (units << 2) + threadIdx.x;
 		out[i] = sdr_unit(in[i]);
 	}
 }
@@ -107,37 +111,32 @@ __device__ __forceinline__ uint32_t sdr_cs12(uint32_t b0, uint32_t b1, uint32_t 
 	return (((b1 << 12) | (b0 << 4)) & 0xffffu) | (((b2 << 8) | (b1 & 0xf0u)) << 16);
 }
 
-// n_elems elements of 3 bytes in, n_elems (I,Q) int16 pairs out; one thread per 16 elements (48 B -> 64 B)
+// n_elems elements of 3 bytes in, n_elems (I,Q) int16 pairs out; one thread per 4 elements (12 B -> 16 B), two units in flight
 __global__ __launch_bounds__(256) void k_sdr_cs12_to_cs16(const uint8_t *__restrict__ in, u64 n_elems, uint32_t *__restrict__ out)
 {
-	const u64 units = n_elems >> 4;
+	const u64 units = n_elems >> 2;
 	const u64 stride = (u64)gridDim.x * blockDim.x;
-	for (u64 u = (u64)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += stride) {
-		const u32x4 *src = reinterpret_cast<const u32x4 *>(in) + 3 * u;
-		uint32_t w[12];
+	const uint32_t *src = reinterpret_cast<const uint32_t *>(in);
+	for (u64 u = (u64)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += 2 * stride) {
+		const u64 u2 = u + stride;
+		const bool two = u2 < units;
+		uint32_t w[2][3];
 #pragma unroll
-		for (int k = 0; k < 3; k++) {
-			const u32x4 a = __builtin_nontemporal_load(src + k);
-			w[4 * k] = a.x; w[4 * k + 1] = a.y; w[4 * k + 2] = a.z; w[4 * k + 3] = a.w;
+		for (int k = 0; k < 3; k++) {                                  // dword loads at 12-byte lane pitch: merged into dwordx3
+			w[0][k] = __builtin_nontemporal_load(src + 3 * u + k);
+			w[1][k] = __builtin_nontemporal_load(src + 3 * (two ? u2 : u) + k);
 		}
-		uint32_t o[16];
 #pragma unroll
-		for (int g = 0; g < 4; g++) {                                  // 3 dwords -> 4 elements
-			const uint32_t x = w[3 * g], y = w[3 * g + 1], z = w[3 * g + 2];
-			o[4 * g] = sdr_cs12(x & 0xffu, (x >> 8) & 0xffu, (x >> 16) & 0xffu);
-			o[4 * g + 1] = sdr_cs12(x >> 24, y & 0xffu, (y >> 8) & 0xffu);
-			o[4 * g + 2] = sdr_cs12((y >> 16) & 0xffu, y >> 24, z & 0xffu);
-			o[4 * g + 3] = sdr_cs12((z >> 8) & 0xffu, (z >> 16) & 0xffu, z >> 24);
-		}
-		u32x4 *dst = reinterpret_cast<u32x4 *>(out) + 4 * u;
-#pragma unroll
-		for (int k = 0; k < 4; k++) {
-			const u32x4 q = {o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]};
-			__builtin_nontemporal_store(q, dst + k);
+		for (int h = 0; h < 2; h++) {
+			const uint32_t x = w[h][0], y = w[h][1], z = w[h][2];
+			const u32x4 q = {sdr_cs12(x & 0xffu, (x >> 8) & 0xffu, (x >> 16) & 0xffu), sdr_cs12(x >> 24, y & 0xffu, (y >> 8) & 0xffu),
+			                 sdr_cs12((y >> 16) & 0xffu, y >> 24, z & 0xffu), sdr_cs12((z >> 8) & 0xffu, (z >> 16) & 0xffu, z >> 24)};
+			if (h == 0 || two)
+				__builtin_nontemporal_store(q, reinterpret_cast<u32x4 *>(out) + (h ? u2 : u));
 		}
 	}
-	if (blockIdx.x == 0 && threadIdx.x < (n_elems & 15)) {
-		const u64 i = (units << 4) + threadIdx.x;
+	if (blockIdx.x == 0 && threadIdx.x < (n_elems & 3)) {
+		const u64 i = (units << 2) + threadIdx.x;
 		out[i] = sdr_cs12(in[3 * i], in[3 * i + 1], in[3 * i + 2]);
 	}
 }
@@ -175,7 +174,7 @@ extern "C" int rxk_sdr_cs12_to_cs16(void *stream, const uint8_t *in, u64 n_elems
 {
 	if (!n_elems)
 		return 0;
-	hipLaunchKernelGGL(k_sdr_cs12_to_cs16, dim3(sdr_grid(n_elems >> 4)), dim3(256), 0, (hipStream_t)stream, in, n_elems,
+	hipLaunchKernelGGL(k_sdr_cs12_to_cs16, dim3(sdr_grid(n_elems >> 3)), dim3(256), 0, (hipStream_t)stream, in, n_elems,
 	                   (uint32_t *)out);
 	LAUNCH_RET();
 }
