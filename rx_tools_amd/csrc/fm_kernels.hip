@@ -3077,8 +3077,12 @@ extern "C" int rxk_fm_deemph_scan_t(void *stream, const int16_t *pcm_t, u64 M, i
 	const unsigned grid = (unsigned)((n_chunks + 255) / 256);
 	hipStream_t s = (hipStream_t)stream;
 	const unsigned mg = deemph_magic(a);
-	if (chl2 == 7 && !getenv("RXGPU_SCAN_T")) {
-		/* 128-sample chunks: the chunk in registers, the warm-up from the neighbouring lane; 63 chunks per wave */
+	const char *pick = getenv("RXGPU_SCAN_T");                       /* "1": always scan_t, "0": scan_r wherever it applies (tests) */
+	if (chl2 == 7 && (pick ? pick[0] == '0' : M >= (1ull << 25))) {
+		/* 128-sample chunks of a LONG run (the small-decimation chains, where the audio stages' traffic counts): the chunk in
+		 * registers, the warm-up from the neighbouring lane; 63 chunks per wave.  Short runs keep scan_t: behind the big-ds
+		 * decimator (56 VGPRs x 8 waves per SIMD) a wave of this kernel (81 VGPRs) waits for TWO of its waves to leave, and the
+		 * audio chain of the headline run doubles (A/B at ds=118: 3 % on the pipelined step) */
 		const unsigned rgrid = (unsigned)(((n_chunks + 62) / 63 + 3) / 4);
 		if (group == 16)
 			hipLaunchKernelGGL((k_fm_deemph_scan_r<16>), dim3(rgrid), dim3(256), 0, s, pcm_t, M, a, mg, warm, lo0, gap_w, (uint4 *)ctab, dev);

@@ -519,6 +519,23 @@ def test_tiled_audio_path_long_run_chunks(params, block_len, n_runs, monkeypatch
     _check(_signals(40 * 8192)["dc"], 8192, n_runs=2, pipelined=True, downsample=4)
 
 
+@pytest.mark.parametrize("params,block_len,n_runs", [
+    (dict(downsample=6), 8192, 3),
+    (dict(downsample=4, deemph_a=9), 2 * 4096 + 8, 2),
+    (dict(downsample=5, deemph_a=15), 2 * 5000, 2),
+    (dict(downsample=118), 2 * 131072, 2),
+])
+@pytest.mark.parametrize("scan", ["0", "1"])
+def test_tiled_audio_path_both_scans(params, block_len, n_runs, scan, monkeypatch):
+    """the two scans of 128-sample chunks: k_fm_deemph_scan_r (chunk in registers, warm-up from the neighbouring lane, 63
+    chunks per wave -- what runs of 2^25 and more demodulated samples take) and k_fm_deemph_scan_t; $RXGPU_SCAN_T picks one"""
+    monkeypatch.setenv("RXGPU_SCAN_T", scan)
+    n_blocks = 4 * n_runs + 1
+    iq = sig_fm(n_blocks * block_len // 2, seed=57, amp=9000.0, noise=900)
+    _check(iq, block_len, n_runs=n_runs, pipelined=n_runs > 1, **params)
+    _check(_signals(40 * 8192)["dc"], 8192, n_runs=2, pipelined=True, downsample=4)
+
+
 def test_tiled_audio_path_multi_level_tree(monkeypatch):
     monkeypatch.setenv("RXGPU_DEEMPH_TOPCAP", "3")
     iq = sig_fm(64 * 16384 // 2, seed=66)
