@@ -3155,6 +3155,23 @@ extern "C" int rxk_fm_resample(void *stream, const int16_t *y, u64 n, int fast, 
 	LAUNCH_RET();
 }
 
+// A few bytes from one place to another as ONE WAVE.  hipMemcpyAsync of 4..240 bytes becomes a blit kernel whose workgroup
+// waits for room while an HBM-bound kernel fills the chip -- rocprofv3 showed the 4-byte copy of the flag count sitting for a
+// millisecond in front of the audio stages, and the next run's decimator waiting for those.  dst may be pinned host memory.
+__global__ void k_copy_small(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, unsigned n)
+{
+	for (unsigned i = threadIdx.x; i < n; i += 64)
+		dst[i] = src[i];
+}
+
+extern "C" int rxk_copy_small(void *stream, void *dst, const void *src, unsigned bytes)
+{
+	if (!bytes)
+		return 0;
+	hipLaunchKernelGGL(k_copy_small, dim3(1), dim3(64), 0, (hipStream_t)stream, (uint8_t *)dst, (const uint8_t *)src, bytes);
+	LAUNCH_RET();
+}
+
 extern "C" int rxk_fm_carry_advance(void *stream, rxk_fm_dev *dev, int advance, int *snap)
 {
 	hipLaunchKernelGGL(k_fm_carry_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, dev, advance, snap);

@@ -628,10 +628,9 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 		RX_K(rxk_fm_carry_advance(sb, s->dev, 1, s->snap_dev + 4 * db));
 		if (g->passes) {
 			/* the histories of the passes stream A runs are advanced there (below), the others here */
-			RX_HIP(hipMemcpyAsync(s->hist_dev + HIST_CAS_IN + fuse_a * 12, s->hist_dev + HIST_CAS_OUT + fuse_a * 12, (size_t)(10 - fuse_a) * 12 * 2,
-			                      hipMemcpyDeviceToDevice, sb));
+			RX_K(rxk_copy_small(sb, s->hist_dev + HIST_CAS_IN + fuse_a * 12, s->hist_dev + HIST_CAS_OUT + fuse_a * 12, (unsigned)(10 - fuse_a) * 12 * 2));
 			if (p->comp_fir_size == 9)
-				RX_HIP(hipMemcpyAsync(s->hist_dev + HIST_DROOP_IN, s->hist_dev + HIST_DROOP_OUT, 18 * 2, hipMemcpyDeviceToDevice, sb));
+				RX_K(rxk_copy_small(sb, s->hist_dev + HIST_DROOP_IN, s->hist_dev + HIST_DROOP_OUT, 18 * 2));
 		}
 	}
 
@@ -705,7 +704,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 				RX_HIP(hipEventRecord(s->ev_up, sb));    /* the history upload above went through stream B */
 				RX_HIP(hipStreamWaitEvent(sa, s->ev_up, 0));
 			} else {
-				RX_HIP(hipMemcpyAsync(s->hist_dev + HIST_CAS_IN, s->hist_dev + HIST_CAS_OUT, (size_t)fuse * 12 * 2, hipMemcpyDeviceToDevice, sa));
+				RX_K(rxk_copy_small(sa, s->hist_dev + HIST_CAS_IN, s->hist_dev + HIST_CAS_OUT, (unsigned)fuse * 12 * 2));
 			}
 			rxgpu_prof_begin_on("fm_fifth", sa);
 			RX_K(rxk_fm_fifth_fused(sa, d_iq, 0, g->rotate, n_blocks, (unsigned)g->n, fuse, s->hist_dev + HIST_CAS_IN,
@@ -785,7 +784,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 	}
 	/* every kernel that can flag a libm sample has been enqueued: the count comes back behind them, and the event
 	 * tells the host when this run's demodulated samples (and its reads of d_iq) are complete */
-	RX_HIP(hipMemcpyAsync(s->flag_cnt_host + db, flag_cnt, sizeof(int), hipMemcpyDeviceToHost, sb));
+	RX_K(rxk_copy_small(sb, s->flag_cnt_host + db, flag_cnt, sizeof(int)));       /* pinned host memory, written by the device */
 	RX_HIP(hipEventRecord(s->ev_disc[db], sb));
 	rc = p->mode == RXGPU_MODE_RAW ? RXGPU_OK : run_audio_stages(s, sb, g->M, g->J, d_out);
 	if (rc != RXGPU_OK)
