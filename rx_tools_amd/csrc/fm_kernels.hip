@@ -3253,6 +3253,21 @@ extern "C" int rxk_fm_prestage(void *stream, const int16_t *in, unsigned n_compl
 	LAUNCH_RET();
 }
 
+// the seam histories of a fused group alone (k_fm_fifth_seams), for callers that run it ahead of the group on another stream;
+// rxk_fm_fifth_fused with hist_in == NULL then skips it
+extern "C" int rxk_fm_fifth_seams(void *stream, const void *in, int stage2, int rotate, u64 n_blocks, unsigned n, int fuse,
+                                  const int16_t *hist_in, int16_t *hist_out, uint32_t *seams)
+{
+	const u64 seam_threads = (n_blocks + 1) * 16;
+	const unsigned sgrid = (unsigned)((seam_threads + 255) / 256);
+	const uint32_t *p = (const uint32_t *)in;
+	hipStream_t s = (hipStream_t)stream;
+	if (stage2) hipLaunchKernelGGL((k_fm_fifth_seams<false, true>), dim3(sgrid), dim3(256), 0, s, p, n_blocks, n, fuse, hist_in, seams, hist_out);
+	else if (rotate) hipLaunchKernelGGL((k_fm_fifth_seams<true, false>), dim3(sgrid), dim3(256), 0, s, p, n_blocks, n, fuse, hist_in, seams, hist_out);
+	else hipLaunchKernelGGL((k_fm_fifth_seams<false, false>), dim3(sgrid), dim3(256), 0, s, p, n_blocks, n, fuse, hist_in, seams, hist_out);
+	LAUNCH_RET();
+}
+
 // `fuse` (1..3) fifth_order passes in one LDS-tiled launch.  stage2 == 0: raw cs16 in (scale + rotate, packed int16
 // arithmetic); stage2 != 0: packed level samples in (int arithmetic), hist_* already offset to the first pass done
 extern "C" int rxk_fm_fifth_fused(void *stream, const void *in, int stage2, int rotate, u64 n_blocks, unsigned n, int fuse,
@@ -3271,7 +3286,7 @@ extern "C" int rxk_fm_fifth_fused(void *stream, const void *in, int stage2, int 
 	 * (A/B in one process, -F ds=128 pipelined: 0.92 -> 0.98 TSample/s; $RXGPU_FF_PAD sets another pad) */
 	const size_t pad = stage2 ? 0 : getenv("RXGPU_FF_PAD") ? (size_t)atoi(getenv("RXGPU_FF_PAD")) : 17000;
 #define FUSED(F, RT, S2) hipLaunchKernelGGL((k_fm_fifth_fused<F, RT, S2, false>), dim3(grid), dim3(256), pad, s, p, n, tiles, tpw, seams, out, n, n >> F)
-#define GO(RT, S2) do { SEAMS(RT, S2); if (fuse == 1) FUSED(1, RT, S2); else if (fuse == 2) FUSED(2, RT, S2); else FUSED(3, RT, S2); } while (0)
+#define GO(RT, S2) do { if (hist_in) SEAMS(RT, S2); if (fuse == 1) FUSED(1, RT, S2); else if (fuse == 2) FUSED(2, RT, S2); else FUSED(3, RT, S2); } while (0)
 	if (stage2) GO(false, true);
 	else if (rotate) GO(true, false);
 	else GO(false, false);

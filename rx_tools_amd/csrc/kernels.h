@@ -174,6 +174,8 @@ int rxk_fm_fifth_pass(void *stream, const void *in, int in_is_raw, int prescaled
  * passes from raw).  stage2 != 0: packed level samples in, the reference's int arithmetic; hist_in/hist_out
  * point at the first pass of the group.  seams: n_blocks*15 dwords of scratch. */
 #define RXK_FIFTH_TILE 2048
+int rxk_fm_fifth_seams(void *stream, const void *in, int stage2, int rotate, unsigned long long n_blocks, unsigned n, int fuse,
+                       const int16_t *hist_in, int16_t *hist_out, uint32_t *seams);
 int rxk_fm_fifth_fused(void *stream, const void *in, int stage2, int rotate, unsigned long long n_blocks, unsigned n, int fuse,
                        const int16_t *hist_in, int16_t *hist_out, uint32_t *seams, uint32_t *out);
 /* F12 generic_fir droop compensation (rtl_fm.c:442-465, 771-776) over the concatenated stream */

@@ -38,6 +38,7 @@ struct rxgpu_fm_stream {
 	uint32_t *seams;                     /* per block: 3 levels x 5 history samples for the fused passes */
 	uint32_t *cas_a[2], *seams_a[2];     /* raw input: the first fused group runs on stream A like the decimator, double-buffered */
 	hipEvent_t ev_up;                    /* carries uploaded on stream B -> stream A may read the cascade history */
+	hipEvent_t ev_seam[2];               /* the seam histories of a run's first fused group are in place (stream 4 -> stream A) */
 	int16_t *pcm_buf[2], *pcm, *y;       /* pcm: the buffer the run in hand uses (double-buffered like lp_raw) */
 	int16_t *rdc_buf, *pcm_post;         /* -E rdc: the corrected, rotated capture; -o: pcm after low_pass_simple */
 	long long *rdc_sums;
@@ -280,7 +281,9 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 				DMALLOC(s->cas_a[i], ((s->max_T >> fuse) + max_blocks) * 4);
 				DMALLOC(s->seams_a[i], (max_blocks + 1) * 15 * 4);
 			}
-			if (hipEventCreateWithFlags(&s->ev_up, hipEventDisableTiming) != hipSuccess) {
+			if (hipEventCreateWithFlags(&s->ev_up, hipEventDisableTiming) != hipSuccess ||
+			    hipEventCreateWithFlags(&s->ev_seam[0], hipEventDisableTiming) != hipSuccess ||
+			    hipEventCreateWithFlags(&s->ev_seam[1], hipEventDisableTiming) != hipSuccess) {
 				rxgpu_fm_stream_destroy(s);
 				return rxgpu_fail(RXGPU_ENODEV, "hipEventCreate failed");
 			}
@@ -322,6 +325,8 @@ void rxgpu_fm_stream_destroy(rxgpu_fm_stream *s)
 	hipFree(s->cas[0]); hipFree(s->cas[1]); hipFree(s->seams);
 	hipFree(s->cas_a[0]); hipFree(s->cas_a[1]); hipFree(s->seams_a[0]); hipFree(s->seams_a[1]);
 	if (s->ev_up) hipEventDestroy(s->ev_up);
+	if (s->ev_seam[0]) hipEventDestroy(s->ev_seam[0]);
+	if (s->ev_seam[1]) hipEventDestroy(s->ev_seam[1]);
 	hipFree(s->pcm_buf[0]); hipFree(s->pcm_buf[1]); hipFree(s->y);
 	
 	hipFree(s->lvl_tab); hipFree(s->lvl_lo); hipFree(s->lvl_gap); hipFree(s->lvl_start); hipFree(s->chunk_pre);
@@ -698,16 +703,24 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 		if (fuse_a) {
 			const int fuse = fuse_a;
 			uint32_t *dst = s->cas_a[db];
-			if (s->ev_small_valid[db])                   /* cas_a[db] was last read by the run two enqueues ago */
-				RX_HIP(hipStreamWaitEvent(sa, s->ev_small[db], 0));
+			/* The group's seam histories need nothing from the previous run but its archive (a few samples, written by ITS seam
+			 * kernel): they go on a stream of their own and are ready long before stream A gets to this run -- left on stream A,
+			 * the history copy and the seam kernel sat between two HBM-bound launches (50-150 us of an idle chip per run). */
+			hipStream_t sd = rxgpu_hip_stream4();
 			if (fresh) {
 				RX_HIP(hipEventRecord(s->ev_up, sb));    /* the history upload above went through stream B */
-				RX_HIP(hipStreamWaitEvent(sa, s->ev_up, 0));
+				RX_HIP(hipStreamWaitEvent(sd, s->ev_up, 0));
 			} else {
-				RX_K(rxk_copy_small(sa, s->hist_dev + HIST_CAS_IN, s->hist_dev + HIST_CAS_OUT, (unsigned)fuse * 12 * 2));
+				RX_K(rxk_copy_small(sd, s->hist_dev + HIST_CAS_IN, s->hist_dev + HIST_CAS_OUT, (unsigned)fuse * 12 * 2));
 			}
+			RX_K(rxk_fm_fifth_seams(sd, d_iq, 0, g->rotate, n_blocks, (unsigned)g->n, fuse, s->hist_dev + HIST_CAS_IN,
+			                        s->hist_dev + HIST_CAS_OUT, s->seams_a[db]));
+			RX_HIP(hipEventRecord(s->ev_seam[db], sd));
+			RX_HIP(hipStreamWaitEvent(sa, s->ev_seam[db], 0));
+			if (s->ev_small_valid[db])                   /* cas_a[db] was last read by the run two enqueues ago */
+				RX_HIP(hipStreamWaitEvent(sa, s->ev_small[db], 0));
 			rxgpu_prof_begin_on("fm_fifth", sa);
-			RX_K(rxk_fm_fifth_fused(sa, d_iq, 0, g->rotate, n_blocks, (unsigned)g->n, fuse, s->hist_dev + HIST_CAS_IN,
+			RX_K(rxk_fm_fifth_fused(sa, d_iq, 0, g->rotate, n_blocks, (unsigned)g->n, fuse, NULL,
 			                        s->hist_dev + HIST_CAS_OUT, s->seams_a[db], dst));
 			rxgpu_prof_end_on("fm_fifth", sa);
 			RX_HIP(hipEventRecord(s->ev_dec[db], sa));

@@ -18,6 +18,7 @@ int rxgpu_fail(int code, const char *fmt, ...);
 int rxgpu_ensure_init(void);
 hipStream_t rxgpu_hip_stream(void);
 hipStream_t rxgpu_hip_stream2(void);   /* second stream: the latency-bound tail of a pipelined rx_fm run */
+hipStream_t rxgpu_hip_stream4(void);   /* fourth stream: small kernels that prepare the NEXT run's stream-A launch while this run's is still going */
 hipStream_t rxgpu_hip_stream3(void);   /* third stream: host <-> device copies of the host-fed entry points */
 
 #define RX_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \

@@ -7,7 +7,7 @@
 #include <string.h>
 
 static int g_device = -1;
-static hipStream_t g_stream, g_stream2, g_stream3;
+static hipStream_t g_stream, g_stream2, g_stream3, g_stream4;
 /* The drop-in is entered from two threads of the reference (rtlsdr_callback on the dongle thread, full_demod on the
  * demod thread, rtl_fm.c:899/923): the error text and the "this thread is bound to the device" flag are per thread,
  * initialisation is serialised. */
@@ -71,6 +71,7 @@ static int init_locked(int device)
 	t_bound_device = device;
 	RX_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
 	RX_HIP(hipStreamCreateWithFlags(&g_stream3, hipStreamNonBlocking));
+	RX_HIP(hipStreamCreateWithFlags(&g_stream4, hipStreamNonBlocking));
 	{
 		/* the tail stream carries many small kernels behind a saturating one: give it the high priority (measured: normal or
 		 * low priority changes nothing -- what those kernels wait for is wave slots, see rxk_fm_decimate_small / rxk_fm_fifth_fused) */
@@ -93,7 +94,8 @@ void rxgpu_shutdown(void)
 	hipStreamDestroy(g_stream);
 	hipStreamDestroy(g_stream2);
 	hipStreamDestroy(g_stream3);
-	g_stream = g_stream2 = g_stream3 = NULL;
+	hipStreamDestroy(g_stream4);
+	g_stream = g_stream2 = g_stream3 = g_stream4 = NULL;
 	g_device = -1;
 }
 
@@ -108,6 +110,7 @@ int rxgpu_ensure_init(void)
 hipStream_t rxgpu_hip_stream(void) { return g_stream; }
 hipStream_t rxgpu_hip_stream2(void) { return g_stream2; }
 hipStream_t rxgpu_hip_stream3(void) { return g_stream3; }
+hipStream_t rxgpu_hip_stream4(void) { return g_stream4; }
 
 /* Host buffers the caller wants DMA'd without a bounce (SURVEY.md section 8b "Ownership"): page-lock them in place. */
 int rxgpu_pin(void *ptr, size_t bytes)
@@ -137,6 +140,7 @@ int rxgpu_sync(void)
 	RX_HIP(hipStreamSynchronize(g_stream));
 	RX_HIP(hipStreamSynchronize(g_stream2));
 	RX_HIP(hipStreamSynchronize(g_stream3));
+	RX_HIP(hipStreamSynchronize(g_stream4));
 	rxgpu_prof_collect();
 	return RXGPU_OK;
 }
