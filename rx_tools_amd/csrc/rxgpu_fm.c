@@ -64,6 +64,7 @@ struct rxgpu_fm_stream {
 	rxk_fm_dev *dev;
 	int16_t *hist_dev;                   /* [10][12] cascade hist in, [10][12] out, [18] droop in, [18] out */
 	int *fir_dev;                        /* 10 ints */
+	int fir_loaded;                      /* cascade depth whose cic_9_tables row is in fir_dev (0: none) */
 	/* pinned host mirrors */
 	rxk_fm_dev *dev_host;
 	int16_t *hist_host;
@@ -274,7 +275,7 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 		/* pass 0 output is half the input, later passes shrink further: two buffers suffice */
 		DMALLOC(s->cas[0], (s->max_T / 2 + max_blocks) * 4);
 		DMALLOC(s->cas[1], (s->max_T / 4 + max_blocks) * 4);
-		DMALLOC(s->seams, 2 * (max_blocks + 1) * 15 * 4);
+		DMALLOC(s->seams, 4 * (max_blocks + 1) * 15 * 4);               /* one region per fused group of a run */
 		if (!params->prescaled) {
 			const int fuse = params->downsample_passes < 3 ? params->downsample_passes : 3;
 			for (int i = 0; i < 2; i++) {
@@ -731,16 +732,20 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 			first_pass = fuse;
 		}
 		rxgpu_prof_begin_on("fm_fifth2", sb);
-		if (fuse_a == 3 && passes > 3 && (n_in % RXK_FIFTH_TILE) == 0) {
-			/* a second fused group on the 1/8-rate stream (3 passes, or 1 so that the ping-pong buffers stay distinct) */
-			const int fuse2 = passes - 3 >= 3 ? 3 : 1;
-			uint32_t *dst2 = s->cas[(3 + fuse2 - 1) & 1];
-			RX_K(rxk_fm_fifth_fused(sb, src, 1, 0, n_blocks, n_in, fuse2, s->hist_dev + HIST_CAS_IN + 3 * 12,
-			                        s->hist_dev + HIST_CAS_OUT + 3 * 12, s->seams + (s->max_blocks + 1) * 15, dst2));
+		/* further fused groups on the decimated stream while whole tiles are left (3 passes, or 1 so that the ping-pong buffers
+		 * stay distinct): passes 4-6 at 1/8 rate, the 7th of ds = 128 at 1/64 -- the one-thread-per-output kernel below took as
+		 * long for that last pass as the three before it */
+		for (int grp = 1; fuse_a == 3 && grp < 4 && first_pass < passes && n_in >= RXK_FIFTH_TILE && (n_in % RXK_FIFTH_TILE) == 0; grp++) {
+			const int fuse2 = passes - first_pass >= 3 ? 3 : 1;
+			if (first_pass + fuse2 > 7)                      /* the kernel's 32-bit sums assume inputs below 2^14: 128 * 2^6 at most */
+				break;
+			uint32_t *dst2 = s->cas[(first_pass + fuse2 - 1) & 1];
+			RX_K(rxk_fm_fifth_fused(sb, src, 1, 0, n_blocks, n_in, fuse2, s->hist_dev + HIST_CAS_IN + first_pass * 12,
+			                        s->hist_dev + HIST_CAS_OUT + first_pass * 12, s->seams + (size_t)grp * (s->max_blocks + 1) * 15, dst2));
 			src = dst2;
 			n_in >>= fuse2;
 			in_stride = n_in;
-			first_pass = 3 + fuse2;
+			first_pass += fuse2;
 		}
 		for (int i = first_pass; i < passes; i++) {
 			uint32_t *dst = s->cas[i & 1];
@@ -754,7 +759,10 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 		rxgpu_prof_end_on("fm_fifth2", sb);
 		s->lp_final = (const uint32_t *)src;             /* [n_blocks][K] contiguous == M samples */
 		if (p->comp_fir_size == 9) {
-			RX_HIP(hipMemcpyAsync(s->fir_dev, cic_9_tables[passes], 10 * sizeof(int), hipMemcpyHostToDevice, sb));
+			if (s->fir_loaded != passes) {                   /* the table of this cascade depth: once */
+				RX_HIP(hipMemcpyAsync(s->fir_dev, cic_9_tables[passes], 10 * sizeof(int), hipMemcpyHostToDevice, sb));
+				s->fir_loaded = passes;
+			}
 			if (!split && p->custom_atan == 1) {
 				/* the droop FIR and the discriminator in one pass; the FIR output itself is only kept where somebody reads it
 				 * back (the drop-in hands lowpassed[] to its caller) */

@@ -140,7 +140,8 @@ def test_fifth_order_chain_bit_exact(passes, fir, sig):
         assert got[10] == want[10] and got[11] == want[11]
 
 
-@pytest.mark.parametrize("passes,fir,n", [(7, 0, 16384), (7, 9, 32768), (6, 0, 32768), (5, 9, 16384), (4, 0, 32768)])
+@pytest.mark.parametrize("passes,fir,n", [(7, 0, 16384), (7, 9, 32768), (6, 0, 32768), (5, 9, 16384), (4, 0, 32768),
+                                          (7, 0, 131072), (7, 9, 262144), (8, 0, 262144), (9, 9, 131072)])   # a third fused group: pass 7 at 1/64 rate
 def test_fifth_order_two_fused_stages(passes, fir, n):
     """blocks long enough for the second fused group (passes 4-6 on the 1/8-rate stream, int arithmetic)"""
     from gpu_support import carry_tuple, carry_from_oracle_state
