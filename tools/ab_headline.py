@@ -11,7 +11,7 @@ ds = int(sys.argv[3]) if len(sys.argv) > 3 else 118
 bl = 2 * 131072
 d_iq = device_capture(torch, torch.device("cuda"), blocks * 131072, seed=5)
 d_out = torch.zeros(blocks * 131072 // (ds if ds > 0 else 8) + 64, dtype=torch.int16, device="cuda")
-s = R.FmStream(R.FmParams.wbfm(downsample=ds) if ds > 0 else R.FmParams.wbfm(downsample_passes=-ds), blocks, bl)
+s = R.FmStream(R.FmParams.wbfm(downsample=ds) if ds > 0 else (R.FmParams.wbfm(downsample_passes=-ds) if ds > -10 else R.FmParams.wbfm(downsample_passes=(-ds) // 10, comp_fir_size=9)), blocks, bl)   # ds: 118 | -7 (passes) | -39 (3 passes + droop FIR)
 def dump(names):
     out = {}
     for n in names:
@@ -31,5 +31,5 @@ for rep in range(4):
         s.wait()
         dt = (time.perf_counter() - t0) / k
         L.rxgpu_prof_enable(0)
-        print((switch + "=1" if on else "default").ljust(22), "us/step", round(dt * 1e6, 1), dump(["fm_decimate", "fm_fifth", "fm_fifth2", "fm_disc", "fm_deemph", "fm_resample"]),
+        print((switch + "=1" if on else "default").ljust(22), "us/step", round(dt * 1e6, 1), dump(["fm_decimate", "fm_fifth", "fm_fifth2", "fm_droop", "fm_disc", "fm_deemph", "fm_resample"]),
               "TS/s", round(blocks * 131072 / dt / 1e12, 3), flush=True)
