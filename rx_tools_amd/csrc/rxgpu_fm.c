@@ -311,6 +311,7 @@ void rxgpu_fm_stream_destroy(rxgpu_fm_stream *s)
 		hipStreamSynchronize(rxgpu_hip_stream());
 		hipStreamSynchronize(rxgpu_hip_stream2());
 		hipStreamSynchronize(rxgpu_hip_stream3());
+		hipStreamSynchronize(rxgpu_hip_stream4());
 	}
 	for (int i = 0; i < 2; i++) {
 		hipFree(s->lp_raw[i]); hipFree(s->head[i]); hipFree(s->tail[i]);
