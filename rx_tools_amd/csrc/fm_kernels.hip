@@ -1724,15 +1724,16 @@ __device__ __forceinline__ u64 div_floor(u64 num, u64 den);
 // starts in the middle of somebody else's window emits that window's (partial, wrong) sum into the slot BEFORE its own first
 // one: slot -1 of the staging for a wave's first lane, otherwise the slot its left neighbour fills in afterwards, when it
 // walks on past its chunk to finish the window it owns -- same wave, later in program order, LDS operations retire in order.
-__device__ __forceinline__ void lpr_step(int N, int nK, int &acc, int &p, int &slot, int thr, int slow, int d_emit, int *stage)
+typedef __attribute__((address_space(3))) int lds_int;         // a pointer the compiler KNOWS to be LDS: ds_write with a 32-bit address
+__device__ __forceinline__ void lpr_step(int N, int nK, int &acc, int &p, lds_int *&slot, int thr, int slow, int d_emit)
 {
 	acc = acc + N + nK;
-	const bool emit = p >= thr;
-	if (emit)
-		*reinterpret_cast<int *>(reinterpret_cast<char *>(stage) + slot) = acc;      // slot counts bytes: the LDS address is stage + slot as it is
-	slot += emit ? 4 : 0;
-	acc = emit ? 0 : acc;
-	p += emit ? d_emit : slow;
+	if (p >= thr) {                              // everything an emission changes sits in the one exec-masked region of the store
+		*slot++ = acc;                           // slot IS the LDS address of the lane's next output
+		acc = 0;
+		p += d_emit - slow;                      // = -fast; the unconditional step below completes it
+	}
+	p += slow;
 }
 
 template <int CHL2>
@@ -1765,8 +1766,9 @@ __global__ __launch_bounds__(256) void k_fm_deemph_apply_rs_t(
 	const bool owns_first = c == 0 || p < slow;
 	const u64 j_first = e0 + (owns_first ? 0 : 1);
 	const u64 jw0 = (u64)__builtin_amdgcn_readfirstlane((int)(unsigned)j_first) | ((u64)__builtin_amdgcn_readfirstlane((int)(unsigned)(j_first >> 32)) << 32);
-	int slot = 4 * ((int)(j_first - jw0) - (owns_first ? 0 : 1));   // in bytes; >= -4: the staging has one spare element in front
 	stage += 1;
+	lds_int *const stage_l = (lds_int *)stage;
+	lds_int *slot = stage_l + ((int)(j_first - jw0) - (owns_first ? 0 : 1));   // >= stage - 1: the staging has one spare element in front
 	if (valid) {
 		const int n = (int)((M - c0) < (u64)CH ? (M - c0) : (u64)CH);
 		int N = de_state(start[c], h);
@@ -1780,16 +1782,16 @@ __global__ __launch_bounds__(256) void k_fm_deemph_apply_rs_t(
 #pragma unroll
 			for (int k = 0; k < 4; k++) {
 				de_step<0>(ww[k], N, magic, -64);
-				lpr_step(N, nK, acc, p, slot, thr, slow, d_emit, stage);
+				lpr_step(N, nK, acc, p, slot, thr, slow, d_emit);
 				de_step<1>(ww[k], N, magic, -64);
-				lpr_step(N, nK, acc, p, slot, thr, slow, d_emit, stage);
+				lpr_step(N, nK, acc, p, slot, thr, slow, d_emit);
 			}
 		}
 		if (n & 7) {
 			const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
 			for (int k = 0; k < (n & 7); k++) {
 				if (k & 1) de_step<1>(ww[k >> 1], N, magic, -64); else de_step<0>(ww[k >> 1], N, magic, -64);
-				lpr_step(N, nK, acc, p, slot, thr, slow, d_emit, stage);
+				lpr_step(N, nK, acc, p, slot, thr, slow, d_emit);
 			}
 		}
 		const u64 end = c0 + (u64)n;
@@ -1813,8 +1815,8 @@ __global__ __launch_bounds__(256) void k_fm_deemph_apply_rs_t(
 				const uint32_t ww[4] = {wv.x, wv.y, wv.z, wv.w};
 				for (int k = (int)(i & 7); k < 8 && open && i < M; k++, i++) {
 					if (k & 1) de_step<1>(ww[k >> 1], N, magic, -64); else de_step<0>(ww[k >> 1], N, magic, -64);
-					const int before = slot;
-					lpr_step(N, nK, acc, p, slot, thr, slow, d_emit, stage);
+					const lds_int *before = slot;
+					lpr_step(N, nK, acc, p, slot, thr, slow, d_emit);
 					open = slot == before;
 				}
 			}
@@ -1823,7 +1825,7 @@ __global__ __launch_bounds__(256) void k_fm_deemph_apply_rs_t(
 		}
 	}
 	// the wave's outputs [jw0, jw0 + cnt) leave coalesced; lanes own ascending, contiguous ranges
-	int cnt = valid ? slot >> 2 : 0;
+	int cnt = valid ? (int)(slot - stage_l) : 0;
 	for (int off = 32; off; off >>= 1)
 		cnt = max(cnt, __shfl_xor(cnt, off));
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
