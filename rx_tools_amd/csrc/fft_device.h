@@ -122,9 +122,6 @@ __device__ __forceinline__ void fft_pass(uint32_t (&v)[16], const uint32_t *__re
 #pragma unroll
 	for (int sp = G::sp0(PASS); sp < 4; sp++) {
 		const int d = 8 >> sp;
-		if (M >= 14)
-			__builtin_amdgcn_sched_barrier(0);                // 1024-thread workgroups have 128 VGPRs: keep one stage's twiddles live, not a pass's
-
 #pragma unroll
 		for (int g = 0; g < (1 << sp); g++) {
 			const unsigned j = (U ? (base << (SH - sp)) : 0u) + ((unsigned)crev<4>(g << (4 - sp)) << (M - 1 - sp));
