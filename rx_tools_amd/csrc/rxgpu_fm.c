@@ -1052,7 +1052,9 @@ static int run_host_chunked(rxgpu_fm_stream *s, const int16_t *h_iq, size_t n_bl
 		 * while the runs of the chunks before it are on the compute streams. */
 		RX_HIP(hipMemcpyAsync(s->stage_in[slot], h_iq + done * block_len, nb * block_len * 2, hipMemcpyHostToDevice, sc));
 		RX_HIP(hipEventRecord(s->ev_h2d[slot], sc));
-		/* both compute streams read the capture (decimator on A; discriminator seams, cascade and generic decimator on B) */
+		/* every stream that reads the capture waits for it (decimator on A; discriminator seams, cascade and generic decimator on
+		 * B; the -F seam histories on the fourth stream) */
+		RX_HIP(hipStreamWaitEvent(rxgpu_hip_stream4(), s->ev_h2d[slot], 0));
 		RX_HIP(hipStreamWaitEvent(sa, s->ev_h2d[slot], 0));
 		RX_HIP(hipStreamWaitEvent(sb, s->ev_h2d[slot], 0));
 		size_t got = 0;
