@@ -216,7 +216,10 @@ int rxk_ch_audio(void *stream, int16_t *rows, unsigned long long row_stride, uns
  * eff_len = int16 per tune actually transformed (buf_len / ds). */
 int rxk_pw_fft(void *stream, const int16_t *in, size_t tune_stride, size_t pass_stride, int passes,
                int tunes, int bin_e, int eff_len, int dc_len, const int *window, const uint32_t *twiddle,
-               int peak_hold, int passes_per_group, long long *avg);
+               int peak_hold, int passes_per_group, long long *avg, long long *partial, size_t partial_cap);
+/* partial (optional, partial_cap int64): with ceil(passes / passes_per_group) * tunes * max(1, 4096 >> bin_e) << bin_e of them the register-
+ * blocked kernels (bin_e 8..13) write per-group spectra there and one reduction adds them to avg -- for sweeps of few tunes, where
+ * every pass lands on the same bins and atomics on avg[] dominate */
 /* samples[t] += blocks_per_tune * ds * passes (rtl_power.c:769) */
 int rxk_pw_samples(void *stream, int *samples, int tunes, int add);
 /* P2 boxcar (rtl_power.c:723-733): every buffer of buf_len int16 -> same-size buffer whose
@@ -250,6 +253,13 @@ int rxk_fm_post_downsample(void *stream, const int16_t *in, unsigned long long n
 
 /* fix_fft for 2^15 < N <= 2^21 (rtl_power.c:485): the same network on a scratch copy in HBM, one launch per stage.
  * scratch: cap_blocks * 2^bin_e dwords; dc: 2 ints per (pass, tune) */
+/* bin_e 14 and 15, eff_len a multiple of 2^(bin_e+1): the register-blocked transform as two launches (first radix-16 pass, then the 16
+ * independent sub-transforms), same scratch / dc workspaces as rxk_pw_fft_big; returns < 0 if the geometry does not fit */
+int rxk_pw_fft_mid(void *stream, const int16_t *in, size_t tune_stride, size_t pass_stride, int passes, int tunes,
+                   int bin_e, int eff_len, const int *window, const uint32_t *twiddle, int peak_hold,
+                   uint32_t *scratch, size_t cap_blocks, int *dc, long long *avg, long long *partial, size_t partial_cap);
+/* workgroups the second launch aims for; partial needs (RXK_PWM_TARGET_WG / 4 + tunes * blocks per tune) * 2^bin_e int64 to be used */
+#define RXK_PWM_TARGET_WG 2048
 int rxk_pw_fft_big(void *stream, const int16_t *in, size_t tune_stride, size_t pass_stride, int passes, int tunes,
                    int bin_e, int eff_len, const int *window, const uint32_t *twiddle, int peak_hold,
                    uint32_t *scratch, size_t cap_blocks, int *dc, long long *avg);

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void k_pw_fft4096(
 template <int M, bool PEAK>
 __global__ __launch_bounds__(((1 << M) / 16 > 256) ? (1 << M) / 16 : 256) void k_pw_fftR(
 	const int16_t *__restrict__ in, size_t tune_stride, size_t pass_stride, int passes, int nb_total,
-	const int *__restrict__ window, const uint32_t *__restrict__ twiddle, int ppg, i64 *__restrict__ avg)
+	const int *__restrict__ window, const uint32_t *__restrict__ twiddle, int ppg, i64 *__restrict__ avg, i64 *__restrict__ partial)
 {
 	typedef fft_geom<M> G;
 	constexpr int N = G::N, TPF = G::TPF, T = TPF > 256 ? TPF : 256, FPW = T / TPF;
@@ -356,10 +356,14 @@ __global__ __launch_bounds__(((1 << M) / 16 > 256) ? (1 << M) / 16 : 256) void k
 		}
 	}
 	if (ACCREG) {
+		// few tunes: the groups' spectra go to partial[((group * tunes + tune) * FPW + fid) * N + bin] and k_pwm_reduce folds them in
+		// (every pass of a one-tune sweep lands on the same N bins: the int64 atomics were most of the launch)
+		i64 *dst = partial ? partial + ((((size_t)blockIdx.y * gridDim.x + tune) * FPW + fid) << M) : nullptr;
 #pragma unroll
 		for (int r = 0; r < 16; r++) {
 			const unsigned bin = __brev((tq << 4) | (unsigned)r) >> (32 - M);
-			if (PEAK) atomicMax((long long *)&avg_t[bin], acc[r]);
+			if (dst) dst[bin] = acc[r];
+			else if (PEAK) atomicMax((long long *)&avg_t[bin], acc[r]);
 			else if (acc[r]) atomicAdd((unsigned long long *)&avg_t[bin], (unsigned long long)acc[r]);
 		}
 	}
@@ -638,6 +642,184 @@ __global__ void k_pwb_acc(const uint32_t *__restrict__ scratch, int tunes, int n
 	else atomicAdd((unsigned long long *)a, (unsigned long long)pw);
 }
 
+// ------------------------------------------------------------------ N = 2^14, 2^15: the register-blocked transform in two launches
+//
+// N/16 threads per transform is 1024 or 2048: one workgroup would have 128 VGPRs per lane (the single-kernel build spilled and lost to
+// the LDS radix-2 kernel) or does not exist.  But after the FIRST radix-16 pass -- stages 0-3 on the top four index bits, which a thread
+// does alone on its 16 values n = col + (N/16) r -- the transform falls apart into 16 independent sub-transforms of N/16 points: every
+// later stage pairs indices that differ below bit M-4.  So:
+//   k_pwm_head  one thread per column: remove_dc + window + stages 0-3, written back in natural order to a scratch copy in HBM
+//               (8 bytes of extra traffic per bin);
+//   k_pwm_tail  N/256 threads per sub-transform, 256 / (N/256) of them side by side in a workgroup: the remaining passes of
+//               fft_device.h (LDS transposes among 64 or 128 threads), |X|^2 into 16 int64 accumulators per thread over every pass
+//               of the launch, one atomic per bin at the end.
+// Block q = (pass * tunes + tune) * nbpt + blk as in the stage-per-launch path below; a launch covers whole passes.
+template <int M>
+__global__ __launch_bounds__(256) void k_pwm_head(const int16_t *__restrict__ in, size_t tune_stride, size_t pass_stride, int tunes, int nbpt,
+                                                 const int *__restrict__ window, const uint32_t *__restrict__ twiddle, const int *__restrict__ dc,
+                                                 size_t q0, size_t nq, uint32_t *__restrict__ scratch)
+{
+	constexpr int N = 1 << M, TPF = N / 16;
+	const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const size_t ql = gid / TPF;
+	if (ql >= nq)
+		return;
+	const unsigned col = (unsigned)(gid % TPF);
+	const size_t q = q0 + ql, pt = q / (size_t)nbpt;
+	const int blk = (int)(q - pt * (size_t)nbpt);
+	const size_t pass = pt / (size_t)tunes, tune = pt - pass * (size_t)tunes;
+	const uint32_t *buf = (const uint32_t *)(in + pass * pass_stride + tune * tune_stride) + (size_t)blk * N;
+	const uint32_t ave = pw_pack(dc[2 * pt], dc[2 * pt + 1]);
+	uint32_t v[16];
+#pragma unroll
+	for (int r = 0; r < 16; r++) {
+		const uint32_t c = (uint32_t)window[col + r * TPF] & 0xffffu;
+		v[r] = pw_pk_mul(pw_pk_sub(buf[col + r * TPF], ave), c | (c << 16));          // remove_dc + window, rtl_power.c:744-758
+	}
+	fft_pass<M, 0>(v, twiddle, col);
+	uint32_t *dst = scratch + (ql << M);
+#pragma unroll
+	for (int r = 0; r < 16; r++)
+		dst[col + r * TPF] = v[r];
+}
+
+// grid: x = (tune * nbpt + blk) * (16 / SPW) + sub-block group, y = group of passes; the launch's passes are p0 .. p0 + np
+// partial != NULL: the accumulators go, without atomics, to partial[((group * tunes + tune) * nbpt + blk) * N + bin] and k_pwm_reduce folds
+// them into avg -- with one tune every pass of a sweep lands on the same N bins, and int64 atomics on a few thousand addresses were
+// three quarters of this kernel's time
+template <int M, bool PEAK>
+__global__ __launch_bounds__(256) void k_pwm_tail(const uint32_t *__restrict__ scratch, int tunes, int nbpt, int p0, int np, int ppg,
+                                                 const uint32_t *__restrict__ twiddle, i64 *__restrict__ avg, i64 *__restrict__ partial)
+{
+	typedef fft_geom<M> G;
+	constexpr int N = 1 << M, TPS = N / 256, SPW = 256 / TPS;       // threads per sub-transform, sub-transforms per workgroup
+	__shared__ __attribute__((aligned(16))) uint32_t lds[256 * G::ROW];
+	const int tid = threadIdx.x;
+	const unsigned sg = blockIdx.x % (16 / SPW), tb = blockIdx.x / (16 / SPW);   // tb = tune * nbpt + blk
+	const unsigned tune = tb / (unsigned)nbpt, blk = tb - tune * (unsigned)nbpt;
+	const unsigned tq = sg * 256u + (unsigned)tid;                   // this thread's index in the whole transform's N/16 (behind pass 0)
+	const unsigned b = tq / TPS, l = tq % TPS;                       // sub-transform (the top four index bits), lane in it
+	uint32_t *lds_t = lds - (size_t)(sg * 256u) * G::ROW;            // fft_exchange addresses rows by tq: this workgroup's are sg*256 ..
+	i64 acc[16];
+#pragma unroll
+	for (int r = 0; r < 16; r++)
+		acc[r] = 0;
+	const int pb = blockIdx.y * ppg, pe = min(np, pb + ppg);
+	// block index inside the launch's scratch: ((pass * tunes + tune) * nbpt + blk); a thread's 16 values are n = b * N/16 + x * TPS + l,
+	// the layout behind the first transpose.  The next pass's values are on their way while this one is transformed.
+	const size_t pass_step = ((size_t)tunes * (size_t)nbpt) << M;
+	const uint32_t *src = scratch + ((((size_t)pb * tunes + tune) * (size_t)nbpt + blk) << M) + (size_t)b * (N / 16) + l;
+	uint32_t nxt[16];
+	if (pb < pe) {
+#pragma unroll
+		for (int x = 0; x < 16; x++)
+			nxt[x] = src[x * TPS];
+	}
+	for (int pl = pb; pl < pe; pl++) {
+		uint32_t v[16];
+#pragma unroll
+		for (int x = 0; x < 16; x++)
+			v[x] = nxt[x];
+		src += pass_step;
+		if (pl + 1 < pe) {
+#pragma unroll
+			for (int x = 0; x < 16; x++)
+				nxt[x] = src[x * TPS];
+		}
+		__syncthreads();                                             // the previous transform's reads of the transpose area
+		fft_pass<M, 1>(v, twiddle, tq);
+		fft_exchange<M, 1>(v, lds_t, tq);
+		fft_pass<M, 2>(v, twiddle, tq);
+		if constexpr (G::P > 3) {
+			__syncthreads();
+			fft_exchange<M, 2>(v, lds_t, tq);
+			fft_pass<M, 3>(v, twiddle, tq);
+		}
+#pragma unroll
+		for (int r = 0; r < 16; r++) {
+			const i64 pw = (i64)pw_norm(v[r]);
+			acc[r] = PEAK ? (pw > acc[r] ? pw : acc[r]) : acc[r] + pw;
+		}
+	}
+	(void)p0;
+	if (partial) {
+		i64 *dst = partial + ((((size_t)blockIdx.y * tunes + tune) * (size_t)nbpt + blk) << M);
+#pragma unroll
+		for (int r = 0; r < 16; r++)
+			dst[__brev((tq << 4) | (unsigned)r) >> (32 - M)] = acc[r];
+		return;
+	}
+	i64 *avg_t = avg + ((size_t)tune << M);
+#pragma unroll
+	for (int r = 0; r < 16; r++) {
+		const unsigned bin = __brev((tq << 4) | (unsigned)r) >> (32 - M);
+		if (PEAK) atomicMax((long long *)&avg_t[bin], acc[r]);
+		else if (acc[r]) atomicAdd((unsigned long long *)&avg_t[bin], (unsigned long long)acc[r]);
+	}
+}
+
+// avg[tune][bin] (+= | max=) over the groups and blocks of partial: x over (tune, bin), y over 16 slices of the groups (a thread's
+// loads are independent and coalesced across the workgroup; 16 atomics per bin instead of one per pass)
+__global__ void k_pwm_reduce(const i64 *__restrict__ partial, int tunes, int nbpt, int groups, int bin_e, int peak_hold, i64 *__restrict__ avg)
+{
+	const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (gid >= ((size_t)tunes << bin_e))
+		return;
+	const size_t tune = gid >> bin_e, bin = gid & (((size_t)1 << bin_e) - 1);
+	const int per = (groups + (int)gridDim.y - 1) / (int)gridDim.y, g0 = (int)blockIdx.y * per, g1 = min(groups, g0 + per);
+	i64 a = 0;
+	bool any = false;
+	for (int g = g0; g < g1; g++)
+		for (int b = 0; b < nbpt; b++) {
+			const i64 v = partial[((((size_t)g * tunes + tune) * (size_t)nbpt + b) << bin_e) + bin];
+			a = peak_hold ? ((!any || v > a) ? v : a) : a + v;
+			any = true;
+		}
+	if (!any)
+		return;
+	if (peak_hold) atomicMax((long long *)&avg[gid], a);
+	else if (a) atomicAdd((unsigned long long *)&avg[gid], (unsigned long long)a);
+}
+
+// eff_len a multiple of 2^(bin_e+1), bin_e = 14 or 15; scratch: cap_blocks * 2^bin_e dwords; dc: 2 ints per (pass, tune)
+extern "C" int rxk_pw_fft_mid(void *stream, const int16_t *in, size_t tune_stride, size_t pass_stride, int passes, int tunes,
+                              int bin_e, int eff_len, const int *window, const uint32_t *twiddle, int peak_hold,
+                              uint32_t *scratch, size_t cap_blocks, int *dc, long long *avg, long long *partial, size_t partial_cap)
+{
+	hipStream_t s = (hipStream_t)stream;
+	const size_t n = (size_t)1 << bin_e;
+	const int nbpt = (int)((size_t)eff_len / (2 * n));
+	const size_t per_pass = (size_t)tunes * (size_t)nbpt;
+	if ((bin_e != 14 && bin_e != 15) || !nbpt || (size_t)eff_len % (2 * n) || cap_blocks < per_pass)
+		return -1;
+	const uint32_t *tw2 = twiddle + (n >> 1);                        // the doubled half of rxgpu_twiddle_table (bfly_pk)
+	hipLaunchKernelGGL(k_pwb_dc, dim3((unsigned)tunes, (unsigned)passes), dim3(256), 0, s, in, tune_stride, pass_stride, tunes, eff_len, dc);
+	const int max_np = (int)(cap_blocks / per_pass);
+	for (int p0 = 0; p0 < passes; p0 += max_np) {
+		const int np = passes - p0 < max_np ? passes - p0 : max_np;
+		const size_t q0 = (size_t)p0 * per_pass, nq = (size_t)np * per_pass;
+		const unsigned g_head = (unsigned)((nq * (n / 16) + 255) / 256);
+		/* enough workgroups to fill the chip, few enough that the int64 accumulators amortise the atomics */
+		const unsigned wg_x = (unsigned)(per_pass * (bin_e == 14 ? 4 : 8));
+		int groups = (int)((RXK_PWM_TARGET_WG + wg_x - 1) / wg_x);
+		if (groups > np) groups = np;
+		const int ppg = (np + groups - 1) / groups;
+		groups = (np + ppg - 1) / ppg;
+#define GOM(MM) do { \
+		hipLaunchKernelGGL((k_pwm_head<MM>), dim3(g_head), dim3(256), 0, s, in, tune_stride, pass_stride, tunes, nbpt, window, tw2, dc, \
+		                   q0, nq, scratch); \
+		if (peak_hold) hipLaunchKernelGGL((k_pwm_tail<MM, true>), dim3(wg_x, (unsigned)groups), dim3(256), 0, s, scratch, tunes, nbpt, p0, np, ppg, tw2, (i64 *)avg, part); \
+		else hipLaunchKernelGGL((k_pwm_tail<MM, false>), dim3(wg_x, (unsigned)groups), dim3(256), 0, s, scratch, tunes, nbpt, p0, np, ppg, tw2, (i64 *)avg, part); } while (0)
+		i64 *part = (partial && (size_t)groups * per_pass * n <= partial_cap) ? (i64 *)partial : nullptr;
+		if (bin_e == 14) GOM(14); else GOM(15);
+#undef GOM
+		if (part)
+			hipLaunchKernelGGL(k_pwm_reduce, dim3((unsigned)((((size_t)tunes << bin_e) + 255) / 256), 16), dim3(256), 0, s, part, tunes, nbpt, groups, bin_e,
+			                   peak_hold, (i64 *)avg);
+	}
+	LAUNCH_RET();
+}
+
 // scratch: cap_blocks * 2^bin_e dwords; dc: 2 ints per (pass, tune)
 extern "C" int rxk_pw_fft_big(void *stream, const int16_t *in, size_t tune_stride, size_t pass_stride, int passes, int tunes,
                               int bin_e, int eff_len, const int *window, const uint32_t *twiddle, int peak_hold,
@@ -662,7 +844,7 @@ extern "C" int rxk_pw_fft_big(void *stream, const int16_t *in, size_t tune_strid
 
 extern "C" int rxk_pw_fft(void *stream, const int16_t *in, size_t tune_stride, size_t pass_stride, int passes, int tunes,
                           int bin_e, int eff_len, int dc_len, const int *window, const uint32_t *twiddle, int peak_hold,
-                          int passes_per_group, long long *avg)
+                          int passes_per_group, long long *avg, long long *partial, size_t partial_cap)
 {
 	(void)dc_len;
 	const int n = 1 << bin_e;
@@ -670,7 +852,11 @@ extern "C" int rxk_pw_fft(void *stream, const int16_t *in, size_t tune_stride, s
 	const int groups = (passes + passes_per_group - 1) / passes_per_group;
 	dim3 grid((unsigned)tunes, (unsigned)groups);
 	hipStream_t s = (hipStream_t)stream;
-	if (bin_e == 12 && (eff_len == 8192 || eff_len == 16384 || eff_len == 32768) && !getenv("RXGPU_FFT_GENERIC")) {
+	const int fpw = n >= 4096 ? 1 : 4096 / n;                       /* transforms side by side in a k_pw_fftR workgroup */
+	const bool k4096 = bin_e == 12 && (eff_len == 8192 || eff_len == 16384 || eff_len == 32768) && !getenv("RXGPU_FFT_GENERIC");
+	i64 *part = (partial && !k4096 && bin_e >= 8 && bin_e <= 13 && eff_len % (2 * n) == 0 &&
+	             (size_t)groups * tunes * fpw * (size_t)n <= partial_cap) ? (i64 *)partial : nullptr;
+	if (k4096) {
 		const int nb = eff_len / 8192;
 #define GO4K(NB) do { if (peak_hold) hipLaunchKernelGGL((k_pw_fft4096<NB, true>), grid, dim3(256), 0, s, in, tune_stride, pass_stride, passes, window, twiddle + 2048, passes_per_group, (i64 *)avg); \
 		else hipLaunchKernelGGL((k_pw_fft4096<NB, false>), grid, dim3(256), 0, s, in, tune_stride, pass_stride, passes, window, twiddle + 2048, passes_per_group, (i64 *)avg); } while (0)
@@ -688,13 +874,16 @@ extern "C" int rxk_pw_fft(void *stream, const int16_t *in, size_t tune_stride, s
 		if (lds_bytes > 64 * 1024) { \
 			(void)hipFuncSetAttribute((const void *)k_pw_fftR<MM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
 			(void)hipFuncSetAttribute((const void *)k_pw_fftR<MM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); } \
-		if (peak_hold) hipLaunchKernelGGL((k_pw_fftR<MM, true>), grid, dim3(T), lds_bytes, s, in, tune_stride, pass_stride, passes, nb_total, window, twiddle + (1 << (MM - 1)), passes_per_group, (i64 *)avg); \
-		else hipLaunchKernelGGL((k_pw_fftR<MM, false>), grid, dim3(T), lds_bytes, s, in, tune_stride, pass_stride, passes, nb_total, window, twiddle + (1 << (MM - 1)), passes_per_group, (i64 *)avg); } while (0)
+		if (peak_hold) hipLaunchKernelGGL((k_pw_fftR<MM, true>), grid, dim3(T), lds_bytes, s, in, tune_stride, pass_stride, passes, nb_total, window, twiddle + (1 << (MM - 1)), passes_per_group, (i64 *)avg, part); \
+		else hipLaunchKernelGGL((k_pw_fftR<MM, false>), grid, dim3(T), lds_bytes, s, in, tune_stride, pass_stride, passes, nb_total, window, twiddle + (1 << (MM - 1)), passes_per_group, (i64 *)avg, part); } while (0)
 		switch (bin_e) {
 		case 8: GOR(8); break; case 9: GOR(9); break; case 10: GOR(10); break; case 11: GOR(11); break;
 		case 12: GOR(12); break; default: GOR(13); break;
 		}
 #undef GOR
+		if (part)
+			hipLaunchKernelGGL(k_pwm_reduce, dim3((unsigned)((((size_t)tunes << bin_e) + 255) / 256), 16), dim3(256), 0, s, part, tunes, fpw, groups, bin_e,
+			                   peak_hold, (i64 *)avg);
 		LAUNCH_RET();
 	}
 #define GO(A) do { \

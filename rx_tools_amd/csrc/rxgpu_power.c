@@ -187,6 +187,8 @@ struct rxgpu_power_scan {
 	uint32_t *big_scratch;     /* N > 2^15: FFT blocks in HBM */
 	int *big_dc;
 	size_t big_cap_blocks, big_dc_cap;
+	int64_t *big_partial;      /* N = 2^14, 2^15: per-group partial spectra of the two-launch transform */
+	size_t big_partial_cap;
 };
 
 /* rtl_fm.c:288-300 == rtl_power.c:213-225 */
@@ -273,7 +275,7 @@ void rxgpu_power_scan_destroy(rxgpu_power_scan *s)
 	hipFree(s->window_dev); hipFree(s->twiddle_dev); hipFree(s->fir_dev);
 	hipFree(s->work[0]); hipFree(s->work[1]);
 	hipFree(s->bx_head); hipFree(s->bx_tail);
-	hipFree(s->big_scratch); hipFree(s->big_dc);
+	hipFree(s->big_scratch); hipFree(s->big_dc); hipFree(s->big_partial);
 	hipFree(s->rms_t); hipFree(s->rms_p);
 	free(s);
 }
@@ -372,15 +374,34 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 	/* enough workgroups to fill 256 CUs several times over, few enough that the per-group
 	 * int64 accumulators amortise the global atomics */
 	int groups = (4096 + tunes - 1) / tunes;
+	/* few tunes (a narrow sweep with fine bins): thousands of passes land on the same N bins.  Fewer, longer groups, and their
+	 * spectra go to a partial buffer that one reduction folds into avg[] instead of int64 atomics from every group */
+	const int few = p->bin_e >= 8 && p->bin_e <= 13 && eff_len % (2 << p->bin_e) == 0 && tunes <= 64 && !getenv("RXGPU_FFT_GENERIC");
+	if (few)
+		groups = (1024 + tunes - 1) / tunes;
 	if (groups > passes) groups = passes;
 	if (groups < 1) groups = 1;
 	const int ppg = (passes + groups - 1) / groups;
 	const int n_blocks = (eff_len + 2 * (1 << p->bin_e) - 1) / (2 * (1 << p->bin_e));
+	if (few) {
+		const size_t fpw = p->bin_e >= 12 ? 1 : (size_t)4096 >> p->bin_e;
+		const size_t need = (size_t)((passes + ppg - 1) / ppg) * (size_t)tunes * fpw << p->bin_e;
+		if (s->big_partial_cap < need && need * 8 <= ((size_t)1 << 29)) {
+			hipFree(s->big_partial);
+			s->big_partial = NULL; s->big_partial_cap = 0;
+			if (hipMalloc((void **)&s->big_partial, need * 8) == hipSuccess)
+				s->big_partial_cap = need;
+		}
+	}
 	rxgpu_prof_begin("pw_fft");
-	if (p->bin_e > PW_LDS_BIN_E) {
+	/* N = 2^14, 2^15 with whole blocks: the register-blocked transform in two launches over a scratch copy (rxk_pw_fft_mid) */
+	const int mid = (p->bin_e == 14 || p->bin_e == 15) && eff_len % (2 << p->bin_e) == 0 && !getenv("RXGPU_FFT_GENERIC");
+	if (p->bin_e > PW_LDS_BIN_E || mid) {
 		const size_t total = (size_t)passes * (size_t)tunes * (size_t)n_blocks, n = (size_t)1 << p->bin_e;
 		size_t want = ((size_t)1 << 28) / n;                /* up to 1 GiB of scratch */
 		if (want > total) want = total;
+		if (mid && want < (size_t)tunes * (size_t)n_blocks)
+			want = (size_t)tunes * (size_t)n_blocks;       /* a launch of the two-kernel path covers whole passes */
 		if (want < 1) want = 1;
 		if (s->big_cap_blocks < want) {
 			hipFree(s->big_scratch);
@@ -394,11 +415,26 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 			RX_HIP(hipMalloc((void **)&s->big_dc, (size_t)passes * (size_t)tunes * 8));
 			s->big_dc_cap = (size_t)passes * (size_t)tunes;
 		}
-		RX_K(rxk_pw_fft_big(st, fft_in, fft_tune_stride, fft_pass_stride, passes, tunes, p->bin_e, eff_len,
-		                    s->window_dev, s->twiddle_dev, p->peak_hold, s->big_scratch, s->big_cap_blocks, s->big_dc, (long long *)d_avg));
+		if (mid) {
+			/* per-group partial spectra instead of atomics on avg[] (one tune: every pass lands on the same N bins) */
+			const size_t need = ((size_t)RXK_PWM_TARGET_WG / 4 + (size_t)tunes * (size_t)n_blocks) * n;
+			if (s->big_partial_cap < need && need * 8 <= ((size_t)1 << 29)) {
+				hipFree(s->big_partial);
+				s->big_partial = NULL; s->big_partial_cap = 0;
+				if (hipMalloc((void **)&s->big_partial, need * 8) == hipSuccess)
+					s->big_partial_cap = need;
+			}
+			RX_K(rxk_pw_fft_mid(st, fft_in, fft_tune_stride, fft_pass_stride, passes, tunes, p->bin_e, eff_len,
+			                    s->window_dev, s->twiddle_dev, p->peak_hold, s->big_scratch, s->big_cap_blocks, s->big_dc, (long long *)d_avg,
+			                    (long long *)s->big_partial, s->big_partial_cap));
+		}
+		else
+			RX_K(rxk_pw_fft_big(st, fft_in, fft_tune_stride, fft_pass_stride, passes, tunes, p->bin_e, eff_len,
+			                    s->window_dev, s->twiddle_dev, p->peak_hold, s->big_scratch, s->big_cap_blocks, s->big_dc, (long long *)d_avg));
 	} else {
 		RX_K(rxk_pw_fft(st, fft_in, fft_tune_stride, fft_pass_stride, passes, tunes, p->bin_e, eff_len, eff_len,
-		                s->window_dev, s->twiddle_dev, p->peak_hold, ppg, (long long *)d_avg));
+		                s->window_dev, s->twiddle_dev, p->peak_hold, ppg, (long long *)d_avg,
+		                few ? (long long *)s->big_partial : NULL, few ? s->big_partial_cap : 0));
 	}
 	rxgpu_prof_end("pw_fft");
 	RX_K(rxk_pw_samples(st, d_samples, tunes, n_blocks * ds * passes));   /* rtl_power.c:769 */

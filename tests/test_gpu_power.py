@@ -55,6 +55,9 @@ CASES = [
     ("100M:100.1M:10", 0.0, "rectangle", (1, 0, 0), 2000, 1, 1),    # N=16384, boxcar ds=28
     ("100M:100.1M:10", 0.0, "youssef", (0, 0, 0), 2000, 2, 1),      # fifth_order ds=16
     ("100M:100.1M:10", 0.0, "hann-poisson", (0, 9, 0), 30000, 1, 1),    # + droop FIR
+    ("100M:100.1M:10", 0.0, "blackman", (1, 0, 1), 32768, 3, 1),    # N=16384 (two-launch register-blocked path), full scale, peak hold
+    ("100M:100.2M:10", 0.0, "hamming", (1, 0, 0), 32768, 3, 1),     # N=32768, full scale
+    ("100M:100.2M:10", 0.0, "rectangle", (1, 0, 1), 9000, 2, 1),    # N=32768, peak hold
     ("100M:100.3M:100", 0.0, "rectangle", (1, 0, 0), 9000, 2, 1),   # boxcar, odd ds
     ("100M:102M:5k", 0.0, "hamming", (1, 0, 0), 20000, 2, 1),       # N=512
     ("100M:102M:10k", 0.0, "rectangle", (1, 0, 1), 9000, 3, 1),     # N=256
