@@ -630,7 +630,8 @@ def main():
             for label, rng, boxcar, window, amp, fir, npasses in (
                     ("full-scale input, hamming window (every int16 wrap of the window product and the butterflies)", "24M:1.7G:1k", 1, "hamming", 32767, 0, passes),
                     ("-f 100M:100.1M:10 -F 9: N=16384, fifth_order x4 (ds=16) + droop FIR, one tune", "100M:100.1M:10", 0, "rectangle", 2000, 9, 4096),
-                    ("-f 100M:100.1M:10 (boxcar ds=28), N=16384, one tune", "100M:100.1M:10", 1, "rectangle", 2000, 0, 4096)):
+                    ("-f 100M:100.1M:10 (boxcar ds=28), N=16384, one tune", "100M:100.1M:10", 1, "rectangle", 2000, 0, 4096),
+                    ("-f 100M:100.2M:10 (boxcar ds=14), N=32768, one tune", "100M:100.2M:10", 1, "rectangle", 2000, 0, 2048)):
                 pl = R.plan_range(rng, 0.0, boxcar)
                 nn = 1 << pl.bin_e
                 p2 = R.PowerScan(R.PowerParams(pl.bin_e, pl.buf_len, pl.downsample, pl.downsample_passes, boxcar, fir, 0), pl.tune_count,
