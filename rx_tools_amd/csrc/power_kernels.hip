@@ -166,7 +166,7 @@ __device__ __forceinline__ void radix16_pass(uint32_t (&v)[16], const uint32_t *
 template <int NB, bool PEAK>
 __global__ __launch_bounds__(256) void k_pw_fft4096(
 	const int16_t *__restrict__ in, size_t tune_stride, size_t pass_stride, int passes,
-	const int *__restrict__ window, const uint32_t *__restrict__ twiddle, int ppg, i64 *__restrict__ avg)
+	const int *__restrict__ window, const uint32_t *__restrict__ twiddle, int ppg, i64 *__restrict__ avg, i64 *__restrict__ partial)
 {
 	__shared__ __attribute__((aligned(16))) uint32_t xa[F4K_BUF];
 	__shared__ __attribute__((aligned(16))) uint32_t xb[F4K_BUF + 16 * 16];
@@ -259,11 +259,15 @@ __global__ __launch_bounds__(256) void k_pw_fft4096(
 			}
 		}
 	}
+	// few tunes: this group's spectrum to partial[(group * tunes + tune) * 4096 + bin] (k_pwm_reduce folds the groups into avg);
+	// otherwise straight into avg with one atomic per bin and group
 	i64 *avg_t = avg + (size_t)tune * 4096;
+	i64 *dst = partial ? partial + ((size_t)blockIdx.y * gridDim.x + tune) * 4096 : nullptr;
 #pragma unroll
 	for (int r = 0; r < 16; r++) {
 		const unsigned bin = base_c + 256u * (unsigned)crev<4>(r);
-		if (PEAK) atomicMax((long long *)&avg_t[bin], acc[r]);
+		if (dst) dst[bin] = acc[r];
+		else if (PEAK) atomicMax((long long *)&avg_t[bin], acc[r]);
 		else atomicAdd((unsigned long long *)&avg_t[bin], (unsigned long long)acc[r]);
 	}
 }
@@ -854,14 +858,17 @@ extern "C" int rxk_pw_fft(void *stream, const int16_t *in, size_t tune_stride, s
 	hipStream_t s = (hipStream_t)stream;
 	const int fpw = n >= 4096 ? 1 : 4096 / n;                       /* transforms side by side in a k_pw_fftR workgroup */
 	const bool k4096 = bin_e == 12 && (eff_len == 8192 || eff_len == 16384 || eff_len == 32768) && !getenv("RXGPU_FFT_GENERIC");
-	i64 *part = (partial && !k4096 && bin_e >= 8 && bin_e <= 13 && eff_len % (2 * n) == 0 &&
+	i64 *part = (partial && bin_e >= 8 && bin_e <= 13 && eff_len % (2 * n) == 0 &&
 	             (size_t)groups * tunes * fpw * (size_t)n <= partial_cap) ? (i64 *)partial : nullptr;
 	if (k4096) {
 		const int nb = eff_len / 8192;
-#define GO4K(NB) do { if (peak_hold) hipLaunchKernelGGL((k_pw_fft4096<NB, true>), grid, dim3(256), 0, s, in, tune_stride, pass_stride, passes, window, twiddle + 2048, passes_per_group, (i64 *)avg); \
-		else hipLaunchKernelGGL((k_pw_fft4096<NB, false>), grid, dim3(256), 0, s, in, tune_stride, pass_stride, passes, window, twiddle + 2048, passes_per_group, (i64 *)avg); } while (0)
+#define GO4K(NB) do { if (peak_hold) hipLaunchKernelGGL((k_pw_fft4096<NB, true>), grid, dim3(256), 0, s, in, tune_stride, pass_stride, passes, window, twiddle + 2048, passes_per_group, (i64 *)avg, part); \
+		else hipLaunchKernelGGL((k_pw_fft4096<NB, false>), grid, dim3(256), 0, s, in, tune_stride, pass_stride, passes, window, twiddle + 2048, passes_per_group, (i64 *)avg, part); } while (0)
 		if (nb == 1) GO4K(1); else if (nb == 2) GO4K(2); else GO4K(4);
 #undef GO4K
+		if (part)
+			hipLaunchKernelGGL(k_pwm_reduce, dim3((unsigned)((((size_t)tunes << bin_e) + 255) / 256), 16), dim3(256), 0, s, part, tunes, 1, groups, bin_e,
+			                   peak_hold, (i64 *)avg);
 		LAUNCH_RET();
 	}
 	if (bin_e >= 8 && bin_e <= 13 && eff_len % (2 * n) == 0 && !getenv("RXGPU_FFT_GENERIC")) {

@@ -50,6 +50,8 @@ CASES = [
     ("24M:1.7G:1k", 0.0, "rectangle", (1, 0, 0), 100, 3, 7),        # config 3 geometry, no window wrap
     ("24M:1.7G:1k", 0.0, "rectangle", (1, 0, 0), 32768, 2, 5),      # full scale: wraps everywhere
     ("24M:1.7G:1k", 0.0, "hamming", (1, 0, 1), 3000, 3, 4),         # peak hold
+    ("24M:1.7G:1k", 0.0, "hamming", (1, 0, 0), 3000, 2, 70),        # more than 64 tunes: straight atomics on avg[] (fewer: per-group partial spectra)
+    ("24M:1.7G:1k", 0.0, "rectangle", (1, 0, 1), 20000, 40, 2),     # many passes of two tunes: several groups per tune through the partial buffer, peak hold
     ("88M:108M:125k", 0.0, "blackman-harris", (1, 0, 0), 5000, 2, 8),   # N=32
     ("100M:101M:1k", 0.2, "bartlett", (1, 0, 0), 500, 2, 1),        # N=1024
     ("100M:100.1M:10", 0.0, "rectangle", (1, 0, 0), 2000, 1, 1),    # N=16384, boxcar ds=28
