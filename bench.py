@@ -12,7 +12,8 @@ own rtlsdr_callback + full_demod) and every output sample and carry of the pipel
 `parity_checked_samples` in the JSON line.
 
 The same line carries:
-  rx_fm_variants   the small-decimation chains (-M wbfm default ds=6; BASELINE configs[0] ds=5 / 240 kHz) and the -F cascade
+  rx_fm_variants   the small-decimation chains (-M wbfm default ds=6; BASELINE configs[0] ds=5 / 240 kHz) and the -F cascade;
+                   the ds=6 chain (other kernels at size) is also compared with the CPU reference, over a quarter of the capture
   host_fed         rxgpu_fm_stream_run_host from pinned host memory (PCIe-inclusive; never `value`) and the drop-in's
                    per-block latency (rxgpu_callback + rxgpu_full_demod on a struct demod_state)
   rx_power         FFT bins/s of the scanner() chain at the configs[2] geometry (-f 24M:1.7G:1k: 599 tunes x 16384 int16,
@@ -428,6 +429,14 @@ def main():
                                    "host_fixups": int(sv.host_fixups)}
                 sv.close()
                 del d_o
+        # the small-decimation chain takes other kernels at size (spans of whole windows, the register scan of runs of 2^25+ demodulated
+        # samples, the occupancy caps): a quarter of the capture through it, pipelined, against the CPU reference as well
+        if world == 1 and args.variants == "all" and not args.no_parity and variants:
+            sub = max(1, n_blocks // 4)
+            pv = check_against_cpu(torch, R, L, d_iq[: sub * block_len], sub, block_len, max(1, sub // 16), dict(downsample=6))
+            variants["-M wbfm default, downsample=6"]["parity"] = {k: pv[k] for k in pv if k not in ("parity_sequence", "parity_checker")}
+            if not pv["parity_ok"]:
+                parity["parity_ok"] = False
         # ---- host-fed leg (PCIe-inclusive, never `value`) and the drop-in's per-block latency
         host_fed = {}
         if world == 1 and args.variants == "all":
