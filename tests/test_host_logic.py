@@ -122,3 +122,17 @@ def test_shard_tunes_cover_every_tune_once():
                 assert per == -(-total // world) and cnt <= per
                 seen += list(range(lo, lo + cnt))
             assert seen == list(range(total))
+
+
+def test_profiles_hold_what_bench_reads():
+    """bench.py takes the decimator's HBM traffic and rx_power's VALU instruction count from the committed PMC summary
+    (profiles/rNN_pmc_summary.json, made by tools/collect_profiles.py): the kernels' template arguments are part of the
+    keys, so a renamed instantiation would silently turn `roofline.traffic` into null"""
+    import json, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pmc = json.load(open(os.path.join(root, "profiles", "r02_pmc_summary.json")))
+    dec = [v for k, v in pmc.items() if k.startswith("k_fm_decimate<false, true, true") and isinstance(v, dict) and v.get("hbm_bytes_per_launch")]
+    fft = [v for k, v in pmc.items() if k.startswith("k_pw_fft4096") and isinstance(v, dict) and v.get("SQ_INSTS_VALU")]
+    assert dec and fft
+    # 4 GiB launches: fetched + written bytes within 2 % of the 4 B per sample the path needs
+    assert abs(dec[0]["hbm_bytes_per_launch"] / (4.0 * (1 << 30)) - 1.0) < 0.02
