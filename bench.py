@@ -236,58 +236,11 @@ def device_capture(torch, dev, n_complex, seed, fs=20.06e6, amp=20000.0, tone=10
     return out
 
 
-def check_against_cpu(torch, R, L, d_iq, n_blocks, block_len, tail_blocks, params_kw):
-    """The pipelined GPU sequence [all n_blocks][the first tail_blocks again, carries chained] against the CPU reference
-    (oracle/_ref: the reference's own rtlsdr_callback + full_demod; the oracle port where the prebuilt object is absent)
-    over the very same samples: every int16 of output, every carry the struct exposes."""
+def parity_module():
+    """tests/parity_at_size.py: the checks against the CPU reference at bench size (checker infrastructure, loads oracle/)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import support
-    from rx_tools_amd.structs import DemodState
-    T = n_blocks * (block_len // 2)
-    ds = params_kw["downsample"]
-    d_out = torch.zeros((T + tail_blocks * (block_len // 2)) // ds + 128, dtype=torch.int16, device=d_iq.device)
-    s = R.FmStream(R.FmParams.wbfm(**params_kw), n_blocks, block_len)
-    t0 = time.perf_counter()
-    n1, _ = s.run_async(d_iq.data_ptr(), n_blocks, block_len, d_out.data_ptr(), d_out.numel())
-    n2, _ = s.run_async(d_iq.data_ptr(), tail_blocks, block_len, d_out.data_ptr() + 2 * n1, d_out.numel() - n1)
-    s.wait()
-    gpu_s = time.perf_counter() - t0
-    got = d_out[:n1 + n2].cpu().numpy()
-    carry = s.get_carry()
-    fix = s.host_fixups
-    s.close()
-    h_iq = d_iq.cpu().numpy()
-    calls = n_blocks + tail_blocks
-    want = np.zeros(n1 + n2 + 4096, np.int16)
-    t0 = time.perf_counter()
-    if support.have_ref():
-        F = support.ref_fm()
-        d, _ = support.ref_fm_reset(F, **params_kw)
-        scratch = np.zeros(block_len, np.int16)
-        produced = F.ref_fm_run_blocks(support.ptr16(h_iq), n_blocks, block_len, calls, support.ptr16(scratch), support.ptr16(want), want.size)
-        d = DemodState.from_address(F.ref_fm_demod())
-        ref_carry = (d.now_r, d.now_j, d.prev_index, d.pre_r, d.pre_j, d.now_lpr, d.prev_lpr_index)
-        kind = "reference"
-    else:
-        O = support.oracle()
-        st = support.oracle_fm_state(**params_kw)
-        produced = O.rxo_fm_stream(C.byref(st), support.ptr16(h_iq), n_blocks, block_len, support.ptr16(want), None)
-        produced += O.rxo_fm_stream(C.byref(st), support.ptr16(h_iq), tail_blocks, block_len, support.ptr16(want[produced:]), None)
-        ref_carry = (st.now_r, st.now_j, st.prev_index, st.pre_r, st.pre_j, st.now_lpr, st.prev_lpr_index)
-        kind = "port"
-    cpu_s = time.perf_counter() - t0
-    gpu_carry = (carry.now_r, carry.now_j, carry.prev_index, carry.pre_r, carry.pre_j, carry.now_lpr, carry.prev_lpr_index)
-    ok = produced == n1 + n2 and np.array_equal(got, want[:produced]) and gpu_carry == ref_carry
-    res = {"parity_checked_samples": calls * (block_len // 2), "parity_ok": bool(ok), "parity_outputs_compared": int(produced),
-           "parity_checker": kind, "parity_cpu_seconds": cpu_s, "parity_gpu_seconds": gpu_s, "parity_host_fixups": int(fix),
-           "parity_sequence": "2 pipelined runs (%d + %d blocks), carries chained on the device; output and now_r/now_j/prev_index/"
-                              "pre_r/pre_j/now_lpr/prev_lpr_index compared" % (n_blocks, tail_blocks)}
-    if not ok:
-        bad = np.nonzero(got[:min(len(got), produced)] != want[:min(len(got), produced)])[0]
-        res["parity_first_mismatch"] = int(bad[0]) if bad.size else -1
-        res["parity_carries"] = {"gpu": gpu_carry, "cpu": ref_carry, "gpu_len": int(n1 + n2), "cpu_len": int(produced)}
-    del h_iq
-    return res
+    import parity_at_size
+    return parity_at_size
 
 
 def main():
@@ -364,6 +317,7 @@ def main():
         raise KeyError(prefix)
 
     result = {}
+    parity_all = {}            # leg -> verdict of its check against the CPU reference at bench size
 
     # ------------------------------------------------------------------ rx_fm (headline)
     if args.workload in ("both", "rx_fm"):
@@ -394,11 +348,9 @@ def main():
         s.close()
         del d_out
         parity = {}
-        if world == 1 and not args.no_parity:
-            parity = check_against_cpu(torch, R, L, d_iq, n_blocks, block_len, max(1, n_blocks // 16), hp)
         # SURVEY 8(d) config 2 also names the -F variant; and the -M wbfm default decimation; BASELINE configs[0] is ds=5 at 240 kHz.
         # Same buffer, same pipelined loop, a few steps each; reported beside the headline, not part of `value`.
-        variants = {}
+        variants, variant_kw = {}, {}
         if world == 1 and args.variants == "all":
             todo = [("-M wbfm default, downsample=6", dict(downsample=6), 6),
                     ("BASELINE configs[0] geometry: -s 240000, downsample=5, deemph_a=19", dict(downsample=5, rate_out=240000, deemph_a=19), 5),
@@ -424,32 +376,51 @@ def main():
                     sms, sn = prof(nm)
                     if sn:
                         stages[nm] = round(sms / sn * 1e3, 1)
+                variant_kw[label] = kw
                 variants[label] = {"value": T * k / tv / 1e6, "unit": "MSample/s", "ms_per_step": tv / k * 1e3, "steps": k,
                                    "frac_of_hbm_peak": 4.0 * T * k / tv / 1e9 / HBM_PEAK_GBS, "stage_us_per_step": stages,
                                    "host_fixups": int(sv.host_fixups)}
                 sv.close()
                 del d_o
-        # the small-decimation chain takes other kernels at size (spans of whole windows, the register scan of runs of 2^25+ demodulated
-        # samples, the occupancy caps): a quarter of the capture through it, pipelined, against the CPU reference as well
-        if world == 1 and args.variants == "all" and not args.no_parity and variants:
-            sub = max(1, n_blocks // 4)
-            pv = check_against_cpu(torch, R, L, d_iq[: sub * block_len], sub, block_len, max(1, sub // 16), dict(downsample=6))
-            variants["-M wbfm default, downsample=6"]["parity"] = {k: pv[k] for k in pv if k not in ("parity_sequence", "parity_checker")}
-            if not pv["parity_ok"]:
-                parity["parity_ok"] = False
+        # Every chain that was timed, in the launch shape that was timed (all n_blocks in one run, then a chained second run), against
+        # the CPU reference over the WHOLE capture: output sample by sample and every carry.  The GPU sequences run first; the
+        # reference legs (one forked checker per chain, tests/parity_at_size.py) then run side by side on the host cores.
+        h_iq = None
+        if world == 1 and not args.no_parity:
+            PA = parity_module()
+            tail = max(1, n_blocks // 16)
+            legs = {"headline": (hp, PA.fm_gpu_sequence(torch, R, d_iq, n_blocks, block_len, tail, hp))}
+            for label, kw in variant_kw.items():
+                legs[label] = (kw, PA.fm_gpu_sequence(torch, R, d_iq, n_blocks, block_len, tail, kw))
+            h_iq = d_iq.cpu().numpy()
+            verdicts = PA.fm_check_many(h_iq, n_blocks, block_len, legs)
+            parity = dict(verdicts["headline"])
+            parity["parity_sequence"] = ("2 pipelined runs (%d + %d blocks), carries chained on the device; output and every carry of the chain "
+                                         "(now_r/now_j/prev_index or lp_*_hist/droop_*_hist, pre_r/pre_j, now_lpr/prev_lpr_index) compared" % (n_blocks, tail))
+            parity["parity_legs"] = {lb: bool(v["parity_ok"]) for lb, v in verdicts.items()}
+            for label in variant_kw:
+                variants[label]["parity"] = verdicts[label]
+            parity["parity_ok"] = all(v["parity_ok"] for v in verdicts.values())
+            headline_got = legs["headline"][1]["got"]
+            del legs
         # ---- host-fed leg (PCIe-inclusive, never `value`) and the drop-in's per-block latency
         host_fed = {}
         if world == 1 and args.variants == "all":
             hb = min(n_blocks, 4096)                                  # 2 GiB of capture from host memory
-            h_iq = d_iq[: hb * block_len].cpu().numpy()
+            h_iq = h_iq[: hb * block_len] if h_iq is not None else d_iq[: hb * block_len].cpu().numpy()
             h_out = np.zeros(hb * (block_len // 2) // 118 + 4096, np.int16)
+            hf_same = None
             sh = R.FmStream(R.FmParams.wbfm(**hp), hb, block_len)
             legs = {}
             for label, pin in (("pinned (rxgpu_pin)", True), ("pageable", False)):
                 if pin:
                     R.check(L.rxgpu_pin(h_iq.ctypes.data, h_iq.nbytes))
                 try:
-                    sh.run_host(h_iq.ctypes.data, hb, block_len, h_out.ctypes.data, h_out.size)        # staging allocated, pages touched
+                    nh, _ = sh.run_host(h_iq.ctypes.data, hb, block_len, h_out.ctypes.data, h_out.size)  # staging allocated, pages touched
+                    if parity and hf_same is None:
+                        # the same chain from host memory, from zero carries: a prefix of what the device-resident run (checked above) produced
+                        hf_same = bool(nh <= headline_got.size and np.array_equal(h_out[:nh], headline_got[:nh]))
+                        hf_n = nh
                     t0 = time.perf_counter()
                     reps = 3
                     for _ in range(reps):
@@ -464,6 +435,11 @@ def main():
             host_fed = {"metric": "rxgpu_fm_stream_run_host: %d blocks (%.1f GiB) from host memory, 64 MiB chunks, H2D on a copy stream "
                                   "overlapped with the demodulation of the previous chunk, results copied back" % (hb, h_iq.nbytes / 2 ** 30),
                         "pcie_peak_GBs": PCIE_PEAK_GBS, "legs": legs}
+            if hf_same is not None:
+                host_fed["parity"] = {"parity_ok": hf_same, "parity_how": "output of the host-fed runs == the first %d int16 of the device-resident "
+                                                                        "sequence that was checked against the reference" % hf_n}
+                parity["parity_legs"]["host_fed"] = hf_same
+                parity["parity_ok"] = parity["parity_ok"] and hf_same
             del h_iq
             # drop-in: rxgpu_callback + rxgpu_full_demod on the reference's own structs, block after block
             from rx_tools_amd.structs import DemodState, DongleState
@@ -530,6 +506,8 @@ def main():
                          "algorithmic_bytes_per_launch": 4 * T, "avg_launch_ms": (ms / launches) if launches else None},
         })
         result.update(parity)
+        if parity:
+            parity_all["rx_fm"] = bool(parity["parity_ok"])
         if rank == 0 and args.cpu_seconds > 0 and world == 1:
             result["cpu_baseline"] = cpu_baseline_fm(block_len, args.cpu_seconds)
             result["cpu_baseline"]["reference_default_build_O0"] = cpu_subprocess("fm", min(3.0, args.cpu_seconds), "libref_fm_O0.so")
@@ -631,6 +609,18 @@ def main():
                          "traffic": None, "algorithmic_bytes_per_launch": 4 * bins_local,
                          "avg_launch_ms": (ms / launches) if launches else None},
         }
+        # the launch that was timed -- all passes, all tunes of this rank -- once more into zeroed integrators, against the
+        # reference's own scanner() over every tune (tests/parity_at_size.py: forked checkers, tunes dealt to the host cores)
+        pw_parity_ok = True
+        if world == 1 and not args.no_parity:
+            PA = parity_module()
+            da = torch.zeros((per, n), dtype=torch.int64, device=dev)
+            dsm = torch.zeros(per, dtype=torch.int32, device=dev)
+            ps.run(d_in.data_ptr(), passes, mine, da.data_ptr(), dsm.data_ptr())
+            R.check(L.rxgpu_sync())
+            pw["parity"] = PA.power_check("24M:1.7G:1k", 0.0, "rectangle", 1, 0, 0, d_in.cpu().numpy(), da.cpu().numpy(), dsm.cpu().numpy())
+            pw_parity_ok = pw["parity"]["parity_ok"]
+            del da, dsm
         ps.close()
         del d_in
         # two more geometries of SURVEY 8(d) config 3, one launch shape each, rank 0 only (not part of `value`)
@@ -661,9 +651,19 @@ def main():
                 more[label] = {"Mbins/s": in_samples / pl.downsample / t2 / 1e6, "input MSample/s": in_samples / t2 / 1e6,
                                "GB/s_in": 4.0 * in_samples / t2 / 1e9, "frac_of_hbm_peak": 4.0 * in_samples / t2 / 1e9 / HBM_PEAK_GBS,
                                "N": nn, "downsample": pl.downsample, "tunes": pl.tune_count, "passes": npasses, "ms": t2 * 1e3}
+                if not args.no_parity:
+                    da.zero_()
+                    dsm.zero_()
+                    p2.run(di.data_ptr(), npasses, pl.tune_count, da.data_ptr(), dsm.data_ptr())
+                    R.check(L.rxgpu_sync())
+                    more[label]["parity"] = PA.power_check(rng, 0.0, window, boxcar, fir, 0, di.cpu().numpy(), da.cpu().numpy(), dsm.cpu().numpy())
+                    pw_parity_ok = pw_parity_ok and more[label]["parity"]["parity_ok"]
                 p2.close()
                 del di, da, dsm
         pw["other_geometries"] = more
+        if world == 1 and not args.no_parity:
+            pw["parity_ok"] = bool(pw_parity_ok)
+            parity_all["rx_power"] = bool(pw_parity_ok)
         if rank == 0 and args.cpu_seconds > 0 and world == 1:
             pw["cpu_baseline"] = cpu_baseline_power(plan, args.cpu_seconds / 2)
             pw["cpu_baseline"]["reference_default_build_O0"] = cpu_subprocess("power", min(3.0, args.cpu_seconds / 2), "libref_power_O0.so")
@@ -700,6 +700,15 @@ def main():
         L.rxgpu_prof_enable(0)
         ms, launches = prof("ch_fft")
         chan_fix = ch.host_fixups
+        chan_parity = None
+        if world == 1 and not args.no_parity:
+            # one more run of the timed shape from zero carries: every window of every channel against the oracle's channeliser
+            PA = parity_module()
+            ch.set_carry(np.zeros(2 * n_ch, np.int32))
+            ch.run(d_iq.data_ptr(), n_blocks, block_len, d_out.data_ptr(), windows)
+            chan_parity = PA.chan_check(d_iq.cpu().numpy(), n_blocks, block_len, bin_e, 384, n_ch, 1, R.sine_table(bin_e),
+                                        d_out.cpu().numpy(), ch.get_carry())
+            parity_all["channeliser"] = bool(chan_parity["parity_ok"])
         ch.close()
         achieved = (4.0 * T) / (ms / launches * 1e-3) / 1e9 if launches else 0.0
         result["channeliser"] = {
@@ -713,6 +722,8 @@ def main():
                          "avg_launch_ms": (ms / launches) if launches else None,
                          "note": "integer-VALU bound like k_pw_fft (register-blocked radix-16 passes, packed butterfly)"},
         }
+        if chan_parity is not None:
+            result["channeliser"]["parity"] = chan_parity
         del d_iq, d_out
 
     # ------------------------------------------------------------------ rx_sdr -F conversions
@@ -723,10 +734,23 @@ def main():
         d12 = torch.randint(0, 256, (3 * n_elems,), dtype=torch.uint8, device=dev, generator=g)
         torch.cuda.synchronize()
         legs = {}
+        sdr_same = True
         for fmt in ("CU8", "CS8", "CF32", "CS16"):
             conv = R.SDR_CONVERSIONS[fmt][0]
             src = d12 if fmt == "CS16" else d16
             out = R.sdr_convert(fmt, src)
+            if not args.no_parity:
+                # head and tail of the 2^28-element launch against the oracle's converters (every int16 value is covered by the tests)
+                PA = parity_module()
+                R.check(L.rxgpu_sync())
+                m = 1 << 20
+                in_per, out_per = (3, 2) if fmt == "CS16" else (2, 2)
+                same = True
+                for lo in (0, n_elems - m):
+                    want = PA.support.oracle_sdr_convert(fmt, src[lo * in_per:(lo + m) * in_per].cpu().numpy())
+                    have = out.view(-1)[lo * out_per:(lo + m) * out_per].cpu().numpy()
+                    same = same and np.array_equal(have.view(np.uint8), want.view(np.uint8))
+                sdr_same = sdr_same and same
             L.rxgpu_prof_reset()
             L.rxgpu_prof_enable(2)
             reps = 10
@@ -743,15 +767,21 @@ def main():
             del out
         result["sdr_convert"] = {"metric": "rx_sdr -F output conversions, complex MSample/s and HBM GB/s (read + write), 2^28 elements per launch",
                                  "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "legs": legs}
+        if not args.no_parity:
+            result["sdr_convert"]["parity_ok"] = bool(sdr_same)
+            parity_all["sdr_convert"] = bool(sdr_same)
         del d16, d12
 
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        if parity_all:
+            result["parity_all_legs"] = parity_all
+            result["parity_ok"] = all(parity_all.values())
         print(json.dumps(result))
         if result.get("parity_ok") is False:
-            sys.stderr.write("bench.py: the pipelined GPU output differs from the CPU reference at bench size\n")
+            sys.stderr.write("bench.py: GPU output differs from the CPU reference at bench size: %s\n" % sorted(k for k, v in parity_all.items() if not v))
             sys.exit(3)
 
 
