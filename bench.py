@@ -258,6 +258,8 @@ def main():
     ap.add_argument("--variants", default="all", choices=["all", "none"],
                     help="rx_fm side figures (ds=6, ds=5/240k, -F cascade, host-fed); `none` keeps the per-kernel averages of a "
                          "rocprofv3 run of this command to the headline launches (the ds=6 chain launches the same decimator kernel)")
+    ap.add_argument("--allow-torch-gather", action="store_true",
+                    help="N>1 only: if librxgpu's own RCCL communicator cannot be created, gather through torch.distributed instead of failing")
     ap.add_argument("--no-parity", action="store_true", help="skip the full-size comparison with the CPU reference")
     args = ap.parse_args()
     if args.cpu_worker:
@@ -531,20 +533,26 @@ def main():
         d_smps = [torch.zeros(per, dtype=torch.int32, device=dev) for _ in range(2)]
         d_avg_all = torch.zeros((world, per, n), dtype=torch.int64, device=dev) if rank == 0 else None
         d_smp_all = torch.zeros((world, per), dtype=torch.int32, device=dev) if rank == 0 else None
-        comm, gather_impl, comm_err = None, "single process (no collective)", None
+        comm, gather_impl = None, "single process (no collective)"
         if world > 1:
+            # the product's own communicator (librccl bound by librxgpu); a failure here FAILS the run -- a scaling curve measured
+            # through torch.distributed.gather would not be the product's -- unless --allow-torch-gather says otherwise
+            comm_err = None
             try:
                 comm = shard.Comm.from_torch_distributed()
-                gather_impl = "librxgpu rxgpu_power_gather: ncclGather(avg int64) + ncclGather(samples int32) from %s on the library's stream" % shard.Comm.library()
-            except Exception as e:                               # noqa: BLE001 -- say so in the line and fall back to torch.distributed
+                gather_impl = "librxgpu rxgpu_power_gather: one ncclGroup {ncclGather(avg int64), ncclGather(samples int32)} from %s on the library's stream" % shard.Comm.library()
+            except Exception as e:                               # noqa: BLE001
                 comm_err = repr(e)
-                gather_impl = "torch.distributed.gather (backend nccl = RCCL); librxgpu's own communicator failed: " + comm_err
             ok = torch.tensor([1 if comm is not None else 0], device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0 and comm is not None:          # all ranks or none
-                comm.close()
-                comm = None
-                gather_impl = "torch.distributed.gather (backend nccl = RCCL); librxgpu's communicator failed on another rank"
+            if int(ok.item()) == 0:                              # all ranks or none
+                if comm is not None:
+                    comm.close()
+                    comm = None
+                if not args.allow_torch_gather:
+                    raise SystemExit("bench.py: librxgpu's RCCL communicator could not be created on every rank (%s); "
+                                     "--allow-torch-gather measures torch.distributed.gather instead" % (comm_err or "another rank failed"))
+                gather_impl = "torch.distributed.gather (backend nccl = RCCL), --allow-torch-gather; librxgpu's communicator failed: %s" % (comm_err or "on another rank")
         gbuf = shard.gather_buffers(d_avgs[0], dst=0) if (world > 1 and comm is None) else None
         sbuf = shard.gather_buffers(d_smps[0], dst=0) if (world > 1 and comm is None) else None
         state = {"k": 0}
@@ -579,6 +587,7 @@ def main():
         L.rxgpu_prof_enable(0)
         ms, launches = prof("pw_fft")
         gms, gl = prof("pw_gather")
+        observed = comm.observed if comm is not None else (0, 1)
         bins_per_step_all = passes * total_tunes * (plan.buf_len // 2)
         bins_local = passes * mine * (plan.buf_len // 2)
         hbm_achieved = (4.0 * bins_local) / (ms / launches * 1e-3) / 1e9 if launches else 0.0
@@ -596,7 +605,10 @@ def main():
             "value": bins_per_step_all * args.steps / dt / 1e6, "unit": "Mbins/s", "n_gpus": world,
             "ms_per_step": dt / args.steps * 1e3, "scaling": "strong", "dtype": "int16/int32/int64",
             "config": {"workload": "599 tunes x 16384 int16, N=4096, 2 FFT blocks/tune/pass, rectangle window (BASELINE configs[2]/[3])",
-                       "passes_per_step": passes, "tunes_this_rank": mine, "tunes_per_rank_padded": per, "rccl_ranks": world,
+                       "passes_per_step": passes, "tunes_this_rank": mine, "tunes_per_rank_padded": per,
+                       "rccl_ranks": observed[1], "rccl_ranks_source": "ncclCommCount, checked by rxgpu_comm_create" if comm is not None else "no communicator",
+                       "rccl_gathers_enqueued": comm.gathers if comm is not None else 0,
+                       "scan_us_per_step_rank0": (ms / launches * 1e3) if launches else None,
                        "parallelism": "tunes sharded x%d, one gather of avg[] + samples to rank 0 per step" % world,
                        "gather": gather_impl, "gather_us_per_step_rank0": (gms / gl * 1e3) if gl else None,
                        "gather_bytes_per_rank": per * n * 8 + per * 4},
@@ -621,6 +633,44 @@ def main():
             pw["parity"] = PA.power_check("24M:1.7G:1k", 0.0, "rectangle", 1, 0, 0, d_in.cpu().numpy(), da.cpu().numpy(), dsm.cpu().numpy())
             pw_parity_ok = pw["parity"]["parity_ok"]
             del da, dsm
+        # the drop-in (rxgpu_scan on the reference's own struct tuning_state array, rtl_power.c:1040): per-sweep cost with the sums left
+        # on the device, and the one download per report interval (rxgpu_scan_sync)
+        if world == 1 and args.variants == "all":
+            from rx_tools_amd.structs import TuningState
+            sweeps = 20
+            h_bufs = d_in[0, :total_tunes].cpu().numpy().copy()
+            h_avgs = np.zeros((total_tunes, n), np.int64)
+            arr = (TuningState * total_tunes)()
+            for t in range(total_tunes):
+                arr[t] = TuningState(plan.first_freq + t * plan.bw_seen, plan.rate, plan.bin_e, C.cast(h_avgs[t].ctypes.data, C.POINTER(C.c_int64)), 0,
+                                     plan.downsample, plan.downsample_passes, plan.crop, C.cast(h_bufs[t].ctypes.data, C.POINTER(C.c_int16)), plan.buf_len)
+            for _ in range(3):
+                R.check(L.rxgpu_scan(arr, total_tunes, wc.ctypes.data, sw.ctypes.data, 1, 0, 0))
+            R.check(L.rxgpu_scan_sync(arr, total_tunes))
+            h_avgs[:] = 0
+            for t in range(total_tunes):
+                arr[t].samples = 0
+            t0 = time.perf_counter()
+            for _ in range(sweeps):
+                R.check(L.rxgpu_scan(arr, total_tunes, wc.ctypes.data, sw.ctypes.data, 1, 0, 0))
+            R.check(L.rxgpu_sync())
+            t_scan = (time.perf_counter() - t0) / sweeps
+            t0 = time.perf_counter()
+            R.check(L.rxgpu_scan_sync(arr, total_tunes))
+            t_sync = time.perf_counter() - t0
+            pw["dropin_scan_us"] = {"rxgpu_scan_per_sweep": t_scan * 1e6, "rxgpu_scan_sync_per_interval": t_sync * 1e6, "sweeps": sweeps,
+                                    "Mbins/s": total_tunes * (plan.buf_len // 2) / t_scan / 1e6,
+                                    "note": "599 tunes x 16384 int16 from the caller's separate buffers: gather into pinned staging, one H2D (9.8 MB), the scan; "
+                                            "avg[] (19.6 MB) crosses PCIe once per interval, not twice per sweep"}
+            if not args.no_parity:
+                want1 = torch.zeros((per, n), dtype=torch.int64, device=dev)
+                ws = torch.zeros(per, dtype=torch.int32, device=dev)
+                ps.run(d_in.data_ptr(), 1, mine, want1.data_ptr(), ws.data_ptr())      # pass 0 alone: part of the launch checked above
+                R.check(L.rxgpu_sync())
+                same = bool(np.array_equal(h_avgs, sweeps * want1[:total_tunes].cpu().numpy()) and all(arr[t].samples == sweeps * int(ws[t]) for t in range(total_tunes)))
+                pw["dropin_scan_us"]["parity_ok"] = same
+                pw_parity_ok = pw_parity_ok and same
+                del want1, ws
         ps.close()
         del d_in
         # two more geometries of SURVEY 8(d) config 3, one launch shape each, rank 0 only (not part of `value`)

@@ -250,9 +250,18 @@ long rxgpu_chan_host_fixups(const rxgpu_chan *s);
  * buf16 the caller has already filled (the device I/O part of scanner(), 683-703, stays with
  * the caller): for every tune, ts->avg[] += / MAX= and ts->samples += exactly as the CPU.
  * Globals of the reference are passed explicitly: window_coefs (rtl_power.c:87,1034-1037),
- * Sinewave (82,240-254; 3/4 * 2^bin_e entries), boxcar/comp_fir_size/peak_hold (115-117). */
+ * Sinewave (82,240-254; 3/4 * 2^bin_e entries), boxcar/comp_fir_size/peak_hold (115-117).
+ * The sums stay ON THE DEVICE between calls (the reference reads avg[] only in csv_dbm, once per report interval,
+ * rtl_power.c:1045-1050): a call uploads the tunes' buf16, adds the sweep to device-resident accumulators and returns
+ * without waiting.  ts->avg[] / ts->samples are brought up to date by rxgpu_scan_sync -- which rxgpu_csv_dbm calls by itself
+ * for a tuning_state of the sweep; call it explicitly in front of the reference's own csv_dbm or any other reader of the
+ * struct ($RXGPU_SCAN_EAGER=1: every rxgpu_scan ends with it). */
 int rxgpu_scan(struct tuning_state *tunes, int tune_count, const int *window_coefs,
                const int16_t *sinewave, int boxcar, int comp_fir_size, int peak_hold);
+/* merge what rxgpu_scan accumulated since the last sync into tunes[i].avg[] (+=, MAX with peak hold) and tunes[i].samples;
+ * tunes == NULL: whatever array the pending sweep belongs to.  A no-op when nothing is pending. */
+int rxgpu_scan_sync(struct tuning_state *tunes, int tune_count);
+long rxgpu_scan_syncs(void);    /* downloads made so far (diagnostics / tests) */
 
 /* csv_dbm(ts) (rtl_power.c:774-817) writing to `file`.  Host code, NOT a device function: our restatement of the
  * reference's text formatter (one index map per printed bin), tested byte-for-byte against the reference's output.
@@ -294,28 +303,34 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 /* ------------------------------------------------------------ rx_power: tunes sharded over the GPUs of one node
  *
  * scanner()'s tunes are independent (rtl_power.c:679-771); rows only meet when main() prints them in tune order
- * (rtl_power.c:1047-1050).  One process per GPU; rank r scans the contiguous range rxgpu_shard_tunes gives it and one
- * ncclGather per report interval (RCCL over xGMI, enqueued on rxgpu_stream() behind the scan) brings every rank's
- * [per][N] int64 avg block and [per] int32 samples to the root, which feeds csv_dbm.  librccl is bound at run time
+ * (rtl_power.c:1047-1050).  One process per GPU; rank r scans the contiguous range rxgpu_shard_tunes gives it and ONE
+ * collective launch per report interval (RCCL over xGMI, enqueued on rxgpu_stream() behind the scan: the ncclGather of the
+ * [per][N] int64 avg block and the ncclGather of the [per] int32 samples inside one ncclGroup) brings every rank's rows to
+ * the root, which feeds csv_dbm.  librccl is bound at run time
  * ($RXGPU_RCCL_LIB, else an already loaded librccl, else the loader path, else /opt/rocm/lib). */
 typedef struct rxgpu_comm rxgpu_comm;
 /* 128 bytes (ncclUniqueId): made on one rank, handed to the others by whatever launched the processes (MPI, a file,
  * torch.distributed's store ...), then every rank calls rxgpu_comm_create -- collective, like ncclCommInitRank */
 int rxgpu_comm_unique_id(void *id128);
 int rxgpu_comm_create(rxgpu_comm **out, const void *id128, int rank, int world);
-/* or wrap an ncclComm_t the application already has (not destroyed by rxgpu_comm_destroy) */
+/* or wrap an ncclComm_t the application already has (not destroyed by rxgpu_comm_destroy).
+ * Both check rank/world against what the communicator itself reports (ncclCommUserRank / ncclCommCount): RXGPU_EINVAL if
+ * the caller's sharding would not match the communicator's. */
 int rxgpu_comm_adopt(rxgpu_comm **out, void *nccl_comm, int rank, int world);
 void rxgpu_comm_destroy(rxgpu_comm *c);
 int rxgpu_comm_rank(const rxgpu_comm *c);
 int rxgpu_comm_world(const rxgpu_comm *c);
+long rxgpu_comm_gathers(const rxgpu_comm *c);   /* grouped gathers enqueued on this communicator so far */
 const char *rxgpu_comm_library(void);     /* which librccl was bound (NULL: none found) */
 /* rank's tunes: [*first, *first + *count), *per = ceil(total / world) = rows of every rank's padded block */
 int rxgpu_shard_tunes(int rank, int world, int total, int *first, int *count, int *per);
 /* d_avg_local [per][n_bins] int64, d_samples_local [per] int32 (DEVICE) -> on the root d_avg_all [world][per][n_bins],
- * d_samples_all [world][per] (ignored elsewhere).  Asynchronous on rxgpu_stream().  c == NULL: a single process. */
+ * d_samples_all [world][per] (ignored elsewhere).  Asynchronous on rxgpu_stream().  c == NULL: a single process.
+ * per == 0 (a sweep of no tunes) is a no-op. */
 int rxgpu_power_gather(rxgpu_comm *c, const int64_t *d_avg_local, const int32_t *d_samples_local, int per, int n_bins,
                        int64_t *d_avg_all, int32_t *d_samples_all, int root);
-/* rxgpu_power_scan_run over this rank's tunes (d_in_local: [passes][count][buf_len]) followed by the gather */
+/* rxgpu_power_scan_run over this rank's tunes (d_in_local: [passes][count][buf_len]) followed by the gather; the padding
+ * rows [count, per) of a short last rank are zeroed here, so the root never sees what the caller left in them */
 int rxgpu_power_scan_run_sharded(rxgpu_power_scan *s, rxgpu_comm *c, const int16_t *d_in_local, int passes, int total_tunes,
                                  int64_t *d_avg_local, int32_t *d_samples_local, int n_bins,
                                  int64_t *d_avg_all, int32_t *d_samples_all, int root);

@@ -93,3 +93,30 @@ void scanner(size_t channel)
 }
 
 long dropin_scans(void) { return scans; }
+
+/* main()'s report loop (rtl_power.c:1045-1050) reads tunes[i].avg through the reference's own csv_dbm: the one added line of
+ * the INTEGRATION.md patch -- rxgpu_scan_sync in front of it -- brings the sums the sweeps left on the device home first
+ * (a no-op from the second row of an interval on), then the reference's csv_dbm prints the row */
+void csv_dbm(struct tuning_state *ts)
+{
+	static void (*ref_csv_dbm)(struct tuning_state *);
+	if (!ref_csv_dbm) {
+		/* the reference object was dlopen'ed after this one (RTLD_NEXT does not reach it): find it through a symbol only it
+		 * defines, and take ITS csv_dbm */
+		Dl_info info;
+		void *h = NULL;
+		if (dladdr(dlsym(RTLD_DEFAULT, "tunes"), &info) && info.dli_fname)
+			h = dlopen(info.dli_fname, RTLD_NOW | RTLD_NOLOAD);
+		if (h)
+			ref_csv_dbm = (void (*)(struct tuning_state *))dlsym(h, "csv_dbm");
+		if (!ref_csv_dbm || ref_csv_dbm == csv_dbm) {
+			fprintf(stderr, "dropin: the reference's csv_dbm was not found\n");
+			_exit(1);
+		}
+	}
+	if (rxgpu_scan_sync(NULL, 0) != RXGPU_OK) {
+		fprintf(stderr, "rxgpu_scan_sync: %s\n", rxgpu_last_error());
+		_exit(1);
+	}
+	ref_csv_dbm(ts);
+}

@@ -25,10 +25,10 @@ EXPORTS = [
     "rxgpu_chan_create", "rxgpu_chan_destroy", "rxgpu_chan_set_carry", "rxgpu_chan_get_carry", "rxgpu_chan_run",
     "rxgpu_chan_set_audio_carry", "rxgpu_chan_get_audio_carry",
     "rxgpu_chan_host_fixups",
-    "rxgpu_scan", "rxgpu_csv_dbm", "rxgpu_power_plan_range", "rxgpu_sine_table", "rxgpu_window_coefs",
+    "rxgpu_scan", "rxgpu_scan_sync", "rxgpu_scan_syncs", "rxgpu_csv_dbm", "rxgpu_power_plan_range", "rxgpu_sine_table", "rxgpu_window_coefs",
     "rxgpu_power_scan_create", "rxgpu_power_scan_destroy", "rxgpu_power_scan_run",
     "rxgpu_comm_unique_id", "rxgpu_comm_create", "rxgpu_comm_adopt", "rxgpu_comm_destroy", "rxgpu_comm_rank", "rxgpu_comm_world",
-    "rxgpu_comm_library", "rxgpu_shard_tunes", "rxgpu_power_gather", "rxgpu_power_scan_run_sharded",
+    "rxgpu_comm_gathers", "rxgpu_comm_library", "rxgpu_shard_tunes", "rxgpu_power_gather", "rxgpu_power_scan_run_sharded",
     "rxgpu_sdr_in_bytes", "rxgpu_sdr_out_bytes", "rxgpu_sdr_convert", "rxgpu_sdr_convert_host", "rxgpu_wav_header",
 ]
 
@@ -83,6 +83,8 @@ def lib():
         L.rxgpu_sine_table.argtypes = [C.c_int, C.c_void_p]
         L.rxgpu_window_coefs.argtypes = [C.c_char_p, C.c_int, C.c_void_p]
         L.rxgpu_scan.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.rxgpu_scan_sync.argtypes = [C.c_void_p, C.c_int]
+        L.rxgpu_scan_syncs.restype = C.c_long
         L.rxgpu_csv_dbm.argtypes = [C.c_void_p, C.c_void_p]
         L.rxgpu_full_demod.argtypes = [C.c_void_p]
         L.rxgpu_set_demod_functions.argtypes = [C.c_void_p] * 5
@@ -108,6 +110,8 @@ def lib():
         L.rxgpu_comm_destroy.restype = None
         L.rxgpu_comm_rank.argtypes = [C.c_void_p]
         L.rxgpu_comm_world.argtypes = [C.c_void_p]
+        L.rxgpu_comm_gathers.argtypes = [C.c_void_p]
+        L.rxgpu_comm_gathers.restype = C.c_long
         L.rxgpu_comm_library.restype = C.c_char_p
         L.rxgpu_shard_tunes.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.rxgpu_power_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]

@@ -2597,6 +2597,179 @@ __global__ void k_fm_post_downsample(const int16_t *__restrict__ in, u64 n_out, 
 	out[j] = (int16_t)sum;
 }
 
+// ------------------------------------------------------------------ the literal per-block path (-F on ragged blocks)
+//
+// readStream may hand the callback any number of elements (rtl_fm.c:894-899), and full_demod's -F cascade is written on the
+// int16 array of ONE block: pass i runs fifth_order(lowpassed, lp_len >> i, lp_i_hist[i]) and fifth_order(lowpassed + 1,
+// (lp_len >> i) - 1, lp_q_hist[i]) (rtl_fm.c:764-769) -- `lp_len >> i` is an int16 count that becomes odd as soon as the block's
+// sample count is not a multiple of 2^passes, I and Q then yield different numbers of outputs, the final lp_len may be odd and
+// fm_demod takes its carried pre_r/pre_j from lp[lp_len-2], lp[lp_len-1] whatever they hold.  The tiled kernels above assume whole
+// tiles; blocks of any other length go through these kernels, which index the block's int16 array exactly like the C loops
+// (one launch per pass and block; rare shapes, correctness only).
+
+// fifth_order (rtl_fm.c:411-440) on both interleaved halves of one block: component c (0 = I at even indices, 1 = Q) sees
+// data = in + c and length = L - c; x[s] = data[2s], x[-t] = hist[6 - t]; output j (written to data[2j]) is the window
+// x[2j-5 .. 2j]; K = 1 + (length - 1) / 4 outputs (one when length <= 4, also when length <= 0: data[0] is always rewritten);
+// hist' = x[2K-7 .. 2K-2], the last iteration's a..f.
+__device__ __forceinline__ int lit_x(const int16_t *__restrict__ in, const int16_t *__restrict__ hist, int c, int s)
+{
+	return s >= 0 ? (int)in[c + 2 * s] : (int)hist[6 + s];
+}
+
+__device__ __forceinline__ int lit_outputs(int length) { return length > 4 ? 1 + (length - 1) / 4 : 1; }
+
+__global__ __launch_bounds__(256) void k_fm_fifth_lit(const int16_t *__restrict__ in, int16_t *__restrict__ out, int L,
+                                                      const int16_t *__restrict__ hist_in, int16_t *__restrict__ hist_out)
+{
+	const int c = blockIdx.y;
+	const int16_t *h = hist_in + 6 * c;
+	const int K = lit_outputs(L - c);
+	const int j = blockIdx.x * 256 + threadIdx.x;
+	if (j >= K)
+		return;
+	const int a = lit_x(in, h, c, 2 * j - 5), b = lit_x(in, h, c, 2 * j - 4), cc = lit_x(in, h, c, 2 * j - 3),
+	          d = lit_x(in, h, c, 2 * j - 2), e = lit_x(in, h, c, 2 * j - 1), f = lit_x(in, h, c, 2 * j);
+	out[c + 2 * j] = (int16_t)((a + (b + e) * 5 + (cc + d) * 10 + f) >> 4);
+	if (j == K - 1) {
+		int16_t *ho = hist_out + 6 * c;
+		ho[0] = (int16_t)a; ho[1] = (int16_t)b; ho[2] = (int16_t)cc; ho[3] = (int16_t)d; ho[4] = (int16_t)e; ho[5] = (int16_t)f;
+	}
+}
+
+// generic_fir (rtl_fm.c:442-465) on both halves: component c sees data = in + c, length = L - c, i.e. C = (length + 1) / 2 samples
+// (none when length <= 0); y[t] = data[2t]; out[t] = FIR over y[t-9 .. t-1] with y[-9..-1] = hist[0..8]; hist' = the last 9 of hist ++ y
+__global__ __launch_bounds__(256) void k_fm_droop_lit(const int16_t *__restrict__ in, int16_t *__restrict__ out, int L, const int *__restrict__ fir,
+                                                      const int16_t *__restrict__ hist_in, int16_t *__restrict__ hist_out)
+{
+	const int c = blockIdx.y;
+	const int16_t *h = hist_in + 9 * c;
+	const int length = L - c;
+	const int C = length > 0 ? (length + 1) / 2 : 0;
+	const int t = blockIdx.x * 256 + threadIdx.x;
+	if (t == 0) {
+		for (int k = 0; k < 9; k++) {
+			const int idx = C - 9 + k;
+			hist_out[9 * c + k] = idx >= 0 ? in[c + 2 * idx] : h[9 + idx];
+		}
+	}
+	if (t >= C) {
+		// in place the C leaves what it does not filter where it was (lowpassed[1] of a one-int16 block: the drop-in reads it back)
+		if (c + 2 * t <= (L > 2 ? L : 2))
+			out[c + 2 * t] = in[c + 2 * t];
+		return;
+	}
+	int y[9];
+#pragma unroll
+	for (int k = 0; k < 9; k++) {
+		const int idx = t - 9 + k;
+		y[k] = idx >= 0 ? (int)in[c + 2 * idx] : (int)h[9 + idx];
+	}
+	const int sum = __mul24(y[0] + y[8], fir[1]) + __mul24(y[1] + y[7], fir[2]) + __mul24(y[2] + y[6], fir[3]) + __mul24(y[3] + y[5], fir[4]) +
+	                __mul24(y[4], fir[5]);
+	out[c + 2 * t] = (int16_t)(sum >> 15);
+}
+
+// power squelch on one block, rtl_fm.c:781-790 with rms() 739-757 over all L int16 (step 1): one workgroup
+__global__ __launch_bounds__(256) void k_fm_squelch_lit(int16_t *__restrict__ lp, int L, int level, int *__restrict__ below)
+{
+	__shared__ i64 red[8];
+	__shared__ int quiet;
+	i64 t = 0, p = 0;
+	for (int i = threadIdx.x; i < L; i += 256) {
+		const i64 v = lp[i];
+		t += v;
+		p += v * v;
+	}
+	for (int off = 32; off; off >>= 1) { t += __shfl_down(t, off); p += __shfl_down(p, off); }
+	if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = t; red[4 + (threadIdx.x >> 6)] = p; }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		t = red[0] + red[1] + red[2] + red[3];
+		p = red[4] + red[5] + red[6] + red[7];
+		const double dc = (double)t / (double)L;
+		const double lhs = (double)(t * 2) * dc;
+		const double rhs = dc * dc * (double)L;
+		const double v = ((double)p - (lhs - rhs)) / (double)L;
+		const int sr = v >= 0.0 ? (int)isqrt_floor(v) : 0;
+		quiet = sr < level;
+		*below = quiet;
+	}
+	__syncthreads();
+	if (quiet)
+		for (int i = threadIdx.x; i < L; i += 256)
+			lp[i] = 0;
+}
+
+// the demodulators on one block's lowpassed[0..L) (L may be odd), result samples to pcm[m0 ..]:
+//   fm_demod (rtl_fm.c:584-615): result[0] through libm against the carried pre_r/pre_j (flagged like k_fm_disc, record index m0),
+//     result[i/2] for i = 2, 4 .. < L-1 per custom_atan, pre' = lp[L-2], lp[L-1] (L >= 2; the host settles L < 2), L/2 results;
+//   am/usb/lsb_demod (617-656): result[i/2] for i = 0, 2 .. < L -- only the L/2 that result_len keeps are stored;
+//   raw_demod (658-665): result = lowpassed, L int16.
+__global__ __launch_bounds__(256) void k_fm_demod_lit(const int16_t *__restrict__ lp, int L, int mode, int custom_atan, int output_scale,
+                                                      int16_t *__restrict__ pcm, u64 m0, rxk_fm_dev *__restrict__ dev, int pre_from_out,
+                                                      rxk_flag_rec *__restrict__ flag_list, int *__restrict__ flag_cnt, const int *__restrict__ atan_lut,
+                                                      int flag_all)
+{
+	const int j = blockIdx.x * 256 + threadIdx.x;
+	if (mode == RXK_LIT_RAW) {
+		if (j < L)
+			pcm[m0 + (u64)j] = lp[j];
+		return;
+	}
+	if (j >= L / 2)
+		return;
+	const int ar = lp[2 * j], aj = lp[2 * j + 1];
+	int out;
+	if (mode != RXK_LIT_FM) {
+		int v;
+		if (mode == RXK_LIT_AM) {
+			const int pw = (int)((unsigned)(ar * ar) + (unsigned)(aj * aj));
+			v = pw < 0 ? 0 : (int)(short)isqrt_floor((double)pw);
+		} else {
+			v = (int)(short)(mode == RXK_LIT_USB ? ar + aj : ar - aj);
+		}
+		pcm[m0 + (u64)j] = (int16_t)(v * output_scale);
+		return;
+	}
+	int br, bj;
+	if (j) { br = lp[2 * j - 2]; bj = lp[2 * j - 1]; }
+	else if (pre_from_out) { br = dev->out_pre_r; bj = dev->out_pre_j; }       // a later block of the same run
+	else { br = dev->in_pre_r; bj = dev->in_pre_j; }
+	const int cr = (int)((unsigned)ar * (unsigned)br + (unsigned)aj * (unsigned)bj);
+	const int cj = (int)((unsigned)aj * (unsigned)br - (unsigned)ar * (unsigned)bj);
+	if (j == 0 || custom_atan == 0) {
+		const double v = atan2((double)cj, (double)cr) / 3.14159 * 16384.0;
+		out = (int)v;
+		if (v != 0.0 && (flag_all || fabs(v - rint(v)) < RXK_LIBM_WINDOW)) {
+			const int idx = atomicAdd(flag_cnt, 1);
+			if (idx < RXK_FLAG_CAP) {
+				rxk_flag_rec r;
+				r.m = m0 + (u64)j; r.ar = ar; r.aj = aj; r.br = br; r.bj = bj;
+				flag_list[idx] = r;
+			}
+			if (flag_all > 1)
+				out += 77;
+		}
+	} else if (custom_atan == 1) {
+		out = fast_atan2_dev(cj, cr);
+	} else if (custom_atan == 2) {
+		out = polar_disc_lut_dev(cr, cj, atan_lut);
+	} else {
+		out = esbensen_dev(ar, aj, br, bj);
+	}
+	pcm[m0 + (u64)j] = (int16_t)out;
+}
+
+// pre' = lp[L-2], lp[L-1] (rtl_fm.c:612-613) -- after the block's demodulator has read the old one; a kernel of its own so that
+// no thread of k_fm_demod_lit races with it
+__global__ void k_fm_pre_lit(const int16_t *__restrict__ lp, int L, rxk_fm_dev *__restrict__ dev)
+{
+	if (L >= 2) {
+		dev->out_pre_r = lp[L - 2];
+		dev->out_pre_j = lp[L - 1];
+	}
+}
+
 // ------------------------------------------------------------------ channeliser (extension)
 
 // BASELINE configs[4] / SURVEY section 8(f) rank 2 -- not in the reference; specified from its primitives
@@ -3295,6 +3468,42 @@ extern "C" int rxk_fm_fifth_fused(void *stream, const void *in, int stage2, int 
 #undef GO
 #undef FUSED
 #undef SEAMS
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_fm_fifth_lit(void *stream, const int16_t *in, int16_t *out, int L, const int16_t *hist_in, int16_t *hist_out)
+{
+	const int K = L > 4 ? 1 + (L - 1) / 4 : 1;                     // the I half has at least as many outputs as the Q half
+	hipLaunchKernelGGL(k_fm_fifth_lit, dim3((unsigned)((K + 255) / 256), 2), dim3(256), 0, (hipStream_t)stream, in, out, L, hist_in, hist_out);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_fm_droop_lit(void *stream, const int16_t *in, int16_t *out, int L, const int *fir, const int16_t *hist_in, int16_t *hist_out)
+{
+	const int n = (L > 2 ? L : 2) / 2 + 2;                          // the filtered samples of the longer half and the few entries behind them
+	hipLaunchKernelGGL(k_fm_droop_lit, dim3((unsigned)((n + 255) / 256), 2), dim3(256), 0, (hipStream_t)stream, in, out, L, fir, hist_in, hist_out);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_fm_squelch_lit(void *stream, int16_t *lp, int L, int level, int *below)
+{
+	hipLaunchKernelGGL(k_fm_squelch_lit, dim3(1), dim3(256), 0, (hipStream_t)stream, lp, L, level, below);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_fm_demod_lit(void *stream, const int16_t *lp, int L, int mode, int custom_atan, int output_scale, int16_t *pcm,
+                                unsigned long long m0, rxk_fm_dev *dev, int pre_from_out, rxk_flag_rec *flag_list, int *flag_cnt,
+                                const int *atan_lut, int flag_all)
+{
+	const int n = mode == RXK_LIT_RAW ? L : L / 2;
+	if (n > 0) {
+		hipLaunchKernelGGL(k_fm_demod_lit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, lp, L, mode, custom_atan, output_scale,
+		                   pcm, (u64)m0, dev, pre_from_out, flag_list, flag_cnt, atan_lut, flag_all);
+		if (hipGetLastError() != hipSuccess)
+			return (int)hipErrorLaunchFailure;
+	}
+	if (mode == RXK_LIT_FM && L >= 2)
+		hipLaunchKernelGGL(k_fm_pre_lit, dim3(1), dim3(1), 0, (hipStream_t)stream, lp, L, dev);
 	LAUNCH_RET();
 }
 

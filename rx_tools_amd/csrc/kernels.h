@@ -188,6 +188,19 @@ int rxk_fm_droop_disc(void *stream, const uint32_t *in, unsigned long long M, co
                       uint32_t *lp_out, unsigned long long uniform_k, int16_t *pcm, int pcm_chl2, rxk_fm_dev *dev, rxk_flag_rec *flag_list,
                       int *flag_cnt, int flag_all);
 
+/* The literal per-block path: full_demod's -F cascade and what follows it on ONE block's int16 lowpassed[] of L int16, indexed exactly
+ * like the C loops (rtl_fm.c:411-465, 584-665, 739-757, 764-790), for blocks whose sample count is not a multiple of 2^passes
+ * (lp_len >> i turns odd, I and Q yield different counts).  hist: I then Q (6 + 6 int16; the droop FIR's 9 + 9). */
+int rxk_fm_fifth_lit(void *stream, const int16_t *in, int16_t *out, int L, const int16_t *hist_in, int16_t *hist_out);
+int rxk_fm_droop_lit(void *stream, const int16_t *in, int16_t *out, int L, const int *fir, const int16_t *hist_in, int16_t *hist_out);
+int rxk_fm_squelch_lit(void *stream, int16_t *lp, int L, int level, int *below);
+enum { RXK_LIT_FM = 0, RXK_LIT_AM = 1, RXK_LIT_USB = 2, RXK_LIT_LSB = 3, RXK_LIT_RAW = 4 };     /* == RXGPU_MODE_* */
+/* results to pcm[m0 ..]: L/2 of them (raw: L); fm: the block's first sample through libm against dev->in_pre (pre_from_out: out_pre, a
+ * later block of the run), then dev->out_pre = lp[L-2], lp[L-1] when L >= 2 */
+int rxk_fm_demod_lit(void *stream, const int16_t *lp, int L, int mode, int custom_atan, int output_scale, int16_t *pcm,
+                     unsigned long long m0, rxk_fm_dev *dev, int pre_from_out, rxk_flag_rec *flag_list, int *flag_cnt,
+                     const int *atan_lut, int flag_all);
+
 /* rtlsdr_callback's scale + rotate alone (rtl_fm.c:845-857), n_complex samples */
 int rxk_fm_prestage(void *stream, const int16_t *in, unsigned n_complex, int rotate, int16_t *out);
 

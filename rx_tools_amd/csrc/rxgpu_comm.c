@@ -6,7 +6,8 @@
  * scans the contiguous range [r*per, min(T,(r+1)*per)), per = ceil(T/W), and its [per][N] int64 avg block and
  * [per] int32 samples (padded to `per` rows so that the collective is fixed-size) go to the root with ncclGather,
  * enqueued on the library's own stream right behind the scan kernels -- no host synchronisation, no reduction
- * (the rows are disjoint), no ring: xGMI is point to point and a gather is W-1 direct transfers into the root.
+ * (the rows are disjoint), no ring: xGMI is point to point and a gather is W-1 direct transfers into the root.  The two
+ * gathers share one ncclGroup: a single collective launch per interval.
  *
  * librccl is bound at run time (dlopen), so librxgpu.so itself keeps loading on hosts without RCCL; the rccl.h
  * declarations are used for the types only. */
@@ -22,6 +23,7 @@ struct rxgpu_comm {
 	ncclComm_t nccl;
 	int rank, world;
 	int owned;                       /* created here (destroy it) or adopted from the caller */
+	long gathers;                    /* grouped gathers enqueued so far */
 };
 
 static struct {
@@ -32,6 +34,8 @@ static struct {
 	ncclResult_t (*Gather)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
 	ncclResult_t (*GroupStart)(void);
 	ncclResult_t (*GroupEnd)(void);
+	ncclResult_t (*CommCount)(const ncclComm_t, int *);
+	ncclResult_t (*CommUserRank)(const ncclComm_t, int *);
 	const char *(*GetErrorString)(ncclResult_t);
 	char path[256];
 } g_rccl;
@@ -65,6 +69,8 @@ static int rccl_bind(void)
 			BIND(Gather, "ncclGather");
 			BIND(GroupStart, "ncclGroupStart");
 			BIND(GroupEnd, "ncclGroupEnd");
+			BIND(CommCount, "ncclCommCount");
+			BIND(CommUserRank, "ncclCommUserRank");
 			BIND(GetErrorString, "ncclGetErrorString");
 #undef BIND
 			if (rc != RXGPU_OK) {
@@ -98,6 +104,17 @@ int rxgpu_comm_unique_id(void *id128)
 	return RXGPU_OK;
 }
 
+/* what the communicator itself says about its size and this process's place in it must be what the caller sharded by */
+static int comm_verify(const rxgpu_comm *c)
+{
+	int n = -1, r = -1;
+	RX_NCCL(g_rccl.CommCount(c->nccl, &n));
+	RX_NCCL(g_rccl.CommUserRank(c->nccl, &r));
+	if (n != c->world || r != c->rank)
+		return rxgpu_fail(RXGPU_EINVAL, "communicator is rank %d of %d, caller said rank %d of %d", r, n, c->rank, c->world);
+	return RXGPU_OK;
+}
+
 int rxgpu_comm_create(rxgpu_comm **out, const void *id128, int rank, int world)
 {
 	int rc;
@@ -120,6 +137,11 @@ int rxgpu_comm_create(rxgpu_comm **out, const void *id128, int rank, int world)
 	c->rank = rank;
 	c->world = world;
 	c->owned = 1;
+	if ((rc = comm_verify(c)) != RXGPU_OK) {
+		g_rccl.CommDestroy(c->nccl);
+		free(c);
+		return rc;
+	}
 	*out = c;
 	return RXGPU_OK;
 }
@@ -129,6 +151,8 @@ int rxgpu_comm_adopt(rxgpu_comm **out, void *nccl_comm, int rank, int world)
 	int rc;
 	if (!out || !nccl_comm || world < 1 || rank < 0 || rank >= world)
 		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_comm_adopt: bad arguments");
+	if ((rc = rxgpu_ensure_init()) != RXGPU_OK)          /* the gather goes on the library's stream: it has to exist */
+		return rc;
 	if ((rc = rccl_bind()) != RXGPU_OK)
 		return rc;
 	rxgpu_comm *c = calloc(1, sizeof(*c));
@@ -138,6 +162,10 @@ int rxgpu_comm_adopt(rxgpu_comm **out, void *nccl_comm, int rank, int world)
 	c->rank = rank;
 	c->world = world;
 	c->owned = 0;
+	if ((rc = comm_verify(c)) != RXGPU_OK) {
+		free(c);
+		return rc;
+	}
 	*out = c;
 	return RXGPU_OK;
 }
@@ -173,17 +201,27 @@ int rxgpu_shard_tunes(int rank, int world, int total, int *first, int *count, in
 	return RXGPU_OK;
 }
 
+/* ONE collective launch per report interval: the avg block and the samples vector of every rank travel in the same
+ * ncclGroup (RCCL fuses the grouped gathers' point-to-point transfers into a single kernel on the stream), enqueued on the
+ * library's stream right behind the scan -- rows merge where the reference prints them, rtl_power.c:1047-1050. */
 int rxgpu_power_gather(rxgpu_comm *c, const int64_t *d_avg_local, const int32_t *d_samples_local, int per, int n_bins,
                        int64_t *d_avg_all, int32_t *d_samples_all, int root)
 {
-	if (!d_avg_local || !d_samples_local || per < 1 || n_bins < 1)
+	int rc;
+	if (per < 0 || n_bins < 1)
 		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_power_gather: bad arguments");
-	hipStream_t st = rxgpu_hip_stream();
 	const int world = c ? c->world : 1, rank = c ? c->rank : 0;
 	if (root < 0 || root >= world)
 		return rxgpu_fail(RXGPU_EINVAL, "root %d outside [0,%d)", root, world);
+	if (per == 0)                                        /* a sweep of no tunes: nothing to merge, on every rank alike */
+		return RXGPU_OK;
+	if (!d_avg_local || !d_samples_local)
+		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_power_gather: null send buffer");
 	if (rank == root && (!d_avg_all || !d_samples_all))
 		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_power_gather: the root needs the receive buffers");
+	if ((rc = rxgpu_ensure_init()) != RXGPU_OK)
+		return rc;
+	hipStream_t st = rxgpu_hip_stream();
 	const size_t n_avg = (size_t)per * (size_t)n_bins;
 	if (!c) {                                            /* one process: the "gather" is the rank's own block */
 		if (d_avg_all != d_avg_local)
@@ -193,11 +231,24 @@ int rxgpu_power_gather(rxgpu_comm *c, const int64_t *d_avg_local, const int32_t 
 		return RXGPU_OK;
 	}
 	rxgpu_prof_begin("pw_gather");
-	RX_NCCL(g_rccl.Gather(d_avg_local, d_avg_all, n_avg, ncclInt64, root, c->nccl, st));
-	RX_NCCL(g_rccl.Gather(d_samples_local, d_samples_all, (size_t)per, ncclInt32, root, c->nccl, st));
+	ncclResult_t r = g_rccl.GroupStart();
+	if (r == ncclSuccess) {
+		ncclResult_t r1 = g_rccl.Gather(d_avg_local, d_avg_all, n_avg, ncclInt64, root, c->nccl, st);
+		ncclResult_t r2 = r1 == ncclSuccess ? g_rccl.Gather(d_samples_local, d_samples_all, (size_t)per, ncclInt32, root, c->nccl, st) : r1;
+		r = g_rccl.GroupEnd();                           /* always closed, also after a failed enqueue */
+		if (r2 != ncclSuccess)
+			r = r2;
+	}
+	if (r != ncclSuccess) {
+		rxgpu_prof_abort();
+		return rxgpu_fail(RXGPU_ENODEV, "grouped ncclGather failed: %s", g_rccl.GetErrorString(r));
+	}
 	rxgpu_prof_end("pw_gather");
+	c->gathers++;
 	return RXGPU_OK;
 }
+
+long rxgpu_comm_gathers(const rxgpu_comm *c) { return c ? c->gathers : 0; }
 
 int rxgpu_power_scan_run_sharded(rxgpu_power_scan *s, rxgpu_comm *c, const int16_t *d_in_local, int passes, int total_tunes,
                                  int64_t *d_avg_local, int32_t *d_samples_local, int n_bins,
@@ -206,7 +257,17 @@ int rxgpu_power_scan_run_sharded(rxgpu_power_scan *s, rxgpu_comm *c, const int16
 	int rc, count = 0, per = 0;
 	if ((rc = rxgpu_shard_tunes(c ? c->rank : 0, c ? c->world : 1, total_tunes, NULL, &count, &per)) != RXGPU_OK)
 		return rc;
+	if (per > 0 && (!d_avg_local || !d_samples_local || n_bins < 1))
+		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_power_scan_run_sharded: null local buffers");
 	if (count > 0 && (rc = rxgpu_power_scan_run(s, d_in_local, passes, count, d_avg_local, d_samples_local)) != RXGPU_OK)
 		return rc;
+	if (count < per) {
+		/* the padding rows of a short last rank (599 tunes over 8 ranks: 75 x 7 + 74) reach the root as zeros, whatever the
+		 * caller left in them */
+		if ((rc = rxgpu_ensure_init()) != RXGPU_OK)
+			return rc;
+		RX_HIP(hipMemsetAsync(d_avg_local + (size_t)count * (size_t)n_bins, 0, (size_t)(per - count) * (size_t)n_bins * 8, rxgpu_hip_stream()));
+		RX_HIP(hipMemsetAsync(d_samples_local + count, 0, (size_t)(per - count) * 4, rxgpu_hip_stream()));
+	}
 	return rxgpu_power_gather(c, d_avg_local, d_samples_local, per, n_bins, d_avg_all, d_samples_all, root);
 }

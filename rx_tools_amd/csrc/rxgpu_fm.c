@@ -9,6 +9,7 @@
 #include "rxgpu_ref_structs.h"
 #include <math.h>
 #include <pthread.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -23,6 +24,8 @@
 struct run_geom {
 	unsigned long long n, T, M, K, J;
 	int passes, ds, p0, pr0, rotate, fast, post;
+	int literal;                         /* -F on blocks that are not whole tiles: the per-block int16-indexed kernels */
+	int lf;                              /* literal: int16 count of a block's lowpassed[] after the cascade, (2n) >> passes (may be odd) */
 };
 
 struct rxgpu_fm_stream {
@@ -78,12 +81,16 @@ struct rxgpu_fm_stream {
 	int chunk;                           /* de-emphasis scan: samples per chunk */
 	int topcap_override;                 /* $RXGPU_DEEMPH_TOPCAP: forces the multi-level scan (tests) */
 	int flag_all;                        /* $RXGPU_FLAG_ALL: every libm discriminator sample goes through the host re-evaluation (tests) */
+	int allow_empty;                     /* the drop-in: a block that yields no decimated sample is legal (the struct-memory reads the
+	                                      * reference then makes are reproduced by rxgpu_full_demod on the real struct) */
+	int16_t *lit[2];                     /* literal -F path: one block's int16 lowpassed[], ping-pong */
 	long fixups;
 	/* pipelining state: at most two runs in flight, run `seq` uses buffer set / slot seq & 1 */
 	hipEvent_t ev_dec[2], ev_small[2], ev_disc[2];
 	int ev_small_valid[2];
 	unsigned long long seq;              /* runs enqueued so far */
 	int pending;                         /* runs enqueued and not yet waited for */
+	int carry_lost;                      /* a sequence failed while being retired: the host copy of the carries is stale until set_carry */
 	int chained;                         /* device carries are ahead of the host copy */
 	int h_prev_index, h_prev_lpr_index;  /* the two carries the host can track in closed form */
 	struct run_rec {
@@ -272,6 +279,8 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 	DMALLOC(s->hist_dev, HIST_TOTAL * 2);
 	DMALLOC(s->fir_dev, 10 * 4);
 	if (params->downsample_passes) {
+		DMALLOC(s->lit[0], block_len * 2 + 64);
+		DMALLOC(s->lit[1], block_len * 2 + 64);
 		/* pass 0 output is half the input, later passes shrink further: two buffers suffice */
 		DMALLOC(s->cas[0], (s->max_T / 2 + max_blocks) * 4);
 		DMALLOC(s->cas[1], (s->max_T / 4 + max_blocks) * 4);
@@ -325,6 +334,7 @@ void rxgpu_fm_stream_destroy(rxgpu_fm_stream *s)
 	}
 	hipFree(s->lp);
 	hipFree(s->cas[0]); hipFree(s->cas[1]); hipFree(s->seams);
+	hipFree(s->lit[0]); hipFree(s->lit[1]);
 	hipFree(s->cas_a[0]); hipFree(s->cas_a[1]); hipFree(s->seams_a[0]); hipFree(s->seams_a[1]);
 	if (s->ev_up) hipEventDestroy(s->ev_up);
 	if (s->ev_seam[0]) hipEventDestroy(s->ev_seam[0]);
@@ -354,9 +364,10 @@ int rxgpu_fm_stream_set_carry(rxgpu_fm_stream *s, const rxgpu_fm_carry *c)
 	int rc;
 	if (!s || !c)
 		return rxgpu_fail(RXGPU_EINVAL, "null argument");
-	if (s->pending && (rc = finish_runs(s)) != RXGPU_OK)
+	if (s->pending && (rc = finish_runs(s)) != RXGPU_OK && !s->carry_lost)
 		return rc;
 	s->carry = *c;
+	s->carry_lost = 0;
 	return RXGPU_OK;
 }
 
@@ -367,6 +378,8 @@ int rxgpu_fm_stream_get_carry(rxgpu_fm_stream *s, rxgpu_fm_carry *c)
 		return rxgpu_fail(RXGPU_EINVAL, "null argument");
 	if (s->pending && (rc = finish_runs(s)) != RXGPU_OK)
 		return rc;
+	if (s->carry_lost)
+		return rxgpu_fail(RXGPU_EINVAL, "the last sequence of runs failed while it was retired: its carries are unknown (set_carry and replay)");
 	*c = s->carry;
 	return RXGPU_OK;
 }
@@ -514,25 +527,38 @@ static int run_geometry(rxgpu_fm_stream *s, size_t n_blocks, size_t block_len, s
 	g->rotate = !p->prescaled && !p->offset_tuning && !p->dc_block_raw;   /* the -E rdc pre-pass rotates */
 	g->K = 0;
 	g->fast = 0;
+	g->literal = 0;
+	g->lf = 0;
 	if (g->passes) {
-		if (g->n % (1ull << g->passes))
-			return rxgpu_fail(RXGPU_EUNSUPPORTED, "fifth_order path needs block samples %% 2^passes == 0 (n=%llu, passes=%d)", g->n, g->passes);
-		g->K = g->n >> g->passes;
-		if ((g->n >> (g->passes - 1)) < 16)
-			return rxgpu_fail(RXGPU_EUNSUPPORTED, "block too short for %d fifth_order passes", g->passes);
+		if ((g->n % (1ull << g->passes)) || (g->n >> (g->passes - 1)) < 16) {
+			/* not whole tiles of the cascade: rtl_fm.c:764-769 taken literally on each block's int16 array (lp_len >> i may be odd) */
+			g->literal = 1;
+			g->lf = (int)((2 * g->n) >> g->passes);
+			g->K = (unsigned long long)(g->lf / 2);          /* result_len = lp_len / 2, rtl_fm.c:614 */
+			if (g->lf < 2 && !s->allow_empty)
+				return rxgpu_fail(RXGPU_EUNSUPPORTED, "a block of %llu samples leaves %d int16 after %d fifth_order passes: the reference then takes "
+				                  "pre_r/pre_j from in front of lowpassed[] (rtl_fm.c:612-613), which only the drop-in on the real struct can reproduce",
+				                  g->n, g->lf, g->passes);
+		} else {
+			g->K = g->n >> g->passes;
+		}
 		g->M = g->K * n_blocks;
 	} else {
 		if (g->p0 < 0 || g->p0 >= g->ds)
 			return rxgpu_fail(RXGPU_EINVAL, "prev_index %d outside [0,%d)", g->p0, g->ds);
-		if (g->n < (unsigned long long)g->ds)
-			return rxgpu_fail(RXGPU_EUNSUPPORTED, "block of %llu samples shorter than downsample %d", g->n, g->ds);
 		g->M = ((unsigned long long)g->p0 + g->T) / (unsigned long long)g->ds;
-		g->fast = g->ds >= 4 && g->ds <= RXK_DEC_MAX_DS && (g->n % 4) == 0;
+		if (g->n < (unsigned long long)g->ds && (n_blocks > 1 || (!g->M && !s->allow_empty)))
+			return rxgpu_fail(RXGPU_EUNSUPPORTED, "blocks of %llu samples are shorter than downsample %d: a block that completes no window makes the "
+			                  "reference's fm_demod read pre_r/pre_j from in front of lowpassed[] (rtl_fm.c:612-613); only the drop-in, block by block "
+			                  "on the real struct, reproduces that", g->n, g->ds);
+		g->fast = g->ds >= 4 && g->ds <= RXK_DEC_MAX_DS && (g->n % 4) == 0 && g->n >= (unsigned long long)g->ds;
 	}
 	if (g->M > s->max_M)
 		return rxgpu_fail(RXGPU_ECAPACITY, "workspace too small for %llu decimated samples", g->M);
-	if (!g->M)
+	if (!g->M && !s->allow_empty)
 		return rxgpu_fail(RXGPU_EUNSUPPORTED, "run produces no decimated sample");
+	if (!g->M && p->dc_block_audio && p->mode != RXGPU_MODE_RAW)
+		return rxgpu_fail(RXGPU_EUNSUPPORTED, "-E adc on a block without a demodulated sample: the reference divides by result_len == 0 (rtl_fm.c:693)");
 	g->J = g->M;
 	g->post = (p->post_downsample > 1 && p->mode != RXGPU_MODE_RAW) ? p->post_downsample : 1;
 	if (g->post > 1) {
@@ -544,7 +570,8 @@ static int run_geometry(rxgpu_fm_stream *s, size_t n_blocks, size_t block_len, s
 		g->J = g->M / (unsigned long long)g->post;
 	}
 	if (p->mode == RXGPU_MODE_RAW) {
-		g->J = 2 * g->M;                         /* raw_demod: result = lowpassed, rtl_fm.c:658-665, 809-811 */
+		/* raw_demod: result = lowpassed, rtl_fm.c:658-665, 809-811 (an odd lp_len included on the literal path) */
+		g->J = g->literal ? (unsigned long long)g->lf * n_blocks : 2 * g->M;
 	} else if (p->rate_out2 > 0) {
 		if (g->pr0 < 0 || g->pr0 >= p->rate_out)
 			return rxgpu_fail(RXGPU_EINVAL, "prev_lpr_index %d outside [0,rate_out)", g->pr0);
@@ -563,7 +590,7 @@ static void block_lengths(const rxgpu_fm_stream *s, const struct run_geom *g, si
 		unsigned long long cum = g->passes ? g->K * (b + 1) : ((unsigned long long)g->p0 + g->n * (b + 1)) / (unsigned long long)g->ds;
 		if (p->mode != RXGPU_MODE_RAW)
 			cum /= (unsigned long long)g->post;
-		unsigned long long jj = p->mode == RXGPU_MODE_RAW ? 2 * cum
+		unsigned long long jj = p->mode == RXGPU_MODE_RAW ? (g->literal ? (unsigned long long)g->lf * (b + 1) : 2 * cum)
 			: p->rate_out2 > 0 ? ((unsigned long long)g->pr0 + cum * (unsigned long long)p->rate_out2) / (unsigned long long)p->rate_out : cum;
 		block_out_len[b] = (int)(jj - j_prev);
 		j_prev = jj;
@@ -605,7 +632,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 	RX_HIP(hipMemsetAsync(s->flag_cnt_dev + db, 0, sizeof(int), sb));
 	/* -F on the raw capture: the first fused group of fifth_order passes reads 8/9 of all the bytes of the run; like the
 	 * boxcar decimator it goes on stream A, so that it overlaps the later passes and the audio stages of the run before */
-	const int fuse_a = (g->passes && !prescaled && (g->n % RXK_FIFTH_TILE) == 0 && s->cas_a[0]) ? (g->passes < 3 ? g->passes : 3) : 0;
+	const int fuse_a = (g->passes && !g->literal && !prescaled && (g->n % RXK_FIFTH_TILE) == 0 && s->cas_a[0]) ? (g->passes < 3 ? g->passes : 3) : 0;
 	const int fresh = !s->chained;
 
 	if (!s->chained) {
@@ -651,9 +678,10 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 	s->last_n_blocks = n_blocks;
 	/* squelch and the non-fm demodulators need the finished lowpassed[] before anything is demodulated */
 	const int split = p->squelch_level != 0 || p->mode != RXGPU_MODE_FM;
+	int lit_done = 0;                        /* the literal per-block path did squelch and demodulation itself */
 	/* de-emphasis + resampler behind an fm discriminator: hand them the demodulated samples in the tiled layout their
 	 * lane-per-chunk kernels stream (rxk_fm_deemph_scan_t / _apply_rs_t).  $RXGPU_NO_TILED keeps the LDS-staged kernels. */
-	if (!split && p->deemph && s->group && p->rate_out2 > 0 && g->post == 1 && !p->dc_block_audio && !getenv("RXGPU_NO_TILED"))
+	if (!split && !g->literal && p->deemph && s->group && p->rate_out2 > 0 && g->post == 1 && !p->dc_block_audio && !getenv("RXGPU_NO_TILED"))
 	{
 		/* $RXGPU_DEEMPH_CHUNK=256 forces the larger chunk where the warm-up would fit 128 (tests of that template; measured: no
 		 * gain -- the scan's warm-up weighs less, but the resampler's per-wave staging doubles and with it the LDS a workgroup needs
@@ -684,7 +712,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 			rxgpu_prof_end_on("fm_decimate", sa);
 			RX_HIP(hipEventRecord(s->ev_dec[db], sa));
 			RX_HIP(hipStreamWaitEvent(sb, s->ev_dec[db], 0));
-		} else {
+		} else if (g->M) {
 			rxgpu_prof_begin_on("fm_decimate_generic", sb);
 			RX_K(rxk_fm_decimate_generic(sb, d_iq, g->T, g->ds, g->p0, g->n, prescaled, g->rotate, s->dev, s->lp, g->M));
 			rxgpu_prof_end_on("fm_decimate_generic", sb);
@@ -695,6 +723,47 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 		                 s->head[db], s->tail[db], g->fast ? s->lp_raw[db] : s->lp, g->M, RXK_FIRST_LOWPASS, 0, p->custom_atan, 1,
 		                 split ? NULL : s->pcm, s->dev, flag_rec, flag_cnt, fused_disc, n_blocks, s->atan_lut, g->fast ? lp_sparse : 0, s->flag_all, s->tiled));
 		rxgpu_prof_end_on("fm_disc", sb);
+	} else if (g->literal) {
+		/* -F on blocks that are not whole tiles: full_demod's cascade, droop FIR, squelch and demodulator block after block on
+		 * the block's own int16 array, exactly as the C loops index it (rtl_fm.c:764-776, 781-790, 808); everything stays on the
+		 * device, histories and pre_r/pre_j chained through hist_dev / dev.  Rare shapes: one small launch per pass and block. */
+		const int passes = g->passes;
+		lit_done = 1;
+		if (p->comp_fir_size == 9 && s->fir_loaded != passes) {
+			RX_HIP(hipMemcpyAsync(s->fir_dev, cic_9_tables[passes], 10 * sizeof(int), hipMemcpyHostToDevice, sb));
+			s->fir_loaded = passes;
+		}
+		const unsigned long long per_out = p->mode == RXGPU_MODE_RAW ? (unsigned long long)g->lf : g->K;
+		for (size_t b = 0; b < n_blocks; b++) {
+			const int16_t *cur = d_iq + b * block_len;
+			int w = 0;
+			if (!prescaled) {
+				RX_K(rxk_fm_prestage(sb, cur, (unsigned)g->n, g->rotate, s->lit[0]));
+				cur = s->lit[0];
+				w = 1;
+			}
+			for (int i = 0; i < passes; i++) {
+				RX_K(rxk_fm_fifth_lit(sb, cur, s->lit[w], (int)((2 * g->n) >> i), s->hist_dev + HIST_CAS_IN + i * 12, s->hist_dev + HIST_CAS_OUT + i * 12));
+				cur = s->lit[w];
+				w ^= 1;
+			}
+			RX_K(rxk_copy_small(sb, s->hist_dev + HIST_CAS_IN, s->hist_dev + HIST_CAS_OUT, (unsigned)passes * 12 * 2));
+			if (p->comp_fir_size == 9) {
+				RX_K(rxk_fm_droop_lit(sb, cur, s->lit[w], g->lf, s->fir_dev, s->hist_dev + HIST_DROOP_IN, s->hist_dev + HIST_DROOP_OUT));
+				RX_K(rxk_copy_small(sb, s->hist_dev + HIST_DROOP_IN, s->hist_dev + HIST_DROOP_OUT, 18 * 2));
+				cur = s->lit[w];
+				w ^= 1;
+			}
+			if (p->squelch_level && g->lf > 0)
+				RX_K(rxk_fm_squelch_lit(sb, (int16_t *)cur, g->lf, p->squelch_level, s->below + b));
+			else if (p->squelch_level)
+				RX_HIP(hipMemsetAsync(s->below + b, 1, sizeof(int), sb));   /* rms() of nothing is (int)NaN = INT_MIN on x86-64: below any level */
+			RX_K(rxk_fm_demod_lit(sb, cur, g->lf, p->mode, p->custom_atan, p->output_scale, p->mode == RXGPU_MODE_RAW ? d_out : s->pcm,
+			                      (unsigned long long)b * per_out, s->dev, b > 0, flag_rec, flag_cnt, s->atan_lut, s->flag_all));
+			s->lp_final = (const uint32_t *)cur;             /* the drop-in hands the (single) block's lowpassed[] back */
+		}
+		if (p->mode == RXGPU_MODE_RAW)
+			RX_K(rxk_fm_passthrough_carry(sb, s->dev, 1, 1));
 	} else {
 		/* F3: cascade (first passes fused where the input is raw), F12 optional */
 		const int passes = g->passes;
@@ -788,7 +857,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 			rxgpu_prof_end_on("fm_disc", sb);
 		}
 	}
-	if (split) {
+	if (split && !lit_done) {
 		uint32_t *lpw = (uint32_t *)s->lp_final;             /* every producer of lp_final owns it writable */
 		if (p->squelch_level)
 			RX_K(rxk_fm_squelch(sb, lpw, s->blk, p->squelch_level, s->below));
@@ -808,7 +877,14 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 	 * tells the host when this run's demodulated samples (and its reads of d_iq) are complete */
 	RX_K(rxk_copy_small(sb, s->flag_cnt_host + db, flag_cnt, sizeof(int)));       /* pinned host memory, written by the device */
 	RX_HIP(hipEventRecord(s->ev_disc[db], sb));
-	rc = p->mode == RXGPU_MODE_RAW ? RXGPU_OK : run_audio_stages(s, sb, g->M, g->J, d_out);
+	if (!g->M) {
+		/* no demodulated sample (the drop-in on a tiny block): the audio stages see result_len == 0 and change nothing */
+		rc = RXGPU_OK;
+		if (p->mode != RXGPU_MODE_RAW)
+			RX_K(rxk_fm_passthrough_carry(sb, s->dev, 1, 1));
+	} else {
+		rc = p->mode == RXGPU_MODE_RAW ? RXGPU_OK : run_audio_stages(s, sb, g->M, g->J, d_out);
+	}
 	if (rc != RXGPU_OK)
 		return rc;
 	if (p->squelch_level)
@@ -905,8 +981,15 @@ static int finish_runs(rxgpu_fm_stream *s)
 	/* oldest first */
 	const int first = (s->rec[0].live && s->rec[1].live) ? (s->rec[0].seq < s->rec[1].seq ? 0 : 1) : (s->rec[0].live ? 0 : 1);
 	if ((rc = retire_slot(s, first)) != RXGPU_OK || (rc = retire_slot(s, first ^ 1)) != RXGPU_OK) {
+		/* the sequence is lost (e.g. more undecided libm samples in one run than are recorded): leave nothing behind that the next
+		 * enqueue would trip over again, and say so to whoever asks for the carries -- set_carry + a replay recovers */
+		hipStreamSynchronize(sa);
+		hipStreamSynchronize(sb);
+		s->rec[0].live = s->rec[1].live = 0;
+		s->flag_cnt_host[0] = s->flag_cnt_host[1] = 0;
 		s->pending = 0;
 		s->chained = 0;
+		s->carry_lost = 1;
 		return rc;
 	}
 	const struct run_geom *g = &s->last;
@@ -954,7 +1037,7 @@ int rxgpu_fm_stream_run_async(rxgpu_fm_stream *s, const int16_t *d_iq, size_t n_
 {
 	int rc;
 	struct run_geom g;
-	if (!s || !d_iq || !d_out || !n_blocks || block_len < 2 || (block_len & 1))
+	if (!s || !d_iq || !d_out || !n_blocks || (block_len < 2 && !s->allow_empty) || (block_len & 1))
 		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_fm_stream_run: bad arguments");
 	if ((rc = rxgpu_ensure_init()) != RXGPU_OK)
 		return rc;
@@ -1189,17 +1272,22 @@ void rxgpu_set_demod_functions(void *fm, void *am, void *usb, void *lsb, void *r
 }
 
 #define SIDECARS 16
-/* side-car of a demod_state: deemph_filter's static accumulator, the stream object, and where the callback left the
- * block it handed over last (slot of g_cb_pre, its length, still valid?) */
+/* side-car of a demod_state: deemph_filter's static accumulator, the stream object, the callback's device buffers for THIS
+ * demod_state (raw block, the pre-staged block written / published in turn, the -E rdc scratch) and where the callback left
+ * the block it handed over last (slot of cb_pre, its length, still valid?).  Everything per demod_state: two dongle threads
+ * feeding two demod_states never touch the same buffer, and a published block can only be consumed by its own full_demod. */
 static struct {
 	const struct demod_state *d;
 	int avg;
 	rxgpu_fm_stream *s;
 	rxgpu_fm_params p;
 	int dev_slot, dev_len, dev_valid;
+	int16_t *cb_in, *cb_pre[2];
+	int *cb_rdc;                         /* dc_avgI/Q, the block averages, the int64 sums */
+	int16_t *fd_in;                      /* full_demod's own upload buffer (the demod thread's; the callback's are the dongle thread's) */
+	pthread_mutex_t cb_lock;             /* one callback at a time per demod_state */
+	int cb_lock_ready;
 } g_side[SIDECARS];
-static int16_t *g_cb_in, *g_cb_pre[2];       /* device: the raw block; the pre-staged block, written / published in turn */
-static int *g_cb_rdc;                        /* -E rdc in the callback: dc_avgI/Q, the block averages, the int64 sums */
 static pthread_mutex_t g_side_lock = PTHREAD_MUTEX_INITIALIZER;
 
 static int side_slot(const struct demod_state *d)
@@ -1214,6 +1302,10 @@ static int side_slot(const struct demod_state *d)
 	}
 	if (found < 0 && free_slot >= 0) {
 		g_side[free_slot].d = d;
+		if (!g_side[free_slot].cb_lock_ready) {
+			pthread_mutex_init(&g_side[free_slot].cb_lock, NULL);
+			g_side[free_slot].cb_lock_ready = 1;
+		}
 		found = free_slot;
 	}
 	pthread_mutex_unlock(&g_side_lock);
@@ -1277,6 +1369,36 @@ int rxgpu_dropin_unpin(struct demod_state *d, struct dongle_state *s)
 	return rc;
 }
 
+/* the callback's device buffers of one demod_state, allocated on first use */
+static int side_buffers(int slot)
+{
+	if (g_side[slot].cb_in)
+		return RXGPU_OK;
+	if (hipMalloc((void **)&g_side[slot].cb_in, RXGPU_MAXIMUM_BUF_LENGTH * 2 + 16) != hipSuccess ||
+	    hipMalloc((void **)&g_side[slot].cb_rdc, 64) != hipSuccess ||
+	    hipMalloc((void **)&g_side[slot].cb_pre[0], RXGPU_MAXIMUM_BUF_LENGTH * 2 + 16) != hipSuccess ||
+	    hipMalloc((void **)&g_side[slot].cb_pre[1], RXGPU_MAXIMUM_BUF_LENGTH * 2 + 16) != hipSuccess)
+		return rxgpu_fail(RXGPU_ENOMEM, "hipMalloc failed");
+	return RXGPU_OK;
+}
+
+/* rxgpu_shutdown: everything the drop-ins keep alive between calls belongs to the device that is going away */
+void rxgpu_fm_dropin_release(void)
+{
+	pthread_mutex_lock(&g_side_lock);
+	for (int i = 0; i < SIDECARS; i++) {
+		if (g_side[i].s)
+			rxgpu_fm_stream_destroy(g_side[i].s);
+		g_side[i].s = NULL;
+		hipFree(g_side[i].cb_in); hipFree(g_side[i].cb_rdc); hipFree(g_side[i].cb_pre[0]); hipFree(g_side[i].cb_pre[1]);
+		hipFree(g_side[i].fd_in);
+		g_side[i].cb_in = g_side[i].cb_pre[0] = g_side[i].cb_pre[1] = g_side[i].fd_in = NULL;
+		g_side[i].cb_rdc = NULL;
+		g_side[i].dev_valid = 0;
+	}
+	pthread_mutex_unlock(&g_side_lock);
+}
+
 void rxgpu_full_demod(struct demod_state *d)
 {
 	int slot = side_slot(d);
@@ -1298,6 +1420,11 @@ void rxgpu_full_demod(struct demod_state *d)
 			rxgpu_fail(RXGPU_EUNSUPPORTED, "mode_demod %p is none of the registered demodulators", fn);
 			die("rxgpu_full_demod");
 		}
+	}
+	/* readStream may return any element count (rtl_fm.c:894-899): lp_len is whatever the callback got, times two */
+	if (d->lp_len < 0 || d->lp_len > RXGPU_MAXIMUM_BUF_LENGTH || (d->lp_len & 1)) {
+		rxgpu_fail(RXGPU_EINVAL, "lp_len %d (the callback stores twice readStream's element count, rtl_fm.c:899: even, at most %d)", d->lp_len, RXGPU_MAXIMUM_BUF_LENGTH);
+		die("rxgpu_full_demod");
 	}
 	rxgpu_fm_params p;
 	memset(&p, 0, sizeof(p));
@@ -1322,6 +1449,7 @@ void rxgpu_full_demod(struct demod_state *d)
 		g_side[slot].s = NULL;
 		if (rxgpu_fm_stream_create(&g_side[slot].s, &p, 1, RXGPU_MAXIMUM_BUF_LENGTH) != RXGPU_OK)
 			die("rxgpu_full_demod");
+		g_side[slot].s->allow_empty = 1;                /* a block that completes no window is legal here, see below */
 		g_side[slot].p = p;
 	}
 	rxgpu_fm_stream *s = g_side[slot].s;
@@ -1337,49 +1465,66 @@ void rxgpu_full_demod(struct demod_state *d)
 	c.now_lpr = d->now_lpr; c.prev_lpr_index = d->prev_lpr_index;
 	c.squelch_hits = d->squelch_hits; c.dc_avg = d->dc_avg;
 	rxgpu_fm_stream_set_carry(s, &c);
-	const int c_in_prev_index = c.prev_index;
+	const int pre_r_in = d->pre_r, pre_j_in = d->pre_j;
 	size_t got = 0;
-	hipStream_t st = rxgpu_hip_stream(), sb = rxgpu_hip_stream2();
-	if (g_side[slot].dev_valid && g_side[slot].dev_len == d->lp_len && g_cb_pre[g_side[slot].dev_slot]) {
+	hipStream_t sb = rxgpu_hip_stream2();
+	const size_t cap = (size_t)RXGPU_MAXIMUM_BUF_LENGTH + 16;
+	if (s->stage_out_cap < cap) {
+		hipFree(s->stage_out);
+		s->stage_out = NULL; s->stage_out_cap = 0;
+		if (hipMalloc((void **)&s->stage_out, cap * 2) != hipSuccess) {
+			rxgpu_fail(RXGPU_ENOMEM, "hipMalloc failed");
+			die("rxgpu_full_demod");
+		}
+		s->stage_out_cap = cap;
+	}
+	const int16_t *d_block;
+	if (g_side[slot].dev_valid && g_side[slot].dev_len == d->lp_len && d->lp_len > 0 && g_side[slot].cb_pre[g_side[slot].dev_slot]) {
 		/* the block is the one rxgpu_callback pre-staged: it is still in HBM, no second trip over PCIe.  (The caller
 		 * holds d->rw like the reference's demod thread, rtl_fm.c:922-924, so the callback cannot publish meanwhile.) */
-		const size_t cap = (size_t)RXGPU_MAXIMUM_BUF_LENGTH + 16;
-		if (s->stage_out_cap < cap) {
-			hipFree(s->stage_out);
-			s->stage_out = NULL; s->stage_out_cap = 0;
-			if (hipMalloc((void **)&s->stage_out, cap * 2) != hipSuccess) {
-				rxgpu_fail(RXGPU_ENOMEM, "hipMalloc failed");
-				die("rxgpu_full_demod");
-			}
-			s->stage_out_cap = cap;
-		}
-		if (rxgpu_fm_stream_run(s, g_cb_pre[g_side[slot].dev_slot], 1, (size_t)d->lp_len, s->stage_out, s->stage_out_cap, &got, NULL) != RXGPU_OK)
-			die("rxgpu_full_demod");
-		if (got > RXGPU_MAXIMUM_BUF_LENGTH) {
-			rxgpu_fail(RXGPU_ECAPACITY, "result needs %zu int16", got);
+		d_block = g_side[slot].cb_pre[g_side[slot].dev_slot];
+	} else {
+		/* any other lowpassed[]: up it goes.  At least the first two int16: an empty -F block still runs fifth_order on lowpassed[0]
+		 * and lowpassed[1] (rtl_fm.c:419-423 reads data[0] whatever the length) */
+		if (!g_side[slot].fd_in && hipMalloc((void **)&g_side[slot].fd_in, RXGPU_MAXIMUM_BUF_LENGTH * 2 + 16) != hipSuccess) {
+			rxgpu_fail(RXGPU_ENOMEM, "hipMalloc failed");
 			die("rxgpu_full_demod");
 		}
-		if (got && hipMemcpyAsync(d->result, s->stage_out, got * 2, hipMemcpyDeviceToHost, sb) != hipSuccess) {
-			rxgpu_fail(RXGPU_ENODEV, "copy of the result failed");
+		const size_t up = (size_t)(d->lp_len > 2 ? d->lp_len : 2) * 2;
+		if (hipMemcpyAsync(g_side[slot].fd_in, d->lowpassed, up, hipMemcpyHostToDevice, sb) != hipSuccess) {
+			rxgpu_fail(RXGPU_ENODEV, "upload of lowpassed[] failed");
 			die("rxgpu_full_demod");
 		}
-		g_side[slot].dev_valid = 0;
-	} else if (rxgpu_fm_stream_run_host(s, d->lowpassed, 1, (size_t)d->lp_len, d->result, RXGPU_MAXIMUM_BUF_LENGTH, &got, NULL) != RXGPU_OK) {
+		if (hipStreamSynchronize(sb) != hipSuccess) {       /* the run below starts on the other streams */
+			rxgpu_fail(RXGPU_ENODEV, "upload of lowpassed[] failed");
+			die("rxgpu_full_demod");
+		}
+		d_block = g_side[slot].fd_in;
+	}
+	if (rxgpu_fm_stream_run(s, d_block, 1, (size_t)d->lp_len, s->stage_out, s->stage_out_cap, &got, NULL) != RXGPU_OK)
+		die("rxgpu_full_demod");
+	g_side[slot].dev_valid = 0;
+	if (got > RXGPU_MAXIMUM_BUF_LENGTH) {
+		rxgpu_fail(RXGPU_ECAPACITY, "result needs %zu int16", got);
 		die("rxgpu_full_demod");
 	}
-	(void)st;
+	if (got && hipMemcpyAsync(d->result, s->stage_out, got * 2, hipMemcpyDeviceToHost, sb) != hipSuccess) {
+		rxgpu_fail(RXGPU_ENODEV, "copy of the result failed");
+		die("rxgpu_full_demod");
+	}
 	rxgpu_fm_stream_get_carry(s, &c);
-	/* decimated IQ back into lowpassed[], like the CPU's in-place stages leave it */
+	/* decimated IQ back into lowpassed[], like the CPU's in-place stages leave it: lp_len' int16 (odd on some -F shapes), and
+	 * never fewer than two -- every fifth_order pass rewrites lowpassed[0] and [1] even for an empty block */
+	const struct run_geom *g = &s->last;
+	const int lp_len_out = g->passes ? (g->literal ? g->lf : (int)(2 * g->K)) : (int)(2 * g->M);
 	{
-		int passes = d->downsample_passes;
-		unsigned long long n = (unsigned long long)d->lp_len / 2;
-		unsigned long long M = passes ? (n >> passes) : ((unsigned long long)c_in_prev_index + n) / (unsigned long long)d->downsample;
-		const uint32_t *src = s->lp_final;
-		if (hipMemcpyAsync(d->lowpassed, src, M * 4, hipMemcpyDeviceToHost, sb) != hipSuccess || hipStreamSynchronize(sb) != hipSuccess) {
+		const size_t back = g->passes ? (size_t)(lp_len_out > 2 ? lp_len_out : 2) : (size_t)lp_len_out;
+		if ((back && hipMemcpyAsync(d->lowpassed, s->lp_final, back * 2, hipMemcpyDeviceToHost, sb) != hipSuccess) ||
+		    hipStreamSynchronize(sb) != hipSuccess) {
 			rxgpu_fail(RXGPU_ENODEV, "copy of decimated IQ failed");
 			die("rxgpu_full_demod");
 		}
-		d->lp_len = (int)(2 * M);
+		d->lp_len = lp_len_out;
 	}
 	d->result_len = (int)got;
 	d->now_r = c.now_r; d->now_j = c.now_j; d->prev_index = c.prev_index;
@@ -1391,6 +1536,18 @@ void rxgpu_full_demod(struct demod_state *d)
 	g_side[slot].avg = c.deemph_avg;
 	d->now_lpr = c.now_lpr; d->prev_lpr_index = c.prev_lpr_index;
 	d->squelch_hits = c.squelch_hits; d->dc_avg = c.dc_avg;
+	if (lp_len_out < 2 && mode == RXGPU_MODE_FM) {
+		/* Fewer than one decimated sample (a read shorter than the decimation).  fm_demod (rtl_fm.c:584-615) still writes result[0]
+		 * from lp[0], lp[1] against the old pre_r/pre_j, and takes the new pre_r/pre_j from lp[lp_len-2], lp[lp_len-1] -- in FRONT of
+		 * lowpassed[] (the tail of d->thread) for lp_len 0 or 1.  The device never sees that memory; the drop-in has the real struct
+		 * and finishes the block the way the C does.  (lowpassed[0], [1]: what low_pass left untouched, or what the last fifth_order
+		 * pass wrote -- copied back above.) */
+		const int16_t *lp = d->lowpassed;
+		const int16_t *end = (const int16_t *)((const char *)d + offsetof(struct demod_state, lowpassed)) + lp_len_out;
+		d->result[0] = (int16_t)polar_discriminant_host(lp[0], lp[1], pre_r_in, pre_j_in);
+		d->pre_r = end[-2];
+		d->pre_j = end[-1];
+	}
 }
 
 void rxgpu_callback(int16_t *buf, uint32_t len, void *ctx)
@@ -1403,6 +1560,7 @@ void rxgpu_callback(int16_t *buf, uint32_t len, void *ctx)
 	if (rxgpu_ensure_init() != RXGPU_OK)
 		die("rxgpu_callback");
 	if (len > RXGPU_MAXIMUM_BUF_LENGTH || (len & 1)) {
+		/* the reference passes r * 2 for r <= MAXIMUM_BUF_LENGTH / 2 elements (rtl_fm.c:872, 894-899): even, bounded */
 		rxgpu_fail(RXGPU_EINVAL, "callback length %u", len);
 		die("rxgpu_callback");
 	}
@@ -1416,38 +1574,41 @@ void rxgpu_callback(int16_t *buf, uint32_t len, void *ctx)
 			buf[i] = 0;
 		s->mute = 0;
 	}
-	if (!g_cb_in) {
-		if (hipMalloc((void **)&g_cb_in, RXGPU_MAXIMUM_BUF_LENGTH * 2) != hipSuccess ||
-		    hipMalloc((void **)&g_cb_rdc, 64) != hipSuccess ||
-		    hipMalloc((void **)&g_cb_pre[0], RXGPU_MAXIMUM_BUF_LENGTH * 2) != hipSuccess ||
-		    hipMalloc((void **)&g_cb_pre[1], RXGPU_MAXIMUM_BUF_LENGTH * 2) != hipSuccess) {
-			rxgpu_fail(RXGPU_ENOMEM, "hipMalloc failed");
-			die("rxgpu_callback");
-		}
+	if (len && d->dc_block_raw && len < 2) {
+		rxgpu_fail(RXGPU_EUNSUPPORTED, "-E rdc on an empty read divides by zero in the reference (rtl_fm.c:711)");
+		die("rxgpu_callback");
 	}
+	pthread_mutex_lock(&g_side[side].cb_lock);       /* the buffers below belong to this demod_state; one callback at a time on them */
+	if (side_buffers(side) != RXGPU_OK) {
+		pthread_mutex_unlock(&g_side[side].cb_lock);
+		die("rxgpu_callback");
+	}
+	int16_t *const cb_in = g_side[side].cb_in;
+	int *const cb_rdc = g_side[side].cb_rdc;
 	/* write the slot that is NOT published: full_demod may be reading the published one right now (it runs under
 	 * d->rw; the publication below happens under d->rw too) */
 	const int w = g_side[side].dev_valid ? g_side[side].dev_slot ^ 1 : 0;
-	int16_t *pre = g_cb_pre[w];
+	int16_t *pre = g_side[side].cb_pre[w];
 	hipStream_t st = rxgpu_hip_stream3();            /* its own stream: the demod thread's runs use the other two */
-	int ok = !len || hipMemcpyAsync(g_cb_in, buf, (size_t)len * 2, hipMemcpyHostToDevice, st) == hipSuccess;
+	int ok = !len || hipMemcpyAsync(cb_in, buf, (size_t)len * 2, hipMemcpyHostToDevice, st) == hipSuccess;
 	if (ok && len && d->dc_block_raw) {
-		/* rtl_fm.c:850-852: scale, dc_block_raw_filter, rotate; g_cb_rdc = state[2] | avg[2] | sums[2] */
+		/* rtl_fm.c:850-852: scale, dc_block_raw_filter, rotate; cb_rdc = state[2] | avg[2] | sums[2] */
 		int state[2] = { d->dc_avgI, d->dc_avgQ };
-		ok = hipMemcpyAsync(g_cb_rdc, state, 8, hipMemcpyHostToDevice, st) == hipSuccess &&
-		     rxk_fm_rdc(st, g_cb_in, 1, len / 2, 0, !s->offset_tuning, d->rdc_block_const, g_cb_rdc, (long long *)(g_cb_rdc + 4),
-		                g_cb_rdc + 2, pre) == 0 &&
-		     hipMemcpyAsync(state, g_cb_rdc, 8, hipMemcpyDeviceToHost, st) == hipSuccess &&
+		ok = hipMemcpyAsync(cb_rdc, state, 8, hipMemcpyHostToDevice, st) == hipSuccess &&
+		     rxk_fm_rdc(st, cb_in, 1, len / 2, 0, !s->offset_tuning, d->rdc_block_const, cb_rdc, (long long *)(cb_rdc + 4),
+		                cb_rdc + 2, pre) == 0 &&
+		     hipMemcpyAsync(state, cb_rdc, 8, hipMemcpyDeviceToHost, st) == hipSuccess &&
 		     hipMemcpyAsync(s->buf16, pre, (size_t)len * 2, hipMemcpyDeviceToHost, st) == hipSuccess &&
 		     hipStreamSynchronize(st) == hipSuccess;
 		d->dc_avgI = state[0];
 		d->dc_avgQ = state[1];
 	} else if (ok && len) {
-		ok = rxk_fm_prestage(st, g_cb_in, len / 2, !s->offset_tuning, pre) == 0 &&
+		ok = rxk_fm_prestage(st, cb_in, len / 2, !s->offset_tuning, pre) == 0 &&
 		     hipMemcpyAsync(s->buf16, pre, (size_t)len * 2, hipMemcpyDeviceToHost, st) == hipSuccess &&
 		     hipStreamSynchronize(st) == hipSuccess;
 	}
 	if (!ok) {
+		pthread_mutex_unlock(&g_side[side].cb_lock);
 		rxgpu_fail(RXGPU_ENODEV, "device pre-stage failed: %s", hipGetErrorString(hipGetLastError()));
 		die("rxgpu_callback");
 	}
@@ -1458,6 +1619,7 @@ void rxgpu_callback(int16_t *buf, uint32_t len, void *ctx)
 	g_side[side].dev_len = (int)len;
 	g_side[side].dev_valid = len > 0;
 	pthread_rwlock_unlock(&d->rw);
+	pthread_mutex_unlock(&g_side[side].cb_lock);
 	pthread_mutex_lock(&d->ready_m);
 	pthread_cond_signal(&d->ready);
 	pthread_mutex_unlock(&d->ready_m);

@@ -26,6 +26,10 @@ hipStream_t rxgpu_hip_stream3(void);   /* third stream: host <-> device copies o
 #define RX_K(call) do { int e_ = (call); if (e_ != 0) \
 	return rxgpu_fail(RXGPU_ENODEV, "%s launch failed: %s (%s:%d)", #call, hipGetErrorString((hipError_t)e_), __FILE__, __LINE__); } while (0)
 
+/* rxgpu_shutdown: free what the drop-in entry points cache between calls (rxgpu_fm.c, rxgpu_power.c) */
+void rxgpu_fm_dropin_release(void);
+void rxgpu_power_dropin_release(void);
+
 /* fix_fft twiddles for the device: n/2 plain + n/2 doubled entries (rxgpu_power.c); tw holds n + 2 */
 void rxgpu_twiddle_table(const int16_t *sinewave, int n, uint32_t *tw);
 
@@ -34,6 +38,8 @@ void rxgpu_prof_begin_on(const char *name, hipStream_t st);
 void rxgpu_prof_end_on(const char *name, hipStream_t st);
 #define rxgpu_prof_begin(name) rxgpu_prof_begin_on((name), rxgpu_hip_stream())
 #define rxgpu_prof_end(name) rxgpu_prof_end_on((name), rxgpu_hip_stream())
+/* drop a begun pair whose kernels were never enqueued (error paths) */
+void rxgpu_prof_abort(void);
 /* fold finished event pairs into the totals (call after a stream sync) */
 void rxgpu_prof_collect(void);
 

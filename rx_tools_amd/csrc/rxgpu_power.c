@@ -323,7 +323,11 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 			const int n_fft = 1 << p->bin_e, eff = buf_len / ds;
 			const int n_read = (eff + 2 * n_fft - 1) / (2 * n_fft) * n_fft;
 			const unsigned long long nc = (unsigned long long)buf_len / 2, T = (unsigned long long)n_bufs * nc;
-			if (ds >= 4 && ds <= RXK_DEC_MAX_DS && nc % (unsigned long long)ds == 0 && T % 4 == 0 && !getenv("RXGPU_BOXCAR_PLAIN")) {
+			/* (eff % (2 * n_fft): with a partial last FFT block the transform reads past the tune's compact output into the next tune's;
+			 * the plain kernel below zero-fills up to n_read like the in-place original.  The reference's planner never makes that
+			 * geometry, rxgpu_power_scan_create accepts it.) */
+			if (ds >= 4 && ds <= RXK_DEC_MAX_DS && nc % (unsigned long long)ds == 0 && T % 4 == 0 && eff % (2 * n_fft) == 0 &&
+			    !getenv("RXGPU_BOXCAR_PLAIN")) {
 				/* whole windows per buffer: the sums over the concatenated buffers are low_pass (rtl_fm.c:351-371) on an already
 				 * scaled, unrotated stream -- the rx_fm decimator, then its per-span seam entries; output compact, eff_len per buffer */
 				const size_t n_spans = (size_t)((T + RXK_DEC_SPAN - 1) / RXK_DEC_SPAN) + 1;
@@ -444,19 +448,35 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 /* ------------------------------------------------------------------ drop-ins */
 
 /* scanner() is called once per sweep for the life of the process with the same geometry and tables (rtl_power.c:1040-1046):
- * the scan object, its device tables and the three device buffers are kept between calls and only rebuilt when the
- * geometry or a table changes. */
+ * the scan object, its device tables and the device buffers are kept between calls and only rebuilt when the geometry or a
+ * table changes.
+ *
+ * The integrators stay on the device between calls.  Nothing reads ts->avg[] / ts->samples between two scanner() calls -- the
+ * reference only looks at them in csv_dbm, once per report interval (rtl_power.c:1045-1050) -- so rxgpu_scan uploads the tunes'
+ * buf16 (9.8 MB at the configs[2] geometry), adds the sweep into device-resident accumulators that start from zero, and
+ * returns without waiting; rxgpu_scan_sync (called by rxgpu_csv_dbm for a tuning_state of the sweep, or explicitly in front of the
+ * reference's own csv_dbm) brings the accumulated sums back ONCE per interval and merges them into the caller's arrays:
+ * avg += delta, or MAX for peak hold (every term is a non-negative power, so a running maximum that starts from zero
+ * commutes with the caller's), samples += delta.  The first version moved all of avg[] both ways on every call: 2 x 19.6 MB
+ * for 9.8 MB of input.  $RXGPU_SCAN_EAGER=1 syncs at the end of every call (the struct is then current after each sweep). */
 static struct {
 	rxgpu_power_scan *s;
 	rxgpu_power_params p;
 	int tune_cap;
 	int *window_copy;
 	int16_t *sine_copy;
-	int16_t *d_in;
-	int64_t *d_avg;
+	int16_t *d_in[2];                /* two sweeps of input in rotation: sweep k+1 is staged while sweep k is transformed */
+	int16_t *h_in[2];                /* pinned staging: tunes[i].buf16 are separate mallocs of the caller */
+	hipEvent_t ev_in[2];
+	int ev_valid[2];
+	unsigned long long calls;
+	int64_t *d_avg;                  /* accumulated since the last sync, from zero */
 	int32_t *d_samples;
-	int64_t *h_avg;                  /* pinned staging: tunes[i].avg are separate mallocs of the caller */
-	int16_t *h_in;
+	int64_t *h_avg;                  /* pinned: download of the accumulators (+ samples behind them) */
+	struct tuning_state *tunes;      /* whose sums the accumulators hold */
+	int tune_count;
+	int dirty;
+	long syncs;
 } g_scan;
 static pthread_mutex_t g_scan_lock = PTHREAD_MUTEX_INITIALIZER;
 
@@ -464,10 +484,56 @@ static void scan_cache_drop(void)
 {
 	rxgpu_power_scan_destroy(g_scan.s);
 	free(g_scan.window_copy); free(g_scan.sine_copy);
-	hipFree(g_scan.d_in); hipFree(g_scan.d_avg); hipFree(g_scan.d_samples);
+	for (int k = 0; k < 2; k++) {
+		hipFree(g_scan.d_in[k]);
+		if (g_scan.h_in[k]) hipHostFree(g_scan.h_in[k]);
+		if (g_scan.ev_in[k]) hipEventDestroy(g_scan.ev_in[k]);
+	}
+	hipFree(g_scan.d_avg); hipFree(g_scan.d_samples);
 	if (g_scan.h_avg) hipHostFree(g_scan.h_avg);
-	if (g_scan.h_in) hipHostFree(g_scan.h_in);
 	memset(&g_scan, 0, sizeof(g_scan));
+}
+
+/* accumulators -> the caller's tuning_state array they belong to; the device side starts from zero again */
+static int scan_sync_locked(void)
+{
+	if (!g_scan.dirty)
+		return RXGPU_OK;
+	hipStream_t st = rxgpu_hip_stream();
+	const int tc = g_scan.tune_count;
+	const size_t n = (size_t)1 << g_scan.p.bin_e;
+	int32_t *h_samples = (int32_t *)(g_scan.h_avg + (size_t)tc * n);
+	RX_HIP(hipMemcpyAsync(g_scan.h_avg, g_scan.d_avg, (size_t)tc * n * 8, hipMemcpyDeviceToHost, st));
+	RX_HIP(hipMemcpyAsync(h_samples, g_scan.d_samples, (size_t)tc * 4, hipMemcpyDeviceToHost, st));
+	RX_HIP(hipMemsetAsync(g_scan.d_avg, 0, (size_t)tc * n * 8, st));
+	RX_HIP(hipMemsetAsync(g_scan.d_samples, 0, (size_t)tc * 4, st));
+	RX_HIP(hipStreamSynchronize(st));
+	for (int i = 0; i < tc; i++) {
+		int64_t *avg = g_scan.tunes[i].avg;
+		const int64_t *delta = g_scan.h_avg + (size_t)i * n;
+		if (g_scan.p.peak_hold) {
+			for (size_t j = 0; j < n; j++)
+				if (delta[j] > avg[j])
+					avg[j] = delta[j];
+		} else {
+			for (size_t j = 0; j < n; j++)
+				avg[j] += delta[j];
+		}
+		g_scan.tunes[i].samples += h_samples[i];
+	}
+	g_scan.dirty = 0;
+	g_scan.syncs++;
+	rxgpu_prof_collect();
+	return RXGPU_OK;
+}
+
+void rxgpu_power_dropin_release(void)
+{
+	pthread_mutex_lock(&g_scan_lock);
+	if (g_scan.dirty)
+		scan_sync_locked();                              /* what was accumulated belongs to the caller */
+	scan_cache_drop();
+	pthread_mutex_unlock(&g_scan_lock);
 }
 
 static int scan_locked(struct tuning_state *tunes, int tune_count, const int *window_coefs,
@@ -490,6 +556,9 @@ static int scan_locked(struct tuning_state *tunes, int tune_count, const int *wi
 	if (same && p.bin_e > 0)
 		same = window_coefs && sinewave && !memcmp(g_scan.window_copy, window_coefs, n * sizeof(int)) &&
 		       !memcmp(g_scan.sine_copy, sinewave, n_sine * sizeof(int16_t));
+	/* another sweep geometry, another tuning_state array or count: what was accumulated goes home first */
+	if (g_scan.dirty && (!same || tunes != g_scan.tunes || tune_count != g_scan.tune_count) && (rc = scan_sync_locked()) != RXGPU_OK)
+		return rc;
 	if (!same) {
 		scan_cache_drop();
 		if ((rc = rxgpu_power_scan_create(&g_scan.s, &p, tune_count, window_coefs, sinewave)) != RXGPU_OK)
@@ -506,36 +575,41 @@ static int scan_locked(struct tuning_state *tunes, int tune_count, const int *wi
 			memcpy(g_scan.window_copy, window_coefs, n * sizeof(int));
 			memcpy(g_scan.sine_copy, sinewave, n_sine * sizeof(int16_t));
 		}
-		if (hipMalloc((void **)&g_scan.d_in, (size_t)tune_count * p.buf_len * 2) != hipSuccess ||
+		const size_t in_bytes = (size_t)tune_count * p.buf_len * 2;
+		if (hipMalloc((void **)&g_scan.d_in[0], in_bytes) != hipSuccess || hipMalloc((void **)&g_scan.d_in[1], in_bytes) != hipSuccess ||
 		    hipMalloc((void **)&g_scan.d_avg, (size_t)tune_count * n * 8) != hipSuccess ||
 		    hipMalloc((void **)&g_scan.d_samples, (size_t)tune_count * 4 + 4) != hipSuccess ||
 		    hipHostMalloc((void **)&g_scan.h_avg, (size_t)tune_count * n * 8 + (size_t)tune_count * 4, 0) != hipSuccess ||
-		    hipHostMalloc((void **)&g_scan.h_in, (size_t)tune_count * p.buf_len * 2, 0) != hipSuccess) {
+		    hipHostMalloc((void **)&g_scan.h_in[0], in_bytes, 0) != hipSuccess || hipHostMalloc((void **)&g_scan.h_in[1], in_bytes, 0) != hipSuccess ||
+		    hipEventCreateWithFlags(&g_scan.ev_in[0], hipEventDisableTiming) != hipSuccess ||
+		    hipEventCreateWithFlags(&g_scan.ev_in[1], hipEventDisableTiming) != hipSuccess ||
+		    hipMemset(g_scan.d_avg, 0, (size_t)tune_count * n * 8) != hipSuccess ||
+		    hipMemset(g_scan.d_samples, 0, (size_t)tune_count * 4 + 4) != hipSuccess) {
 			scan_cache_drop();
 			return rxgpu_fail(RXGPU_ENOMEM, "rxgpu_scan: buffer allocation failed");
 		}
 	}
+	g_scan.tunes = tunes;
+	g_scan.tune_count = tune_count;
 	hipStream_t st = rxgpu_hip_stream();
-	/* gather the caller's scattered buffers into the pinned staging, then three copies instead of 3 per tune */
-	int32_t *h_samples = (int32_t *)(g_scan.h_avg + (size_t)tune_count * n);
-	for (int i = 0; i < tune_count; i++) {
-		memcpy(g_scan.h_in + (size_t)i * p.buf_len, tunes[i].buf16, (size_t)p.buf_len * 2);
-		memcpy(g_scan.h_avg + (size_t)i * n, tunes[i].avg, n * 8);
-		h_samples[i] = tunes[i].samples;
-	}
-	RX_HIP(hipMemcpyAsync(g_scan.d_in, g_scan.h_in, (size_t)tune_count * p.buf_len * 2, hipMemcpyHostToDevice, st));
-	RX_HIP(hipMemcpyAsync(g_scan.d_avg, g_scan.h_avg, (size_t)tune_count * n * 8, hipMemcpyHostToDevice, st));
-	RX_HIP(hipMemcpyAsync(g_scan.d_samples, h_samples, (size_t)tune_count * 4, hipMemcpyHostToDevice, st));
-	if ((rc = rxgpu_power_scan_run(g_scan.s, g_scan.d_in, 1, tune_count, g_scan.d_avg, g_scan.d_samples)) != RXGPU_OK)
+	/* gather the caller's scattered buffers into pinned staging (one copy instead of one per tune); the staging of two sweeps
+	 * ago has long been read */
+	const int k = (int)(g_scan.calls++ & 1);
+	if (g_scan.ev_valid[k])
+		RX_HIP(hipEventSynchronize(g_scan.ev_in[k]));
+	for (int i = 0; i < tune_count; i++)
+		memcpy(g_scan.h_in[k] + (size_t)i * p.buf_len, tunes[i].buf16, (size_t)p.buf_len * 2);
+	RX_HIP(hipMemcpyAsync(g_scan.d_in[k], g_scan.h_in[k], (size_t)tune_count * p.buf_len * 2, hipMemcpyHostToDevice, st));
+	if ((rc = rxgpu_power_scan_run(g_scan.s, g_scan.d_in[k], 1, tune_count, g_scan.d_avg, g_scan.d_samples)) != RXGPU_OK)
 		return rc;
-	RX_HIP(hipMemcpyAsync(g_scan.h_avg, g_scan.d_avg, (size_t)tune_count * n * 8, hipMemcpyDeviceToHost, st));
-	RX_HIP(hipMemcpyAsync(h_samples, g_scan.d_samples, (size_t)tune_count * 4, hipMemcpyDeviceToHost, st));
-	RX_HIP(hipStreamSynchronize(st));
-	for (int i = 0; i < tune_count; i++) {
-		memcpy(tunes[i].avg, g_scan.h_avg + (size_t)i * n, n * 8);
-		tunes[i].samples = h_samples[i];
+	RX_HIP(hipEventRecord(g_scan.ev_in[k], st));
+	g_scan.ev_valid[k] = 1;
+	g_scan.dirty = 1;
+	{
+		const char *e = getenv("RXGPU_SCAN_EAGER");
+		if (e && atoi(e) > 0)
+			return scan_sync_locked();
 	}
-	rxgpu_prof_collect();
 	return RXGPU_OK;
 }
 
@@ -552,6 +626,22 @@ int rxgpu_scan(struct tuning_state *tunes, int tune_count, const int *window_coe
 	pthread_mutex_unlock(&g_scan_lock);
 	return rc;
 }
+
+int rxgpu_scan_sync(struct tuning_state *tunes, int tune_count)
+{
+	int rc = RXGPU_OK;
+	pthread_mutex_lock(&g_scan_lock);
+	if (g_scan.dirty) {
+		if (tunes && (tunes != g_scan.tunes || tune_count != g_scan.tune_count))
+			rc = rxgpu_fail(RXGPU_EINVAL, "rxgpu_scan_sync: the accumulated sweep belongs to another tuning_state array (%d tunes)", g_scan.tune_count);
+		else
+			rc = scan_sync_locked();
+	}
+	pthread_mutex_unlock(&g_scan_lock);
+	return rc;
+}
+
+long rxgpu_scan_syncs(void) { return g_scan.syncs; }
 
 /* One CSV row for a tuning_state, byte for byte what csv_dbm prints (rtl_power.c:774-817) -- a restatement, because
  * the text has to be identical: the bins are read through the index map the reference's in-place edits amount to
@@ -571,6 +661,12 @@ static int64_t csv_bin(const struct tuning_state *ts, int len, int i)
 void rxgpu_csv_dbm(struct tuning_state *ts, void *file)
 {
 	FILE *f = (FILE *)file;
+	/* the row of a sweep whose sums are still on the device: bring them home first (once per interval -- the next rows find
+	 * nothing pending) */
+	pthread_mutex_lock(&g_scan_lock);
+	if (g_scan.dirty && ts >= g_scan.tunes && ts < g_scan.tunes + g_scan.tune_count && scan_sync_locked() != RXGPU_OK)
+		fprintf(stderr, "rxgpu_csv_dbm: %s\n", rxgpu_last_error());
+	pthread_mutex_unlock(&g_scan_lock);
 	const int len = 1 << ts->bin_e, ds = ts->downsample;
 	const int kept = (int)((double)len * (1.0 - ts->crop));
 	const int half_bw = (int)(((double)ts->rate * (double)kept) / (len * 2 * ds));

@@ -90,6 +90,12 @@ void rxgpu_shutdown(void)
 		return;
 	hipStreamSynchronize(g_stream);
 	hipStreamSynchronize(g_stream2);
+	hipStreamSynchronize(g_stream3);
+	hipStreamSynchronize(g_stream4);
+	/* what the drop-ins keep between calls (stream objects, the callback's device buffers, the scan object and its staging) lives
+	 * on this device: none of it may survive into a re-initialisation on another one */
+	rxgpu_fm_dropin_release();
+	rxgpu_power_dropin_release();
 	rxgpu_prof_reset();
 	hipStreamDestroy(g_stream);
 	hipStreamDestroy(g_stream2);
@@ -230,6 +236,17 @@ void rxgpu_prof_end_on(const char *name, hipStream_t st)
 	t_cur.a = NULL;
 }
 
+void rxgpu_prof_abort(void)
+{
+	if (t_cur.slot < 0 || !t_cur.a)
+		return;
+	pthread_mutex_lock(&g_prof_lock);
+	g_free[g_nfree++] = t_cur.a;
+	pthread_mutex_unlock(&g_prof_lock);
+	t_cur.slot = -1;
+	t_cur.a = NULL;
+}
+
 static void prof_collect_locked(void);
 
 void rxgpu_prof_collect(void)
@@ -261,6 +278,8 @@ void rxgpu_prof_reset(void)
 	if (g_device >= 0 && g_npend) {
 		hipStreamSynchronize(g_stream);
 		hipStreamSynchronize(g_stream2);
+		hipStreamSynchronize(g_stream3);
+		hipStreamSynchronize(g_stream4);
 		rxgpu_prof_collect();
 	}
 	g_ntot = 0;
@@ -271,6 +290,8 @@ int rxgpu_prof_get(const char *name, double *total_ms, long *launches)
 	if (g_device >= 0 && g_npend) {
 		hipStreamSynchronize(g_stream);
 		hipStreamSynchronize(g_stream2);
+		hipStreamSynchronize(g_stream3);
+		hipStreamSynchronize(g_stream4);
 		rxgpu_prof_collect();
 	}
 	for (int i = 0; i < g_ntot; i++)

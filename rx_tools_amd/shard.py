@@ -1,8 +1,8 @@
 """Multi-GPU rx_power: contiguous tune ranges per rank and the one gather that merges them.
 
-The product path is librxgpu's own (rxgpu_comm_*, rxgpu_power_gather in rxgpu_comm.c: ncclGather from librccl on the
-library's stream, right behind the scan kernels); `Comm` binds it.  The torch.distributed helpers below it are what the
-CPU tests (gloo) and bench.py's fallback use.
+The product path is librxgpu's own (rxgpu_comm_*, rxgpu_power_gather in rxgpu_comm.c: one grouped ncclGather launch from
+librccl on the library's stream, right behind the scan kernels); `Comm` binds it.  The torch.distributed helpers below it
+are what the CPU tests (gloo) use, and bench.py only with --allow-torch-gather.
 
 scanner()'s tunes are independent units (rtl_power.c:679-771: own buf16, avg, samples); nothing
 crosses tunes until csv_dbm prints rows in tune order (1047-1050).  So rank r scans tunes
@@ -61,6 +61,15 @@ class Comm:
     def library():
         p = lib().rxgpu_comm_library()
         return p.decode() if p else None
+
+    @property
+    def observed(self):
+        """(rank, world) as the communicator reports them (checked against ncclCommUserRank / ncclCommCount at creation)"""
+        return lib().rxgpu_comm_rank(self._h), lib().rxgpu_comm_world(self._h)
+
+    @property
+    def gathers(self):
+        return lib().rxgpu_comm_gathers(self._h)
 
     def gather(self, d_avg_local, d_samples_local, per, n_bins, d_avg_all=0, d_samples_all=0, root=0):
         """device addresses; asynchronous on the library's stream"""

@@ -29,7 +29,8 @@ def main():
     from rx_tools_amd.structs import TuningState
     from support import oracle, sig_noise, PowerCfg, ptr16, ptr32, ptr64
     L = R.lib()
-    dev = rank % max(1, torch.cuda.device_count())
+    # RCCL_WORKER_ONE_GPU: every rank on device 0 (only with a transport that allows it: tests/fake_rccl.c)
+    dev = 0 if os.environ.get("RCCL_WORKER_ONE_GPU") else rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev)
     R.check(L.rxgpu_init(dev))
     id_path = os.path.join(tmp, "nccl_id.bin")
@@ -55,6 +56,9 @@ def main():
     d_in = torch.from_numpy(np.ascontiguousarray(data[:, first:first + count])).cuda() if count else torch.zeros(1, dtype=torch.int16, device="cuda")
     d_avg = torch.zeros((per, n), dtype=torch.int64, device="cuda")
     d_smp = torch.zeros(per, dtype=torch.int32, device="cuda")
+    if os.environ.get("RCCL_WORKER_DIRTY_PADDING") and count < per:
+        d_avg[count:] = 123456789                # the sharded entry point has to hand the root zeros for rows no tune owns
+        d_smp[count:] = 77
     d_avg_all = torch.zeros((world, per, n), dtype=torch.int64, device="cuda") if rank == 0 else None
     d_smp_all = torch.zeros((world, per), dtype=torch.int32, device="cuda") if rank == 0 else None
     torch.cuda.synchronize()
@@ -77,6 +81,8 @@ def main():
                 want_smp[t] = s.value
         assert np.array_equal(merged, want_avg), "gathered avg[] rows differ from the single-process sweep"
         assert np.array_equal(msmp, want_smp)
+        assert not d_avg_all.reshape(world * per, n)[TOTAL_TUNES:].any() and not d_smp_all.reshape(world * per)[TOTAL_TUNES:].any(), "padding rows not zero"
+        assert comm.observed == (rank, world) and comm.gathers == 1
         # rank 0 prints the CSV rows in tune order (rtl_power.c:1047-1050) -- through the product's csv writer
         libc = C.CDLL(None)
         libc.fopen.restype = C.c_void_p

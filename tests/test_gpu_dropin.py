@@ -25,7 +25,7 @@ def fresh_demod(**kw):
     d.post_downsample = kw.get("post_downsample", 1)
     d.dc_block_raw = kw.get("dc_block_raw", 0)
     d.rdc_block_const = kw.get("rdc_block_const", 9)
-    d.output_scale = 1
+    d.output_scale = kw.get("output_scale", 1)
     d.squelch_level = kw.get("squelch_level", 0)
     d.squelch_hits = 11
     d.dc_block_audio = kw.get("dc_block_audio", 0)
@@ -106,8 +106,23 @@ def test_scan_and_csv_dropin(rng, flags, window, tmp_path):
             O.rxo_power_tune(C.byref(cfg), ptr16(np.ascontiguousarray(data[t])), ptr16(work), ptr64(want_avg[t]), C.byref(smp))
             want_samples[t] = smp.value
         R.check(L.rxgpu_scan(arr, tunes, wc.ctypes.data, sw.ctypes.data, *flags))
+        if p == 0:
+            # the sums stay on the device until somebody asks: the struct still shows what the caller left there
+            assert not any(a.any() for a in avgs) and all(arr[t].samples == 0 for t in range(tunes))
+            continue
+        syncs = L.rxgpu_scan_syncs()
+        R.check(L.rxgpu_scan_sync(arr, tunes))                # both sweeps in one download
+        assert L.rxgpu_scan_syncs() == syncs + 1
         for t in range(tunes):
             assert np.array_equal(avgs[t], want_avg[t]) and arr[t].samples == want_samples[t]
+    # a third sweep is brought home by rxgpu_csv_dbm itself (below); the caller's partial sums are added to, not replaced
+    data = sig_noise(tunes * plan.buf_len, seed=52, amp=2500).reshape(tunes, plan.buf_len)
+    for t in range(tunes):
+        bufs[t][:] = data[t]
+        smp = C.c_int(int(want_samples[t]))
+        O.rxo_power_tune(C.byref(cfg), ptr16(np.ascontiguousarray(data[t])), ptr16(work), ptr64(want_avg[t]), C.byref(smp))
+        want_samples[t] = smp.value
+    R.check(L.rxgpu_scan(arr, tunes, wc.ctypes.data, sw.ctypes.data, *flags))
     libc = C.CDLL(None)
     libc.fopen.restype = C.c_void_p
     libc.fclose.argtypes = [C.c_void_p]
@@ -159,3 +174,68 @@ def test_dropin_handoff_stays_on_the_device_unless_invalidated():
             assert d.lp_len == lp_len.value and np.array_equal(np.ctypeslib.as_array(d.lowpassed)[:d.lp_len], lp[:lp_len.value])
         if edit:
             R.check(L.rxgpu_dropin_unpin(C.addressof(d), C.addressof(s)))
+
+
+def _same_state(d, r, L, check_result0):
+    n = r.result_len
+    assert d.result_len == n and d.lp_len == r.lp_len
+    assert np.array_equal(np.ctypeslib.as_array(d.result)[:n], np.ctypeslib.as_array(r.result)[:n])
+    assert np.array_equal(np.ctypeslib.as_array(d.lowpassed)[:d.lp_len], np.ctypeslib.as_array(r.lowpassed)[:r.lp_len])
+    if check_result0:
+        assert d.result[0] == r.result[0]
+    for f in ("now_r", "now_j", "prev_index", "pre_r", "pre_j", "now_lpr", "prev_lpr_index", "squelch_hits", "dc_avg", "dc_avgI", "dc_avgQ"):
+        assert getattr(d, f) == getattr(r, f), f
+    assert bytes(d.lp_i_hist) == bytes(r.lp_i_hist) and bytes(d.lp_q_hist) == bytes(r.lp_q_hist)
+    assert bytes(d.droop_i_hist) == bytes(r.droop_i_hist) and bytes(d.droop_q_hist) == bytes(r.droop_q_hist)
+
+
+ANY_LENGTH_PARAMS = [
+    dict(downsample=6), dict(downsample=118), dict(downsample=2000, custom_atan=0), dict(downsample=118, squelch_level=40),
+    dict(downsample=9, mode=1, deemph=0), dict(downsample=300, mode=4),
+    dict(downsample_passes=3), dict(downsample_passes=3, comp_fir_size=9), dict(downsample_passes=7), dict(downsample_passes=7, squelch_level=50),
+    dict(downsample_passes=4, mode=1, output_scale=2, deemph=0), dict(downsample_passes=5, mode=4), dict(downsample_passes=10, comp_fir_size=9),
+    dict(downsample_passes=2, dc_block_raw=1, rdc_block_const=3),
+]
+
+
+@pytest.mark.parametrize("kw", ANY_LENGTH_PARAMS)
+def test_dropin_takes_every_block_length_the_reference_takes(kw):
+    """readStream may return ANY element count (rtl_fm.c:894-899): the drop-in, call after call with a different length -- primes,
+    two samples, reads shorter than the decimation, an empty read -- against the reference ITSELF (oracle/_ref: its own
+    rtlsdr_callback + full_demod on its own struct), including the shapes where the C reads pre_r/pre_j from in front of
+    lowpassed[] (the tail of d->thread: both structs carry the same value there) and where a -F block leaves an odd lp_len."""
+    from support import have_ref, ref_fm, ref_fm_reset
+    if not have_ref():
+        pytest.skip("oracle/_ref not built")
+    L = R.lib()
+    R.check(L.rxgpu_init(0))
+    F = ref_fm()
+    r, rs = ref_fm_reset(F, **kw)
+    d = fresh_demod(**kw)
+    d.mode_demod = r.mode_demod
+    L.rxgpu_set_demod_functions(F.ref_fm_fn(0), F.ref_fm_fn(2), F.ref_fm_fn(3), F.ref_fm_fn(4), F.ref_fm_fn(1))
+    d.thread = r.thread = 0x00007F3A5C1E9700
+    s = DongleState()
+    s.demod_target = C.pointer(d)
+    L.rxgpu_deemph_state(C.addressof(d)).contents.value = 0
+    rng = np.random.default_rng(abs(hash(str(sorted(kw.items())))) % (1 << 31))
+    lens = [2 * 4099, 2 * 97, 2, 2 * 33, 0, 2 * 7, 2 * 65537, 2 * 131071, 2 * 1, 2 * 129, 2 * 100000, 4, 6, 2 * 1009, 2 * 131072, 2 * 12]
+    lens += [2 * int(v) for v in rng.integers(1, 3000, 6)]
+    if kw.get("dc_block_raw"):
+        lens = [v for v in lens if v]                     # the reference divides by zero on an empty read with -E rdc (rtl_fm.c:711)
+    iq = sig_fm(sum(lens) // 2 + 8, seed=77)
+    pos = 0
+    try:
+        for ln in lens:
+            blk = np.ascontiguousarray(iq[pos:pos + max(ln, 2)])
+            pos += ln
+            a, b = blk.copy(), blk.copy()
+            F.ref_fm_callback(ptr16(a), C.c_uint32(ln), C.byref(rs))
+            L.rxgpu_callback(b.ctypes.data, ln, C.addressof(s))
+            assert d.lp_len == r.lp_len == ln
+            assert np.array_equal(np.ctypeslib.as_array(d.lowpassed)[:ln], np.ctypeslib.as_array(r.lowpassed)[:ln])
+            F.full_demod(C.byref(r))
+            L.rxgpu_full_demod(C.addressof(d))
+            _same_state(d, r, L, kw.get("mode", 0) == 0 and r.lp_len < 2)
+    finally:
+        L.rxgpu_set_demod_functions(None, None, None, None, None)

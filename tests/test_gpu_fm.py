@@ -22,10 +22,10 @@ def _signals(n_int16):
     }
 
 
-def _check(iq, block_len, n_runs=1, pipelined=False, **params):
+def _check(iq, block_len, n_runs=1, pipelined=False, carry_in=None, **params):
     from gpu_support import gpu_fm_stream, carry_tuple, carry_from_oracle_state
     want, want_lens, st = oracle_fm_stream(iq, block_len, **params)
-    got, got_lens, carry, _ = gpu_fm_stream(iq, block_len, n_runs=n_runs, pipelined=pipelined, **params)
+    got, got_lens, carry, _ = gpu_fm_stream(iq, block_len, n_runs=n_runs, pipelined=pipelined, carry=carry_in, **params)
     assert len(got) == len(want)
     bad = np.nonzero(got != want)[0]
     assert bad.size == 0, "first mismatch at %d: got %d want %d (%d bad of %d)" % (
@@ -354,13 +354,18 @@ def test_error_codes():
     for args, code in [((d_iq.data_ptr(), 0, 16384, d_out.data_ptr(), 16384), -2),        # no blocks: EINVAL
                        ((d_iq.data_ptr(), 8, 16384, d_out.data_ptr(), 16384), -5),        # more than the stream holds: ECAPACITY
                        ((d_iq.data_ptr(), 4, 16384, d_out.data_ptr(), 10), -5),           # output too small: ECAPACITY
-                       ((d_iq.data_ptr(), 4, 8, d_out.data_ptr(), 16384), -3)]:           # block shorter than the boxcar: EUNSUPPORTED
+                       ((d_iq.data_ptr(), 4, 8, d_out.data_ptr(), 16384), -3),           # blocks shorter than the boxcar: EUNSUPPORTED (drop-in only)
+                       ((d_iq.data_ptr(), 4, 0, d_out.data_ptr(), 16384), -2),           # empty blocks: EINVAL (drop-in only)
+                       ((d_iq.data_ptr(), 4, 7, d_out.data_ptr(), 16384), -2)]:          # an odd int16 count: EINVAL
         n = __import__("ctypes").c_size_t(0)
         assert L.rxgpu_fm_stream_run(s._h, *args, __import__("ctypes").byref(n), None) == code, L.rxgpu_last_error()
     s.close()
     s = R.FmStream(R.FmParams.wbfm(downsample_passes=5), 4, 16384)
     n = __import__("ctypes").c_size_t(0)
-    assert L.rxgpu_fm_stream_run(s._h, d_iq.data_ptr(), 4, 2 * 1000, d_out.data_ptr(), 16384, __import__("ctypes").byref(n), None) == -3
+    # a -F block that is not a multiple of 2^passes is taken (the literal per-block path) ...
+    assert L.rxgpu_fm_stream_run(s._h, d_iq.data_ptr(), 4, 2 * 1000, d_out.data_ptr(), 16384, __import__("ctypes").byref(n), None) == 0
+    # ... unless it leaves fewer than two int16 after the cascade (the reference then reads in front of lowpassed[])
+    assert L.rxgpu_fm_stream_run(s._h, d_iq.data_ptr(), 4, 2 * 20, d_out.data_ptr(), 16384, __import__("ctypes").byref(n), None) == -3
     s.close()
     with pytest.raises(R.RxGpuError):
         R.FmStream(R.FmParams.wbfm(custom_atan=7), 4, 16384)
@@ -541,3 +546,40 @@ def test_tiled_audio_path_multi_level_tree(monkeypatch):
     monkeypatch.setenv("RXGPU_DEEMPH_TOPCAP", "3")
     iq = sig_fm(64 * 16384 // 2, seed=66)
     _check(iq, 16384, n_runs=2, pipelined=True, downsample=4)
+
+
+@pytest.mark.parametrize("params", [
+    dict(downsample_passes=1), dict(downsample_passes=3), dict(downsample_passes=3, comp_fir_size=9), dict(downsample_passes=7),
+    dict(downsample_passes=4, mode=1, output_scale=2), dict(downsample_passes=2, mode=4), dict(downsample_passes=5, mode=2, deemph=0),
+    dict(downsample_passes=3, squelch_level=40), dict(downsample_passes=2, comp_fir_size=9, squelch_level=3000, dc_block_audio=1),
+    dict(downsample_passes=3, custom_atan=0), dict(downsample_passes=4, custom_atan=2, offset_tuning=1), dict(downsample_passes=3, dc_block_raw=1),
+])
+@pytest.mark.parametrize("n", [97, 1009, 4099, 65537, 8190, 2048 + 4, 12])
+def test_fifth_order_on_ragged_blocks(params, n):
+    """-F on callback blocks whose sample count is not a multiple of 2^passes (readStream may return any count, rtl_fm.c:894-899):
+    the literal per-block kernels follow every odd `lp_len >> i` of rtl_fm.c:764-769 -- different I and Q output counts, an odd
+    final lp_len, pre_r/pre_j from lp[lp_len-2], lp[lp_len-1] -- through several blocks and two chained runs"""
+    p = params["downsample_passes"]
+    if ((2 * n) >> p) < 2:
+        pytest.skip("the reference reads in front of lowpassed[] here: drop-in only (test_gpu_dropin.py)")
+    block_len = 2 * n
+    iq = sig_fm(5 * n, seed=1234 + n) if n % 2 else sig_noise(5 * block_len, seed=n, amp=9000)
+    # squelch_hits starts at demod_init's 11 (rtl_fm.c:1091) on both sides
+    carry, st = _check(iq, block_len, n_runs=2, carry_in=R.FmCarry(squelch_hits=11) if params.get("squelch_level") else None, **params)
+    assert bytes(carry.lp_i_hist) == bytes(st.lp_i_hist) and bytes(carry.lp_q_hist) == bytes(st.lp_q_hist)
+    assert bytes(carry.droop_i_hist) == bytes(st.droop_i_hist) and bytes(carry.droop_q_hist) == bytes(st.droop_q_hist)
+    assert carry.dc_avg == st.dc_avg and (not params.get("squelch_level") or carry.squelch_hits == st.squelch_hits)
+
+
+def test_stream_refuses_blocks_only_the_dropin_can_reproduce():
+    """a block that leaves fewer than two int16 after the cascade, or low_pass blocks shorter than the decimation: the reference then
+    reads pre_r/pre_j from in front of lowpassed[] -- struct memory the batched stream does not have"""
+    from gpu_support import torch_cuda
+    torch = torch_cuda()
+    d_iq = torch.zeros(4096, dtype=torch.int16, device="cuda")
+    d_out = torch.zeros(4096, dtype=torch.int16, device="cuda")
+    for kw, block_len, n_blocks in ((dict(downsample_passes=7), 2 * 100, 2), (dict(downsample=118), 2 * 50, 4)):
+        s = R.FmStream(R.FmParams.wbfm(**kw), n_blocks, block_len)
+        with pytest.raises(R.RxGpuError, match="lowpassed"):
+            s.run(d_iq.data_ptr(), n_blocks, block_len, d_out.data_ptr(), d_out.numel())
+        s.close()

@@ -107,12 +107,13 @@ def test_scan_linearity_in_passes_full_geometry():
     assert np.array_equal(a1[:3], want)
 
 
-def _run_rccl_world(world, tmp_path):
+def _run_rccl_world(world, tmp_path, env=None):
     import os
     import subprocess
     import sys
     worker = os.path.join(os.path.dirname(__file__), "rccl_worker.py")
-    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              env=dict(os.environ, **(env or {})))
              for r in range(world)]
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
@@ -135,6 +136,70 @@ def test_sharded_sweep_through_librxgpu_rccl_multi_gpu(world, tmp_path):
     if torch.cuda.device_count() < world:
         pytest.skip("needs %d GPUs, %d visible" % (world, torch.cuda.device_count()))
     assert ("world=%d" % world) in _run_rccl_world(world, tmp_path)
+
+
+def _fake_rccl():
+    """tests/fake_rccl.c built on demand: a file-based transport that lets several ranks share the one GPU of the test box"""
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    so, src = os.path.join(here, "libfake_rccl.so"), os.path.join(here, "fake_rccl.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-shared", "-fPIC", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", src, "-o", so,
+                               "-L/opt/rocm/lib", "-lamdhip64"])
+    return so
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_sweep_multi_rank_on_one_gpu(world, tmp_path):
+    """The product's multi-rank path with 2, 4, 8 PROCESSES on this box's one GPU: every rank creates its communicator through
+    rxgpu_comm_create, scans its contiguous tune range with rxgpu_power_scan_run_sharded (padding rows zeroed, grouped gather),
+    the root merges the rows and prints the CSV == the oracle's single-process sweep.  RCCL itself refuses two ranks per device,
+    so $RXGPU_RCCL_LIB points librxgpu at tests/fake_rccl.c (a file transport); everything above the transport is the product."""
+    env = {"RXGPU_RCCL_LIB": _fake_rccl(), "FAKE_RCCL_DIR": str(tmp_path), "RCCL_WORKER_ONE_GPU": "1", "RCCL_WORKER_DIRTY_PADDING": "1"}
+    ok = _run_rccl_world(world, tmp_path, env)
+    assert ("world=%d" % world) in ok and "libfake_rccl" in ok
+
+
+def test_comm_rejects_a_rank_the_communicator_does_not_report(tmp_path):
+    """rxgpu_comm_adopt checks rank/world against ncclCommUserRank/ncclCommCount"""
+    import ctypes as C
+    import os
+    env_before = os.environ.get("RXGPU_RCCL_LIB")
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import rx_tools_amd as R\n"
+        "from rx_tools_amd import shard\n"
+        "L = R.lib(); R.check(L.rxgpu_init(0))\n"
+        "c = shard.Comm(shard.Comm.unique_id(), 0, 1)\n"
+        "assert c.observed == (0, 1)\n"
+        "fk = C.CDLL(os.environ['RXGPU_RCCL_LIB'])\n"
+        "h = C.c_void_p()\n"
+        "# the same ncclComm_t adopted under a wrong world size must be refused\n"
+        "inner = C.cast(c._h, C.POINTER(C.c_void_p))[0]\n"
+        "rc = L.rxgpu_comm_adopt(C.byref(h), inner, 0, 2)\n"
+        "assert rc == -2, rc\n"
+        "rc = L.rxgpu_comm_adopt(C.byref(h), inner, 0, 1)\n"
+        "assert rc == 0, rc\n"
+        "L.rxgpu_comm_destroy(h)\n"
+        "print('adopt-ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RXGPU_RCCL_LIB=_fake_rccl(), FAKE_RCCL_DIR=str(tmp_path)),
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert out.returncode == 0 and b"adopt-ok" in out.stdout, out.stdout.decode()[-2000:]
+    assert os.environ.get("RXGPU_RCCL_LIB") == env_before
+
+
+def test_gather_of_no_tunes_is_a_noop():
+    L = R.lib()
+    R.check(L.rxgpu_init(0))
+    R.check(L.rxgpu_power_gather(None, None, None, 0, 4096, None, None, 0))
+    from rx_tools_amd import shard
+    first, count, per = shard.tune_range(0, 4, 0)
+    assert (first, count, per) == (0, 0, 0)
 
 
 def test_gather_without_a_communicator_is_a_copy():

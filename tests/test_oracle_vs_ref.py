@@ -125,3 +125,61 @@ def test_power_scan_matches_reference(rng, crop, window, flags, amp, passes, cap
             O.rxo_power_tune(C.byref(cfg), ptr16(np.ascontiguousarray(d3[p, i])), ptr16(work), ptr64(avg[i]), C.byref(s))
             samples[i] = s.value
     assert np.array_equal(avg, ref_avg) and list(samples) == ref_samples
+
+
+RAGGED_PARAMS = [
+    dict(downsample=6), dict(downsample=118), dict(downsample=7, custom_atan=0, deemph=0, rate_out2=-1),
+    dict(downsample_passes=1), dict(downsample_passes=3), dict(downsample_passes=3, comp_fir_size=9), dict(downsample_passes=7),
+    dict(downsample_passes=4, mode=1, output_scale=2), dict(downsample_passes=2, mode=4), dict(downsample_passes=5, mode=2, deemph=0),
+    dict(downsample_passes=3, squelch_level=40), dict(downsample_passes=2, comp_fir_size=9, squelch_level=3000, dc_block_audio=1),
+    dict(downsample=6, squelch_level=60, mode=3),
+]
+
+
+def ragged_lengths(seed, count=10):
+    """int16 counts of callback blocks: readStream may return any element count (rtl_fm.c:894-899)"""
+    rng = np.random.default_rng(seed)
+    fixed = [2 * p for p in (97, 251, 1009, 4099, 8191, 65537, 131071)]
+    return fixed + [2 * int(v) for v in rng.integers(300, 131072, count)]
+
+
+def benign(params, n, prev_index):
+    """does a block of n samples leave every read of the reference inside lowpassed[] (no lp[-1], lp[-2])?"""
+    p = params.get("downsample_passes", 0)
+    if p:
+        return ((2 * n) >> p) >= 2
+    return (prev_index + n) // params["downsample"] >= 1
+
+
+@pytest.mark.parametrize("params", RAGGED_PARAMS)
+def test_fm_ragged_blocks_match_reference(params):
+    """one stream cut into callback blocks of arbitrary even lengths, a different one every call: the restatement follows the
+    reference through every odd `lp_len >> i` of the -F cascade (I and Q yielding different counts, an odd final lp_len,
+    pre_r/pre_j taken from lp[lp_len-2], lp[lp_len-1]) and through low_pass windows that straddle several short blocks"""
+    from rx_tools_amd.structs import DemodState
+    from support import ref_fm_reset, oracle_fm_state
+    L, O = ref_fm(), oracle()
+    lens = ragged_lengths(11) + [2 * v for v in (20, 33, 64, 100, 7, 129)]
+    iq = sig_fm(sum(lens) // 2, seed=5)
+    d, s = ref_fm_reset(L, **params)
+    st = oracle_fm_state(**params)
+    pos = 0
+    lp = np.zeros(262144, np.int16)
+    out = np.zeros(262144, np.int16)
+    for ln in lens:
+        if not benign(params, ln // 2, st.prev_index):
+            continue
+        blk = np.ascontiguousarray(iq[pos:pos + ln])
+        pos += ln
+        buf = blk.copy()
+        L.ref_fm_callback(ptr16(buf), C.c_uint32(ln), C.byref(s))
+        L.full_demod(C.byref(d))
+        lp_len = C.c_int(0)
+        n = O.rxo_fm_block(C.byref(st), ptr16(blk.copy()), ln, ptr16(lp), C.byref(lp_len), ptr16(out))
+        assert n == d.result_len and lp_len.value == d.lp_len, (ln, params)
+        assert np.array_equal(np.ctypeslib.as_array(d.result)[:n], out[:n]), (ln, params)
+        assert np.array_equal(np.ctypeslib.as_array(d.lowpassed)[:d.lp_len], lp[:lp_len.value]), (ln, params)
+        assert (d.now_r, d.now_j, d.prev_index, d.pre_r, d.pre_j, d.now_lpr, d.prev_lpr_index, d.squelch_hits, d.dc_avg) == \
+            (st.now_r, st.now_j, st.prev_index, st.pre_r, st.pre_j, st.now_lpr, st.prev_lpr_index, st.squelch_hits, st.dc_avg), (ln, params)
+        assert bytes(d.lp_i_hist) == bytes(st.lp_i_hist) and bytes(d.lp_q_hist) == bytes(st.lp_q_hist)
+        assert bytes(d.droop_i_hist) == bytes(st.droop_i_hist) and bytes(d.droop_q_hist) == bytes(st.droop_q_hist)
