@@ -289,7 +289,7 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 			const int fuse = params->downsample_passes < 3 ? params->downsample_passes : 3;
 			for (int i = 0; i < 2; i++) {
 				DMALLOC(s->cas_a[i], ((s->max_T >> fuse) + max_blocks) * 4);
-				DMALLOC(s->seams_a[i], (max_blocks + 1) * 15 * 4);
+				DMALLOC(s->seams_a[i], (max_blocks + 1) * 20 * 4);             /* up to four levels of five history samples per block */
 			}
 			if (hipEventCreateWithFlags(&s->ev_up, hipEventDisableTiming) != hipSuccess ||
 			    hipEventCreateWithFlags(&s->ev_seam[0], hipEventDisableTiming) != hipSuccess ||
@@ -632,7 +632,9 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 	RX_HIP(hipMemsetAsync(s->flag_cnt_dev + db, 0, sizeof(int), sb));
 	/* -F on the raw capture: the first fused group of fifth_order passes reads 8/9 of all the bytes of the run; like the
 	 * boxcar decimator it goes on stream A, so that it overlaps the later passes and the audio stages of the run before */
-	const int fuse_a = (g->passes && !g->literal && !prescaled && (g->n % RXK_FIFTH_TILE) == 0 && s->cas_a[0]) ? (g->passes < 3 ? g->passes : 3) : 0;
+	/* four passes in that group where the cascade has them (the next group then reads 1/16 of the capture, not 1/8); $RXGPU_FUSE_A=3 keeps three */
+	const int fuse_a_max = (getenv("RXGPU_FUSE_A") && atoi(getenv("RXGPU_FUSE_A")) == 3) ? 3 : 4;
+	const int fuse_a = (g->passes && !g->literal && !prescaled && (g->n % RXK_FIFTH_TILE) == 0 && s->cas_a[0]) ? (g->passes < fuse_a_max ? g->passes : fuse_a_max) : 0;
 	const int fresh = !s->chained;
 
 	if (!s->chained) {
@@ -805,7 +807,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 		/* further fused groups on the decimated stream while whole tiles are left (3 passes, or 1 so that the ping-pong buffers
 		 * stay distinct): passes 4-6 at 1/8 rate, the 7th of ds = 128 at 1/64 -- the one-thread-per-output kernel below took as
 		 * long for that last pass as the three before it */
-		for (int grp = 1; fuse_a == 3 && grp < 4 && first_pass < passes && n_in >= RXK_FIFTH_TILE && (n_in % RXK_FIFTH_TILE) == 0; grp++) {
+		for (int grp = 1; fuse_a >= 3 && grp < 4 && first_pass < passes && n_in >= RXK_FIFTH_TILE && (n_in % RXK_FIFTH_TILE) == 0; grp++) {
 			const int fuse2 = passes - first_pass >= 3 ? 3 : 1;
 			if (first_pass + fuse2 > 7)                      /* the kernel's 32-bit sums assume inputs below 2^14: 128 * 2^6 at most */
 				break;
