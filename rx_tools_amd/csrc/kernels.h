@@ -268,8 +268,9 @@ int rxk_fm_post_downsample(void *stream, const int16_t *in, unsigned long long n
 
 /* fix_fft for 2^15 < N <= 2^21 (rtl_power.c:485): the same network on a scratch copy in HBM, one launch per stage.
  * scratch: cap_blocks * 2^bin_e dwords; dc: 2 ints per (pass, tune) */
-/* bin_e 14 and 15, eff_len a multiple of 2^(bin_e+1): the register-blocked transform as two launches (first radix-16 pass, then the 16
- * independent sub-transforms), same scratch / dc workspaces as rxk_pw_fft_big; returns < 0 if the geometry does not fit */
+/* bin_e 14 .. 21, eff_len a multiple of 2^(bin_e+1): the register-blocked transform as two to four launches (radix-16 passes through a
+ * scratch copy in HBM until a sub-transform fits one workgroup, then the independent sub-transforms), same scratch / dc workspaces as
+ * rxk_pw_fft_big; returns < 0 if the geometry does not fit */
 int rxk_pw_fft_mid(void *stream, const int16_t *in, size_t tune_stride, size_t pass_stride, int passes, int tunes,
                    int bin_e, int eff_len, const int *window, const uint32_t *twiddle, int peak_hold,
                    uint32_t *scratch, size_t cap_blocks, int *dc, long long *avg, long long *partial, size_t partial_cap);

@@ -646,7 +646,7 @@ __global__ void k_pwb_acc(const uint32_t *__restrict__ scratch, int tunes, int n
 	else atomicAdd((unsigned long long *)a, (unsigned long long)pw);
 }
 
-// ------------------------------------------------------------------ N = 2^14, 2^15: the register-blocked transform in two launches
+// ------------------------------------------------------------------ N = 2^14 .. 2^21: the register-blocked transform in two to four launches
 //
 // N/16 threads per transform is 1024 or 2048: one workgroup would have 128 VGPRs per lane (the single-kernel build spilled and lost to
 // the LDS radix-2 kernel) or does not exist.  But after the FIRST radix-16 pass -- stages 0-3 on the top four index bits, which a thread
@@ -687,37 +687,77 @@ __global__ __launch_bounds__(256) void k_pwm_head(const int16_t *__restrict__ in
 		dst[col + r * TPF] = v[r];
 }
 
-// grid: x = (tune * nbpt + blk) * (16 / SPW) + sub-block group, y = group of passes; the launch's passes are p0 .. p0 + np
+// A further radix-16 pass through HBM for N > 2^16 (stages 4 PASS .. 4 PASS + 3 on the scratch copy, in place): after pass 0 the
+// transform is 16 independent sub-transforms of N/16 points, after this one 256 of N/256, and so on until a sub-transform's N/16^H
+// points fit the 256 threads of a workgroup (<= 4096 points: H = 1 up to 2^16, 2 up to 2^20, 3 for 2^21 -- the reference's limit,
+// rtl_power.c:485).  A thread takes the 16 values of the pass's index field, 2^f(PASS) apart: consecutive threads, consecutive dwords.
+template <int M, int PASS>
+__global__ __launch_bounds__(256) void k_pwm_head_mid(uint32_t *__restrict__ scratch, size_t nq, const uint32_t *__restrict__ twiddle)
+{
+	typedef fft_geom<M> G;
+	constexpr int TPF = (1 << M) / 16, F = G::f(PASS);
+	const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const size_t ql = gid / TPF;
+	if (ql >= nq)
+		return;
+	const unsigned tq = (unsigned)(gid % TPF);
+	uint32_t *x = scratch + (ql << M) + ((size_t)(tq >> F) << (F + 4)) + (tq & ((1u << F) - 1u));
+	uint32_t v[16];
+#pragma unroll
+	for (int r = 0; r < 16; r++)
+		v[r] = x[(size_t)r << F];
+	fft_pass<M, PASS>(v, twiddle, tq);
+#pragma unroll
+	for (int r = 0; r < 16; r++)
+		x[(size_t)r << F] = v[r];
+}
+
+// the passes H .. P-1 of one thread's 16 values, an LDS transpose between two of them
+template <int M, int PASS>
+__device__ __forceinline__ void pwm_tail_passes(uint32_t (&v)[16], uint32_t *lds_t, const uint32_t *__restrict__ tw, unsigned tq, bool first)
+{
+	typedef fft_geom<M> G;
+	if (!first)
+		__syncthreads();                                             // the transpose area: the reads of the pass before
+	fft_pass<M, PASS>(v, tw, tq);
+	if constexpr (PASS + 1 < G::P) {
+		fft_exchange<M, PASS>(v, lds_t, tq);
+		pwm_tail_passes<M, PASS + 1>(v, lds_t, tw, tq, false);
+	}
+}
+
+// grid: x = (tune * nbpt + blk) * WPB + workgroup of the block (WPB = N/4096 workgroups of 256 threads per transform), y = group of
+// passes; the launch's passes are p0 .. p0 + np.  H = radix-16 passes already done through HBM (k_pwm_head, k_pwm_head_mid).
 // partial != NULL: the accumulators go, without atomics, to partial[((group * tunes + tune) * nbpt + blk) * N + bin] and k_pwm_reduce folds
 // them into avg -- with one tune every pass of a sweep lands on the same N bins, and int64 atomics on a few thousand addresses were
 // three quarters of this kernel's time
-template <int M, bool PEAK>
+template <int M, bool PEAK, int H = 1>
 __global__ __launch_bounds__(256) void k_pwm_tail(const uint32_t *__restrict__ scratch, int tunes, int nbpt, int p0, int np, int ppg,
                                                  const uint32_t *__restrict__ twiddle, i64 *__restrict__ avg, i64 *__restrict__ partial)
 {
 	typedef fft_geom<M> G;
-	constexpr int N = 1 << M, TPS = N / 256, SPW = 256 / TPS;       // threads per sub-transform, sub-transforms per workgroup
+	constexpr int N = 1 << M, WPB = N / 4096, F = G::f(H);
+	static_assert(M - 4 * H <= 12 && H < G::P, "a sub-transform has to fit the workgroup");
 	__shared__ __attribute__((aligned(16))) uint32_t lds[256 * G::ROW];
 	const int tid = threadIdx.x;
-	const unsigned sg = blockIdx.x % (16 / SPW), tb = blockIdx.x / (16 / SPW);   // tb = tune * nbpt + blk
+	const unsigned sg = blockIdx.x % WPB, tb = blockIdx.x / WPB;         // tb = tune * nbpt + blk
 	const unsigned tune = tb / (unsigned)nbpt, blk = tb - tune * (unsigned)nbpt;
-	const unsigned tq = sg * 256u + (unsigned)tid;                   // this thread's index in the whole transform's N/16 (behind pass 0)
-	const unsigned b = tq / TPS, l = tq % TPS;                       // sub-transform (the top four index bits), lane in it
+	const unsigned tq = sg * 256u + (unsigned)tid;                   // this thread's index in the whole transform's N/16
 	uint32_t *lds_t = lds - (size_t)(sg * 256u) * G::ROW;            // fft_exchange addresses rows by tq: this workgroup's are sg*256 ..
 	i64 acc[16];
 #pragma unroll
 	for (int r = 0; r < 16; r++)
 		acc[r] = 0;
 	const int pb = blockIdx.y * ppg, pe = min(np, pb + ppg);
-	// block index inside the launch's scratch: ((pass * tunes + tune) * nbpt + blk); a thread's 16 values are n = b * N/16 + x * TPS + l,
-	// the layout behind the first transpose.  The next pass's values are on their way while this one is transformed.
+	// block index inside the launch's scratch: ((pass * tunes + tune) * nbpt + blk); a thread's 16 values are the index field of pass H,
+	// 2^F apart.  The next pass's values are on their way while this one is transformed.
 	const size_t pass_step = ((size_t)tunes * (size_t)nbpt) << M;
-	const uint32_t *src = scratch + ((((size_t)pb * tunes + tune) * (size_t)nbpt + blk) << M) + (size_t)b * (N / 16) + l;
+	const uint32_t *src = scratch + ((((size_t)pb * tunes + tune) * (size_t)nbpt + blk) << M) + ((size_t)(tq >> F) << (F + 4)) + (tq & ((1u << F) - 1u));
 	uint32_t nxt[16];
 	if (pb < pe) {
 #pragma unroll
 		for (int x = 0; x < 16; x++)
-			nxt[x] = src[x * TPS];
+			nxt[x] = src[(size_t)x << F];
 	}
 	for (int pl = pb; pl < pe; pl++) {
 		uint32_t v[16];
@@ -728,17 +768,10 @@ __global__ __launch_bounds__(256) void k_pwm_tail(const uint32_t *__restrict__ s
 		if (pl + 1 < pe) {
 #pragma unroll
 			for (int x = 0; x < 16; x++)
-				nxt[x] = src[x * TPS];
+				nxt[x] = src[(size_t)x << F];
 		}
 		__syncthreads();                                             // the previous transform's reads of the transpose area
-		fft_pass<M, 1>(v, twiddle, tq);
-		fft_exchange<M, 1>(v, lds_t, tq);
-		fft_pass<M, 2>(v, twiddle, tq);
-		if constexpr (G::P > 3) {
-			__syncthreads();
-			fft_exchange<M, 2>(v, lds_t, tq);
-			fft_pass<M, 3>(v, twiddle, tq);
-		}
+		pwm_tail_passes<M, H>(v, lds_t, twiddle, tq, true);
 #pragma unroll
 		for (int r = 0; r < 16; r++) {
 			const i64 pw = (i64)pw_norm(v[r]);
@@ -785,7 +818,7 @@ __global__ void k_pwm_reduce(const i64 *__restrict__ partial, int tunes, int nbp
 	else if (a) atomicAdd((unsigned long long *)&avg[gid], (unsigned long long)a);
 }
 
-// eff_len a multiple of 2^(bin_e+1), bin_e = 14 or 15; scratch: cap_blocks * 2^bin_e dwords; dc: 2 ints per (pass, tune)
+// eff_len a multiple of 2^(bin_e+1), bin_e = 14 .. 21; scratch: cap_blocks * 2^bin_e dwords; dc: 2 ints per (pass, tune)
 extern "C" int rxk_pw_fft_mid(void *stream, const int16_t *in, size_t tune_stride, size_t pass_stride, int passes, int tunes,
                               int bin_e, int eff_len, const int *window, const uint32_t *twiddle, int peak_hold,
                               uint32_t *scratch, size_t cap_blocks, int *dc, long long *avg, long long *partial, size_t partial_cap)
@@ -794,7 +827,7 @@ extern "C" int rxk_pw_fft_mid(void *stream, const int16_t *in, size_t tune_strid
 	const size_t n = (size_t)1 << bin_e;
 	const int nbpt = (int)((size_t)eff_len / (2 * n));
 	const size_t per_pass = (size_t)tunes * (size_t)nbpt;
-	if ((bin_e != 14 && bin_e != 15) || !nbpt || (size_t)eff_len % (2 * n) || cap_blocks < per_pass)
+	if (bin_e < 14 || bin_e > 21 || !nbpt || (size_t)eff_len % (2 * n) || cap_blocks < per_pass)
 		return -1;
 	const uint32_t *tw2 = twiddle + (n >> 1);                        // the doubled half of rxgpu_twiddle_table (bfly_pk)
 	hipLaunchKernelGGL(k_pwb_dc, dim3((unsigned)tunes, (unsigned)passes), dim3(256), 0, s, in, tune_stride, pass_stride, tunes, eff_len, dc);
@@ -804,19 +837,30 @@ extern "C" int rxk_pw_fft_mid(void *stream, const int16_t *in, size_t tune_strid
 		const size_t q0 = (size_t)p0 * per_pass, nq = (size_t)np * per_pass;
 		const unsigned g_head = (unsigned)((nq * (n / 16) + 255) / 256);
 		/* enough workgroups to fill the chip, few enough that the int64 accumulators amortise the atomics */
-		const unsigned wg_x = (unsigned)(per_pass * (bin_e == 14 ? 4 : 8));
+		const unsigned wg_x = (unsigned)(per_pass * (n / 4096));
 		int groups = (int)((RXK_PWM_TARGET_WG + wg_x - 1) / wg_x);
 		if (groups > np) groups = np;
 		const int ppg = (np + groups - 1) / groups;
 		groups = (np + ppg - 1) / ppg;
-#define GOM(MM) do { \
-		hipLaunchKernelGGL((k_pwm_head<MM>), dim3(g_head), dim3(256), 0, s, in, tune_stride, pass_stride, tunes, nbpt, window, tw2, dc, \
-		                   q0, nq, scratch); \
-		if (peak_hold) hipLaunchKernelGGL((k_pwm_tail<MM, true>), dim3(wg_x, (unsigned)groups), dim3(256), 0, s, scratch, tunes, nbpt, p0, np, ppg, tw2, (i64 *)avg, part); \
-		else hipLaunchKernelGGL((k_pwm_tail<MM, false>), dim3(wg_x, (unsigned)groups), dim3(256), 0, s, scratch, tunes, nbpt, p0, np, ppg, tw2, (i64 *)avg, part); } while (0)
 		i64 *part = (partial && (size_t)groups * per_pass * n <= partial_cap) ? (i64 *)partial : nullptr;
-		if (bin_e == 14) GOM(14); else GOM(15);
-#undef GOM
+#define HEAD0(MM) hipLaunchKernelGGL((k_pwm_head<MM>), dim3(g_head), dim3(256), 0, s, in, tune_stride, pass_stride, tunes, nbpt, window, tw2, dc, q0, nq, scratch)
+#define HEADN(MM, PP) hipLaunchKernelGGL((k_pwm_head_mid<MM, PP>), dim3(g_head), dim3(256), 0, s, scratch, nq, tw2)
+#define TAIL(MM, HH) do { \
+		if (peak_hold) hipLaunchKernelGGL((k_pwm_tail<MM, true, HH>), dim3(wg_x, (unsigned)groups), dim3(256), 0, s, scratch, tunes, nbpt, p0, np, ppg, tw2, (i64 *)avg, part); \
+		else hipLaunchKernelGGL((k_pwm_tail<MM, false, HH>), dim3(wg_x, (unsigned)groups), dim3(256), 0, s, scratch, tunes, nbpt, p0, np, ppg, tw2, (i64 *)avg, part); } while (0)
+		switch (bin_e) {
+		case 14: HEAD0(14); TAIL(14, 1); break;
+		case 15: HEAD0(15); TAIL(15, 1); break;
+		case 16: HEAD0(16); TAIL(16, 1); break;
+		case 17: HEAD0(17); HEADN(17, 1); TAIL(17, 2); break;
+		case 18: HEAD0(18); HEADN(18, 1); TAIL(18, 2); break;
+		case 19: HEAD0(19); HEADN(19, 1); TAIL(19, 2); break;
+		case 20: HEAD0(20); HEADN(20, 1); TAIL(20, 2); break;
+		default: HEAD0(21); HEADN(21, 1); HEADN(21, 2); TAIL(21, 3); break;
+		}
+#undef TAIL
+#undef HEADN
+#undef HEAD0
 		if (part)
 			hipLaunchKernelGGL(k_pwm_reduce, dim3((unsigned)((((size_t)tunes << bin_e) + 255) / 256), 16), dim3(256), 0, s, part, tunes, nbpt, groups, bin_e,
 			                   peak_hold, (i64 *)avg);

@@ -398,8 +398,11 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 		}
 	}
 	rxgpu_prof_begin("pw_fft");
-	/* N = 2^14, 2^15 with whole blocks: the register-blocked transform in two launches over a scratch copy (rxk_pw_fft_mid) */
-	const int mid = (p->bin_e == 14 || p->bin_e == 15) && eff_len % (2 << p->bin_e) == 0 && !getenv("RXGPU_FFT_GENERIC");
+	/* N = 2^14 .. 2^21 (the reference's limit) with whole blocks: the register-blocked transform in two to four launches over a scratch
+	 * copy (rxk_pw_fft_mid: radix-16 passes through HBM until a sub-transform fits a workgroup); $RXGPU_FFT_STAGEWISE keeps the
+	 * one-launch-per-radix-2-stage network for N > 2^15 */
+	const int mid = p->bin_e >= 14 && p->bin_e <= 21 && eff_len % (2 << p->bin_e) == 0 && !getenv("RXGPU_FFT_GENERIC") &&
+	                !(p->bin_e > 15 && getenv("RXGPU_FFT_STAGEWISE"));
 	if (p->bin_e > PW_LDS_BIN_E || mid) {
 		const size_t total = (size_t)passes * (size_t)tunes * (size_t)n_blocks, n = (size_t)1 << p->bin_e;
 		size_t want = ((size_t)1 << 28) / n;                /* up to 1 GiB of scratch */
@@ -421,8 +424,8 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 		}
 		if (mid) {
 			/* per-group partial spectra instead of atomics on avg[] (one tune: every pass lands on the same N bins) */
-			const size_t need = ((size_t)RXK_PWM_TARGET_WG / 4 + (size_t)tunes * (size_t)n_blocks) * n;
-			if (s->big_partial_cap < need && need * 8 <= ((size_t)1 << 29)) {
+			const size_t need = ((size_t)RXK_PWM_TARGET_WG / (n / 4096) + (size_t)tunes * (size_t)n_blocks) * n;
+			if (s->big_partial_cap < need && need * 8 <= ((size_t)1 << 30)) {
 				hipFree(s->big_partial);
 				s->big_partial = NULL; s->big_partial_cap = 0;
 				if (hipMalloc((void **)&s->big_partial, need * 8) == hipSuccess)

@@ -66,8 +66,13 @@ CASES = [
     ("100M:102.5M:600", 0.0, "blackman", (1, 0, 0), 32768, 2, 1),   # N=8192
     ("100M:102M:2k", 0.0, "bartlett", (1, 0, 0), 12000, 2, 1),      # N=1024
     ("100M:102M:1500", 0.0, "rectangle", (1, 0, 0), 12000, 2, 1),   # N=2048
-    ("100M:102M:40", 0.0, "hamming", (1, 0, 0), 20000, 2, 1),       # N=2^16: the global-memory network (N > 2^15)
+    # N > 2^15: radix-16 passes through a scratch copy in HBM until a sub-transform fits a workgroup (one head pass up to 2^16, two
+    # up to 2^20, three for 2^21), then the register-blocked tail
+    ("100M:102M:40", 0.0, "hamming", (1, 0, 0), 20000, 2, 1),       # N=2^16
+    ("100M:102M:20", 0.0, "blackman", (1, 0, 0), 32768, 3, 1),      # N=2^17, full scale, several passes (the per-group partial spectra)
     ("100M:102.8M:20", 0.0, "rectangle", (1, 0, 1), 32768, 2, 1),   # N=2^18, peak hold, full scale
+    ("100M:102.8M:10", 0.0, "hamming", (1, 0, 0), 12000, 2, 1),     # N=2^19
+    ("100M:102.8M:5", 0.0, "rectangle", (1, 0, 1), 32768, 2, 1),    # N=2^20, peak hold
     ("100M:102.8M:2", 0.0, "blackman", (1, 0, 0), 3000, 1, 1),      # N=2^21, the reference's largest
     ("100M:110M:1M", 0.0, "rectangle", (1, 0, 0), 5000, 3, 10),     # rms_power path
     ("100M:110M:1M", 0.0, "rectangle", (1, 0, 1), 5000, 3, 10),
@@ -191,6 +196,20 @@ def test_comm_rejects_a_rank_the_communicator_does_not_report(tmp_path):
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     assert out.returncode == 0 and b"adopt-ok" in out.stdout, out.stdout.decode()[-2000:]
     assert os.environ.get("RXGPU_RCCL_LIB") == env_before
+
+
+@pytest.mark.parametrize("rng", ["100M:102M:40", "100M:102.8M:20"])
+def test_large_transform_paths_agree(rng, monkeypatch):
+    """N = 2^16 / 2^18: the radix-16 path and the one-launch-per-stage network ($RXGPU_FFT_STAGEWISE) are two implementations of the
+    same fix_fft -- identical avg[] (and both equal to the oracle in test_scan_bit_exact)"""
+    plan = R.plan_range(rng, 0.0, 1)
+    n = 1 << plan.bin_e
+    wc, sw = R.window_coefs("hamming", n), R.sine_table(plan.bin_e)
+    data = sig_noise(3 * plan.buf_len, seed=5, amp=32768)
+    a, sa = gpu_scan(data, 3, 1, plan, wc, sw, 1, 0, 0)
+    monkeypatch.setenv("RXGPU_FFT_STAGEWISE", "1")
+    b, sb = gpu_scan(data, 3, 1, plan, wc, sw, 1, 0, 0)
+    assert np.array_equal(a, b) and np.array_equal(sa, sb)
 
 
 def test_gather_of_no_tunes_is_a_noop():
