@@ -44,9 +44,34 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 PCIE_PEAK_GBS = 63.0           # MI355X_MICROARCH.md: PCIe Gen5 x16
-# integer VALU issue: one wave64 instruction per quad-cycle per SIMD (the packed 16-bit / mad ops of the FFT butterfly each
-# count one SQ_ACTIVE_INST_VALU quad-cycle): 256 CUs x 4 SIMDs x 2.4 GHz / 4
+# integer VALU issue, nominal: one wave64 instruction per quad-cycle per SIMD: 256 CUs x 4 SIMDs x 2.4 GHz / 4.  The figure bench.py
+# reports is MEASURED where the tables exist: tools/valu_issue.hip (profiles/rNN_valu_issue.json) gives wave64 instructions per SIMD-cycle
+# for every opcode class (v_mad_i32_i16, the packed 16-bit ops, v_bfi, v_dot2, conversions, DPP: 0.24; v_add/sub/and/ashr, v_fma_f32: 0.40-0.46
+# at the reported clock), tools/kernel_mix.py the kernel's opcode mix; valu_ceiling() weights one with the other.
 VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4.0
+SIMDS, CLOCK_GHZ = 256 * 4, 2.4
+
+
+def valu_ceiling(kernel_substr):
+    """(G wave-instr/s the kernel's opcode mix can issue at most, source text) from the measured per-opcode rates; (nominal, None) without them"""
+    try:
+        issue = json.load(open(os.path.join(ROOT, "profiles", "r03_valu_issue.json")))["ops"]
+        mix = json.load(open(os.path.join(ROOT, "profiles", "r03_kernel_mix.json")))
+        ops = next(v for k, v in mix.items() if kernel_substr in k)
+    except (OSError, ValueError, KeyError, StopIteration):
+        return VALU_PEAK_GINSTR, None
+    alias = {"v_pk_mad_u16": "pk_mad_i16", "v_dot2c_i32_i16": "dot2_i32_i16", "v_fma_f32": "pk_fma_f32x", "v_mov_b32_dpp": "mov_dpp_wshr", "v_or_b32": "and_b32",
+             "v_xor_b32": "and_b32", "v_mov_b32": "and_b32", "v_lshrrev_b32": "lshlrev_b32", "v_add_co_u32": "add_u32", "v_addc_co_u32": "add_u32"}
+    slow = min(v["wall_w8"] for k, v in issue.items() if k in ("mad_i32_i16", "pk_add_u16", "bfi_b32"))     # the half-rate class
+    cycles = total = 0.0
+    for op, n in ops.items():
+        key = alias.get(op, op[2:])
+        rate = issue.get(key, {}).get("wall_w8", slow)
+        cycles += n / rate
+        total += n
+    rate = total / cycles
+    return rate * SIMDS * CLOCK_GHZ, ("profiles/r03_valu_issue.json (tools/valu_issue.hip: measured wave64 instructions per SIMD-cycle per opcode, 8 waves/SIMD) weighted with "
+                                      "profiles/r03_kernel_mix.json (the kernel's opcode counts): %.3f per SIMD-cycle x %d SIMDs x %.1f GHz" % (rate, SIMDS, CLOCK_GHZ))
 
 
 def cpu_model():
@@ -304,7 +329,7 @@ def main():
         return ms.value, n.value
 
     def pmc_summary():
-        for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+        for name in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
             try:
                 return json.load(open(os.path.join(ROOT, "profiles", name))), "profiles/" + name
             except (OSError, ValueError):
@@ -374,7 +399,7 @@ def main():
                 tv = time.perf_counter() - tv
                 L.rxgpu_prof_enable(0)
                 stages = {}
-                for nm in ("fm_decimate", "fm_fifth", "fm_droop", "fm_disc", "fm_deemph", "fm_resample"):
+                for nm in ("fm_decimate", "fm_fifth", "fm_fifth2", "fm_droop", "fm_disc", "fm_deemph", "fm_resample"):
                     sms, sn = prof(nm)
                     if sn:
                         stages[nm] = round(sms / sn * 1e3, 1)
@@ -481,10 +506,24 @@ def main():
         value = world * T * args.steps / dt / 1e6
         traffic, traffic_src = None, None
         pmc, pmc_src = pmc_summary()
+        # HBM bytes every chain moves per step (all its kernels: FETCH_SIZE x 2 + WRITE_SIZE from the counter passes in profiles/), beside the
+        # 4 B per input sample the metric counts: what the chains below the roofline spend their time on
+        chain_keys = {"-M wbfm default, downsample=6": "-M wbfm default, downsample=6",
+                      "BASELINE configs[0] geometry: -s 240000, downsample=5, deemph_a=19": "configs[0] geometry: ds=5, 240 kHz",
+                      "-F cascade, downsample_passes=7 (ds=128)": "-F cascade, 7 passes (ds=128)",
+                      "-F 9 cascade as -M wbfm -F 9 sets it: downsample_passes=3 (ds=8) + droop FIR": "-M wbfm -F 9: 3 passes + droop FIR"}
+        for label, v in variants.items():
+            c = pmc.get("_chains", {}).get(chain_keys.get(label, ""), None)
+            if c:
+                scale = (4.0 * T) / c["algorithmic_bytes_per_step"]
+                v["traffic"] = {"hbm_bytes_per_step": c["hbm_bytes_per_step"] * scale, "algorithmic_bytes_per_step": 4.0 * T,
+                                "traffic_over_algorithmic": c["traffic_over_algorithmic"],
+                                "achieved_GBs_of_traffic": c["hbm_bytes_per_step"] * scale / (v["ms_per_step"] * 1e-3) / 1e9,
+                                "source": pmc_src + " (per-kernel table: profiles/r03_pmc_chains.json)"}
         try:
             k = pmc_kernel(pmc, "k_fm_decimate<false, true, true", "hbm_bytes_per_launch")
             # measured on 2^30-sample launches (--blocks 8192); bytes scale with the launch
-            traffic = k["hbm_bytes_per_launch"] * (T / float(1 << 30))
+            traffic = k["hbm_bytes_per_launch"] * (T / float(k.get("launch_samples", 1 << 30)))
             traffic_src = pmc_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per gfx950 note)"
         except (KeyError, TypeError):
             pass
@@ -592,14 +631,17 @@ def main():
         bins_local = passes * mine * (plan.buf_len // 2)
         hbm_achieved = (4.0 * bins_local) / (ms / launches * 1e-3) / 1e9 if launches else 0.0
         pmc, pmc_src = pmc_summary()
-        valu = None
+        valu, pw_traffic = None, None
         try:
             k = pmc_kernel(pmc, "k_pw_fft4096", "SQ_INSTS_VALU")
-            # counted on a 512-pass, 599-tune launch; instructions scale with the bins of the launch
+            # counted on a 512-pass, 599-tune launch; instructions and bytes scale with the bins of the launch
             instr = k["SQ_INSTS_VALU"] * (bins_local / float(512 * 599 * 8192))
             valu = instr / (ms / launches * 1e-3) / 1e9
+            if k.get("hbm_bytes_per_launch"):
+                pw_traffic = k["hbm_bytes_per_launch"] * (bins_local / float(512 * 599 * 8192))
         except (KeyError, TypeError, ZeroDivisionError):
             pass
+        pw_peak, pw_peak_src = valu_ceiling("k_pw_fft4096")
         pw = {
             "metric": "rx_power FFT bins/s (scanner() chain, -f 24M:1.7G:1k geometry)",
             "value": bins_per_step_all * args.steps / dt / 1e6, "unit": "Mbins/s", "n_gpus": world,
@@ -613,12 +655,13 @@ def main():
                        "gather": gather_impl, "gather_us_per_step_rank0": (gms / gl * 1e3) if gl else None,
                        "gather_bytes_per_rank": per * n * 8 + per * 4},
             "roofline": {"bound": "valu", "kernel": "k_pw_fft4096 (P4-P8)",
-                         "achieved": valu, "peak": VALU_PEAK_GINSTR * 1e0, "unit": "G wave-instr/s",
-                         "frac": (valu / VALU_PEAK_GINSTR) if valu else None,
-                         "valu_source": (pmc_src + " (rocprofv3 --pmc SQ_INSTS_VALU per launch) / live launch time; peak = 1024 SIMDs x 2.4 GHz / 4 "
-                                         "(one wave64 integer instruction per quad-cycle)") if valu else None,
+                         "achieved": valu, "peak": pw_peak, "unit": "G wave-instr/s",
+                         "frac": (valu / pw_peak) if valu else None,
+                         "valu_source": (pmc_src + " (rocprofv3 --pmc SQ_INSTS_VALU per launch) / live launch time") if valu else None,
+                         "peak_source": pw_peak_src or "nominal: 1024 SIMDs x 2.4 GHz / 4 (one wave64 integer instruction per quad-cycle)",
+                         "nominal_peak": VALU_PEAK_GINSTR, "frac_of_nominal": (valu / VALU_PEAK_GINSTR) if valu else None,
                          "hbm_achieved": hbm_achieved, "hbm_peak": HBM_PEAK_GBS, "hbm_unit": "GB/s", "hbm_frac": hbm_achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_launch": 4 * bins_local,
+                         "traffic": pw_traffic, "algorithmic_bytes_per_launch": 4 * bins_local,
                          "avg_launch_ms": (ms / launches) if launches else None},
         }
         # the launch that was timed -- all passes, all tunes of this rank -- once more into zeroed integrators, against the
@@ -680,7 +723,8 @@ def main():
                     ("full-scale input, hamming window (every int16 wrap of the window product and the butterflies)", "24M:1.7G:1k", 1, "hamming", 32767, 0, passes),
                     ("-f 100M:100.1M:10 -F 9: N=16384, fifth_order x4 (ds=16) + droop FIR, one tune", "100M:100.1M:10", 0, "rectangle", 2000, 9, 4096),
                     ("-f 100M:100.1M:10 (boxcar ds=28), N=16384, one tune", "100M:100.1M:10", 1, "rectangle", 2000, 0, 4096),
-                    ("-f 100M:100.2M:10 (boxcar ds=14), N=32768, one tune", "100M:100.2M:10", 1, "rectangle", 2000, 0, 2048)):
+                    ("-f 100M:100.2M:10 (boxcar ds=14), N=32768, one tune", "100M:100.2M:10", 1, "rectangle", 2000, 0, 2048),
+                    ("-f 100M:102.8M:20, N=262144 (radix-16 passes through HBM + register-blocked tail), one tune", "100M:102.8M:20", 1, "hamming", 20000, 0, 256)):
                 pl = R.plan_range(rng, 0.0, boxcar)
                 nn = 1 << pl.bin_e
                 p2 = R.PowerScan(R.PowerParams(pl.bin_e, pl.buf_len, pl.downsample, pl.downsample_passes, boxcar, fir, 0), pl.tune_count,
@@ -761,6 +805,16 @@ def main():
             parity_all["channeliser"] = bool(chan_parity["parity_ok"])
         ch.close()
         achieved = (4.0 * T) / (ms / launches * 1e-3) / 1e9 if launches else 0.0
+        pmc, pmc_src = pmc_summary()
+        ch_traffic = ch_valu = None
+        try:
+            k = pmc_kernel(pmc, "k_ch_fft", "SQ_INSTS_VALU")
+            ch_valu = k["SQ_INSTS_VALU"] * (T / float(2048 * 131072)) / (ms / launches * 1e-3) / 1e9
+            if k.get("hbm_bytes_per_launch"):
+                ch_traffic = k["hbm_bytes_per_launch"] * (T / float(2048 * 131072))
+        except (KeyError, TypeError, ZeroDivisionError):
+            pass
+        ch_peak, ch_peak_src = valu_ceiling("k_ch_fftR")
         result["channeliser"] = {
             "metric": "256-channel NBFM channeliser, capture MSample/s (extension: fix_fft per 1024-sample window + fm_demod per channel)",
             "value": world * T * steps / dt / 1e6, "unit": "MSample/s", "n_gpus": world, "steps": steps,
@@ -768,9 +822,11 @@ def main():
             "config": {"workload": "BASELINE configs[4]: 256 channels x 19.5 kHz from one 20 Msps capture, N=1024, -A fast",
                        "blocks_per_step": n_blocks, "parallelism": "replicas x%d" % world, "host_fixups_last_step": int(chan_fix)},
             "roofline": {"bound": "hbm", "kernel": "k_ch_fft", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": 4 * T,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": ch_traffic, "algorithmic_bytes_per_launch": 4 * T,
                          "avg_launch_ms": (ms / launches) if launches else None,
-                         "note": "integer-VALU bound like k_pw_fft (register-blocked radix-16 passes, packed butterfly)"},
+                         "valu": {"achieved": ch_valu, "peak": ch_peak, "unit": "G wave-instr/s", "frac": (ch_valu / ch_peak) if ch_valu else None,
+                                  "peak_source": ch_peak_src, "valu_source": (pmc_src + " (SQ_INSTS_VALU per launch) / live launch time") if ch_valu else None},
+                         "note": "integer-VALU bound like k_pw_fft (register-blocked radix-16 passes, packed butterfly): the binding roofline is `valu`"},
         }
         if chan_parity is not None:
             result["channeliser"]["parity"] = chan_parity

@@ -69,8 +69,13 @@ int rxgpu_prof_get(const char *name, double *total_ms, long *launches);
  * function-static `avg` (rtl_fm.c:669) has no field in the struct: it lives in a side-car
  * keyed by the demod_state address (rxgpu_deemph_state).  Covered: -M fm|am|usb|lsb|raw,
  * -A std|fast|lut|ale, -l squelch, -F 0|9, -E deemp|adc|rdc (rdc runs in rxgpu_callback), -o, -r.
+ * Any block length the reference takes: readStream may return any element count (rtl_fm.c:894-899), so lp_len is any even number from 0 to
+ * MAXIMUM_BUF_LENGTH -- -F blocks that are not a multiple of 2^passes follow the C's own int16 indexing (lp_len >> i turns odd, the final
+ * lp_len may be odd), and a block that completes no decimated sample gets what the C does on the struct's memory (fm_demod's result[0], and
+ * pre_r/pre_j from lp[lp_len-2], lp[lp_len-1] in front of lowpassed[]).
  * Not on the device path, by decision: -L level printing (file-static counters of rtl_fm.c) and -o with a block
- * whose demodulated length is not a multiple of the step (the reference then reads stale data): those print to
+ * whose demodulated length is not a multiple of the step (the reference then reads stale data); and the two shapes the reference itself dies on
+ * (-E adc with no demodulated sample: division by result_len == 0, rtl_fm.c:693; -E rdc on an empty read, rtl_fm.c:711): those print to
  * stderr and exit(1) -- there is no CPU fallback.
  * If the block in d->lowpassed is the one rxgpu_callback handed over last (same demod_state, same lp_len, nobody
  * called rxgpu_dropin_invalidate), the copy it left in HBM is used and the block does not cross PCIe a second time. */
@@ -170,6 +175,9 @@ int rxgpu_fm_stream_get_carry(rxgpu_fm_stream *s, rxgpu_fm_carry *c);
 /* n_blocks consecutive callback blocks through rtlsdr_callback's pre-stage + full_demod,
  * with exactly the per-block semantics of the reference (rotation phase restart, libm
  * discriminator on each block's first sample, fifth_order seam rule, carries).
+ * block_len: any even int16 count >= 2.  -F blocks that are not a multiple of 2^passes take the per-block kernels that index like the C
+ * (slow path); RXGPU_EUNSUPPORTED only where the reference reads struct memory the stream does not have: -F blocks that leave fewer than
+ * two int16 after the cascade, low_pass blocks shorter than downsample (the drop-in handles both on the real struct).
  * d_iq : DEVICE pointer, n_blocks * block_len int16, resident in HBM.
  * d_out: DEVICE pointer, capacity out_cap int16; receives the concatenated result[] of all
  *        blocks.  *out_len = int16 written.  block_out_len (HOST, optional, n_blocks ints)
@@ -213,7 +221,11 @@ long rxgpu_fm_stream_host_fixups(const rxgpu_fm_stream *s);
  * every offset at once, in the reference's fixed-point scaling -- and bin first_bin+c of successive windows
  * is channel c's lowpassed[] stream, demodulated by fm_demod (rtl_fm.c:584-615; each callback block's
  * first sample through libm atan2, the rest per custom_atan) with per-channel carried pre_r/pre_j.
- * Channel spacing = channel sample rate = fs/N (20 Msps, N=1024: 19.5 kHz NBFM channels). */
+ * Channel spacing = channel sample rate = fs/N (20 Msps, N=1024: 19.5 kHz NBFM channels).
+ * Channel response: a rectangular N-sample window, critically sampled -- each channel is the boxcar low_pass of the reference, so its
+ * selectivity is a sinc's (first side lobe -13 dB, nulls at the neighbouring channel centres): adjacent-channel energy away from those
+ * centres leaks in, exactly as it does into rx_fm's own low_pass at ds = N.  There is no windowed / polyphase prototype filter here,
+ * because the reference has none to pin one against. */
 typedef struct rxgpu_chan_params {
 	int bin_e;               /* window length 2^bin_e complex samples (1..15) */
 	int first_bin;           /* channel c = FFT bin (first_bin + c) mod N */

@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""Fold gpurun_out/prof_TAG (tools/profile_round3.sh) into profiles/:
+
+    python tools/collect_round3.py r03 gpurun_out/prof_r03
+
+  rNN_bench_n1.json, rNN_bench_profiled_run.json           the bench lines (plain, and under --kernel-trace)
+  rNN_bench_kernel_stats.csv, rNN_bench_kernel_trace.csv   rocprofv3 --kernel-trace --stats of the headline command (our kernels' rows)
+  rNN_variants_kernel_stats.csv                            the same for the rx_fm variants
+  rNN_pmc_chains.json     per rx_fm chain / rx_power / channeliser: per kernel {launches, VALU wave-instructions, shader cycles, waves waiting,
+                          FETCH_SIZE, WRITE_SIZE} and the chain's HBM bytes per step beside its algorithmic bytes
+  rNN_pmc_summary.json    the per-kernel entries bench.py reads (k_fm_decimate traffic, k_pw_fft4096 / k_ch_fftR instruction counts)
+  rNN_valu_issue.json/.txt  tools/valu_issue.hip: wave64 instructions per SIMD-cycle per opcode (the VALU roofline's anchor)
+
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies a 128-byte request as 64 bytes, so it is doubled (MI355X_MICROARCH.md,
+HBM section); WRITE_SIZE is taken as reported."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "").strip()
+
+
+def one(pattern):
+    hits = glob.glob(pattern)
+    return hits[0] if hits else None
+
+
+def per_kernel(path, min_grid=0):
+    """{kernel: {counter: SUM over its dispatches, '_dispatches': n}} for our kernels"""
+    acc = defaultdict(lambda: defaultdict(float))
+    cnt = defaultdict(lambda: defaultdict(int))
+    for r in csv.DictReader(open(path)):
+        k = short(r["Kernel_Name"])
+        if not k.startswith("k_") or int(r["Grid_Size"]) < min_grid:
+            continue
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        cnt[k][r["Counter_Name"]] += 1
+    out = {}
+    for k, d in acc.items():
+        out[k] = dict(d)
+        out[k]["_dispatches"] = max(cnt[k].values())
+    return out
+
+
+def chain_entry(src, prefix, steps, algorithmic_bytes_per_step, what):
+    merged = {}
+    for f in sorted(glob.glob(os.path.join(src, prefix + "_p*", "*", "*_counter_collection.csv"))):
+        for k, d in per_kernel(f).items():
+            e = merged.setdefault(k, {})
+            for c, v in d.items():
+                e[c] = v if c != "_dispatches" else max(v, e.get(c, 0))
+    if not merged:
+        return None
+    kernels, total = {}, 0.0
+    for k, d in sorted(merged.items()):
+        n = d.get("_dispatches", 1)
+        e = {"dispatches_in_run": n}
+        if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
+            e["hbm_bytes_per_step"] = (2.0 * d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)) * 1024.0 / steps
+            e["fetch_bytes_per_step"] = 2.0 * d.get("FETCH_SIZE", 0.0) * 1024.0 / steps
+            e["write_bytes_per_step"] = d.get("WRITE_SIZE", 0.0) * 1024.0 / steps
+            total += e["hbm_bytes_per_step"]
+        if d.get("SQ_INSTS_VALU") is not None:
+            e["valu_wave_instr_per_step"] = d["SQ_INSTS_VALU"] / steps
+        if d.get("GRBM_GUI_ACTIVE") and d.get("SQ_INSTS_VALU") is not None:
+            cyc = d["GRBM_GUI_ACTIVE"] / 8.0                                    # summed over the 8 XCDs
+            e["shader_cycles_per_step"] = cyc / steps
+            e["valu_wave_instr_per_simd_cycle"] = d["SQ_INSTS_VALU"] / (cyc * 1024.0)
+        if d.get("SQ_WAVE_CYCLES"):
+            e["wave_time_waiting"] = d.get("SQ_WAIT_ANY", 0.0) / d["SQ_WAVE_CYCLES"]
+        if d.get("SQ_LDS_IDX_ACTIVE"):
+            e["lds_conflict_fraction"] = d.get("SQ_LDS_BANK_CONFLICT", 0.0) / d["SQ_LDS_IDX_ACTIVE"]
+        kernels[k] = e
+    return {"what": what, "steps_in_run": steps, "algorithmic_bytes_per_step": algorithmic_bytes_per_step,
+            "hbm_bytes_per_step": total, "traffic_over_algorithmic": total / algorithmic_bytes_per_step if algorithmic_bytes_per_step else None,
+            "kernels": kernels}
+
+
+def main():
+    tag, src = sys.argv[1], sys.argv[2]
+    dst = os.path.join(ROOT, "profiles")
+    for pat, name in (("bench_n1.json", "%s_bench_n1.json"), ("trace_bench.json", "%s_bench_profiled_run.json"),
+                      ("trace/*/*_kernel_stats.csv", "%s_bench_kernel_stats.csv"), ("trace_variants/*/*_kernel_stats.csv", "%s_variants_kernel_stats.csv"),
+                      ("valu_issue.json", "%s_valu_issue.json"), ("valu_issue.txt", "%s_valu_issue.txt")):
+        f = one(os.path.join(src, pat))
+        if f:
+            shutil.copy(f, os.path.join(dst, name % tag))
+    f = one(os.path.join(src, "trace/*/*_kernel_trace.csv"))
+    if f:
+        rows = list(csv.DictReader(open(f)))
+        keep = [r for r in rows if "k_" in r["Kernel_Name"].split("(")[0]]
+        with open(os.path.join(dst, "%s_bench_kernel_trace.csv" % tag), "w", newline="") as o:
+            w = csv.DictWriter(o, fieldnames=list(rows[0].keys()))
+            w.writeheader()
+            w.writerows(keep)
+    chains = {}
+    T4 = 8192 * 131072                                                           # samples per chain_once.py run
+    for ds, label in ((118, "headline: low_pass ds=118"), (6, "-M wbfm default, downsample=6"), (5, "configs[0] geometry: ds=5, 240 kHz"),
+                      (-7, "-F cascade, 7 passes (ds=128)"), (-39, "-M wbfm -F 9: 3 passes + droop FIR")):
+        e = chain_entry(src, "chain_%d" % ds, 2, 4.0 * T4,
+                        "tools/chain_once.py 8192 %d 2: two pipelined runs of 8192 blocks (4 GiB each); counters summed over every kernel of the chain, per run" % ds)
+        if e:
+            chains[label] = e
+    e = chain_entry(src, "rx_power", 3, 4.0 * 512 * 599 * 8192, "bench.py --workload rx_power --steps 2 --warmup 1: three 512-pass launches of the configs[2] geometry")
+    if e:
+        chains["rx_power configs[2]"] = e
+    e = chain_entry(src, "chan", 6, 4.0 * 2048 * 131072, "bench.py --workload chan --steps 2 --warmup 1 (5 timed + 1 warm-up run of 1 GiB)")
+    if e:
+        chains["channeliser"] = e
+    json.dump(chains, open(os.path.join(dst, "%s_pmc_chains.json" % tag), "w"), indent=1)
+    # what bench.py reads
+    summ = {}
+    hd = chains.get("headline: low_pass ds=118", {}).get("kernels", {})
+    for k, v in hd.items():
+        if k.startswith("k_fm_decimate<") and "hbm_bytes_per_step" in v:
+            summ[k] = {"hbm_bytes_per_launch": v["hbm_bytes_per_step"], "launch_samples": T4,
+                       "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE uncorrected"}
+    for src_label, prefix in (("rx_power configs[2]", "k_pw_fft4096"), ("channeliser", "k_ch_fft")):
+        for k, v in chains.get(src_label, {}).get("kernels", {}).items():
+            if k.startswith(prefix) and "valu_wave_instr_per_step" in v:
+                summ[k] = {"SQ_INSTS_VALU": v["valu_wave_instr_per_step"], "hbm_bytes_per_launch": v.get("hbm_bytes_per_step"),
+                           "valu_wave_instr_per_simd_cycle": v.get("valu_wave_instr_per_simd_cycle"), "wave_time_waiting": v.get("wave_time_waiting"),
+                           "lds_conflict_fraction": v.get("lds_conflict_fraction")}
+    summ["_chains"] = {k: {"hbm_bytes_per_step": v["hbm_bytes_per_step"], "algorithmic_bytes_per_step": v["algorithmic_bytes_per_step"],
+                           "traffic_over_algorithmic": v["traffic_over_algorithmic"]} for k, v in chains.items()}
+    json.dump(summ, open(os.path.join(dst, "%s_pmc_summary.json" % tag), "w"), indent=1)
+    for k, v in chains.items():
+        print("%-44s HBM bytes/step %.3f GB = %.3f x algorithmic" % (k, v["hbm_bytes_per_step"] / 1e9, v["traffic_over_algorithmic"] or 0))
+        for kk, e in v["kernels"].items():
+            if e.get("hbm_bytes_per_step", 0) > 5e7 or e.get("valu_wave_instr_per_step", 0) > 1e7:
+                print("      %-56s %8.3f GB  valu %7.1f M  %.3f/SIMD-cycle  waiting %.2f" % (kk[:56], e.get("hbm_bytes_per_step", 0) / 1e9, e.get("valu_wave_instr_per_step", 0) / 1e6,
+                                                                                             e.get("valu_wave_instr_per_simd_cycle", 0) or 0, e.get("wave_time_waiting", 0) or 0))
+
+
+if __name__ == "__main__":
+    main()
