@@ -113,6 +113,22 @@ template <int M> struct fft_geom {
 	__host__ __device__ static constexpr int sp0(int p) { return (p == P - 1) ? (4 * P - M) : 0; }                // stages already done
 };
 
+// The threads of one transform exchange their values through LDS between two passes.  With N/16 <= 64 threads per transform (N <= 1024)
+// those threads are lanes of ONE wave (the kernels give a transform an aligned run of threads): a wave's LDS instructions execute in
+// program order, so no s_barrier is needed -- only that the compiler keeps the order -- and the waves of a workgroup stop waiting for
+// each other three times per transform.  Larger transforms span waves: a workgroup barrier.
+template <int M>
+__device__ __forceinline__ void fft_sync()
+{
+	if constexpr (((1 << M) / 16) <= 64) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	} else {
+		__syncthreads();
+	}
+}
+
 template <int M, int PASS>
 __device__ __forceinline__ void fft_pass(uint32_t (&v)[16], const uint32_t *__restrict__ tw, unsigned tq)
 {
@@ -148,7 +164,7 @@ __device__ __forceinline__ void fft_exchange(uint32_t (&v)[16], uint32_t *__rest
 		const unsigned col = (n >> F2) & 15u;
 		lds[row * G::ROW + col] = v[r];
 	}
-	__syncthreads();
+	fft_sync<M>();
 #pragma unroll
 	for (int c = 0; c < 4; c++) {
 		const uint4 t4 = *reinterpret_cast<const uint4 *>(&lds[tq * G::ROW + 4 * c]);
@@ -166,19 +182,19 @@ __device__ __forceinline__ void fft_reg(uint32_t (&v)[16], unsigned tq, uint32_t
 	typedef fft_geom<M> G;
 	// the previous transform's last reads of lds_a must be over before this one's first writes
 	if (!DOUBLE || (G::P % 2) == 0)
-		__syncthreads();
+		fft_sync<M>();
 	fft_pass<M, 0>(v, tw, tq);
 	if constexpr (G::P > 1) {
 		fft_exchange<M, 0>(v, lds_a, tq);
 		fft_pass<M, 1>(v, tw, tq);
 	}
 	if constexpr (G::P > 2) {
-		if (!DOUBLE) __syncthreads();
+		if (!DOUBLE) fft_sync<M>();
 		fft_exchange<M, 1>(v, DOUBLE ? lds_b : lds_a, tq);
 		fft_pass<M, 2>(v, tw, tq);
 	}
 	if constexpr (G::P > 3) {
-		if (!DOUBLE) __syncthreads();
+		if (!DOUBLE) fft_sync<M>();
 		fft_exchange<M, 2>(v, lds_a, tq);
 		fft_pass<M, 3>(v, tw, tq);
 	}

@@ -3015,7 +3015,14 @@ __global__ __launch_bounds__(256) void k_ch_fft(const uint32_t *__restrict__ iq,
 // window, 256/(N/16) windows side by side, CH_WPG windows per workgroup so that every channel's
 // outputs leave as one contiguous segment.
 // windows per workgroup: 32 while the [n_channels][wpg] staging fits beside the transform buffers, else 16
-static inline int ch_wpg(int n_channels) { return n_channels <= 512 ? 32 : 16; }
+static inline int ch_wpg(int n_channels)
+{
+	const char *e = getenv("RXGPU_CH_WPG");                  /* 16 | 32: A/B of the window group (LDS per workgroup vs work of the sparse demodulator pass) */
+	if (e && (atoi(e) == 16 || atoi(e) == 32))
+		return atoi(e);
+	(void)n_channels;
+	return 16;                                               /* round 3, 256 channels: 387-392 GS/s with 16 windows per group, 367-375 with 32 */
+}
 // FUSED: also fm_demod (-A fast) for every window but the workgroup's first, straight from the LDS copy of the bins; then
 // only the entries k_ch_demod(sparse) reads are stored in chan_lp (each group's first and last window).  Needs the
 // callback blocks to be whole groups of CH_WPG windows, so that a block's first (libm) window is a group's first.
@@ -3027,9 +3034,13 @@ __global__ __launch_bounds__(256) void k_ch_fftR(const uint32_t *__restrict__ iq
 {
 	typedef fft_geom<M> G;
 	constexpr int N = G::N, TPF = G::TPF, FPW = 256 / TPF;
+	// N <= 1024: a window's N/16 threads are lanes of one wave, its transposes need no workgroup barrier (fft_sync) and -- a wave's LDS
+	// instructions being in order -- no second transpose area either: 20 KB less LDS per workgroup, and the four waves run their windows
+	// without waiting for each other (round 2: 72 KB and three barriers per window group left two barrier-coupled waves per SIMD)
+	constexpr bool WAVE = TPF <= 64;
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-	uint32_t *xa = lds, *xb = lds + 256 * G::ROW;
-	uint32_t *outt = lds + 2 * 256 * G::ROW;                 // [n_channels][CH_WPG]
+	uint32_t *xa = lds, *xb = WAVE ? lds : lds + 256 * G::ROW;
+	uint32_t *outt = lds + (WAVE ? 1 : 2) * 256 * G::ROW;    // [n_channels][CH_WPG]
 	const int tid = threadIdx.x, fid = tid / TPF;
 	const unsigned tq = tid % TPF;
 	const u64 w0 = (u64)blockIdx.x * CH_WPG;
@@ -3040,7 +3051,7 @@ __global__ __launch_bounds__(256) void k_ch_fftR(const uint32_t *__restrict__ iq
 #pragma unroll
 		for (int r = 0; r < 16; r++)
 			v[r] = live ? iq[(w << M) + tq + r * TPF] : 0u;
-		fft_reg<M, true>(v, tq, xa + fid * TPF * G::ROW, xb + fid * TPF * G::ROW, twiddle);
+		fft_reg<M, !WAVE>(v, tq, xa + fid * TPF * G::ROW, xb + fid * TPF * G::ROW, twiddle);
 #pragma unroll
 		for (int r = 0; r < 16; r++) {
 			const unsigned bin = __brev((tq << 4) | (unsigned)r) >> (32 - M);
@@ -3785,7 +3796,7 @@ extern "C" int rxk_ch_fft(void *stream, const int16_t *iq, u64 total_windows, in
 		return 0;
 	if (bin_e >= 8 && bin_e <= 12) {
 		const int CH_WPG = ch_wpg(n_channels);
-		const size_t shm = (size_t)(2 * 256 * 20 + n_channels * CH_WPG) * 4;
+		const size_t shm = (size_t)((bin_e <= 10 ? 1 : 2) * 256 * 20 + n_channels * CH_WPG) * 4;     /* N <= 1024: one transpose area (k_ch_fftR) */
 		const unsigned grid = (unsigned)((total_windows + CH_WPG - 1) / CH_WPG);
 		hipStream_t s = (hipStream_t)stream;
 		const uint32_t *p = (const uint32_t *)iq;
