@@ -302,10 +302,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    # $RXGPU_BENCH_SHARE_GPU=1 (test hook, tests/test_gpu_power.py): every rank on device 0 and torch.distributed over gloo -- with
+    # $RXGPU_RCCL_LIB pointing at tests/fake_rccl.c this runs the N > 1 path of this file on a box with ONE GPU (RCCL refuses two
+    # ranks per device).  Not a measurement.
+    share_gpu = os.environ.get("RXGPU_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     R.check(R.lib().rxgpu_init(local))
     L = R.lib()
     dev = torch.device("cuda", local)
@@ -319,7 +328,7 @@ def main():
     def max_over_ranks(seconds):
         if world == 1:
             return seconds
-        t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+        t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if share_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -582,7 +591,7 @@ def main():
                 gather_impl = "librxgpu rxgpu_power_gather: one ncclGroup {ncclGather(avg int64), ncclGather(samples int32)} from %s on the library's stream" % shard.Comm.library()
             except Exception as e:                               # noqa: BLE001
                 comm_err = repr(e)
-            ok = torch.tensor([1 if comm is not None else 0], device=dev)
+            ok = torch.tensor([1 if comm is not None else 0], device="cpu" if share_gpu else dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 0:                              # all ranks or none
                 if comm is not None:

@@ -167,6 +167,36 @@ def test_sharded_sweep_multi_rank_on_one_gpu(world, tmp_path):
     assert ("world=%d" % world) in ok and "libfake_rccl" in ok
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_multi_rank_path_on_one_gpu(world, tmp_path):
+    """bench.py --gpus N exactly as the driver launches it (torch.distributed.run, one process per rank), on this box's one GPU: every
+    rank on device 0, torch.distributed over gloo and librxgpu's communicator over the file transport ($RXGPU_BENCH_SHARE_GPU is the
+    hook).  The N > 1 code of bench.py -- rx_fm replicas with a max over ranks, rx_power tunes sharded through
+    rxgpu_power_scan_run_sharded with the grouped gather, one JSON line from rank 0 -- has then run before the driver's 8-GPU node runs it."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RXGPU_RCCL_LIB=_fake_rccl(), FAKE_RCCL_DIR=str(tmp_path), RXGPU_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
+           "--blocks", "256", "--passes", "8", "--cpu-seconds", "0"]
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=800)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    line = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == world and line["value"] > 0 and line["config"]["parallelism"].startswith("replicas x%d" % world)
+    pw = line["rx_power"]
+    assert pw["n_gpus"] == world and pw["config"]["rccl_ranks"] == world and pw["config"]["rccl_gathers_enqueued"] == 3
+    assert "rxgpu_power_gather" in pw["config"]["gather"] and "libfake_rccl" in pw["config"]["gather"]
+    assert pw["config"]["tunes_per_rank_padded"] == -(-599 // world) and pw["value"] > 0
+
+
 def test_comm_rejects_a_rank_the_communicator_does_not_report(tmp_path):
     """rxgpu_comm_adopt checks rank/world against ncclCommUserRank/ncclCommCount"""
     import ctypes as C
