@@ -479,6 +479,7 @@ def main():
             del h_iq
             # drop-in: rxgpu_callback + rxgpu_full_demod on the reference's own structs, block after block
             from rx_tools_amd.structs import DemodState, DongleState
+            os.environ["RXGPU_DROPIN_TIMING"] = "1"                   # read once, at the first drop-in call of the process
             d = DemodState()
             d.rate_in = d.rate_out = 170000
             d.rate_out2, d.custom_atan, d.deemph, d.deemph_a, d.downsample = 32000, 1, 1, 13, 118
@@ -495,19 +496,29 @@ def main():
                 L.rxgpu_callback(blk.ctypes.data, block_len, C.addressof(g))
                 L.rxgpu_full_demod(C.addressof(d))
             nb = 200
+            phases = (C.c_double * 7)()
+            L.rxgpu_dropin_timing(phases, 7)                          # clear (the table fills only with $RXGPU_DROPIN_TIMING=1, set below)
             t0 = time.perf_counter()
             for _ in range(nb):
                 L.rxgpu_callback(blk.ctypes.data, block_len, C.addressof(g))
             t_cb = (time.perf_counter() - t0) / nb
+            L.rxgpu_dropin_timing(phases, 7)
             t0 = time.perf_counter()
             for _ in range(nb):
                 L.rxgpu_callback(blk.ctypes.data, block_len, C.addressof(g))
                 L.rxgpu_full_demod(C.addressof(d))
             t_both = (time.perf_counter() - t0) / nb
+            L.rxgpu_dropin_timing(phases, 7)
+            ph = list(phases)
+            breakdown = None
+            if ph[5] and ph[6]:
+                breakdown = {"callback: H2D + pre-stage kernel + D2H (enqueue..sync)": ph[0] / ph[5], "callback: hand-off (rw lock, memcpy, signal)": ph[1] / ph[5],
+                             "full_demod: set-up (params, side-car, carries in)": ph[2] / ph[6], "full_demod: run (kernels, carries back)": ph[3] / ph[6],
+                             "full_demod: D2H of result[] and lowpassed[], struct fields": ph[4] / ph[6]}
             R.check(L.rxgpu_dropin_unpin(C.addressof(d), C.addressof(g)))
             host_fed["dropin_block_us"] = {"callback": t_cb * 1e6, "callback+full_demod": t_both * 1e6,
                                            "block_complex_samples": block_len // 2,
-                                           "MSample/s": (block_len // 2) / t_both / 1e6,
+                                           "MSample/s": (block_len // 2) / t_both / 1e6, "phase_us": breakdown,
                                            "note": "one 1 MiB block per call pair: H2D raw, pre-stage kernel, D2H into buf16/lowpassed[]; "
                                                    "full_demod consumes the copy left in HBM, D2H of lowpassed[]/result[] only"}
         del d_iq

@@ -90,6 +90,11 @@ void rxgpu_dropin_invalidate(const struct demod_state *d);
 int rxgpu_dropin_pin(struct demod_state *d, struct dongle_state *s);
 int rxgpu_dropin_unpin(struct demod_state *d, struct dongle_state *s);
 
+/* Diagnostics: with $RXGPU_DROPIN_TIMING=1 the two drop-ins accumulate host-clock microseconds per phase -- us[0] callback copies + pre-stage
+ * kernel, [1] callback hand-off, [2] full_demod set-up, [3] full_demod run (kernels + carries), [4] full_demod result / lowpassed[] copies,
+ * [5] callbacks, [6] full_demod calls.  Copies up to n (<= 7) values, clears the table, returns how many. */
+int rxgpu_dropin_timing(double *us, int n);
+
 /* Replaces rtlsdr_callback(buf, len, ctx) at rtl_fm.c:899 (definition 828-863):
  * mute-zero, CS16 -> 8-bit-range scale, rotate16_90 unless offset tuning, hand-off into
  * s->demod_target->lowpassed under d->rw, signal d->ready.  len = int16 count. */

@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #define DEEMPH_CHUNK_MIN 128           /* chunk = power of two >= warm: one lane per chunk, 64 chunks per workgroup */
 #define DEEMPH_LEVELS 8
@@ -1371,6 +1372,38 @@ int rxgpu_dropin_unpin(struct demod_state *d, struct dongle_state *s)
 	return rc;
 }
 
+/* Where a drop-in call pair spends its time (host clock, $RXGPU_DROPIN_TIMING=1; rxgpu_dropin_timing reads and clears):
+ *   0 callback: H2D of the raw block + pre-stage kernel + D2H into buf16 (enqueue .. stream sync)
+ *   1 callback: the hand-off (d->rw, memcpy into lowpassed[], publication, cond_signal)
+ *   2 full_demod: parameters, side-car, carries in
+ *   3 full_demod: the run (upload if the block is not the pre-staged one, every kernel, carries back)
+ *   4 full_demod: D2H of result[] and lowpassed[], carries into the struct
+ *   5 calls of rxgpu_callback, 6 calls of rxgpu_full_demod */
+static double g_dt[7];
+static int g_dt_on = -1;
+static double now_us(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec * 1e6 + (double)ts.tv_nsec * 1e-3;
+}
+static int dt_on(void)
+{
+	if (g_dt_on < 0) {
+		const char *e = getenv("RXGPU_DROPIN_TIMING");
+		g_dt_on = e && atoi(e) > 0;
+	}
+	return g_dt_on;
+}
+int rxgpu_dropin_timing(double *us, int n)
+{
+	for (int i = 0; i < n && i < 7; i++) {
+		us[i] = g_dt[i];
+		g_dt[i] = 0;
+	}
+	return n < 7 ? n : 7;
+}
+
 /* the callback's device buffers of one demod_state, allocated on first use */
 static int side_buffers(int slot)
 {
@@ -1403,6 +1436,8 @@ void rxgpu_fm_dropin_release(void)
 
 void rxgpu_full_demod(struct demod_state *d)
 {
+	const int timing = dt_on();
+	double t_a = timing ? now_us() : 0, t_b;
 	int slot = side_slot(d);
 	if (slot < 0) {
 		rxgpu_fail(RXGPU_ECAPACITY, "more than %d demod_state objects", SIDECARS);
@@ -1481,6 +1516,7 @@ void rxgpu_full_demod(struct demod_state *d)
 		s->stage_out_cap = cap;
 	}
 	const int16_t *d_block;
+	if (timing) { t_b = now_us(); g_dt[2] += t_b - t_a; t_a = t_b; }
 	if (g_side[slot].dev_valid && g_side[slot].dev_len == d->lp_len && d->lp_len > 0 && g_side[slot].cb_pre[g_side[slot].dev_slot]) {
 		/* the block is the one rxgpu_callback pre-staged: it is still in HBM, no second trip over PCIe.  (The caller
 		 * holds d->rw like the reference's demod thread, rtl_fm.c:922-924, so the callback cannot publish meanwhile.) */
@@ -1506,6 +1542,8 @@ void rxgpu_full_demod(struct demod_state *d)
 	if (rxgpu_fm_stream_run(s, d_block, 1, (size_t)d->lp_len, s->stage_out, s->stage_out_cap, &got, NULL) != RXGPU_OK)
 		die("rxgpu_full_demod");
 	g_side[slot].dev_valid = 0;
+	rxgpu_fm_stream_get_carry(s, &c);
+	if (timing) { t_b = now_us(); g_dt[3] += t_b - t_a; t_a = t_b; }
 	if (got > RXGPU_MAXIMUM_BUF_LENGTH) {
 		rxgpu_fail(RXGPU_ECAPACITY, "result needs %zu int16", got);
 		die("rxgpu_full_demod");
@@ -1514,7 +1552,6 @@ void rxgpu_full_demod(struct demod_state *d)
 		rxgpu_fail(RXGPU_ENODEV, "copy of the result failed");
 		die("rxgpu_full_demod");
 	}
-	rxgpu_fm_stream_get_carry(s, &c);
 	/* decimated IQ back into lowpassed[], like the CPU's in-place stages leave it: lp_len' int16 (odd on some -F shapes), and
 	 * never fewer than two -- every fifth_order pass rewrites lowpassed[0] and [1] even for an empty block */
 	const struct run_geom *g = &s->last;
@@ -1550,6 +1587,7 @@ void rxgpu_full_demod(struct demod_state *d)
 		d->pre_r = end[-2];
 		d->pre_j = end[-1];
 	}
+	if (timing) { g_dt[4] += now_us() - t_a; g_dt[6] += 1; }
 }
 
 void rxgpu_callback(int16_t *buf, uint32_t len, void *ctx)
@@ -1580,6 +1618,8 @@ void rxgpu_callback(int16_t *buf, uint32_t len, void *ctx)
 		rxgpu_fail(RXGPU_EUNSUPPORTED, "-E rdc on an empty read divides by zero in the reference (rtl_fm.c:711)");
 		die("rxgpu_callback");
 	}
+	const int timing = dt_on();
+	double t_a = timing ? now_us() : 0, t_b;
 	pthread_mutex_lock(&g_side[side].cb_lock);       /* the buffers below belong to this demod_state; one callback at a time on them */
 	if (side_buffers(side) != RXGPU_OK) {
 		pthread_mutex_unlock(&g_side[side].cb_lock);
@@ -1614,6 +1654,7 @@ void rxgpu_callback(int16_t *buf, uint32_t len, void *ctx)
 		rxgpu_fail(RXGPU_ENODEV, "device pre-stage failed: %s", hipGetErrorString(hipGetLastError()));
 		die("rxgpu_callback");
 	}
+	if (timing) { t_b = now_us(); g_dt[0] += t_b - t_a; t_a = t_b; }
 	pthread_rwlock_wrlock(&d->rw);                   /* rtl_fm.c:858-862 */
 	memcpy(d->lowpassed, s->buf16, 2 * (size_t)len);
 	d->lp_len = (int)len;
@@ -1625,4 +1666,5 @@ void rxgpu_callback(int16_t *buf, uint32_t len, void *ctx)
 	pthread_mutex_lock(&d->ready_m);
 	pthread_cond_signal(&d->ready);
 	pthread_mutex_unlock(&d->ready_m);
+	if (timing) { g_dt[1] += now_us() - t_a; g_dt[5] += 1; }
 }
