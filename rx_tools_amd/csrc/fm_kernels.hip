@@ -2109,14 +2109,18 @@ __global__ void k_fm_fifth_seams(const uint32_t *__restrict__ iq, u64 n_blocks, 
                                  const int16_t *__restrict__ hist_in, uint32_t *__restrict__ seams,
                                  int16_t *__restrict__ hist_out)
 {
-	constexpr int SL = LV == 3 ? 16 : 32;                  // slots (threads) per block, LV * 5 of them used
+	constexpr int SL = LV == 3 ? 16 : 32;                  // slots (threads) per block, LV * 5 of them used (LV <= 5)
 	const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
 	const u64 b = gid / SL;
 	const int slot = (int)(gid % SL), p = slot / 5, q = slot % 5;
 	auto level = [&](const uint32_t *blk_raw, int idx) -> uint32_t {
-		if constexpr (LV == 4) {
+		if constexpr (LV >= 4) {
 			if (p == 3)
 				return level_val<3, ROTATE, STAGE2>(blk_raw, idx);
+		}
+		if constexpr (LV >= 5) {
+			if (p == 4)
+				return level_val<4, ROTATE, STAGE2>(blk_raw, idx);
 		}
 		return p == 0 ? level_val<0, ROTATE, STAGE2>(blk_raw, idx) : p == 1 ? level_val<1, ROTATE, STAGE2>(blk_raw, idx) : level_val<2, ROTATE, STAGE2>(blk_raw, idx);
 	};
@@ -2361,7 +2365,7 @@ __global__ __launch_bounds__(256) void k_fm_fifth_fused(
 
 // The first three fifth_order passes on the raw capture WITHOUT LDS and WITHOUT barriers (round 3; the LDS-tiled kernel above
 // spent 70 % of its wave-time parked: its HBM, VALU and LDS phases ran one after the other between four barriers per tile, and
-// it issued ~21 instructions per sample).  A decimating FIR keeps its taps next door when every lane owns a CONTIGUOUS run:
+// it issued ~21 instructions per sample).  A decimating FIR keeps its taps next door when every lane owns a CONTIGUOUS run (for three passes):
 //   lane l holds 8 consecutive level-0 samples x[8l .. 8l+7] (two 16-byte loads, scale + rotate as in the decimator),
 //   level 1:  y[4l+k] = W(x[8l+2k-5 .. 8l+2k]),  k < 4 -- its own registers plus the left neighbour's x3..x7,
 //   level 2:  z[2l+k] = W(y[4l+2k-5 .. 4l+2k]),  k < 2 -- own, the neighbour's y0..y3 and the neighbour-but-one's y3,
@@ -2373,10 +2377,10 @@ __global__ __launch_bounds__(256) void k_fm_fifth_fused(
 // five lanes are where the history belongs: k_fm_fifth_seams' five samples per level (the block seam rule, rtl_fm.c:416-432)
 // are written over lane 4's x3..x7, over y3 of lane 3 and y0..y3 of lane 4, over z1 of lane 2 and z0, z1 of lanes 3 and 4.
 // A wave never straddles a block.  n % 8 == 0.
-// Measured (round 3, 8 GiB steps): alone this kernel is no faster than the LDS-tiled one (1.90 vs 1.92 ms: both move 9.7 GB at the
-// ~5.1 TB/s this part gives a read stream with 11 % of writes mixed in) -- but it issues half the instructions, holds no LDS and no
-// wave at a barrier, so the later passes / discriminator / audio kernels of the previous run, which overlap it, run twice as fast;
-// and its four-pass sibling below cuts the bytes: -F ds=128 1.02 -> 1.24 TSample/s.
+// Measured (round 3, 8 GiB steps): with THREE passes this form is no faster than the LDS-tiled one (1.90 vs 1.92 ms alone: both move
+// 9.7 GB at the ~5.1 TB/s this part gives a read stream with 11 % of writes mixed in; in the -F 9 chain the LDS kernel is 3-5 % ahead) --
+// but it goes a level deeper for 6 more instructions per 16 samples, and that cuts the bytes: with FOUR passes -F ds=128 went
+// 1.02 -> 1.24-1.33 TSample/s.  Five passes (1/32 out) bought nothing more: the kernel is then bound by its reads (5.5-5.9 TB/s).
 #define FR_OUT 59                                         // outputs per wave
 __device__ __forceinline__ uint32_t fr_shr(uint32_t v)
 {
@@ -2384,98 +2388,51 @@ __device__ __forceinline__ uint32_t fr_shr(uint32_t v)
 	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);
 }
 
-template <bool ROTATE, int NT>
-__global__ __launch_bounds__(256) void k_fm_fifth_reg(const uint32_t *__restrict__ iq, unsigned n, unsigned tiles_per_block, unsigned wgs_per_block,
-                                                      unsigned total_wgs, const uint32_t *__restrict__ seams, uint32_t *__restrict__ out)
+// Written once for any depth: LV passes, 2^LV samples per lane (LV = 4, the default first group of a cascade of four or more passes: its
+// output -- written once, read once -- is 1/16 of the capture; 3 and 5 are instantiated too).  One level: out[k] = W(X[2k-5 .. 2k]) over the
+// lane's NIN values, X[-t] (t = 1..5) sitting `hops` = ceil(t / NIN) lanes to the left at register NIN * hops - t -- that many wave_shr moves
+// away; at a block's start the same five places (in lanes 5 - hops) take the seam history instead.  WIDE levels (the fourth pass on: its
+// inputs reach 1024) sum in 32 bits.  Seams: 5 LV dwords per block (k_fm_fifth_seams<.., LV>).  n % 2^LV == 0.
+template <int NIN, bool WIDE>
+__device__ __forceinline__ void fr_level(uint32_t (&in)[NIN], uint32_t (&out)[NIN / 2], unsigned lane, bool first, const uint32_t *__restrict__ sm)
 {
-	const unsigned lane = threadIdx.x & 63u;
-	// Workgroup b runs on XCD b % 8: every XCD takes one contiguous eighth of the (block, tile) sequence, so that the partial output
-	// lines of neighbouring waves (59 dwords each) and the 160-byte halo re-reads meet in one L2 (the grid is a multiple of 8).
-	const unsigned per = gridDim.x >> 3;
-	const unsigned wgi = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-	if (wgi >= total_wgs)
-		return;
-	// wave-uniform values as scalars: the block and the wave's first tile (four waves per workgroup, NT consecutive tiles each) -- base
-	// addresses stay in SGPRs and the block-start path below is a scalar branch
-	const unsigned blk32 = wgi / wgs_per_block;
-	const unsigned tile0 = ((wgi - blk32 * wgs_per_block) * 4 + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * NT;
-	if (tile0 >= tiles_per_block)                            // spare waves of a block's last workgroup (no barrier in this kernel)
-		return;
-	const u64 blk = blk32;
-	const uint32_t *braw = iq + blk * (u64)n;
-	const unsigned K = n >> 3;
-	uint32_t *bout = out + blk * (u64)K;
-	const scale_k SK = scale_consts();
-	const uint32_t *sm = seams + blk * 15;
-	// lane l <-> block samples [s, s+8), s = 472 tile + 8 (l - 5); out-of-block pieces are clamped (their values are replaced or unused).
-	// A lane's 32 contiguous bytes as two 16-byte register loads would make every wave load a stride-32 access: 32 cache-line
-	// accesses per instruction instead of 16, and the vector L1 -- which takes about four cycles per access on this part (a bare
-	// contiguous read stops at 7.1 TB/s) -- then caps the kernel near 4.3 TB/s (measured: 2.04 ms per 8 GiB whatever the
-	// number of loads in flight; PMC TCP_TOTAL_CACHE_ACCESSES = 31 per load instruction).  So the tile comes in lane-contiguous
-	// through LDS-DMA (global_load_lds_dwordx4: piece k of the tile from lane k & 63 of load k >> 6, straight into the wave's own
-	// 2 KiB of LDS, natural order) and every lane then reads ITS 32 bytes with two ds_read_b128.  Wave-private LDS: still no barrier.
-	__shared__ u32x4 stage[4][NT][128];
-	const unsigned wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-	const int s_max = (int)n - 4;
+	if (first) {
 #pragma unroll
-	for (int t = 0; t < NT; t++) {
-#pragma unroll
-		for (int h = 0; h < 2; h++) {
-			int sp = (int)((tile0 + t) * (FR_OUT * 8)) - 40 + 256 * h + 4 * (int)lane;
-			sp = sp < 0 ? 0 : (sp > s_max ? s_max : sp);
-			__builtin_amdgcn_global_load_lds((const void *)(braw + sp), (__attribute__((address_space(3))) void *)&stage[wv][t][64 * h], 16, 0, 2);
+		for (int t = 1; t <= 5; t++) {
+			const int hops = (t + NIN - 1) / NIN, idx = NIN * hops - t;
+			if (lane == 5u - (unsigned)hops)
+				in[idx] = sm[5 - t];
 		}
 	}
+	uint32_t xm[6];                                           // xm[t] = X[-t]
 #pragma unroll
-	for (int t = 0; t < NT; t++) {
-		const unsigned tile = tile0 + t;
-		if (t == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NT - 1)) : "memory");
-		else if (t == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NT > 1 ? NT - 2 : 0)) : "memory");
-		else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		const u32x4 va = stage[wv][t][2 * lane], vb = stage[wv][t][2 * lane + 1];
-		uint32_t x0, x1, x2, x3, x4, x5, x6, x7;
-		dec_contrib<false, ROTATE>(va, x0, x1, x2, x3, SK);
-		dec_contrib<false, ROTATE>(vb, x4, x5, x6, x7, SK);
-		const bool first = tile == 0;                        // wave-uniform
-		if (first && lane == 4) { x3 = sm[0]; x4 = sm[1]; x5 = sm[2]; x6 = sm[3]; x7 = sm[4]; }
-		// level 1
-		const uint32_t p3 = fr_shr(x3), p4 = fr_shr(x4), p5 = fr_shr(x5), p6 = fr_shr(x6), p7 = fr_shr(x7);
-		uint32_t y0 = fifth_pk(p3, p4, p5, p6, p7, x0);
-		uint32_t y1 = fifth_pk(p5, p6, p7, x0, x1, x2);
-		uint32_t y2 = fifth_pk(p7, x0, x1, x2, x3, x4);
-		uint32_t y3 = fifth_pk(x1, x2, x3, x4, x5, x6);
-		if (first) {
-			if (lane == 3) y3 = sm[5];
-			if (lane == 4) { y0 = sm[6]; y1 = sm[7]; y2 = sm[8]; y3 = sm[9]; }
+	for (int t = 1; t <= 5; t++) {
+		const int hops = (t + NIN - 1) / NIN, idx = NIN * hops - t;
+		uint32_t v = fr_shr(in[idx]);
+		if (hops > 1) v = fr_shr(v);
+		if (hops > 2) v = fr_shr(v);
+		xm[t] = v;
+	}
+#pragma unroll
+	for (int k = 0; k < NIN / 2; k++) {
+		uint32_t tap[6];
+#pragma unroll
+		for (int q = 0; q < 6; q++) {
+			const int i = 2 * k - 5 + q;
+			tap[q] = i >= 0 ? in[i >= 0 ? i : 0] : xm[i < 0 ? -i : 1];
 		}
-		// level 2
-		const uint32_t q0 = fr_shr(y0), q1 = fr_shr(y1), q2 = fr_shr(y2), q3 = fr_shr(y3), qq3 = fr_shr(q3);
-		uint32_t z0 = fifth_pk(qq3, q0, q1, q2, q3, y0);
-		uint32_t z1 = fifth_pk(q1, q2, q3, y0, y1, y2);
-		if (first) {
-			if (lane == 2) z1 = sm[10];
-			if (lane == 3) { z0 = sm[11]; z1 = sm[12]; }
-			if (lane == 4) { z0 = sm[13]; z1 = sm[14]; }
-		}
-		// level 3
-		const uint32_t r0 = fr_shr(z0), r1 = fr_shr(z1), rr0 = fr_shr(r0), rr1 = fr_shr(r1), rrr1 = fr_shr(rr1);
-		const uint32_t w = fifth_pk(rrr1, rr0, rr1, r0, r1, z0);
-		const unsigned j = tile * FR_OUT + lane - 5u;
-		if (lane >= 5u && j < K)
-			__builtin_nontemporal_store(w, bout + j);
+		out[k] = WIDE ? fifth_pk32(tap[0], tap[1], tap[2], tap[3], tap[4], tap[5]) : fifth_pk(tap[0], tap[1], tap[2], tap[3], tap[4], tap[5]);
 	}
 }
 
-// The same with FOUR passes and 16 samples per lane (x[16] -> y[8] -> z[4] -> w[2] -> v[1]): a cascade of four or more passes then
-// hands 1/16 of the capture to the next group instead of 1/8 -- the -F chains are bound by what they move through HBM, and the
-// first group's output is written once and read once.  The fourth pass sums exceed int16 (its inputs reach 1024): fifth_pk32.
-// Seams: 20 dwords per block (k_fm_fifth_seams<.., 4>).  n % 16 == 0.
-template <bool ROTATE>
-__global__ __launch_bounds__(256) void k_fm_fifth_reg4(const uint32_t *__restrict__ iq, unsigned n, unsigned tiles_per_block, unsigned wgs_per_block,
+template <bool ROTATE, int LV>
+__global__ __launch_bounds__(256) void k_fm_fifth_regn(const uint32_t *__restrict__ iq, unsigned n, unsigned tiles_per_block, unsigned wgs_per_block,
                                                        unsigned total_wgs, const uint32_t *__restrict__ seams, uint32_t *__restrict__ out)
 {
+	constexpr int R = 1 << LV, NP = R / 4;                   // samples per lane, 16-byte pieces per lane
+	static_assert(LV >= 3 && LV <= 5, "3 to 5 passes");
 	const unsigned lane = threadIdx.x & 63u;
-	const unsigned per = gridDim.x >> 3;                     // XCD-contiguous order, see k_fm_fifth_reg
+	const unsigned per = gridDim.x >> 3;                     // XCD-contiguous order, see k_fm_fifth_regn
 	const unsigned wgi = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
 	if (wgi >= total_wgs)
 		return;
@@ -2486,69 +2443,51 @@ __global__ __launch_bounds__(256) void k_fm_fifth_reg4(const uint32_t *__restric
 		return;
 	const u64 blk = blk32;
 	const uint32_t *braw = iq + blk * (u64)n;
-	const unsigned K = n >> 4;
+	const unsigned K = n >> LV;
 	uint32_t *bout = out + blk * (u64)K;
 	const scale_k SK = scale_consts();
-	const uint32_t *sm = seams + blk * 20;
-	// lane l <-> block samples [s, s+16), s = 944 tile + 16 (l - 5): the tile (1024 samples, 4 KiB) lane-contiguous through LDS-DMA
-	__shared__ u32x4 stage[4][256];
+	const uint32_t *sm = seams + blk * (5 * LV);
+	// lane l <-> block samples [s, s + R), s = 59 R tile + R (l - 5): the tile lane-contiguous through LDS-DMA, wave-private
+	__shared__ u32x4 stage[4][64 * NP];
 	const int s_max = (int)n - 4;
 #pragma unroll
-	for (int h = 0; h < 4; h++) {
-		int sp = (int)(tile * (FR_OUT * 16)) - 80 + 256 * h + 4 * (int)lane;
+	for (int h = 0; h < NP; h++) {
+		int sp = (int)(tile * (FR_OUT * R)) - 5 * R + 256 * h + 4 * (int)lane;
 		sp = sp < 0 ? 0 : (sp > s_max ? s_max : sp);
 		__builtin_amdgcn_global_load_lds((const void *)(braw + sp), (__attribute__((address_space(3))) void *)&stage[wv][64 * h], 16, 0, 2);
 	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	uint32_t x[16];
+	uint32_t x[R];
 #pragma unroll
-	for (int j = 0; j < 4; j++)
-		dec_contrib<false, ROTATE>(stage[wv][4 * lane + j], x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3], SK);
+	for (int j = 0; j < NP; j++)
+		dec_contrib<false, ROTATE>(stage[wv][NP * lane + j], x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3], SK);
 	const bool first = tile == 0;                            // wave-uniform
-	if (first && lane == 4) { x[11] = sm[0]; x[12] = sm[1]; x[13] = sm[2]; x[14] = sm[3]; x[15] = sm[4]; }
-	// level 1: y[k] = W(X[2k-5 .. 2k]), X[-5..-1] = the left neighbour's x11..x15
-	uint32_t y[8];
-	{
-		const uint32_t p11 = fr_shr(x[11]), p12 = fr_shr(x[12]), p13 = fr_shr(x[13]), p14 = fr_shr(x[14]), p15 = fr_shr(x[15]);
-		y[0] = fifth_pk(p11, p12, p13, p14, p15, x[0]);
-		y[1] = fifth_pk(p13, p14, p15, x[0], x[1], x[2]);
-		y[2] = fifth_pk(p15, x[0], x[1], x[2], x[3], x[4]);
-#pragma unroll
-		for (int k = 3; k < 8; k++)
-			y[k] = fifth_pk(x[2 * k - 5], x[2 * k - 4], x[2 * k - 3], x[2 * k - 2], x[2 * k - 1], x[2 * k]);
+	uint32_t res;
+	if constexpr (LV == 3) {
+		uint32_t y[4], z[2], w[1];
+		fr_level<8, false>(x, y, lane, first, sm);
+		fr_level<4, false>(y, z, lane, first, sm + 5);
+		fr_level<2, false>(z, w, lane, first, sm + 10);
+		res = w[0];
+	} else if constexpr (LV == 4) {
+		uint32_t y[8], z[4], w[2], v[1];
+		fr_level<16, false>(x, y, lane, first, sm);
+		fr_level<8, false>(y, z, lane, first, sm + 5);
+		fr_level<4, false>(z, w, lane, first, sm + 10);
+		fr_level<2, true>(w, v, lane, first, sm + 15);
+		res = v[0];
+	} else {
+		uint32_t y[16], z[8], w[4], v[2], u[1];
+		fr_level<32, false>(x, y, lane, first, sm);
+		fr_level<16, false>(y, z, lane, first, sm + 5);
+		fr_level<8, false>(z, w, lane, first, sm + 10);
+		fr_level<4, true>(w, v, lane, first, sm + 15);
+		fr_level<2, true>(v, u, lane, first, sm + 20);
+		res = u[0];
 	}
-	if (first && lane == 4) { y[3] = sm[5]; y[4] = sm[6]; y[5] = sm[7]; y[6] = sm[8]; y[7] = sm[9]; }
-	// level 2: z[k] = W(Y[2k-5 .. 2k]), Y[-5..-1] = the left neighbour's y3..y7
-	uint32_t z[4];
-	{
-		const uint32_t q3 = fr_shr(y[3]), q4 = fr_shr(y[4]), q5 = fr_shr(y[5]), q6 = fr_shr(y[6]), q7 = fr_shr(y[7]);
-		z[0] = fifth_pk(q3, q4, q5, q6, q7, y[0]);
-		z[1] = fifth_pk(q5, q6, q7, y[0], y[1], y[2]);
-		z[2] = fifth_pk(q7, y[0], y[1], y[2], y[3], y[4]);
-		z[3] = fifth_pk(y[1], y[2], y[3], y[4], y[5], y[6]);
-	}
-	if (first) {
-		if (lane == 3) z[3] = sm[10];
-		if (lane == 4) { z[0] = sm[11]; z[1] = sm[12]; z[2] = sm[13]; z[3] = sm[14]; }
-	}
-	// level 3: w[k] = W(Z[2k-5 .. 2k]), Z[-4..-1] = the neighbour's z0..z3, Z[-5] = the neighbour-but-one's z3
-	uint32_t w0, w1;
-	{
-		const uint32_t r0 = fr_shr(z[0]), r1 = fr_shr(z[1]), r2 = fr_shr(z[2]), r3 = fr_shr(z[3]), rr3 = fr_shr(r3);
-		w0 = fifth_pk(rr3, r0, r1, r2, r3, z[0]);
-		w1 = fifth_pk(r1, r2, r3, z[0], z[1], z[2]);
-	}
-	if (first) {
-		if (lane == 2) w1 = sm[15];
-		if (lane == 3) { w0 = sm[16]; w1 = sm[17]; }
-		if (lane == 4) { w0 = sm[18]; w1 = sm[19]; }
-	}
-	// level 4 (32-bit sums): v = W(w of lanes l-3 .. l)
-	const uint32_t t0 = fr_shr(w0), t1 = fr_shr(w1), tt0 = fr_shr(t0), tt1 = fr_shr(t1), ttt1 = fr_shr(tt1);
-	const uint32_t v = fifth_pk32(ttt1, tt0, tt1, t0, t1, w0);
 	const unsigned j = tile * FR_OUT + lane - 5u;
 	if (lane >= 5u && j < K)
-		__builtin_nontemporal_store(v, bout + j);
+		__builtin_nontemporal_store(res, bout + j);
 }
 
 // ------------------------------------------------------------------ F12 droop FIR
@@ -3649,10 +3588,15 @@ extern "C" int rxk_fm_fifth_seams(void *stream, const void *in, int stage2, int 
 	const unsigned sgrid = (unsigned)((seam_threads + 255) / 256);
 	const uint32_t *p = (const uint32_t *)in;
 	hipStream_t s = (hipStream_t)stream;
-	if (fuse == 4 && !stage2) {                                  /* the four-pass register kernel's layout: 20 dwords per block */
+	if (fuse >= 4 && !stage2) {                                  /* the four- / five-pass register kernels' layout: 5 * fuse dwords per block */
 		const unsigned sgrid4 = (unsigned)(((n_blocks + 1) * 32 + 255) / 256);
-		if (rotate) hipLaunchKernelGGL((k_fm_fifth_seams<true, false, 4>), dim3(sgrid4), dim3(256), 0, s, p, n_blocks, n, fuse, hist_in, seams, hist_out);
-		else hipLaunchKernelGGL((k_fm_fifth_seams<false, false, 4>), dim3(sgrid4), dim3(256), 0, s, p, n_blocks, n, fuse, hist_in, seams, hist_out);
+		if (fuse == 4) {
+			if (rotate) hipLaunchKernelGGL((k_fm_fifth_seams<true, false, 4>), dim3(sgrid4), dim3(256), 0, s, p, n_blocks, n, fuse, hist_in, seams, hist_out);
+			else hipLaunchKernelGGL((k_fm_fifth_seams<false, false, 4>), dim3(sgrid4), dim3(256), 0, s, p, n_blocks, n, fuse, hist_in, seams, hist_out);
+		} else {
+			if (rotate) hipLaunchKernelGGL((k_fm_fifth_seams<true, false, 5>), dim3(sgrid4), dim3(256), 0, s, p, n_blocks, n, fuse, hist_in, seams, hist_out);
+			else hipLaunchKernelGGL((k_fm_fifth_seams<false, false, 5>), dim3(sgrid4), dim3(256), 0, s, p, n_blocks, n, fuse, hist_in, seams, hist_out);
+		}
 		LAUNCH_RET();
 	}
 	if (stage2) hipLaunchKernelGGL((k_fm_fifth_seams<false, true>), dim3(sgrid), dim3(256), 0, s, p, n_blocks, n, fuse, hist_in, seams, hist_out);
@@ -3680,39 +3624,23 @@ extern "C" int rxk_fm_fifth_fused(void *stream, const void *in, int stage2, int 
 	const size_t pad = stage2 ? 0 : getenv("RXGPU_FF_PAD") ? (size_t)atoi(getenv("RXGPU_FF_PAD")) : 17000;
 #define FUSED(F, RT, S2) hipLaunchKernelGGL((k_fm_fifth_fused<F, RT, S2, false>), dim3(grid), dim3(256), pad, s, p, n, tiles, tpw, seams, out, n, n >> F)
 #define GO(RT, S2) do { if (hist_in) SEAMS(RT, S2); if (fuse == 1) FUSED(1, RT, S2); else if (fuse == 2) FUSED(2, RT, S2); else FUSED(3, RT, S2); } while (0)
-	/* four passes on the raw capture: the 16-samples-per-lane register kernel */
-	if (!stage2 && fuse == 4) {
-		const unsigned tiles_r = ((n >> 4) + FR_OUT - 1) / FR_OUT;
+	/* four (or five) passes on the raw capture: the register kernel, 16 (32) samples per lane.  Three passes stay with the LDS-tiled kernel
+	 * below -- in the -M wbfm -F 9 chain it is 3-5 % ahead (A/B) -- unless $RXGPU_FR_GENERIC=1 (tests: the LV = 3 instantiation) */
+	if (!stage2 && (fuse == 4 || fuse == 5 || (fuse == 3 && getenv("RXGPU_FR_GENERIC")))) {
+		const unsigned tiles_r = ((n >> fuse) + FR_OUT - 1) / FR_OUT;
 		const unsigned wgs_per_block = (tiles_r + 3) / 4;
 		const u64 total = n_blocks * (u64)wgs_per_block;
 		if (total > 0xfffffff0ull)
 			return (int)hipErrorInvalidValue;
 		const unsigned rgrid = (unsigned)((total + 7) / 8 * 8);
-		const unsigned sgrid4 = (unsigned)(((n_blocks + 1) * 32 + 255) / 256);
-		if (hist_in) {
-			if (rotate) hipLaunchKernelGGL((k_fm_fifth_seams<true, false, 4>), dim3(sgrid4), dim3(256), 0, s, p, n_blocks, n, fuse, hist_in, seams, hist_out);
-			else hipLaunchKernelGGL((k_fm_fifth_seams<false, false, 4>), dim3(sgrid4), dim3(256), 0, s, p, n_blocks, n, fuse, hist_in, seams, hist_out);
-		}
-		if (rotate) hipLaunchKernelGGL((k_fm_fifth_reg4<true>), dim3(rgrid), dim3(256), 0, s, p, n, tiles_r, wgs_per_block, (unsigned)total, seams, out);
-		else hipLaunchKernelGGL((k_fm_fifth_reg4<false>), dim3(rgrid), dim3(256), 0, s, p, n, tiles_r, wgs_per_block, (unsigned)total, seams, out);
-		LAUNCH_RET();
-	}
-	/* three passes on the raw capture: the register / DPP kernel (no LDS, no barriers); $RXGPU_FIFTH_LDS=1 keeps the LDS-tiled one */
-	if (!stage2 && fuse == 3 && !getenv("RXGPU_FIFTH_LDS")) {
-		const unsigned tiles_r = ((n >> 3) + FR_OUT - 1) / FR_OUT;
-		/* tiles per wave, all loads issued up front; $RXGPU_FR_NT = 1 | 2 | 4 */
-		const int nt = getenv("RXGPU_FR_NT") ? atoi(getenv("RXGPU_FR_NT")) : 2;
-		const unsigned per_wg = 4u * (unsigned)(nt == 4 ? 4 : nt == 2 ? 2 : 1);
-		const unsigned wgs_per_block = (tiles_r + per_wg - 1) / per_wg;
-		const u64 total = n_blocks * (u64)wgs_per_block;
-		if (total > 0xfffffff0ull)
-			return (int)hipErrorInvalidValue;
-		const unsigned rgrid = (unsigned)((total + 7) / 8 * 8);
-		if (hist_in) { if (rotate) SEAMS(true, false); else SEAMS(false, false); }
-#define FREG(RT, NT) hipLaunchKernelGGL((k_fm_fifth_reg<RT, NT>), dim3(rgrid), dim3(256), 0, s, p, n, tiles_r, wgs_per_block, (unsigned)total, seams, out)
-		if (rotate) { if (nt == 4) FREG(true, 4); else if (nt == 2) FREG(true, 2); else FREG(true, 1); }
-		else { if (nt == 4) FREG(false, 4); else if (nt == 2) FREG(false, 2); else FREG(false, 1); }
-#undef FREG
+		const unsigned sgridn = (unsigned)(((n_blocks + 1) * (fuse == 3 ? 16 : 32) + 255) / 256);
+#define SEAMN(RT, LVV) hipLaunchKernelGGL((k_fm_fifth_seams<RT, false, LVV>), dim3(sgridn), dim3(256), 0, s, p, n_blocks, n, fuse, hist_in, seams, hist_out)
+#define REGN(RT, LVV) hipLaunchKernelGGL((k_fm_fifth_regn<RT, LVV>), dim3(rgrid), dim3(256), 0, s, p, n, tiles_r, wgs_per_block, (unsigned)total, seams, out)
+#define GON(LVV) do { if (rotate) { if (hist_in) SEAMN(true, LVV); REGN(true, LVV); } else { if (hist_in) SEAMN(false, LVV); REGN(false, LVV); } } while (0)
+		if (fuse == 3) GON(3); else if (fuse == 4) GON(4); else GON(5);
+#undef GON
+#undef REGN
+#undef SEAMN
 		LAUNCH_RET();
 	}
 	if (stage2) GO(false, true);

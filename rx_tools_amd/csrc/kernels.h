@@ -169,12 +169,12 @@ int rxk_fm_passthrough_carry(void *stream, rxk_fm_dev *dev, int deemph_off, int 
 int rxk_fm_fifth_pass(void *stream, const void *in, int in_is_raw, int prescaled, int rotate,
                       unsigned long long n_blocks, unsigned n_in, unsigned in_stride, uint32_t *out,
                       unsigned out_stride, const int16_t *hist_in, int16_t *hist_out);
-/* `fuse` (1..3) passes of the cascade in one launch; n % RXK_FIFTH_TILE == 0.  Raw input (stage2 == 0) also takes fuse == 4 (n % 16 == 0;
- * seams then holds 20 dwords per block): three and four passes from raw run in registers (k_fm_fifth_reg / _reg4: lane-contiguous runs,
- * neighbours by DPP, no LDS tiles, no barriers), everything else in the LDS-tiled kernel.
+/* `fuse` (1..3) passes of the cascade in one launch; n % RXK_FIFTH_TILE == 0.  Raw input (stage2 == 0) also takes fuse == 4 and 5 (n % 2^fuse == 0;
+ * seams then holds 5 * fuse dwords per block): those run in registers (k_fm_fifth_regn: lane-contiguous runs, neighbours by DPP, no LDS
+ * tiles, no barriers; $RXGPU_FR_GENERIC=1: fuse == 3 too), everything else in the LDS-tiled kernel.
  * stage2 == 0: raw cs16 input (scale + rotate on the fly; packed-int16 arithmetic is exact through three
  * passes from raw).  stage2 != 0: packed level samples in, the reference's int arithmetic; hist_in/hist_out
- * point at the first pass of the group.  seams: n_blocks*15 dwords of scratch. */
+ * point at the first pass of the group.  seams: n_blocks * 5 * fuse dwords of scratch. */
 #define RXK_FIFTH_TILE 2048
 int rxk_fm_fifth_seams(void *stream, const void *in, int stage2, int rotate, unsigned long long n_blocks, unsigned n, int fuse,
                        const int16_t *hist_in, int16_t *hist_out, uint32_t *seams);

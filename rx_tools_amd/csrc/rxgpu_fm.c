@@ -290,7 +290,7 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 			const int fuse = params->downsample_passes < 3 ? params->downsample_passes : 3;
 			for (int i = 0; i < 2; i++) {
 				DMALLOC(s->cas_a[i], ((s->max_T >> fuse) + max_blocks) * 4);
-				DMALLOC(s->seams_a[i], (max_blocks + 1) * 20 * 4);             /* up to four levels of five history samples per block */
+				DMALLOC(s->seams_a[i], (max_blocks + 1) * 25 * 4);             /* up to five levels of five history samples per block */
 			}
 			if (hipEventCreateWithFlags(&s->ev_up, hipEventDisableTiming) != hipSuccess ||
 			    hipEventCreateWithFlags(&s->ev_seam[0], hipEventDisableTiming) != hipSuccess ||
@@ -634,7 +634,8 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 	/* -F on the raw capture: the first fused group of fifth_order passes reads 8/9 of all the bytes of the run; like the
 	 * boxcar decimator it goes on stream A, so that it overlaps the later passes and the audio stages of the run before */
 	/* four passes in that group where the cascade has them (the next group then reads 1/16 of the capture, not 1/8); $RXGPU_FUSE_A=3 keeps three */
-	const int fuse_a_max = (getenv("RXGPU_FUSE_A") && atoi(getenv("RXGPU_FUSE_A")) == 3) ? 3 : 4;
+	const int fuse_a_env = getenv("RXGPU_FUSE_A") ? atoi(getenv("RXGPU_FUSE_A")) : 0;
+	const int fuse_a_max = (fuse_a_env >= 3 && fuse_a_env <= 5) ? fuse_a_env : 4;
 	const int fuse_a = (g->passes && !g->literal && !prescaled && (g->n % RXK_FIFTH_TILE) == 0 && s->cas_a[0]) ? (g->passes < fuse_a_max ? g->passes : fuse_a_max) : 0;
 	const int fresh = !s->chained;
 

@@ -153,6 +153,22 @@ def test_fifth_order_two_fused_stages(passes, fir, n):
     _check(iq, 2 * n, n_runs=2, pipelined=True, downsample_passes=passes, comp_fir_size=fir, offset_tuning=1)
 
 
+@pytest.mark.parametrize("env,passes", [({"RXGPU_FUSE_A": "3", "RXGPU_FR_GENERIC": "1"}, 3), ({"RXGPU_FUSE_A": "3", "RXGPU_FR_GENERIC": "1"}, 7),
+                                        ({"RXGPU_FUSE_A": "5"}, 5), ({"RXGPU_FUSE_A": "5"}, 9), ({"RXGPU_FUSE_A": "3"}, 7)])
+def test_first_group_depths(env, passes, monkeypatch):
+    """the register kernel of the first group is one template for 3, 4 and 5 passes (4 is what every other test runs); the knobs
+    that pick the other depths -- and the LDS-tiled kernel for three -- give the same bits, seams and histories included"""
+    from gpu_support import carry_tuple, carry_from_oracle_state
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    n = 131072
+    for iq, off in ((sig_fm(3 * n, seed=61), 0), (sig_noise(6 * n, seed=62), 1), (np.full(6 * n, -32768, np.int16), 0)):
+        carry, st = _check(iq, 2 * n, downsample_passes=passes, comp_fir_size=9, offset_tuning=off)
+        want, got = carry_tuple(carry_from_oracle_state(st)), carry_tuple(carry)
+        assert got[8][:12 * passes] == want[8][:12 * passes] and got[9][:12 * passes] == want[9][:12 * passes]
+    _check(sig_noise(8 * n, seed=63, amp=30000), 2 * n, n_runs=2, pipelined=True, downsample_passes=passes, comp_fir_size=0)
+
+
 def test_fifth_order_carry_across_runs():
     iq = sig_noise(12 * 16384, seed=21, amp=20000)
     _check(iq, 16384, n_runs=3, downsample_passes=3, comp_fir_size=9)
