@@ -2425,14 +2425,60 @@ __device__ __forceinline__ void fr_level(uint32_t (&in)[NIN], uint32_t (&out)[NI
 	}
 }
 
-template <bool ROTATE, int LV>
-__global__ __launch_bounds__(256) void k_fm_fifth_regn(const uint32_t *__restrict__ iq, unsigned n, unsigned tiles_per_block, unsigned wgs_per_block,
-                                                       unsigned total_wgs, const uint32_t *__restrict__ seams, uint32_t *__restrict__ out)
+// LEFT more levels on NIN values per lane; DONE = passes already behind them (their seams at sm + 5 DONE; 32-bit sums from the fourth on)
+template <int NIN, int LEFT, int DONE>
+__device__ __forceinline__ void fr_cascade(uint32_t (&in)[NIN], uint32_t (&res)[NIN >> LEFT], unsigned lane, bool first, const uint32_t *__restrict__ sm)
 {
-	constexpr int R = 1 << LV, NP = R / 4;                   // samples per lane, 16-byte pieces per lane
-	static_assert(LV >= 3 && LV <= 5, "3 to 5 passes");
+	if constexpr (LEFT == 0) {
+#pragma unroll
+		for (int k = 0; k < NIN; k++)
+			res[k] = in[k];
+	} else {
+		uint32_t o[NIN / 2];
+		fr_level<NIN, (DONE >= 3)>(in, o, lane, first, sm + 5 * DONE);
+		fr_cascade<NIN / 2, LEFT - 1, DONE + 1>(o, res, lane, first, sm);
+	}
+}
+
+// the -A fast discriminator on two packed samples (multiply_conjugate + fast_atan2, rtl_fm.c:467-513)
+__device__ __forceinline__ int disc_fast(uint32_t a, uint32_t b)
+{
+	const int ar = lo16(a), aj = hi16(a), br = lo16(b), bj = hi16(b);
+	const int cr = (int)((unsigned)ar * (unsigned)br + (unsigned)aj * (unsigned)bj);
+	const int cj = (int)((unsigned)aj * (unsigned)br - (unsigned)ar * (unsigned)bj);
+	return fast_atan2_dev(cj, cr);
+}
+
+// generic_fir's sum over the nine samples w[0..8] BEFORE an output (rtl_fm.c:442-465); 24-bit multiplies, see k_fm_droop
+__device__ __forceinline__ uint32_t droop9(const uint32_t *w, int f1, int f2, int f3, int f4, int f5)
+{
+	const int si = __mul24(lo16(w[0]) + lo16(w[8]), f1) + __mul24(lo16(w[1]) + lo16(w[7]), f2) + __mul24(lo16(w[2]) + lo16(w[6]), f3) +
+	               __mul24(lo16(w[3]) + lo16(w[5]), f4) + __mul24(lo16(w[4]), f5);
+	const int sq = __mul24(hi16(w[0]) + hi16(w[8]), f1) + __mul24(hi16(w[1]) + hi16(w[7]), f2) + __mul24(hi16(w[2]) + hi16(w[6]), f3) +
+	               __mul24(hi16(w[3]) + hi16(w[5]), f4) + __mul24(hi16(w[4]), f5);
+	return pack_iq(si >> 15, sq >> 15);
+}
+
+// DD == 0: the cascade alone, one output per lane into `out`.
+// DD != 0: the WHOLE -F chain of a cascade that fits the group -- LV passes, then (DD == 2) the droop FIR, then the -A fast discriminator --
+// with nothing but pcm leaving the kernel (the `-M wbfm -F 9` chain wrote the 1/8-rate stream and read it back: 2 of its 13 GB per step).
+// A lane then owns 4 << LV samples and four level-LV outputs w[4l .. 4l+3]; the FIR's nine samples before an output sit in the two lanes to
+// the left and one register of the third (9 wave_shr moves), the discriminator's previous FIR output one more move away; the five halo
+// lanes cover that (35 + 80 samples of 160).  At a block's start the previous block's last ten level-LV samples (k_fm_fifth_tails: the FIR and
+// the discriminator run on across callback blocks, rtl_fm.c:442-465, 485-513) are written over the halo lanes' w before the FIR.  Two things
+// are left to a small kernel behind this one (k_fm_dd_edges, stream B: they need the previous run's carries and the libm flag list): each
+// block's FIRST demodulated sample -- polar_discriminant in double, rtl_fm.c:476-483, 667-682 -- and pre_r/pre_j; for them the kernel leaves
+// each block's first and last FIR output in `edges`.
+template <bool ROTATE, int LV, int DD>
+__global__ __launch_bounds__(256) void k_fm_fifth_regn(const uint32_t *__restrict__ iq, unsigned n, unsigned tiles_per_block, unsigned wgs_per_block,
+                                                       unsigned total_wgs, const uint32_t *__restrict__ seams, uint32_t *__restrict__ out,
+                                                       const uint32_t *__restrict__ tails, int f1, int f2, int f3, int f4, int f5,
+                                                       int16_t *__restrict__ pcm, int pcm_chl2, uint32_t *__restrict__ edges)
+{
+	constexpr int NOUT = DD ? 4 : 1, R = NOUT << LV, NP = R / 4;   // outputs and samples per lane, 16-byte pieces per lane
+	static_assert(LV >= 3 && LV <= 5 && NP <= 16, "3 to 5 passes");
 	const unsigned lane = threadIdx.x & 63u;
-	const unsigned per = gridDim.x >> 3;                     // XCD-contiguous order, see k_fm_fifth_regn
+	const unsigned per = gridDim.x >> 3;                     // XCD-contiguous order: workgroup b runs on XCD b % 8, every XCD takes one contiguous eighth
 	const unsigned wgi = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
 	if (wgi >= total_wgs)
 		return;
@@ -2444,50 +2490,134 @@ __global__ __launch_bounds__(256) void k_fm_fifth_regn(const uint32_t *__restric
 	const u64 blk = blk32;
 	const uint32_t *braw = iq + blk * (u64)n;
 	const unsigned K = n >> LV;
-	uint32_t *bout = out + blk * (u64)K;
 	const scale_k SK = scale_consts();
 	const uint32_t *sm = seams + blk * (5 * LV);
-	// lane l <-> block samples [s, s + R), s = 59 R tile + R (l - 5): the tile lane-contiguous through LDS-DMA, wave-private
+	// lane l <-> block samples [s, s + R), s = 59 R tile + R (l - 5): the tile comes in through LDS-DMA (whole lines), wave-private.
+	// Slot (h, lane) of the stage takes the piece its READER wants there: lane l reads its j-th piece from slot NP l + (j + rot(l)) % NP,
+	// rot(l) = l NP / 16 -- sixteen neighbouring lanes' b128 reads then fall on sixteen different bank groups
 	__shared__ u32x4 stage[4][64 * NP];
 	const int s_max = (int)n - 4;
 #pragma unroll
 	for (int h = 0; h < NP; h++) {
-		int sp = (int)(tile * (FR_OUT * R)) - 5 * R + 256 * h + 4 * (int)lane;
+		const unsigned slot = 64u * h + lane, sl = slot / NP, sj = (slot - (sl * NP) / 16u) % NP;   // slot % NP - rot(sl), mod NP (NP | 64 h + ...)
+		int sp = (int)(tile * (FR_OUT * R)) - 5 * R + (int)(4u * (sl * NP + sj));
 		sp = sp < 0 ? 0 : (sp > s_max ? s_max : sp);
 		__builtin_amdgcn_global_load_lds((const void *)(braw + sp), (__attribute__((address_space(3))) void *)&stage[wv][64 * h], 16, 0, 2);
 	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	uint32_t x[R];
+	const unsigned rot = (lane * NP) / 16u;
 #pragma unroll
 	for (int j = 0; j < NP; j++)
-		dec_contrib<false, ROTATE>(stage[wv][NP * lane + j], x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3], SK);
+		dec_contrib<false, ROTATE>(stage[wv][NP * lane + ((j + rot) % NP)], x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3], SK);
 	const bool first = tile == 0;                            // wave-uniform
-	uint32_t res;
-	if constexpr (LV == 3) {
-		uint32_t y[4], z[2], w[1];
-		fr_level<8, false>(x, y, lane, first, sm);
-		fr_level<4, false>(y, z, lane, first, sm + 5);
-		fr_level<2, false>(z, w, lane, first, sm + 10);
-		res = w[0];
-	} else if constexpr (LV == 4) {
-		uint32_t y[8], z[4], w[2], v[1];
-		fr_level<16, false>(x, y, lane, first, sm);
-		fr_level<8, false>(y, z, lane, first, sm + 5);
-		fr_level<4, false>(z, w, lane, first, sm + 10);
-		fr_level<2, true>(w, v, lane, first, sm + 15);
-		res = v[0];
+	uint32_t w[NOUT];
+	fr_cascade<R, LV, 0>(x, w, lane, first, sm);
+	const unsigned j = tile * FR_OUT + lane - 5u;            // the lane's place among the block's K / NOUT lanes
+	if constexpr (DD == 0) {
+		if (lane >= 5u && j < K)
+			__builtin_nontemporal_store(w[0], out + blk * (u64)K + j);
 	} else {
-		uint32_t y[16], z[8], w[4], v[2], u[1];
-		fr_level<32, false>(x, y, lane, first, sm);
-		fr_level<16, false>(y, z, lane, first, sm + 5);
-		fr_level<8, false>(z, w, lane, first, sm + 10);
-		fr_level<4, true>(w, v, lane, first, sm + 15);
-		fr_level<2, true>(v, u, lane, first, sm + 20);
-		res = u[0];
+		if (first) {
+			const uint32_t *tl = tails + blk * 10;               // the previous block's level-LV samples K-10 .. K-1
+			if (lane == 4u) { w[0] = tl[6]; w[1] = tl[7]; w[2] = tl[8]; w[3] = tl[9]; }
+			else if (lane == 3u) { w[0] = tl[2]; w[1] = tl[3]; w[2] = tl[4]; w[3] = tl[5]; }
+			else if (lane == 2u) { w[2] = tl[0]; w[3] = tl[1]; }
+		}
+		uint32_t y[4];
+		if constexpr (DD == 2) {
+			uint32_t W[13];                                      // W[i] = level-LV sample 4l - 9 + i
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				W[9 + k] = w[k];
+				W[5 + k] = fr_shr(w[k]);
+				W[1 + k] = fr_shr(W[5 + k]);
+			}
+			W[0] = fr_shr(W[4]);
+#pragma unroll
+			for (int k = 0; k < 4; k++)
+				y[k] = droop9(W + k, f1, f2, f3, f4, f5);
+		} else {
+#pragma unroll
+			for (int k = 0; k < 4; k++)
+				y[k] = w[k];
+		}
+		const uint32_t yp = fr_shr(y[3]);
+		if (lane >= 5u && 4u * j < K) {
+			const int r0 = j ? disc_fast(y[0], yp) : 0;           // a block's first sample: k_fm_dd_edges
+			const int r1 = disc_fast(y[1], y[0]), r2 = disc_fast(y[2], y[1]), r3 = disc_fast(y[3], y[2]);
+			const u64 m0 = blk * (u64)K + 4u * j;
+			int16_t *dst = pcm + pcm_index(m0, pcm_chl2);        // four consecutive samples stay inside one 16-byte unit of the tiled layout
+			*reinterpret_cast<uint2 *>(dst) = make_uint2((uint32_t)(uint16_t)r0 | ((uint32_t)(uint16_t)r1 << 16), (uint32_t)(uint16_t)r2 | ((uint32_t)(uint16_t)r3 << 16));
+			if (j == 0)
+				edges[2 * blk] = y[0];
+			if (4u * j + 4u == K)
+				edges[2 * blk + 1] = y[3];
+		}
 	}
-	const unsigned j = tile * FR_OUT + lane - 5u;
-	if (lane >= 5u && j < K)
-		__builtin_nontemporal_store(res, bout + j);
+}
+
+// the previous block's last ten level-LV samples for every block (block 0: the carried droop history hist[0..8] = s[-9..-1], or nothing
+// without the FIR), and behind the last block the new droop history, its last nine (rtl_fm.c:453-463)
+template <bool ROTATE, int LV>
+__global__ void k_fm_fifth_tails(const uint32_t *__restrict__ iq, u64 n_blocks, unsigned n, const int16_t *__restrict__ droop_in,
+                                 int16_t *__restrict__ droop_out, uint32_t *__restrict__ tails)
+{
+	const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	const u64 b = gid / 16;
+	const int q = (int)(gid % 16);
+	if (q >= 10 || b > n_blocks)
+		return;
+	const int K = (int)(n >> LV);
+	if (b == 0) {
+		tails[q] = (droop_in && q) ? pack_iq(droop_in[q - 1], droop_in[9 + q - 1]) : 0u;
+		return;
+	}
+	const uint32_t v = level_val<LV, ROTATE, false>(iq + (b - 1) * (u64)n, K - 10 + q);
+	if (b < n_blocks)
+		tails[b * 10 + q] = v;
+	else if (droop_out && q) {
+		droop_out[q - 1] = (int16_t)lo16(v);
+		droop_out[9 + q - 1] = (int16_t)hi16(v);
+	}
+}
+
+// what k_fm_fifth_regn<.., DD> leaves: each block's first demodulated sample (libm, with the 2^-33 window and the host fix-up records
+// like k_fm_droop_disc) from the block's first FIR output and the previous block's last -- the carried pre_r/pre_j for block 0 -- and the
+// run's pre_r/pre_j out
+__global__ void k_fm_dd_edges(const uint32_t *__restrict__ edges, u64 n_blocks, u64 K, int16_t *__restrict__ pcm, int pcm_chl2, rxk_fm_dev *__restrict__ dev,
+                              rxk_flag_rec *__restrict__ flag_list, int *__restrict__ flag_cnt, int flag_all)
+{
+	const u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= n_blocks)
+		return;
+	const uint32_t a = edges[2 * b];
+	const int ar = lo16(a), aj = hi16(a);
+	int br, bj;
+	if (b) { br = lo16(edges[2 * b - 1]); bj = hi16(edges[2 * b - 1]); }
+	else { br = dev->in_pre_r; bj = dev->in_pre_j; }
+	const int cr = (int)((unsigned)ar * (unsigned)br + (unsigned)aj * (unsigned)bj);
+	const int cj = (int)((unsigned)aj * (unsigned)br - (unsigned)ar * (unsigned)bj);
+	const u64 m = b * K;
+	// polar_discriminant, rtl_fm.c:476-483 (see k_fm_disc)
+	const double v = atan2((double)cj, (double)cr) / 3.14159 * 16384.0;
+	int out = (int)v;
+	if (v != 0.0 && (flag_all || fabs(v - rint(v)) < RXK_LIBM_WINDOW)) {
+		const int idx = atomicAdd(flag_cnt, 1);
+		if (idx < RXK_FLAG_CAP) {
+			rxk_flag_rec rec;
+			rec.m = m; rec.ar = ar; rec.aj = aj; rec.br = br; rec.bj = bj;
+			flag_list[idx] = rec;
+		}
+		if (flag_all > 1)
+			out += 77;
+	}
+	pcm[pcm_index(m, pcm_chl2)] = (int16_t)out;
+	if (b == n_blocks - 1) {
+		const uint32_t l = edges[2 * b + 1];
+		dev->out_pre_r = lo16(l);
+		dev->out_pre_j = hi16(l);
+	}
 }
 
 // ------------------------------------------------------------------ F12 droop FIR
@@ -3635,7 +3765,8 @@ extern "C" int rxk_fm_fifth_fused(void *stream, const void *in, int stage2, int 
 		const unsigned rgrid = (unsigned)((total + 7) / 8 * 8);
 		const unsigned sgridn = (unsigned)(((n_blocks + 1) * (fuse == 3 ? 16 : 32) + 255) / 256);
 #define SEAMN(RT, LVV) hipLaunchKernelGGL((k_fm_fifth_seams<RT, false, LVV>), dim3(sgridn), dim3(256), 0, s, p, n_blocks, n, fuse, hist_in, seams, hist_out)
-#define REGN(RT, LVV) hipLaunchKernelGGL((k_fm_fifth_regn<RT, LVV>), dim3(rgrid), dim3(256), 0, s, p, n, tiles_r, wgs_per_block, (unsigned)total, seams, out)
+#define REGN(RT, LVV) hipLaunchKernelGGL((k_fm_fifth_regn<RT, LVV, 0>), dim3(rgrid), dim3(256), 0, s, p, n, tiles_r, wgs_per_block, (unsigned)total, seams, out, \
+		                                     (const uint32_t *)nullptr, 0, 0, 0, 0, 0, (int16_t *)nullptr, 0, (uint32_t *)nullptr)
 #define GON(LVV) do { if (rotate) { if (hist_in) SEAMN(true, LVV); REGN(true, LVV); } else { if (hist_in) SEAMN(false, LVV); REGN(false, LVV); } } while (0)
 		if (fuse == 3) GON(3); else if (fuse == 4) GON(4); else GON(5);
 #undef GON
@@ -3649,6 +3780,48 @@ extern "C" int rxk_fm_fifth_fused(void *stream, const void *in, int stage2, int 
 #undef GO
 #undef FUSED
 #undef SEAMS
+	LAUNCH_RET();
+}
+
+// the whole -F chain of a three-pass cascade in one launch (k_fm_fifth_regn<.., 3, DD>): seams from rxk_fm_fifth_seams (fuse = 3), tails from
+// rxk_fm_fifth_tails; fir == NULL: no droop FIR.  n % RXK_FIFTH_TILE == 0
+extern "C" int rxk_fm_fifth_dd(void *stream, const void *in, int rotate, u64 n_blocks, unsigned n, int fuse, const uint32_t *seams, const uint32_t *tails,
+                               const int *fir, int16_t *pcm, int pcm_chl2, uint32_t *edges)
+{
+	if (fuse != 3)
+		return (int)hipErrorInvalidValue;
+	hipStream_t s = (hipStream_t)stream;
+	const uint32_t *p = (const uint32_t *)in;
+	const unsigned tiles_r = ((n >> fuse) / 4 + FR_OUT - 1) / FR_OUT;
+	const unsigned wgs_per_block = (tiles_r + 3) / 4;
+	const u64 total = n_blocks * (u64)wgs_per_block;
+	if (total > 0xfffffff0ull)
+		return (int)hipErrorInvalidValue;
+	const unsigned rgrid = (unsigned)((total + 7) / 8 * 8);
+#define DDK(RT, D) hipLaunchKernelGGL((k_fm_fifth_regn<RT, 3, D>), dim3(rgrid), dim3(256), 0, s, p, n, tiles_r, wgs_per_block, (unsigned)total, seams, (uint32_t *)nullptr, \
+		                              tails, fir ? fir[1] : 0, fir ? fir[2] : 0, fir ? fir[3] : 0, fir ? fir[4] : 0, fir ? fir[5] : 0, pcm, pcm_chl2, edges)
+	if (fir) { if (rotate) DDK(true, 2); else DDK(false, 2); }
+	else { if (rotate) DDK(true, 1); else DDK(false, 1); }
+#undef DDK
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_fm_fifth_tails(void *stream, const void *in, int rotate, u64 n_blocks, unsigned n, int fuse, const int16_t *droop_in, int16_t *droop_out,
+                                  uint32_t *tails)
+{
+	if (fuse != 3)
+		return (int)hipErrorInvalidValue;
+	const unsigned grid = (unsigned)(((n_blocks + 1) * 16 + 255) / 256);
+	if (rotate) hipLaunchKernelGGL((k_fm_fifth_tails<true, 3>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint32_t *)in, n_blocks, n, droop_in, droop_out, tails);
+	else hipLaunchKernelGGL((k_fm_fifth_tails<false, 3>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint32_t *)in, n_blocks, n, droop_in, droop_out, tails);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_fm_dd_edges(void *stream, const uint32_t *edges, u64 n_blocks, u64 K, int16_t *pcm, int pcm_chl2, rxk_fm_dev *dev, rxk_flag_rec *flag_list,
+                               int *flag_cnt, int flag_all)
+{
+	hipLaunchKernelGGL(k_fm_dd_edges, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, edges, n_blocks, K, pcm, pcm_chl2, dev, flag_list,
+	                   flag_cnt, flag_all);
 	LAUNCH_RET();
 }
 

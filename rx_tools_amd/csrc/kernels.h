@@ -180,6 +180,16 @@ int rxk_fm_fifth_seams(void *stream, const void *in, int stage2, int rotate, uns
                        const int16_t *hist_in, int16_t *hist_out, uint32_t *seams);
 int rxk_fm_fifth_fused(void *stream, const void *in, int stage2, int rotate, unsigned long long n_blocks, unsigned n, int fuse,
                        const int16_t *hist_in, int16_t *hist_out, uint32_t *seams, uint32_t *out);
+/* A three-pass cascade on raw input with everything behind it in the same launch (k_fm_fifth_regn<.., 3, DD>): droop FIR (fir = the
+ * cic_9_tables row, HOST pointer, or NULL) and the -A fast discriminator; pcm linear or tiled (pcm_chl2).  seams: rxk_fm_fifth_seams with
+ * fuse = 3; tails (10 dwords per block) and the new droop history: rxk_fm_fifth_tails; every block's first sample and pre_r/pre_j out:
+ * rxk_fm_dd_edges on `edges` (2 dwords per block), which alone touches dev and the flag list. */
+int rxk_fm_fifth_dd(void *stream, const void *in, int rotate, unsigned long long n_blocks, unsigned n, int fuse, const uint32_t *seams,
+                    const uint32_t *tails, const int *fir, int16_t *pcm, int pcm_chl2, uint32_t *edges);
+int rxk_fm_fifth_tails(void *stream, const void *in, int rotate, unsigned long long n_blocks, unsigned n, int fuse, const int16_t *droop_in,
+                       int16_t *droop_out, uint32_t *tails);
+int rxk_fm_dd_edges(void *stream, const uint32_t *edges, unsigned long long n_blocks, unsigned long long K, int16_t *pcm, int pcm_chl2,
+                    rxk_fm_dev *dev, rxk_flag_rec *flag_list, int *flag_cnt, int flag_all);
 /* F12 generic_fir droop compensation (rtl_fm.c:442-465, 771-776) over the concatenated stream */
 int rxk_fm_droop(void *stream, const uint32_t *in, unsigned long long M, const int *fir,
                  const int16_t *hist_in, int16_t *hist_out, uint32_t *out);

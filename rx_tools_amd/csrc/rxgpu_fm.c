@@ -41,6 +41,7 @@ struct rxgpu_fm_stream {
 	uint32_t *cas[2];                    /* fifth_order ping-pong */
 	uint32_t *seams;                     /* per block: 3 levels x 5 history samples for the fused passes */
 	uint32_t *cas_a[2], *seams_a[2];     /* raw input: the first fused group runs on stream A like the decimator, double-buffered */
+	uint32_t *edges_a[2];                /* ... and where it also demodulates: each block's first and last FIR output */
 	hipEvent_t ev_up;                    /* carries uploaded on stream B -> stream A may read the cascade history */
 	hipEvent_t ev_seam[2];               /* the seam histories of a run's first fused group are in place (stream 4 -> stream A) */
 	int16_t *pcm_buf[2], *pcm, *y;       /* pcm: the buffer the run in hand uses (double-buffered like lp_raw) */
@@ -290,7 +291,8 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 			const int fuse = params->downsample_passes < 3 ? params->downsample_passes : 3;
 			for (int i = 0; i < 2; i++) {
 				DMALLOC(s->cas_a[i], ((s->max_T >> fuse) + max_blocks) * 4);
-				DMALLOC(s->seams_a[i], (max_blocks + 1) * 25 * 4);             /* up to five levels of five history samples per block */
+				DMALLOC(s->seams_a[i], (max_blocks + 1) * 25 * 4);             /* up to five levels of five history samples per block, or three and ten tail samples */
+				DMALLOC(s->edges_a[i], (max_blocks + 1) * 2 * 4);
 			}
 			if (hipEventCreateWithFlags(&s->ev_up, hipEventDisableTiming) != hipSuccess ||
 			    hipEventCreateWithFlags(&s->ev_seam[0], hipEventDisableTiming) != hipSuccess ||
@@ -336,7 +338,7 @@ void rxgpu_fm_stream_destroy(rxgpu_fm_stream *s)
 	hipFree(s->lp);
 	hipFree(s->cas[0]); hipFree(s->cas[1]); hipFree(s->seams);
 	hipFree(s->lit[0]); hipFree(s->lit[1]);
-	hipFree(s->cas_a[0]); hipFree(s->cas_a[1]); hipFree(s->seams_a[0]); hipFree(s->seams_a[1]);
+	hipFree(s->cas_a[0]); hipFree(s->cas_a[1]); hipFree(s->seams_a[0]); hipFree(s->seams_a[1]); hipFree(s->edges_a[0]); hipFree(s->edges_a[1]);
 	if (s->ev_up) hipEventDestroy(s->ev_up);
 	if (s->ev_seam[0]) hipEventDestroy(s->ev_seam[0]);
 	if (s->ev_seam[1]) hipEventDestroy(s->ev_seam[1]);
@@ -637,6 +639,10 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 	const int fuse_a_env = getenv("RXGPU_FUSE_A") ? atoi(getenv("RXGPU_FUSE_A")) : 0;
 	const int fuse_a_max = (fuse_a_env >= 3 && fuse_a_env <= 5) ? fuse_a_env : 4;
 	const int fuse_a = (g->passes && !g->literal && !prescaled && (g->n % RXK_FIFTH_TILE) == 0 && s->cas_a[0]) ? (g->passes < fuse_a_max ? g->passes : fuse_a_max) : 0;
+	/* a three-pass cascade is the whole of the group: the droop FIR and the discriminator ride in the same launch and only pcm leaves it
+	 * ($RXGPU_NO_FUSED_DD=1: the separate kernels) */
+	const int fuse_dd = fuse_a == 3 && g->passes == 3 && p->mode == RXGPU_MODE_FM && !p->squelch_level && p->custom_atan == 1 &&
+	                    (p->comp_fir_size == 9 || p->comp_fir_size == 0) && !getenv("RXGPU_NO_FUSED_DD");
 	const int fresh = !s->chained;
 
 	if (!s->chained) {
@@ -667,7 +673,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 		if (g->passes) {
 			/* the histories of the passes stream A runs are advanced there (below), the others here */
 			RX_K(rxk_copy_small(sb, s->hist_dev + HIST_CAS_IN + fuse_a * 12, s->hist_dev + HIST_CAS_OUT + fuse_a * 12, (unsigned)(10 - fuse_a) * 12 * 2));
-			if (p->comp_fir_size == 9)
+			if (p->comp_fir_size == 9 && !fuse_dd)
 				RX_K(rxk_copy_small(sb, s->hist_dev + HIST_DROOP_IN, s->hist_dev + HIST_DROOP_OUT, 18 * 2));
 		}
 	}
@@ -787,19 +793,36 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 				RX_HIP(hipStreamWaitEvent(sd, s->ev_up, 0));
 			} else {
 				RX_K(rxk_copy_small(sd, s->hist_dev + HIST_CAS_IN, s->hist_dev + HIST_CAS_OUT, (unsigned)fuse * 12 * 2));
+				if (fuse_dd && p->comp_fir_size == 9)
+					RX_K(rxk_copy_small(sd, s->hist_dev + HIST_DROOP_IN, s->hist_dev + HIST_DROOP_OUT, 18 * 2));
 			}
 			RX_K(rxk_fm_fifth_seams(sd, d_iq, 0, g->rotate, n_blocks, (unsigned)g->n, fuse, s->hist_dev + HIST_CAS_IN,
 			                        s->hist_dev + HIST_CAS_OUT, s->seams_a[db]));
+			uint32_t *const tails = s->seams_a[db] + (s->max_blocks + 1) * 15;
+			if (fuse_dd)
+				RX_K(rxk_fm_fifth_tails(sd, d_iq, g->rotate, n_blocks, (unsigned)g->n, fuse, p->comp_fir_size == 9 ? s->hist_dev + HIST_DROOP_IN : NULL,
+				                        p->comp_fir_size == 9 ? s->hist_dev + HIST_DROOP_OUT : NULL, tails));
 			RX_HIP(hipEventRecord(s->ev_seam[db], sd));
 			RX_HIP(hipStreamWaitEvent(sa, s->ev_seam[db], 0));
 			if (s->ev_small_valid[db])                   /* cas_a[db] was last read by the run two enqueues ago */
 				RX_HIP(hipStreamWaitEvent(sa, s->ev_small[db], 0));
 			rxgpu_prof_begin_on("fm_fifth", sa);
-			RX_K(rxk_fm_fifth_fused(sa, d_iq, 0, g->rotate, n_blocks, (unsigned)g->n, fuse, NULL,
-			                        s->hist_dev + HIST_CAS_OUT, s->seams_a[db], dst));
+			if (fuse_dd)
+				RX_K(rxk_fm_fifth_dd(sa, d_iq, g->rotate, n_blocks, (unsigned)g->n, fuse, s->seams_a[db], tails,
+				                     p->comp_fir_size == 9 ? cic_9_tables[passes] : NULL, s->pcm, s->tiled, s->edges_a[db]));
+			else
+				RX_K(rxk_fm_fifth_fused(sa, d_iq, 0, g->rotate, n_blocks, (unsigned)g->n, fuse, NULL,
+				                        s->hist_dev + HIST_CAS_OUT, s->seams_a[db], dst));
 			rxgpu_prof_end_on("fm_fifth", sa);
 			RX_HIP(hipEventRecord(s->ev_dec[db], sa));
 			RX_HIP(hipStreamWaitEvent(sb, s->ev_dec[db], 0));
+			if (fuse_dd) {
+				/* what needs the carries and the flag list: each block's first sample, pre_r/pre_j out */
+				rxgpu_prof_begin_on("fm_disc", sb);
+				RX_K(rxk_fm_dd_edges(sb, s->edges_a[db], n_blocks, g->K, s->pcm, s->tiled, s->dev, flag_rec, flag_cnt, s->flag_all));
+				rxgpu_prof_end_on("fm_disc", sb);
+				fused_dd = 1;
+			}
 			src = dst;
 			n_in = (unsigned)(g->n >> fuse);
 			in_stride = n_in;
@@ -831,8 +854,8 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 			in_stride = n_out;
 		}
 		rxgpu_prof_end_on("fm_fifth2", sb);
-		s->lp_final = (const uint32_t *)src;             /* [n_blocks][K] contiguous == M samples */
-		if (p->comp_fir_size == 9) {
+		s->lp_final = fuse_dd ? NULL : (const uint32_t *)src;   /* [n_blocks][K] contiguous == M samples */
+		if (p->comp_fir_size == 9 && !fuse_dd) {
 			if (s->fir_loaded != passes) {                   /* the table of this cascade depth: once */
 				RX_HIP(hipMemcpyAsync(s->fir_dev, cic_9_tables[passes], 10 * sizeof(int), hipMemcpyHostToDevice, sb));
 				s->fir_loaded = passes;

@@ -169,6 +169,46 @@ def test_first_group_depths(env, passes, monkeypatch):
     _check(sig_noise(8 * n, seed=63, amp=30000), 2 * n, n_runs=2, pipelined=True, downsample_passes=passes, comp_fir_size=0)
 
 
+@pytest.mark.parametrize("fir", [9, 0])
+@pytest.mark.parametrize("extra", [dict(), dict(offset_tuning=1), dict(deemph=0), dict(rate_out2=0), dict(dc_block_audio=1),
+                                   dict(rate_out=250000, rate_out2=48000, deemph_a=7)])
+def test_whole_chain_in_the_cascade_kernel(fir, extra, monkeypatch):
+    """three fifth_order passes, the droop FIR and the -A fast discriminator in ONE launch (k_fm_fifth_regn<.., 3, DD> + k_fm_fifth_tails +
+    k_fm_dd_edges): oracle bits and carries for every audio tail behind it, one run and chained pipelined runs (histories, pre_r/pre_j and
+    the FIR's nine samples crossing block and run seams), and the same bits as the separate kernels ($RXGPU_NO_FUSED_DD)"""
+    from gpu_support import gpu_fm_stream, carry_tuple, carry_from_oracle_state
+    n = 16384
+    params = dict(downsample_passes=3, comp_fir_size=fir, **extra)
+    for iq in (sig_fm(5 * n, seed=81, amp=9000.0, noise=900), sig_noise(10 * n, seed=82), np.full(10 * n, -32768, np.int16), sig_alternating(10 * n)):
+        carry, st = _check(iq, 2 * n, **params)
+        want, got = carry_tuple(carry_from_oracle_state(st)), carry_tuple(carry)
+        assert got[8][:36] == want[8][:36] and got[9][:36] == want[9][:36]
+        if fir == 9:
+            assert got[10] == want[10] and got[11] == want[11]
+    iq = sig_fm(13 * n, seed=83, amp=12000.0, noise=2000)
+    _check(iq, 2 * n, n_runs=4, pipelined=True, **params)
+    _check(iq, 2 * n, n_runs=3, **params)
+    fused = gpu_fm_stream(iq, 2 * n, n_runs=4, pipelined=True, **params)
+    monkeypatch.setenv("RXGPU_NO_FUSED_DD", "1")
+    plain = gpu_fm_stream(iq, 2 * n, n_runs=4, pipelined=True, **params)
+    assert np.array_equal(fused[0], plain[0]) and carry_tuple(fused[2]) == carry_tuple(plain[2])
+
+
+def test_whole_chain_kernel_block_shapes_and_libm_records(monkeypatch):
+    """block lengths from one tile (2048 samples: 256 outputs, two waves) to 2^18, and every block's first sample flagged for the host
+    (flag_all): the records k_fm_dd_edges writes are re-evaluated with libm and patched into the tiled pcm like k_fm_droop_disc's"""
+    for n, nb in ((2048, 9), (4096, 5), (6144, 3), (262144, 2), (2048 * 59, 2)):
+        iq = sig_fm(nb * n, seed=90 + nb, amp=7000.0, noise=500)
+        _check(iq, 2 * n, downsample_passes=3, comp_fir_size=9)
+        _check(iq, 2 * n, n_runs=2, pipelined=True, downsample_passes=3, comp_fir_size=0, offset_tuning=1)
+    monkeypatch.setenv("RXGPU_FLAG_ALL", "2")
+    from gpu_support import gpu_fm_stream
+    iq = sig_fm(12 * 8192, seed=95, amp=7000.0, noise=500)
+    want, _, _ = oracle_fm_stream(iq, 16384, downsample_passes=3, comp_fir_size=9)
+    got, _, _, fix = gpu_fm_stream(iq, 16384, n_runs=3, pipelined=True, downsample_passes=3, comp_fir_size=9)
+    assert np.array_equal(got, want) and fix >= 11
+
+
 def test_fifth_order_carry_across_runs():
     iq = sig_noise(12 * 16384, seed=21, amp=20000)
     _check(iq, 16384, n_runs=3, downsample_passes=3, comp_fir_size=9)

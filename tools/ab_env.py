@@ -1,5 +1,6 @@
 """tools/ab_env.py BLOCKS DS VAR=VAL[,VAR=VAL...] [VAR=VAL...] -- pipelined step time of one rx_fm chain under several environment settings, alternating
-inside one process (same box).  DS: 118 | 6 | -7 (passes) | -39 (3 passes + droop FIR).  'default' (no variable) is always measured too."""
+inside one process (same box).  DS: 118 | 6 | -7 (passes) | -39 (3 passes + droop FIR).  'default' (no variable) is always measured too.
+AB_SYNC=1 in the environment: runs one at a time (no overlap between consecutive runs)."""
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -30,8 +31,11 @@ for rep in range(3):
         L.rxgpu_prof_reset(); L.rxgpu_prof_enable(2)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         k = 20
-        for _ in range(k): s.run_async(d_iq.data_ptr(), blocks, bl, d_out.data_ptr(), d_out.numel())
-        s.wait()
+        if os.environ.get("AB_SYNC"):                 # every run alone on the device: what each kernel takes without the other stream beside it
+            for _ in range(k): s.run(d_iq.data_ptr(), blocks, bl, d_out.data_ptr(), d_out.numel())
+        else:
+            for _ in range(k): s.run_async(d_iq.data_ptr(), blocks, bl, d_out.data_ptr(), d_out.numel())
+            s.wait()
         dt = (time.perf_counter() - t0) / k
         L.rxgpu_prof_enable(0)
         print((",".join("%s=%s" % kv for kv in st.items()) or "default").ljust(34), "us/step", round(dt * 1e6, 1),
