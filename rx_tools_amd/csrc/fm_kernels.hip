@@ -2440,22 +2440,28 @@ __device__ __forceinline__ void fr_cascade(uint32_t (&in)[NIN], uint32_t (&res)[
 	}
 }
 
-// the -A fast discriminator on two packed samples (multiply_conjugate + fast_atan2, rtl_fm.c:467-513)
+// the -A fast discriminator on two packed samples (multiply_conjugate + fast_atan2, rtl_fm.c:467-513); SMALL: |cr| + |cj| < 2^24
+template <bool SMALL>
 __device__ __forceinline__ int disc_fast(uint32_t a, uint32_t b)
 {
-	const int ar = lo16(a), aj = hi16(a), br = lo16(b), bj = hi16(b);
-	const int cr = (int)((unsigned)ar * (unsigned)br + (unsigned)aj * (unsigned)bj);
-	const int cj = (int)((unsigned)aj * (unsigned)br - (unsigned)ar * (unsigned)bj);
-	return fast_atan2_dev(cj, cr);
+	int cr, cj;
+	mul_conj_pk(a, b, cr, cj);
+	return fast_atan2_dev<SMALL>(cj, cr);
 }
 
 // generic_fir's sum over the nine samples w[0..8] BEFORE an output (rtl_fm.c:442-465); 24-bit multiplies, see k_fm_droop
+__device__ __forceinline__ int mad24(int a, int b, int c)
+{
+	int r;
+	asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+	return r;
+}
 __device__ __forceinline__ uint32_t droop9(const uint32_t *w, int f1, int f2, int f3, int f4, int f5)
 {
-	const int si = __mul24(lo16(w[0]) + lo16(w[8]), f1) + __mul24(lo16(w[1]) + lo16(w[7]), f2) + __mul24(lo16(w[2]) + lo16(w[6]), f3) +
-	               __mul24(lo16(w[3]) + lo16(w[5]), f4) + __mul24(lo16(w[4]), f5);
-	const int sq = __mul24(hi16(w[0]) + hi16(w[8]), f1) + __mul24(hi16(w[1]) + hi16(w[7]), f2) + __mul24(hi16(w[2]) + hi16(w[6]), f3) +
-	               __mul24(hi16(w[3]) + hi16(w[5]), f4) + __mul24(hi16(w[4]), f5);
+	const int si = mad24(lo16(w[0]) + lo16(w[8]), f1, mad24(lo16(w[1]) + lo16(w[7]), f2, mad24(lo16(w[2]) + lo16(w[6]), f3,
+	               mad24(lo16(w[3]) + lo16(w[5]), f4, __mul24(lo16(w[4]), f5)))));
+	const int sq = mad24(hi16(w[0]) + hi16(w[8]), f1, mad24(hi16(w[1]) + hi16(w[7]), f2, mad24(hi16(w[2]) + hi16(w[6]), f3,
+	               mad24(hi16(w[3]) + hi16(w[5]), f4, __mul24(hi16(w[4]), f5)))));
 	return pack_iq(si >> 15, sq >> 15);
 }
 
@@ -2469,7 +2475,7 @@ __device__ __forceinline__ uint32_t droop9(const uint32_t *w, int f1, int f2, in
 // are left to a small kernel behind this one (k_fm_dd_edges, stream B: they need the previous run's carries and the libm flag list): each
 // block's FIRST demodulated sample -- polar_discriminant in double, rtl_fm.c:476-483, 667-682 -- and pre_r/pre_j; for them the kernel leaves
 // each block's first and last FIR output in `edges`.
-template <bool ROTATE, int LV, int DD>
+template <bool ROTATE, int LV, int DD, int TW = 1>
 __global__ __launch_bounds__(256) void k_fm_fifth_regn(const uint32_t *__restrict__ iq, unsigned n, unsigned tiles_per_block, unsigned wgs_per_block,
                                                        unsigned total_wgs, const uint32_t *__restrict__ seams, uint32_t *__restrict__ out,
                                                        const uint32_t *__restrict__ tails, int f1, int f2, int f3, int f4, int f5,
@@ -2484,7 +2490,8 @@ __global__ __launch_bounds__(256) void k_fm_fifth_regn(const uint32_t *__restric
 		return;
 	const unsigned blk32 = wgi / wgs_per_block;
 	const unsigned wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-	const unsigned tile = (wgi - blk32 * wgs_per_block) * 4 + wv;
+	// a workgroup takes 4 TW consecutive tiles of its block, four at a time: wave wv walks tiles base + wv, base + 4 + wv, ...
+	unsigned tile = (wgi - blk32 * wgs_per_block) * (4 * TW) + wv;
 	if (tile >= tiles_per_block)
 		return;
 	const u64 blk = blk32;
@@ -2497,63 +2504,87 @@ __global__ __launch_bounds__(256) void k_fm_fifth_regn(const uint32_t *__restric
 	// rot(l) = l NP / 16 -- sixteen neighbouring lanes' b128 reads then fall on sixteen different bank groups
 	__shared__ u32x4 stage[4][64 * NP];
 	const int s_max = (int)n - 4;
-#pragma unroll
-	for (int h = 0; h < NP; h++) {
-		const unsigned slot = 64u * h + lane, sl = slot / NP, sj = (slot - (sl * NP) / 16u) % NP;   // slot % NP - rot(sl), mod NP (NP | 64 h + ...)
-		int sp = (int)(tile * (FR_OUT * R)) - 5 * R + (int)(4u * (sl * NP + sj));
-		sp = sp < 0 ? 0 : (sp > s_max ? s_max : sp);
-		__builtin_amdgcn_global_load_lds((const void *)(braw + sp), (__attribute__((address_space(3))) void *)&stage[wv][64 * h], 16, 0, 2);
-	}
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	uint32_t x[R];
 	const unsigned rot = (lane * NP) / 16u;
+	auto fetch = [&](unsigned t) {
 #pragma unroll
-	for (int j = 0; j < NP; j++)
-		dec_contrib<false, ROTATE>(stage[wv][NP * lane + ((j + rot) % NP)], x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3], SK);
-	const bool first = tile == 0;                            // wave-uniform
-	uint32_t w[NOUT];
-	fr_cascade<R, LV, 0>(x, w, lane, first, sm);
-	const unsigned j = tile * FR_OUT + lane - 5u;            // the lane's place among the block's K / NOUT lanes
-	if constexpr (DD == 0) {
-		if (lane >= 5u && j < K)
-			__builtin_nontemporal_store(w[0], out + blk * (u64)K + j);
-	} else {
-		if (first) {
-			const uint32_t *tl = tails + blk * 10;               // the previous block's level-LV samples K-10 .. K-1
-			if (lane == 4u) { w[0] = tl[6]; w[1] = tl[7]; w[2] = tl[8]; w[3] = tl[9]; }
-			else if (lane == 3u) { w[0] = tl[2]; w[1] = tl[3]; w[2] = tl[4]; w[3] = tl[5]; }
-			else if (lane == 2u) { w[2] = tl[0]; w[3] = tl[1]; }
+		for (int h = 0; h < NP; h++) {
+			const unsigned slot = 64u * h + lane, sl = slot / NP, sj = (slot - (sl * NP) / 16u) % NP;   // slot % NP - rot(sl), mod NP
+			int sp = (int)(t * (FR_OUT * R)) - 5 * R + (int)(4u * (sl * NP + sj));
+			sp = sp < 0 ? 0 : (sp > s_max ? s_max : sp);
+			__builtin_amdgcn_global_load_lds((const void *)(braw + sp), (__attribute__((address_space(3))) void *)&stage[wv][64 * h], 16, 0, 2);
 		}
-		uint32_t y[4];
-		if constexpr (DD == 2) {
-			uint32_t W[13];                                      // W[i] = level-LV sample 4l - 9 + i
+	};
+	fetch(tile);
+#pragma unroll 1
+	for (int it = 0; it < TW; it++, tile += 4) {
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		uint32_t x[R];
+		if constexpr (TW > 1) {
+			// the stage is free as soon as its pieces sit in registers: the next tile's loads fly while this one is computed
+			u32x4 raw[NP];
 #pragma unroll
-			for (int k = 0; k < 4; k++) {
-				W[9 + k] = w[k];
-				W[5 + k] = fr_shr(w[k]);
-				W[1 + k] = fr_shr(W[5 + k]);
-			}
-			W[0] = fr_shr(W[4]);
+			for (int j = 0; j < NP; j++)
+				raw[j] = stage[wv][NP * lane + ((j + rot) % NP)];
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+			if (it + 1 < TW && tile + 4 < tiles_per_block)
+				fetch(tile + 4);
 #pragma unroll
-			for (int k = 0; k < 4; k++)
-				y[k] = droop9(W + k, f1, f2, f3, f4, f5);
+			for (int j = 0; j < NP; j++)
+				dec_contrib<false, ROTATE>(raw[j], x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3], SK);
 		} else {
 #pragma unroll
-			for (int k = 0; k < 4; k++)
-				y[k] = w[k];
+			for (int j = 0; j < NP; j++)
+				dec_contrib<false, ROTATE>(stage[wv][NP * lane + ((j + rot) % NP)], x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3], SK);
 		}
-		const uint32_t yp = fr_shr(y[3]);
-		if (lane >= 5u && 4u * j < K) {
-			const int r0 = j ? disc_fast(y[0], yp) : 0;           // a block's first sample: k_fm_dd_edges
-			const int r1 = disc_fast(y[1], y[0]), r2 = disc_fast(y[2], y[1]), r3 = disc_fast(y[3], y[2]);
-			const u64 m0 = blk * (u64)K + 4u * j;
-			int16_t *dst = pcm + pcm_index(m0, pcm_chl2);        // four consecutive samples stay inside one 16-byte unit of the tiled layout
-			*reinterpret_cast<uint2 *>(dst) = make_uint2((uint32_t)(uint16_t)r0 | ((uint32_t)(uint16_t)r1 << 16), (uint32_t)(uint16_t)r2 | ((uint32_t)(uint16_t)r3 << 16));
-			if (j == 0)
-				edges[2 * blk] = y[0];
-			if (4u * j + 4u == K)
-				edges[2 * blk + 1] = y[3];
+		const bool first = tile == 0;                            // wave-uniform
+		uint32_t w[NOUT];
+		fr_cascade<R, LV, 0>(x, w, lane, first, sm);
+		const unsigned j = tile * FR_OUT + lane - 5u;            // the lane's place among the block's K / NOUT lanes
+		if constexpr (DD == 0) {
+			if (lane >= 5u && j < K)
+				__builtin_nontemporal_store(w[0], out + blk * (u64)K + j);
+		} else {
+			if (first) {
+				const uint32_t *tl = tails + blk * 10;               // the previous block's level-LV samples K-10 .. K-1
+				if (lane == 4u) { w[0] = tl[6]; w[1] = tl[7]; w[2] = tl[8]; w[3] = tl[9]; }
+				else if (lane == 3u) { w[0] = tl[2]; w[1] = tl[3]; w[2] = tl[4]; w[3] = tl[5]; }
+				else if (lane == 2u) { w[2] = tl[0]; w[3] = tl[1]; }
+			}
+			uint32_t y[4];
+			if constexpr (DD == 2) {
+				uint32_t W[13];                                      // W[i] = level-LV sample 4l - 9 + i
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					W[9 + k] = w[k];
+					W[5 + k] = fr_shr(w[k]);
+					W[1 + k] = fr_shr(W[5 + k]);
+				}
+				W[0] = fr_shr(W[4]);
+#pragma unroll
+				for (int k = 0; k < 4; k++)
+					y[k] = droop9(W + k, f1, f2, f3, f4, f5);
+			} else {
+#pragma unroll
+				for (int k = 0; k < 4; k++)
+					y[k] = w[k];
+			}
+			const uint32_t yp = fr_shr(y[3]);
+			if (lane >= 5u && 4u * j < K) {
+				// without the FIR the samples stay below 2^10 << (LV - 3) and |cr| + |cj| below 2^24 (LV <= 3): the short division
+				constexpr bool SMALL = DD == 1 && LV == 3;
+				const int r0 = j ? disc_fast<SMALL>(y[0], yp) : 0;    // a block's first sample: k_fm_dd_edges
+				const int r1 = disc_fast<SMALL>(y[1], y[0]), r2 = disc_fast<SMALL>(y[2], y[1]), r3 = disc_fast<SMALL>(y[3], y[2]);
+				const u64 m0 = blk * (u64)K + 4u * j;
+				int16_t *dst = pcm + pcm_index(m0, pcm_chl2);        // four consecutive samples stay inside one 16-byte unit of the tiled layout
+				*reinterpret_cast<uint2 *>(dst) = make_uint2((uint32_t)(uint16_t)r0 | ((uint32_t)(uint16_t)r1 << 16), (uint32_t)(uint16_t)r2 | ((uint32_t)(uint16_t)r3 << 16));
+				if (j == 0)
+					edges[2 * blk] = y[0];
+				if (4u * j + 4u == K)
+					edges[2 * blk + 1] = y[3];
+			}
 		}
+		if (TW > 1 && tile + 4 >= tiles_per_block)
+			break;
 	}
 }
 
@@ -3758,6 +3789,8 @@ extern "C" int rxk_fm_fifth_fused(void *stream, const void *in, int stage2, int 
 	 * below -- in the -M wbfm -F 9 chain it is 3-5 % ahead (A/B) -- unless $RXGPU_FR_GENERIC=1 (tests: the LV = 3 instantiation) */
 	if (!stage2 && (fuse == 4 || fuse == 5 || (fuse == 3 && getenv("RXGPU_FR_GENERIC")))) {
 		const unsigned tiles_r = ((n >> fuse) + FR_OUT - 1) / FR_OUT;
+		/* one tile per wave: walking two or four with the next one's loads in flight (what the whole-chain kernel below does) made this
+		 * one, which has half the arithmetic per byte, 5-10 % slower (A/B, -F ds=128: 1730 / 1823 / 1908 us per step) */
 		const unsigned wgs_per_block = (tiles_r + 3) / 4;
 		const u64 total = n_blocks * (u64)wgs_per_block;
 		if (total > 0xfffffff0ull)
@@ -3765,12 +3798,14 @@ extern "C" int rxk_fm_fifth_fused(void *stream, const void *in, int stage2, int 
 		const unsigned rgrid = (unsigned)((total + 7) / 8 * 8);
 		const unsigned sgridn = (unsigned)(((n_blocks + 1) * (fuse == 3 ? 16 : 32) + 255) / 256);
 #define SEAMN(RT, LVV) hipLaunchKernelGGL((k_fm_fifth_seams<RT, false, LVV>), dim3(sgridn), dim3(256), 0, s, p, n_blocks, n, fuse, hist_in, seams, hist_out)
-#define REGN(RT, LVV) hipLaunchKernelGGL((k_fm_fifth_regn<RT, LVV, 0>), dim3(rgrid), dim3(256), 0, s, p, n, tiles_r, wgs_per_block, (unsigned)total, seams, out, \
-		                                     (const uint32_t *)nullptr, 0, 0, 0, 0, 0, (int16_t *)nullptr, 0, (uint32_t *)nullptr)
+#define REGK(RT, LVV, T) hipLaunchKernelGGL((k_fm_fifth_regn<RT, LVV, 0, T>), dim3(rgrid), dim3(256), 0, s, p, n, tiles_r, wgs_per_block, (unsigned)total, seams, out, \
+		                                    (const uint32_t *)nullptr, 0, 0, 0, 0, 0, (int16_t *)nullptr, 0, (uint32_t *)nullptr)
+#define REGN(RT, LVV) REGK(RT, LVV, 1)
 #define GON(LVV) do { if (rotate) { if (hist_in) SEAMN(true, LVV); REGN(true, LVV); } else { if (hist_in) SEAMN(false, LVV); REGN(false, LVV); } } while (0)
 		if (fuse == 3) GON(3); else if (fuse == 4) GON(4); else GON(5);
 #undef GON
 #undef REGN
+#undef REGK
 #undef SEAMN
 		LAUNCH_RET();
 	}
@@ -3793,15 +3828,21 @@ extern "C" int rxk_fm_fifth_dd(void *stream, const void *in, int rotate, u64 n_b
 	hipStream_t s = (hipStream_t)stream;
 	const uint32_t *p = (const uint32_t *)in;
 	const unsigned tiles_r = ((n >> fuse) / 4 + FR_OUT - 1) / FR_OUT;
-	const unsigned wgs_per_block = (tiles_r + 3) / 4;
+	/* tiles a wave walks, the next one's loads in flight behind the current one's arithmetic ($RXGPU_DD_TW=1|2|4) */
+	const char *tw_env = getenv("RXGPU_DD_TW");
+	const unsigned tw = tw_env ? (unsigned)atoi(tw_env) : 2u;
+	const unsigned twn = (tw == 4 || tw == 2) && tiles_r >= 4 * tw ? tw : 1u;
+	const unsigned wgs_per_block = (tiles_r + 4 * twn - 1) / (4 * twn);
 	const u64 total = n_blocks * (u64)wgs_per_block;
 	if (total > 0xfffffff0ull)
 		return (int)hipErrorInvalidValue;
 	const unsigned rgrid = (unsigned)((total + 7) / 8 * 8);
-#define DDK(RT, D) hipLaunchKernelGGL((k_fm_fifth_regn<RT, 3, D>), dim3(rgrid), dim3(256), 0, s, p, n, tiles_r, wgs_per_block, (unsigned)total, seams, (uint32_t *)nullptr, \
-		                              tails, fir ? fir[1] : 0, fir ? fir[2] : 0, fir ? fir[3] : 0, fir ? fir[4] : 0, fir ? fir[5] : 0, pcm, pcm_chl2, edges)
-	if (fir) { if (rotate) DDK(true, 2); else DDK(false, 2); }
-	else { if (rotate) DDK(true, 1); else DDK(false, 1); }
+#define DDK(RT, D, T) hipLaunchKernelGGL((k_fm_fifth_regn<RT, 3, D, T>), dim3(rgrid), dim3(256), 0, s, p, n, tiles_r, wgs_per_block, (unsigned)total, seams, (uint32_t *)nullptr, \
+		                                 tails, fir ? fir[1] : 0, fir ? fir[2] : 0, fir ? fir[3] : 0, fir ? fir[4] : 0, fir ? fir[5] : 0, pcm, pcm_chl2, edges)
+#define DDT(RT, D) do { if (twn == 4) DDK(RT, D, 4); else if (twn == 2) DDK(RT, D, 2); else DDK(RT, D, 1); } while (0)
+	if (fir) { if (rotate) DDT(true, 2); else DDT(false, 2); }
+	else { if (rotate) DDT(true, 1); else DDT(false, 1); }
+#undef DDT
 #undef DDK
 	LAUNCH_RET();
 }

@@ -194,10 +194,13 @@ def test_whole_chain_in_the_cascade_kernel(fir, extra, monkeypatch):
     assert np.array_equal(fused[0], plain[0]) and carry_tuple(fused[2]) == carry_tuple(plain[2])
 
 
-def test_whole_chain_kernel_block_shapes_and_libm_records(monkeypatch):
-    """block lengths from one tile (2048 samples: 256 outputs, two waves) to 2^18, and every block's first sample flagged for the host
-    (flag_all): the records k_fm_dd_edges writes are re-evaluated with libm and patched into the tiled pcm like k_fm_droop_disc's"""
-    for n, nb in ((2048, 9), (4096, 5), (6144, 3), (262144, 2), (2048 * 59, 2)):
+@pytest.mark.parametrize("tw", ["1", "2", "4"])
+def test_whole_chain_kernel_block_shapes_and_libm_records(tw, monkeypatch):
+    """block lengths from one tile (2048 samples: 256 outputs, two waves) to 2^18 with one, two and four tiles walked per wave, and every
+    block's first sample flagged for the host (flag_all): the records k_fm_dd_edges writes are re-evaluated with libm and patched into
+    the tiled pcm like k_fm_droop_disc's"""
+    monkeypatch.setenv("RXGPU_DD_TW", tw)
+    for n, nb in ((2048, 9), (4096, 5), (6144, 3), (262144, 2), (2048 * 59, 2), (2048 * 15, 3)):
         iq = sig_fm(nb * n, seed=90 + nb, amp=7000.0, noise=500)
         _check(iq, 2 * n, downsample_passes=3, comp_fir_size=9)
         _check(iq, 2 * n, n_runs=2, pipelined=True, downsample_passes=3, comp_fir_size=0, offset_tuning=1)
