@@ -10,6 +10,7 @@
                           FETCH_SIZE, WRITE_SIZE} and the chain's HBM bytes per step beside its algorithmic bytes
   rNN_pmc_summary.json    the per-kernel entries bench.py reads (k_fm_decimate traffic, k_pw_fft4096 / k_ch_fftR instruction counts)
   rNN_valu_issue.json/.txt  tools/valu_issue.hip: wave64 instructions per SIMD-cycle per opcode (the VALU roofline's anchor)
+  rNN_rwmix.json/.txt       tools/rwmix.hip: what HBM gives a read stream with writes mixed in, on the box of this profile run
 
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies a 128-byte request as 64 bytes, so it is doubled (MI355X_MICROARCH.md,
 HBM section); WRITE_SIZE is taken as reported."""
@@ -89,7 +90,8 @@ def main():
     dst = os.path.join(ROOT, "profiles")
     for pat, name in (("bench_n1.json", "%s_bench_n1.json"), ("trace_bench.json", "%s_bench_profiled_run.json"),
                       ("trace/*/*_kernel_stats.csv", "%s_bench_kernel_stats.csv"), ("trace_variants/*/*_kernel_stats.csv", "%s_variants_kernel_stats.csv"),
-                      ("valu_issue.json", "%s_valu_issue.json"), ("valu_issue.txt", "%s_valu_issue.txt")):
+                      ("valu_issue.json", "%s_valu_issue.json"), ("valu_issue.txt", "%s_valu_issue.txt"),
+                      ("rwmix.json", "%s_rwmix.json"), ("rwmix.txt", "%s_rwmix.txt")):
         f = one(os.path.join(src, pat))
         if f:
             shutil.copy(f, os.path.join(dst, name % tag))

@@ -32,6 +32,8 @@ for wl in rx_power chan; do
 done
 # 6. the VALU issue ceiling per opcode
 timeout 200 $REPO/tools/valu_issue $OUT/valu_issue.json > $OUT/valu_issue.txt 2>&1
+# 7. the HBM ceiling for read streams with writes mixed in, on this box
+timeout 120 $REPO/tools/rwmix $OUT/rwmix.json > $OUT/rwmix.txt 2>&1
 cd $REPO
 cut -c1-400 $OUT/bench_n1.json
 ls $OUT | head -60

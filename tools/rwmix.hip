@@ -1,8 +1,8 @@
 // tools/rwmix.hip -- what HBM gives a kernel that READS a stream and WRITES a fraction of it back: the ceiling of the rx_fm chains
 // that are bound by the bytes they move.  For read:write ratios from pure read to 1:1, contiguous non-temporal
 // 16-byte loads (the decimators' pattern) and either contiguous 16-byte stores or 16-byte pieces 1 KiB apart (what the tiled pcm
-// layout receives from one wave).  Ratios below 16 only: with fewer than 256 output vectors per workgroup some threads' loads would be
-// dead code.  Diagnostic only.
+// layout receives from one wave), and the register cascade's own shape (4 KiB in, a 236-byte run of dwords out per wave).  Ratios below 16
+// only: with fewer than 256 output vectors per workgroup some threads' loads would be dead code.  Diagnostic only.
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/rwmix tools/rwmix.hip && /tmp/rwmix [json-out]
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -50,6 +50,29 @@ __global__ __launch_bounds__(256) void k_rw(const u32x4 *__restrict__ src, u32x4
 		if (acc.x == 0x12345678u && acc.y == 0x9abcdef0u)
 			dst[wg] = acc;
 	}
+}
+
+
+// the register cascade's shape (k_fm_fifth_regn<., 4>): a wave reads 4 KiB and stores ONE DWORD PER LANE from 59 lanes -- 236-byte runs laid end to
+// end, so that neighbouring waves complete each other's lines
+__global__ __launch_bounds__(256) void k_rw_runs(const u32x4 *__restrict__ src, unsigned *__restrict__ dst, size_t n_waves)
+{
+	const unsigned per = gridDim.x >> 3;
+	const size_t wg = (size_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+	const size_t wave = wg * 4 + (threadIdx.x >> 6);
+	const unsigned lane = threadIdx.x & 63;
+	if (wave >= n_waves)
+		return;
+	const u32x4 *p = src + wave * 256 + lane;
+	u32x4 v[4];
+#pragma unroll
+	for (int u = 0; u < 4; u++)
+		v[u] = __builtin_nontemporal_load(p + u * 64);
+	const u32x4 acc = v[0] + v[1] + v[2] + v[3];
+	unsigned r = acc.x ^ acc.y ^ acc.z ^ acc.w;
+	r ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)r, 0x138, 0xf, 0xf, true);      // every lane's loads feed a stored value
+	if (lane >= 5)
+		__builtin_nontemporal_store(r, dst + wave * 59 + (lane - 5));
 }
 
 __global__ void k_fill(unsigned *p, size_t n)
@@ -101,6 +124,11 @@ int main(int argc, char **argv)
 	LEG("read:write 4:1 contiguous", 4, false);
 	LEG("read:write 2:1 contiguous", 2, false);
 	LEG("read:write 1:1 contiguous (copy)", 1, false);
+	{
+		const size_t n_waves = bytes / 4096;
+		const unsigned g2 = (unsigned)(((n_waves + 3) / 4 + 7) / 8 * 8);
+		run("read:write 17:1, 236-byte runs of dwords", [&] { hipLaunchKernelGGL(k_rw_runs, dim3(g2), dim3(256), 0, 0, src, (unsigned *)dst, n_waves); }, (double)n_waves * 236);
+	}
 	json += "}}";
 	if (argc > 1) {
 		FILE *f = fopen(argv[1], "w");
