@@ -30,8 +30,9 @@ def short(name):
 
 
 def one(pattern):
+    """the NEWEST match: gpurun merges a run's files into what earlier runs left in the same directory"""
     hits = glob.glob(pattern)
-    return hits[0] if hits else None
+    return max(hits, key=os.path.getmtime) if hits else None
 
 
 def per_kernel(path, min_grid=0):
@@ -53,7 +54,10 @@ def per_kernel(path, min_grid=0):
 
 def chain_entry(src, prefix, steps, algorithmic_bytes_per_step, what):
     merged = {}
-    for f in sorted(glob.glob(os.path.join(src, prefix + "_p*", "*", "*_counter_collection.csv"))):
+    for pass_dir in sorted(glob.glob(os.path.join(src, prefix + "_p*"))):
+        f = one(os.path.join(pass_dir, "*", "*_counter_collection.csv"))
+        if not f:
+            continue
         for k, d in per_kernel(f).items():
             e = merged.setdefault(k, {})
             for c, v in d.items():
