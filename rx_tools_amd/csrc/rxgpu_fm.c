@@ -42,6 +42,7 @@ struct rxgpu_fm_stream {
 	uint32_t *seams;                     /* per block: 3 levels x 5 history samples for the fused passes */
 	uint32_t *cas_a[2], *seams_a[2];     /* raw input: the first fused group runs on stream A like the decimator, double-buffered */
 	uint32_t *edges_a[2];                /* ... and where it also demodulates: each block's first and last FIR output */
+	int last_fuse_a, last_fuse_dd;       /* how the previous run split its histories between the seam stream and stream B */
 	hipEvent_t ev_up;                    /* carries uploaded on stream B -> stream A may read the cascade history */
 	hipEvent_t ev_seam[2];               /* the seam histories of a run's first fused group are in place (stream 4 -> stream A) */
 	int16_t *pcm_buf[2], *pcm, *y;       /* pcm: the buffer the run in hand uses (double-buffered like lp_raw) */
@@ -792,6 +793,11 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 				RX_HIP(hipEventRecord(s->ev_up, sb));    /* the history upload above went through stream B */
 				RX_HIP(hipStreamWaitEvent(sd, s->ev_up, 0));
 			} else {
+				/* histories this run advances on the seam stream were left there by the previous run's seam kernels -- unless that run
+				 * had another shape (a ragged run between whole-tile runs, a shorter first group): then stream B wrote some of them, at
+				 * the end of its chain */
+				if ((s->last_fuse_a != fuse_a || s->last_fuse_dd != fuse_dd) && s->ev_small_valid[db ^ 1])
+					RX_HIP(hipStreamWaitEvent(sd, s->ev_small[db ^ 1], 0));
 				RX_K(rxk_copy_small(sd, s->hist_dev + HIST_CAS_IN, s->hist_dev + HIST_CAS_OUT, (unsigned)fuse * 12 * 2));
 				if (fuse_dd && p->comp_fir_size == 9)
 					RX_K(rxk_copy_small(sd, s->hist_dev + HIST_DROOP_IN, s->hist_dev + HIST_DROOP_OUT, 18 * 2));
@@ -925,6 +931,8 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 		s->h_prev_lpr_index = (int)((unsigned long long)g->pr0 + (g->M / (unsigned long long)g->post) * (unsigned long long)p->rate_out2 -
 		                            g->J * (unsigned long long)p->rate_out);
 	s->chained = 1;
+	s->last_fuse_a = fuse_a;
+	s->last_fuse_dd = fuse_dd;
 	s->pending++;
 	s->last = *g;
 	s->rec[db].live = 1;

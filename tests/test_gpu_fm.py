@@ -401,6 +401,49 @@ def test_config1_ragged_last_block():
     s.close()
 
 
+@pytest.mark.parametrize("kw", [dict(downsample_passes=3, comp_fir_size=9), dict(downsample_passes=4), dict(downsample_passes=7, comp_fir_size=9),
+                                dict(downsample_passes=3, comp_fir_size=9, custom_atan=0)])
+def test_pipelined_runs_of_different_shapes(kw):
+    """one pipelined sequence whose runs change shape -- whole tiles, ragged blocks (the literal per-block path), a block length with a
+    shorter first group -- so that the cascade and droop histories change hands between the seam stream and stream B from run to run;
+    block by block against the oracle, carries included"""
+    import ctypes as C
+    from gpu_support import to_dev, torch_cuda, carry_tuple, carry_from_oracle_state
+    from support import oracle, oracle_fm_state, ptr16
+    torch = torch_cuda()
+    shapes = [(4, 4096), (3, 1009), (2, 16384), (1, 4100), (3, 4096), (2, 2048), (2, 777), (5, 8192)]    # (blocks, complex samples per block)
+    total = sum(nb * n for nb, n in shapes)
+    iq = sig_fm(total, seed=123, amp=9000.0, noise=1200)
+    O, st = oracle(), oracle_fm_state(**kw)
+    lp, res, want = np.zeros(262144, np.int16), np.zeros(131072, np.int16), []
+    pos = 0
+    for nb, n in shapes:
+        for _ in range(nb):
+            blk = np.ascontiguousarray(iq[2 * pos:2 * (pos + n)])
+            k = O.rxo_fm_block(C.byref(st), ptr16(blk), 2 * n, ptr16(lp), None, ptr16(res))
+            want.append(res[:k].copy())
+            pos += n
+    want = np.concatenate(want)
+    for rep in range(3):                                     # the hand-over is a matter of timing: a few times
+        s = R.FmStream(R.FmParams.wbfm(**kw), 8, 2 * 16384)
+        d_iq = to_dev(iq)
+        d_out = torch.zeros(len(want) + 4096, dtype=torch.int16, device="cuda")
+        pos = got_n = 0
+        for nb, n in shapes:
+            k, _ = s.run_async(d_iq.data_ptr() + 4 * pos, nb, 2 * n, d_out.data_ptr() + 2 * got_n, d_out.numel() - got_n)
+            got_n += k
+            pos += nb * n
+        s.wait()
+        got = d_out[:got_n].cpu().numpy()
+        assert got_n == len(want) and np.array_equal(got, want)
+        cg, cw = carry_tuple(s.get_carry()), carry_tuple(carry_from_oracle_state(st))
+        np_ = 12 * kw["downsample_passes"]
+        assert cg[:8] == cw[:8] and cg[8][:np_] == cw[8][:np_] and cg[9][:np_] == cw[9][:np_]
+        if kw.get("comp_fir_size") == 9:
+            assert cg[10] == cw[10] and cg[11] == cw[11]
+        s.close()
+
+
 def test_error_codes():
     """bad geometry fails loudly with the documented codes, never silently"""
     import rx_tools_amd as R
