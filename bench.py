@@ -480,6 +480,7 @@ def main():
             # drop-in: rxgpu_callback + rxgpu_full_demod on the reference's own structs, block after block
             from rx_tools_amd.structs import DemodState, DongleState
             os.environ["RXGPU_DROPIN_TIMING"] = "1"                   # read once, at the first drop-in call of the process
+            L.rxgpu_knobs_reload()                                    # ... from the library's knob snapshot
             d = DemodState()
             d.rate_in = d.rate_out = 170000
             d.rate_out2, d.custom_atan, d.deemph, d.deemph_a, d.downsample = 32000, 1, 1, 13, 118

@@ -46,6 +46,10 @@ const char *rxgpu_last_error(void);
 /* the hipStream_t (as void*) all kernels of this library are launched on */
 void *rxgpu_stream(void);
 int rxgpu_sync(void);
+/* The $RXGPU_* tuning knobs (last table) are read from the environment at rxgpu_init and whenever a stream,
+ * channeliser or scan object is created -- never on a per-block path -- and an object keeps the plan it was created with.
+ * rxgpu_knobs_reload re-reads them now (A/B tools that flip a kernel-variant knob between runs of one object). */
+void rxgpu_knobs_reload(void);
 /* Page-lock / release a host buffer in place (hipHostRegister), so that the host-fed entry points
  * (rxgpu_fm_stream_run_host, the drop-ins) DMA it without a bounce.  Optional: pageable memory works too. */
 int rxgpu_pin(void *ptr, size_t bytes);
@@ -268,16 +272,27 @@ long rxgpu_chan_host_fixups(const rxgpu_chan *s);
  * the caller): for every tune, ts->avg[] += / MAX= and ts->samples += exactly as the CPU.
  * Globals of the reference are passed explicitly: window_coefs (rtl_power.c:87,1034-1037),
  * Sinewave (82,240-254; 3/4 * 2^bin_e entries), boxcar/comp_fir_size/peak_hold (115-117).
- * The sums stay ON THE DEVICE between calls (the reference reads avg[] only in csv_dbm, once per report interval,
- * rtl_power.c:1045-1050): a call uploads the tunes' buf16, adds the sweep to device-resident accumulators and returns
- * without waiting.  ts->avg[] / ts->samples are brought up to date by rxgpu_scan_sync -- which rxgpu_csv_dbm calls by itself
- * for a tuning_state of the sweep; call it explicitly in front of the reference's own csv_dbm or any other reader of the
- * struct ($RXGPU_SCAN_EAGER=1: every rxgpu_scan ends with it). */
+ * By default the call ends with the merge: the structs are current when it returns and the library keeps no pointer of the
+ * caller's past the call.
+ *
+ * rxgpu_scan_deferred(1) (or $RXGPU_SCAN_DEFERRED=1 at the first scan) -- what the INTEGRATION.md patch switches on, because the
+ * reference reads avg[] only in csv_dbm, once per report interval (rtl_power.c:1045-1050): the sums then stay ON THE DEVICE between
+ * calls -- a call uploads the tunes' buf16, adds the sweep to device-resident accumulators and returns without waiting -- and
+ * ts->avg[] / ts->samples are brought up to date by rxgpu_scan_sync(tunes, n), which rxgpu_csv_dbm calls by itself for a
+ * tuning_state of the sweep; call it explicitly in front of the reference's own csv_dbm or any other reader of the struct.
+ * LIFETIME in deferred mode: `tunes` must stay allocated until rxgpu_scan_sync has returned -- sync BEFORE freeing or replacing the
+ * array.  The library never writes through a pointer that was not handed to the running call: a pending interval that meets
+ * another array, count or geometry makes rxgpu_scan fail (RXGPU_EINVAL, "sync first"), one still pending at rxgpu_shutdown is
+ * dropped with a line on stderr. */
 int rxgpu_scan(struct tuning_state *tunes, int tune_count, const int *window_coefs,
                const int16_t *sinewave, int boxcar, int comp_fir_size, int peak_hold);
-/* merge what rxgpu_scan accumulated since the last sync into tunes[i].avg[] (+=, MAX with peak hold) and tunes[i].samples;
- * tunes == NULL: whatever array the pending sweep belongs to.  A no-op when nothing is pending. */
+/* deferred mode: merge what rxgpu_scan accumulated since the last sync into tunes[i].avg[] (+=, MAX with peak hold) and
+ * tunes[i].samples.  `tunes`/`tune_count` must be the array of the pending sweep (RXGPU_EINVAL otherwise, nothing is written).
+ * A no-op when nothing is pending (and always in the default mode). */
 int rxgpu_scan_sync(struct tuning_state *tunes, int tune_count);
+/* 1: leave the sums on the device between rxgpu_scan calls; 0 (default): merge at the end of every call.  Switching off with an
+ * interval pending is RXGPU_EINVAL. */
+int rxgpu_scan_deferred(int on);
 long rxgpu_scan_syncs(void);    /* downloads made so far (diagnostics / tests) */
 
 /* csv_dbm(ts) (rtl_power.c:774-817) writing to `file`.  Host code, NOT a device function: our restatement of the

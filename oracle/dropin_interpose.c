@@ -73,6 +73,11 @@ void scanner(size_t channel)
 	read_stream_fn SoapySDRDevice_readStream = (read_stream_fn)dlsym(RTLD_DEFAULT, "SoapySDRDevice_readStream");
 	(void)channel;
 	static int16_t flush[4 * 16384];
+	static int deferred;
+	if (!deferred) {                   /* tunes[] is a static global of the reference: it outlives every pending interval */
+		rxgpu_scan_deferred(1);
+		deferred = 1;
+	}
 	for (int i = 0; i < tune_count; i++) {
 		void *buffs[] = { tunes[i].buf16 };
 		void *fbuffs[] = { flush };
@@ -114,7 +119,7 @@ void csv_dbm(struct tuning_state *ts)
 			_exit(1);
 		}
 	}
-	if (rxgpu_scan_sync(NULL, 0) != RXGPU_OK) {
+	if (rxgpu_scan_sync((struct tuning_state *)dlsym(RTLD_DEFAULT, "tunes"), *(int *)dlsym(RTLD_DEFAULT, "tune_count")) != RXGPU_OK) {
 		fprintf(stderr, "rxgpu_scan_sync: %s\n", rxgpu_last_error());
 		_exit(1);
 	}

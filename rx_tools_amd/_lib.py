@@ -14,7 +14,7 @@ _lib = None
 
 # every symbol include/rxgpu.h declares; tests/test_abi.py checks they are all exported
 EXPORTS = [
-    "rxgpu_init", "rxgpu_shutdown", "rxgpu_device_count", "rxgpu_last_error", "rxgpu_stream", "rxgpu_sync",
+    "rxgpu_init", "rxgpu_shutdown", "rxgpu_device_count", "rxgpu_last_error", "rxgpu_stream", "rxgpu_sync", "rxgpu_knobs_reload",
     "rxgpu_pin", "rxgpu_unpin",
     "rxgpu_prof_enable", "rxgpu_prof_reset", "rxgpu_prof_get",
     "rxgpu_full_demod", "rxgpu_callback", "rxgpu_deemph_state", "rxgpu_set_demod_functions", "rxgpu_dropin_invalidate", "rxgpu_dropin_pin", "rxgpu_dropin_unpin", "rxgpu_dropin_timing",
@@ -25,7 +25,7 @@ EXPORTS = [
     "rxgpu_chan_create", "rxgpu_chan_destroy", "rxgpu_chan_set_carry", "rxgpu_chan_get_carry", "rxgpu_chan_run",
     "rxgpu_chan_set_audio_carry", "rxgpu_chan_get_audio_carry",
     "rxgpu_chan_host_fixups",
-    "rxgpu_scan", "rxgpu_scan_sync", "rxgpu_scan_syncs", "rxgpu_csv_dbm", "rxgpu_power_plan_range", "rxgpu_sine_table", "rxgpu_window_coefs",
+    "rxgpu_scan", "rxgpu_scan_sync", "rxgpu_scan_syncs", "rxgpu_scan_deferred", "rxgpu_csv_dbm", "rxgpu_power_plan_range", "rxgpu_sine_table", "rxgpu_window_coefs",
     "rxgpu_power_scan_create", "rxgpu_power_scan_destroy", "rxgpu_power_scan_run",
     "rxgpu_comm_unique_id", "rxgpu_comm_create", "rxgpu_comm_adopt", "rxgpu_comm_destroy", "rxgpu_comm_rank", "rxgpu_comm_world",
     "rxgpu_comm_gathers", "rxgpu_comm_library", "rxgpu_shard_tunes", "rxgpu_power_gather", "rxgpu_power_scan_run_sharded",
@@ -54,6 +54,7 @@ def lib():
         L.rxgpu_deemph_state.restype = C.POINTER(C.c_int)
         L.rxgpu_deemph_state.argtypes = [C.c_void_p]
         L.rxgpu_init.argtypes = [C.c_int]
+        L.rxgpu_knobs_reload.restype = None
         L.rxgpu_prof_enable.argtypes = [C.c_int]
         L.rxgpu_fm_stream_host_fixups.restype = C.c_long
         L.rxgpu_fm_stream_host_fixups.argtypes = [C.c_void_p]
@@ -85,6 +86,7 @@ def lib():
         L.rxgpu_scan.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.rxgpu_scan_sync.argtypes = [C.c_void_p, C.c_int]
         L.rxgpu_scan_syncs.restype = C.c_long
+        L.rxgpu_scan_deferred.argtypes = [C.c_int]
         L.rxgpu_csv_dbm.argtypes = [C.c_void_p, C.c_void_p]
         L.rxgpu_full_demod.argtypes = [C.c_void_p]
         L.rxgpu_set_demod_functions.argtypes = [C.c_void_p] * 5

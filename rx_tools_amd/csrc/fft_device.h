@@ -117,9 +117,16 @@ template <int M> struct fft_geom {
 // those threads are lanes of ONE wave (the kernels give a transform an aligned run of threads): a wave's LDS instructions execute in
 // program order, so no s_barrier is needed -- only that the compiler keeps the order -- and the waves of a workgroup stop waiting for
 // each other three times per transform.  Larger transforms span waves: a workgroup barrier.
+// The wave-private form is only right on 64-wide waves with a transform's TPF threads an aligned run of lanes inside one wave: gfx950 is
+// wave64 only, and the callers assert the layout (TPF divides 64, blockDim a multiple of 64).
+// (ROCm 7 no longer defines __AMDGCN_WAVEFRONT_SIZE; the target is checked instead, and rxgpu_init refuses a device whose warpSize is not 64.)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "fft_sync and the DPP scans of librxgpu are written for the 64-wide wavefronts of gfx950"
+#endif
 template <int M>
 __device__ __forceinline__ void fft_sync()
 {
+	static_assert(((1 << M) / 16) > 64 || 64 % ((1 << M) / 16) == 0, "a transform's threads must be an aligned run of lanes of one wave");
 	if constexpr (((1 << M) / 16) <= 64) {
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();

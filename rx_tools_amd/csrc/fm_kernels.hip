@@ -2098,7 +2098,9 @@ __device__ uint32_t level_val(const uint32_t *__restrict__ blk_raw, int idx)
 #pragma unroll
 		for (int k = 0; k < 6; k++)
 			t[k] = level_val<P - 1, ROTATE, STAGE2>(blk_raw, 2 * idx - 5 + k);
-		return fifth_any<STAGE2 ? 2 : 0>(t[0], t[1], t[2], t[3], t[4], t[5]);
+		// raw input: level P - 1 holds values up to 128 << (P - 1), the tap sum reaches 32 times that -- 2^15 from the fifth level on
+		// (P >= 4), where the packed int16 sum would wrap on a saturated capture: 32-bit sums there, like the register kernel's WIDE passes
+		return fifth_any<STAGE2 ? 2 : (P >= 4 ? 1 : 0)>(t[0], t[1], t[2], t[3], t[4], t[5]);
 	}
 }
 
@@ -3117,7 +3119,7 @@ __global__ __launch_bounds__(256) void k_ch_fft(const uint32_t *__restrict__ iq,
 // windows per workgroup: 32 while the [n_channels][wpg] staging fits beside the transform buffers, else 16
 static inline int ch_wpg(int n_channels)
 {
-	const char *e = getenv("RXGPU_CH_WPG");                  /* 16 | 32: A/B of the window group (LDS per workgroup vs work of the sparse demodulator pass) */
+	const char *e = rxgpu_knob("RXGPU_CH_WPG");                  /* 16 | 32: A/B of the window group (LDS per workgroup vs work of the sparse demodulator pass) */
 	if (e && (atoi(e) == 16 || atoi(e) == 32))
 		return atoi(e);
 	(void)n_channels;
@@ -3369,7 +3371,7 @@ extern "C" int rxk_fm_decimate(void *stream, const int16_t *iq, u64 T, int ds, i
 	const unsigned slot_cap = (RXK_DEC_SPAN + ds) / ds + 4 + 64;      /* + one turn of lanes past the last output (read, never used) */
 	/* 16-byte slot records (the prefix selection left to the reader, dec_prefix_wide) where they stay small: raw input, ds >= 64
 	 * (at most 5 KiB of LDS per workgroup); $RXGPU_DEC_NARROW keeps the 4-byte slots (A/B) */
-	const bool wide = !prescaled && ds >= 64 && !getenv("RXGPU_DEC_NARROW");
+	const bool wide = !prescaled && ds >= 64 && !rxgpu_knob("RXGPU_DEC_NARROW");
 	const size_t shm = (size_t)((wide ? 4 : 1) * slot_cap + 4) * sizeof(uint32_t);
 	hipStream_t s = (hipStream_t)stream;
 	const u32x4 *p = (const u32x4 *)iq;
@@ -3397,7 +3399,7 @@ extern "C" int rxk_fm_decimate_small(void *stream, const int16_t *iq, u64 T, int
 	 * and the audio stages of the previous run -- long, latency-bound waves on the other stream -- always find slots beside them
 	 * (A/B in one process at ds = 6: 2 % on the pipelined step; $RXGPU_DSM_LDS sets another floor) */
 	size_t lds = (size_t)(span + 2 * DSM_HALO + 8) * 4;
-	const size_t lds_floor = getenv("RXGPU_DSM_LDS") ? (size_t)atoi(getenv("RXGPU_DSM_LDS")) : 32000;
+	const size_t lds_floor = rxgpu_knob("RXGPU_DSM_LDS") ? (size_t)atoi(rxgpu_knob("RXGPU_DSM_LDS")) : 32000;
 	if (lds < lds_floor && lds_floor <= 65536)
 		lds = lds_floor;
 	hipStream_t s = (hipStream_t)stream;
@@ -3564,7 +3566,7 @@ extern "C" int rxk_fm_deemph_scan_t(void *stream, const int16_t *pcm_t, u64 M, i
 	const unsigned grid = (unsigned)((n_chunks + 255) / 256);
 	hipStream_t s = (hipStream_t)stream;
 	const unsigned mg = deemph_magic(a);
-	const char *pick = getenv("RXGPU_SCAN_T");                       /* "1": always scan_t, "0": scan_r wherever it applies (tests) */
+	const char *pick = rxgpu_knob("RXGPU_SCAN_T");                       /* "1": always scan_t, "0": scan_r wherever it applies (tests) */
 	if (chl2 == 7 && (pick ? pick[0] == '0' : M >= (1ull << 25))) {
 		/* 128-sample chunks of a LONG run (the small-decimation chains, where the audio stages' traffic counts): the chunk in
 		 * registers, the warm-up from the neighbouring lane; 63 chunks per wave.  Short runs keep scan_t: behind the big-ds
@@ -3782,12 +3784,12 @@ extern "C" int rxk_fm_fifth_fused(void *stream, const void *in, int stage2, int 
 	/* the raw stage's workgroups take a fifth of the CU's LDS each (15 KiB of tiles + this pad): with eight per CU the kernel is no
 	 * faster, and the later passes / discriminator / audio stages of the previous run on the other stream wait for wave slots
 	 * (A/B in one process, -F ds=128 pipelined: 0.92 -> 0.98 TSample/s; $RXGPU_FF_PAD sets another pad) */
-	const size_t pad = stage2 ? 0 : getenv("RXGPU_FF_PAD") ? (size_t)atoi(getenv("RXGPU_FF_PAD")) : 17000;
+	const size_t pad = stage2 ? 0 : rxgpu_knob("RXGPU_FF_PAD") ? (size_t)atoi(rxgpu_knob("RXGPU_FF_PAD")) : 17000;
 #define FUSED(F, RT, S2) hipLaunchKernelGGL((k_fm_fifth_fused<F, RT, S2, false>), dim3(grid), dim3(256), pad, s, p, n, tiles, tpw, seams, out, n, n >> F)
 #define GO(RT, S2) do { if (hist_in) SEAMS(RT, S2); if (fuse == 1) FUSED(1, RT, S2); else if (fuse == 2) FUSED(2, RT, S2); else FUSED(3, RT, S2); } while (0)
 	/* four (or five) passes on the raw capture: the register kernel, 16 (32) samples per lane.  Three passes stay with the LDS-tiled kernel
 	 * below -- in the -M wbfm -F 9 chain it is 3-5 % ahead (A/B) -- unless $RXGPU_FR_GENERIC=1 (tests: the LV = 3 instantiation) */
-	if (!stage2 && (fuse == 4 || fuse == 5 || (fuse == 3 && getenv("RXGPU_FR_GENERIC")))) {
+	if (!stage2 && (fuse == 4 || fuse == 5 || (fuse == 3 && rxgpu_knob("RXGPU_FR_GENERIC")))) {
 		const unsigned tiles_r = ((n >> fuse) + FR_OUT - 1) / FR_OUT;
 		/* one tile per wave: walking two or four with the next one's loads in flight (what the whole-chain kernel below does) made this
 		 * one, which has half the arithmetic per byte, 5-10 % slower (A/B, -F ds=128: 1730 / 1823 / 1908 us per step) */
@@ -3829,7 +3831,7 @@ extern "C" int rxk_fm_fifth_dd(void *stream, const void *in, int rotate, u64 n_b
 	const uint32_t *p = (const uint32_t *)in;
 	const unsigned tiles_r = ((n >> fuse) / 4 + FR_OUT - 1) / FR_OUT;
 	/* tiles a wave walks, the next one's loads in flight behind the current one's arithmetic ($RXGPU_DD_TW=1|2|4) */
-	const char *tw_env = getenv("RXGPU_DD_TW");
+	const char *tw_env = rxgpu_knob("RXGPU_DD_TW");
 	const unsigned tw = tw_env ? (unsigned)atoi(tw_env) : 2u;
 	const unsigned twn = (tw == 4 || tw == 2) && tiles_r >= 4 * tw ? tw : 1u;
 	const unsigned wgs_per_block = (tiles_r + 4 * twn - 1) / (4 * twn);

@@ -12,6 +12,10 @@
 extern "C" {
 #endif
 
+/* the snapshot of a $RXGPU_* tuning knob (rxgpu_rt.c: read at rxgpu_init, object creation and rxgpu_knobs_reload -- never on a launch
+ * path); NULL when unset */
+const char *rxgpu_knob(const char *name);
+
 /* complex samples one workgroup of the fast boxcar decimator covers (power of two) */
 #define RXK_DEC_SPAN 16384
 #define RXK_DEC_SPAN_LOG2 14

@@ -901,7 +901,7 @@ extern "C" int rxk_pw_fft(void *stream, const int16_t *in, size_t tune_stride, s
 	dim3 grid((unsigned)tunes, (unsigned)groups);
 	hipStream_t s = (hipStream_t)stream;
 	const int fpw = n >= 4096 ? 1 : 4096 / n;                       /* transforms side by side in a k_pw_fftR workgroup */
-	const bool k4096 = bin_e == 12 && (eff_len == 8192 || eff_len == 16384 || eff_len == 32768) && !getenv("RXGPU_FFT_GENERIC");
+	const bool k4096 = bin_e == 12 && (eff_len == 8192 || eff_len == 16384 || eff_len == 32768) && !rxgpu_knob("RXGPU_FFT_GENERIC");
 	i64 *part = (partial && bin_e >= 8 && bin_e <= 13 && eff_len % (2 * n) == 0 &&
 	             (size_t)groups * tunes * fpw * (size_t)n <= partial_cap) ? (i64 *)partial : nullptr;
 	if (k4096) {
@@ -915,7 +915,7 @@ extern "C" int rxk_pw_fft(void *stream, const int16_t *in, size_t tune_stride, s
 			                   peak_hold, (i64 *)avg);
 		LAUNCH_RET();
 	}
-	if (bin_e >= 8 && bin_e <= 13 && eff_len % (2 * n) == 0 && !getenv("RXGPU_FFT_GENERIC")) {
+	if (bin_e >= 8 && bin_e <= 13 && eff_len % (2 * n) == 0 && !rxgpu_knob("RXGPU_FFT_GENERIC")) {
 		/* register-blocked kernel for every power of two from 256 to 8192.  2^14 was tried (round 2): N/16 = 1024 threads leave 128
 		 * VGPRs per lane, the transform wants ~200, and the spilling build ran 3.3x slower than the LDS radix-2 kernel below */
 		const int nb_total = eff_len / (2 * n);

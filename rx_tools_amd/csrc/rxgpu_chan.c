@@ -46,6 +46,7 @@ int rxgpu_chan_create(rxgpu_chan **out, const rxgpu_chan_params *p, size_t max_b
 		return rxgpu_fail(RXGPU_EUNSUPPORTED, "low_pass_real needs rate_out >= rate_out2 > 0 (got %d, %d)", p->rate_out, p->rate_out2);
 	if ((rc = rxgpu_ensure_init()) != RXGPU_OK)
 		return rc;
+	rxgpu_knobs_reload();                            /* the object keeps the kernel variants chosen now */
 	s = calloc(1, sizeof(*s));
 	if (!s)
 		return rxgpu_fail(RXGPU_ENOMEM, "out of host memory");

@@ -83,6 +83,9 @@ struct rxgpu_fm_stream {
 	int group, warm, lo0, hi0, gap_w;
 	int chunk;                           /* de-emphasis scan: samples per chunk */
 	int topcap_override;                 /* $RXGPU_DEEMPH_TOPCAP: forces the multi-level scan (tests) */
+	/* plan knobs, read once at creation (rxgpu_knob): $RXGPU_FUSE_A, _NO_FUSED_DD, _NO_TILED, _NO_SMALL, _DEEMPH_CHUNK, _HOST_CHUNK */
+	int k_fuse_a, k_no_fused_dd, k_no_tiled, k_no_small, k_deemph_chunk;
+	unsigned long long k_host_chunk;
 	int flag_all;                        /* $RXGPU_FLAG_ALL: every libm discriminator sample goes through the host re-evaluation (tests) */
 	int allow_empty;                     /* the drop-in: a block that yields no decimated sample is legal (the struct-memory reads the
 	                                      * reference then makes are reproduced by rxgpu_full_demod on the real struct) */
@@ -205,10 +208,21 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 	if (!s->p.output_scale)
 		s->p.output_scale = 1;
 	{
-		const char *e = getenv("RXGPU_DEEMPH_TOPCAP");
+		/* the knobs that shape this stream's launch plan, fixed for its life: chained runs never see one flip */
+		rxgpu_knobs_reload();
+		const char *e = rxgpu_knob("RXGPU_DEEMPH_TOPCAP");
 		s->topcap_override = (e && atoi(e) > 0) ? atoi(e) : 0;
-		e = getenv("RXGPU_FLAG_ALL");
+		e = rxgpu_knob("RXGPU_FLAG_ALL");
 		s->flag_all = (e && atoi(e) > 0) ? atoi(e) : 0;
+		e = rxgpu_knob("RXGPU_FUSE_A");
+		s->k_fuse_a = e ? atoi(e) : 0;
+		s->k_no_fused_dd = rxgpu_knob("RXGPU_NO_FUSED_DD") != NULL;
+		s->k_no_tiled = rxgpu_knob("RXGPU_NO_TILED") != NULL;
+		s->k_no_small = rxgpu_knob("RXGPU_NO_SMALL") != NULL;
+		e = rxgpu_knob("RXGPU_DEEMPH_CHUNK");
+		s->k_deemph_chunk = e ? atoi(e) : 0;
+		e = rxgpu_knob("RXGPU_HOST_CHUNK");
+		s->k_host_chunk = e ? strtoull(e, NULL, 10) : 0;
 	}
 	s->max_blocks = max_blocks;
 	s->block_len = block_len;
@@ -637,13 +651,13 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 	/* -F on the raw capture: the first fused group of fifth_order passes reads 8/9 of all the bytes of the run; like the
 	 * boxcar decimator it goes on stream A, so that it overlaps the later passes and the audio stages of the run before */
 	/* four passes in that group where the cascade has them (the next group then reads 1/16 of the capture, not 1/8); $RXGPU_FUSE_A=3 keeps three */
-	const int fuse_a_env = getenv("RXGPU_FUSE_A") ? atoi(getenv("RXGPU_FUSE_A")) : 0;
+	const int fuse_a_env = s->k_fuse_a;
 	const int fuse_a_max = (fuse_a_env >= 3 && fuse_a_env <= 5) ? fuse_a_env : 4;
 	const int fuse_a = (g->passes && !g->literal && !prescaled && (g->n % RXK_FIFTH_TILE) == 0 && s->cas_a[0]) ? (g->passes < fuse_a_max ? g->passes : fuse_a_max) : 0;
 	/* a three-pass cascade is the whole of the group: the droop FIR and the discriminator ride in the same launch and only pcm leaves it
 	 * ($RXGPU_NO_FUSED_DD=1: the separate kernels) */
 	const int fuse_dd = fuse_a == 3 && g->passes == 3 && p->mode == RXGPU_MODE_FM && !p->squelch_level && p->custom_atan == 1 &&
-	                    (p->comp_fir_size == 9 || p->comp_fir_size == 0) && !getenv("RXGPU_NO_FUSED_DD");
+	                    (p->comp_fir_size == 9 || p->comp_fir_size == 0) && !s->k_no_fused_dd;
 	const int fresh = !s->chained;
 
 	if (!s->chained) {
@@ -692,13 +706,12 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 	int lit_done = 0;                        /* the literal per-block path did squelch and demodulation itself */
 	/* de-emphasis + resampler behind an fm discriminator: hand them the demodulated samples in the tiled layout their
 	 * lane-per-chunk kernels stream (rxk_fm_deemph_scan_t / _apply_rs_t).  $RXGPU_NO_TILED keeps the LDS-staged kernels. */
-	if (!split && !g->literal && p->deemph && s->group && p->rate_out2 > 0 && g->post == 1 && !p->dc_block_audio && !getenv("RXGPU_NO_TILED"))
+	if (!split && !g->literal && p->deemph && s->group && p->rate_out2 > 0 && g->post == 1 && !p->dc_block_audio && !s->k_no_tiled)
 	{
 		/* $RXGPU_DEEMPH_CHUNK=256 forces the larger chunk where the warm-up would fit 128 (tests of that template; measured: no
 		 * gain -- the scan's warm-up weighs less, but the resampler's per-wave staging doubles and with it the LDS a workgroup needs
 		 * to find beside the decimator's) */
-		const char *force = getenv("RXGPU_DEEMPH_CHUNK");
-		const int chunk = (force && atoi(force) == 256 && s->chunk < 256) ? 256 : s->chunk;
+		const int chunk = (s->k_deemph_chunk == 256 && s->chunk < 256) ? 256 : s->chunk;
 		s->tiled = rxk_fm_deemph_tiled_ok(p->deemph_a, s->group, chunk, p->rate_out, p->rate_out2);
 	}
 	if (!g->passes) {
@@ -708,7 +721,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 		const int lp_sparse = fused_disc && !prescaled && g->ds <= RXK_LP_SPARSE_MAX_DS;
 		/* small decimation on the raw capture: the direct kernel (samples staged in LDS, a thread per output, no seams) */
 		const int small = g->fast && fused_disc && !prescaled && g->ds >= RXK_DEC_SMALL_MIN && g->ds <= RXK_DEC_SMALL_MAX &&
-		                  !getenv("RXGPU_NO_SMALL");
+		                  !s->k_no_small;
 		if (g->fast) {
 			s->lp_final = s->lp_raw[db];
 			/* buffer set `db` was last read by the audio chain two runs ago */
@@ -1020,6 +1033,7 @@ static int finish_runs(rxgpu_fm_stream *s)
 		 * enqueue would trip over again, and say so to whoever asks for the carries -- set_carry + a replay recovers */
 		hipStreamSynchronize(sa);
 		hipStreamSynchronize(sb);
+		hipStreamSynchronize(rxgpu_hip_stream4());       /* the seam/history kernels of a -F run that was enqueued ahead */
 		s->rec[0].live = s->rec[1].live = 0;
 		s->flag_cnt_host[0] = s->flag_cnt_host[1] = 0;
 		s->pending = 0;
@@ -1122,11 +1136,8 @@ static int run_host_chunked(rxgpu_fm_stream *s, const int16_t *h_iq, size_t n_bl
 	int rc;
 	hipStream_t sa = rxgpu_hip_stream(), sb = rxgpu_hip_stream2(), sc = rxgpu_hip_stream3();
 	size_t chunk_target = HOST_CHUNK_BYTES;
-	{
-		const char *e = getenv("RXGPU_HOST_CHUNK");      /* bytes; tests use it to get many chunks out of a small capture */
-		if (e && atol(e) > 0)
-			chunk_target = (size_t)atol(e);
-	}
+	if (s->k_host_chunk)                                 /* $RXGPU_HOST_CHUNK, bytes; tests use it to get many chunks out of a small capture */
+		chunk_target = (size_t)s->k_host_chunk;
 	size_t cb = chunk_target / (block_len * 2);
 	if (cb < 1) cb = 1;
 	if (cb > n_blocks) cb = n_blocks;
@@ -1422,7 +1433,7 @@ static double now_us(void)
 static int dt_on(void)
 {
 	if (g_dt_on < 0) {
-		const char *e = getenv("RXGPU_DROPIN_TIMING");
+		const char *e = rxgpu_knob("RXGPU_DROPIN_TIMING");
 		g_dt_on = e && atoi(e) > 0;
 	}
 	return g_dt_on;
@@ -1646,7 +1657,7 @@ void rxgpu_callback(int16_t *buf, uint32_t len, void *ctx)
 			buf[i] = 0;
 		s->mute = 0;
 	}
-	if (len && d->dc_block_raw && len < 2) {
+	if (!len && d->dc_block_raw) {
 		rxgpu_fail(RXGPU_EUNSUPPORTED, "-E rdc on an empty read divides by zero in the reference (rtl_fm.c:711)");
 		die("rxgpu_callback");
 	}

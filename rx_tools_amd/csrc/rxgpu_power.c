@@ -242,6 +242,7 @@ int rxgpu_power_scan_create(rxgpu_power_scan **out, const rxgpu_power_params *p,
 		return rxgpu_fail(RXGPU_EINVAL, "buf_len %d shorter than one FFT block", p->buf_len);
 	if ((rc = rxgpu_ensure_init()) != RXGPU_OK)
 		return rc;
+	rxgpu_knobs_reload();                            /* the object keeps the kernel variants chosen now */
 	s = calloc(1, sizeof(*s));
 	if (!s)
 		return rxgpu_fail(RXGPU_ENOMEM, "out of host memory");
@@ -327,7 +328,7 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 			 * the plain kernel below zero-fills up to n_read like the in-place original.  The reference's planner never makes that
 			 * geometry, rxgpu_power_scan_create accepts it.) */
 			if (ds >= 4 && ds <= RXK_DEC_MAX_DS && nc % (unsigned long long)ds == 0 && T % 4 == 0 && eff % (2 * n_fft) == 0 &&
-			    !getenv("RXGPU_BOXCAR_PLAIN")) {
+			    !rxgpu_knob("RXGPU_BOXCAR_PLAIN")) {
 				/* whole windows per buffer: the sums over the concatenated buffers are low_pass (rtl_fm.c:351-371) on an already
 				 * scaled, unrotated stream -- the rx_fm decimator, then its per-span seam entries; output compact, eff_len per buffer */
 				const size_t n_spans = (size_t)((T + RXK_DEC_SPAN - 1) / RXK_DEC_SPAN) + 1;
@@ -352,7 +353,7 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 			for (int j = 0; j < ds_p;) {
 				/* up to three passes per launch while the pass input is whole tiles; otherwise one pass at a time */
 				int fuse = ds_p - j < 3 ? ds_p - j : 3;
-				while (fuse > 0 && (n_in % RXK_FIFTH_TILE || getenv("RXGPU_FIFTH_PLAIN")))
+				while (fuse > 0 && (n_in % RXK_FIFTH_TILE || rxgpu_knob("RXGPU_FIFTH_PLAIN")))
 					fuse = 0;
 				if (fuse) {
 					RX_K(rxk_pw_fifth_fused(st, src, n_bufs, (unsigned)n_in, (unsigned)(buf_len / 2), fuse, s->work[which], (unsigned)(buf_len / 2)));
@@ -380,7 +381,7 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 	int groups = (4096 + tunes - 1) / tunes;
 	/* few tunes (a narrow sweep with fine bins): thousands of passes land on the same N bins.  Fewer, longer groups, and their
 	 * spectra go to a partial buffer that one reduction folds into avg[] instead of int64 atomics from every group */
-	const int few = p->bin_e >= 8 && p->bin_e <= 13 && eff_len % (2 << p->bin_e) == 0 && tunes <= 64 && !getenv("RXGPU_FFT_GENERIC");
+	const int few = p->bin_e >= 8 && p->bin_e <= 13 && eff_len % (2 << p->bin_e) == 0 && tunes <= 64 && !rxgpu_knob("RXGPU_FFT_GENERIC");
 	if (few)
 		groups = (1024 + tunes - 1) / tunes;
 	if (groups > passes) groups = passes;
@@ -401,8 +402,8 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 	/* N = 2^14 .. 2^21 (the reference's limit) with whole blocks: the register-blocked transform in two to four launches over a scratch
 	 * copy (rxk_pw_fft_mid: radix-16 passes through HBM until a sub-transform fits a workgroup); $RXGPU_FFT_STAGEWISE keeps the
 	 * one-launch-per-radix-2-stage network for N > 2^15 */
-	const int mid = p->bin_e >= 14 && p->bin_e <= 21 && eff_len % (2 << p->bin_e) == 0 && !getenv("RXGPU_FFT_GENERIC") &&
-	                !(p->bin_e > 15 && getenv("RXGPU_FFT_STAGEWISE"));
+	const int mid = p->bin_e >= 14 && p->bin_e <= 21 && eff_len % (2 << p->bin_e) == 0 && !rxgpu_knob("RXGPU_FFT_GENERIC") &&
+	                !(p->bin_e > 15 && rxgpu_knob("RXGPU_FFT_STAGEWISE"));
 	if (p->bin_e > PW_LDS_BIN_E || mid) {
 		const size_t total = (size_t)passes * (size_t)tunes * (size_t)n_blocks, n = (size_t)1 << p->bin_e;
 		size_t want = ((size_t)1 << 28) / n;                /* up to 1 GiB of scratch */
@@ -461,7 +462,14 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
  * reference's own csv_dbm) brings the accumulated sums back ONCE per interval and merges them into the caller's arrays:
  * avg += delta, or MAX for peak hold (every term is a non-negative power, so a running maximum that starts from zero
  * commutes with the caller's), samples += delta.  The first version moved all of avg[] both ways on every call: 2 x 19.6 MB
- * for 9.8 MB of input.  $RXGPU_SCAN_EAGER=1 syncs at the end of every call (the struct is then current after each sweep). */
+ * for 9.8 MB of input.
+ *
+ * Deferred accumulation is OPT-IN (rxgpu_scan_deferred(1), or $RXGPU_SCAN_DEFERRED=1 read at the first rxgpu_scan): by default every
+ * rxgpu_scan ends with the merge, so the structs are current when it returns ("exactly as the CPU") and the library keeps no pointer of
+ * the caller's past the call.  In deferred mode the library keeps `tunes` between calls, and the rule is: it only ever writes through a
+ * pointer the caller has handed to the call that is running -- rxgpu_scan_sync(tunes, n), rxgpu_csv_dbm(&tunes[i]) -- so a pending
+ * interval that meets another array, count or geometry FAILS rxgpu_scan (RXGPU_EINVAL: sync first), and one that is still pending at
+ * rxgpu_shutdown / rxgpu_power_dropin_release is dropped with a line on stderr: the old array may be gone by then. */
 static struct {
 	rxgpu_power_scan *s;
 	rxgpu_power_params p;
@@ -479,8 +487,9 @@ static struct {
 	struct tuning_state *tunes;      /* whose sums the accumulators hold */
 	int tune_count;
 	int dirty;
+	int deferred;                    /* -1: not decided yet ($RXGPU_SCAN_DEFERRED at the first scan), 0: every scan merges, 1: rxgpu_scan_sync does */
 	long syncs;
-} g_scan;
+} g_scan = { .deferred = -1 };
 static pthread_mutex_t g_scan_lock = PTHREAD_MUTEX_INITIALIZER;
 
 static void scan_cache_drop(void)
@@ -494,11 +503,16 @@ static void scan_cache_drop(void)
 	}
 	hipFree(g_scan.d_avg); hipFree(g_scan.d_samples);
 	if (g_scan.h_avg) hipHostFree(g_scan.h_avg);
+	const int deferred = g_scan.deferred;
+	const long syncs = g_scan.syncs;
 	memset(&g_scan, 0, sizeof(g_scan));
+	g_scan.deferred = deferred;
+	g_scan.syncs = syncs;
 }
 
-/* accumulators -> the caller's tuning_state array they belong to; the device side starts from zero again */
-static int scan_sync_locked(void)
+/* accumulators -> `tunes`, the array the running call was handed (the one the pending sums belong to: the callers check);
+ * the device side starts from zero again */
+static int scan_sync_locked(struct tuning_state *tunes)
 {
 	if (!g_scan.dirty)
 		return RXGPU_OK;
@@ -512,7 +526,7 @@ static int scan_sync_locked(void)
 	RX_HIP(hipMemsetAsync(g_scan.d_samples, 0, (size_t)tc * 4, st));
 	RX_HIP(hipStreamSynchronize(st));
 	for (int i = 0; i < tc; i++) {
-		int64_t *avg = g_scan.tunes[i].avg;
+		int64_t *avg = tunes[i].avg;
 		const int64_t *delta = g_scan.h_avg + (size_t)i * n;
 		if (g_scan.p.peak_hold) {
 			for (size_t j = 0; j < n; j++)
@@ -522,9 +536,10 @@ static int scan_sync_locked(void)
 			for (size_t j = 0; j < n; j++)
 				avg[j] += delta[j];
 		}
-		g_scan.tunes[i].samples += h_samples[i];
+		tunes[i].samples += h_samples[i];
 	}
 	g_scan.dirty = 0;
+	g_scan.tunes = NULL;                             /* nothing pending: no pointer of the caller's is kept */
 	g_scan.syncs++;
 	rxgpu_prof_collect();
 	return RXGPU_OK;
@@ -533,8 +548,9 @@ static int scan_sync_locked(void)
 void rxgpu_power_dropin_release(void)
 {
 	pthread_mutex_lock(&g_scan_lock);
-	if (g_scan.dirty)
-		scan_sync_locked();                              /* what was accumulated belongs to the caller */
+	if (g_scan.dirty)                                    /* deferred mode only; the array it belongs to may be gone: never written here */
+		fprintf(stderr, "librxgpu: dropping the sums of a sweep interval over %d tunes that was never merged "
+		        "(rxgpu_scan_sync before rxgpu_shutdown)\n", g_scan.tune_count);
 	scan_cache_drop();
 	pthread_mutex_unlock(&g_scan_lock);
 }
@@ -559,9 +575,15 @@ static int scan_locked(struct tuning_state *tunes, int tune_count, const int *wi
 	if (same && p.bin_e > 0)
 		same = window_coefs && sinewave && !memcmp(g_scan.window_copy, window_coefs, n * sizeof(int)) &&
 		       !memcmp(g_scan.sine_copy, sinewave, n_sine * sizeof(int16_t));
-	/* another sweep geometry, another tuning_state array or count: what was accumulated goes home first */
-	if (g_scan.dirty && (!same || tunes != g_scan.tunes || tune_count != g_scan.tune_count) && (rc = scan_sync_locked()) != RXGPU_OK)
-		return rc;
+	if (g_scan.deferred < 0) {
+		const char *e = rxgpu_knob("RXGPU_SCAN_DEFERRED");
+		g_scan.deferred = e && atoi(e) > 0;
+	}
+	/* a pending interval (deferred mode) and another sweep geometry, tuning_state array or count: the sums belong to an array this
+	 * call was not handed -- it may have been freed -- so they are not written anywhere; the caller has to merge them first */
+	if (g_scan.dirty && (!same || tunes != g_scan.tunes || tune_count != g_scan.tune_count))
+		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_scan: %d tunes of another sweep are still accumulated on the device "
+		                  "(deferred mode): call rxgpu_scan_sync on that array first", g_scan.tune_count);
 	if (!same) {
 		scan_cache_drop();
 		if ((rc = rxgpu_power_scan_create(&g_scan.s, &p, tune_count, window_coefs, sinewave)) != RXGPU_OK)
@@ -608,11 +630,8 @@ static int scan_locked(struct tuning_state *tunes, int tune_count, const int *wi
 	RX_HIP(hipEventRecord(g_scan.ev_in[k], st));
 	g_scan.ev_valid[k] = 1;
 	g_scan.dirty = 1;
-	{
-		const char *e = getenv("RXGPU_SCAN_EAGER");
-		if (e && atoi(e) > 0)
-			return scan_sync_locked();
-	}
+	if (!g_scan.deferred)
+		return scan_sync_locked(tunes);
 	return RXGPU_OK;
 }
 
@@ -635,11 +654,25 @@ int rxgpu_scan_sync(struct tuning_state *tunes, int tune_count)
 	int rc = RXGPU_OK;
 	pthread_mutex_lock(&g_scan_lock);
 	if (g_scan.dirty) {
-		if (tunes && (tunes != g_scan.tunes || tune_count != g_scan.tune_count))
+		if (!tunes)
+			rc = rxgpu_fail(RXGPU_EINVAL, "rxgpu_scan_sync: pass the tuning_state array of the pending sweep (%d tunes)", g_scan.tune_count);
+		else if (tunes != g_scan.tunes || tune_count != g_scan.tune_count)
 			rc = rxgpu_fail(RXGPU_EINVAL, "rxgpu_scan_sync: the accumulated sweep belongs to another tuning_state array (%d tunes)", g_scan.tune_count);
 		else
-			rc = scan_sync_locked();
+			rc = scan_sync_locked(tunes);
 	}
+	pthread_mutex_unlock(&g_scan_lock);
+	return rc;
+}
+
+int rxgpu_scan_deferred(int on)
+{
+	int rc = RXGPU_OK;
+	pthread_mutex_lock(&g_scan_lock);
+	if (g_scan.dirty && !on)
+		rc = rxgpu_fail(RXGPU_EINVAL, "rxgpu_scan_deferred(0): %d tunes are still accumulated on the device, rxgpu_scan_sync first", g_scan.tune_count);
+	else
+		g_scan.deferred = on ? 1 : 0;
 	pthread_mutex_unlock(&g_scan_lock);
 	return rc;
 }
@@ -667,7 +700,7 @@ void rxgpu_csv_dbm(struct tuning_state *ts, void *file)
 	/* the row of a sweep whose sums are still on the device: bring them home first (once per interval -- the next rows find
 	 * nothing pending) */
 	pthread_mutex_lock(&g_scan_lock);
-	if (g_scan.dirty && ts >= g_scan.tunes && ts < g_scan.tunes + g_scan.tune_count && scan_sync_locked() != RXGPU_OK)
+	if (g_scan.dirty && ts >= g_scan.tunes && ts < g_scan.tunes + g_scan.tune_count && scan_sync_locked(g_scan.tunes) != RXGPU_OK)
 		fprintf(stderr, "rxgpu_csv_dbm: %s\n", rxgpu_last_error());
 	pthread_mutex_unlock(&g_scan_lock);
 	const int len = 1 << ts->bin_e, ds = ts->downsample;

@@ -36,6 +36,45 @@ int rxgpu_device_count(void)
 
 static int init_locked(int device);
 
+/* ------------------------------------------------------------------ tuning knobs
+ * $RXGPU_* switches (A/B of kernel variants, test hooks; INTEGRATION.md lists them) are read from the environment in ONE place and
+ * at known times -- rxgpu_init, the creation of a stream / channeliser / scan object, rxgpu_knobs_reload -- into a snapshot the
+ * launch paths read: no getenv() on the per-block path (getenv is not safe against a concurrent setenv, and the drop-in runs on
+ * two threads of the caller), and a knob cannot flip between two chained runs of one object.  A value that changes gets a fresh
+ * copy and the old one is never freed (a reader may still hold it): a few bytes per changed knob. */
+static const char *const g_knob_names[] = {
+	"RXGPU_FUSE_A", "RXGPU_NO_FUSED_DD", "RXGPU_NO_TILED", "RXGPU_DEEMPH_CHUNK", "RXGPU_NO_SMALL", "RXGPU_DEEMPH_TOPCAP", "RXGPU_FLAG_ALL",
+	"RXGPU_HOST_CHUNK", "RXGPU_DROPIN_TIMING", "RXGPU_BOXCAR_PLAIN", "RXGPU_FIFTH_PLAIN", "RXGPU_FFT_GENERIC", "RXGPU_FFT_STAGEWISE",
+	"RXGPU_SCAN_DEFERRED", "RXGPU_CH_WPG", "RXGPU_DEC_NARROW", "RXGPU_DSM_LDS", "RXGPU_SCAN_T", "RXGPU_FF_PAD", "RXGPU_FR_GENERIC", "RXGPU_DD_TW",
+	"RXGPU_FFT_TW", "RXGPU_CH_DENSE", "RXGPU_NO_DEC_TABLE", "RXGPU_APPLY_ILP", "RXGPU_CAS_MAILBOX", "RXGPU_SDR_V", "RXGPU_EXP0", "RXGPU_EXP1", "RXGPU_EXP2", "RXGPU_EXP3",
+};
+#define N_KNOBS ((int)(sizeof(g_knob_names) / sizeof(g_knob_names[0])))
+static const char *volatile g_knob_val[sizeof(g_knob_names) / sizeof(g_knob_names[0])];
+static pthread_mutex_t g_knob_lock = PTHREAD_MUTEX_INITIALIZER;
+
+void rxgpu_knobs_reload(void)
+{
+	pthread_mutex_lock(&g_knob_lock);
+	for (int i = 0; i < N_KNOBS; i++) {
+		const char *e = getenv(g_knob_names[i]);
+		const char *old = g_knob_val[i];
+		if (!e)
+			g_knob_val[i] = NULL;
+		else if (!old || strcmp(old, e))
+			g_knob_val[i] = strdup(e);
+	}
+	pthread_mutex_unlock(&g_knob_lock);
+}
+
+const char *rxgpu_knob(const char *name)
+{
+	for (int i = 0; i < N_KNOBS; i++)
+		if (!strcmp(g_knob_names[i], name))
+			return g_knob_val[i];
+	fprintf(stderr, "librxgpu: knob %s is not in the snapshot table (rxgpu_rt.c)\n", name);
+	abort();
+}
+
 int rxgpu_init(int device)
 {
 	pthread_mutex_lock(&g_init_lock);
@@ -47,6 +86,7 @@ int rxgpu_init(int device)
 static int init_locked(int device)
 {
 	int n = 0;
+	rxgpu_knobs_reload();
 	if (device < 0) {
 		const char *e = getenv("RXGPU_DEVICE");
 		if (!e || !*e)
@@ -68,6 +108,13 @@ static int init_locked(int device)
 	if (device >= n)
 		return rxgpu_fail(RXGPU_ENODEV, "device %d requested but only %d visible", device, n);
 	RX_HIP(hipSetDevice(device));
+	{
+		/* the kernels' wave-private LDS exchanges and DPP scans assume 64 lanes per wave */
+		int ws = 0;
+		RX_HIP(hipDeviceGetAttribute(&ws, hipDeviceAttributeWarpSize, device));
+		if (ws != 64)
+			return rxgpu_fail(RXGPU_ENODEV, "device %d has %d-wide wavefronts; librxgpu is written for gfx950 (64)", device, ws);
+	}
 	t_bound_device = device;
 	RX_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
 	RX_HIP(hipStreamCreateWithFlags(&g_stream3, hipStreamNonBlocking));

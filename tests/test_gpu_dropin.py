@@ -82,8 +82,9 @@ def test_full_demod_and_callback_dropin(kw):
 @pytest.mark.parametrize("rng,flags,window", [("24M:60M:1k", (1, 0, 0), "hamming"), ("100M:105M:1M", (1, 0, 1), "rectangle"),
                                               ("100M:100.1M:100", (0, 9, 0), "blackman")])
 def test_scan_and_csv_dropin(rng, flags, window, tmp_path):
-    """rxgpu_scan on an array of struct tuning_state (+ rxgpu_csv_dbm) == the oracle's scanner()/csv_dbm, two passes"""
+    """rxgpu_scan on an array of struct tuning_state (+ rxgpu_csv_dbm) == the oracle's scanner()/csv_dbm, two passes; deferred mode"""
     L, O = R.lib(), oracle()
+    R.check(L.rxgpu_scan_deferred(1))
     plan = R.plan_range(rng, 0.0, flags[0])
     tunes, n = min(plan.tune_count, 5), 1 << plan.bin_e
     wc, sw = R.window_coefs(window, n), R.sine_table(plan.bin_e)
@@ -138,6 +139,75 @@ def test_scan_and_csv_dropin(rng, flags, window, tmp_path):
     assert open(str(tmp_path / "o.csv")).read() == "".join(rows)
 
 
+def _tuning_array(plan, tunes, n):
+    bufs = [np.zeros(plan.buf_len, np.int16) for _ in range(tunes)]
+    avgs = [np.zeros(n, np.int64) for _ in range(tunes)]
+    arr = (TuningState * tunes)()
+    for t in range(tunes):
+        arr[t] = TuningState(plan.first_freq + t * plan.bw_seen, plan.rate, plan.bin_e, ptr64(avgs[t]), 0, plan.downsample,
+                             plan.downsample_passes, plan.crop, ptr16(bufs[t]), plan.buf_len)
+    return arr, bufs, avgs
+
+
+def test_scan_default_is_current_after_every_call_and_never_writes_a_stale_array(capfd):
+    """Default mode: ts->avg[] / ts->samples are the CPU's after EVERY rxgpu_scan and no pointer is kept.  Deferred mode: a pending
+    interval is never written through an array the running call was not handed -- another array fails the scan until the first is
+    synced, and a release with sums pending drops them (stderr) instead of touching the old array."""
+    L, O = R.lib(), oracle()
+    plan = R.plan_range("24M:60M:1k", 0.0, 1)
+    tunes, n = 4, 1 << plan.bin_e
+    wc, sw = R.window_coefs("hamming", n), R.sine_table(plan.bin_e)
+    cfg = PowerCfg(plan.bin_e, plan.buf_len, plan.downsample, plan.downsample_passes, 1, 0, 0, ptr32(wc), ptr16(sw))
+    work = np.zeros(plan.buf_len, np.int16)
+
+    def feed(arr_bufs, want_avg, want_samples, seed):
+        data = sig_noise(tunes * plan.buf_len, seed=seed, amp=2500).reshape(tunes, plan.buf_len)
+        for t in range(tunes):
+            arr_bufs[t][:] = data[t]
+            smp = C.c_int(int(want_samples[t]))
+            O.rxo_power_tune(C.byref(cfg), ptr16(np.ascontiguousarray(data[t])), ptr16(work), ptr64(want_avg[t]), C.byref(smp))
+            want_samples[t] = smp.value
+
+    R.check(L.rxgpu_scan_deferred(0))
+    arr, bufs, avgs = _tuning_array(plan, tunes, n)
+    want_avg, want_samples = np.zeros((tunes, n), np.int64), np.zeros(tunes, np.int32)
+    for p in range(3):
+        feed(bufs, want_avg, want_samples, 70 + p)
+        R.check(L.rxgpu_scan(arr, tunes, wc.ctypes.data, sw.ctypes.data, 1, 0, 0))
+        for t in range(tunes):                                 # current after each call, nothing to sync
+            assert np.array_equal(avgs[t], want_avg[t]) and arr[t].samples == want_samples[t]
+    R.check(L.rxgpu_scan_sync(arr, tunes))                     # a no-op in this mode
+    # another array right away: fine, nothing was pending
+    arr2, bufs2, avgs2 = _tuning_array(plan, tunes, n)
+    want2, ws2 = np.zeros((tunes, n), np.int64), np.zeros(tunes, np.int32)
+    feed(bufs2, want2, ws2, 90)
+    R.check(L.rxgpu_scan(arr2, tunes, wc.ctypes.data, sw.ctypes.data, 1, 0, 0))
+    assert all(np.array_equal(avgs2[t], want2[t]) for t in range(tunes))
+
+    # deferred: the interval of `arr` is pending; arr2 must be refused and `arr` left alone until its own sync
+    R.check(L.rxgpu_scan_deferred(1))
+    feed(bufs, want_avg, want_samples, 95)
+    before = [a.copy() for a in avgs]
+    R.check(L.rxgpu_scan(arr, tunes, wc.ctypes.data, sw.ctypes.data, 1, 0, 0))
+    assert L.rxgpu_scan(arr2, tunes, wc.ctypes.data, sw.ctypes.data, 1, 0, 0) == -2
+    assert b"rxgpu_scan_sync" in L.rxgpu_last_error()
+    assert L.rxgpu_scan_sync(arr2, tunes) == -2 and L.rxgpu_scan_sync(None, 0) == -2
+    assert L.rxgpu_scan_deferred(0) == -2
+    assert all(np.array_equal(avgs[t], before[t]) for t in range(tunes))       # nothing written behind the caller's back
+    R.check(L.rxgpu_scan_sync(arr, tunes))
+    assert all(np.array_equal(avgs[t], want_avg[t]) and arr[t].samples == want_samples[t] for t in range(tunes))
+    # pending at release: dropped with a note, the array is not touched
+    feed(bufs, want_avg, want_samples, 96)
+    before = [a.copy() for a in avgs]
+    R.check(L.rxgpu_scan(arr, tunes, wc.ctypes.data, sw.ctypes.data, 1, 0, 0))
+    capfd.readouterr()
+    L.rxgpu_shutdown()                                         # releases the drop-in caches
+    R.check(L.rxgpu_init(0))
+    assert "never merged" in capfd.readouterr().err
+    assert all(np.array_equal(avgs[t], before[t]) for t in range(tunes))
+    R.check(L.rxgpu_scan_deferred(0))
+
+
 def test_dropin_handoff_stays_on_the_device_unless_invalidated():
     """rxgpu_callback leaves the pre-staged block in HBM and rxgpu_full_demod uses that copy; a caller that edits
     d->lowpassed in between says so with rxgpu_dropin_invalidate and gets the edited block demodulated"""
@@ -174,6 +244,26 @@ def test_dropin_handoff_stays_on_the_device_unless_invalidated():
             assert d.lp_len == lp_len.value and np.array_equal(np.ctypeslib.as_array(d.lowpassed)[:d.lp_len], lp[:lp_len.value])
         if edit:
             R.check(L.rxgpu_dropin_unpin(C.addressof(d), C.addressof(s)))
+
+
+def test_rdc_on_an_empty_read_exits_like_the_header_says():
+    """-E rdc on an EMPTY read: the reference divides by len/2 == 0 (rtl_fm.c:710-711); rxgpu_callback says so on stderr and exit(1)s
+    (the reference's failure convention) instead of publishing an empty block"""
+    import os
+    import subprocess
+    import sys
+    code = ("import ctypes as C, sys\n"
+            "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np, rx_tools_amd as R\n"
+            "from test_gpu_dropin import fresh_demod\n"
+            "from rx_tools_amd.structs import DongleState\n"
+            "L = R.lib(); R.check(L.rxgpu_init(0))\n"
+            "d = fresh_demod(dc_block_raw=1); s = DongleState(); s.demod_target = C.pointer(d)\n"
+            "buf = np.zeros(16, np.int16)\n"
+            "L.rxgpu_callback(buf.ctypes.data, 0, C.addressof(s))\n"
+            "print('survived')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 1 and b"survived" not in out.stdout and b"rdc" in out.stderr, (out.returncode, out.stderr[-600:])
 
 
 def _same_state(d, r, L, check_result0):

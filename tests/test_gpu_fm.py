@@ -162,7 +162,8 @@ def test_first_group_depths(env, passes, monkeypatch):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     n = 131072
-    for iq, off in ((sig_fm(3 * n, seed=61), 0), (sig_noise(6 * n, seed=62), 1), (np.full(6 * n, -32768, np.int16), 0)):
+    # +32767 everywhere without the rotation: every tap is +128 after the scale and the level-4 tap sum reaches 2^15 (32-bit sums there)
+    for iq, off in ((sig_fm(3 * n, seed=61), 0), (sig_noise(6 * n, seed=62), 1), (np.full(6 * n, -32768, np.int16), 0), (np.full(6 * n, 32767, np.int16), 1)):
         carry, st = _check(iq, 2 * n, downsample_passes=passes, comp_fir_size=9, offset_tuning=off)
         want, got = carry_tuple(carry_from_oracle_state(st)), carry_tuple(carry)
         assert got[8][:12 * passes] == want[8][:12 * passes] and got[9][:12 * passes] == want[9][:12 * passes]

@@ -15,7 +15,6 @@ d_iq = device_capture(torch, torch.device("cuda"), blocks * 131072, seed=5)
 d_out = torch.zeros(blocks * 131072 // (ds if ds > 0 else 8) + 64, dtype=torch.int16, device="cuda")
 kw = dict(downsample=ds) if ds > 0 else (dict(downsample_passes=-ds) if ds > -10 else dict(downsample_passes=(-ds) // 10, comp_fir_size=9))
 if ds == 5: kw.update(rate_out=240000, deemph_a=19)
-s = R.FmStream(R.FmParams.wbfm(**kw), blocks, bl)
 def dump(names):
     out = {}
     for n in names:
@@ -27,6 +26,7 @@ for rep in range(3):
     for st in settings:
         for v in allvars: os.environ.pop(v, None)
         os.environ.update(st)
+        s = R.FmStream(R.FmParams.wbfm(**kw), blocks, bl)          # a stream keeps the knobs it was created with (rxgpu_knob snapshot)
         for _ in range(3): s.run(d_iq.data_ptr(), blocks, bl, d_out.data_ptr(), d_out.numel())
         L.rxgpu_prof_reset(); L.rxgpu_prof_enable(2)
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -38,5 +38,6 @@ for rep in range(3):
             s.wait()
         dt = (time.perf_counter() - t0) / k
         L.rxgpu_prof_enable(0)
+        s.close()
         print((",".join("%s=%s" % kv for kv in st.items()) or "default").ljust(34), "us/step", round(dt * 1e6, 1),
               dump(["fm_decimate", "fm_fifth", "fm_fifth2", "fm_droop", "fm_disc", "fm_deemph", "fm_resample"]), "TS/s", round(blocks * 131072 / dt / 1e12, 3), flush=True)

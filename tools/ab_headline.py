@@ -23,6 +23,7 @@ for rep in range(4):
     for on in (1, 0):
         if on: os.environ[switch] = sys.argv[4] if len(sys.argv) > 4 else "1"
         else: os.environ.pop(switch, None)
+        L.rxgpu_knobs_reload()       # kernel-variant knobs are read from a snapshot; plan knobs (RXGPU_FUSE_A, ...) need a new stream: tools/ab_env.py
         for _ in range(3): s.run(d_iq.data_ptr(), blocks, bl, d_out.data_ptr(), d_out.numel())
         L.rxgpu_prof_reset(); L.rxgpu_prof_enable(2)
         torch.cuda.synchronize(); t0 = time.perf_counter()
