@@ -268,6 +268,67 @@ def parity_module():
     return parity_at_size
 
 
+VARIANT_SHORT = {"-M wbfm default, downsample=6": "rx_fm ds=6 (-M wbfm default)",
+                 "BASELINE configs[0] geometry: -s 240000, downsample=5, deemph_a=19": "rx_fm ds=5 (configs[0], 240 kHz)",
+                 "-F cascade, downsample_passes=7 (ds=128)": "rx_fm -F ds=128",
+                 "-F 9 cascade as -M wbfm -F 9 sets it: downsample_passes=3 (ds=8) + droop FIR": "rx_fm -M wbfm -F 9"}
+
+
+def hoist(result, parity_all, world):
+    """The driver's record keeps the top-level scalars, `config`, `roofline` and `cpu_baseline` of the line and only the NAMES of
+    everything else.  So what the other legs measured is repeated, compact, inside those two objects: `config` answers "did RCCL
+    see N ranks, what was the sharded rx_power rate, was the gathered result bit-exact" from a SCALE record alone, `roofline.legs`
+    carries every leg's fraction of its binding roofline, its HBM traffic over its algorithmic bytes and its parity verdict."""
+    cfg, roof = result.get("config"), result.get("roofline")
+    pw = result.get("rx_power") if isinstance(result.get("rx_power"), dict) else (result if "Mbins" in str(result.get("unit")) else None)
+    if isinstance(cfg, dict) and pw is not None and pw is not result:
+        c = pw["config"]
+        cfg.update({
+            "rx_power_Mbins_per_s": pw["value"], "rx_power_ms_per_step": pw["ms_per_step"], "rx_power_scaling": "strong (one sweep sharded by tune)",
+            "rx_power_passes_per_step": c["passes_per_step"],
+            "rccl_ranks": c["rccl_ranks"], "rccl_ranks_source": c["rccl_ranks_source"], "rccl_gathers_enqueued": c["rccl_gathers_enqueued"],
+            "gather": c["gather"], "gather_bytes_per_rank": c["gather_bytes_per_rank"],
+            "scan_us_rank0": c["scan_us_per_step_rank0"], "gather_us_rank0": c["gather_us_per_step_rank0"],
+            "tunes_per_rank": c["tunes_per_rank_padded"], "tunes_rank0": c["tunes_this_rank"],
+            "rx_power_parity_ok": pw.get("parity_ok"),
+            "rx_power_parity": ({k: pw["parity_sharded"].get(k) for k in ("parity_checker", "parity_tunes_compared", "parity_passes", "parity_ranks",
+                                                                          "parity_padding_rows_zero", "parity_inputs_regenerated_match_owner_checksums")}
+                                if "parity_sharded" in pw else {k: pw.get("parity", {}).get(k) for k in ("parity_checker", "parity_tunes_compared", "parity_passes")}),
+            "rx_power_cpu_baseline_Mbins_per_s_1core": (pw.get("cpu_baseline") or {}).get("value"),
+            "rx_power_cpu_baseline_kind": (pw.get("cpu_baseline") or {}).get("kind"),
+            "parity_all_legs": dict(parity_all), "n_ranks": world})
+    if not isinstance(roof, dict):
+        return
+    legs = {}
+    for label, v in (result.get("rx_fm_variants") or {}).items():
+        t = v.get("traffic") or {}
+        legs[VARIANT_SHORT.get(label, label)] = {"bound": "hbm", "frac": v["frac_of_hbm_peak"], "MSample_per_s": v["value"], "steps": v["steps"],
+                                                 "traffic_over_algorithmic": t.get("traffic_over_algorithmic"),
+                                                 "parity_ok": (v.get("parity") or {}).get("parity_ok")}
+    if pw is not None and pw is not result:
+        r = pw["roofline"]
+        legs["rx_power N=4096 (configs[2])"] = {"bound": r["bound"], "frac": r["frac"], "hbm_frac": r["hbm_frac"], "Mbins_per_s": pw["value"],
+                                                "avg_launch_ms": r["avg_launch_ms"],
+                                                "traffic_over_algorithmic": (r["traffic"] / r["algorithmic_bytes_per_launch"]) if r.get("traffic") else None,
+                                                "parity_ok": pw.get("parity_ok")}
+        for label, v in (pw.get("other_geometries") or {}).items():
+            legs["rx_power " + label.split(",")[0][:60]] = {"bound": v.get("bound", "hbm"), "frac": v.get("frac", v["frac_of_hbm_peak"]), "hbm_frac": v["frac_of_hbm_peak"],
+                                                            "Mbins_per_s": v["Mbins/s"], "N": v["N"], "parity_ok": (v.get("parity") or {}).get("parity_ok")}
+    ch = result.get("channeliser")
+    if ch:
+        r = ch["roofline"]
+        legs["channeliser 256 ch"] = {"bound": "valu", "frac": r["valu"]["frac"], "hbm_frac": r["frac"], "MSample_per_s": ch["value"],
+                                      "traffic_over_algorithmic": (r["traffic"] / r["algorithmic_bytes_per_launch"]) if r.get("traffic") else None,
+                                      "parity_ok": (ch.get("parity") or {}).get("parity_ok"), "parity_checker": (ch.get("parity") or {}).get("parity_checker")}
+    for label, v in ((result.get("sdr_convert") or {}).get("legs") or {}).items():
+        legs["rx_sdr " + label] = {"bound": "hbm", "frac": v["frac_of_hbm_peak"], "GBs": v["GB/s"], "parity_ok": (result["sdr_convert"]).get("parity_ok")}
+    hf = (result.get("host_fed") or {}).get("legs") or {}
+    for label, v in hf.items():
+        legs["rx_fm host-fed " + label] = {"bound": "pcie", "frac": v["frac_of_pcie"], "GS_per_s": v["GS/s"],
+                                           "parity_ok": ((result.get("host_fed") or {}).get("parity") or {}).get("parity_ok")}
+    roof["legs"] = legs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -398,7 +459,7 @@ def main():
                 for _ in range(2):
                     sv.run_async(d_iq.data_ptr(), n_blocks, block_len, d_o.data_ptr(), d_o.numel())
                 sv.wait()
-                k = max(5, args.steps // 5)
+                k = max(20, args.steps)                                # the side figures get as many timed steps as the headline
                 L.rxgpu_prof_reset()
                 L.rxgpu_prof_enable(2)
                 tv = time.perf_counter()
@@ -422,7 +483,7 @@ def main():
         # the CPU reference over the WHOLE capture: output sample by sample and every carry.  The GPU sequences run first; the
         # reference legs (one forked checker per chain, tests/parity_at_size.py) then run side by side on the host cores.
         h_iq = None
-        if world == 1 and not args.no_parity:
+        if rank == 0 and not args.no_parity:                      # N > 1: rank 0's replica is checked, the others wait at the next collective
             PA = parity_module()
             tail = max(1, n_blocks // 16)
             legs = {"headline": (hp, PA.fm_gpu_sequence(torch, R, d_iq, n_blocks, block_len, tail, hp))}
@@ -570,7 +631,7 @@ def main():
         result.update(parity)
         if parity:
             parity_all["rx_fm"] = bool(parity["parity_ok"])
-        if rank == 0 and args.cpu_seconds > 0 and world == 1:
+        if rank == 0 and args.cpu_seconds > 0:
             result["cpu_baseline"] = cpu_baseline_fm(block_len, args.cpu_seconds)
             result["cpu_baseline"]["reference_default_build_O0"] = cpu_subprocess("fm", min(3.0, args.cpu_seconds), "libref_fm_O0.so")
             result["cpu_baseline"]["all_cores"] = cpu_all_cores("fm", min(3.0, args.cpu_seconds))
@@ -697,6 +758,56 @@ def main():
             pw["parity"] = PA.power_check("24M:1.7G:1k", 0.0, "rectangle", 1, 0, 0, d_in.cpu().numpy(), da.cpu().numpy(), dsm.cpu().numpy())
             pw_parity_ok = pw["parity"]["parity_ok"]
             del da, dsm
+        # N > 1: the SHARDED interval once more into zeroed integrators -- every rank scans its tune range, the one grouped gather lands in
+        # rank 0's [world][per][N] block -- and rank 0 compares every gathered row with the reference's own scanner() (rtl_power.c:670-772)
+        # run on the input of the rank that owns the tune (regenerated here from that rank's seed; a checksum from the owner proves the
+        # regeneration), and checks that the padding rows of a short last rank arrived as zeros.  This is the "bit-exact CSV" of
+        # BASELINE configs[3]: csv_dbm prints avg[]/samples and nothing else (rtl_power.c:1047-1050).
+        if world > 1 and not args.no_parity:
+            for b in range(2):
+                d_avgs[b].zero_()
+                d_smps[b].zero_()
+            if rank == 0:
+                d_avg_all.fill_(-1)                               # a padding row the gather does not deliver as zeros would show
+                d_smp_all.fill_(-1)
+            torch.cuda.synchronize()
+            state["k"] = 0
+            step()
+            L.rxgpu_sync()
+            barrier()
+            mysum = int(d_in.view(torch.int32).sum(dtype=torch.int64).item())
+            sums = [None] * world
+            dist.gather_object(mysum, sums if rank == 0 else None, dst=0)
+            if rank == 0:
+                PA = parity_module()
+                got_all, smp_all = d_avg_all.cpu().numpy(), d_smp_all.cpu().numpy()
+                h_in = np.empty((passes, total_tunes, plan.buf_len), np.int16)
+                got_avg = np.empty((total_tunes, n), np.int64)
+                got_smp = np.empty(total_tunes, np.int64)
+                regen_ok, pad_ok = True, True
+                for r in range(world):
+                    lo_r, mine_r, _ = shard.tune_range(r, world, total_tunes)
+                    g_r = torch.Generator(device=dev)
+                    g_r.manual_seed(777 + r)
+                    d_r = torch.randint(-100, 101, (passes, max(mine_r, 1), plan.buf_len), dtype=torch.int16, device=dev, generator=g_r)
+                    regen_ok = regen_ok and int(d_r.view(torch.int32).sum(dtype=torch.int64).item()) == sums[r]
+                    h_in[:, lo_r:lo_r + mine_r] = d_r[:, :mine_r].cpu().numpy()
+                    got_avg[lo_r:lo_r + mine_r] = got_all[r, :mine_r]
+                    got_smp[lo_r:lo_r + mine_r] = smp_all[r, :mine_r]
+                    pad_ok = pad_ok and not got_all[r, mine_r:].any() and not smp_all[r, mine_r:].any()
+                    del d_r
+                v = PA.power_check("24M:1.7G:1k", 0.0, "rectangle", 1, 0, 0, h_in, got_avg, got_smp)
+                v["parity_what"] = ("rank 0's gathered [world][per][N] avg block and samples after one sharded interval of %d passes: every tune of every rank "
+                                    "against the reference's scanner() on that rank's input" % passes)
+                v["parity_inputs_regenerated_match_owner_checksums"] = bool(regen_ok)
+                v["parity_padding_rows_zero"] = bool(pad_ok)
+                v["parity_ranks"] = world
+                v["parity_ok"] = bool(v["parity_ok"] and regen_ok and pad_ok)
+                pw["parity_sharded"] = v
+                pw_parity_ok = v["parity_ok"]
+                pw["parity_ok"] = bool(pw_parity_ok)
+                parity_all["rx_power_sharded"] = bool(pw_parity_ok)
+                del h_in, got_all, got_avg
         # the drop-in (rxgpu_scan on the reference's own struct tuning_state array, rtl_power.c:1040): per-sweep cost with the sums left
         # on the device, and the one download per report interval (rxgpu_scan_sync)
         if world == 1 and args.variants == "all":
@@ -708,6 +819,7 @@ def main():
             for t in range(total_tunes):
                 arr[t] = TuningState(plan.first_freq + t * plan.bw_seen, plan.rate, plan.bin_e, C.cast(h_avgs[t].ctypes.data, C.POINTER(C.c_int64)), 0,
                                      plan.downsample, plan.downsample_passes, plan.crop, C.cast(h_bufs[t].ctypes.data, C.POINTER(C.c_int16)), plan.buf_len)
+            R.check(L.rxgpu_scan_deferred(1))                         # what the INTEGRATION.md patch switches on: one merge per report interval
             for _ in range(3):
                 R.check(L.rxgpu_scan(arr, total_tunes, wc.ctypes.data, sw.ctypes.data, 1, 0, 0))
             R.check(L.rxgpu_scan_sync(arr, total_tunes))
@@ -722,6 +834,7 @@ def main():
             t0 = time.perf_counter()
             R.check(L.rxgpu_scan_sync(arr, total_tunes))
             t_sync = time.perf_counter() - t0
+            R.check(L.rxgpu_scan_deferred(0))
             pw["dropin_scan_us"] = {"rxgpu_scan_per_sweep": t_scan * 1e6, "rxgpu_scan_sync_per_interval": t_sync * 1e6, "sweeps": sweeps,
                                     "Mbins/s": total_tunes * (plan.buf_len // 2) / t_scan / 1e6,
                                     "note": "599 tunes x 16384 int16 from the caller's separate buffers: gather into pinned staging, one H2D (9.8 MB), the scan; "
@@ -779,7 +892,7 @@ def main():
         if world == 1 and not args.no_parity:
             pw["parity_ok"] = bool(pw_parity_ok)
             parity_all["rx_power"] = bool(pw_parity_ok)
-        if rank == 0 and args.cpu_seconds > 0 and world == 1:
+        if rank == 0 and args.cpu_seconds > 0:
             pw["cpu_baseline"] = cpu_baseline_power(plan, args.cpu_seconds / 2)
             pw["cpu_baseline"]["reference_default_build_O0"] = cpu_subprocess("power", min(3.0, args.cpu_seconds / 2), "libref_power_O0.so")
             pw["cpu_baseline"]["all_cores"] = cpu_all_cores("power", min(3.0, args.cpu_seconds / 2))
@@ -816,7 +929,7 @@ def main():
         ms, launches = prof("ch_fft")
         chan_fix = ch.host_fixups
         chan_parity = None
-        if world == 1 and not args.no_parity:
+        if rank == 0 and not args.no_parity:
             # one more run of the timed shape from zero carries: every window of every channel against the oracle's channeliser
             PA = parity_module()
             ch.set_carry(np.zeros(2 * n_ch, np.int32))
@@ -903,6 +1016,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        hoist(result, parity_all, world)
         if parity_all:
             result["parity_all_legs"] = parity_all
             result["parity_ok"] = all(parity_all.values())

@@ -143,3 +143,63 @@ int ref_fm_wav_header(int rate, int raw_mode, unsigned char *out, size_t cap)
 	free(mem);
 	return (int)len;
 }
+
+/* ---- channeliser checker (the channeliser is an extension specified from reference primitives: the decimated stream of a
+ * channel is handed to the reference's OWN full_demod, one callback block at a time, on the reference's own global demod_state).
+ * The de-emphasis state is one function-static int for the whole process (rtl_fm.c:669), so it is forced to the channel's carried
+ * value in front of every call (ref_fm_deemph_force) and read back afterwards with the reference's own deemph_filter on a single
+ * zero sample with a = 2^20: |0 - avg| + a/2 < a, the update term truncates to 0 and result[0] is avg, unchanged. */
+static int ref_fm_deemph_peek(void)
+{
+	static struct demod_state tmp;
+	tmp.deemph_a = 1 << 20;
+	tmp.result_len = 1;
+	tmp.result[0] = 0;
+	deemph_filter(&tmp);
+	return tmp.result[0];
+}
+
+/* lp: [n_ch][2 * wpb] int16, channel c's decimated IQ of this block (what low_pass at downsample = 1 passes through unchanged,
+ * rtl_fm.c:351-371).  pre: 2 ints per channel (pre_r, pre_j); audio: 3 per channel (deemph avg, now_lpr, prev_lpr_index).
+ * out: [n_ch][out_stride]; returns result_len of the last channel (the same for all: equal lengths and phases), or -1. */
+int ref_fm_chan_block(const int16_t *lp, int n_ch, int wpb, int custom_atan, int deemph, int deemph_a, int rate_out, int rate_out2,
+                      int *pre, int *audio, int16_t *out, size_t out_stride)
+{
+	int n_out = -1;
+	demod_init(&demod);
+	demod.downsample = 1;
+	demod.downsample_passes = 0;
+	demod.post_downsample = 1;
+	demod.squelch_level = 0;
+	demod.mode_demod = &fm_demod;
+	demod.custom_atan = custom_atan;
+	demod.deemph = deemph;
+	demod.deemph_a = deemph_a;
+	demod.rate_in = demod.rate_out = rate_out;
+	demod.rate_out2 = rate_out2;
+	demod.dc_block_audio = 0;
+	for (int c = 0; c < n_ch; c++) {
+		memcpy(demod.lowpassed, lp + (size_t)c * 2 * wpb, (size_t)2 * wpb * sizeof(int16_t));
+		demod.lp_len = 2 * wpb;
+		demod.now_r = demod.now_j = 0;
+		demod.prev_index = 0;
+		demod.pre_r = pre[2 * c];
+		demod.pre_j = pre[2 * c + 1];
+		demod.now_lpr = audio[3 * c + 1];
+		demod.prev_lpr_index = audio[3 * c + 2];
+		if (deemph && ref_fm_deemph_force(audio[3 * c]) != audio[3 * c])
+			return -2;
+		full_demod(&demod);
+		pre[2 * c] = demod.pre_r;
+		pre[2 * c + 1] = demod.pre_j;
+		if (deemph)
+			audio[3 * c] = ref_fm_deemph_peek();
+		audio[3 * c + 1] = demod.now_lpr;
+		audio[3 * c + 2] = demod.prev_lpr_index;
+		if ((size_t)demod.result_len > out_stride)
+			return -3;
+		memcpy(out + (size_t)c * out_stride, demod.result, (size_t)demod.result_len * sizeof(int16_t));
+		n_out = demod.result_len;
+	}
+	return n_out;
+}

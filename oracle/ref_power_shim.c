@@ -99,3 +99,31 @@ int ref_power_csv(const char *path)
 	fclose(file);
 	return 0;
 }
+
+/* ---- channeliser checker: every window of 2^bin_e complex samples through the reference's OWN fix_fft (rtl_power.c:264-320,
+ * with the table its own sine_table built), bins first_bin .. first_bin + n_ch - 1 (mod N) of window w written as channel c's
+ * w-th decimated IQ sample: lp[c][2 * w], lp[c][2 * w + 1].  Returns fix_fft's worst return value. */
+int ref_power_chan_windows(const int16_t *in, int windows, int bin_e, int first_bin, int n_ch, int16_t *lp)
+{
+	static int table_for = -1;
+	const int n = 1 << bin_e;
+	int rc = 0;
+	if (table_for != bin_e) {
+		sine_table(bin_e);
+		table_for = bin_e;
+	}
+	int16_t *win = malloc((size_t)2 * n * sizeof(int16_t));
+	for (int w = 0; w < windows; w++) {
+		memcpy(win, in + (size_t)w * 2 * n, (size_t)2 * n * sizeof(int16_t));
+		int r = fix_fft(win, bin_e);
+		if (r < rc)
+			rc = r;
+		for (int c = 0; c < n_ch; c++) {
+			const int bin = (first_bin + c) & (n - 1);
+			lp[((size_t)c * windows + w) * 2] = win[2 * bin];
+			lp[((size_t)c * windows + w) * 2 + 1] = win[2 * bin + 1];
+		}
+	}
+	free(win);
+	return rc;
+}

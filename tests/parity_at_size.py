@@ -331,40 +331,42 @@ def power_check(range_arg, crop, window, boxcar, comp_fir, peak_hold, h_in, got_
 # ------------------------------------------------------------------------------------------------ channeliser
 
 def chan_check(h_iq, n_blocks, block_len, bin_e, first_bin, n_ch, custom_atan, sinewave, got, got_pre):
-    """Every window of every channel: rxo_chan_block (fix_fft per window + fm_demod per channel, both pinned against the
-    reference) over the whole capture, block ranges dealt to children; a child warms its per-channel pre_r/pre_j up on the
-    block in front of its range (a block's carry-out depends on its last window only).  got: [n_ch][windows] int16 from a
-    run that started with zero carries; got_pre: the carries it left."""
-    O = support.oracle()
+    """Every window of every channel over the whole capture.  Where oracle/_ref exists (this container, and the GPU box: the
+    prebuilt objects travel) the checker is REFERENCE-BUILT code only -- the reference's own fix_fft per window (libref_power.so)
+    and the reference's own full_demod per channel and callback block (libref_fm.so), support.ref_chan_stream -- else the oracle's
+    restatement rxo_chan_block, which tests/test_chan_oracle.py pins against exactly that chain.  Block ranges are dealt to
+    forked children; a child warms its per-channel pre_r/pre_j up on the block in front of its range (a block's carry-out
+    depends on its last window only).  got: [n_ch][windows] int16 from a run that started with zero carries; got_pre: the
+    carries it left."""
     n = 1 << bin_e
     wpb = block_len // 2 // n
-    sw = np.ascontiguousarray(sinewave, np.int16)
-
-    class Cfg(C.Structure):
-        _fields_ = [("bin_e", C.c_int), ("first_bin", C.c_int), ("n_channels", C.c_int), ("custom_atan", C.c_int), ("sinewave", support.i16p)]
-    cfg = Cfg(bin_e, first_bin, n_ch, custom_atan, support.ptr16(sw))
-    O.rxo_chan_block.argtypes = [C.c_void_p, support.i16p, C.c_int, support.intp, support.i16p, C.c_size_t]
-    O.rxo_chan_block.restype = None
     jobs = split_range(n_blocks, n_workers())
+    use_ref = support.have_ref()
+    if use_ref:
+        support.ref_power()
+        support.ref_fm()
+        kind = "reference (oracle/_ref: the reference's own fix_fft per window + its own full_demod per channel and callback block)"
+        stream = support.ref_chan_stream
+    else:
+        support.oracle()
+        kind = "port (rxo_chan_block: fix_fft + fm_demod restatements; pinned against the reference-built chain in tests/test_chan_oracle.py)"
+        stream = support.oracle_chan_stream_compare
 
     def one(job):
         lo, hi = job
-        pre = np.zeros(2 * n_ch, np.int32)
-        out = np.zeros((n_ch, wpb), np.int16)
+        pre = None
         if lo:
-            O.rxo_chan_block(C.byref(cfg), support.ptr16(h_iq[(lo - 1) * block_len:lo * block_len]), block_len, support.ptr32(pre), support.ptr16(out), wpb)
-        first_bad = -1
-        for b in range(lo, hi):
-            O.rxo_chan_block(C.byref(cfg), support.ptr16(h_iq[b * block_len:(b + 1) * block_len]), block_len, support.ptr32(pre), support.ptr16(out), wpb)
-            if first_bad < 0 and not np.array_equal(out, got[:, b * wpb:(b + 1) * wpb]):
-                first_bad = b
-        return first_bad, (pre if hi == n_blocks else None)
+            _, pre, _ = stream(h_iq[(lo - 1) * block_len:lo * block_len], block_len, bin_e, first_bin, n_ch, custom_atan,
+                               compare=got[:, (lo - 1) * wpb:lo * wpb])
+        bad, pre, _ = stream(h_iq[lo * block_len:hi * block_len], block_len, bin_e, first_bin, n_ch, custom_atan, pre=pre,
+                             compare=got[:, lo * wpb:hi * wpb])
+        return (lo + bad if bad >= 0 else -1), (pre if hi == n_blocks else None)
     t0 = time.perf_counter()
     parts = fork_map(one, jobs)
     bad = [p[0] for p in parts if p[0] >= 0]
     pre_end = parts[-1][1]
     ok = not bad and np.array_equal(pre_end, np.asarray(got_pre, np.int32))
-    res = {"parity_ok": bool(ok), "parity_checker": "port (rxo_chan_block: fix_fft + fm_demod restatements, each pinned against the reference)",
+    res = {"parity_ok": bool(ok), "parity_checker": kind,
            "parity_windows_compared": int(n_blocks * wpb), "parity_channels": int(n_ch), "parity_checked_samples": int(n_blocks * (block_len // 2)),
            "parity_how": "%d forked checkers" % len(jobs), "parity_seconds": time.perf_counter() - t0}
     if bad:

@@ -295,3 +295,99 @@ def oracle_fm_stream(iq, block_len, **params):
 
 # ------------------------------------------------------------------ signal generators
 from rx_tools_amd.synth import lcg_stream, sig_fm, sig_noise, sig_alternating  # noqa: E402,F401
+
+
+# --------------------------------------------------------------- channeliser: the oracle's restatement and the reference-built checker
+
+class ChanCfg(C.Structure):
+    _fields_ = [("bin_e", C.c_int), ("first_bin", C.c_int), ("n_channels", C.c_int), ("custom_atan", C.c_int), ("sinewave", i16p)]
+
+
+def oracle_chan_stream(iq, block_len, bin_e, first_bin, n_channels, custom_atan, deemph=0, a=0, rate_out=0, rate_out2=-1, pre=None, audio=None):
+    """rxo_chan_block callback block after callback block, then -- every channel a demod_state of its own -- rxo_deemph and
+    rxo_low_pass_real on the channel's samples with its carried avg / now_lpr / prev_lpr_index (oracle/rx_oracle.c).
+    Returns (out [n_channels][samples], pre [2 n_channels], audio [n_channels][3])."""
+    import rx_tools_amd as R
+    O = oracle()
+    O.rxo_chan_block.argtypes = [C.POINTER(ChanCfg), i16p, C.c_int, intp, i16p, C.c_size_t]
+    O.rxo_chan_block.restype = None
+    O.rxo_deemph.argtypes = [i16p, C.c_int, C.c_int, intp]
+    O.rxo_low_pass_real.argtypes = [i16p, C.c_int, C.c_int, C.c_int, intp, intp]
+    sw = R.sine_table(bin_e)
+    cfg = ChanCfg(bin_e, first_bin, n_channels, custom_atan, ptr16(sw))
+    n = 1 << bin_e
+    n_blocks = len(iq) // block_len
+    wpb = block_len // 2 // n
+    pre = np.zeros(2 * n_channels, np.int32) if pre is None else np.array(pre, np.int32)
+    state = np.zeros((n_channels, 3), np.int32) if audio is None else np.array(audio, np.int32).reshape(n_channels, 3)
+    outs = [[] for _ in range(n_channels)]
+    tmp = np.zeros((n_channels, wpb), np.int16)
+    for b in range(n_blocks):
+        blk = np.ascontiguousarray(iq[b * block_len:(b + 1) * block_len])
+        O.rxo_chan_block(C.byref(cfg), ptr16(blk), block_len, pre.ctypes.data_as(intp), ptr16(tmp), wpb)
+        for c in range(n_channels):
+            row = np.ascontiguousarray(tmp[c])
+            k = wpb
+            avg, now, idx = (C.c_int(int(v)) for v in state[c])
+            if deemph:
+                O.rxo_deemph(ptr16(row), k, a, C.byref(avg))
+            if rate_out2 > 0:
+                k = O.rxo_low_pass_real(ptr16(row), k, rate_out, rate_out2, C.byref(now), C.byref(idx))
+            state[c] = (avg.value, now.value, idx.value)
+            outs[c].append(row[:k].copy())
+    return np.stack([np.concatenate(o) for o in outs]), pre, state
+
+
+def ref_chan_stream(iq, block_len, bin_e, first_bin, n_channels, custom_atan, deemph=0, a=0, rate_out=0, rate_out2=-1, pre=None, audio=None,
+                    compare=None):
+    """The same stream through REFERENCE-BUILT code only (oracle/_ref): every window through the reference's own fix_fft
+    (libref_power.so, rtl_power.c:264-320, its own sine_table), every channel's decimated block through the reference's own
+    full_demod (libref_fm.so, rtl_fm.c:759-824: low_pass at downsample 1 = identity, fm_demod, deemph_filter, low_pass_real) on
+    the reference's global demod_state, with the channel's carries set in front of the call and read back after it
+    (ref_fm_chan_block in oracle/ref_fm_shim.c).  compare: optional [n_channels][samples] array checked block by block instead
+    of returning the output (bench-size runs); then the first differing block index (or -1) is returned in place of `out`."""
+    P, F = ref_power(), ref_fm()
+    P.ref_power_chan_windows.argtypes = [i16p, C.c_int, C.c_int, C.c_int, C.c_int, i16p]
+    F.ref_fm_chan_block.argtypes = [i16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, intp, intp, i16p, C.c_size_t]
+    n = 1 << bin_e
+    n_blocks = len(iq) // block_len
+    wpb = block_len // 2 // n
+    pre = np.zeros(2 * n_channels, np.int32) if pre is None else np.array(pre, np.int32)
+    state = np.zeros(3 * n_channels, np.int32) if audio is None else np.array(audio, np.int32).reshape(-1).copy()
+    lp = np.zeros((n_channels, 2 * wpb), np.int16)
+    tmp = np.zeros((n_channels, wpb), np.int16)
+    outs, pos, first_bad = [], 0, -1
+    for b in range(n_blocks):
+        blk = np.ascontiguousarray(iq[b * block_len:(b + 1) * block_len])
+        rc = P.ref_power_chan_windows(ptr16(blk), wpb, bin_e, first_bin, n_channels, ptr16(lp))
+        assert rc == 0, "fix_fft returned %d" % rc
+        k = F.ref_fm_chan_block(ptr16(lp), n_channels, wpb, custom_atan, deemph, a, rate_out, rate_out2,
+                                pre.ctypes.data_as(intp), state.ctypes.data_as(intp), ptr16(tmp), wpb)
+        assert k >= 0, "ref_fm_chan_block: %d" % k
+        if compare is None:
+            outs.append(tmp[:, :k].copy())
+        elif first_bad < 0 and not np.array_equal(tmp[:, :k], compare[:, pos:pos + k]):
+            first_bad = b
+        pos += k
+    if compare is not None:
+        return first_bad, pre, state.reshape(n_channels, 3)
+    return np.concatenate(outs, axis=1), pre, state.reshape(n_channels, 3)
+
+
+def oracle_chan_stream_compare(iq, block_len, bin_e, first_bin, n_channels, custom_atan, pre=None, compare=None):
+    """oracle_chan_stream (demodulator only) in the compare-as-you-go form of ref_chan_stream: (first differing block or -1, pre, None)"""
+    import rx_tools_amd as R
+    O = oracle()
+    O.rxo_chan_block.argtypes = [C.POINTER(ChanCfg), i16p, C.c_int, intp, i16p, C.c_size_t]
+    O.rxo_chan_block.restype = None
+    sw = R.sine_table(bin_e)
+    cfg = ChanCfg(bin_e, first_bin, n_channels, custom_atan, ptr16(sw))
+    wpb = block_len // 2 >> bin_e
+    pre = np.zeros(2 * n_channels, np.int32) if pre is None else np.array(pre, np.int32)
+    tmp = np.zeros((n_channels, wpb), np.int16)
+    first_bad = -1
+    for b in range(len(iq) // block_len):
+        O.rxo_chan_block(C.byref(cfg), ptr16(np.ascontiguousarray(iq[b * block_len:(b + 1) * block_len])), block_len, pre.ctypes.data_as(intp), ptr16(tmp), wpb)
+        if first_bad < 0 and not np.array_equal(tmp, compare[:, b * wpb:(b + 1) * wpb]):
+            first_bad = b
+    return first_bad, pre, None

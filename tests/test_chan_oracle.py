@@ -57,3 +57,56 @@ def test_block_structure_and_carry():
     whole, pre_w = run(iq.copy(), 8, 5, 50, 0)
     assert np.array_equal(np.concatenate([a, b], axis=1), whole)   # -A std: every sample is the libm one
     assert np.array_equal(pre_b, pre_w)
+
+
+# ----------------------------------------------------------------------------- pinned against the reference itself
+
+import pytest                                                      # noqa: E402
+from support import have_ref, oracle_chan_stream, ref_chan_stream, sig_fm, sig_noise    # noqa: E402
+
+skip_without_ref = pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+
+# the geometries, discriminator modes and audio configurations tests/test_gpu_chan.py holds the device to (block counts kept, the
+# largest blocks shortened where the case only needs "several windows per block": the reference legs run on one core here)
+GEOMETRIES = [(10, 384, 256, 2 * 131072, 3), (10, 900, 256, 2 * 8192, 5), (8, 0, 256, 2 * 4096, 4), (12, 100, 7, 2 * 8192, 6), (5, 3, 20, 2 * 1024, 3),
+              (9, 17, 100, 2 * 16384, 5), (11, 2000, 96, 2 * 131072, 2), (10, 0, 1024, 2 * 16384, 3)]
+AUDIO = [(10, 256, 2 * 131072, 3, 1, 2, 19531, 8000, 1), (8, 64, 2 * 65536, 4, 1, 13, 170000, 32000, 1), (8, 64, 2 * 65536, 4, 1, 13, 170000, -1, 0),
+         (9, 100, 2 * 32768, 5, 0, 0, 48000, 8000, 1), (8, 32, 2 * 65536, 3, 1, 64, 24000, 12000, 1), (8, 32, 2 * 16384, 3, 1, 200, 24000, 6000, 1),
+         (8, 16, 2 * 1024, 6, 1, 9, 24000, 8000, 1)]
+
+
+@pytest.mark.ref
+@skip_without_ref
+@pytest.mark.parametrize("bin_e,first_bin,n_channels,block_len,n_blocks", GEOMETRIES)
+@pytest.mark.parametrize("custom_atan", [1, 0])
+def test_chan_oracle_equals_reference_built_chain(bin_e, first_bin, n_channels, block_len, n_blocks, custom_atan):
+    """rxo_chan_block == [the reference's fix_fft per window] -> [the reference's full_demod per channel and callback block]: every output
+    sample and every channel's pre_r/pre_j, on the FM signal and on full-scale noise (int32 wraps of fast_atan2, int16 wraps of the butterflies)"""
+    for iq in (sig_fm(n_blocks * block_len // 2, seed=70, amp=9000), sig_noise(n_blocks * block_len, seed=71)):
+        want, want_pre, _ = ref_chan_stream(iq, block_len, bin_e, first_bin, n_channels, custom_atan)
+        got, pre, _ = oracle_chan_stream(iq, block_len, bin_e, first_bin, n_channels, custom_atan)
+        assert got.shape == want.shape
+        bad = np.argwhere(got != want)
+        assert bad.size == 0, "first mismatch at %s: port %d reference %d (%d bad)" % (bad[0], got[tuple(bad[0])], want[tuple(bad[0])], len(bad))
+        assert np.array_equal(pre, want_pre)
+
+
+@pytest.mark.ref
+@skip_without_ref
+@pytest.mark.parametrize("bin_e,n_channels,block_len,n_blocks,deemph,a,rate_out,rate_out2,custom_atan", AUDIO)
+def test_chan_audio_oracle_equals_reference_built_chain(bin_e, n_channels, block_len, n_blocks, deemph, a, rate_out, rate_out2, custom_atan):
+    """... and with the per-channel audio stages: the reference's full_demod runs deemph_filter (its one static accumulator forced to the
+    channel's carried value in front of every call and read back after it) and low_pass_real on its own demod_state; output and the
+    channel's (avg, now_lpr, prev_lpr_index) after every block, including a second run that starts from carried state"""
+    iq = sig_noise(n_blocks * block_len, seed=4 + bin_e, amp=2500)
+    half = (n_blocks + 1) // 2 * block_len
+    kw = dict(deemph=deemph, a=a, rate_out=rate_out, rate_out2=rate_out2)
+    want, want_pre, want_state = ref_chan_stream(iq, block_len, bin_e, 5, n_channels, custom_atan, **kw)
+    got, pre, state = oracle_chan_stream(iq, block_len, bin_e, 5, n_channels, custom_atan, **kw)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    assert np.array_equal(pre, want_pre) and np.array_equal(state, want_state)
+    # two runs with the carries handed over == one
+    a1, p1, s1 = ref_chan_stream(iq[:half], block_len, bin_e, 5, n_channels, custom_atan, **kw)
+    a2, p2, s2 = ref_chan_stream(iq[half:], block_len, bin_e, 5, n_channels, custom_atan, pre=p1, audio=s1, **kw)
+    assert np.array_equal(np.concatenate([a1, a2], axis=1), want) and np.array_equal(p2, want_pre) and np.array_equal(s2, want_state)
+

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import rx_tools_amd as R
-from support import oracle, sig_fm, sig_noise, ptr16, i16p, intp
+from support import oracle, sig_fm, sig_noise, ptr16, i16p, intp, have_ref, ref_chan_stream
 
 pytestmark = pytest.mark.gpu
 
@@ -77,6 +77,10 @@ def test_channeliser_bit_exact(bin_e, first_bin, n_channels, block_len, n_blocks
         bad = np.argwhere(got != want)
         assert bad.size == 0, "first mismatch at %s: got %d want %d (%d bad)" % (bad[0], got[tuple(bad[0])], want[tuple(bad[0])], len(bad))
         assert np.array_equal(pre, want_pre)
+        if have_ref():
+            # ... and directly against reference-built code: the reference's own fix_fft per window, its own full_demod per channel and block
+            ref_out, ref_pre, _ = ref_chan_stream(iq, block_len, bin_e, first_bin, n_channels, custom_atan)
+            assert np.array_equal(got, ref_out) and np.array_equal(pre, ref_pre)
 
 
 def test_channeliser_carry_across_runs():
@@ -119,36 +123,11 @@ def test_channeliser_finds_the_carrier():
 # ----------------------------------------------------------------------------- round 2: per-channel audio stages
 
 def oracle_chan_audio(iq, block_len, bin_e, first_bin, n_channels, custom_atan, deemph, a, rate_out, rate_out2):
-    """every channel a demod_state of its own: after fm_demod, deemph_filter and low_pass_real (the reference's functions as
-    restated and pinned in oracle/rx_oracle.c) on the channel's samples, callback block after callback block, with the
-    channel's own carried avg / now_lpr / prev_lpr_index"""
-    O = oracle()
-    O.rxo_chan_block.argtypes = [C.POINTER(ChanCfg), i16p, C.c_int, intp, i16p, C.c_size_t]
-    O.rxo_deemph.argtypes = [i16p, C.c_int, C.c_int, intp]
-    O.rxo_low_pass_real.argtypes = [i16p, C.c_int, C.c_int, C.c_int, intp, intp]
-    sw = R.sine_table(bin_e)
-    cfg = ChanCfg(bin_e, first_bin, n_channels, custom_atan, ptr16(sw))
-    n = 1 << bin_e
-    n_blocks = len(iq) // block_len
-    wpb = block_len // 2 // n
-    pre = np.zeros(2 * n_channels, np.int32)
-    state = np.zeros((n_channels, 3), np.int32)
-    outs = [[] for _ in range(n_channels)]
-    tmp = np.zeros((n_channels, wpb), np.int16)
-    for b in range(n_blocks):
-        blk = np.ascontiguousarray(iq[b * block_len:(b + 1) * block_len])
-        O.rxo_chan_block(C.byref(cfg), ptr16(blk), block_len, pre.ctypes.data_as(intp), ptr16(tmp), wpb)
-        for c in range(n_channels):
-            row = np.ascontiguousarray(tmp[c])
-            k = wpb
-            avg, now, idx = (C.c_int(int(v)) for v in state[c])
-            if deemph:
-                O.rxo_deemph(ptr16(row), k, a, C.byref(avg))
-            if rate_out2 > 0:
-                k = O.rxo_low_pass_real(ptr16(row), k, rate_out, rate_out2, C.byref(now), C.byref(idx))
-            state[c] = (avg.value, now.value, idx.value)
-            outs[c].append(row[:k].copy())
-    return np.stack([np.concatenate(o) for o in outs]), pre, state
+    """every channel a demod_state of its own: after fm_demod, deemph_filter and low_pass_real on the channel's samples, callback block
+    after callback block, with the channel's own carried avg / now_lpr / prev_lpr_index (support.oracle_chan_stream; pinned against the
+    reference's own fix_fft + full_demod in tests/test_chan_oracle.py)"""
+    from support import oracle_chan_stream
+    return oracle_chan_stream(iq, block_len, bin_e, first_bin, n_channels, custom_atan, deemph, a, rate_out, rate_out2)
 
 
 @pytest.mark.parametrize("bin_e,n_channels,block_len,n_blocks,deemph,a,rate_out,rate_out2,custom_atan", [
@@ -180,6 +159,9 @@ def test_channeliser_per_channel_audio_stages(bin_e, n_channels, block_len, n_bl
     got = np.concatenate(outs, axis=1)
     assert got.shape == want.shape
     assert np.array_equal(got, want)
+    if have_ref():
+        ref_out, ref_pre, ref_state = ref_chan_stream(iq, block_len, bin_e, 5, n_channels, custom_atan, deemph, a, rate_out, rate_out2)
+        assert np.array_equal(got, ref_out) and np.array_equal(ch.get_carry(), ref_pre) and np.array_equal(ch.get_audio_carry().reshape(n_channels, 3), ref_state)
     assert np.array_equal(ch.get_carry(), want_pre)
     state = ch.get_audio_carry().reshape(n_channels, 3)
     bad = np.argwhere(state != want_state)

@@ -186,15 +186,29 @@ def test_bench_multi_rank_path_on_one_gpu(world, tmp_path):
     env = dict(os.environ, RXGPU_RCCL_LIB=_fake_rccl(), FAKE_RCCL_DIR=str(tmp_path), RXGPU_BENCH_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
-           "--blocks", "256", "--passes", "8", "--cpu-seconds", "0"]
+           "--blocks", "256", "--passes", "8", "--cpu-seconds", "1.5"]
     out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=800)
     assert out.returncode == 0, out.stderr.decode()[-3000:]
     line = json.loads(out.stdout.decode().strip().splitlines()[-1])
     assert line["n_gpus"] == world and line["value"] > 0 and line["config"]["parallelism"].startswith("replicas x%d" % world)
     pw = line["rx_power"]
-    assert pw["n_gpus"] == world and pw["config"]["rccl_ranks"] == world and pw["config"]["rccl_gathers_enqueued"] == 3
+    # warm-up + steps + the one parity interval
+    assert pw["n_gpus"] == world and pw["config"]["rccl_ranks"] == world and pw["config"]["rccl_gathers_enqueued"] == 4
     assert "rxgpu_power_gather" in pw["config"]["gather"] and "libfake_rccl" in pw["config"]["gather"]
     assert pw["config"]["tunes_per_rank_padded"] == -(-599 // world) and pw["value"] > 0
+    # what the driver's record keeps (top-level config / roofline / cpu_baseline) answers the scaling questions by itself:
+    cfg = line["config"]
+    assert cfg["n_ranks"] == world and cfg["rccl_ranks"] == world and cfg["rccl_gathers_enqueued"] == 4
+    assert cfg["rx_power_Mbins_per_s"] == pw["value"] and cfg["rx_power_ms_per_step"] > 0 and cfg["tunes_per_rank"] == -(-599 // world)
+    assert cfg["scan_us_rank0"] > 0 and cfg["gather_us_rank0"] > 0 and "rxgpu_power_gather" in cfg["gather"]
+    # ... and the gathered rows of the sharded interval were compared with the CPU checker over every tune of every rank
+    v = pw["parity_sharded"]
+    assert v["parity_ok"] and v["parity_ranks"] == world and v["parity_tunes_compared"] == 599 and v["parity_passes"] == 8
+    assert v["parity_padding_rows_zero"] and v["parity_inputs_regenerated_match_owner_checksums"]
+    assert cfg["rx_power_parity_ok"] is True and cfg["parity_all_legs"]["rx_power_sharded"] is True and cfg["parity_all_legs"]["rx_fm"] is True
+    assert line["parity_ok"] is True and line["parity_checked_samples"] > 0
+    assert "rx_power N=4096 (configs[2])" in line["roofline"]["legs"] and "channeliser 256 ch" in line["roofline"]["legs"]
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] == 1 and cfg["rx_power_cpu_baseline_Mbins_per_s_1core"] > 0
 
 
 def test_comm_rejects_a_rank_the_communicator_does_not_report(tmp_path):

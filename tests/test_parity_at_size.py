@@ -104,6 +104,7 @@ def test_chan_checker():
         got[:, b * wpb:(b + 1) * wpb] = tmp
     r = PA.chan_check(iq, n_blocks, block_len, bin_e, first_bin, n_ch, 1, sw, got, pre)
     assert r["parity_ok"] and r["parity_windows_compared"] == n_blocks * wpb, r
+    assert r["parity_checker"].startswith("reference" if support.have_ref() else "port")
     got[3, 5 * wpb + 1] ^= 2
     r = PA.chan_check(iq, n_blocks, block_len, bin_e, first_bin, n_ch, 1, sw, got, pre)
     assert not r["parity_ok"] and r["parity_first_bad_block"] == 5
