@@ -775,6 +775,7 @@ def main():
             step()
             L.rxgpu_sync()
             barrier()
+            pw["config"]["rccl_gathers_enqueued"] = comm.gathers if comm is not None else 0      # warm-up + timed steps + this interval
             mysum = int(d_in.view(torch.int32).sum(dtype=torch.int64).item())
             sums = [None] * world
             dist.gather_object(mysum, sums if rank == 0 else None, dst=0)

@@ -1,4 +1,4 @@
-/* Stand-in for <SoapySDR/Device.h> -- TEST INFRASTRUCTURE ONLY (see Version.h).
+/* Stand-in for <SoapySDR/Device.h> -- the capture-replay stand-in (see Version.h).
  * Only the entry points rx_tools references are declared. */
 #pragma once
 #include <stddef.h>

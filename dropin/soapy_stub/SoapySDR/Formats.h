@@ -1,4 +1,4 @@
-/* Stand-in for <SoapySDR/Formats.h> -- TEST INFRASTRUCTURE ONLY (see Version.h). */
+/* Stand-in for <SoapySDR/Formats.h> -- the capture-replay stand-in (see Version.h). */
 #pragma once
 #include <stddef.h>
 #define SOAPY_SDR_CF64 "CF64"

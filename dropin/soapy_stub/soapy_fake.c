@@ -1,14 +1,24 @@
-/* Fake libSoapySDR -- TEST INFRASTRUCTURE ONLY.
+/* Stand-in libSoapySDR: a capture-replay device.  No radio, no DSP.
  *
- * Implements the handful of SoapySDR C entry points the reference links against
- * (see soapy_stub/SoapySDR/Device.h) on top of an in-memory cs16 sample source, so
- * that the reference's own translation units can be linked and, where wanted, its
- * main()/threads driven end to end without radio hardware.  Nothing here is DSP.
- *
- * The sample source is installed with soapy_fake_set_source(); readStream hands out
- * consecutive chunks of it and reports SOAPY_SDR_STREAM_ERROR once it is exhausted
- * (after calling the optional end-of-stream hook).
+ * Implements the handful of SoapySDR C entry points rx_tools links against (see SoapySDR/Device.h next to this file) on top of a
+ * cs16 sample source, so that rx_tools' own translation units link and run end to end on a machine without SoapySDR or a radio:
+ *   * dropin/Makefile links it into rx_fm / rx_power when no real SoapySDR is found (SOAPY=stub); the capture then comes from a file:
+ *       $SOAPY_FAKE_FILE       raw interleaved int16 I,Q (what `rx_sdr -F CS16` writes)
+ *       $SOAPY_FAKE_PACE       real-time factor of the replay: 1 = at the sample rate the program set, 0.25 = four times slower,
+ *                              unset/0 = as fast as it is read
+ *       $SOAPY_FAKE_MAX_READ   elements per readStream at most (a real device returns what it has, not what was asked for)
+ *       $SOAPY_FAKE_EOF_SIGINT at the end of the file: raise SIGINT once, after this many milliseconds (what a user's ^C does to
+ *                              rx_fm, rtl_fm.c:274-278); the read itself reports SOAPY_SDR_STREAM_ERROR
+ *   * oracle/Makefile links it into the reference-built checker objects (TEST INFRASTRUCTURE), which install an in-memory source
+ *     and hooks through the soapy_fake_* calls below.
+ * readStream hands out consecutive chunks and reports SOAPY_SDR_STREAM_ERROR once the source is exhausted (after calling the
+ * optional end-of-stream hook).
  */
+#define _GNU_SOURCE
+#include <signal.h>
+#include <stdio.h>
+#include <time.h>
+#include <unistd.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -43,6 +53,49 @@ void soapy_fake_set_freq_script(const double *f, size_t n) { g_freq_script = f; 
 void soapy_fake_set_eos_hook(void (*fn)(void)) { g_eos_hook = fn; }
 void soapy_fake_set_pace_hook(void (*fn)(void)) { g_pace_hook = fn; g_reads = 0; }
 size_t soapy_fake_position(void) { return g_src_pos; }
+
+/* ---- file replay ($SOAPY_FAKE_FILE), set up at the first read */
+static int g_env_done;
+static double g_pace;             /* real-time factor, 0 = unpaced */
+static long g_eos_sigint_ms = -1;
+static double g_t0;
+static size_t g_paced;            /* elements handed out since g_t0 */
+
+static double mono_s(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec + (double)ts.tv_nsec * 1e-9;
+}
+
+static void env_setup(void)
+{
+	g_env_done = 1;
+	const char *path = getenv("SOAPY_FAKE_FILE"), *e;
+	if ((e = getenv("SOAPY_FAKE_PACE")) != NULL)
+		g_pace = atof(e);
+	if ((e = getenv("SOAPY_FAKE_MAX_READ")) != NULL && atol(e) > 0)
+		g_max_chunk = (size_t)atol(e);
+	if ((e = getenv("SOAPY_FAKE_EOF_SIGINT")) != NULL)
+		g_eos_sigint_ms = atol(e);
+	if (path && !g_src) {
+		FILE *f = fopen(path, "rb");
+		if (!f) {
+			fprintf(stderr, "soapy_fake: cannot open %s\n", path);
+			return;
+		}
+		fseek(f, 0, SEEK_END);
+		long bytes = ftell(f);
+		fseek(f, 0, SEEK_SET);
+		int16_t *buf = malloc(bytes > 0 ? (size_t)bytes : 1);
+		if (buf && fread(buf, 1, (size_t)bytes, f) == (size_t)bytes) {
+			g_src = buf;
+			g_src_len = (size_t)bytes / g_elem;
+			g_src_pos = 0;
+		}
+		fclose(f);
+	}
+}
 
 size_t SoapySDR_formatToSize(const char *format)
 {
@@ -81,6 +134,8 @@ int SoapySDRDevice_readStream(SoapySDRDevice *d, SoapySDRStream *s, void * const
 {
 	size_t n = numElems;
 	(void)d; (void)s; (void)flags; (void)timeNs; (void)timeoutUs;
+	if (!g_env_done)
+		env_setup();
 	if (g_discard && buffs[0] == g_discard) {
 		memset(buffs[0], 0, n * 2 * sizeof(int16_t));
 		return (int)n;
@@ -89,10 +144,27 @@ int SoapySDRDevice_readStream(SoapySDRDevice *d, SoapySDRStream *s, void * const
 		g_pace_hook();
 	if (!g_src || g_src_pos >= g_src_len) {
 		if (g_eos_hook) { void (*h)(void) = g_eos_hook; g_eos_hook = NULL; h(); }
+		if (g_eos_sigint_ms >= 0) {
+			long ms = g_eos_sigint_ms;
+			g_eos_sigint_ms = -1;
+			usleep((useconds_t)ms * 1000);
+			raise(SIGINT);
+		} else if (!g_pace_hook) {
+			usleep(1000);                                  /* an exhausted capture is polled, not spun on */
+		}
 		return SOAPY_SDR_STREAM_ERROR;
 	}
 	if (g_max_chunk && n > g_max_chunk) n = g_max_chunk;
 	if (n > g_src_len - g_src_pos) n = g_src_len - g_src_pos;
+	if (g_pace > 0 && g_dev.rate > 0) {
+		/* deliver no faster than pace x the sample rate the program asked for: a block is "received" when its last sample would be */
+		if (g_t0 == 0)
+			g_t0 = mono_s();
+		g_paced += n;
+		const double due = g_t0 + (double)g_paced / (g_dev.rate * g_pace), now = mono_s();
+		if (due > now)
+			usleep((useconds_t)((due - now) * 1e6));
+	}
 	memcpy(buffs[0], (const char *)g_src + g_elem * g_src_pos, n * g_elem);
 	g_src_pos += n;
 	return (int)n;

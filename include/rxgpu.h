@@ -77,7 +77,10 @@ int rxgpu_prof_get(const char *name, double *total_ms, long *launches);
  * MAXIMUM_BUF_LENGTH -- -F blocks that are not a multiple of 2^passes follow the C's own int16 indexing (lp_len >> i turns odd, the final
  * lp_len may be odd), and a block that completes no decimated sample gets what the C does on the struct's memory (fm_demod's result[0], and
  * pre_r/pre_j from lp[lp_len-2], lp[lp_len-1] in front of lowpassed[]).
- * Not on the device path, by decision: -L level printing (file-static counters of rtl_fm.c) and -o with a block
+ * -L level printing (rtl_fm.c:792-807) sits inside full_demod on file-static counters of rtl_fm.c: the library cannot see them, so the
+ * block stays with the caller -- behind this call, fed `sr` from rxgpu_dropin_block_rms (dropin/rx_fm_unit.c does exactly that, and the
+ * rx_fm built by dropin/Makefile prints the reference's level lines).
+ * Not on the device path, by decision: -o with a block
  * whose demodulated length is not a multiple of the step (the reference then reads stale data); and the two shapes the reference itself dies on
  * (-E adc with no demodulated sample: division by result_len == 0, rtl_fm.c:693; -E rdc on an empty read, rtl_fm.c:711): those print to
  * stderr and exit(1) -- there is no CPU fallback.
@@ -86,6 +89,15 @@ int rxgpu_prof_get(const char *name, double *total_ms, long *launches);
 void rxgpu_full_demod(struct demod_state *d);
 /* a caller that edits d->lowpassed between rxgpu_callback and rxgpu_full_demod says so here */
 void rxgpu_dropin_invalidate(const struct demod_state *d);
+/* full_demod's `sr` (rtl_fm.c:781: rms(d->lowpassed, d->lp_len, 1) of the decimated block, BEFORE a quiet block is zeroed) for the
+ * block the last rxgpu_full_demod(d) took, as the squelch kernel computed it; INT_MIN for an empty block ((int)NaN on x86-64).
+ * RXGPU_EUNSUPPORTED when that block ran without squelch (squelch_level == 0): lowpassed[] is then intact and the reference's own
+ * rms(d->lowpassed, d->lp_len, 1) is the value.  What -L needs (rtl_fm.c:792-807). */
+int rxgpu_dropin_block_rms(const struct demod_state *d, int *sr);
+/* Forget a demod_state: frees its stream object, device buffers, de-emphasis accumulator and side-car slot (16 exist; the 17th
+ * distinct live demod_state makes the drop-ins fail).  For callers that create and destroy demod_states; the reference's own is a
+ * global.  RXGPU_EINVAL if `d` has no side-car. */
+int rxgpu_dropin_release(const struct demod_state *d);
 /* Optional, once at start-up: page-lock lowpassed[]..result[] of *d and buf16[] of *s so that the drop-in's copies are
  * DMA'd in place (SURVEY.md section 8b "Ownership").  The structs must outlive the registration -- the reference's are
  * globals (rtl_fm.c:190-191); rxgpu_dropin_unpin before freeing heap-allocated ones.  Either pointer may be NULL.

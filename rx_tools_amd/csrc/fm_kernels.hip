@@ -850,7 +850,7 @@ __device__ __forceinline__ i64 isqrt_floor(double v)
 }
 
 // rtl_fm.c:781-790 with rms() 739-757 (step 1, over both components): one workgroup per callback block
-__global__ __launch_bounds__(256) void k_fm_squelch(uint32_t *__restrict__ lp, rxk_fm_blocks g, int level, int *__restrict__ below)
+__global__ __launch_bounds__(256) void k_fm_squelch(uint32_t *__restrict__ lp, rxk_fm_blocks g, int level, int *__restrict__ below, int *__restrict__ sr_out)
 {
 	__shared__ i64 red[8];
 	__shared__ int quiet;
@@ -878,6 +878,7 @@ __global__ __launch_bounds__(256) void k_fm_squelch(uint32_t *__restrict__ lp, r
 		const int sr = v >= 0.0 ? (int)isqrt_floor(v) : 0;
 		quiet = sr < level;
 		below[b] = quiet;
+		sr_out[b] = sr;                                      // the `sr` of full_demod (rtl_fm.c:781): what -L prints (rtl_fm.c:792-807)
 	}
 	__syncthreads();
 	if (quiet)
@@ -2973,7 +2974,7 @@ __global__ __launch_bounds__(256) void k_fm_droop_lit(const int16_t *__restrict_
 }
 
 // power squelch on one block, rtl_fm.c:781-790 with rms() 739-757 over all L int16 (step 1): one workgroup
-__global__ __launch_bounds__(256) void k_fm_squelch_lit(int16_t *__restrict__ lp, int L, int level, int *__restrict__ below)
+__global__ __launch_bounds__(256) void k_fm_squelch_lit(int16_t *__restrict__ lp, int L, int level, int *__restrict__ below, int *__restrict__ sr_out)
 {
 	__shared__ i64 red[8];
 	__shared__ int quiet;
@@ -2996,6 +2997,7 @@ __global__ __launch_bounds__(256) void k_fm_squelch_lit(int16_t *__restrict__ lp
 		const int sr = v >= 0.0 ? (int)isqrt_floor(v) : 0;
 		quiet = sr < level;
 		*below = quiet;
+		*sr_out = sr;
 	}
 	__syncthreads();
 	if (quiet)
@@ -3882,9 +3884,9 @@ extern "C" int rxk_fm_droop_lit(void *stream, const int16_t *in, int16_t *out, i
 	LAUNCH_RET();
 }
 
-extern "C" int rxk_fm_squelch_lit(void *stream, int16_t *lp, int L, int level, int *below)
+extern "C" int rxk_fm_squelch_lit(void *stream, int16_t *lp, int L, int level, int *below, int *sr_out)
 {
-	hipLaunchKernelGGL(k_fm_squelch_lit, dim3(1), dim3(256), 0, (hipStream_t)stream, lp, L, level, below);
+	hipLaunchKernelGGL(k_fm_squelch_lit, dim3(1), dim3(256), 0, (hipStream_t)stream, lp, L, level, below, sr_out);
 	LAUNCH_RET();
 }
 
@@ -3904,9 +3906,9 @@ extern "C" int rxk_fm_demod_lit(void *stream, const int16_t *lp, int L, int mode
 	LAUNCH_RET();
 }
 
-extern "C" int rxk_fm_squelch(void *stream, uint32_t *lp, rxk_fm_blocks blk, int level, int *below)
+extern "C" int rxk_fm_squelch(void *stream, uint32_t *lp, rxk_fm_blocks blk, int level, int *below, int *sr_out)
 {
-	hipLaunchKernelGGL(k_fm_squelch, dim3((unsigned)blk.n_blocks), dim3(256), 0, (hipStream_t)stream, lp, blk, level, below);
+	hipLaunchKernelGGL(k_fm_squelch, dim3((unsigned)blk.n_blocks), dim3(256), 0, (hipStream_t)stream, lp, blk, level, below, sr_out);
 	LAUNCH_RET();
 }
 

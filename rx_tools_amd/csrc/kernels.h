@@ -149,7 +149,7 @@ int rxk_fm_deemph_serial(void *stream, const int16_t *pcm, unsigned long long M,
 int rxk_fm_resample(void *stream, const int16_t *y, unsigned long long n, int fast, int slow,
                     unsigned long long J, int16_t *out, rxk_fm_dev *dev);
 /* power squelch (rtl_fm.c:781-790, rms 739-757) per callback block: below[b] = rms < level, and such blocks are zeroed */
-int rxk_fm_squelch(void *stream, uint32_t *lp, rxk_fm_blocks blk, int level, int *below);
+int rxk_fm_squelch(void *stream, uint32_t *lp, rxk_fm_blocks blk, int level, int *below, int *sr_out);   /* sr_out[b]: the block's rms, rtl_fm.c:781 */
 /* am/usb/lsb_demod (rtl_fm.c:617-656) on the final decimated IQ */
 int rxk_fm_simple_demod(void *stream, const uint32_t *lp, unsigned long long M, int mode, int output_scale, int16_t *pcm);
 /* dc_block_audio_filter (rtl_fm.c:684-697): per-block mean, first-order recursion across blocks, subtract */
@@ -209,7 +209,7 @@ int rxk_fm_droop_disc(void *stream, const uint32_t *in, unsigned long long M, co
  * (lp_len >> i turns odd, I and Q yield different counts).  hist: I then Q (6 + 6 int16; the droop FIR's 9 + 9). */
 int rxk_fm_fifth_lit(void *stream, const int16_t *in, int16_t *out, int L, const int16_t *hist_in, int16_t *hist_out);
 int rxk_fm_droop_lit(void *stream, const int16_t *in, int16_t *out, int L, const int *fir, const int16_t *hist_in, int16_t *hist_out);
-int rxk_fm_squelch_lit(void *stream, int16_t *lp, int L, int level, int *below);
+int rxk_fm_squelch_lit(void *stream, int16_t *lp, int L, int level, int *below, int *sr_out);
 enum { RXK_LIT_FM = 0, RXK_LIT_AM = 1, RXK_LIT_USB = 2, RXK_LIT_LSB = 3, RXK_LIT_RAW = 4 };     /* == RXGPU_MODE_* */
 /* results to pcm[m0 ..]: L/2 of them (raw: L); fm: the block's first sample through libm against dev->in_pre (pre_from_out: out_pre, a
  * later block of the run), then dev->out_pre = lp[L-2], lp[L-1] when L >= 2 */

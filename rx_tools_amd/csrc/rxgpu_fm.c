@@ -8,6 +8,7 @@
 #include "rxgpu_internal.h"
 #include "rxgpu_ref_structs.h"
 #include <math.h>
+#include <limits.h>
 #include <pthread.h>
 #include <stddef.h>
 #include <stdio.h>
@@ -278,7 +279,7 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 	DMALLOC(s->flag_cnt_dev, 2 * sizeof(int));
 	DMALLOC(s->flag_rec_dev, 2 * RXK_FLAG_CAP * sizeof(rxk_flag_rec));
 	DMALLOC(s->snap_dev, 8 * sizeof(int));
-	DMALLOC(s->below, (max_blocks + 1) * 4);
+	DMALLOC(s->below, 2 * (max_blocks + 1) * 4);           /* verdicts, then the rms values behind them */
 	DMALLOC(s->dc_sums, (max_blocks + 1) * 8);
 	DMALLOC(s->dc_avgs, (max_blocks + 1) * 4);
 	if (params->custom_atan == 2) {
@@ -321,7 +322,7 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 	    hipHostMalloc((void **)&s->hist_host, HIST_TOTAL * 2, 0) != hipSuccess ||
 	    hipHostMalloc((void **)&s->flag_rec_host, RXK_FLAG_CAP * sizeof(rxk_flag_rec), 0) != hipSuccess ||
 	    hipHostMalloc((void **)&s->flag_cnt_host, 2 * sizeof(int), 0) != hipSuccess ||
-	    hipHostMalloc((void **)&s->below_host, (max_blocks + 1) * 4, 0) != hipSuccess) {
+	    hipHostMalloc((void **)&s->below_host, 2 * (max_blocks + 1) * 4, 0) != hipSuccess) {
 		rxgpu_fm_stream_destroy(s);
 		return rxgpu_fail(RXGPU_ENOMEM, "hipHostMalloc failed");
 	}
@@ -779,9 +780,11 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 				w ^= 1;
 			}
 			if (p->squelch_level && g->lf > 0)
-				RX_K(rxk_fm_squelch_lit(sb, (int16_t *)cur, g->lf, p->squelch_level, s->below + b));
-			else if (p->squelch_level)
+				RX_K(rxk_fm_squelch_lit(sb, (int16_t *)cur, g->lf, p->squelch_level, s->below + b, s->below + s->max_blocks + 1 + b));
+			else if (p->squelch_level) {
 				RX_HIP(hipMemsetAsync(s->below + b, 1, sizeof(int), sb));   /* rms() of nothing is (int)NaN = INT_MIN on x86-64: below any level */
+				RX_HIP(hipMemsetAsync(s->below + s->max_blocks + 1 + b, 0x80, sizeof(int), sb));   /* 0x80808080: negative, stands for that INT_MIN (block_rms) */
+			}
 			RX_K(rxk_fm_demod_lit(sb, cur, g->lf, p->mode, p->custom_atan, p->output_scale, p->mode == RXGPU_MODE_RAW ? d_out : s->pcm,
 			                      (unsigned long long)b * per_out, s->dev, b > 0, flag_rec, flag_cnt, s->atan_lut, s->flag_all));
 			s->lp_final = (const uint32_t *)cur;             /* the drop-in hands the (single) block's lowpassed[] back */
@@ -906,7 +909,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 	if (split && !lit_done) {
 		uint32_t *lpw = (uint32_t *)s->lp_final;             /* every producer of lp_final owns it writable */
 		if (p->squelch_level)
-			RX_K(rxk_fm_squelch(sb, lpw, s->blk, p->squelch_level, s->below));
+			RX_K(rxk_fm_squelch(sb, lpw, s->blk, p->squelch_level, s->below, s->below + s->max_blocks + 1));
 		if (p->mode == RXGPU_MODE_FM) {
 			rxgpu_prof_begin_on("fm_disc", sb);
 			RX_K(rxk_fm_disc(sb, d_iq, g->T, g->ds, g->p0, g->n, prescaled, g->rotate, 0, lpw, NULL, NULL, NULL, g->M,
@@ -934,7 +937,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 	if (rc != RXGPU_OK)
 		return rc;
 	if (p->squelch_level)
-		RX_HIP(hipMemcpyAsync(s->below_host, s->below, n_blocks * 4, hipMemcpyDeviceToHost, sb));
+		RX_HIP(hipMemcpyAsync(s->below_host, s->below, (s->max_blocks + 1 + n_blocks) * 4, hipMemcpyDeviceToHost, sb));
 	RX_HIP(hipEventRecord(s->ev_small[db], sb));
 	s->ev_small_valid[db] = 1;
 	/* what the next run needs from this one on the host side is closed-form */
@@ -1328,6 +1331,7 @@ static struct {
 	rxgpu_fm_stream *s;
 	rxgpu_fm_params p;
 	int dev_slot, dev_len, dev_valid;
+	int last_sr, last_sr_valid;          /* the squelch rms of the block the last rxgpu_full_demod took (rxgpu_dropin_block_rms) */
 	int16_t *cb_in, *cb_pre[2];
 	int *cb_rdc;                         /* dc_avgI/Q, the block averages, the int64 sums */
 	int16_t *fd_in;                      /* full_demod's own upload buffer (the demod thread's; the callback's are the dongle thread's) */
@@ -1362,6 +1366,43 @@ int *rxgpu_deemph_state(const struct demod_state *d)
 {
 	int i = side_slot(d);
 	return i < 0 ? NULL : &g_side[i].avg;
+}
+
+int rxgpu_dropin_block_rms(const struct demod_state *d, int *sr)
+{
+	int i = side_slot(d);
+	if (i < 0 || !sr)
+		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_dropin_block_rms: unknown demod_state");
+	if (!g_side[i].last_sr_valid)
+		return rxgpu_fail(RXGPU_EUNSUPPORTED, "no squelch on the last block: rms(d->lowpassed, d->lp_len, 1) is the value (lowpassed[] is intact)");
+	*sr = g_side[i].last_sr;
+	return RXGPU_OK;
+}
+
+/* Forget a demod_state: its stream object, device buffers, de-emphasis accumulator and side-car slot (SIDECARS of them exist).
+ * For callers that create and destroy demod_state objects; the reference's own is a global that lives as long as the process. */
+int rxgpu_dropin_release(const struct demod_state *d)
+{
+	int found = -1;
+	pthread_mutex_lock(&g_side_lock);
+	for (int i = 0; i < SIDECARS; i++)
+		if (g_side[i].d == d && d)
+			found = i;
+	if (found >= 0) {
+		const int i = found;
+		pthread_mutex_lock(&g_side[i].cb_lock);          /* a callback of this demod_state still running finishes first */
+		if (g_side[i].s)
+			rxgpu_fm_stream_destroy(g_side[i].s);
+		hipFree(g_side[i].cb_in); hipFree(g_side[i].cb_rdc); hipFree(g_side[i].cb_pre[0]); hipFree(g_side[i].cb_pre[1]);
+		hipFree(g_side[i].fd_in);
+		pthread_mutex_t keep = g_side[i].cb_lock;
+		memset(&g_side[i], 0, sizeof(g_side[i]));
+		g_side[i].cb_lock = keep;
+		g_side[i].cb_lock_ready = 1;
+		pthread_mutex_unlock(&g_side[i].cb_lock);
+	}
+	pthread_mutex_unlock(&g_side_lock);
+	return found >= 0 ? RXGPU_OK : rxgpu_fail(RXGPU_EINVAL, "rxgpu_dropin_release: no side-car for this demod_state");
 }
 
 void rxgpu_dropin_invalidate(const struct demod_state *d)
@@ -1618,6 +1659,11 @@ void rxgpu_full_demod(struct demod_state *d)
 	g_side[slot].avg = c.deemph_avg;
 	d->now_lpr = c.now_lpr; d->prev_lpr_index = c.prev_lpr_index;
 	d->squelch_hits = c.squelch_hits; d->dc_avg = c.dc_avg;
+	g_side[slot].last_sr_valid = p.squelch_level != 0;
+	if (p.squelch_level) {
+		const int sr = s->below_host[s->max_blocks + 1];
+		g_side[slot].last_sr = sr < 0 ? INT_MIN : sr;       /* an empty block: (int)NaN, rtl_fm.c:756 on x86-64 */
+	}
 	if (lp_len_out < 2 && mode == RXGPU_MODE_FM) {
 		/* Fewer than one decimated sample (a read shorter than the decimation).  fm_demod (rtl_fm.c:584-615) still writes result[0]
 		 * from lp[0], lp[1] against the old pre_r/pre_j, and takes the new pre_r/pre_j from lp[lp_len-2], lp[lp_len-1] -- in FRONT of

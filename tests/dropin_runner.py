@@ -1,10 +1,8 @@
 """Runs the reference's own rx_fm main() (oracle/_ref/libref_fm.so = rtl_fm.c compiled unmodified)
-on a synthetic cs16 capture served by the fake SoapySDR device, in one of two modes:
-  cpu : untouched -- the reference's threads call the reference's full_demod
-  gpu : oracle/_ref/libdropin.so is loaded first with RTLD_GLOBAL, so the same threads call
-        rxgpu_full_demod through the reference's own PLT (no source change)
-Usage: python dropin_runner.py cpu|gpu <iq.npy> <out.raw> [rx_fm args...]
-       python dropin_runner.py power-cpu|power-gpu <iq.npy> <out.csv> [rx_power args...]
+on a synthetic cs16 capture served by the fake SoapySDR device, untouched: the reference's threads call the reference's
+full_demod / scanner.  (The GPU side of the end-to-end tests runs the product's own executables, dropin/Makefile.)
+Usage: python dropin_runner.py cpu <iq.npy> <out.raw> [rx_fm args...]
+       python dropin_runner.py power-cpu <iq.npy> <out.csv> [rx_power args...]
        python dropin_runner.py plan <out.json> [rx_fm args...]
 (plan: the reference's main() parses the flags and derives its parameters itself -- getopt, `rate_in *= post_downsample`,
 optimal_settings via the controller thread, deemph_a -- on a one-block capture; when the fake device runs dry the
@@ -24,11 +22,6 @@ REF = os.path.join(ROOT, "oracle", "_ref")
 
 
 def main_power(mode, iq, out_path, extra):
-    dropin = None
-    if mode == "power-gpu":
-        import rx_tools_amd as R
-        R.check(R.lib().rxgpu_init(0))
-        dropin = C.CDLL(os.path.join(REF, "libdropin.so"), mode=C.RTLD_GLOBAL)
     ref = C.CDLL(os.path.join(REF, "libref_power.so"), mode=C.RTLD_GLOBAL)
     ref.soapy_fake_set_source.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
     # scanner() asks for buf_len complex elements but consumes buf_len int16: hand out buf_len/2 per read
@@ -38,9 +31,6 @@ def main_power(mode, iq, out_path, extra):
     args = [b"rx_power"] + [a.encode() for a in extra] + [out_path.encode()]
     argv = (C.c_char_p * (len(args) + 1))(*args, None)
     rc = ref.rx_power_main(len(args), argv)
-    if dropin is not None:
-        dropin.dropin_scans.restype = C.c_long
-        sys.stderr.write("dropin scanner passes: %d\n" % dropin.dropin_scans())
     os._exit(rc)
 
 
@@ -88,42 +78,27 @@ def main():
     iq = np.load(iq_path)
     if mode.startswith("power"):
         return main_power(mode, iq, out_path, extra)
-    dropin = None
-    if mode == "gpu":
-        import rx_tools_amd as R          # loads torch's HIP runtime first, then librxgpu
-        R.check(R.lib().rxgpu_init(0))
-        dropin = C.CDLL(os.path.join(REF, "libdropin.so"), mode=C.RTLD_GLOBAL)
     ref = C.CDLL(os.path.join(REF, "libref_fm.so"), mode=C.RTLD_GLOBAL)
     ref.soapy_fake_set_source.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
     ref.soapy_fake_set_source(iq.ctypes.data, len(iq) // 2, 0)
-    if dropin is not None:
-        ref.soapy_fake_set_pace_hook(C.cast(dropin.dropin_pace, C.c_void_p))
-        ref.soapy_fake_set_eos_hook(C.cast(dropin.dropin_eos, C.c_void_p))
-    else:
-        # same pacing/shutdown for the untouched run, from Python callbacks
-        import signal
-        import time
-        PACE = C.CFUNCTYPE(None)
-        state = {"n": 0}
+    # pacing and shutdown from Python callbacks
+    import signal
+    import time
+    PACE = C.CFUNCTYPE(None)
 
-        def pace():
-            # wait until the demod thread has consumed the previous block: result_len changes per block;
-            # a fixed sleep well above one block's CPU time is enough here
-            time.sleep(0.02)
+    def pace():
+        # wait until the demod thread has consumed the previous block: a fixed sleep well above one block's CPU time
+        time.sleep(0.02)
 
-        def eos():
-            time.sleep(0.1)
-            os.kill(os.getpid(), signal.SIGINT)
-        keep = (PACE(pace), PACE(eos))
-        state["keep"] = keep
-        ref.soapy_fake_set_pace_hook(keep[0])
-        ref.soapy_fake_set_eos_hook(keep[1])
+    def eos():
+        time.sleep(0.1)
+        os.kill(os.getpid(), signal.SIGINT)
+    keep = (PACE(pace), PACE(eos))
+    ref.soapy_fake_set_pace_hook(keep[0])
+    ref.soapy_fake_set_eos_hook(keep[1])
     args = [b"rx_fm"] + [a.encode() for a in extra] + [out_path.encode()]
     argv = (C.c_char_p * (len(args) + 1))(*args, None)
     rc = ref.rx_fm_main(len(args), argv)
-    if dropin is not None:
-        dropin.dropin_calls.restype = C.c_long
-        sys.stderr.write("dropin full_demod calls: %d\n" % dropin.dropin_calls())
     os._exit(rc)
 
 

@@ -1,9 +1,11 @@
-"""End to end through the reference's OWN main(), threads and SoapySDR read loop (libref_fm.so =
-rtl_fm.c compiled unmodified; the prebuilt object travels to the GPU box):
-  * CPU: the untouched reference binary path reproduces the oracle -> validates the harness
-  * GPU: with full_demod interposed by rxgpu_full_demod (oracle/dropin_interpose.c, i.e. the
-    INTEGRATION.md patch applied by the dynamic linker) the same run gives the same S16LE bytes.
-Flags are the reference's: -M wbfm -f 100M [-F 9]."""
+"""End to end through the reference's OWN main(), threads and SoapySDR read loop:
+  * CPU: the untouched reference (libref_fm.so / libref_power.so = rtl_fm.c / rtl_power.c compiled unmodified) reproduces the oracle
+    -> validates the harness
+  * GPU: the PRODUCT'S drop-in executables -- rx_fm and rx_power as dropin/Makefile builds them from the reference checkout
+    (sources compiled where they lie; full_demod / scanner / csv_dbm redirected to librxgpu at link time; the PATCH=1 flavour also
+    with rxgpu_callback at rtl_fm.c:899), linked against the capture-replay SoapySDR stand-in -- give the same S16LE bytes / CSV rows.
+    The binaries are built in this container (make -C oracle ref -> oracle/_ref/dropin_bin*/) and travel to the GPU box.
+Flags are the reference's: -M wbfm -f 100M [-F 9] [-l N -L N], -f lo:hi:bin -w hamming -i 2 -1."""
 import os
 import subprocess
 import sys
@@ -63,20 +65,57 @@ def test_reference_main_untouched_matches_oracle(tmp_path, extra, kw):
     assert np.array_equal(got, want)
 
 
+def dropin_bin(name, patched=False):
+    return os.path.join(ROOT, "oracle", "_ref", "dropin_bin_patched" if patched else "dropin_bin", name)
+
+
+def run_dropin_rx_fm(iq, tmp_path, extra, patched):
+    """the product's rx_fm executable on a capture file, replayed at a quarter of real time (the reference's hand-off between its
+    dongle and demod threads is a single lossy slot, rtl_fm.c:858-862/921-924: a real-time source never overruns it), ^C at the end"""
+    exe = dropin_bin("rx_fm", patched)
+    if not os.path.exists(exe):
+        pytest.skip("dropin binaries not built (make -C oracle ref)")
+    iq_path, out_path = str(tmp_path / "iq.cs16"), str(tmp_path / "out.raw")
+    iq.tofile(iq_path)
+    env = dict(os.environ, SOAPY_FAKE_FILE=iq_path, SOAPY_FAKE_PACE="0.25", SOAPY_FAKE_EOF_SIGINT="300")
+    p = subprocess.run([exe] + extra + [out_path], env=env, capture_output=True, timeout=300)
+    assert os.path.exists(out_path), p.stderr.decode()[-2000:]
+    return np.fromfile(out_path, dtype=np.int16), p.stderr.decode()
+
+
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
+@pytest.mark.parametrize("patched", [False, True])
 @pytest.mark.parametrize("extra,kw", [
     (["-M", "wbfm", "-f", "100M"], dict(downsample=6)),
     (["-M", "wbfm", "-F", "9", "-f", "100M"], dict(downsample_passes=3, comp_fir_size=9)),
     (["-M", "wbfm", "-o", "4", "-E", "rdc", "-f", "100M"], dict(downsample=2, post_downsample=4, dc_block_raw=1)),
 ])
-def test_reference_main_with_rxgpu_full_demod(tmp_path, extra, kw):
+def test_dropin_rx_fm_executable(tmp_path, extra, kw, patched):
     iq = sig_fm(5 * 131072, seed=2025)
-    got, err = run_ref_main("gpu", iq, tmp_path, extra)
-    want = expected(iq, **kw)
-    assert "dropin full_demod calls: 6" in err, err[-1500:]      # 5 blocks + the shutdown wake-up
+    got, err = run_dropin_rx_fm(iq, tmp_path, extra, patched)
+    want = expected(iq, **kw)                                     # 5 blocks + the shutdown wake-up
     assert len(got) == len(want), err[-1500:]
     assert np.array_equal(got, want)
+
+
+LEVEL_LINE = __import__("re").compile(r"^-?[0-9.]+(e[+-]?[0-9]+)?, -?\d+, -?\d+, -?\d+$")
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("extra", [["-M", "wbfm", "-f", "100M", "-L", "2"], ["-M", "fm", "-s", "170k", "-f", "100M", "-l", "60", "-L", "3"]])
+def test_dropin_rx_fm_prints_the_reference_level_lines(tmp_path, extra):
+    """-L (rtl_fm.c:792-807): the level lines of the drop-in executable == those of the untouched reference main(), with and without
+    squelch (a block the squelch zeroes is measured before it is zeroed: the device's rms)"""
+    iq = sig_fm(6 * 131072, seed=2026)
+    iq[2 * 262144:3 * 262144] //= 64                               # one quiet block for the squelch
+    got, err_gpu = run_dropin_rx_fm(iq, tmp_path, extra, False)
+    want, err_cpu = run_ref_main("cpu", iq, tmp_path, extra)
+    assert np.array_equal(got, want)
+    lv_gpu = [ln for ln in err_gpu.splitlines() if LEVEL_LINE.match(ln.strip())]
+    lv_cpu = [ln for ln in err_cpu.splitlines() if LEVEL_LINE.match(ln.strip())]
+    assert lv_cpu and lv_gpu == lv_cpu, (lv_gpu, lv_cpu)
 
 
 # ------------------------------------------------------------------ rx_power
@@ -136,14 +175,27 @@ def test_reference_rx_power_main_untouched_matches_oracle(tmp_path):
     assert got == want, err[-1500:]
 
 
+def run_dropin_rx_power(data, plan, tmp_path, extra):
+    exe = dropin_bin("rx_power")
+    if not os.path.exists(exe):
+        pytest.skip("dropin binaries not built (make -C oracle ref)")
+    iq_path, out_path = str(tmp_path / "iq.cs16"), str(tmp_path / "out.csv")
+    np.ascontiguousarray(data).tofile(iq_path)
+    # scanner() asks for buf_len ELEMENTS but consumes buf_len int16 (rtl_power.c:526/715): the device hands out buf_len/2 per read;
+    # retune()'s flush reads go to the file-static `dump`, which the unit tells the replay device to leave the capture alone for
+    env = dict(os.environ, SOAPY_FAKE_FILE=iq_path, SOAPY_FAKE_MAX_READ=str(plan.buf_len // 2))
+    p = subprocess.run([exe] + extra + [out_path], env=env, capture_output=True, timeout=300)
+    assert os.path.exists(out_path), p.stderr.decode()[-2000:]
+    return [line.split(", ", 2)[2] for line in open(out_path).read().splitlines()], p.stderr.decode()
+
+
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
-def test_reference_rx_power_main_with_rxgpu_scan(tmp_path):
+def test_dropin_rx_power_executable(tmp_path):
     from support import sig_noise
     rng, window, flags, args = POWER_ARGS
     passes = 3
     data = sig_noise(passes * 8 * 16384, seed=607, amp=3000)
     want, plan = power_expected_rows(data, passes, rng, window, flags)
-    got, err = run_power_main("power-gpu", data, plan, tmp_path, args)
-    assert "dropin scanner passes: 3" in err, err[-1500:]
-    assert got == want
+    got, err = run_dropin_rx_power(data, plan, tmp_path, args)
+    assert got == want, err[-1500:]
