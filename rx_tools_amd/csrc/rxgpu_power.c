@@ -44,80 +44,108 @@ static double parse_suffixed(const char *s)
 	return atof(tmp) * mult;
 }
 
-/* frequency_range, rtl_power.c:431-543, without the allocation and the stderr report */
+/* ---- sweep geometry: what frequency_range (rtl_power.c:431-543) derives from "lower:upper:bin", as a closed form.
+ *
+ * The reference finds the hop count and the bin exponent by counting upwards until a condition holds.  Both conditions are
+ * monotone in the counter -- a hop's share of the span shrinks as the hops grow, a bin narrows as the exponent grows -- so each
+ * result is "the least value for which the condition holds", which a bisection over the same arithmetic expression gives
+ * without walking the range (the reference's own note asks for exactly that: "todo, replace loop with algebra/log2").  Every
+ * expression that decides a result keeps the reference's types and operation order (int64 quotient first, then one double
+ * division by 1 - crop, truncation), because the geometry has to come out identical: tests/golden/plans.npz holds nine plans
+ * produced by the reference's frequency_range, tests/test_oracle_vs_ref.py sweeps random ranges against the reference itself. */
+
+/* least v in [lo, hi] with holds(v, ctx), for a predicate that never turns false again once true; hi + 1 if it never holds */
+static int64_t least_holding(int64_t lo, int64_t hi, int (*holds)(int64_t, const void *), const void *ctx)
+{
+	const int64_t none = hi + 1;
+	if (!holds(hi, ctx))
+		return none;
+	while (lo < hi) {
+		const int64_t mid = lo + (hi - lo) / 2;
+		if (holds(mid, ctx))
+			hi = mid;
+		else
+			lo = mid + 1;
+	}
+	return lo;
+}
+
+struct hop_ctx { int64_t span; double keep; };             /* keep = 1 - crop */
+/* the rate one of `hops` equal pieces of the span needs once the cropped edges are added back */
+static int64_t hop_rate(int64_t hops, const struct hop_ctx *c) { return (int64_t)((double)(c->span / hops) / c->keep); }
+static int hop_fits(int64_t hops, const void *ctx) { return hop_rate(hops, ctx) <= MAXIMUM_RATE; }
+
+struct bin_ctx { int64_t rate, ds; double widest; };
+static double bin_width(int64_t e, const struct bin_ctx *c) { return (double)c->rate / (double)(((int64_t)1 << e) * c->ds); }
+static int bin_fits(int64_t e, const void *ctx) { return bin_width(e, ctx) <= ((const struct bin_ctx *)ctx)->widest; }
+
 int rxgpu_power_plan_range(const char *range, double crop, int boxcar, rxgpu_power_plan *plan)
 {
-	char buf[192];
-	char *stop, *step;
-	int i, bin_e = 0, buf_len, tune_count = 0;
-	int64_t upper, lower, max_size, bw_seen = 0, bw_used = 0, downsample = 1, downsample_passes = 0;
-	double bin_size;
-	if (!range || !plan || strlen(range) >= sizeof(buf))
+	enum { HOPS_TRIED = 1499, BIN_E_MAX = 21 };
+	char text[192];
+	if (!range || !plan || strlen(range) >= sizeof(text))
 		return rxgpu_fail(RXGPU_EINVAL, "bad range string");
-	strcpy(buf, range);
-	stop = strchr(buf, ':');
-	if (!stop)
+	strcpy(text, range);
+	char *second = strchr(text, ':');
+	char *third = second ? strchr(second + 1, ':') : NULL;
+	if (!third)
 		return rxgpu_fail(RXGPU_EINVAL, "range must be lower:upper:bin_size");
-	*stop++ = 0;
-	step = strchr(stop, ':');
-	if (!step)
-		return rxgpu_fail(RXGPU_EINVAL, "range must be lower:upper:bin_size");
-	*step++ = 0;
-	lower = (int64_t)parse_suffixed(buf);
-	upper = (int64_t)parse_suffixed(stop);
-	max_size = (int64_t)parse_suffixed(step);
-	/* evenly sized ranges, as close to MAXIMUM_RATE as possible (456-463) */
-	for (i = 1; i < 1500; i++) {
-		bw_seen = (upper - lower) / i;
-		bw_used = (int64_t)((double)bw_seen / (1.0 - crop));
-		if (bw_used > MAXIMUM_RATE)
-			continue;
-		tune_count = i;
-		break;
-	}
-	/* unless small bandwidth (465-473) */
-	if (bw_used < MINIMUM_RATE) {
-		tune_count = 1;
-		if (bw_used <= 0)
+	*second++ = 0;
+	*third++ = 0;
+	const int64_t lower = (int64_t)parse_suffixed(text), upper = (int64_t)parse_suffixed(second);
+	const int64_t widest_bin = (int64_t)parse_suffixed(third);
+	const struct hop_ctx hc = { upper - lower, 1.0 - crop };
+
+	/* hops: as few as fit the tuner's widest rate; a span no hop count up to the limit covers keeps the last count tried and no tunes */
+	int64_t hops = least_holding(1, HOPS_TRIED, hop_fits, &hc);
+	const int covered = hops <= HOPS_TRIED;
+	int64_t piece = hc.span / (covered ? hops : HOPS_TRIED);   /* Hz each hop contributes to the sweep */
+	int64_t rate = hop_rate(covered ? hops : HOPS_TRIED, &hc); /* Hz each hop samples */
+	if (!covered)
+		hops = 0;
+
+	/* a span narrower than the tuner's slowest rate: one hop, oversampled by a whole factor and decimated back */
+	int64_t ds = 1;
+	int ds_passes = 0;
+	if (rate < MINIMUM_RATE) {
+		if (rate <= 0)
 			return rxgpu_fail(RXGPU_EINVAL, "unsupported bandwidth");
-		downsample = MAXIMUM_RATE / bw_used;
-		if (downsample <= 0)
-			return rxgpu_fail(RXGPU_EINVAL, "unsupported bandwidth");
-		bw_used = bw_used * downsample;
+		hops = 1;
+		ds = MAXIMUM_RATE / rate;
+		rate *= ds;
 	}
-	if (!boxcar && downsample > 1) {                       /* 474-482 */
-		downsample_passes = (int)log2((double)downsample);
-		downsample = 1 << downsample_passes;
-		bw_used = (int)((double)(bw_seen * downsample) / (1.0 - crop));
+	if (!boxcar && ds > 1) {
+		/* the fifth_order cascade halves per pass: the largest power of two within the factor (floor(log2) of an integer below 2^22
+		 * is its top bit whichever way it is computed) */
+		ds_passes = 63 - __builtin_clzll((unsigned long long)ds);
+		ds = (int64_t)1 << ds_passes;
+		rate = (int)((double)(piece * ds) / hc.keep);
 	}
-	/* number of bins is power-of-two, bin size is under limit (485-491) */
-	for (i = 1; i <= 21; i++) {
-		bin_e = i;
-		bin_size = (double)bw_used / (double)((1 << i) * downsample);
-		if (bin_size <= (double)max_size)
-			break;
-	}
-	/* unless giant bins (493-499) */
-	if (max_size >= MINIMUM_RATE) {
-		bw_seen = max_size;
-		bw_used = max_size;
-		tune_count = (int)((upper - lower) / bw_seen);
+
+	/* bins: the fewest (a power of two, 2 .. 2^21) that are no wider than asked; 2^21 if even those are wider */
+	const struct bin_ctx bc = { rate, ds, (double)widest_bin };
+	int64_t bin_e = least_holding(1, BIN_E_MAX, bin_fits, &bc);
+	if (bin_e > BIN_E_MAX)
+		bin_e = BIN_E_MAX;
+
+	/* bins of a whole tuner bandwidth or more: no transform, one rms_power bin per hop, nothing cropped */
+	if (widest_bin >= MINIMUM_RATE) {
+		piece = rate = widest_bin;
+		hops = hc.span / piece;
 		bin_e = 0;
 		crop = 0;
 	}
-	if (tune_count > MAX_TUNES)
+	if (hops > MAX_TUNES)
 		return rxgpu_fail(RXGPU_EINVAL, "bandwidth too wide");
-	buf_len = 2 * (1 << bin_e) * (int)downsample;          /* 504-507 */
-	if (buf_len < DEFAULT_BUF_LENGTH)
-		buf_len = DEFAULT_BUF_LENGTH;
-	plan->tune_count = tune_count;
-	plan->bin_e = bin_e;
-	plan->buf_len = buf_len;
-	plan->downsample = (int)downsample;
-	plan->downsample_passes = (int)downsample_passes;
-	plan->rate = (int)bw_used;
-	plan->first_freq = lower + bw_seen / 2;                /* tune i: lower + i*bw_seen + bw_seen/2 (511) */
-	plan->bw_seen = bw_seen;
+	const int one_block = 2 * (1 << bin_e) * (int)ds;          /* int16 of one transform's input */
+	plan->tune_count = (int)hops;
+	plan->bin_e = (int)bin_e;
+	plan->buf_len = one_block < DEFAULT_BUF_LENGTH ? DEFAULT_BUF_LENGTH : one_block;
+	plan->downsample = (int)ds;
+	plan->downsample_passes = ds_passes;
+	plan->rate = (int)rate;
+	plan->first_freq = lower + piece / 2;                      /* hop i is centred on lower + i * piece + piece / 2 */
+	plan->bw_seen = piece;
 	plan->crop = crop;
 	return RXGPU_OK;
 }

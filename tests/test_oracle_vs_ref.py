@@ -183,3 +183,52 @@ def test_fm_ragged_blocks_match_reference(params):
             (st.now_r, st.now_j, st.prev_index, st.pre_r, st.pre_j, st.now_lpr, st.prev_lpr_index, st.squelch_hits, st.dc_avg), (ln, params)
         assert bytes(d.lp_i_hist) == bytes(st.lp_i_hist) and bytes(d.lp_q_hist) == bytes(st.lp_q_hist)
         assert bytes(d.droop_i_hist) == bytes(st.droop_i_hist) and bytes(d.droop_q_hist) == bytes(st.droop_q_hist)
+
+
+def test_plan_range_random_sweep_matches_frequency_range(capfd):
+    """rxgpu_power_plan_range (closed form: bisections over the reference's own expressions) == the reference's frequency_range
+    (rtl_power.c:431-543, counting loops) on 300 random ranges: narrow spans (downsampling, boxcar and fifth_order flavour), wide spans
+    (many hops), cropped edges, giant bins, spans no hop count covers"""
+    import rx_tools_amd as R
+    from rx_tools_amd.structs import TuningState
+    P = ref_power()
+    rnd = np.random.RandomState(2468)
+    checked = 0
+    for case in range(300):
+        kind = case % 5
+        lower = int(rnd.randint(24, 1700)) * 10 ** 6 + int(rnd.randint(0, 10 ** 6))
+        if kind == 0:
+            span = int(rnd.randint(2_000, 900_000))                       # one hop, downsampled
+        elif kind == 1:
+            span = int(rnd.randint(900_000, 6_000_000))                   # around the MINIMUM / MAXIMUM_RATE edges
+        elif kind == 2:
+            span = int(rnd.randint(6_000_000, 400_000_000))               # many hops
+        elif kind == 3:
+            span = int(rnd.choice([2_800_000, 2_800_001, 5_600_000, 999_999, 1_000_000, 1_000_001, 2_799_999]))
+        else:
+            span = int(rnd.randint(100_000_000, 2_000_000_000)) * int(rnd.choice([1, 3]))   # some beyond 1499 hops of 2.8 MHz
+        binw = int(rnd.choice([1, 10, 100, 125, 333, 1000, 5000, 12_500, 100_000, 999_999, 1_000_000, 2_000_000, int(rnd.randint(1, 300_000))]))
+        crop = float(rnd.choice([0.0, 0.0, 0.1, 0.25, 0.5, 0.73]))
+        boxcar = int(rnd.randint(0, 2))
+        rng = "%d:%d:%d" % (lower, lower + span, binw)
+        try:
+            p = R.plan_range(rng, crop, boxcar)
+        except R.RxGpuError:
+            continue                                                     # the reference exit(1)s on those (unsupported bandwidth / too wide)
+        if p.tune_count * (8 << p.bin_e) > (48 << 20) or p.tune_count * p.buf_len * 4 > (48 << 20):
+            continue                                                     # frequency_range mallocs every tune's avg[] and buf16 and never frees
+        P.ref_power_set_flags(boxcar, 0, 0)
+        tc = P.ref_power_setup(rng.encode(), crop, b"rectangle")
+        capfd.readouterr()
+        assert tc == p.tune_count, (rng, crop, boxcar, tc, p.tune_count)
+        if tc == 0:
+            continue
+        arr = (TuningState * tc).from_address(P.ref_power_tunes())
+        t0 = arr[0]
+        got = (p.bin_e, p.buf_len, p.downsample, p.downsample_passes, p.rate, p.first_freq, p.crop)
+        want = (t0.bin_e, t0.buf_len, t0.downsample, t0.downsample_passes, t0.rate, t0.freq, t0.crop)
+        assert got == want, (rng, crop, boxcar, got, want)
+        if tc > 1:
+            assert arr[1].freq - arr[0].freq == p.bw_seen and arr[tc - 1].freq == p.first_freq + (tc - 1) * p.bw_seen, rng
+        checked += 1
+    assert checked >= 150, checked
