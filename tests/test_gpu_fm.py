@@ -402,6 +402,79 @@ def test_config1_ragged_last_block():
     s.close()
 
 
+SOAK_CHAINS = [
+    dict(downsample_passes=3, comp_fir_size=9),                    # the whole chain inside the cascade kernel
+    dict(downsample_passes=3),
+    dict(downsample_passes=4),
+    dict(downsample_passes=7, comp_fir_size=9),                    # three fused groups
+    dict(downsample=5, rate_out=240000, deemph_a=19),              # BASELINE configs[0]: the small-decimation kernel, 256-sample chunks
+    dict(downsample=6),                                            # -M wbfm default
+    dict(downsample=118),                                          # the headline's prefix-scan decimator
+]
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("seed", [0, 1, 2])
+@pytest.mark.parametrize("kw", SOAK_CHAINS)
+def test_soak_of_320_pipelined_runs_of_random_shapes(kw, seed, monkeypatch):
+    """ONE stream object, 320 rxgpu_fm_stream_run_async calls without a wait in between, every run of another shape drawn at random --
+    whole tiles, ragged block lengths (the literal per-block kernels on the -F chains), blocks barely longer than the decimation, one to
+    four blocks per run -- with a pseudo-random eighth of the libm samples handed to the host WRONG ($RXGPU_FLAG_ALL=3), so that runs
+    with and without fix-ups, and fix-ups that re-run the audio stages of the run behind them, interleave with the four-stream
+    pipeline's buffer hand-overs.  Output of the whole sequence and every carry against the oracle; three shuffles per chain."""
+    import ctypes as C
+    from gpu_support import to_dev, torch_cuda, carry_tuple, carry_from_oracle_state
+    from support import oracle, oracle_fm_state, ptr16
+    torch = torch_cuda()
+    monkeypatch.setenv("RXGPU_FLAG_ALL", "3")
+    rnd = np.random.RandomState(1000 * seed + 7 * kw.get("downsample", 0) + kw.get("downsample_passes", 0) + kw.get("comp_fir_size", 0))
+    passes = kw.get("downsample_passes", 0)
+    least = (2 << passes) if passes else kw["downsample"]          # shortest block the stream API takes (shorter ones: drop-in only)
+    whole = [2048, 4096, 8192, 16384, 6144]
+    ragged = [1009, 777, 4100, 2050, 12290, 3 * 2048 + 2]
+    short = [least + 2, least + 9, 2 * least + 1, 300]
+    shapes = []
+    for _ in range(320):
+        kind = rnd.choice(3, p=[0.5, 0.3, 0.2])
+        n = int(rnd.choice([whole, ragged, short][kind]))
+        if n % 2 and passes and ((2 * n) >> passes) < 2:
+            n = 2 * least + 2
+        shapes.append((int(rnd.randint(1, 5)), max(n, least)))
+    total = sum(nb * n for nb, n in shapes)
+    iq = sig_fm(total, seed=500 + seed, amp=9000.0, noise=1200)
+    O, st = oracle(), oracle_fm_state(**kw)
+    lp, res, want = np.zeros(262144, np.int16), np.zeros(131072, np.int16), []
+    pos = 0
+    for nb, n in shapes:
+        for _ in range(nb):
+            blk = np.ascontiguousarray(iq[2 * pos:2 * (pos + n)])
+            k = O.rxo_fm_block(C.byref(st), ptr16(blk), 2 * n, ptr16(lp), None, ptr16(res))
+            want.append(res[:k].copy())
+            pos += n
+    want = np.concatenate(want)
+    s = R.FmStream(R.FmParams.wbfm(**kw), 4, 2 * 16384)
+    d_iq = to_dev(iq)
+    d_out = torch.zeros(len(want) + 4096, dtype=torch.int16, device="cuda")
+    pos = got_n = 0
+    for nb, n in shapes:
+        k, _ = s.run_async(d_iq.data_ptr() + 4 * pos, nb, 2 * n, d_out.data_ptr() + 2 * got_n, d_out.numel() - got_n)
+        got_n += k
+        pos += nb * n
+    s.wait()
+    got = d_out[:got_n].cpu().numpy()
+    assert got_n == len(want)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, "first mismatch at output %d of %d: got %d want %d (%d bad)" % (bad[0], len(want), got[bad[0]], want[bad[0]], bad.size)
+    assert s.host_fixups > 20                                      # the forced flags did go through the host
+    cg, cw = carry_tuple(s.get_carry()), carry_tuple(carry_from_oracle_state(st))
+    assert cg[:8] == cw[:8]
+    if passes:
+        assert cg[8][:12 * passes] == cw[8][:12 * passes] and cg[9][:12 * passes] == cw[9][:12 * passes]
+    if kw.get("comp_fir_size") == 9:
+        assert cg[10] == cw[10] and cg[11] == cw[11]
+    s.close()
+
+
 @pytest.mark.parametrize("kw", [dict(downsample_passes=3, comp_fir_size=9), dict(downsample_passes=4), dict(downsample_passes=7, comp_fir_size=9),
                                 dict(downsample_passes=3, comp_fir_size=9, custom_atan=0)])
 def test_pipelined_runs_of_different_shapes(kw):
