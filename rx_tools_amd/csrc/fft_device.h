@@ -111,7 +111,45 @@ template <int M> struct fft_geom {
 	__host__ __device__ static constexpr int f(int p) { return (M - 4 * (p + 1)) > 0 ? (M - 4 * (p + 1)) : 0; }   // field's low bit
 	__host__ __device__ static constexpr int u(int p) { return M - 4 - f(p); }                                    // bits above the field
 	__host__ __device__ static constexpr int sp0(int p) { return (p == P - 1) ? (4 * P - M) : 0; }                // stages already done
+	// the workgroup's LDS copy of the (doubled) twiddle table, N/2 entries PERMUTED: entry j at row j >> TWC, column rev_TWC(j), rows TWS
+	// dwords apart (fft_tw_fill / fft_tw_addr below)
+	static constexpr int TWC = M - 4;
+	static constexpr int TWS = (1 << TWC) + 8;
+	static constexpr int TW_WORDS = 8 * TWS;
+	// dwords to reserve per thread-row of a transpose area: ROW plus the skew of fft_exchange (at most 8 dwords every 8 rows)
+	static constexpr int XROW = ROW + 1;
 };
+
+// ---- twiddles from LDS (round 4; north_star: "fix_fft twiddles staged in LDS").  Stage s' of a pass indexes the table with
+//   j = (rev_U(x) << (SH - s')) + K(s', g),   x = the thread's U index bits above the pass's field, K a compile-time multiple of 2^(M-1-s')
+// -- a different entry for every thread, which the compiler leaves inside the caller's block loop as 15 global_load_dword per pass (an L1
+// hit still costs several hundred cycles, waited for right behind the transpose).  The table is small (N/2 dwords): a workgroup keeps a
+// copy in LDS.  In natural order the bit-reversed index would put a wave's reads of one stage on 1, 2, 4 or 8 banks; the copy is
+// therefore permuted: entry j sits at row j >> (M-4) (eight rows), column rev_{M-4}(j's low bits).  For the thread, with k = 3 - s':
+//   column = x >> k   (consecutive lanes, consecutive columns),   row = rev_k(x's low k bits) + K / 2^(M-4),
+// and K's part is an immediate offset of the ds_read_b32.  Rows are 2^(M-4) + 8 dwords apart (8 mod 32 banks for M >= 9): at most a
+// 2-way conflict on any read.  Pass 0 (U = 0) has wave-uniform indices: those stay scalar loads from the global table.
+template <int M>
+__device__ __forceinline__ void fft_tw_fill(uint32_t *__restrict__ tl, const uint32_t *__restrict__ tw, int tid, int threads)
+{
+	typedef fft_geom<M> G;
+	for (int j = tid; j < G::N / 2; j += threads)
+		tl[(j >> G::TWC) * G::TWS + (int)(__brev((unsigned)j) >> (32 - G::TWC))] = tw[j];
+}
+
+template <int M, int PASS>
+__device__ __forceinline__ void fft_tw_addr(unsigned tq, unsigned (&ta)[4])
+{
+	typedef fft_geom<M> G;
+	const unsigned x = tq >> G::f(PASS);
+#pragma unroll
+	for (int sp = 0; sp < 4; sp++) {
+		const int k = 3 - sp;
+		const unsigned low = x & ((1u << k) - 1u);
+		const unsigned row = k ? (__brev(low) >> (32 - k)) : 0u;
+		ta[sp] = row * G::TWS + (x >> k);
+	}
+}
 
 // The threads of one transform exchange their values through LDS between two passes.  With N/16 <= 64 threads per transform (N <= 1024)
 // those threads are lanes of ONE wave (the kernels give a transform an aligned run of threads): a wave's LDS instructions execute in
@@ -158,33 +196,104 @@ __device__ __forceinline__ void fft_pass(uint32_t (&v)[16], const uint32_t *__re
 	}
 }
 
-// LDS transpose between the layouts of pass PASS and PASS+1 (rows of 20 dwords: ds_read_b128 conflict-free)
+// the same pass with its twiddles from the workgroup's permuted LDS copy (fft_tw_fill); ta: fft_tw_addr<M, PASS>(tq)
 template <int M, int PASS>
-__device__ __forceinline__ void fft_exchange(uint32_t (&v)[16], uint32_t *__restrict__ lds, unsigned tq)
+__device__ __forceinline__ void fft_pass_lds(uint32_t (&v)[16], const uint32_t *tl, const unsigned (&ta)[4])
 {
 	typedef fft_geom<M> G;
-	constexpr int F = G::f(PASS), F2 = G::f(PASS + 1);
+	static_assert(G::u(PASS) > 0, "pass 0 has wave-uniform twiddles: scalar loads from the global table");
+#pragma unroll
+	for (int sp = G::sp0(PASS); sp < 4; sp++) {
+		const int d = 8 >> sp;
+#pragma unroll
+		for (int g = 0; g < (1 << sp); g++) {
+			const unsigned krow = ((unsigned)crev<4>(g << (4 - sp)) << (M - 1 - sp)) >> G::TWC;     // compile-time
+			const uint32_t w = tl[ta[sp] + krow * G::TWS];
+#pragma unroll
+			for (int q = 0; q < d; q++) {
+				const int r = g * 2 * d + q;
+				bfly_pk(v[r], v[r + d], w);
+			}
+		}
+	}
+}
+
+// ... or from registers the caller loaded once for all its transforms (a thread's twiddles do not change from block to block): twr[15],
+// slot (1 << sp) - 1 + g
+template <int M, int PASS>
+__device__ __forceinline__ void fft_tw_regs(uint32_t (&twr)[15], const uint32_t *__restrict__ tw, unsigned tq)
+{
+	typedef fft_geom<M> G;
+	constexpr int F = G::f(PASS), U = G::u(PASS), SH = M - 1 - U;
+	const unsigned base = U ? (__brev(tq >> F) >> (32 - (U ? U : 1))) : 0u;
+#pragma unroll
+	for (int sp = 0; sp < 4; sp++)
+#pragma unroll
+		for (int g = 0; g < (1 << sp); g++) {
+			const unsigned j = (U ? (base << (SH - sp)) : 0u) + ((unsigned)crev<4>(g << (4 - sp)) << (M - 1 - sp));
+			twr[(1 << sp) - 1 + g] = sp >= G::sp0(PASS) ? tw[j] : 0u;
+		}
+}
+template <int M, int PASS>
+__device__ __forceinline__ void fft_pass_regs(uint32_t (&v)[16], const uint32_t (&twr)[15])
+{
+	typedef fft_geom<M> G;
+#pragma unroll
+	for (int sp = G::sp0(PASS); sp < 4; sp++) {
+		const int d = 8 >> sp;
+#pragma unroll
+		for (int g = 0; g < (1 << sp); g++) {
+			const uint32_t w = twr[(1 << sp) - 1 + g];
+#pragma unroll
+			for (int q = 0; q < d; q++) {
+				const int r = g * 2 * d + q;
+				bfly_pk(v[r], v[r + d], w);
+			}
+		}
+	}
+}
+
+// Row skew of the transposes.  Rows are ROW = 20 dwords (16 data + 4 pad: every lane's ds_read_b128 of its row is aligned and the eight
+// lanes of a read cycle cover all 32 banks).  The WRITE side stores one dword per lane into 64 different rows, and 20 * row mod 32 takes
+// only eight values: the rows a half-wave writes met on 2 to 4 banks (rocprofv3 round 3: 76 % of k_ch_fftR<10>'s LDS cycles were
+// conflicts).  Every eight rows the area shifts by G dwords (16-byte aligned: the read side is unchanged); G per (M, PASS) from an
+// exhaustive search over the write patterns (profiles/README.md): conflict-free for every case but the 2-way ones noted there.
+template <int M, int PASS> __host__ __device__ constexpr int fft_skew()
+{
+	// the last transpose (next field at bit 0) of a field that starts at bit 3 or 4 wants 8, everything else 4
+	return (fft_geom<M>::f(PASS + 1) == 0 && (fft_geom<M>::f(PASS) == 3 || fft_geom<M>::f(PASS) == 4)) ? 8 : 4;
+}
+
+// LDS transpose between the layouts of pass PASS and PASS+1.  row0 (a multiple of 8): the first row of the transform that `lds` holds --
+// a workgroup that owns rows row0 .. of a larger transform (k_pwm_tail) passes its own area and its first row
+template <int M, int PASS>
+__device__ __forceinline__ void fft_exchange(uint32_t (&v)[16], uint32_t *__restrict__ lds, unsigned tq, unsigned row0 = 0)
+{
+	typedef fft_geom<M> G;
+	constexpr int F = G::f(PASS), F2 = G::f(PASS + 1), SK = fft_skew<M, PASS>();
 #pragma unroll
 	for (int r = 0; r < 16; r++) {
 		const unsigned n = ((tq >> F) << (F + 4)) | ((unsigned)r << F) | (tq & ((1u << F) - 1u));
-		const unsigned row = ((n >> (F2 + 4)) << F2) | (n & ((1u << F2) - 1u));
+		const unsigned row = (((n >> (F2 + 4)) << F2) | (n & ((1u << F2) - 1u))) - row0;
 		const unsigned col = (n >> F2) & 15u;
-		lds[row * G::ROW + col] = v[r];
+		lds[row * G::ROW + (row >> 3) * SK + col] = v[r];
 	}
 	fft_sync<M>();
+	const unsigned tl = tq - row0;
 #pragma unroll
 	for (int c = 0; c < 4; c++) {
-		const uint4 t4 = *reinterpret_cast<const uint4 *>(&lds[tq * G::ROW + 4 * c]);
+		const uint4 t4 = *reinterpret_cast<const uint4 *>(&lds[tl * G::ROW + (tl >> 3) * SK + 4 * c]);
 		v[4 * c] = t4.x; v[4 * c + 1] = t4.y; v[4 * c + 2] = t4.z; v[4 * c + 3] = t4.w;
 	}
 }
 
 // in:  v[r] = x[tq + r * N/16]  (natural order)          out: v[r] = X[rev_M((tq << 4) | r)]
-// lds_a/lds_b: this transform's transpose areas (N/16 rows of 20 dwords each); if they are the same
+// lds_a/lds_b: this transform's transpose areas (N/16 rows, XROW dwords reserved per row); if they are the same
 // buffer the caller's DOUBLE must be false and a barrier separates reuse.
-template <int M, bool DOUBLE>
+// tl != nullptr (TWL): passes 1.. take their twiddles from the workgroup's LDS copy (fft_tw_fill), ta[p - 1] = fft_tw_addr<M, p>(tq).
+template <int M, bool DOUBLE, bool TWL = false>
 __device__ __forceinline__ void fft_reg(uint32_t (&v)[16], unsigned tq, uint32_t *lds_a, uint32_t *lds_b,
-                                        const uint32_t *__restrict__ tw)
+                                        const uint32_t *__restrict__ tw, const uint32_t *tl = nullptr, const unsigned (*ta)[4] = nullptr)
 {
 	typedef fft_geom<M> G;
 	// the previous transform's last reads of lds_a must be over before this one's first writes
@@ -193,18 +302,31 @@ __device__ __forceinline__ void fft_reg(uint32_t (&v)[16], unsigned tq, uint32_t
 	fft_pass<M, 0>(v, tw, tq);
 	if constexpr (G::P > 1) {
 		fft_exchange<M, 0>(v, lds_a, tq);
-		fft_pass<M, 1>(v, tw, tq);
+		if constexpr (TWL) fft_pass_lds<M, 1>(v, tl, ta[0]);
+		else fft_pass<M, 1>(v, tw, tq);
 	}
 	if constexpr (G::P > 2) {
 		if (!DOUBLE) fft_sync<M>();
 		fft_exchange<M, 1>(v, DOUBLE ? lds_b : lds_a, tq);
-		fft_pass<M, 2>(v, tw, tq);
+		if constexpr (TWL) fft_pass_lds<M, 2>(v, tl, ta[1]);
+		else fft_pass<M, 2>(v, tw, tq);
 	}
 	if constexpr (G::P > 3) {
 		if (!DOUBLE) fft_sync<M>();
 		fft_exchange<M, 2>(v, lds_a, tq);
-		fft_pass<M, 3>(v, tw, tq);
+		if constexpr (TWL) fft_pass_lds<M, 3>(v, tl, ta[2]);
+		else fft_pass<M, 3>(v, tw, tq);
 	}
+}
+
+// ta for fft_reg<.., TWL = true>
+template <int M>
+__device__ __forceinline__ void fft_tw_addr_all(unsigned tq, unsigned (&ta)[3][4])
+{
+	typedef fft_geom<M> G;
+	if constexpr (G::P > 1) fft_tw_addr<M, 1>(tq, ta[0]);
+	if constexpr (G::P > 2) fft_tw_addr<M, 2>(tq, ta[1]);
+	if constexpr (G::P > 3) fft_tw_addr<M, 3>(tq, ta[2]);
 }
 
 #endif

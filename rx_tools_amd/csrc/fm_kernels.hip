@@ -3151,19 +3151,36 @@ __global__ __launch_bounds__(256) void k_ch_fftR(const uint32_t *__restrict__ iq
 	// without waiting for each other (round 2: 72 KB and three barriers per window group left two barrier-coupled waves per SIMD)
 	constexpr bool WAVE = TPF <= 64;
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-	uint32_t *xa = lds, *xb = WAVE ? lds : lds + 256 * G::ROW;
-	uint32_t *outt = lds + (WAVE ? 1 : 2) * 256 * G::ROW;    // [n_channels][CH_WPG]
+	uint32_t *xa = lds, *xb = WAVE ? lds : lds + 256 * G::XROW;
+	uint32_t *tl = lds + (WAVE ? 1 : 2) * 256 * G::XROW;     // the permuted twiddle copy (fft_device.h), G::TW_WORDS dwords
+	uint32_t *outt = tl + G::TW_WORDS;                      // [n_channels][CH_WPG]
 	const int tid = threadIdx.x, fid = tid / TPF;
 	const unsigned tq = tid % TPF;
 	const u64 w0 = (u64)blockIdx.x * CH_WPG;
+	fft_tw_fill<M>(tl, twiddle, tid, 256);
+	unsigned ta[3][4];
+	fft_tw_addr_all<M>(tq, ta);
+	// the next group of windows is requested while this one is transformed (round 4)
+	uint32_t nxt[16];
+	{
+		const u64 w = w0 + fid;
+#pragma unroll
+		for (int r = 0; r < 16; r++)
+			nxt[r] = w < total_windows ? iq[(w << M) + tq + r * TPF] : 0u;
+	}
+	__syncthreads();                                        // the twiddle copy
 	for (int it = 0; it < CH_WPG; it += FPW) {
-		const u64 w = w0 + it + fid;
-		const bool live = w < total_windows;
 		uint32_t v[16];
 #pragma unroll
 		for (int r = 0; r < 16; r++)
-			v[r] = live ? iq[(w << M) + tq + r * TPF] : 0u;
-		fft_reg<M, !WAVE>(v, tq, xa + fid * TPF * G::ROW, xb + fid * TPF * G::ROW, twiddle);
+			v[r] = nxt[r];
+		if (it + FPW < CH_WPG) {
+			const u64 w = w0 + it + FPW + fid;
+#pragma unroll
+			for (int r = 0; r < 16; r++)
+				nxt[r] = w < total_windows ? iq[(w << M) + tq + r * TPF] : 0u;
+		}
+		fft_reg<M, !WAVE, true>(v, tq, xa + fid * TPF * G::XROW, xb + fid * TPF * G::XROW, twiddle, tl, ta);
 #pragma unroll
 		for (int r = 0; r < 16; r++) {
 			const unsigned bin = __brev((tq << 4) | (unsigned)r) >> (32 - M);
@@ -3950,7 +3967,8 @@ extern "C" int rxk_ch_fft(void *stream, const int16_t *iq, u64 total_windows, in
 		return 0;
 	if (bin_e >= 8 && bin_e <= 12) {
 		const int CH_WPG = ch_wpg(n_channels);
-		const size_t shm = (size_t)((bin_e <= 10 ? 1 : 2) * 256 * 20 + n_channels * CH_WPG) * 4;     /* N <= 1024: one transpose area (k_ch_fftR) */
+		/* N <= 1024: one transpose area (k_ch_fftR); rows of XROW = 21 dwords (fft_exchange's skew), the permuted twiddle copy, the staging */
+		const size_t shm = (size_t)((bin_e <= 10 ? 1 : 2) * 256 * 21 + 8 * ((1 << (bin_e - 4)) + 8) + n_channels * CH_WPG) * 4;
 		const unsigned grid = (unsigned)((total_windows + CH_WPG - 1) / CH_WPG);
 		hipStream_t s = (hipStream_t)stream;
 		const uint32_t *p = (const uint32_t *)iq;

@@ -156,6 +156,49 @@ __device__ __forceinline__ void radix16_pass(uint32_t (&v)[16], const uint32_t *
 	}
 }
 
+// ---- the twiddle table in LDS (round 4).  Stages 4-11 index the table with the thread's own reversed index bits: 15 loads per pass
+// and thread that the compiler keeps inside the block loop as global_load_dword (an L1 hit is still several hundred cycles, waited for
+// right behind the transpose's barrier: four exposed stalls per pass of the tune -- the counters' 26 % of wave time waiting).  The
+// doubled table of N = 4096 is 2048 dwords: one copy per workgroup, loaded once for all the passes of its group, PERMUTED so that the
+// reads are (nearly) conflict-free: entry j sits at row (j >> 8), column rev8(j & 255), rows F4K_TWS dwords apart.  For the last field
+// (stages 8-11, base = rev8(tid)) the index is (base << (3 - s')) + K: its low eight bits reversed are tid >> (3 - s') -- consecutive
+// lanes, consecutive columns -- and its row is rev(tid's low 3 - s' bits) + K / 256; the middle field (stages 4-7, base = rev4(tid >> 4))
+// is the same with tid >> 4 in place of tid (sixteen lanes share an address: a broadcast).  K / 256 * F4K_TWS is an immediate offset of
+// the ds_read_b32.  Row stride 264 = 8 mod 32 banks: at most a 2-way conflict on any of the 30 reads.
+#define F4K_TWS 264
+#define F4K_TW_WORDS (8 * F4K_TWS)
+
+// the four (one per stage of the pass) LDS word addresses of a thread's twiddles, without the K / 256 * F4K_TWS part; x = tid >> 4 for the
+// middle field, tid for the last one
+__device__ __forceinline__ void f4k_tw_addr(unsigned x, unsigned (&ta)[4])
+{
+#pragma unroll
+	for (int sp = 0; sp < 4; sp++) {
+		const int k = 3 - sp;                                           // index bits that spill into the row
+		const unsigned low = x & ((1u << k) - 1u);
+		const unsigned row = k ? (__brev(low) >> (32 - k)) : 0u;
+		ta[sp] = row * F4K_TWS + (x >> k);
+	}
+}
+
+__device__ __forceinline__ void radix16_pass_lds(uint32_t (&v)[16], const uint32_t *tl, const unsigned (&ta)[4])
+{
+#pragma unroll
+	for (int sp = 0; sp < 4; sp++) {
+		const int d = 8 >> sp;
+#pragma unroll
+		for (int g = 0; g < (1 << sp); g++) {
+			const unsigned krow = ((unsigned)crev<4>(g << (4 - sp)) << (11 - sp)) >> 8;      // compile-time
+			const uint32_t w = tl[ta[sp] + krow * F4K_TWS];
+#pragma unroll
+			for (int q = 0; q < d; q++) {
+				const int r = g * 2 * d + q;
+				bfly_pk(v[r], v[r + d], w);
+			}
+		}
+	}
+}
+
 #define F4K_ROW 20                       // 16 data dwords + 4 pad: rows stay 16-byte aligned, b128 reads conflict-free
 #define F4K_BUF (256 * F4K_ROW)
 
@@ -163,7 +206,7 @@ __device__ __forceinline__ void radix16_pass(uint32_t (&v)[16], const uint32_t *
 // are loaded once into registers, remove_dc is reduced from them, then per block:
 //   window -> stages 0-3 in registers -> LDS transpose -> stages 4-7 -> LDS transpose -> stages 8-11
 //   -> |X|^2 into 16 per-thread int64 accumulators (bin = rev8(tid) + 256 * rev4(r)).
-template <int NB, bool PEAK>
+template <int NB, bool PEAK, bool TWL = true>
 __global__ __launch_bounds__(256) void k_pw_fft4096(
 	const int16_t *__restrict__ in, size_t tune_stride, size_t pass_stride, int passes,
 	const int *__restrict__ window, const uint32_t *__restrict__ twiddle, int ppg, i64 *__restrict__ avg, i64 *__restrict__ partial)
@@ -171,7 +214,17 @@ __global__ __launch_bounds__(256) void k_pw_fft4096(
 	__shared__ __attribute__((aligned(16))) uint32_t xa[F4K_BUF];
 	__shared__ __attribute__((aligned(16))) uint32_t xb[F4K_BUF + 16 * 16];
 	__shared__ i64 red[8];
+	__shared__ uint32_t tl[TWL ? F4K_TW_WORDS : 1];
 	const int tid = threadIdx.x;
+	unsigned ta_b[4], ta_c[4];
+	if (TWL) {
+		// the doubled table, permuted (see F4K_TWS): 8 entries per thread, once per workgroup; the first __syncthreads of the pass loop orders it
+#pragma unroll
+		for (int k = 0; k < 8; k++)
+			tl[k * F4K_TWS + (__brev((unsigned)tid) >> 24)] = twiddle[tid + 256 * k];
+		f4k_tw_addr((unsigned)tid >> 4, ta_b);
+		f4k_tw_addr((unsigned)tid, ta_c);
+	}
 	const int tune = blockIdx.x;
 	const int p_begin = blockIdx.y * ppg;
 	const int p_end = min(passes, p_begin + ppg);
@@ -198,6 +251,17 @@ __global__ __launch_bounds__(256) void k_pw_fft4096(
 	for (int r = 0; r < 16; r++)
 		acc[r] = 0;
 
+	// TWL: the next pass's samples are requested while this pass is transformed (the LDS table frees the registers: 129 + 16 NB VGPRs,
+	// three waves per SIMD either way -- the workgroup's LDS allows no more); without it every pass began by waiting for HBM
+	uint32_t dn[TWL ? NB : 1][16];
+	if (TWL && p_begin < p_end) {
+		const uint32_t *buf0 = (const uint32_t *)(in + (size_t)p_begin * pass_stride + (size_t)tune * tune_stride);
+#pragma unroll
+		for (int b = 0; b < NB; b++)
+#pragma unroll
+			for (int r = 0; r < 16; r++)
+				dn[b][r] = buf0[b * 4096 + tid + 256 * r];
+	}
 	for (int pass = p_begin; pass < p_end; pass++) {
 		const uint32_t *buf = (const uint32_t *)(in + (size_t)pass * pass_stride + (size_t)tune * tune_stride);
 		uint32_t d[NB][16];
@@ -206,10 +270,18 @@ __global__ __launch_bounds__(256) void k_pw_fft4096(
 		for (int b = 0; b < NB; b++)
 #pragma unroll
 			for (int r = 0; r < 16; r++) {
-				d[b][r] = buf[b * 4096 + tid + 256 * r];
+				d[b][r] = TWL ? dn[b][r] : buf[b * 4096 + tid + 256 * r];
 				si = pw_dot(d[b][r], 0x00000001u, si);           // += I
 				sq = pw_dot(d[b][r], 0x00010000u, sq);           // += Q
 			}
+		if (TWL && pass + 1 < p_end) {
+			const uint32_t *bufn = (const uint32_t *)(in + (size_t)(pass + 1) * pass_stride + (size_t)tune * tune_stride);
+#pragma unroll
+			for (int b = 0; b < NB; b++)
+#pragma unroll
+				for (int r = 0; r < 16; r++)
+					dn[b][r] = bufn[b * 4096 + tid + 256 * r];
+		}
 		// remove_dc, rtl_power.c:609-624 via 744-745 (L = 2*4096*NB int16, both halves complete)
 		for (int off = 32; off; off >>= 1) { si += __shfl_down(si, off); sq += __shfl_down(sq, off); }
 		__syncthreads();
@@ -238,7 +310,8 @@ __global__ __launch_bounds__(256) void k_pw_fft4096(
 				v[4 * c] = ta.x; v[4 * c + 1] = ta.y; v[4 * c + 2] = tb.x; v[4 * c + 3] = tb.y;
 			}
 			// stages 4-7: n = hi4<<8 | r<<4 | lo4
-			radix16_pass<7, false>(v, twiddle, base_b);
+			if (TWL) radix16_pass_lds(v, tl, ta_b);
+			else radix16_pass<7, false>(v, twiddle, base_b);
 			// transpose 2: next field is bits 3..0; row = bits 11..4
 #pragma unroll
 			for (int r = 0; r < 16; r++)
@@ -250,7 +323,8 @@ __global__ __launch_bounds__(256) void k_pw_fft4096(
 				v[4 * c] = t4.x; v[4 * c + 1] = t4.y; v[4 * c + 2] = t4.z; v[4 * c + 3] = t4.w;
 			}
 			// stages 8-11: n = tid<<4 | r
-			radix16_pass<3, false>(v, twiddle, base_c);
+			if (TWL) radix16_pass_lds(v, tl, ta_c);
+			else radix16_pass<3, false>(v, twiddle, base_c);
 			// real_conj + accumulate, rtl_power.c:664-668, 760-768; re^2+im^2 <= 2^31 fits u32
 #pragma unroll
 			for (int r = 0; r < 16; r++) {
@@ -286,12 +360,16 @@ __global__ __launch_bounds__(((1 << M) / 16 > 256) ? (1 << M) / 16 : 256) void k
 	constexpr int N = G::N, TPF = G::TPF, T = TPF > 256 ? TPF : 256, FPW = T / TPF;
 	constexpr bool DB = M <= 12;
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-	uint32_t *xa = lds, *xb = DB ? lds + T * G::ROW : lds;
-	i64 *red = (i64 *)(lds + (DB ? 2 : 1) * T * G::ROW);
+	uint32_t *xa = lds, *xb = DB ? lds + T * G::XROW : lds;
+	i64 *red = (i64 *)(lds + (DB ? 2 : 1) * T * G::XROW);
+	uint32_t *tl = (uint32_t *)(red + 32);                  // the permuted twiddle copy (fft_tw_fill), G::TW_WORDS dwords
 	const int tid = threadIdx.x, fid = tid / TPF;
 	const unsigned tq = tid % TPF;
 	const int tune = blockIdx.x;
 	const int p_begin = blockIdx.y * ppg, p_end = min(passes, p_begin + ppg);
+	fft_tw_fill<M>(tl, twiddle, tid, T);                   // ordered by the pass loop's first __syncthreads
+	unsigned ta[3][4];
+	fft_tw_addr_all<M>(tq, ta);
 	constexpr bool WREG = M <= 12;                         // 512- and 1024-thread workgroups are short of VGPRs: reload instead
 	constexpr bool ACCREG = M <= 13;                       // (a 1024-thread build would have no room for 16 int64 accumulators)
 	uint32_t wcoef[WREG ? 16 : 1];
@@ -343,7 +421,7 @@ __global__ __launch_bounds__(((1 << M) / 16 > 256) ? (1 << M) / 16 : 256) void k
 				}
 				v[r] = pw_pk_mul(pw_pk_sub(w, ave), wc);                       // window, rtl_power.c:749-758
 			}
-			fft_reg<M, DB>(v, tq, xa + fid * TPF * G::ROW, xb + fid * TPF * G::ROW, twiddle);
+			fft_reg<M, DB, true>(v, tq, xa + fid * TPF * G::XROW, xb + fid * TPF * G::XROW, twiddle, tl, ta);
 			if (live) {
 #pragma unroll
 				for (int r = 0; r < 16; r++) {
@@ -564,16 +642,46 @@ __global__ void k_pw_rms_apply(const i64 *__restrict__ t_in, const i64 *__restri
 // The reference takes FFT lengths up to 2^21 (rtl_power.c:485); beyond 2^15 a block no longer fits LDS, so the same
 // radix-2 network (bit-reversed load, rtl_power.c:275-290, then one launch per stage, 291-318) runs on a scratch copy
 // in HBM, many blocks side by side.  Correct and plain -- these lengths are for 1-Hz-class bins on a narrow range.
+// remove_dc's sums (rtl_power.c:609-624 via 744-745) of every (pass, tune) buffer, in front of the transform.  Round 4: a buffer is cut into
+// `slices` pieces, one workgroup each, 16-byte loads with four in flight per lane, int64 atomics into sums[2 * (pass * tunes + tune)]
+// (zeroed by the launcher), and k_pwb_dc_fin divides.  One workgroup per buffer with dword loads moved 0.64 TB/s and was HALF of the
+// N = 2^18 launch (420 of 790 us, rocprofv3).
 __global__ __launch_bounds__(256) void k_pwb_dc(const int16_t *__restrict__ in, size_t tune_stride, size_t pass_stride, int tunes,
-                                                int eff_len, int *__restrict__ dc)
+                                                int eff_len, int slices, i64 *__restrict__ sums)
 {
 	__shared__ i64 red[8];
-	const int tune = blockIdx.x, pass = blockIdx.y, tid = threadIdx.x;
+	const int pt = blockIdx.x / slices, sl = blockIdx.x - pt * slices, tid = threadIdx.x;
+	const int pass = pt / tunes, tune = pt - pass * tunes;
 	const uint32_t *buf = (const uint32_t *)(in + (size_t)pass * pass_stride + (size_t)tune * tune_stride);
 	const int L = eff_len;
-	const int ci = (L + 1) / 2, cq = L / 2;
+	const int ci = (L + 1) / 2, cq = L / 2;                              // complex samples whose I / Q half takes part
+	// slice: whole 16-byte vectors [v0, v1) of the buffer; the ragged end (ci not a multiple of 4, or an odd L) goes to the last slice, dword by dword
+	const int nv = cq / 4, per = (nv + slices - 1) / slices;
+	const int v0 = sl * per, v1 = min(nv, v0 + per);
 	i64 si = 0, sq = 0;
-	for (int c = tid; c < ci; c += 256) {
+	const bool aligned = (((size_t)buf) & 15) == 0;
+	if (aligned) {
+		const uint4 *b4 = reinterpret_cast<const uint4 *>(buf);
+		int v = v0 + tid;
+		for (; v + 768 < v1; v += 1024) {
+			const uint4 a = b4[v], b = b4[v + 256], c = b4[v + 512], d = b4[v + 768];
+			int i32 = 0, q32 = 0;                                        // 16 samples of int16: far from int32's range
+#define ACC4(VV) do { i32 = pw_dot((VV).x, 1u, i32); q32 = pw_dot((VV).x, 0x10000u, q32); i32 = pw_dot((VV).y, 1u, i32); q32 = pw_dot((VV).y, 0x10000u, q32); \
+			     i32 = pw_dot((VV).z, 1u, i32); q32 = pw_dot((VV).z, 0x10000u, q32); i32 = pw_dot((VV).w, 1u, i32); q32 = pw_dot((VV).w, 0x10000u, q32); } while (0)
+			ACC4(a); ACC4(b); ACC4(c); ACC4(d);
+			si += i32; sq += q32;
+		}
+		for (; v < v1; v += 256) {
+			const uint4 a = b4[v];
+			int i32 = 0, q32 = 0;
+			ACC4(a);
+#undef ACC4
+			si += i32; sq += q32;
+		}
+	}
+	const int c_lo = aligned ? ((sl == slices - 1) ? nv * 4 : ci) : (int)((i64)ci * sl / slices);
+	const int c_hi = aligned ? ci : (int)((i64)ci * (sl + 1) / slices);
+	for (int c = c_lo + tid; c < c_hi; c += 256) {
 		const uint32_t w = buf[c];
 		si += pw_lo(w);
 		if (c < cq) sq += pw_hi(w);
@@ -584,9 +692,34 @@ __global__ __launch_bounds__(256) void k_pwb_dc(const int16_t *__restrict__ in, 
 	if (tid == 0) {
 		si = red[0] + red[1] + red[2] + red[3];
 		sq = red[4] + red[5] + red[6] + red[7];
-		dc[2 * ((size_t)pass * tunes + tune)] = (int)(short)(si / (i64)L);                       // remove_dc, rtl_power.c:609-624
-		dc[2 * ((size_t)pass * tunes + tune) + 1] = (L > 1) ? (int)(short)(sq / (i64)(L - 1)) : 0;
+		atomicAdd((unsigned long long *)&sums[2 * (size_t)pt], (unsigned long long)si);
+		atomicAdd((unsigned long long *)&sums[2 * (size_t)pt + 1], (unsigned long long)sq);
 	}
+}
+
+__global__ void k_pwb_dc_fin(const i64 *__restrict__ sums, int n, int eff_len, int *__restrict__ dc)
+{
+	const int pt = blockIdx.x * blockDim.x + threadIdx.x;
+	if (pt >= n)
+		return;
+	const i64 L = eff_len;
+	dc[2 * pt] = (int)(short)(sums[2 * pt] / L);                                                // remove_dc, rtl_power.c:609-624
+	dc[2 * pt + 1] = (L > 1) ? (int)(short)(sums[2 * pt + 1] / (L - 1)) : 0;
+}
+
+// dc: 2 ints per (pass, tune), then -- 16-byte aligned -- 2 int64 per (pass, tune) of scratch for the sums (RXK_PW_DC_BYTES per pair)
+static void pwb_dc(hipStream_t s, const int16_t *in, size_t tune_stride, size_t pass_stride, int passes, int tunes, int eff_len, int *dc)
+{
+	const size_t n = (size_t)passes * tunes;
+	i64 *sums = (i64 *)(dc + ((2 * n + 3) & ~(size_t)3));
+	(void)hipMemsetAsync(sums, 0, n * 16, s);
+	// enough workgroups to fill the chip (about eight per CU), slices of at least 16 KiB
+	int slices = (int)((2048 + n - 1) / n);
+	const int max_slices = eff_len / 8192 > 0 ? eff_len / 8192 : 1;
+	if (slices > max_slices) slices = max_slices;
+	if (slices < 1) slices = 1;
+	hipLaunchKernelGGL(k_pwb_dc, dim3((unsigned)(n * slices)), dim3(256), 0, s, in, tune_stride, pass_stride, tunes, eff_len, slices, sums);
+	hipLaunchKernelGGL(k_pwb_dc_fin, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sums, (int)n, eff_len, dc);
 }
 
 // block q = (pass * tunes + tune) * nbpt + blk;  this launch covers blocks q0 .. q0+nq
@@ -712,17 +845,26 @@ __global__ __launch_bounds__(256) void k_pwm_head_mid(uint32_t *__restrict__ scr
 		x[(size_t)r << F] = v[r];
 }
 
-// the passes H .. P-1 of one thread's 16 values, an LDS transpose between two of them
-template <int M, int PASS>
-__device__ __forceinline__ void pwm_tail_passes(uint32_t (&v)[16], uint32_t *lds_t, const uint32_t *__restrict__ tw, unsigned tq, bool first)
+// the passes H .. P-1 of one thread's 16 values, an LDS transpose between two of them.  The thread's twiddles (15 per pass) do not
+// change from one block of the launch to the next: they are loaded ONCE, in front of the pass loop, into twr[PASS - H] (round 4; they
+// used to be 15 global loads per pass and block, waited for right behind each barrier)
+template <int M, int PASS, int H>
+__device__ __forceinline__ void pwm_tail_twiddles(uint32_t (&twr)[fft_geom<M>::P - H][15], const uint32_t *__restrict__ tw, unsigned tq)
+{
+	fft_tw_regs<M, PASS>(twr[PASS - H], tw, tq);
+	if constexpr (PASS + 1 < fft_geom<M>::P)
+		pwm_tail_twiddles<M, PASS + 1, H>(twr, tw, tq);
+}
+template <int M, int PASS, int H>
+__device__ __forceinline__ void pwm_tail_passes(uint32_t (&v)[16], uint32_t *lds, const uint32_t (&twr)[fft_geom<M>::P - H][15], unsigned tq, unsigned row0, bool first)
 {
 	typedef fft_geom<M> G;
 	if (!first)
 		__syncthreads();                                             // the transpose area: the reads of the pass before
-	fft_pass<M, PASS>(v, tw, tq);
+	fft_pass_regs<M, PASS>(v, twr[PASS - H]);
 	if constexpr (PASS + 1 < G::P) {
-		fft_exchange<M, PASS>(v, lds_t, tq);
-		pwm_tail_passes<M, PASS + 1>(v, lds_t, tw, tq, false);
+		fft_exchange<M, PASS>(v, lds, tq, row0);
+		pwm_tail_passes<M, PASS + 1, H>(v, lds, twr, tq, row0, false);
 	}
 }
 
@@ -738,12 +880,14 @@ __global__ __launch_bounds__(256) void k_pwm_tail(const uint32_t *__restrict__ s
 	typedef fft_geom<M> G;
 	constexpr int N = 1 << M, WPB = N / 4096, F = G::f(H);
 	static_assert(M - 4 * H <= 12 && H < G::P, "a sub-transform has to fit the workgroup");
-	__shared__ __attribute__((aligned(16))) uint32_t lds[256 * G::ROW];
+	__shared__ __attribute__((aligned(16))) uint32_t lds[256 * G::XROW];
 	const int tid = threadIdx.x;
 	const unsigned sg = blockIdx.x % WPB, tb = blockIdx.x / WPB;         // tb = tune * nbpt + blk
 	const unsigned tune = tb / (unsigned)nbpt, blk = tb - tune * (unsigned)nbpt;
 	const unsigned tq = sg * 256u + (unsigned)tid;                   // this thread's index in the whole transform's N/16
-	uint32_t *lds_t = lds - (size_t)(sg * 256u) * G::ROW;            // fft_exchange addresses rows by tq: this workgroup's are sg*256 ..
+	const unsigned row0 = sg * 256u;                                 // fft_exchange addresses rows by tq: this workgroup's are row0 ..
+	uint32_t twr[G::P - H][15];
+	pwm_tail_twiddles<M, H, H>(twr, twiddle, tq);
 	i64 acc[16];
 #pragma unroll
 	for (int r = 0; r < 16; r++)
@@ -771,7 +915,7 @@ __global__ __launch_bounds__(256) void k_pwm_tail(const uint32_t *__restrict__ s
 				nxt[x] = src[(size_t)x << F];
 		}
 		__syncthreads();                                             // the previous transform's reads of the transpose area
-		pwm_tail_passes<M, H>(v, lds_t, twiddle, tq, true);
+		pwm_tail_passes<M, H, H>(v, lds, twr, tq, row0, true);
 #pragma unroll
 		for (int r = 0; r < 16; r++) {
 			const i64 pw = (i64)pw_norm(v[r]);
@@ -830,7 +974,7 @@ extern "C" int rxk_pw_fft_mid(void *stream, const int16_t *in, size_t tune_strid
 	if (bin_e < 14 || bin_e > 21 || !nbpt || (size_t)eff_len % (2 * n) || cap_blocks < per_pass)
 		return -1;
 	const uint32_t *tw2 = twiddle + (n >> 1);                        // the doubled half of rxgpu_twiddle_table (bfly_pk)
-	hipLaunchKernelGGL(k_pwb_dc, dim3((unsigned)tunes, (unsigned)passes), dim3(256), 0, s, in, tune_stride, pass_stride, tunes, eff_len, dc);
+	pwb_dc(s, in, tune_stride, pass_stride, passes, tunes, eff_len, dc);
 	const int max_np = (int)(cap_blocks / per_pass);
 	for (int p0 = 0; p0 < passes; p0 += max_np) {
 		const int np = passes - p0 < max_np ? passes - p0 : max_np;
@@ -877,7 +1021,7 @@ extern "C" int rxk_pw_fft_big(void *stream, const int16_t *in, size_t tune_strid
 	const size_t n = (size_t)1 << bin_e;
 	const int nbpt = (int)(((size_t)eff_len + 2 * n - 1) / (2 * n));
 	const size_t total = (size_t)passes * (size_t)tunes * (size_t)nbpt;
-	hipLaunchKernelGGL(k_pwb_dc, dim3((unsigned)tunes, (unsigned)passes), dim3(256), 0, s, in, tune_stride, pass_stride, tunes, eff_len, dc);
+	pwb_dc(s, in, tune_stride, pass_stride, passes, tunes, eff_len, dc);
 	for (size_t q0 = 0; q0 < total; q0 += cap_blocks) {
 		const size_t nq = total - q0 < cap_blocks ? total - q0 : cap_blocks;
 		const unsigned g_full = (unsigned)((nq * n + 255) / 256), g_half = (unsigned)((nq * (n / 2) + 255) / 256);
@@ -906,8 +1050,12 @@ extern "C" int rxk_pw_fft(void *stream, const int16_t *in, size_t tune_stride, s
 	             (size_t)groups * tunes * fpw * (size_t)n <= partial_cap) ? (i64 *)partial : nullptr;
 	if (k4096) {
 		const int nb = eff_len / 8192;
-#define GO4K(NB) do { if (peak_hold) hipLaunchKernelGGL((k_pw_fft4096<NB, true>), grid, dim3(256), 0, s, in, tune_stride, pass_stride, passes, window, twiddle + 2048, passes_per_group, (i64 *)avg, part); \
-		else hipLaunchKernelGGL((k_pw_fft4096<NB, false>), grid, dim3(256), 0, s, in, tune_stride, pass_stride, passes, window, twiddle + 2048, passes_per_group, (i64 *)avg, part); } while (0)
+#define GO4K_(NB, TWL) do { if (peak_hold) hipLaunchKernelGGL((k_pw_fft4096<NB, true, TWL>), grid, dim3(256), 0, s, in, tune_stride, pass_stride, passes, window, twiddle + 2048, passes_per_group, (i64 *)avg, part); \
+		else hipLaunchKernelGGL((k_pw_fft4096<NB, false, TWL>), grid, dim3(256), 0, s, in, tune_stride, pass_stride, passes, window, twiddle + 2048, passes_per_group, (i64 *)avg, part); } while (0)
+	/* $RXGPU_FFT_TW=global: the twiddles of stages 4-11 through the vector cache (rounds 1-3) instead of the workgroup's LDS copy (A/B) */
+	const char *tw_knob = rxgpu_knob("RXGPU_FFT_TW");
+	const bool tw_global = tw_knob && tw_knob[0] == 'g';
+#define GO4K(NB) do { if (tw_global) GO4K_(NB, false); else GO4K_(NB, true); } while (0)
 		if (nb == 1) GO4K(1); else if (nb == 2) GO4K(2); else GO4K(4);
 #undef GO4K
 		if (part)
@@ -920,7 +1068,7 @@ extern "C" int rxk_pw_fft(void *stream, const int16_t *in, size_t tune_stride, s
 		 * VGPRs per lane, the transform wants ~200, and the spilling build ran 3.3x slower than the LDS radix-2 kernel below */
 		const int nb_total = eff_len / (2 * n);
 		const int T = (n / 16 > 256) ? n / 16 : 256;
-		const size_t lds_bytes = (size_t)(bin_e <= 12 ? 2 : 1) * T * 20 * 4 + 32 * 8;
+		const size_t lds_bytes = (size_t)(bin_e <= 12 ? 2 : 1) * T * 21 * 4 + 32 * 8 + (size_t)8 * ((n >> 4) + 8) * 4;   /* transposes (XROW), red, twiddle copy */
 #define GOR(MM) do { \
 		if (lds_bytes > 64 * 1024) { \
 			(void)hipFuncSetAttribute((const void *)k_pw_fftR<MM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \

@@ -448,7 +448,8 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 		if (s->big_dc_cap < (size_t)passes * (size_t)tunes) {
 			hipFree(s->big_dc);
 			s->big_dc = NULL; s->big_dc_cap = 0;
-			RX_HIP(hipMalloc((void **)&s->big_dc, (size_t)passes * (size_t)tunes * 8));
+			/* 2 ints per (pass, tune), then the int64 sums the reduction accumulates (power_kernels.hip pwb_dc) */
+			RX_HIP(hipMalloc((void **)&s->big_dc, (size_t)passes * (size_t)tunes * 24 + 64));
 			s->big_dc_cap = (size_t)passes * (size_t)tunes;
 		}
 		if (mid) {
