@@ -321,7 +321,8 @@ def hoist(result, parity_all, world):
                                       "traffic_over_algorithmic": (r["traffic"] / r["algorithmic_bytes_per_launch"]) if r.get("traffic") else None,
                                       "parity_ok": (ch.get("parity") or {}).get("parity_ok"), "parity_checker": (ch.get("parity") or {}).get("parity_checker")}
     for label, v in ((result.get("sdr_convert") or {}).get("legs") or {}).items():
-        legs["rx_sdr " + label] = {"bound": "hbm", "frac": v["frac_of_hbm_peak"], "GBs": v["GB/s"], "parity_ok": (result["sdr_convert"]).get("parity_ok")}
+        legs["rx_sdr " + label] = {"bound": "hbm", "frac": v["frac_of_hbm_peak"], "GBs": v["GB/s"], "frac_of_box_ceiling": v.get("frac_of_box_ceiling"),
+                                   "parity_ok": (result["sdr_convert"]).get("parity_ok")}
     hf = (result.get("host_fed") or {}).get("legs") or {}
     for label, v in hf.items():
         legs["rx_fm host-fed " + label] = {"bound": "pcie", "frac": v["frac_of_pcie"], "GS_per_s": v["GS/s"],
@@ -415,6 +416,17 @@ def main():
 
     result = {}
     parity_all = {}            # leg -> verdict of its check against the CPU reference at bench size
+
+    # What THIS box's HBM gives plain streams in the access shapes of the HBM-bound kernels, arithmetic taken out (rxgpu_diag_stream_rate:
+    # non-temporal 16-byte pieces, grid-stride, two in flight per lane): the boxes of the pool differ by +-4 % on pure reads and by more on
+    # mixed read/write traffic, so every HBM-bound leg is also printed as a fraction of the ceiling measured in the same process.
+    def box_rate(mode, units=1 << 26, reps=5):
+        g = C.c_double(0)
+        R.check(L.rxgpu_diag_stream_rate(mode, units, reps, C.byref(g)))
+        return g.value
+    box = {"read_only_GBs": box_rate(0), "copy_1_1_GBs": box_rate(1), "expand_1_2_GBs": box_rate(2, 1 << 27), "shrink_2_1_GBs": box_rate(3),
+           "read_only_grid_stride_loop_GBs": box_rate(4),
+           "how": "rxgpu_diag_stream_rate: 1 GiB read per launch, 5 launches, hipEvents; read + written bytes"}
 
     # ------------------------------------------------------------------ rx_fm (headline)
     if args.workload in ("both", "rx_fm"):
@@ -626,6 +638,7 @@ def main():
             "host_fed": host_fed,
             "roofline": {"bound": "hbm", "kernel": "k_fm_decimate (F0+F1+F2)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "box_ceilings": box, "frac_of_box_read_only": achieved / box["read_only_GBs"],
                          "algorithmic_bytes_per_launch": 4 * T, "avg_launch_ms": (ms / launches) if launches else None},
         })
         result.update(parity)
@@ -1002,12 +1015,14 @@ def main():
             ms, launches = prof("sdr_convert")
             nbytes = L.rxgpu_sdr_in_bytes(conv, n_elems) + L.rxgpu_sdr_out_bytes(conv, n_elems)
             gbs = nbytes / (ms / launches * 1e-3) / 1e9 if launches else 0.0
+            ceil_key = {"CU8": "shrink_2_1_GBs", "CS8": "shrink_2_1_GBs", "CF32": "expand_1_2_GBs", "CS16": "copy_1_1_GBs"}[fmt]
             legs[("CS12->" if fmt == "CS16" else "CS16->") + fmt] = {
                 "MSample/s": n_elems / (ms / launches * 1e-3) / 1e6 if launches else 0.0,
-                "GB/s": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "bytes_per_element": nbytes / n_elems}
+                "GB/s": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "bytes_per_element": nbytes / n_elems,
+                "box_ceiling_GBs": box[ceil_key], "box_ceiling_shape": ceil_key, "frac_of_box_ceiling": gbs / box[ceil_key]}
             del out
         result["sdr_convert"] = {"metric": "rx_sdr -F output conversions, complex MSample/s and HBM GB/s (read + write), 2^28 elements per launch",
-                                 "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "legs": legs}
+                                 "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "legs": legs, "box_ceilings": box}
         if not args.no_parity:
             result["sdr_convert"]["parity_ok"] = bool(sdr_same)
             parity_all["sdr_convert"] = bool(sdr_same)

@@ -55,6 +55,11 @@ void rxgpu_knobs_reload(void);
 int rxgpu_pin(void *ptr, size_t bytes);
 int rxgpu_unpin(void *ptr);
 
+/* Diagnostics: GB/s (read + written bytes) this box's HBM gives a plain stream in the access shapes of the HBM-bound kernels, arithmetic
+ * taken out -- mode 0: 16 B read per unit, nothing written; 1: 16 B read, 16 B written; 2: 8 B read, 16 B written (CS16->CF32); 3: 16 B
+ * read, 8 B written (CS16->CS8); 4: 16 B read through the round-3 grid-stride loop (what the span order replaced).  bench.py prints every HBM-bound leg beside the ceiling of the box it ran on. */
+int rxgpu_diag_stream_rate(int mode, size_t units, int reps, double *gbs);
+
 /* Per-kernel device timing with hipEvents on the launch stream.  level 1 brackets only the
  * kernels that dominate each path ("fm_decimate", "fm_fifth", "pw_fft"), level 2 every
  * stage ("fm_disc", "fm_deemph", "fm_resample", "fm_droop", "pw_downsample", "pw_rms", ...);

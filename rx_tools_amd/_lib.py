@@ -16,7 +16,7 @@ _lib = None
 EXPORTS = [
     "rxgpu_init", "rxgpu_shutdown", "rxgpu_device_count", "rxgpu_last_error", "rxgpu_stream", "rxgpu_sync", "rxgpu_knobs_reload",
     "rxgpu_pin", "rxgpu_unpin",
-    "rxgpu_prof_enable", "rxgpu_prof_reset", "rxgpu_prof_get",
+    "rxgpu_prof_enable", "rxgpu_prof_reset", "rxgpu_prof_get", "rxgpu_diag_stream_rate",
     "rxgpu_full_demod", "rxgpu_callback", "rxgpu_deemph_state", "rxgpu_set_demod_functions", "rxgpu_dropin_invalidate", "rxgpu_dropin_block_rms", "rxgpu_dropin_release", "rxgpu_dropin_pin", "rxgpu_dropin_unpin", "rxgpu_dropin_timing",
     "rxgpu_fm_params_init", "rxgpu_fm_plan_settings",
     "rxgpu_fm_stream_create", "rxgpu_fm_stream_destroy", "rxgpu_fm_stream_set_carry", "rxgpu_fm_stream_get_carry",
@@ -56,6 +56,7 @@ def lib():
         L.rxgpu_init.argtypes = [C.c_int]
         L.rxgpu_knobs_reload.restype = None
         L.rxgpu_prof_enable.argtypes = [C.c_int]
+        L.rxgpu_diag_stream_rate.argtypes = [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
         L.rxgpu_fm_stream_host_fixups.restype = C.c_long
         L.rxgpu_fm_stream_host_fixups.argtypes = [C.c_void_p]
         L.rxgpu_prof_get.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_long)]

@@ -403,10 +403,10 @@ __device__ __forceinline__ uint32_t dsm_window(const uint32_t *sm, int r, int ds
 
 // span of a workgroup in samples: a multiple of 256 * ds (64 * ds for ds > 18) not above 4608, so that every span holds the same
 // whole number of windows -- whatever the phase p0 -- and the four waves get whole 64-output turns of them
-static inline unsigned dsm_span(int ds)
+static inline unsigned dsm_span(int ds, unsigned span_max = DSM_SPAN_MAX)
 {
 	const unsigned unit = (ds <= 18 ? 256u : 64u) * (unsigned)ds;
-	return (DSM_SPAN_MAX / unit) * unit;
+	return (span_max / unit) * unit;
 }
 
 // NR: rounds of 256 vectors that cover the staged range (4 or 5)
@@ -1783,20 +1783,36 @@ __global__ __launch_bounds__(256) void k_fm_deemph_apply_rs_t(
 		int N = de_state(start[c], h);
 		const uint4 *row = tile_unit(pcm_t, c, CHL2);
 		const int nu = n >> 3;
-		uint4 w = row[0];
-		for (int u = 0; u < nu; u++) {
-			const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-			if (u + 1 < UPC)
-				w = row[(size_t)(u + 1) * 64];
+		// FOUR units on their way per lane (round 4; one before): eight samples are ~70 dependent instructions, a load under the next run's
+		// decimator takes several times that, and the waves that could cover it are exactly what the two kernels compete for.  The chunk's
+		// units all lie inside the tile (loads past a short last chunk's end read allocated, unused samples).
+		uint4 q[4];
 #pragma unroll
-			for (int k = 0; k < 4; k++) {
-				de_step<0>(ww[k], N, magic, -64);
-				lpr_step(N, nK, acc, p, slot, thr, slow, d_emit);
-				de_step<1>(ww[k], N, magic, -64);
-				lpr_step(N, nK, acc, p, slot, thr, slow, d_emit);
+		for (int k = 0; k < 4; k++)
+			q[k] = row[(size_t)k * 64];
+		uint4 w = q[0];
+		for (int u0 = 0; u0 < nu; u0 += 4) {
+#pragma unroll
+			for (int k4 = 0; k4 < 4; k4++) {
+				const int u = u0 + k4;
+				w = q[k4];
+				if (u + 4 < UPC)
+					q[k4] = row[(size_t)(u + 4) * 64];
+				if (u < nu) {
+					const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+					for (int k = 0; k < 4; k++) {
+						de_step<0>(ww[k], N, magic, -64);
+						lpr_step(N, nK, acc, p, slot, thr, slow, d_emit);
+						de_step<1>(ww[k], N, magic, -64);
+						lpr_step(N, nK, acc, p, slot, thr, slow, d_emit);
+					}
+				}
 			}
 		}
 		if (n & 7) {
+			// the ragged end of the run (its last chunk only): unit nu once more, plainly
+			w = row[(size_t)nu * 64];
 			const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
 			for (int k = 0; k < (n & 7); k++) {
 				if (k & 1) de_step<1>(ww[k >> 1], N, magic, -64); else de_step<0>(ww[k >> 1], N, magic, -64);
@@ -3138,7 +3154,7 @@ static inline int ch_wpg(int n_channels)
 // FUSED: also fm_demod (-A fast) for every window but the workgroup's first, straight from the LDS copy of the bins; then
 // only the entries k_ch_demod(sparse) reads are stored in chan_lp (each group's first and last window).  Needs the
 // callback blocks to be whole groups of CH_WPG windows, so that a block's first (libm) window is a group's first.
-template <int M, bool FUSED>
+template <int M, bool FUSED, bool TWL = true>
 __global__ __launch_bounds__(256) void k_ch_fftR(const uint32_t *__restrict__ iq, u64 total_windows,
                                                  const uint32_t *__restrict__ twiddle, int first_bin, int n_channels,
                                                  uint32_t *__restrict__ chan_lp, int16_t *__restrict__ out, u64 out_stride,
@@ -3180,7 +3196,9 @@ __global__ __launch_bounds__(256) void k_ch_fftR(const uint32_t *__restrict__ iq
 			for (int r = 0; r < 16; r++)
 				nxt[r] = w < total_windows ? iq[(w << M) + tq + r * TPF] : 0u;
 		}
-		fft_reg<M, !WAVE, true>(v, tq, xa + fid * TPF * G::XROW, xb + fid * TPF * G::XROW, twiddle, tl, ta);
+		fft_reg<M, !WAVE, TWL>(v, tq, xa + fid * TPF * G::XROW, xb + fid * TPF * G::XROW, twiddle, tl, ta);
+		// (hoisting the slot arithmetic -- a bit reversal, a multiply, a compare per register -- out of the window loop, with a wave-uniform
+		// skip of registers nobody needs, measured 0-3 % SLOWER in one process: 16 more live VGPRs for nothing the scheduler could not hide)
 #pragma unroll
 		for (int r = 0; r < 16; r++) {
 			const unsigned bin = __brev((tq << 4) | (unsigned)r) >> (32 - M);
@@ -3420,7 +3438,13 @@ extern "C" int rxk_fm_decimate(void *stream, const int16_t *iq, u64 T, int ds, i
 extern "C" int rxk_fm_decimate_small(void *stream, const int16_t *iq, u64 T, int ds, int p0, int rotate, unsigned long long M, int16_t *pcm,
                                      int pcm_chl2)
 {
-	const unsigned span = dsm_span(ds);
+	/* $RXGPU_EXP0=6400 (ds 5, 6): longer spans -- at ds = 6 a span's 1024 outputs are eight whole 128-sample chunks of the tiled pcm layout, the
+	 * sixteen runs a workgroup writes are then whole 128-byte lines (96-byte runs otherwise); A/B */
+	const char *smx = rxgpu_knob("RXGPU_EXP0");
+	/* ds = 5 (BASELINE configs[0], 256-sample chunks) takes 6400 by default: +3 % on the pipelined step, nothing at ds = 6 (A/B, profiles/README.md); 0 keeps 4608 */
+	const unsigned span_max = smx ? ((atoi(smx) > DSM_SPAN_MAX && atoi(smx) <= 6400 && (ds == 5 || ds == 6)) ? (unsigned)atoi(smx) : DSM_SPAN_MAX)
+	                              : (ds == 5 ? 6400u : DSM_SPAN_MAX);
+	const unsigned span = dsm_span(ds, span_max);
 	const unsigned grid = ((unsigned)((T + span - 1) / span) + 7u) & ~7u;
 	/* the staged span, padded to a fifth of the CU's LDS: five workgroups per CU (20 waves) run the kernel as fast as eight do,
 	 * and the audio stages of the previous run -- long, latency-bound waves on the other stream -- always find slots beside them
@@ -3434,6 +3458,13 @@ extern "C" int rxk_fm_decimate_small(void *stream, const int16_t *iq, u64 T, int
 	const bool four = (span + 2 * DSM_HALO) / 4 <= 1024;
 #define GO2(RT, K) do { if (four) hipLaunchKernelGGL((k_fm_decimate_small<RT, K, 4>), dim3(grid), dim3(256), lds, s, p, T, ds, p0, M, pcm, pcm_chl2, span, span / (unsigned)ds); \
 		else hipLaunchKernelGGL((k_fm_decimate_small<RT, K, 5>), dim3(grid), dim3(256), lds, s, p, T, ds, p0, M, pcm, pcm_chl2, span, span / (unsigned)ds); } while (0)
+	if (span > DSM_SPAN_MAX) {
+		if (rotate) { if (ds == 5) hipLaunchKernelGGL((k_fm_decimate_small<true, 5, 7>), dim3(grid), dim3(256), lds, s, p, T, ds, p0, M, pcm, pcm_chl2, span, span / (unsigned)ds);
+		              else hipLaunchKernelGGL((k_fm_decimate_small<true, 6, 7>), dim3(grid), dim3(256), lds, s, p, T, ds, p0, M, pcm, pcm_chl2, span, span / (unsigned)ds); }
+		else { if (ds == 5) hipLaunchKernelGGL((k_fm_decimate_small<false, 5, 7>), dim3(grid), dim3(256), lds, s, p, T, ds, p0, M, pcm, pcm_chl2, span, span / (unsigned)ds);
+		       else hipLaunchKernelGGL((k_fm_decimate_small<false, 6, 7>), dim3(grid), dim3(256), lds, s, p, T, ds, p0, M, pcm, pcm_chl2, span, span / (unsigned)ds); }
+		LAUNCH_RET();
+	}
 #define GO(RT) do { switch (ds) { case 4: GO2(RT, 4); break; case 5: GO2(RT, 5); break; case 6: GO2(RT, 6); break; \
 		case 7: GO2(RT, 7); break; case 8: GO2(RT, 8); break; default: GO2(RT, 0); break; } } while (0)
 	if (rotate) GO(true); else GO(false);
@@ -3972,15 +4003,20 @@ extern "C" int rxk_ch_fft(void *stream, const int16_t *iq, u64 total_windows, in
 		const unsigned grid = (unsigned)((total_windows + CH_WPG - 1) / CH_WPG);
 		hipStream_t s = (hipStream_t)stream;
 		const uint32_t *p = (const uint32_t *)iq;
-#define GOF(MM, FU) do { if (shm > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_ch_fftR<MM, FU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
-		hipLaunchKernelGGL((k_ch_fftR<MM, FU>), dim3(grid), dim3(256), shm, s, p, total_windows, twiddle + (1 << (MM - 1)), first_bin, n_channels, chan_lp, \
+#define GOF_(MM, FU, TW) do { if (shm > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_ch_fftR<MM, FU, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+		hipLaunchKernelGGL((k_ch_fftR<MM, FU, TW>), dim3(grid), dim3(256), shm, s, p, total_windows, twiddle + (1 << (MM - 1)), first_bin, n_channels, chan_lp, \
 		                   out, out_stride, pre_out, CH_WPG); } while (0)
+		/* A/B (N = 1024 only): $RXGPU_FFT_TW=global -- the twiddles of stages 4.. through the vector cache instead of the workgroup's LDS copy */
+		const char *twk = rxgpu_knob("RXGPU_FFT_TW");
+		const bool ab_tw = bin_e == 10 && twk && twk[0] == 'g';
+#define GOF(MM, FU) do { if (MM == 10 && ab_tw) GOF_(10, FU, false); else GOF_(MM, FU, true); } while (0)
 #define GOC(MM) do { if (fused) GOF(MM, true); else GOF(MM, false); } while (0)
 		switch (bin_e) {
 		case 8: GOC(8); break; case 9: GOC(9); break; case 10: GOC(10); break; case 11: GOC(11); break; default: GOC(12); break;
 		}
 #undef GOC
 #undef GOF
+#undef GOF_
 		LAUNCH_RET();
 	}
 	int wpg = bin_e >= 13 ? 1 : (8192 >> bin_e);

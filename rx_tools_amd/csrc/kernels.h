@@ -299,6 +299,9 @@ int rxk_sdr_cs16_to_8(void *stream, const int16_t *in, unsigned long long n16, i
 int rxk_sdr_cs16_to_cf32(void *stream, const int16_t *in, unsigned long long n16, float *out);
 int rxk_sdr_cs12_to_cs16(void *stream, const uint8_t *in, unsigned long long n_elems, int16_t *out);
 
+/* diagnostics: the converters' loop with the arithmetic taken out (sdr_kernels.hip k_diag_stream); units of 16 B read (8 B for mode 2) */
+int rxk_diag_stream(void *stream, int mode, const void *in, unsigned long long units, void *out);
+
 #ifdef __cplusplus
 }
 #endif

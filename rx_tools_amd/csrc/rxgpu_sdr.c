@@ -120,3 +120,41 @@ void rxgpu_wav_header(int rate, int raw_mode, unsigned char out[44])
 	out[34] = 0x10; out[35] = 0;                                   /* bits per channel */
 	memcpy(out + 36, "data\xFF\xFF\xFF\xFF", 8);
 }
+
+/* What this box's HBM gives a plain stream in the converters' access shapes (no arithmetic): GB/s of read + written bytes.  The pool's
+ * boxes differ by several per cent on pure reads and by more on mixed traffic; bench.py reports every HBM-bound leg
+ * beside the ceiling measured in the same process. */
+int rxgpu_diag_stream_rate(int mode, size_t units, int reps, double *gbs)
+{
+	int rc;
+	if (mode < 0 || mode > 4 || !units || reps < 1 || !gbs)
+		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_diag_stream_rate: bad arguments");
+	if ((rc = rxgpu_ensure_init()) != RXGPU_OK)
+		return rc;
+	const size_t in_b = units * (mode == 2 ? 8 : 16), out_b = (mode == 0 || mode == 4) ? 64 : units * (mode == 3 ? 8 : 16);
+	void *d_in = NULL, *d_out = NULL;
+	hipEvent_t e0 = NULL, e1 = NULL;
+	hipStream_t st = rxgpu_hip_stream();
+	if (hipMalloc(&d_in, in_b) != hipSuccess || hipMalloc(&d_out, out_b) != hipSuccess ||
+	    hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+		hipFree(d_in); hipFree(d_out);
+		if (e0) hipEventDestroy(e0);
+		if (e1) hipEventDestroy(e1);
+		return rxgpu_fail(RXGPU_ENOMEM, "rxgpu_diag_stream_rate: allocation failed");
+	}
+	hipMemsetAsync(d_in, 0x5a, in_b, st);
+	rc = rxk_diag_stream(st, mode, d_in, units, d_out);                 /* warm */
+	hipEventRecord(e0, st);
+	for (int i = 0; i < reps && !rc; i++)
+		rc = rxk_diag_stream(st, mode, d_in, units, d_out);
+	hipEventRecord(e1, st);
+	float ms = 0;
+	if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || ms <= 0)
+		rc = rc ? rc : -1;
+	hipFree(d_in); hipFree(d_out);
+	hipEventDestroy(e0); hipEventDestroy(e1);
+	if (rc)
+		return rxgpu_fail(RXGPU_ENODEV, "rxgpu_diag_stream_rate: launch failed");
+	*gbs = (double)(in_b + ((mode == 0 || mode == 4) ? 0 : out_b)) * reps / (ms * 1e-3) / 1e9;
+	return RXGPU_OK;
+}

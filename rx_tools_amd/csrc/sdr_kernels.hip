@@ -57,25 +57,50 @@ __device__ __forceinline__ uint32_t sdr_pack4(uint32_t a, uint32_t b)
 
 // Every kernel below gives consecutive lanes consecutive pieces of BOTH streams: a wave instruction then reads or writes one
 // contiguous run (1 KiB for 16-byte pieces).  The first versions gave a thread 32-64 contiguous bytes of its own, i.e. two to four
-// instructions each touching every other (third, fourth) 16-byte piece of a 2-4 KiB window: 3.3-5.3 TB/s against a copy
-// ceiling of 6.3.
+// instructions each touching every other (third, fourth) 16-byte piece of a 2-4 KiB window: 3.3-5.3 TB/s.
+//
+// Round 4: spans instead of a grid-stride loop.  A workgroup owns SDR_SPAN consecutive units (16 per thread: eight loads in flight, twice),
+// and workgroup b -- which the hardware places on XCD b mod 8 -- takes span (b mod 8) * (grid / 8) + b / 8: every XCD streams one
+// contiguous eighth of the capture, like the decimators (fm_kernels.hip).  The grid-stride form had a lane's two pieces in flight a
+// whole grid apart and neighbouring workgroups on different XCDs: the loop alone, arithmetic taken out (rxgpu_diag_stream_rate), read
+// 5.8 TB/s where the span order reads 7.2 on the same box.
+#define SDR_SPAN 4096
 
-// n16 int16 in, n16 bytes out; one thread per 8 values (16 bytes in, 8 bytes out), two units in flight
+// the span this workgroup owns (XCD-contiguous order); false: past the end (the grid is rounded up to a multiple of 8)
+__device__ __forceinline__ bool sdr_span(u64 units, u64 &first)
+{
+	const unsigned per = gridDim.x >> 3;
+	const u64 wg = (u64)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+	first = wg * SDR_SPAN;
+	return first < units;
+}
+
+// n16 int16 in, n16 bytes out; a unit = 8 values (16 bytes in, 8 bytes out)
 template <bool UNSIGNED>
 __global__ __launch_bounds__(256) void k_sdr_cs16_to_8(const int16_t *__restrict__ in, u64 n16, uint8_t *__restrict__ out)
 {
 	const u64 units = n16 >> 3;
-	const u64 stride = (u64)gridDim.x * blockDim.x;
-	for (u64 u = (u64)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += 2 * stride) {
-		const u64 u2 = u + stride;
-		const bool two = u2 < units;
-		const u32x4 a = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(in) + u);
-		const u32x4 b = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(in) + (two ? u2 : u));
-		const u32x2 oa = {sdr_pack4<UNSIGNED>(a.x, a.y), sdr_pack4<UNSIGNED>(a.z, a.w)};
-		const u32x2 ob = {sdr_pack4<UNSIGNED>(b.x, b.y), sdr_pack4<UNSIGNED>(b.z, b.w)};
-		__builtin_nontemporal_store(oa, reinterpret_cast<u32x2 *>(out) + u);
-		if (two)
-			__builtin_nontemporal_store(ob, reinterpret_cast<u32x2 *>(out) + u2);
+	u64 first;
+	if (sdr_span(units, first)) {
+		const u32x4 *src = reinterpret_cast<const u32x4 *>(in) + first + threadIdx.x;
+		u32x2 *dst = reinterpret_cast<u32x2 *>(out) + first + threadIdx.x;
+		const u64 left = units - first;
+#pragma unroll
+		for (int h = 0; h < 2; h++) {
+			u32x4 v[8];
+#pragma unroll
+			for (int k = 0; k < 8; k++) {
+				const unsigned o = (h * 8 + k) * 256;
+				v[k] = (o + threadIdx.x < left) ? __builtin_nontemporal_load(src + o) : (u32x4)(0u);
+			}
+#pragma unroll
+			for (int k = 0; k < 8; k++) {
+				const unsigned o = (h * 8 + k) * 256;
+				const u32x2 r = {sdr_pack4<UNSIGNED>(v[k].x, v[k].y), sdr_pack4<UNSIGNED>(v[k].z, v[k].w)};
+				if (o + threadIdx.x < left)
+					__builtin_nontemporal_store(r, dst + o);
+			}
+		}
 	}
 	if (blockIdx.x == 0 && threadIdx.x < (n16 & 7)) {                  // ragged end
 		const u64 i = (units << 3) + threadIdx.x;
@@ -83,21 +108,31 @@ __global__ __launch_bounds__(256) void k_sdr_cs16_to_8(const int16_t *__restrict
 	}
 }
 
-// n16 int16 in, n16 floats out; one thread per 4 values (8 bytes in, 16 bytes out), two units in flight
+// n16 int16 in, n16 floats out; a unit = 4 values (8 bytes in, 16 bytes out)
 __global__ __launch_bounds__(256) void k_sdr_cs16_to_cf32(const int16_t *__restrict__ in, u64 n16, float *__restrict__ out)
 {
 	const u64 units = n16 >> 2;
-	const u64 stride = (u64)gridDim.x * blockDim.x;
-	for (u64 u = (u64)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += 2 * stride) {
-		const u64 u2 = u + stride;
-		const bool two = u2 < units;
-		const u32x2 a = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(in) + u);
-		const u32x2 b = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(in) + (two ? u2 : u));
-		const f32x4 oa = {sdr_unit((int)(short)(a.x & 0xffffu)), sdr_unit((int)a.x >> 16), sdr_unit((int)(short)(a.y & 0xffffu)), sdr_unit((int)a.y >> 16)};
-		const f32x4 ob = {sdr_unit((int)(short)(b.x & 0xffffu)), sdr_unit((int)b.x >> 16), sdr_unit((int)(short)(b.y & 0xffffu)), sdr_unit((int)b.y >> 16)};
-		__builtin_nontemporal_store(oa, reinterpret_cast<f32x4 *>(out) + u);
-		if (two)
-			__builtin_nontemporal_store(ob, reinterpret_cast<f32x4 *>(out) + u2);
+	u64 first;
+	if (sdr_span(units, first)) {
+		const u32x2 *src = reinterpret_cast<const u32x2 *>(in) + first + threadIdx.x;
+		f32x4 *dst = reinterpret_cast<f32x4 *>(out) + first + threadIdx.x;
+		const u64 left = units - first;
+#pragma unroll
+		for (int h = 0; h < 2; h++) {
+			u32x2 v[8];
+#pragma unroll
+			for (int k = 0; k < 8; k++) {
+				const unsigned o = (h * 8 + k) * 256;
+				v[k] = (o + threadIdx.x < left) ? __builtin_nontemporal_load(src + o) : (u32x2)(0u);
+			}
+#pragma unroll
+			for (int k = 0; k < 8; k++) {
+				const unsigned o = (h * 8 + k) * 256;
+				const f32x4 r = {sdr_unit((int)(short)(v[k].x & 0xffffu)), sdr_unit((int)v[k].x >> 16), sdr_unit((int)(short)(v[k].y & 0xffffu)), sdr_unit((int)v[k].y >> 16)};
+				if (o + threadIdx.x < left)
+					__builtin_nontemporal_store(r, dst + o);
+			}
+		}
 	}
 	if (blockIdx.x == 0 && threadIdx.x < (n16 & 3)) {
 		const u64 i = (units << 2) + threadIdx.x;
@@ -111,28 +146,43 @@ __device__ __forceinline__ uint32_t sdr_cs12(uint32_t b0, uint32_t b1, uint32_t 
 	return (((b1 << 12) | (b0 << 4)) & 0xffffu) | (((b2 << 8) | (b1 & 0xf0u)) << 16);
 }
 
-// n_elems elements of 3 bytes in, n_elems (I,Q) int16 pairs out; one thread per 4 elements (12 B -> 16 B), two units in flight
+// n_elems elements of 3 bytes in, n_elems (I,Q) int16 pairs out; a unit = 4 elements (12 B -> 16 B)
 __global__ __launch_bounds__(256) void k_sdr_cs12_to_cs16(const uint8_t *__restrict__ in, u64 n_elems, uint32_t *__restrict__ out)
 {
 	const u64 units = n_elems >> 2;
-	const u64 stride = (u64)gridDim.x * blockDim.x;
-	const uint32_t *src = reinterpret_cast<const uint32_t *>(in);
-	for (u64 u = (u64)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += 2 * stride) {
-		const u64 u2 = u + stride;
-		const bool two = u2 < units;
-		uint32_t w[2][3];
-#pragma unroll
-		for (int k = 0; k < 3; k++) {                                  // dword loads at 12-byte lane pitch: merged into dwordx3
-			w[0][k] = __builtin_nontemporal_load(src + 3 * u + k);
-			w[1][k] = __builtin_nontemporal_load(src + 3 * (two ? u2 : u) + k);
-		}
+	u64 first;
+	if (sdr_span(units, first)) {
+		const uint32_t *src = reinterpret_cast<const uint32_t *>(in) + 3 * (first + threadIdx.x);
+		u32x4 *dst = reinterpret_cast<u32x4 *>(out) + first + threadIdx.x;
+		const u64 left = units - first;
 #pragma unroll
 		for (int h = 0; h < 2; h++) {
-			const uint32_t x = w[h][0], y = w[h][1], z = w[h][2];
-			const u32x4 q = {sdr_cs12(x & 0xffu, (x >> 8) & 0xffu, (x >> 16) & 0xffu), sdr_cs12(x >> 24, y & 0xffu, (y >> 8) & 0xffu),
-			                 sdr_cs12((y >> 16) & 0xffu, y >> 24, z & 0xffu), sdr_cs12((z >> 8) & 0xffu, (z >> 16) & 0xffu, z >> 24)};
-			if (h == 0 || two)
-				__builtin_nontemporal_store(q, reinterpret_cast<u32x4 *>(out) + (h ? u2 : u));
+			uint32_t w[8][3];
+			if (left >= SDR_SPAN) {                                          // a whole span: plain loads, which the compiler merges into dwordx3
+#pragma unroll
+				for (int k = 0; k < 8; k++)
+#pragma unroll
+					for (int c = 0; c < 3; c++)
+						w[k][c] = __builtin_nontemporal_load(src + 3 * (size_t)((h * 8 + k) * 256) + c);
+			} else {
+#pragma unroll
+				for (int k = 0; k < 8; k++) {
+					const unsigned o = (h * 8 + k) * 256;
+					const bool live = o + threadIdx.x < left;
+#pragma unroll
+					for (int c = 0; c < 3; c++)
+						w[k][c] = live ? __builtin_nontemporal_load(src + 3 * (size_t)o + c) : 0u;
+				}
+			}
+#pragma unroll
+			for (int k = 0; k < 8; k++) {
+				const unsigned o = (h * 8 + k) * 256;
+				const uint32_t x = w[k][0], y = w[k][1], z = w[k][2];
+				const u32x4 q = {sdr_cs12(x & 0xffu, (x >> 8) & 0xffu, (x >> 16) & 0xffu), sdr_cs12(x >> 24, y & 0xffu, (y >> 8) & 0xffu),
+				                 sdr_cs12((y >> 16) & 0xffu, y >> 24, z & 0xffu), sdr_cs12((z >> 8) & 0xffu, (z >> 16) & 0xffu, z >> 24)};
+				if (o + threadIdx.x < left)
+					__builtin_nontemporal_store(q, dst + o);
+			}
 		}
 	}
 	if (blockIdx.x == 0 && threadIdx.x < (n_elems & 3)) {
@@ -141,12 +191,64 @@ __global__ __launch_bounds__(256) void k_sdr_cs12_to_cs16(const uint8_t *__restr
 	}
 }
 
+// ---- diagnostics: what this box's HBM gives the converters' loop with the arithmetic taken out (rxgpu_diag_stream_rate): the same spans,
+// eight non-temporal pieces in flight per lane.  MODE 0: 16 B read per unit, nothing written; 1: 16 B read, 16 B written (copy); 2: 8 B
+// read, 16 B written (the CS16->CF32 shape); 3: 16 B read, 8 B written (the CS16->CS8/CU8 shape); 4: the round-3 grid-stride loop, 16 B
+// read, nothing written (what the span order replaced)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_diag_stream(const uint32_t *__restrict__ in, u64 units, uint32_t *__restrict__ out)
+{
+	u32x4 sink = (u32x4)(0u);
+	if (MODE == 4) {
+		const u64 stride = (u64)gridDim.x * blockDim.x;
+		for (u64 u = (u64)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += 2 * stride) {
+			const u64 u2 = u + stride;
+			sink += __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(in) + u) + __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(in) + (u2 < units ? u2 : u));
+		}
+	} else {
+		u64 first;
+		if (sdr_span(units, first)) {
+			const u64 left = units - first;
+#pragma unroll
+			for (int h = 0; h < 2; h++) {
+				u32x4 v[8];
+#pragma unroll
+				for (int k = 0; k < 8; k++) {
+					const unsigned o = (h * 8 + k) * 256;
+					const bool live = o + threadIdx.x < left;
+					if (MODE == 2) {
+						const u32x2 t = live ? __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(in) + first + threadIdx.x + o) : (u32x2)(0u);
+						v[k] = (u32x4){t.x, t.y, t.x ^ 1u, t.y ^ 1u};
+					} else {
+						v[k] = live ? __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(in) + first + threadIdx.x + o) : (u32x4)(0u);
+					}
+				}
+#pragma unroll
+				for (int k = 0; k < 8; k++) {
+					const unsigned o = (h * 8 + k) * 256;
+					const bool live = o + threadIdx.x < left;
+					if (MODE == 0)
+						sink += v[k];
+					else if (MODE == 3) {
+						const u32x2 r = {v[k].x ^ v[k].z, v[k].y ^ v[k].w};
+						if (live) __builtin_nontemporal_store(r, reinterpret_cast<u32x2 *>(out) + first + threadIdx.x + o);
+					} else if (live) {
+						__builtin_nontemporal_store(v[k], reinterpret_cast<u32x4 *>(out) + first + threadIdx.x + o);
+					}
+				}
+			}
+		}
+	}
+	if ((MODE == 0 || MODE == 4) && sink.x == 0x12345678u && sink.y == 0x9abcdef0u && sink.z == 1u)
+		out[0] = sink.w;
+}
+
+// workgroups for `units` units in spans of SDR_SPAN, rounded up to a multiple of 8 (one contiguous eighth per XCD)
 static unsigned sdr_grid(u64 units)
 {
-	const u64 want = (units + 255) / 256;
-	const u64 cap = 256ull * 16;                                       // 16 workgroups per CU, grid-stride beyond
-	const u64 g = want < cap ? want : cap;
-	return (unsigned)(g ? g : 1);
+	const u64 spans = (units + SDR_SPAN - 1) / SDR_SPAN;
+	const u64 g = (spans + 7) & ~7ull;
+	return (unsigned)(g ? g : 8);
 }
 
 #define LAUNCH_RET() do { hipError_t e_ = hipGetLastError(); return (int)e_; } while (0)
@@ -156,9 +258,9 @@ extern "C" int rxk_sdr_cs16_to_8(void *stream, const int16_t *in, u64 n16, int i
 	if (!n16)
 		return 0;
 	if (is_unsigned)
-		hipLaunchKernelGGL((k_sdr_cs16_to_8<true>), dim3(sdr_grid(n16 >> 4)), dim3(256), 0, (hipStream_t)stream, in, n16, out);
+		hipLaunchKernelGGL((k_sdr_cs16_to_8<true>), dim3(sdr_grid(n16 >> 3)), dim3(256), 0, (hipStream_t)stream, in, n16, out);
 	else
-		hipLaunchKernelGGL((k_sdr_cs16_to_8<false>), dim3(sdr_grid(n16 >> 4)), dim3(256), 0, (hipStream_t)stream, in, n16, out);
+		hipLaunchKernelGGL((k_sdr_cs16_to_8<false>), dim3(sdr_grid(n16 >> 3)), dim3(256), 0, (hipStream_t)stream, in, n16, out);
 	LAUNCH_RET();
 }
 
@@ -166,7 +268,7 @@ extern "C" int rxk_sdr_cs16_to_cf32(void *stream, const int16_t *in, u64 n16, fl
 {
 	if (!n16)
 		return 0;
-	hipLaunchKernelGGL(k_sdr_cs16_to_cf32, dim3(sdr_grid(n16 >> 3)), dim3(256), 0, (hipStream_t)stream, in, n16, out);
+	hipLaunchKernelGGL(k_sdr_cs16_to_cf32, dim3(sdr_grid(n16 >> 2)), dim3(256), 0, (hipStream_t)stream, in, n16, out);
 	LAUNCH_RET();
 }
 
@@ -174,7 +276,21 @@ extern "C" int rxk_sdr_cs12_to_cs16(void *stream, const uint8_t *in, u64 n_elems
 {
 	if (!n_elems)
 		return 0;
-	hipLaunchKernelGGL(k_sdr_cs12_to_cs16, dim3(sdr_grid(n_elems >> 3)), dim3(256), 0, (hipStream_t)stream, in, n_elems,
+	hipLaunchKernelGGL(k_sdr_cs12_to_cs16, dim3(sdr_grid(n_elems >> 2)), dim3(256), 0, (hipStream_t)stream, in, n_elems,
 	                   (uint32_t *)out);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_diag_stream(void *stream, int mode, const void *in, u64 units, void *out)
+{
+	hipStream_t s = (hipStream_t)stream;
+	const unsigned grid = sdr_grid(units);
+	switch (mode) {
+	case 0: hipLaunchKernelGGL(k_diag_stream<0>, dim3(grid), dim3(256), 0, s, (const uint32_t *)in, units, (uint32_t *)out); break;
+	case 1: hipLaunchKernelGGL(k_diag_stream<1>, dim3(grid), dim3(256), 0, s, (const uint32_t *)in, units, (uint32_t *)out); break;
+	case 2: hipLaunchKernelGGL(k_diag_stream<2>, dim3(grid), dim3(256), 0, s, (const uint32_t *)in, units, (uint32_t *)out); break;
+	case 3: hipLaunchKernelGGL(k_diag_stream<3>, dim3(grid), dim3(256), 0, s, (const uint32_t *)in, units, (uint32_t *)out); break;
+	default: hipLaunchKernelGGL(k_diag_stream<4>, dim3(256 * 16), dim3(256), 0, s, (const uint32_t *)in, units, (uint32_t *)out); break;
+	}
 	LAUNCH_RET();
 }
