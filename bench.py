@@ -54,11 +54,16 @@ SIMDS, CLOCK_GHZ = 256 * 4, 2.4
 
 def valu_ceiling(kernel_substr):
     """(G wave-instr/s the kernel's opcode mix can issue at most, source text) from the measured per-opcode rates; (nominal, None) without them"""
-    try:
-        issue = json.load(open(os.path.join(ROOT, "profiles", "r03_valu_issue.json")))["ops"]
-        mix = json.load(open(os.path.join(ROOT, "profiles", "r03_kernel_mix.json")))
-        ops = next(v for k, v in mix.items() if kernel_substr in k)
-    except (OSError, ValueError, KeyError, StopIteration):
+    issue = mix = None
+    for rnd in ("r04", "r03"):
+        try:
+            issue = json.load(open(os.path.join(ROOT, "profiles", rnd + "_valu_issue.json")))["ops"]
+            mix = json.load(open(os.path.join(ROOT, "profiles", rnd + "_kernel_mix.json")))
+            ops = next(v for k, v in mix.items() if kernel_substr in k)
+            break
+        except (OSError, ValueError, KeyError, StopIteration):
+            issue = mix = None
+    if issue is None:
         return VALU_PEAK_GINSTR, None
     alias = {"v_pk_mad_u16": "pk_mad_i16", "v_dot2c_i32_i16": "dot2_i32_i16", "v_fma_f32": "pk_fma_f32x", "v_mov_b32_dpp": "mov_dpp_wshr", "v_or_b32": "and_b32",
              "v_xor_b32": "and_b32", "v_mov_b32": "and_b32", "v_lshrrev_b32": "lshlrev_b32", "v_add_co_u32": "add_u32", "v_addc_co_u32": "add_u32"}
@@ -70,8 +75,8 @@ def valu_ceiling(kernel_substr):
         cycles += n / rate
         total += n
     rate = total / cycles
-    return rate * SIMDS * CLOCK_GHZ, ("profiles/r03_valu_issue.json (tools/valu_issue.hip: measured wave64 instructions per SIMD-cycle per opcode, 8 waves/SIMD) weighted with "
-                                      "profiles/r03_kernel_mix.json (the kernel's opcode counts): %.3f per SIMD-cycle x %d SIMDs x %.1f GHz" % (rate, SIMDS, CLOCK_GHZ))
+    return rate * SIMDS * CLOCK_GHZ, ("profiles/%s_valu_issue.json (tools/valu_issue.hip: measured wave64 instructions per SIMD-cycle per opcode, 8 waves/SIMD) weighted with "
+                                      "profiles/%s_kernel_mix.json (the kernel's opcode counts): %.3f per SIMD-cycle x %d SIMDs x %.1f GHz" % (rnd, rnd, rate, SIMDS, CLOCK_GHZ))
 
 
 def cpu_model():
@@ -313,6 +318,7 @@ def hoist(result, parity_all, world):
                                                 "parity_ok": pw.get("parity_ok")}
         for label, v in (pw.get("other_geometries") or {}).items():
             legs["rx_power " + label.split(",")[0][:60]] = {"bound": v.get("bound", "hbm"), "frac": v.get("frac", v["frac_of_hbm_peak"]), "hbm_frac": v["frac_of_hbm_peak"],
+                                                            "traffic_frac": v.get("traffic_frac_of_hbm_peak"), "valu_frac": v.get("valu_frac"),
                                                             "Mbins_per_s": v["Mbins/s"], "N": v["N"], "parity_ok": (v.get("parity") or {}).get("parity_ok")}
     ch = result.get("channeliser")
     if ch:
@@ -400,7 +406,7 @@ def main():
         return ms.value, n.value
 
     def pmc_summary():
-        for name in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
+        for name in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
             try:
                 return json.load(open(os.path.join(ROOT, "profiles", name))), "profiles/" + name
             except (OSError, ValueError):
@@ -613,7 +619,7 @@ def main():
                 v["traffic"] = {"hbm_bytes_per_step": c["hbm_bytes_per_step"] * scale, "algorithmic_bytes_per_step": 4.0 * T,
                                 "traffic_over_algorithmic": c["traffic_over_algorithmic"],
                                 "achieved_GBs_of_traffic": c["hbm_bytes_per_step"] * scale / (v["ms_per_step"] * 1e-3) / 1e9,
-                                "source": pmc_src + " (per-kernel table: profiles/r03_pmc_chains.json)"}
+                                "source": pmc_src + " (per-kernel table: " + pmc_src.replace("summary", "chains") + ")"}
         try:
             k = pmc_kernel(pmc, "k_fm_decimate<false, true, true", "hbm_bytes_per_launch")
             # measured on 2^30-sample launches (--blocks 8192); bytes scale with the launch
@@ -866,6 +872,11 @@ def main():
         del d_in
         # two more geometries of SURVEY 8(d) config 3, one launch shape each, rank 0 only (not part of `value`)
         more = {}
+        try:
+            pw_legs_pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_power_legs.json")))
+        except (OSError, ValueError):
+            pw_legs_pmc = {}
+        fft_peak, _ = valu_ceiling("k_pwm_tail")
         if world == 1 and args.variants == "all":
             for label, rng, boxcar, window, amp, fir, npasses in (
                     ("full-scale input, hamming window (every int16 wrap of the window product and the butterflies)", "24M:1.7G:1k", 1, "hamming", 32767, 0, passes),
@@ -893,6 +904,16 @@ def main():
                 more[label] = {"Mbins/s": in_samples / pl.downsample / t2 / 1e6, "input MSample/s": in_samples / t2 / 1e6,
                                "GB/s_in": 4.0 * in_samples / t2 / 1e9, "frac_of_hbm_peak": 4.0 * in_samples / t2 / 1e9 / HBM_PEAK_GBS,
                                "N": nn, "downsample": pl.downsample, "tunes": pl.tune_count, "passes": npasses, "ms": t2 * 1e3}
+                # which roofline binds this leg: every kernel of the launch counted (rocprofv3 --pmc, profiles/r04_pmc_power_legs.json), the live time
+                # of the whole launch -- HBM traffic (fetched x2 + written) against 8 TB/s, VALU wave-instructions against the measured issue ceiling
+                cnt = next((v for k, v in pw_legs_pmc.items() if label.startswith(k)), None)
+                if cnt and cnt.get("passes"):
+                    sc = npasses / float(cnt["passes"])
+                    tr, vi = cnt["hbm_bytes_per_launch"] * sc / t2 / 1e9, cnt["valu_wave_instr_per_launch"] * sc / t2 / 1e9
+                    more[label].update({"traffic_GBs": tr, "traffic_frac_of_hbm_peak": tr / HBM_PEAK_GBS, "traffic_over_input_bytes": cnt["hbm_bytes_per_launch"] * sc / (4.0 * in_samples),
+                                        "valu_G_wave_instr_per_s": vi, "valu_frac": vi / fft_peak,
+                                        "bound": "hbm" if tr / HBM_PEAK_GBS >= vi / fft_peak else "valu", "frac": max(tr / HBM_PEAK_GBS, vi / fft_peak),
+                                        "roofline_source": "profiles/r04_pmc_power_legs.json (all kernels of the launch) / live launch time"})
                 if not args.no_parity:
                     da.zero_()
                     dsm.zero_()

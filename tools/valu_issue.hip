@@ -79,7 +79,9 @@ OP3(k_cvt_f32_i32_sdwa, "v_cvt_f32_i32_sdwa", " dst_sel:DWORD dst_unused:UNUSED_
 OP3(k_bfe_i32,        "v_bfe_i32",          ", 16, 16")
 OP3(k_ashrrev_i32,    "v_ashrrev_i32",      ", 16")          // dst = 16 >> acc ... rate only
 OP3(k_alignbit,       "v_alignbit_b32",     ", %8, %9")
-OP3(k_cndmask,        "v_cndmask_b32",      ", %8, vcc")
+// the mask in an SGPR pair: with vcc as a long-lived mask the loop measured 0.044 per SIMD-cycle -- an artefact of that loop (tools/cndmask_probe.hip:
+// cmp + cndmask through vcc runs at 0.247, a cndmask on an SGPR pair at 0.23), which round 3's table carried
+OP3(k_cndmask,        "v_cndmask_b32_e64",  ", %8, s[20:21]")
 OP3(k_max_i32,        "v_max_i32",          ", %8")
 OP3(k_sub_u32,        "v_sub_u32",          ", %8")
 
