@@ -138,28 +138,35 @@ def test_profiles_hold_what_bench_reads():
     assert abs(dec[0]["hbm_bytes_per_launch"] / (4.0 * (1 << 30)) - 1.0) < 0.02
 
 
-def test_round3_profiles_hold_what_bench_reads():
-    """the round-3 tables behind bench.py's `roofline` objects: the counter summary (the decimator's traffic, the FFT kernels'
+def test_newest_round_profiles_hold_what_bench_reads():
+    """the tables behind bench.py's `roofline` objects, newest round first: the counter summary (the decimator's traffic, the FFT kernels'
     instruction counts, one traffic entry per timed rx_fm chain) and the measured VALU ceiling (per-opcode issue rates x the static
     opcode mix of the kernels tools/kernel_mix.py names) -- a renamed kernel instantiation must fail here, not turn a field into null"""
     import json, os, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     import bench
-    pmc = json.load(open(os.path.join(root, "profiles", "r03_pmc_summary.json")))
+    rnd = next(r for r in ("r04", "r03") if os.path.exists(os.path.join(root, "profiles", r + "_pmc_summary.json")))
+    pmc = json.load(open(os.path.join(root, "profiles", rnd + "_pmc_summary.json")))
     assert any(k.startswith("k_fm_decimate<false, true, true") and v.get("hbm_bytes_per_launch") for k, v in pmc.items() if isinstance(v, dict))
+    assert any(k.startswith("k_pw_fft4096") and v.get("SQ_INSTS_VALU") for k, v in pmc.items() if isinstance(v, dict))
+    assert any(k.startswith("k_ch_fft") and v.get("SQ_INSTS_VALU") for k, v in pmc.items() if isinstance(v, dict))
     chains = pmc["_chains"]
-    assert len(chains) == 7
+    assert len(chains) >= 7
     for name, c in chains.items():
         assert 1.0 <= c["traffic_over_algorithmic"] < 2.0, (name, c)
     # the whole-chain -F kernel took the 1/8-rate stream out of the `-M wbfm -F 9` chain
     assert [c for n, c in chains.items() if "-F 9" in n][0]["traffic_over_algorithmic"] < 1.35
-    for sub in ("k_pw_fft4096", "k_ch_fftR"):
+    for sub in ("k_pw_fft4096", "k_ch_fftR", "k_pwm_tail"):
         peak, src = bench.valu_ceiling(sub)
         assert src is not None and 0.20 * bench.SIMDS * bench.CLOCK_GHZ < peak < 0.30 * bench.SIMDS * bench.CLOCK_GHZ
     sys.path.insert(0, os.path.join(root, "tools"))
     import kernel_mix
-    mix = json.load(open(os.path.join(root, "profiles", "r03_kernel_mix.json")))
+    mrnd = next(r for r in ("r04", "r03") if os.path.exists(os.path.join(root, "profiles", r + "_kernel_mix.json")))
+    mix = json.load(open(os.path.join(root, "profiles", mrnd + "_kernel_mix.json")))
     for names in kernel_mix.WANT.values():
         for n in names:
             assert any(n in k for k in mix), n
+    if rnd == "r04":
+        legs = json.load(open(os.path.join(root, "profiles", "r04_pmc_power_legs.json")))
+        assert len(legs) == 4 and all(v["valu_wave_instr_per_launch"] > 0 and v["hbm_bytes_per_launch"] > 0 for v in legs.values())
