@@ -3204,7 +3204,7 @@ __global__ __launch_bounds__(256) void k_ch_fftR(const uint32_t *__restrict__ iq
 			const unsigned bin = __brev((tq << 4) | (unsigned)r) >> (32 - M);
 			const unsigned c = (bin - (unsigned)first_bin) & (N - 1);
 			if (c < (unsigned)n_channels)
-				outt[c * CH_WPG + it + fid] = v[r];
+				outt[c * (CH_WPG + 1) + it + fid] = v[r];          // rows of CH_WPG + 1: the 64 channels a wave's store touches fall on 32 banks twice, not on two banks
 		}
 	}
 	__syncthreads();
@@ -3213,7 +3213,7 @@ __global__ __launch_bounds__(256) void k_ch_fftR(const uint32_t *__restrict__ iq
 		const u64 w = w0 + k;
 		if (w >= total_windows)
 			continue;
-		const uint32_t a = outt[idx];
+		const uint32_t a = outt[idx + c];                    // = c * (CH_WPG + 1) + k
 		if (!FUSED) {
 			chan_lp[(u64)c * total_windows + w] = a;
 			continue;
@@ -3225,7 +3225,7 @@ __global__ __launch_bounds__(256) void k_ch_fftR(const uint32_t *__restrict__ iq
 			pre_out[2 * c + 1] = hi16(a);
 		}
 		if (k) {
-			const uint32_t b = outt[idx - 1];
+			const uint32_t b = outt[idx + c - 1];
 			const int ar = lo16(a), aj = hi16(a), br = lo16(b), bj = hi16(b);
 			const int cr = (int)((unsigned)ar * (unsigned)br + (unsigned)aj * (unsigned)bj);
 			const int cj = (int)((unsigned)aj * (unsigned)br - (unsigned)ar * (unsigned)bj);
@@ -3999,7 +3999,7 @@ extern "C" int rxk_ch_fft(void *stream, const int16_t *iq, u64 total_windows, in
 	if (bin_e >= 8 && bin_e <= 12) {
 		const int CH_WPG = ch_wpg(n_channels);
 		/* N <= 1024: one transpose area (k_ch_fftR); rows of XROW = 21 dwords (fft_exchange's skew), the permuted twiddle copy, the staging */
-		const size_t shm = (size_t)((bin_e <= 10 ? 1 : 2) * 256 * 21 + 8 * ((1 << (bin_e - 4)) + 8) + n_channels * CH_WPG) * 4;
+		const size_t shm = (size_t)((bin_e <= 10 ? 1 : 2) * 256 * 21 + 8 * ((1 << (bin_e - 4)) + 8) + n_channels * (CH_WPG + 1)) * 4;
 		const unsigned grid = (unsigned)((total_windows + CH_WPG - 1) / CH_WPG);
 		hipStream_t s = (hipStream_t)stream;
 		const uint32_t *p = (const uint32_t *)iq;

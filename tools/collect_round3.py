@@ -41,7 +41,7 @@ def per_kernel(path, min_grid=0):
     cnt = defaultdict(lambda: defaultdict(int))
     for r in csv.DictReader(open(path)):
         k = short(r["Kernel_Name"])
-        if not k.startswith("k_") or int(r["Grid_Size"]) < min_grid:
+        if not k.startswith("k_") or k.startswith("k_diag_") or int(r["Grid_Size"]) < min_grid:   # k_diag_*: bench.py's box-ceiling probe, no leg's kernel
             continue
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[k][r["Counter_Name"]] += 1
