@@ -907,13 +907,19 @@ def main():
                 # which roofline binds this leg: every kernel of the launch counted (rocprofv3 --pmc, profiles/r04_pmc_power_legs.json), the live time
                 # of the whole launch -- HBM traffic (fetched x2 + written) against 8 TB/s, VALU wave-instructions against the measured issue ceiling
                 cnt = next((v for k, v in pw_legs_pmc.items() if label.startswith(k)), None)
+                if cnt is None and nn == 4096 and pl.tune_count == total_tunes:
+                    try:                                              # the configs[2] kernel on other data: the same instructions and bytes per launch
+                        k4 = pmc_kernel(pmc, "k_pw_fft4096", "SQ_INSTS_VALU")
+                        cnt = {"passes": 512, "valu_wave_instr_per_launch": k4["SQ_INSTS_VALU"], "hbm_bytes_per_launch": k4.get("hbm_bytes_per_launch") or 0.0}
+                    except (KeyError, TypeError):
+                        cnt = None
                 if cnt and cnt.get("passes"):
                     sc = npasses / float(cnt["passes"])
                     tr, vi = cnt["hbm_bytes_per_launch"] * sc / t2 / 1e9, cnt["valu_wave_instr_per_launch"] * sc / t2 / 1e9
                     more[label].update({"traffic_GBs": tr, "traffic_frac_of_hbm_peak": tr / HBM_PEAK_GBS, "traffic_over_input_bytes": cnt["hbm_bytes_per_launch"] * sc / (4.0 * in_samples),
                                         "valu_G_wave_instr_per_s": vi, "valu_frac": vi / fft_peak,
                                         "bound": "hbm" if tr / HBM_PEAK_GBS >= vi / fft_peak else "valu", "frac": max(tr / HBM_PEAK_GBS, vi / fft_peak),
-                                        "roofline_source": "profiles/r04_pmc_power_legs.json (all kernels of the launch) / live launch time"})
+                                        "roofline_source": "profiles/r04_pmc_power_legs.json or, N = 4096, r04_pmc_summary.json (all kernels of the launch) / live launch time"})
                 if not args.no_parity:
                     da.zero_()
                     dsm.zero_()
