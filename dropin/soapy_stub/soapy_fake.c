@@ -157,13 +157,16 @@ int SoapySDRDevice_readStream(SoapySDRDevice *d, SoapySDRStream *s, void * const
 	if (g_max_chunk && n > g_max_chunk) n = g_max_chunk;
 	if (n > g_src_len - g_src_pos) n = g_src_len - g_src_pos;
 	if (g_pace > 0 && g_dev.rate > 0) {
-		/* deliver no faster than pace x the sample rate the program asked for: a block is "received" when its last sample would be */
-		if (g_t0 == 0)
-			g_t0 = mono_s();
+		/* deliver no faster than pace x the sample rate the program asked for: a block is "received" one block time after the previous
+		 * one was handed out -- a reader that stalled (the first full_demod of a process pages the HIP runtime in) does not get the
+		 * backlog in a burst, which the reference's single-slot hand-off (rtl_fm.c:858-862) would lose */
+		const double now = mono_s();
+		if (g_t0 < now)
+			g_t0 = now;
+		g_t0 += (double)n / (g_dev.rate * g_pace);
 		g_paced += n;
-		const double due = g_t0 + (double)g_paced / (g_dev.rate * g_pace), now = mono_s();
-		if (due > now)
-			usleep((useconds_t)((due - now) * 1e6));
+		if (g_t0 > now)
+			usleep((useconds_t)((g_t0 - now) * 1e6));
 	}
 	memcpy(buffs[0], (const char *)g_src + g_elem * g_src_pos, n * g_elem);
 	g_src_pos += n;
