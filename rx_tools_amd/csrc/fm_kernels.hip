@@ -1600,12 +1600,12 @@ __global__ __launch_bounds__(256) void k_fm_deemph_scan_t(
 // 0.6 GB more per 8 GiB of capture, and the kernel runs at memory speed.  Here a lane loads its chunk's 16 units into registers
 // first, and the warm-up of lane L walks the registers of lane L - 1 (one wave_shr:1 DPP move per dword).  A wave therefore
 // covers 63 chunks: its lane 0 only supplies the chunk in front of them (1.6 % of the stream is loaded by two waves).
-template <int GS>
+template <int GS, int CHL2 = 7>
 __global__ __launch_bounds__(256) void k_fm_deemph_scan_r(
 	const int16_t *__restrict__ pcm_t, u64 M, int a, unsigned magic, int warm, int lo0, int gap_w,
 	uint4 *__restrict__ ctab, rxk_fm_dev *__restrict__ dev)
 {
-	constexpr int CHL2 = 7, CH = 1 << CHL2, UPC = CH / 8;
+	constexpr int CH = 1 << CHL2, UPC = CH / 8;                // CHL2 = 8 (round 4): 256-sample chunks, 128 VGPRs of samples per lane
 	const int lane = threadIdx.x & 63;
 	const u64 wv = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
 	const u64 n_chunks = (M + CH - 1) >> CHL2;
@@ -3625,6 +3625,17 @@ extern "C" int rxk_fm_deemph_scan_t(void *stream, const int16_t *pcm_t, u64 M, i
 	hipStream_t s = (hipStream_t)stream;
 	const unsigned mg = deemph_magic(a);
 	const char *pick = rxgpu_knob("RXGPU_SCAN_T");                       /* "1": always scan_t, "0": scan_r wherever it applies (tests) */
+	if (chl2 == 8 && pick && pick[0] == '0') {
+		/* 256-sample chunks (a = 19 at 240 kHz, BASELINE configs[0]) in the register form, $RXGPU_SCAN_T=0 only: it reads every chunk once where
+		 * scan_t reads the tails twice (0.43 instead of 0.74 GB per 4 GiB of capture at ds = 5), but at 145 VGPRs per wave the kernel itself takes
+		 * 1.2 ms instead of 0.66 and the pipelined step does not move (round 4, A/B in one process): scan_t stays the default */
+		const unsigned rgrid = (unsigned)(((n_chunks + 62) / 63 + 3) / 4);
+		if (group == 16)
+			hipLaunchKernelGGL((k_fm_deemph_scan_r<16, 8>), dim3(rgrid), dim3(256), 0, s, pcm_t, M, a, mg, warm, lo0, gap_w, (uint4 *)ctab, dev);
+		else
+			hipLaunchKernelGGL((k_fm_deemph_scan_r<64, 8>), dim3(rgrid), dim3(256), 0, s, pcm_t, M, a, mg, warm, lo0, gap_w, (uint4 *)ctab, dev);
+		LAUNCH_RET();
+	}
 	if (chl2 == 7 && (pick ? pick[0] == '0' : M >= (1ull << 25))) {
 		/* 128-sample chunks of a LONG run (the small-decimation chains, where the audio stages' traffic counts): the chunk in
 		 * registers, the warm-up from the neighbouring lane; 63 chunks per wave.  Short runs keep scan_t: behind the big-ds
