@@ -796,8 +796,10 @@ def main():
             barrier()
             pw["config"]["rccl_gathers_enqueued"] = comm.gathers if comm is not None else 0      # warm-up + timed steps + this interval
             mysum = int(d_in.view(torch.int32).sum(dtype=torch.int64).item())
-            sums = [None] * world
-            dist.gather_object(mysum, sums if rank == 0 else None, dst=0)
+            t_sum = torch.tensor([mysum], dtype=torch.int64, device="cpu" if share_gpu else dev)
+            t_all = [torch.zeros_like(t_sum) for _ in range(world)]
+            dist.all_gather(t_all, t_sum)                        # a plain tensor collective (gloo in the one-GPU test, RCCL otherwise)
+            sums = [int(t.item()) for t in t_all]
             if rank == 0:
                 PA = parity_module()
                 got_all, smp_all = d_avg_all.cpu().numpy(), d_smp_all.cpu().numpy()
