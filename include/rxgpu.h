@@ -379,7 +379,10 @@ int rxgpu_shard_tunes(int rank, int world, int total, int *first, int *count, in
 int rxgpu_power_gather(rxgpu_comm *c, const int64_t *d_avg_local, const int32_t *d_samples_local, int per, int n_bins,
                        int64_t *d_avg_all, int32_t *d_samples_all, int root);
 /* rxgpu_power_scan_run over this rank's tunes (d_in_local: [passes][count][buf_len]) followed by the gather; the padding
- * rows [count, per) of a short last rank are zeroed here, so the root never sees what the caller left in them */
+ * rows [count, per) of a short last rank are zeroed here, so the root never sees what the caller left in them.
+ * Asynchronous: the scan on rxgpu_stream(), the gather behind it on the library's copy stream, so that the NEXT interval's scan
+ * overlaps this interval's transfer -- alternate two sets of local buffers to use that (a call that finds its send buffers still
+ * being gathered makes its scan wait).  The root reads d_avg_all / d_samples_all after rxgpu_sync(), which covers both streams. */
 int rxgpu_power_scan_run_sharded(rxgpu_power_scan *s, rxgpu_comm *c, const int16_t *d_in_local, int passes, int total_tunes,
                                  int64_t *d_avg_local, int32_t *d_samples_local, int n_bins,
                                  int64_t *d_avg_all, int32_t *d_samples_all, int root);

@@ -24,6 +24,10 @@ struct rxgpu_comm {
 	int rank, world;
 	int owned;                       /* created here (destroy it) or adopted from the caller */
 	long gathers;                    /* grouped gathers enqueued so far */
+	/* rxgpu_power_scan_run_sharded: the gather of interval k runs on the copy stream while interval k + 1 is scanned (round 4) */
+	hipEvent_t ev_scan;              /* the scan (and the padding memsets) of the interval whose gather is being enqueued */
+	struct { const void *avg, *samples; hipEvent_t ev; int valid; } pend[2];   /* send buffers a gather may still be reading */
+	int pend_next;
 };
 
 static struct {
@@ -174,11 +178,17 @@ void rxgpu_comm_destroy(rxgpu_comm *c)
 {
 	if (!c)
 		return;
-	if (c->owned && c->nccl && g_rccl.CommDestroy) {
-		if (rxgpu_hip_stream())
-			hipStreamSynchronize(rxgpu_hip_stream());
+	if (rxgpu_hip_stream())
+		hipStreamSynchronize(rxgpu_hip_stream());
+	if (rxgpu_hip_stream3())
+		hipStreamSynchronize(rxgpu_hip_stream3());
+	if (c->owned && c->nccl && g_rccl.CommDestroy)
 		g_rccl.CommDestroy(c->nccl);
-	}
+	if (c->ev_scan)
+		hipEventDestroy(c->ev_scan);
+	for (int i = 0; i < 2; i++)
+		if (c->pend[i].ev)
+			hipEventDestroy(c->pend[i].ev);
 	free(c);
 }
 
@@ -204,8 +214,8 @@ int rxgpu_shard_tunes(int rank, int world, int total, int *first, int *count, in
 /* ONE collective launch per report interval: the avg block and the samples vector of every rank travel in the same
  * ncclGroup (RCCL fuses the grouped gathers' point-to-point transfers into a single kernel on the stream), enqueued on the
  * library's stream right behind the scan -- rows merge where the reference prints them, rtl_power.c:1047-1050. */
-int rxgpu_power_gather(rxgpu_comm *c, const int64_t *d_avg_local, const int32_t *d_samples_local, int per, int n_bins,
-                       int64_t *d_avg_all, int32_t *d_samples_all, int root)
+static int gather_on(rxgpu_comm *c, hipStream_t st, const int64_t *d_avg_local, const int32_t *d_samples_local, int per, int n_bins,
+                     int64_t *d_avg_all, int32_t *d_samples_all, int root)
 {
 	int rc;
 	if (per < 0 || n_bins < 1)
@@ -221,7 +231,8 @@ int rxgpu_power_gather(rxgpu_comm *c, const int64_t *d_avg_local, const int32_t 
 		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_power_gather: the root needs the receive buffers");
 	if ((rc = rxgpu_ensure_init()) != RXGPU_OK)
 		return rc;
-	hipStream_t st = rxgpu_hip_stream();
+	if (!st)
+		st = rxgpu_hip_stream();
 	const size_t n_avg = (size_t)per * (size_t)n_bins;
 	if (!c) {                                            /* one process: the "gather" is the rank's own block */
 		if (d_avg_all != d_avg_local)
@@ -230,7 +241,7 @@ int rxgpu_power_gather(rxgpu_comm *c, const int64_t *d_avg_local, const int32_t 
 			RX_HIP(hipMemcpyAsync(d_samples_all, d_samples_local, (size_t)per * 4, hipMemcpyDeviceToDevice, st));
 		return RXGPU_OK;
 	}
-	rxgpu_prof_begin("pw_gather");
+	rxgpu_prof_begin_on("pw_gather", st);
 	ncclResult_t r = g_rccl.GroupStart();
 	if (r == ncclSuccess) {
 		ncclResult_t r1 = g_rccl.Gather(d_avg_local, d_avg_all, n_avg, ncclInt64, root, c->nccl, st);
@@ -243,13 +254,26 @@ int rxgpu_power_gather(rxgpu_comm *c, const int64_t *d_avg_local, const int32_t 
 		rxgpu_prof_abort();
 		return rxgpu_fail(RXGPU_ENODEV, "grouped ncclGather failed: %s", g_rccl.GetErrorString(r));
 	}
-	rxgpu_prof_end("pw_gather");
+	rxgpu_prof_end_on("pw_gather", st);
 	c->gathers++;
 	return RXGPU_OK;
 }
 
+/* the public form: on the library's stream, ordered with whatever the caller enqueues there next */
+int rxgpu_power_gather(rxgpu_comm *c, const int64_t *d_avg_local, const int32_t *d_samples_local, int per, int n_bins,
+                       int64_t *d_avg_all, int32_t *d_samples_all, int root)
+{
+	return gather_on(c, NULL, d_avg_local, d_samples_local, per, n_bins, d_avg_all, d_samples_all, root);
+}
+
 long rxgpu_comm_gathers(const rxgpu_comm *c) { return c ? c->gathers : 0; }
 
+/* One report interval of a sharded sweep.  The scan goes on the library's stream, the grouped gather behind it on the COPY stream
+ * (an event orders them): the next interval's scan does not wait for this interval's rows to cross xGMI -- at eight ranks the
+ * root takes in 7 x 2.4 MB per interval while each rank scans 75 tunes.  What the gather still reads must not be scanned into:
+ * a call whose send buffers are those of a gather that may be in flight (a caller that alternates two buffer sets meets its own
+ * gather two intervals later, one that reuses a single set meets it at once) makes its scan wait for that gather.  The root's
+ * receive buffers are filled in interval order (one stream); rxgpu_sync() covers both streams. */
 int rxgpu_power_scan_run_sharded(rxgpu_power_scan *s, rxgpu_comm *c, const int16_t *d_in_local, int passes, int total_tunes,
                                  int64_t *d_avg_local, int32_t *d_samples_local, int n_bins,
                                  int64_t *d_avg_all, int32_t *d_samples_all, int root)
@@ -259,15 +283,39 @@ int rxgpu_power_scan_run_sharded(rxgpu_power_scan *s, rxgpu_comm *c, const int16
 		return rc;
 	if (per > 0 && (!d_avg_local || !d_samples_local || n_bins < 1))
 		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_power_scan_run_sharded: null local buffers");
+	if ((rc = rxgpu_ensure_init()) != RXGPU_OK)
+		return rc;
+	hipStream_t sa = rxgpu_hip_stream(), sc = rxgpu_hip_stream3();
+	if (c) {
+		for (int i = 0; i < 2; i++)
+			if (c->pend[i].valid && (c->pend[i].avg == (const void *)d_avg_local || c->pend[i].samples == (const void *)d_samples_local)) {
+				RX_HIP(hipStreamWaitEvent(sa, c->pend[i].ev, 0));
+				c->pend[i].valid = 0;
+			}
+	}
 	if (count > 0 && (rc = rxgpu_power_scan_run(s, d_in_local, passes, count, d_avg_local, d_samples_local)) != RXGPU_OK)
 		return rc;
 	if (count < per) {
 		/* the padding rows of a short last rank (599 tunes over 8 ranks: 75 x 7 + 74) reach the root as zeros, whatever the
 		 * caller left in them */
-		if ((rc = rxgpu_ensure_init()) != RXGPU_OK)
-			return rc;
-		RX_HIP(hipMemsetAsync(d_avg_local + (size_t)count * (size_t)n_bins, 0, (size_t)(per - count) * (size_t)n_bins * 8, rxgpu_hip_stream()));
-		RX_HIP(hipMemsetAsync(d_samples_local + count, 0, (size_t)(per - count) * 4, rxgpu_hip_stream()));
+		RX_HIP(hipMemsetAsync(d_avg_local + (size_t)count * (size_t)n_bins, 0, (size_t)(per - count) * (size_t)n_bins * 8, sa));
+		RX_HIP(hipMemsetAsync(d_samples_local + count, 0, (size_t)(per - count) * 4, sa));
 	}
-	return rxgpu_power_gather(c, d_avg_local, d_samples_local, per, n_bins, d_avg_all, d_samples_all, root);
+	if (!c || per == 0)
+		return gather_on(c, sa, d_avg_local, d_samples_local, per, n_bins, d_avg_all, d_samples_all, root);
+	if (!c->ev_scan)
+		RX_HIP(hipEventCreateWithFlags(&c->ev_scan, hipEventDisableTiming));
+	RX_HIP(hipEventRecord(c->ev_scan, sa));
+	RX_HIP(hipStreamWaitEvent(sc, c->ev_scan, 0));
+	if ((rc = gather_on(c, sc, d_avg_local, d_samples_local, per, n_bins, d_avg_all, d_samples_all, root)) != RXGPU_OK)
+		return rc;
+	const int k = c->pend_next;
+	c->pend_next ^= 1;
+	if (!c->pend[k].ev)
+		RX_HIP(hipEventCreateWithFlags(&c->pend[k].ev, hipEventDisableTiming));
+	RX_HIP(hipEventRecord(c->pend[k].ev, sc));
+	c->pend[k].avg = d_avg_local;
+	c->pend[k].samples = d_samples_local;
+	c->pend[k].valid = 1;
+	return RXGPU_OK;
 }
