@@ -86,9 +86,12 @@ def main():
     import time
     PACE = C.CFUNCTYPE(None)
 
+    pace_s = float(os.environ.get("DROPIN_PACE", "0.02"))
+
     def pace():
         # wait until the demod thread has consumed the previous block: a fixed sleep well above one block's CPU time
-        time.sleep(0.02)
+        # (the reference's hand-off is a single lossy slot, rtl_fm.c:858-862: on a loaded host the caller raises $DROPIN_PACE)
+        time.sleep(pace_s)
 
     def eos():
         time.sleep(0.1)

@@ -21,10 +21,12 @@ pytestmark = pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built")
 BLOCK = 2 * 131072        # dongle_thread_fn reads MAXIMUM_BUF_LENGTH/2 complex samples per readStream (rtl_fm.c:871)
 
 
-def run_ref_main(mode, iq, tmp_path, extra):
+def run_ref_main(mode, iq, tmp_path, extra, pace=None):
     iq_path, out_path = str(tmp_path / "iq.npy"), str(tmp_path / ("out_%s.raw" % mode))
     np.save(iq_path, iq)
     env = dict(os.environ)
+    if pace is not None:
+        env["DROPIN_PACE"] = str(pace)
     p = subprocess.run([sys.executable, RUNNER, mode, iq_path, out_path] + extra, env=env, capture_output=True, timeout=300)
     assert os.path.exists(out_path), p.stderr.decode()[-2000:]
     return np.fromfile(out_path, dtype=np.int16), p.stderr.decode()
@@ -111,7 +113,12 @@ def test_dropin_rx_fm_prints_the_reference_level_lines(tmp_path, extra):
     iq = sig_fm(6 * 131072, seed=2026)
     iq[2 * 262144:3 * 262144] //= 64                               # one quiet block for the squelch
     got, err_gpu = run_dropin_rx_fm(iq, tmp_path, extra, False)
-    want, err_cpu = run_ref_main("cpu", iq, tmp_path, extra)
+    # the checker is the untouched reference main(), whose own hand-off between its threads is lossy (rtl_fm.c:858-862): on a loaded host a
+    # block can go missing from the CPU run -- paced more slowly until it has taken every block the executable took
+    for pace in (0.02, 0.1, 0.4):
+        want, err_cpu = run_ref_main("cpu", iq, tmp_path, extra, pace)
+        if len(want) >= len(got):
+            break
     assert np.array_equal(got, want)
     lv_gpu = [ln for ln in err_gpu.splitlines() if LEVEL_LINE.match(ln.strip())]
     lv_cpu = [ln for ln in err_cpu.splitlines() if LEVEL_LINE.match(ln.strip())]
