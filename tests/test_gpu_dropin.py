@@ -246,6 +246,35 @@ def test_dropin_handoff_stays_on_the_device_unless_invalidated():
             R.check(L.rxgpu_dropin_unpin(C.addressof(d), C.addressof(s)))
 
 
+def test_dropin_release_frees_the_side_car_slot():
+    """sixteen side-car slots exist (stream object, callback staging, de-emphasis accumulator per demod_state); a caller that creates and
+    destroys demod_states hands each slot back with rxgpu_dropin_release -- forty of them in a row, every one demodulating like the oracle"""
+    L, O = R.lib(), oracle()
+    R.check(L.rxgpu_init(0))
+    block_len = 4096
+    iq = sig_fm(block_len // 2, seed=7)
+    kw = dict(downsample=6)
+    want = np.zeros(block_len, np.int16)
+    for i in range(40):
+        d = fresh_demod(**kw)
+        s = DongleState()
+        s.demod_target = C.pointer(d)
+        st = oracle_fm_state(**kw)
+        L.rxgpu_deemph_state(C.addressof(d)).contents.value = 0
+        raw = iq.copy()
+        L.rxgpu_callback(raw.ctypes.data, block_len, C.addressof(s))
+        lp = np.ctypeslib.as_array(d.lowpassed)[:block_len].copy()
+        lp_len = C.c_int(block_len)
+        n_want = O.rxo_fm_full_demod(C.byref(st), ptr16(lp), C.byref(lp_len), ptr16(want))
+        L.rxgpu_full_demod(C.addressof(d))
+        assert d.result_len == n_want and np.array_equal(np.ctypeslib.as_array(d.result)[:n_want], want[:n_want]), i
+        sr = C.c_int(0)
+        assert L.rxgpu_dropin_block_rms(C.addressof(d), C.byref(sr)) == -3          # no squelch on that block: the caller's own rms() applies
+        R.check(L.rxgpu_dropin_release(C.addressof(d)))
+        assert L.rxgpu_dropin_release(C.addressof(d)) == -2                          # nothing left to release
+        del s, d
+
+
 def test_rdc_on_an_empty_read_exits_like_the_header_says():
     """-E rdc on an EMPTY read: the reference divides by len/2 == 0 (rtl_fm.c:710-711); rxgpu_callback says so on stderr and exit(1)s
     (the reference's failure convention) instead of publishing an empty block"""
