@@ -326,6 +326,9 @@ def hoist(result, parity_all, world):
         legs["channeliser 256 ch"] = {"bound": "valu", "frac": r["valu"]["frac"], "hbm_frac": r["frac"], "MSample_per_s": ch["value"],
                                       "traffic_over_algorithmic": (r["traffic"] / r["algorithmic_bytes_per_launch"]) if r.get("traffic") else None,
                                       "parity_ok": (ch.get("parity") or {}).get("parity_ok"), "parity_checker": (ch.get("parity") or {}).get("parity_checker")}
+        if ch.get("nco_mode"):
+            legs["channeliser 256 ch, NCO -> low_pass mode"] = {"bound": "valu", "MSample_per_s": ch["nco_mode"]["value"], "frac": None,
+                                                               "parity_ok": (ch["nco_mode"].get("parity") or {}).get("parity_ok")}
     for label, v in ((result.get("sdr_convert") or {}).get("legs") or {}).items():
         legs["rx_sdr " + label] = {"bound": "hbm", "frac": v["frac_of_hbm_peak"], "GBs": v["GB/s"], "frac_of_box_ceiling": v.get("frac_of_box_ceiling"),
                                    "parity_ok": (result["sdr_convert"]).get("parity_ok")}
@@ -1007,6 +1010,42 @@ def main():
         }
         if chan_parity is not None:
             result["channeliser"]["parity"] = chan_parity
+        # SURVEY 8(f)2's literal definition as the second mode (rxgpu_chan_params.nco: callback scale -> integer NCO per channel -> low_pass at
+        # downsample N): the same 256 channels in another fixed-point rounding, ~50 times the arithmetic of the bank -- timed on 1/8 of the capture
+        if rank == 0 and args.variants == "all":
+            nb2 = max(2, n_blocks // 8)
+            T2 = nb2 * (block_len // 2)
+            w2 = T2 >> bin_e
+            d_o2 = torch.zeros((n_ch, w2), dtype=torch.int16, device=dev)
+            ch2 = R.Channeliser(R.ChanParams(bin_e, 384, n_ch, 1, 0, 0, 0, -1, 1), nb2, block_len, R.sine_table(bin_e))
+            ch2.run(d_iq.data_ptr(), nb2, block_len, d_o2.data_ptr(), w2)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                ch2.run(d_iq.data_ptr(), nb2, block_len, d_o2.data_ptr(), w2)
+            torch.cuda.synchronize()
+            t_nco = (time.perf_counter() - t0) / 3
+            nco = {"value": T2 / t_nco / 1e6, "unit": "MSample/s", "ms": t_nco * 1e3, "blocks": nb2,
+                   "note": "rxgpu_chan_params.nco = 1; N^2-ish by definition (one multiply-accumulate per sample and channel), which is why the fix_fft bank is the default"}
+            if not args.no_parity:
+                PA = parity_module()
+                nbc = 2                                            # two callback blocks of every channel against the checker (a block is 2.7e7 products per channel set)
+                ch2.set_carry(np.zeros(2 * n_ch, np.int32))
+                ch2.run(d_iq.data_ptr(), nbc, block_len, d_o2.data_ptr(), w2)
+                h2 = d_iq[: nbc * block_len].cpu().numpy()
+                wpb2 = block_len // 2 >> bin_e
+                if PA.support.have_ref():
+                    want2, pre2 = PA.support.ref_chan_nco_stream(h2, block_len, bin_e, 384, n_ch, 1)
+                    kind2 = "reference (the reference's callback scale, Sinewave table, FIX_MPY, and full_demod at downsample N)"
+                else:
+                    want2, pre2 = PA.support.oracle_chan_nco_stream(h2, block_len, bin_e, 384, n_ch, 1)
+                    kind2 = "port (rxo_chan_nco_block, pinned against the reference-built chain in tests/test_chan_oracle.py)"
+                same2 = bool(np.array_equal(d_o2[:, : nbc * wpb2].cpu().numpy(), want2) and np.array_equal(ch2.get_carry(), pre2))
+                nco["parity"] = {"parity_ok": same2, "parity_checker": kind2, "parity_windows_compared": int(nbc * wpb2), "parity_channels": int(n_ch)}
+                parity_all["channeliser_nco"] = same2
+            ch2.close()
+            result["channeliser"]["nco_mode"] = nco
+            del d_o2
         del d_iq, d_out
 
     # ------------------------------------------------------------------ rx_sdr -F conversions

@@ -261,6 +261,11 @@ typedef struct rxgpu_chan_params {
 	 * rtl_fm.c:1086-1099): deemph_filter (rtl_fm.c:667-682) and low_pass_real (389-409) on the channel's demodulated stream */
 	int deemph, deemph_a;    /* -E deemp; deemph_a as rxgpu_fm_plan_settings derives it for the channel rate fs / N */
 	int rate_out, rate_out2; /* low_pass_real: channel rate (fs / N) -> rate_out2; rate_out2 <= 0 disables it */
+	/* 0: the bank of fix_fft bins above (default).  1: SURVEY 8(f)2's literal definition -- the capture through the callback's scale
+	 * (rtl_fm.c:845-848, no rotation), per channel an integer NCO at k * fs / N (cos / sin from the reference's Sinewave table, each product
+	 * rounded by FIX_MPY, rtl_power.c:256-262), then low_pass (rtl_fm.c:351-371) at downsample N; everything behind it as above.  The
+	 * same channels in another fixed-point rounding, at ~50 times the arithmetic: windows of 2^3 .. 2^12 samples. */
+	int nco;
 } rxgpu_chan_params;
 
 typedef struct rxgpu_chan rxgpu_chan;

@@ -162,12 +162,45 @@ static int ref_fm_deemph_peek(void)
 /* lp: [n_ch][2 * wpb] int16, channel c's decimated IQ of this block (what low_pass at downsample = 1 passes through unchanged,
  * rtl_fm.c:351-371).  pre: 2 ints per channel (pre_r, pre_j); audio: 3 per channel (deemph avg, now_lpr, prev_lpr_index).
  * out: [n_ch][out_stride]; returns result_len of the last channel (the same for all: equal lengths and phases), or -1. */
+static int ref_fm_chan_block_ds(const int16_t *lp, int n_ch, int wpb, int ds, int custom_atan, int deemph, int deemph_a, int rate_out, int rate_out2,
+                                int *pre, int *audio, int16_t *out, size_t out_stride);
 int ref_fm_chan_block(const int16_t *lp, int n_ch, int wpb, int custom_atan, int deemph, int deemph_a, int rate_out, int rate_out2,
                       int *pre, int *audio, int16_t *out, size_t out_stride)
 {
+	return ref_fm_chan_block_ds(lp, n_ch, wpb, 1, custom_atan, deemph, deemph_a, rate_out, rate_out2, pre, audio, out, out_stride);
+}
+/* the NCO mode: lp holds channel c's MIXED stream at the capture rate, [n_ch][2 * wpb * ds] int16; the reference's own low_pass at
+ * downsample = ds (rtl_fm.c:351-371) decimates it inside full_demod */
+int ref_fm_chan_block_mixed(const int16_t *lp, int n_ch, int wpb, int ds, int custom_atan, int *pre, int16_t *out, size_t out_stride)
+{
+	static int audio[3 * 4096];
+	if (n_ch > 4096 || (size_t)2 * wpb * ds > (size_t)MAXIMUM_BUF_LENGTH)
+		return -4;
+	memset(audio, 0, sizeof(audio));
+	return ref_fm_chan_block_ds(lp, n_ch, wpb, ds, custom_atan, 0, 0, 0, -1, pre, audio, out, out_stride);
+}
+/* the callback's scale (rtl_fm.c:845-848) without the rotation, through the reference's own rtlsdr_callback: buf -> out, len int16 */
+void ref_fm_scale_block(const int16_t *buf, uint32_t len, int16_t *out)
+{
+	static int16_t tmp[MAXIMUM_BUF_LENGTH];
+	const int saved = dongle.offset_tuning, saved_mute = dongle.mute, saved_dc = demod.dc_block_raw;
+	memcpy(tmp, buf, (size_t)len * sizeof(int16_t));
+	dongle.offset_tuning = 1;                                /* rotate16_90 off (rtl_fm.c:854) */
+	dongle.mute = 0;
+	demod.dc_block_raw = 0;
+	dongle.demod_target = &demod;
+	rtlsdr_callback(tmp, len, &dongle);
+	memcpy(out, demod.lowpassed, (size_t)len * sizeof(int16_t));
+	dongle.offset_tuning = saved;
+	dongle.mute = saved_mute;
+	demod.dc_block_raw = saved_dc;
+}
+static int ref_fm_chan_block_ds(const int16_t *lp, int n_ch, int wpb, int ds, int custom_atan, int deemph, int deemph_a, int rate_out, int rate_out2,
+                                int *pre, int *audio, int16_t *out, size_t out_stride)
+{
 	int n_out = -1;
 	demod_init(&demod);
-	demod.downsample = 1;
+	demod.downsample = ds;
 	demod.downsample_passes = 0;
 	demod.post_downsample = 1;
 	demod.squelch_level = 0;
@@ -179,8 +212,8 @@ int ref_fm_chan_block(const int16_t *lp, int n_ch, int wpb, int custom_atan, int
 	demod.rate_out2 = rate_out2;
 	demod.dc_block_audio = 0;
 	for (int c = 0; c < n_ch; c++) {
-		memcpy(demod.lowpassed, lp + (size_t)c * 2 * wpb, (size_t)2 * wpb * sizeof(int16_t));
-		demod.lp_len = 2 * wpb;
+		memcpy(demod.lowpassed, lp + (size_t)c * 2 * wpb * ds, (size_t)2 * wpb * ds * sizeof(int16_t));
+		demod.lp_len = 2 * wpb * ds;
 		demod.now_r = demod.now_j = 0;
 		demod.prev_index = 0;
 		demod.pre_r = pre[2 * c];

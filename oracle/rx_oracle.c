@@ -699,6 +699,47 @@ void rxo_chan_block(const rxo_chan_cfg *cfg, const int16_t *in, int len, int *pr
 	free(lp);
 }
 
+/* The channeliser's second definition, SURVEY.md section 8(f)2 to the letter: per channel an integer NCO, then the reference's low_pass
+ * (rtl_fm.c:351-371) at downsample = N, fm_demod per channel.  The reference has no mixer beyond rotate16_90, so the NCO is specified
+ * here from the reference's own fixed-point pieces: the block goes through the callback's scale (rtl_fm.c:845-848, no rotation), sample n
+ * of a window is multiplied by e^(-j 2 pi k n / N), k = (first_bin + c) mod N, with cos / sin taken from the reference's Sinewave table
+ * (rtl_power.c:240-254; the half period it holds, mirrored with a sign for the other half) and every one of the four products rounded by
+ * FIX_MPY (rtl_power.c:256-262) and stored as int16; low_pass then sums N mixed samples per output in int and stores them as int16
+ * (wrapping for an in-channel carrier above a quarter of full scale, as low_pass itself would at that decimation). */
+static void nco_tw(const int16_t *sinewave, int n, int p, int *c, int *s)
+{
+	const int h = n / 2, q = p & (h - 1);                    /* cos(t) = sin(t + pi/2); the second half period is the first, negated */
+	const int cc = sinewave[q + n / 4], ss = sinewave[q];
+	*c = p >= h ? -cc : cc;
+	*s = p >= h ? -ss : ss;
+}
+
+void rxo_chan_nco_block(const rxo_chan_cfg *cfg, const int16_t *in, int len, int *pre, int16_t *out, size_t out_stride)
+{
+	const int n = 1 << cfg->bin_e, windows = len / 2 / n;
+	int16_t *lp = malloc((size_t)2 * windows * sizeof(int16_t) + 4);
+	for (int ch = 0; ch < cfg->n_channels; ch++) {
+		const int k = (cfg->first_bin + ch) & (n - 1);
+		for (int w = 0; w < windows; w++) {
+			int now_r = 0, now_j = 0;                          /* low_pass's accumulators: a window is exactly one output (prev_index returns to 0) */
+			for (int i = 0; i < n; i++) {
+				const int16_t *x = in + ((size_t)w * n + i) * 2;
+				const int16_t xr = rxo_scale_sample(x[0]), xi = rxo_scale_sample(x[1]);
+				int c, s;
+				nco_tw(cfg->sinewave, n, (int)(((long long)k * i) & (n - 1)), &c, &s);
+				const int16_t yr = (int16_t)(rxo_fix_mpy(xr, (int16_t)c) + rxo_fix_mpy(xi, (int16_t)s));
+				const int16_t yi = (int16_t)(rxo_fix_mpy(xi, (int16_t)c) - rxo_fix_mpy(xr, (int16_t)s));
+				now_r += yr;
+				now_j += yi;
+			}
+			lp[2 * w] = (int16_t)now_r;
+			lp[2 * w + 1] = (int16_t)now_j;
+		}
+		rxo_fm_demod(lp, 2 * windows, cfg->custom_atan, &pre[2 * ch], &pre[2 * ch + 1], out + (size_t)ch * out_stride);
+	}
+	free(lp);
+}
+
 /* =============================================================== rx_sdr output formats, rx_fm WAV header */
 
 /* rtl_sdr.c:368-370.  The fp64 sum reaches 128 for x >= 32665, which an int8 cannot hold; the reference

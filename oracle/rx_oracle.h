@@ -118,6 +118,9 @@ typedef struct rxo_chan_cfg {
 /* one callback block of len int16 (len/2 % N == 0): out[c * out_stride + w] for its len/2/N windows;
  * pre[2*c], pre[2*c+1] = the channel's carried pre_r, pre_j; work: 2*N int16 + n_channels*2*windows int16 */
 void rxo_chan_block(const rxo_chan_cfg *cfg, const int16_t *in, int len, int *pre, int16_t *out, size_t out_stride);
+/* the same interface for SURVEY 8(f)2's literal definition: callback scale -> integer NCO (Sinewave table, FIX_MPY per product) ->
+ * low_pass at downsample N -> fm_demod, per channel (rx_oracle.c) */
+void rxo_chan_nco_block(const rxo_chan_cfg *cfg, const int16_t *in, int len, int *pre, int16_t *out, size_t out_stride);
 
 /* --------------------------------------------------------------- rx_power */
 

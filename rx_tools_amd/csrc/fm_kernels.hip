@@ -3234,6 +3234,51 @@ __global__ __launch_bounds__(256) void k_ch_fftR(const uint32_t *__restrict__ iq
 	}
 }
 
+// The channeliser's second definition (SURVEY 8(f)2 to the letter; rxgpu_chan_params.nco): per channel an integer NCO, then low_pass
+// (rtl_fm.c:351-371) at downsample = N.  The capture goes through the callback's scale (rtl_fm.c:845-848, no rotation); sample n of a
+// window is multiplied by e^(-j 2 pi k n / N), k = (first_bin + c) mod N, with cos / sin from the reference's Sinewave table (nco_tw: the
+// full period as packed (cos, sin), built on the host) and each of the four products rounded by FIX_MPY (rtl_power.c:256-262); low_pass
+// sums the N mixed samples of a window in int and stores the sum as int16.  |scaled sample| <= 128, so a FIX_MPY result is at most 128 in
+// magnitude and a mixed component 256: nothing wraps before low_pass's own int16 store.  One thread per channel, the window and the
+// table in LDS (the sample is a broadcast read, the table index k * n mod N differs per lane): N^2-ish work -- 256 channels of 1024 cost
+// ~50 times the fix_fft bank's butterflies -- which is why the bank is the default; this mode exists because the survey named it.
+template <int DUMMY = 0>
+__global__ __launch_bounds__(256) void k_ch_nco(const uint32_t *__restrict__ iq, u64 total_windows, int bin_e, const uint32_t *__restrict__ tw_full,
+                                                int first_bin, int n_channels, uint32_t *__restrict__ chan_lp, int wpg)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t nco_sm[];      // [N] scaled window, [N] table
+	const int n = 1 << bin_e;
+	uint32_t *xs = nco_sm, *tw = nco_sm + n;
+	for (int i = threadIdx.x; i < n; i += 256)
+		tw[i] = tw_full[i];
+	const unsigned c = blockIdx.y * 256u + threadIdx.x;
+	const unsigned k = ((unsigned)first_bin + c) & (unsigned)(n - 1);
+	for (int wi = 0; wi < wpg; wi++) {
+		const u64 w = (u64)blockIdx.x * wpg + wi;
+		if (w >= total_windows)
+			break;
+		__syncthreads();
+		for (int i = threadIdx.x; i < n; i += 256) {
+			const uint32_t v = iq[(w << bin_e) + i];
+			xs[i] = pack_iq(scale_cs16(lo16(v)), scale_cs16(hi16(v)));
+		}
+		__syncthreads();
+		int sr = 0, sj = 0;
+		unsigned p = 0;
+		for (int i = 0; i < n; i++) {
+			const uint32_t x = xs[i], t = tw[p];
+			p = (p + k) & (unsigned)(n - 1);
+			const int xr = lo16(x), xi = hi16(x), co = lo16(t), si = hi16(t);
+			const int rc = (xr * co + 16384) >> 15, is = (xi * si + 16384) >> 15;       // FIX_MPY: ((a*b >> 14) + 1) >> 1
+			const int ic = (xi * co + 16384) >> 15, rs = (xr * si + 16384) >> 15;
+			sr += rc + is;
+			sj += ic - rs;
+		}
+		if (c < (unsigned)n_channels)
+			chan_lp[(u64)c * total_windows + w] = pack_iq(sr, sj);                  // low_pass's int16 stores
+	}
+}
+
 // fm_demod (rtl_fm.c:584-615) per channel: thread (c, t); the first window of every callback block
 // goes through the libm discriminator like every block's first sample does in rx_fm
 // sparse = group size of k_ch_fftR<FUSED> (0: dense): only the first window of every group, thread (c, group)
@@ -4040,6 +4085,20 @@ extern "C" int rxk_ch_fft(void *stream, const int16_t *iq, u64 total_windows, in
 	const unsigned grid = (unsigned)((total_windows + wpg - 1) / wpg);
 	hipLaunchKernelGGL(k_ch_fft, dim3(grid), dim3(256), shm, (hipStream_t)stream, (const uint32_t *)iq, total_windows, bin_e, wpg,
 	                   twiddle, first_bin, n_channels, chan_lp);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_ch_nco(void *stream, const int16_t *iq, u64 total_windows, int bin_e, const uint32_t *tw_full, int first_bin, int n_channels,
+                          uint32_t *chan_lp)
+{
+	if (!total_windows)
+		return 0;
+	const int wpg = 4;
+	const size_t shm = (size_t)2 * ((size_t)1 << bin_e) * 4;
+	if (shm > 64 * 1024)
+		(void)hipFuncSetAttribute((const void *)k_ch_nco<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+	hipLaunchKernelGGL(k_ch_nco<0>, dim3((unsigned)((total_windows + wpg - 1) / wpg), (unsigned)((n_channels + 255) / 256)), dim3(256), shm, (hipStream_t)stream,
+	                   (const uint32_t *)iq, total_windows, bin_e, tw_full, first_bin, n_channels, chan_lp, wpg);
 	LAUNCH_RET();
 }
 

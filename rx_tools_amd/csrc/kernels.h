@@ -226,6 +226,9 @@ int rxk_fm_prestage(void *stream, const int16_t *in, unsigned n_complex, int rot
 int rxk_ch_fused_ok(int bin_e, unsigned long long wpb, int custom_atan, int n_channels);   /* 0, or the group size to pass as `fused` / `sparse` */
 int rxk_ch_fft(void *stream, const int16_t *iq, unsigned long long total_windows, int bin_e, const uint32_t *twiddle,
                int first_bin, int n_channels, uint32_t *chan_lp, int fused, int16_t *out, unsigned long long out_stride, int *pre_out);
+/* the NCO mode of the channeliser: chan_lp[c][w] = low_pass at downsample N of the scaled capture mixed by channel c's NCO; tw_full: N packed (cos, sin) */
+int rxk_ch_nco(void *stream, const int16_t *iq, unsigned long long total_windows, int bin_e, const uint32_t *tw_full, int first_bin, int n_channels,
+               uint32_t *chan_lp);
 int rxk_ch_demod(void *stream, const uint32_t *chan_lp, unsigned long long total_windows, unsigned long long wpb, int n_channels,
                  int custom_atan, const int *pre_in, int *pre_out, int16_t *out, unsigned long long out_stride,
                  rxk_fm_dev *dev, unsigned long long *flag_list, int sparse);

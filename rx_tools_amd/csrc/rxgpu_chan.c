@@ -16,6 +16,7 @@ struct rxgpu_chan {
 	rxgpu_chan_params p;
 	size_t max_windows;
 	uint32_t *twiddle_dev, *chan_lp;
+	uint32_t *nco_tw_dev;            /* p.nco: the full period of the NCO, N packed (cos, sin) from the reference's Sinewave table */
 	int *pre_dev[2];                 /* carried (pre_r, pre_j) per channel: in / out */
 	int *pre_host;
 	int *audio_dev[2], *audio_host;  /* per channel {deemph avg, now_lpr, prev_lpr_index}: in / out */
@@ -44,6 +45,10 @@ int rxgpu_chan_create(rxgpu_chan **out, const rxgpu_chan_params *p, size_t max_b
 		return rxgpu_fail(RXGPU_EINVAL, "deemph_a %d < 1", p->deemph_a);
 	if (p->rate_out2 > 0 && (p->rate_out < p->rate_out2 || p->rate_out <= 0))
 		return rxgpu_fail(RXGPU_EUNSUPPORTED, "low_pass_real needs rate_out >= rate_out2 > 0 (got %d, %d)", p->rate_out, p->rate_out2);
+	if (p->nco != 0 && p->nco != 1)
+		return rxgpu_fail(RXGPU_EINVAL, "nco %d is neither 0 (bins of fix_fft) nor 1 (NCO -> low_pass)", p->nco);
+	if (p->nco && (p->bin_e < 3 || p->bin_e > 12))
+		return rxgpu_fail(RXGPU_EUNSUPPORTED, "NCO mode: windows of 2^3 .. 2^12 samples (window and table are staged in LDS)");
 	if ((rc = rxgpu_ensure_init()) != RXGPU_OK)
 		return rc;
 	rxgpu_knobs_reload();                            /* the object keeps the kernel variants chosen now */
@@ -73,6 +78,20 @@ int rxgpu_chan_create(rxgpu_chan **out, const rxgpu_chan_params *p, size_t max_b
 		return rxgpu_fail(RXGPU_ENOMEM, "channeliser workspace allocation failed");
 	}
 	free(tw);
+	if (p->nco) {
+		/* cos(t) = sin(t + pi/2); the table holds 3/4 of a period (rtl_power.c:240-254): the second half period is the first, negated */
+		uint32_t *full = malloc(n * 4);
+		if (!full) { rxgpu_chan_destroy(s); return rxgpu_fail(RXGPU_ENOMEM, "out of host memory"); }
+		for (size_t q = 0; q < n; q++) {
+			const size_t h = n / 2, r = q & (h - 1);
+			int co = sinewave[r + n / 4], si = sinewave[r];
+			if (q >= h) { co = -co; si = -si; }
+			full[q] = ((uint32_t)co & 0xffffu) | ((uint32_t)si << 16);
+		}
+		const int bad = hipMalloc((void **)&s->nco_tw_dev, n * 4) != hipSuccess || hipMemcpy(s->nco_tw_dev, full, n * 4, hipMemcpyHostToDevice) != hipSuccess;
+		free(full);
+		if (bad) { rxgpu_chan_destroy(s); return rxgpu_fail(RXGPU_ENOMEM, "channeliser workspace allocation failed"); }
+	}
 	memset(s->pre_host, 0, nc * 8);
 	memset(s->audio_host, 0, nc * 12);
 	*out = s;
@@ -83,7 +102,7 @@ void rxgpu_chan_destroy(rxgpu_chan *s)
 {
 	if (!s)
 		return;
-	hipFree(s->twiddle_dev); hipFree(s->chan_lp); hipFree(s->pre_dev[0]); hipFree(s->pre_dev[1]);
+	hipFree(s->twiddle_dev); hipFree(s->nco_tw_dev); hipFree(s->chan_lp); hipFree(s->pre_dev[0]); hipFree(s->pre_dev[1]);
 	hipFree(s->audio_dev[0]); hipFree(s->audio_dev[1]); hipFree(s->audio_y);
 	if (s->audio_host) hipHostFree(s->audio_host);
 	hipFree(s->dev); hipFree(s->flag_list);
@@ -168,10 +187,13 @@ int rxgpu_chan_run(rxgpu_chan *s, const int16_t *d_iq, size_t n_blocks, size_t b
 	RX_HIP(hipMemcpyAsync(s->dev, h, sizeof(*h), hipMemcpyHostToDevice, st));
 	RX_HIP(hipMemcpyAsync(s->pre_dev[0], s->pre_host, nc * 8, hipMemcpyHostToDevice, st));
 	/* -A fast with whole groups of windows per block: fm_demod runs inside the FFT kernel for all but each group's first window */
-	const int fused = rxk_ch_fused_ok(s->p.bin_e, wpb, s->p.custom_atan, s->p.n_channels);
+	const int fused = s->p.nco ? 0 : rxk_ch_fused_ok(s->p.bin_e, wpb, s->p.custom_atan, s->p.n_channels);
 	rxgpu_prof_begin("ch_fft");
-	RX_K(rxk_ch_fft(st, d_iq, total, s->p.bin_e, s->twiddle_dev, s->p.first_bin, s->p.n_channels, s->chan_lp, fused, d_out, out_stride,
-	                s->pre_dev[1]));
+	if (s->p.nco)                                         /* SURVEY 8(f)2's literal definition: NCO -> low_pass at downsample N, per channel */
+		RX_K(rxk_ch_nco(st, d_iq, total, s->p.bin_e, s->nco_tw_dev, s->p.first_bin, s->p.n_channels, s->chan_lp));
+	else
+		RX_K(rxk_ch_fft(st, d_iq, total, s->p.bin_e, s->twiddle_dev, s->p.first_bin, s->p.n_channels, s->chan_lp, fused, d_out, out_stride,
+		                s->pre_dev[1]));
 	rxgpu_prof_end("ch_fft");
 	rxgpu_prof_begin("ch_demod");
 	RX_K(rxk_ch_demod(st, s->chan_lp, total, wpb, s->p.n_channels, s->p.custom_atan, s->pre_dev[0], s->pre_dev[1], d_out, out_stride,

@@ -120,7 +120,7 @@ class FmStream:
 
 class ChanParams(C.Structure):
     """struct rxgpu_chan_params (channeliser extension, include/rxgpu.h)"""
-    _fields_ = [(n, C.c_int) for n in ("bin_e", "first_bin", "n_channels", "custom_atan", "deemph", "deemph_a", "rate_out", "rate_out2")]
+    _fields_ = [(n, C.c_int) for n in ("bin_e", "first_bin", "n_channels", "custom_atan", "deemph", "deemph_a", "rate_out", "rate_out2", "nco")]
 
 
 class Channeliser:

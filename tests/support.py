@@ -391,3 +391,72 @@ def oracle_chan_stream_compare(iq, block_len, bin_e, first_bin, n_channels, cust
         if first_bad < 0 and not np.array_equal(tmp, compare[:, b * wpb:(b + 1) * wpb]):
             first_bad = b
     return first_bad, pre, None
+
+
+# ---- the channeliser's NCO mode (SURVEY 8(f)2's literal definition)
+
+def oracle_chan_nco_stream(iq, block_len, bin_e, first_bin, n_channels, custom_atan, pre=None):
+    """rxo_chan_nco_block callback block after callback block: (out [n_channels][windows], pre)"""
+    import rx_tools_amd as R
+    O = oracle()
+    O.rxo_chan_nco_block.argtypes = [C.POINTER(ChanCfg), i16p, C.c_int, intp, i16p, C.c_size_t]
+    O.rxo_chan_nco_block.restype = None
+    sw = R.sine_table(bin_e)
+    cfg = ChanCfg(bin_e, first_bin, n_channels, custom_atan, ptr16(sw))
+    wpb = block_len // 2 >> bin_e
+    n_blocks = len(iq) // block_len
+    pre = np.zeros(2 * n_channels, np.int32) if pre is None else np.array(pre, np.int32)
+    out = np.zeros((n_channels, n_blocks * wpb), np.int16)
+    tmp = np.zeros((n_channels, wpb), np.int16)
+    for b in range(n_blocks):
+        O.rxo_chan_nco_block(C.byref(cfg), ptr16(np.ascontiguousarray(iq[b * block_len:(b + 1) * block_len])), block_len, pre.ctypes.data_as(intp), ptr16(tmp), wpb)
+        out[:, b * wpb:(b + 1) * wpb] = tmp
+    return out, pre
+
+
+def ref_chan_nco_stream(iq, block_len, bin_e, first_bin, n_channels, custom_atan, pre=None):
+    """The same through reference-built code wherever the reference has code for it: the callback's scale by the reference's own
+    rtlsdr_callback (ref_fm_scale_block), the Sinewave table by its own sine_table, the decimation and the demodulation by its own
+    full_demod with downsample = N (low_pass, fm_demod) per channel on its global demod_state.  Only the mixer between them is not the
+    reference's -- it has none: numpy, with FIX_MPY written out ((a * b >> 14) + 1) >> 1 and checked against the reference's FIX_MPY."""
+    P, F = ref_power(), ref_fm()
+    n = 1 << bin_e
+    P.sine_table.argtypes = [C.c_int]
+    P.sine_table(bin_e)
+    sw = np.ctypeslib.as_array(P.ref_power_sinewave(), shape=(3 * n // 4,)).astype(np.int32)
+    F.ref_fm_scale_block.argtypes = [i16p, C.c_uint32, i16p]
+    F.ref_fm_scale_block.restype = None
+    F.ref_fm_chan_block_mixed.argtypes = [i16p, C.c_int, C.c_int, C.c_int, C.c_int, intp, i16p, C.c_size_t]
+    wpb = block_len // 2 >> bin_e
+    n_blocks = len(iq) // block_len
+    pre = np.zeros(2 * n_channels, np.int32) if pre is None else np.array(pre, np.int32)
+
+    def fix_mpy(a, b):
+        return ((((a * b) >> 14) + 1) >> 1).astype(np.int16).astype(np.int32)
+    rs = np.random.RandomState(3)
+    for a, b in zip(rs.randint(-32768, 32768, 64), rs.randint(-32768, 32768, 64)):
+        assert int(fix_mpy(np.int32(a), np.int32(b))) == P.FIX_MPY(int(a), int(b))
+    idx = np.arange(n)
+    h = n // 2
+    out = np.zeros((n_channels, n_blocks * wpb), np.int16)
+    tmp = np.zeros((n_channels, wpb), np.int16)
+    scaled = np.zeros(block_len, np.int16)
+    mixed = np.zeros((n_channels, block_len), np.int16)
+    for b in range(n_blocks):
+        F.ref_fm_scale_block(ptr16(np.ascontiguousarray(iq[b * block_len:(b + 1) * block_len])), block_len, ptr16(scaled))
+        xr = scaled[0::2].astype(np.int32).reshape(wpb, n)
+        xi = scaled[1::2].astype(np.int32).reshape(wpb, n)
+        for c in range(n_channels):
+            k = (first_bin + c) & (n - 1)
+            p = (k * idx) & (n - 1)
+            q = p & (h - 1)
+            co = np.where(p >= h, -sw[q + n // 4], sw[q + n // 4])
+            si = np.where(p >= h, -sw[q], sw[q])
+            yr = (fix_mpy(xr, co) + fix_mpy(xi, si)).astype(np.int16)
+            yi = (fix_mpy(xi, co) - fix_mpy(xr, si)).astype(np.int16)
+            mixed[c, 0::2] = yr.reshape(-1)
+            mixed[c, 1::2] = yi.reshape(-1)
+        k = F.ref_fm_chan_block_mixed(ptr16(mixed), n_channels, wpb, n, custom_atan, pre.ctypes.data_as(intp), ptr16(tmp), wpb)
+        assert k == wpb, "ref_fm_chan_block_mixed: %d" % k
+        out[:, b * wpb:(b + 1) * wpb] = tmp
+    return out, pre

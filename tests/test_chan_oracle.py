@@ -62,7 +62,7 @@ def test_block_structure_and_carry():
 # ----------------------------------------------------------------------------- pinned against the reference itself
 
 import pytest                                                      # noqa: E402
-from support import have_ref, oracle_chan_stream, ref_chan_stream, sig_fm, sig_noise    # noqa: E402
+from support import have_ref, oracle_chan_stream, ref_chan_stream, oracle_chan_nco_stream, ref_chan_nco_stream, sig_fm, sig_noise    # noqa: E402
 
 skip_without_ref = pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built (needs /root/reference)")
 
@@ -110,3 +110,33 @@ def test_chan_audio_oracle_equals_reference_built_chain(bin_e, n_channels, block
     a2, p2, s2 = ref_chan_stream(iq[half:], block_len, bin_e, 5, n_channels, custom_atan, pre=p1, audio=s1, **kw)
     assert np.array_equal(np.concatenate([a1, a2], axis=1), want) and np.array_equal(p2, want_pre) and np.array_equal(s2, want_state)
 
+
+
+NCO_GEOMETRIES = [(6, 10, 24, 2 * 1024, 3), (8, 200, 64, 2 * 4096, 4), (10, 384, 16, 2 * 8192, 2), (5, 0, 32, 2 * 256, 5), (12, 4000, 6, 2 * 8192, 2)]
+
+
+@pytest.mark.ref
+@skip_without_ref
+@pytest.mark.parametrize("bin_e,first_bin,n_channels,block_len,n_blocks", NCO_GEOMETRIES)
+@pytest.mark.parametrize("custom_atan", [1, 0])
+def test_chan_nco_oracle_equals_reference_built_chain(bin_e, first_bin, n_channels, block_len, n_blocks, custom_atan):
+    """SURVEY 8(f)2's literal definition (rxo_chan_nco_block) == [the reference's callback scale] -> [NCO on its Sinewave table, products
+    rounded by its FIX_MPY] -> [the reference's full_demod at downsample N: low_pass + fm_demod] per channel: every sample, every carry"""
+    for iq in (sig_fm(n_blocks * block_len // 2, seed=91, amp=9000), sig_noise(n_blocks * block_len, seed=92)):
+        want, want_pre = ref_chan_nco_stream(iq, block_len, bin_e, first_bin, n_channels, custom_atan)
+        got, pre = oracle_chan_nco_stream(iq, block_len, bin_e, first_bin, n_channels, custom_atan)
+        bad = np.argwhere(got != want)
+        assert bad.size == 0, "first mismatch at %s: port %d reference %d (%d bad)" % (bad[0], got[tuple(bad[0])], want[tuple(bad[0])], len(bad))
+        assert np.array_equal(pre, want_pre)
+
+
+def test_nco_mode_sees_the_same_channels_as_the_bank():
+    """the two definitions are the same filter bank in two fixed-point roundings: an unmodulated carrier at bin k lands in channel k of
+    both, and a phase step per window comes out of both discriminators as the same frequency (to the rounding)"""
+    n, k = 256, 77
+    dphi = 0.4
+    iq = tone(n, k, 40, 6000, dphi)
+    a, _ = run(iq, 8, 70, 16, 0)
+    b, _ = oracle_chan_nco_stream(iq, len(iq), 8, 70, 16, 0)
+    want = dphi / 3.14159 * 16384
+    assert np.all(np.abs(a[7, 2:] - want) < 80) and np.all(np.abs(b[7, 2:] - want) < 400)

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import rx_tools_amd as R
-from support import oracle, sig_fm, sig_noise, ptr16, i16p, intp, have_ref, ref_chan_stream
+from support import oracle, sig_fm, sig_noise, ptr16, i16p, intp, have_ref, ref_chan_stream, oracle_chan_nco_stream, ref_chan_nco_stream
 
 pytestmark = pytest.mark.gpu
 
@@ -167,3 +167,77 @@ def test_channeliser_per_channel_audio_stages(bin_e, n_channels, block_len, n_bl
     bad = np.argwhere(state != want_state)
     assert bad.size == 0, "first differing carries (channel, field): %s got %s want %s" % (bad[:5].tolist(), state[bad[:5, 0]].tolist(), want_state[bad[:5, 0]].tolist())
     ch.close()
+
+
+# ----------------------------------------------------------------------------- round 4: the NCO -> low_pass mode (SURVEY 8(f)2's literal definition)
+
+@pytest.mark.parametrize("bin_e,first_bin,n_channels,block_len,n_blocks", [
+    (10, 384, 256, 2 * 8192, 3),          # the configs[4] bank, eight windows per block
+    (8, 200, 64, 2 * 4096, 4),            # channels wrapping through bin 0
+    (6, 10, 24, 2 * 1024, 3),
+    (10, 0, 700, 2 * 2048, 2),            # more channels than a workgroup has threads
+    (12, 4000, 6, 2 * 8192, 2),           # the largest window of this mode
+    (3, 1, 5, 2 * 64, 6),
+])
+@pytest.mark.parametrize("custom_atan", [1, 0])
+def test_channeliser_nco_mode_bit_exact(bin_e, first_bin, n_channels, block_len, n_blocks, custom_atan):
+    """rxgpu_chan_params.nco = 1: callback scale -> per-channel integer NCO -> low_pass at downsample N -> fm_demod, against the oracle's
+    restatement and (where oracle/_ref travels) the reference-built chain; full-scale noise included (low_pass's int16 store wraps)"""
+    from gpu_support import to_dev, torch_cuda
+    torch = torch_cuda()
+    n = 1 << bin_e
+    wpb = block_len // 2 // n
+    for iq in (sig_fm(n_blocks * block_len // 2, seed=93, amp=9000), sig_noise(n_blocks * block_len, seed=94)):
+        want, want_pre = oracle_chan_nco_stream(iq, block_len, bin_e, first_bin, n_channels, custom_atan)
+        per = (n_blocks + 1) // 2                               # two runs: the carries cross a run boundary
+        ch = R.Channeliser(R.ChanParams(bin_e, first_bin, n_channels, custom_atan, 0, 0, 0, -1, 1), per, block_len, R.sine_table(bin_e))
+        d_iq = to_dev(iq)
+        outs, b = [], 0
+        while b < n_blocks:
+            nb = min(per, n_blocks - b)
+            d_out = torch.zeros((n_channels, nb * wpb), dtype=torch.int16, device="cuda")
+            w = ch.run(d_iq.data_ptr() + b * block_len * 2, nb, block_len, d_out.data_ptr(), nb * wpb)
+            assert w == nb * wpb
+            outs.append(d_out.cpu().numpy())
+            b += nb
+        got, pre = np.concatenate(outs, axis=1), ch.get_carry()
+        ch.close()
+        bad = np.argwhere(got != want)
+        assert bad.size == 0, "first mismatch at %s: got %d want %d (%d bad)" % (bad[0], got[tuple(bad[0])], want[tuple(bad[0])], len(bad))
+        assert np.array_equal(pre, want_pre)
+        if have_ref() and n_channels <= 256:
+            ref_out, ref_pre = ref_chan_nco_stream(iq, block_len, bin_e, first_bin, n_channels, custom_atan)
+            assert np.array_equal(got, ref_out) and np.array_equal(pre, ref_pre)
+
+
+def test_channeliser_nco_mode_with_audio_stages_and_limits():
+    """the per-channel audio stages behind the NCO mode are the bank's; windows beyond 2^12 and nco values other than 0/1 are refused"""
+    from gpu_support import to_dev, torch_cuda
+    from support import oracle
+    torch = torch_cuda()
+    bin_e, n_channels, block_len, n_blocks = 8, 32, 2 * 65536, 3
+    iq = sig_noise(n_blocks * block_len, seed=95, amp=6000)
+    dem, _ = oracle_chan_nco_stream(iq, block_len, bin_e, 5, n_channels, 1)
+    O = oracle()
+    O.rxo_deemph.argtypes = [i16p, C.c_int, C.c_int, intp]
+    O.rxo_low_pass_real.argtypes = [i16p, C.c_int, C.c_int, C.c_int, intp, intp]
+    wpb = block_len // 2 >> bin_e
+    want = []
+    for c in range(n_channels):
+        avg, now, idx = C.c_int(0), C.c_int(0), C.c_int(0)
+        rows = []
+        for b in range(n_blocks):
+            row = np.ascontiguousarray(dem[c, b * wpb:(b + 1) * wpb])
+            O.rxo_deemph(ptr16(row), wpb, 13, C.byref(avg))
+            k = O.rxo_low_pass_real(ptr16(row), wpb, 170000, 32000, C.byref(now), C.byref(idx))
+            rows.append(row[:k].copy())
+        want.append(np.concatenate(rows))
+    want = np.stack(want)
+    ch = R.Channeliser(R.ChanParams(bin_e, 5, n_channels, 1, 1, 13, 170000, 32000, 1), n_blocks, block_len, R.sine_table(bin_e))
+    d_out = torch.zeros((n_channels, n_blocks * wpb), dtype=torch.int16, device="cuda")
+    w = ch.run(to_dev(iq).data_ptr(), n_blocks, block_len, d_out.data_ptr(), n_blocks * wpb)
+    ch.close()
+    assert w == want.shape[1] and np.array_equal(d_out[:, :w].cpu().numpy(), want)
+    for bad in (R.ChanParams(13, 0, 4, 1, 0, 0, 0, -1, 1), R.ChanParams(8, 0, 4, 1, 0, 0, 0, -1, 2)):
+        with pytest.raises(R.RxGpuError):
+            R.Channeliser(bad, 1, 2 * (1 << bad.bin_e), R.sine_table(bad.bin_e))
