@@ -960,8 +960,9 @@ def main():
         windows = T >> bin_e
         d_out = torch.zeros((n_ch, windows), dtype=torch.int16, device=dev)
         ch = R.Channeliser(R.ChanParams(bin_e, 384, n_ch, 1), n_blocks, block_len, R.sine_table(bin_e))
-        steps = max(5, args.steps // 5)
-        for _ in range(max(1, args.warmup // 3)):
+        steps = max(20, args.steps)
+        # 0.6 ms per run: the clocks of an idle part take some ten milliseconds of load to settle (the first launches after a pause measured 10 % slower)
+        for _ in range(max(40, args.warmup)):
             ch.run(d_iq.data_ptr(), n_blocks, block_len, d_out.data_ptr(), windows)
         L.rxgpu_prof_reset()
         L.rxgpu_prof_enable(args.prof_level)

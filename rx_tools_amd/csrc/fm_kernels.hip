@@ -3143,25 +3143,41 @@ __global__ __launch_bounds__(256) void k_ch_fft(const uint32_t *__restrict__ iq,
 // window, 256/(N/16) windows side by side, CH_WPG windows per workgroup so that every channel's
 // outputs leave as one contiguous segment.
 // windows per workgroup: 32 while the [n_channels][wpg] staging fits beside the transform buffers, else 16
-static inline int ch_wpg(int n_channels)
+static inline int ch_wpg(int bin_e)
 {
-	const char *e = rxgpu_knob("RXGPU_CH_WPG");                  /* 16 | 32: A/B of the window group (LDS per workgroup vs work of the sparse demodulator pass) */
-	if (e && (atoi(e) == 16 || atoi(e) == 32))
-		return atoi(e);
-	(void)n_channels;
+	const char *e = rxgpu_knob("RXGPU_CH_WPG");                  /* 8 | 16 | 32: A/B of the window group (LDS per workgroup vs length of the segments written) */
+	const int w = e ? atoi(e) : 0;
+	if (w == 16 || w == 32 || (w == 8 && bin_e >= 9))        /* a group holds at least the windows of one pass over the workgroup: 16 for N = 256 */
+		return w;
 	return 16;                                               /* round 3, 256 channels: 387-392 GS/s with 16 windows per group, 367-375 with 32 */
 }
-// FUSED: also fm_demod (-A fast) for every window but the workgroup's first, straight from the LDS copy of the bins; then
-// only the entries k_ch_demod(sparse) reads are stored in chan_lp (each group's first and last window).  Needs the
-// callback blocks to be whole groups of CH_WPG windows, so that a block's first (libm) window is a group's first.
-template <int M, bool FUSED, bool TWL = true>
+// groups of WPG windows a workgroup walks (round 4): the twiddle copy, the slot arithmetic and the addresses are set up once per run of
+// WPG * GPW windows, and the last window of a group stays in LDS as the next group's predecessor -- only a RUN's first window is left to
+// k_ch_demod(sparse).  The largest of 8, 4, 2, 1 (default 4, $RXGPU_CH_GPW) that divides the callback block's windows.
+static inline int ch_gpw(int wpg, u64 wpb)
+{
+	const char *e = rxgpu_knob("RXGPU_CH_GPW");
+	int g = e && atoi(e) >= 1 && atoi(e) <= 8 ? atoi(e) : 4;
+	while (g > 1 && (g & (g - 1)))
+		g--;
+	while (g > 1 && wpb % (u64)(wpg * g))
+		g >>= 1;
+	return g;
+}
+// FUSED: also fm_demod (-A fast) for every window but the run's first, straight from the LDS copy of the bins; then
+// only the entries k_ch_demod(sparse) reads are stored in chan_lp (each run's first and last window).  Needs the
+// callback blocks to be whole runs of WPG * GPW windows, so that a block's first (libm) window is a run's first.
+// Staging rows: [channel][1 + WPG] -- column 0 holds the previous group's last window -- padded to WPG + 3 dwords (odd: the 64 channels a
+// wave's store touches fall on 32 banks twice, not on two banks).  The tail's thread (c, k) keeps its window k for every channel it visits:
+// its pointers advance by a constant, nothing is divided.
+template <int M, bool FUSED, bool TWL = true, int WPG = 16>
 __global__ __launch_bounds__(256) void k_ch_fftR(const uint32_t *__restrict__ iq, u64 total_windows,
                                                  const uint32_t *__restrict__ twiddle, int first_bin, int n_channels,
                                                  uint32_t *__restrict__ chan_lp, int16_t *__restrict__ out, u64 out_stride,
-                                                 int *__restrict__ pre_out, int CH_WPG)
+                                                 int *__restrict__ pre_out, int GPW)
 {
 	typedef fft_geom<M> G;
-	constexpr int N = G::N, TPF = G::TPF, FPW = 256 / TPF;
+	constexpr int N = G::N, TPF = G::TPF, FPW = 256 / TPF, S = WPG + 3, CPI = 256 / WPG;
 	// N <= 1024: a window's N/16 threads are lanes of one wave, its transposes need no workgroup barrier (fft_sync) and -- a wave's LDS
 	// instructions being in order -- no second transpose area either: 20 KB less LDS per workgroup, and the four waves run their windows
 	// without waiting for each other (round 2: 72 KB and three barriers per window group left two barrier-coupled waves per SIMD)
@@ -3169,68 +3185,93 @@ __global__ __launch_bounds__(256) void k_ch_fftR(const uint32_t *__restrict__ iq
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 	uint32_t *xa = lds, *xb = WAVE ? lds : lds + 256 * G::XROW;
 	uint32_t *tl = lds + (WAVE ? 1 : 2) * 256 * G::XROW;     // the permuted twiddle copy (fft_device.h), G::TW_WORDS dwords
-	uint32_t *outt = tl + G::TW_WORDS;                      // [n_channels][CH_WPG]
+	uint32_t *outt = tl + G::TW_WORDS;                      // [n_channels][S]
 	const int tid = threadIdx.x, fid = tid / TPF;
 	const unsigned tq = tid % TPF;
-	const u64 w0 = (u64)blockIdx.x * CH_WPG;
+	const int RUN = WPG * GPW;
+	// XCD-contiguous order: workgroup b runs on XCD b % 8, every XCD takes one contiguous eighth of the capture -- the 32-byte pieces that
+	// neighbouring runs write into a channel's row then meet in ONE L2
+	const unsigned per = gridDim.x >> 3, run_i = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+	const u64 w0 = (u64)run_i * RUN;
+	if (w0 >= total_windows)
+		return;
+	const u64 w_last = total_windows - 1;
 	fft_tw_fill<M>(tl, twiddle, tid, 256);
 	unsigned ta[3][4];
 	fft_tw_addr_all<M>(tq, ta);
-	// the next group of windows is requested while this one is transformed (round 4)
+	// the next windows are requested while these are transformed (round 4); past the capture's end the last window again (never stored)
 	uint32_t nxt[16];
 	{
-		const u64 w = w0 + fid;
+		const u64 w = w0 + fid < w_last ? w0 + fid : w_last;
+		const uint32_t *src = iq + (w << M) + tq;
 #pragma unroll
 		for (int r = 0; r < 16; r++)
-			nxt[r] = w < total_windows ? iq[(w << M) + tq + r * TPF] : 0u;
+			nxt[r] = src[r * TPF];
 	}
+	const int k = tid & (WPG - 1), c0 = tid / WPG;
 	__syncthreads();                                        // the twiddle copy
-	for (int it = 0; it < CH_WPG; it += FPW) {
+#pragma unroll 1
+	for (int it = 0; it < RUN; it += FPW) {
 		uint32_t v[16];
 #pragma unroll
 		for (int r = 0; r < 16; r++)
 			v[r] = nxt[r];
-		if (it + FPW < CH_WPG) {
-			const u64 w = w0 + it + FPW + fid;
+		if (it + FPW < RUN) {
+			const u64 wn = w0 + it + FPW + fid, w = wn < w_last ? wn : w_last;
+			const uint32_t *src = iq + (w << M) + tq;
 #pragma unroll
 			for (int r = 0; r < 16; r++)
-				nxt[r] = w < total_windows ? iq[(w << M) + tq + r * TPF] : 0u;
+				nxt[r] = src[r * TPF];
 		}
 		fft_reg<M, !WAVE, TWL>(v, tq, xa + fid * TPF * G::XROW, xb + fid * TPF * G::XROW, twiddle, tl, ta);
-		// (hoisting the slot arithmetic -- a bit reversal, a multiply, a compare per register -- out of the window loop, with a wave-uniform
-		// skip of registers nobody needs, measured 0-3 % SLOWER in one process: 16 more live VGPRs for nothing the scheduler could not hide)
+		const int col = (it & (WPG - 1)) + fid + 1;
 #pragma unroll
 		for (int r = 0; r < 16; r++) {
 			const unsigned bin = __brev((tq << 4) | (unsigned)r) >> (32 - M);
 			const unsigned c = (bin - (unsigned)first_bin) & (N - 1);
 			if (c < (unsigned)n_channels)
-				outt[c * (CH_WPG + 1) + it + fid] = v[r];          // rows of CH_WPG + 1: the 64 channels a wave's store touches fall on 32 banks twice, not on two banks
+				outt[c * S + col] = v[r];
 		}
-	}
-	__syncthreads();
-	for (int idx = tid; idx < n_channels * CH_WPG; idx += 256) {
-		const int c = idx >> (31 - __clz(CH_WPG)), k = idx & (CH_WPG - 1);       // CH_WPG is 16 or 32
-		const u64 w = w0 + k;
-		if (w >= total_windows)
+		const bool run_done = w0 + it + FPW >= total_windows;    // workgroup-uniform: a ragged last run (never in FUSED form)
+		if (((it + FPW) & (WPG - 1)) && !run_done)
 			continue;
-		const uint32_t a = outt[idx + c];                    // = c * (CH_WPG + 1) + k
-		if (!FUSED) {
-			chan_lp[(u64)c * total_windows + w] = a;
-			continue;
+		// a group is complete
+		__syncthreads();
+		const int g = it / WPG;                                 // (it + FPW) / WPG - 1
+		const u64 w = w0 + (u64)g * WPG + k;
+		if (w < total_windows) {
+			const bool run_first = g == 0 && k == 0;
+			const bool run_last = k == WPG - 1 && g == GPW - 1;
+			const bool keep = !FUSED || run_first || run_last;
+			const bool last = w == w_last;
+			// FUSED: only what k_ch_demod(sparse) reads is kept, compact: [channel][run] first windows, then [channel][run] last windows
+			const u64 n_runs = total_windows / (u64)RUN, lp_stride = FUSED ? n_runs : total_windows;
+			uint32_t *lp = chan_lp + (u64)c0 * lp_stride + (FUSED ? (run_last ? (u64)n_channels * n_runs : 0) + run_i : w);
+			int16_t *o = out + (u64)c0 * out_stride + w;
+			const uint32_t *row = outt + c0 * S + k;
+			for (int c = c0; c < n_channels; c += CPI, lp += (u64)CPI * lp_stride, o += (u64)CPI * out_stride, row += CPI * S) {
+				const uint32_t a = row[1];
+				if (keep)
+					*lp = a;
+				if (!FUSED)
+					continue;
+				const uint32_t b = row[0];
+				if (last) {                                         // fm_demod's carry, rtl_fm.c:612-613
+					pre_out[2 * c] = lo16(a);
+					pre_out[2 * c + 1] = hi16(a);
+				}
+				if (!run_first) {
+					int cr, cj;
+					mul_conj_pk(a, b, cr, cj);
+					*o = (int16_t)fast_atan2_dev<false>(cj, cr);
+				}
+				if (k == WPG - 1)
+					outt[c * S] = a;                                // the next group's window -1 (read above by lane k == 0 of this wave, in order)
+			}
 		}
-		if (k == 0 || k == CH_WPG - 1 || w == total_windows - 1)
-			chan_lp[(u64)c * total_windows + w] = a;
-		if (w == total_windows - 1) {                        // fm_demod's carry, rtl_fm.c:612-613
-			pre_out[2 * c] = lo16(a);
-			pre_out[2 * c + 1] = hi16(a);
-		}
-		if (k) {
-			const uint32_t b = outt[idx + c - 1];
-			const int ar = lo16(a), aj = hi16(a), br = lo16(b), bj = hi16(b);
-			const int cr = (int)((unsigned)ar * (unsigned)br + (unsigned)aj * (unsigned)bj);
-			const int cj = (int)((unsigned)aj * (unsigned)br - (unsigned)ar * (unsigned)bj);
-			out[(u64)c * out_stride + w] = (int16_t)fast_atan2_dev(cj, cr);
-		}
+		if (run_done)
+			break;
+		__syncthreads();
 	}
 }
 
@@ -3281,30 +3322,42 @@ __global__ __launch_bounds__(256) void k_ch_nco(const uint32_t *__restrict__ iq,
 
 // fm_demod (rtl_fm.c:584-615) per channel: thread (c, t); the first window of every callback block
 // goes through the libm discriminator like every block's first sample does in rx_fm
-// sparse = group size of k_ch_fftR<FUSED> (0: dense): only the first window of every group, thread (c, group)
+// sparse = run length of k_ch_fftR<FUSED> (0: dense): only the first window of every run, thread (c, run)
 __global__ void k_ch_demod(const uint32_t *__restrict__ chan_lp, u64 total_windows, u64 wpb, int n_channels, int custom_atan,
                            const int *__restrict__ pre_in, int *__restrict__ pre_out, int16_t *__restrict__ out, u64 out_stride,
-                           rxk_fm_dev *__restrict__ dev, u64 *__restrict__ flag_list, int sparse)
+                           rxk_fm_dev *__restrict__ dev, u64 *__restrict__ flag_list, int sparse, int flag_all)
 {
 	u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-	const int CH_WPG = sparse;                               // the group size of the fused FFT kernel
-	if (sparse) {
-		const u64 groups = (total_windows + CH_WPG - 1) / CH_WPG;
-		if (gid >= (u64)n_channels * groups)
-			return;
-		const u64 cc = gid / groups;
-		gid = cc * total_windows + (gid - cc * groups) * CH_WPG;
-	}
-	if (gid >= (u64)n_channels * total_windows)
-		return;
-	const u64 c = gid / total_windows, t = gid - c * total_windows;
-	const uint32_t a = chan_lp[gid];
+	u64 c, t;
+	uint32_t a;
 	int br, bj;
-	if (t) {
-		const uint32_t b = chan_lp[gid - 1];
-		br = lo16(b); bj = hi16(b);
+	if (sparse) {
+		// the fused FFT kernel left [channel][run] first windows, then [channel][run] last windows
+		const u64 runs = total_windows / (u64)sparse;
+		if (gid >= (u64)n_channels * runs)
+			return;
+		c = gid / runs;
+		const u64 r = gid - c * runs;
+		t = r * (u64)sparse;
+		a = chan_lp[gid];
+		if (r) {
+			const uint32_t b = chan_lp[(u64)n_channels * runs + gid - 1];
+			br = lo16(b); bj = hi16(b);
+		} else {
+			br = pre_in[2 * c]; bj = pre_in[2 * c + 1];
+		}
+		gid = c * total_windows + t;                         // the flag list names samples, not slots
 	} else {
-		br = pre_in[2 * c]; bj = pre_in[2 * c + 1];
+		if (gid >= (u64)n_channels * total_windows)
+			return;
+		c = gid / total_windows; t = gid - c * total_windows;
+		a = chan_lp[gid];
+		if (t) {
+			const uint32_t b = chan_lp[gid - 1];
+			br = lo16(b); bj = hi16(b);
+		} else {
+			br = pre_in[2 * c]; bj = pre_in[2 * c + 1];
+		}
 	}
 	const int ar = lo16(a), aj = hi16(a);
 	const int cr = (int)((unsigned)ar * (unsigned)br + (unsigned)aj * (unsigned)bj);
@@ -3314,10 +3367,12 @@ __global__ void k_ch_demod(const uint32_t *__restrict__ chan_lp, u64 total_windo
 		const double ang = atan2((double)cj, (double)cr);
 		const double r = ang / 3.14159 * 16384.0;
 		v = (int)r;
-		if (r != 0.0 && fabs(r - rint(r)) < RXK_LIBM_WINDOW) {
+		if (r != 0.0 && (flag_forced(flag_all, gid) || fabs(r - rint(r)) < RXK_LIBM_WINDOW)) {
 			const int idx = atomicAdd(&dev->flag_cnt, 1);
 			if (idx < RXK_FLAG_CAP)
 				flag_list[idx] = gid;
+			if (flag_all >= 2)
+				v ^= 0x55;                                       // $RXGPU_FLAG_ALL=2|3: only the host's re-evaluation can make it right
 		}
 	} else {
 		v = fast_atan2_dev(cj, cr);
@@ -4044,7 +4099,9 @@ extern "C" int rxk_fm_dc_block(void *stream, int16_t *y, u64 M, rxk_fm_blocks bl
 
 extern "C" int rxk_ch_fused_ok(int bin_e, u64 wpb, int custom_atan, int n_channels)
 {
-	return (bin_e >= 8 && bin_e <= 12 && custom_atan == 1 && wpb % ch_wpg(n_channels) == 0) ? ch_wpg(n_channels) : 0;
+	const int wpg = ch_wpg(bin_e);
+	/* the run of windows a workgroup walks: what k_ch_demod(sparse) then skips over */
+	return (bin_e >= 8 && bin_e <= 12 && custom_atan == 1 && wpb % wpg == 0) ? wpg * ch_gpw(wpg, wpb) : 0;
 }
 
 extern "C" int rxk_ch_fft(void *stream, const int16_t *iq, u64 total_windows, int bin_e, const uint32_t *twiddle,
@@ -4053,15 +4110,18 @@ extern "C" int rxk_ch_fft(void *stream, const int16_t *iq, u64 total_windows, in
 	if (!total_windows)
 		return 0;
 	if (bin_e >= 8 && bin_e <= 12) {
-		const int CH_WPG = ch_wpg(n_channels);
+		const int CH_WPG = ch_wpg(bin_e);
+		const int GPW = fused ? fused / CH_WPG : ch_gpw(CH_WPG, 0);
 		/* N <= 1024: one transpose area (k_ch_fftR); rows of XROW = 21 dwords (fft_exchange's skew), the permuted twiddle copy, the staging */
-		const size_t shm = (size_t)((bin_e <= 10 ? 1 : 2) * 256 * 21 + 8 * ((1 << (bin_e - 4)) + 8) + n_channels * (CH_WPG + 1)) * 4;
-		const unsigned grid = (unsigned)((total_windows + CH_WPG - 1) / CH_WPG);
+		const size_t shm = (size_t)((bin_e <= 10 ? 1 : 2) * 256 * 21 + 8 * ((1 << (bin_e - 4)) + 8) + n_channels * (CH_WPG + 3)) * 4;
+		const u64 run = (u64)CH_WPG * GPW;
+		const unsigned grid = (unsigned)(((total_windows + run - 1) / run + 7) / 8 * 8);   /* XCD-contiguous order inside the kernel */
 		hipStream_t s = (hipStream_t)stream;
 		const uint32_t *p = (const uint32_t *)iq;
-#define GOF_(MM, FU, TW) do { if (shm > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_ch_fftR<MM, FU, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
-		hipLaunchKernelGGL((k_ch_fftR<MM, FU, TW>), dim3(grid), dim3(256), shm, s, p, total_windows, twiddle + (1 << (MM - 1)), first_bin, n_channels, chan_lp, \
-		                   out, out_stride, pre_out, CH_WPG); } while (0)
+#define GOF__(MM, FU, TW, WP) do { if (shm > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_ch_fftR<MM, FU, TW, WP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+		hipLaunchKernelGGL((k_ch_fftR<MM, FU, TW, WP>), dim3(grid), dim3(256), shm, s, p, total_windows, twiddle + (1 << (MM - 1)), first_bin, n_channels, chan_lp, \
+		                   out, out_stride, pre_out, GPW); } while (0)
+#define GOF_(MM, FU, TW) do { if (CH_WPG == 32) GOF__(MM, FU, TW, 32); else if (CH_WPG == 8) GOF__(MM, FU, TW, 8); else GOF__(MM, FU, TW, 16); } while (0)
 		/* A/B (N = 1024 only): $RXGPU_FFT_TW=global -- the twiddles of stages 4.. through the vector cache instead of the workgroup's LDS copy */
 		const char *twk = rxgpu_knob("RXGPU_FFT_TW");
 		const bool ab_tw = bin_e == 10 && twk && twk[0] == 'g';
@@ -4073,6 +4133,7 @@ extern "C" int rxk_ch_fft(void *stream, const int16_t *iq, u64 total_windows, in
 #undef GOC
 #undef GOF
 #undef GOF_
+#undef GOF__
 		LAUNCH_RET();
 	}
 	int wpg = bin_e >= 13 ? 1 : (8192 >> bin_e);
@@ -4109,7 +4170,8 @@ extern "C" int rxk_ch_demod(void *stream, const uint32_t *chan_lp, u64 total_win
 	if (!total)
 		return 0;
 	hipLaunchKernelGGL(k_ch_demod, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, chan_lp, total_windows, wpb,
-	                   n_channels, custom_atan, pre_in, pre_out, out, out_stride, dev, flag_list, sparse);
+	                   n_channels, custom_atan, pre_in, pre_out, out, out_stride, dev, flag_list, sparse,
+	                   rxgpu_knob("RXGPU_FLAG_ALL") ? atoi(rxgpu_knob("RXGPU_FLAG_ALL")) : 0);
 	LAUNCH_RET();
 }
 

@@ -220,9 +220,14 @@ int rxgpu_chan_run(rxgpu_chan *s, const int16_t *d_iq, size_t n_blocks, size_t b
 			unsigned long long gid = s->flag_host[i], c = gid / total, t = gid - c * total;
 			uint32_t a, b;
 			int br, bj;
-			RX_HIP(hipMemcpy(&a, s->chan_lp + gid, 4, hipMemcpyDeviceToHost));
+			/* fused: the FFT kernel kept [channel][run] first windows, then [channel][run] last windows (flagged samples are block starts,
+			 * hence run starts); else the dense [channel][window] array */
+			const unsigned long long runs = fused ? total / (unsigned long long)fused : 0, r = fused ? t / (unsigned long long)fused : 0;
+			const uint32_t *pa = fused ? s->chan_lp + c * runs + r : s->chan_lp + gid;
+			const uint32_t *pb = fused ? s->chan_lp + nc * runs + c * runs + r - 1 : s->chan_lp + gid - 1;
+			RX_HIP(hipMemcpy(&a, pa, 4, hipMemcpyDeviceToHost));
 			if (t) {
-				RX_HIP(hipMemcpy(&b, s->chan_lp + gid - 1, 4, hipMemcpyDeviceToHost));
+				RX_HIP(hipMemcpy(&b, pb, 4, hipMemcpyDeviceToHost));
 				br = (int16_t)(b & 0xffff); bj = (int16_t)(b >> 16);
 			} else {
 				br = pre_in_copy[2 * c]; bj = pre_in_copy[2 * c + 1];

@@ -98,6 +98,38 @@ def test_channeliser_fused_carry_across_runs():
     assert np.array_equal(got, want) and np.array_equal(pre, want_pre)
 
 
+@pytest.mark.parametrize("flag_all", ["1", "2"])
+@pytest.mark.parametrize("bin_e,first_bin,n_channels,block_len,n_blocks,custom_atan", [
+    (10, 384, 24, 2 * 65536, 5, 1),       # fused: 64 windows per block, the kernel keeps [channel][run] first / last windows only
+    (10, 384, 24, 2 * 131072, 3, 1),      # fused, two runs of 64 per block: only every other run start is a libm sample
+    (10, 20, 8, 2 * 4096, 6, 0),          # dense: -A std, every sample is libm (4 windows per block)
+    (9, 17, 30, 2 * 16384, 4, 1),         # fused with groups of 16 in a run of 32
+])
+def test_channeliser_host_fixups_forced(monkeypatch, flag_all, bin_e, first_bin, n_channels, block_len, n_blocks, custom_atan):
+    """$RXGPU_FLAG_ALL hands every libm sample of the channeliser to the host (2: after storing a wrong value), so the host's addressing of
+    the bins the FFT kernel kept -- compact [channel][run] edges in the fused form, the dense array otherwise -- is what makes the output right"""
+    monkeypatch.setenv("RXGPU_FLAG_ALL", flag_all)
+    iq = sig_fm(n_blocks * block_len // 2, seed=75, amp=9000)
+    want, want_pre = oracle_chan(iq, block_len, bin_e, first_bin, n_channels, custom_atan)
+    got, pre, fix = gpu_chan(iq, block_len, bin_e, first_bin, n_channels, custom_atan, n_runs=2)
+    assert fix > 0
+    bad = np.argwhere(got != want)
+    assert bad.size == 0, "first mismatch at %s: got %d want %d (%d bad)" % (bad[0], got[tuple(bad[0])], want[tuple(bad[0])], len(bad))
+    assert np.array_equal(pre, want_pre)
+
+
+@pytest.mark.parametrize("wpg,gpw", [("8", "8"), ("8", "2"), ("16", "1"), ("16", "8"), ("32", "4"), ("32", "1")])
+def test_channeliser_window_groups_and_runs(monkeypatch, wpg, gpw):
+    """every shape of the fused kernel's run ($RXGPU_CH_WPG windows per group x $RXGPU_CH_GPW groups per workgroup) gives the same samples"""
+    monkeypatch.setenv("RXGPU_CH_WPG", wpg)
+    monkeypatch.setenv("RXGPU_CH_GPW", gpw)
+    for bin_e, first_bin, n_channels, block_len, n_blocks in ((10, 384, 256, 2 * 131072, 3), (9, 500, 100, 2 * 32768, 5), (11, 2000, 96, 2 * 131072, 3)):
+        iq = sig_fm(n_blocks * block_len // 2, seed=76, amp=9000)
+        want, want_pre = oracle_chan(iq, block_len, bin_e, first_bin, n_channels, 1)
+        got, pre, _ = gpu_chan(iq, block_len, bin_e, first_bin, n_channels, 1, n_runs=2)
+        assert np.array_equal(got, want) and np.array_equal(pre, want_pre)
+
+
 def test_channeliser_finds_the_carrier():
     """sanity of the specification itself: an unmodulated carrier at bin k*fs/N shows up in channel k only"""
     n, k = 1024, 300

@@ -1,5 +1,5 @@
 """tools/ab_chan.py [VAR=VAL ...] -- the 256-channel channeliser run of bench.py (1 GiB capture, N=1024) under environment settings, alternating in one process"""
-import os, sys, time
+import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import rx_tools_amd as R
@@ -21,8 +21,16 @@ for rep in range(3):
         ch.run(d_iq.data_ptr(), n_blocks, block_len, d_out.data_ptr(), windows)
         if ref is None: ref = d_out.clone()
         same = bool(torch.equal(ref, d_out))
+        for _ in range(3): ch.run(d_iq.data_ptr(), n_blocks, block_len, d_out.data_ptr(), windows)
+        L.rxgpu_prof_reset(); L.rxgpu_prof_enable(2)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(10): ch.run(d_iq.data_ptr(), n_blocks, block_len, d_out.data_ptr(), windows)
-        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
-        print((",".join("%s=%s" % kv for kv in st.items()) or "default").ljust(24), "ms", round(dt * 1e3, 3), "GS/s", round(T / dt / 1e9, 1), "same output:", same, flush=True)
+        for _ in range(20): ch.run(d_iq.data_ptr(), n_blocks, block_len, d_out.data_ptr(), windows)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
+        L.rxgpu_prof_enable(0)
+        ks = {}
+        for nme in ("ch_fft", "ch_demod"):
+            ms, k = C.c_double(0), C.c_long(0)
+            L.rxgpu_prof_get(nme.encode(), C.byref(ms), C.byref(k))
+            if k.value: ks[nme] = round(ms.value / k.value * 1e3, 1)
+        print((",".join("%s=%s" % kv for kv in st.items()) or "default").ljust(24), "ms", round(dt * 1e3, 3), "GS/s", round(T / dt / 1e9, 1), ks, "same output:", same, flush=True)
         ch.close()
