@@ -32,5 +32,5 @@ for rep in range(4):
         s.wait()
         dt = (time.perf_counter() - t0) / k
         L.rxgpu_prof_enable(0)
-        print((switch + "=1" if on else "default").ljust(22), "us/step", round(dt * 1e6, 1), dump(["fm_decimate", "fm_fifth", "fm_fifth2", "fm_droop", "fm_disc", "fm_deemph", "fm_resample"]),
+        print((switch + "=" + (sys.argv[4] if len(sys.argv) > 4 else "1") if on else "default").ljust(22), "us/step", round(dt * 1e6, 1), dump(["fm_decimate", "fm_fifth", "fm_fifth2", "fm_droop", "fm_disc", "fm_deemph", "fm_resample"]),
               "TS/s", round(blocks * 131072 / dt / 1e12, 3), flush=True)
