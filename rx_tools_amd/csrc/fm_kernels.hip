@@ -832,6 +832,89 @@ __global__ __launch_bounds__(256) void k_fm_disc(
 	}
 }
 
+// ------------------------------------------------------------------ F2 + F5/F6 of ONE callback block (the drop-in's latency path)
+
+// full_demod() on a single block through rxgpu_fm_stream_run costs a dozen launches over four streams, carries up and down
+// (84 us of host time for 1 MiB, round 3).  One block of the plain chain -- low_pass (rtl_fm.c:351-371) on the block the callback
+// pre-staged, then fm_demod (584-615) -- is one launch here: a wave per decimated sample sums its window (and its predecessor's,
+// again: there is no neighbour to wait for), lane 0 stores lowpassed[m] and the discriminator's sample; the wave behind the last
+// window leaves low_pass's carry.  All carries come in as arguments and go out in `out`, which the host reads back together with
+// the rows; the de-emphasis / resampler seeds are passed on to k_ch_audio (one workgroup, the next launch) through audio_in.
+// blk: the block as the callback left it (scaled, rotated); n complex samples; p0 = prev_index.
+__device__ __forceinline__ void blk_window(const uint32_t *__restrict__ blk, long s0, long e0, unsigned lane, int &si, int &sq)
+{
+	si = 0; sq = 0;
+	for (long k = s0 + lane; k < e0; k += 64) {
+		const uint32_t w = blk[k];
+		si += lo16(w); sq += hi16(w);
+	}
+	for (int off = 32; off; off >>= 1) { si += __shfl_down(si, off); sq += __shfl_down(sq, off); }
+}
+
+__global__ __launch_bounds__(256) void k_fm_block_dd(const uint32_t *__restrict__ blk, unsigned n, int ds, int p0, int now_r, int now_j,
+                                                     int pre_r, int pre_j, int custom_atan, int flag_all, uint32_t *__restrict__ lp,
+                                                     int16_t *__restrict__ pcm, int16_t *__restrict__ keep, rxk_blk_out *__restrict__ out,
+                                                     int *__restrict__ audio_in, int avg, int now_lpr, int prev_lpr_index)
+{
+	const unsigned lane = threadIdx.x & 63u;
+	const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long)gridDim.x * 4;
+	const long M = ((long)p0 + (long)n) / ds;
+	if (gw == 0 && lane == 0) {
+		audio_in[0] = avg; audio_in[1] = now_lpr; audio_in[2] = prev_lpr_index;
+	}
+	for (long m = gw; m <= M; m += nw) {
+		// window m: samples [m ds - p0, (m + 1) ds - p0) of the block, the first one on top of the carried sums
+		const long s0 = m * ds - p0;
+		int si, sq;
+		blk_window(blk, s0 < 0 ? 0 : s0, m == M ? (long)n : s0 + ds, lane, si, sq);
+		if (m == 0) { si += now_r; sq += now_j; }
+		if (m == M) {                                             // what is left behind the last complete window
+			if (lane == 0) {
+				out->now_r = si; out->now_j = sq; out->prev_index = (int)((long)p0 + (long)n - M * ds);
+				if (M == 0) { out->pre_r = pre_r; out->pre_j = pre_j; }
+			}
+			continue;
+		}
+		int br = pre_r, bj = pre_j;
+		if (m) {
+			int ti, tq;
+			blk_window(blk, s0 - ds < 0 ? 0 : s0 - ds, s0, lane, ti, tq);
+			if (m == 1) { ti += now_r; tq += now_j; }
+			br = (int16_t)ti; bj = (int16_t)tq;                 // lowpassed[] is int16 (rtl_fm.c:363-364)
+		}
+		if (lane)
+			continue;
+		const int ar = (int16_t)si, aj = (int16_t)sq;
+		lp[m] = pack_iq(ar, aj);
+		const int cr = (int)((unsigned)ar * (unsigned)br + (unsigned)aj * (unsigned)bj);
+		const int cj = (int)((unsigned)aj * (unsigned)br - (unsigned)ar * (unsigned)bj);
+		int v;
+		if (m == 0 || custom_atan == 0) {
+			// polar_discriminant, rtl_fm.c:476-483: (int)(atan2(cj,cr) / 3.14159 * (1<<14)); undecided within RXK_LIBM_WINDOW: the host's libm
+			const double ang = atan2((double)cj, (double)cr);
+			const double r = ang / 3.14159 * 16384.0;
+			v = (int)r;
+			if (r != 0.0 && (flag_forced(flag_all, (u64)m) || fabs(r - rint(r)) < RXK_LIBM_WINDOW)) {
+				const int idx = atomicAdd(&out->flag_cnt, 1);
+				if (idx < RXK_BLK_FLAGS) {
+					rxk_flag_rec rec;
+					rec.m = (u64)m; rec.ar = ar; rec.aj = aj; rec.br = br; rec.bj = bj;
+					out->rec[idx] = rec;
+				}
+				if (flag_all > 1)
+					v += 77;                                        // test hook: only the host's re-evaluation can make this sample right
+			}
+		} else if (custom_atan == 1) {
+			v = fast_atan2_dev(cj, cr);
+		} else {
+			v = esbensen_dev(ar, aj, br, bj);
+		}
+		pcm[m] = (int16_t)v;
+		keep[m] = (int16_t)v;                                   // the row as demodulated: what the audio stages start again from after a host fix-up
+		if (m == M - 1) { out->pre_r = ar; out->pre_j = aj; }
+	}
+}
+
 // ------------------------------------------------------------------ squelch, am/usb/lsb, dc block
 
 __device__ __forceinline__ void block_range(const rxk_fm_blocks &g, u64 b, u64 &m0, u64 &m1)
@@ -4172,6 +4255,167 @@ extern "C" int rxk_ch_demod(void *stream, const uint32_t *chan_lp, u64 total_win
 	hipLaunchKernelGGL(k_ch_demod, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, chan_lp, total_windows, wpb,
 	                   n_channels, custom_atan, pre_in, pre_out, out, out_stride, dev, flag_list, sparse,
 	                   rxgpu_knob("RXGPU_FLAG_ALL") ? atoi(rxgpu_knob("RXGPU_FLAG_ALL")) : 0);
+	LAUNCH_RET();
+}
+
+// deemph_filter (rtl_fm.c:667-682) + low_pass_real (389-409) on ONE short row (the drop-in's single blocks: a thousand samples behind ds = 118),
+// k_ch_audio's scheme with the row in LDS and the chunk length cut loose from the warm-up: k_ch_audio walks global memory sample by sample
+// (46 us for 1 110 samples: every step of every chain waits for its load) and gives each thread a chunk of at least `warm` samples (ten threads
+// busy).  Here thread 0 takes the first `warm` samples from the carried state, every other thread a chunk of C samples behind them, warmed up
+// on the `warm` samples before its own (two trajectories from the ends of the int16 range, as there), then the chunk tables are walked by one
+// thread and every chunk is replayed from its exact start.  a > 64, a == 1 or a carried state outside int16 (serial): one thread, the
+// reference's own expression.  W <= row_cap samples (the launcher's LDS size).  row: in (demodulated) / out (result); audio: {avg, now_lpr,
+// prev_lpr_index} in, the same three out at audio + 3.
+template <bool EVEN, bool D24>
+__global__ __launch_bounds__(256) void k_fm_row_audio(int16_t *__restrict__ row_g, unsigned W, int deemph, int a, unsigned magic, int bias, int warm,
+                                                      int serial, int fast, int slow, unsigned J, int *__restrict__ audio)
+{
+	extern __shared__ __attribute__((aligned(16))) int16_t ra_row[];       // [W] the samples, then (in place) the de-emphasised ones
+	__shared__ uint4 tab[256];
+	__shared__ int start[256];
+	const int tid = threadIdx.x;
+	for (unsigned i = tid; i < W; i += 256)
+		ra_row[i] = row_g[i];
+	const int avg_in = audio[0];
+	__syncthreads();
+	if (deemph) {
+		const int h = a / 2, xoff = h + bias * a;
+		// chunk 0 = [0, w0), chunk t >= 1 = [w0 + (t - 1) C, w0 + t C): at most 255 of them
+		const unsigned w0 = serial ? W : min((unsigned)warm, W);
+		// (the walk over the chunk tables is one thread's, ~250 cycles per table, a step of a chain ~50: chunks of 48 balance the two at W ~ 1000)
+		unsigned Cn = (W - w0 + 254) / 255;
+		Cn = Cn < 48 ? 48 : Cn;
+		const int active = 1 + (int)((W - w0 + Cn - 1) / Cn);
+		const unsigned b = tid ? w0 + (unsigned)(tid - 1) * Cn : 0u, e = tid ? min(W, b + Cn) : w0;
+		if (tid < active && !serial) {
+			int lo, hi;
+			if (tid == 0) {
+				lo = hi = avg_in;
+			} else {
+				lo = -32768; hi = 32767;
+				// four samples per LDS read (b and warm are multiples of 8): a chain step is five instructions, a read's latency a hundred cycles
+				for (unsigned i = b - (unsigned)warm; i < b; i += 4) {
+					const uint2 v = *reinterpret_cast<const uint2 *>(&ra_row[i]);
+					const int xs[4] = {lo16(v.x), hi16(v.x), lo16(v.y), hi16(v.y)};
+#pragma unroll
+					for (int q = 0; q < 4; q++) {
+						lo = deemph_step_d<EVEN, D24>(lo, xs[q] + xoff, xs[q], magic, bias);
+						hi = deemph_step_d<EVEN, D24>(hi, xs[q] + xoff, xs[q], magic, bias);
+					}
+				}
+			}
+			int gap = hi - lo;
+			if (gap > 63) gap = 63;                               // excluded by `warm`
+			const int lo_start = lo;
+			int cnt = gap + 1;
+			u64 mask = (((u64)1 << gap) - 1);
+			unsigned i = b;
+			for (; i + 4 <= e; i += 4) {
+				const uint2 v = *reinterpret_cast<const uint2 *>(&ra_row[i]);
+				const int xs[4] = {lo16(v.x), hi16(v.x), lo16(v.y), hi16(v.y)};
+#pragma unroll
+				for (int q = 0; q < 4; q++)
+					deemph_track<EVEN, D24>(lo, cnt, mask, xs[q], a, xoff, magic, bias);
+			}
+			for (; i < e; i++)
+				deemph_track<EVEN, D24>(lo, cnt, mask, (int)ra_row[i], a, xoff, magic, bias);
+			tab[tid] = make_uint4((uint32_t)lo_start, ((uint32_t)lo & 0xffffu) | ((uint32_t)gap << 16), (uint32_t)mask, (uint32_t)(mask >> 32));
+		}
+		__syncthreads();
+		if (tid == 0) {
+			int s = avg_in;
+			if (!serial) {
+#pragma unroll 4
+				for (int t = 0; t < active; t++) {
+					start[t] = s;
+					s = ctab_apply(tab[t], s);
+				}
+				audio[3] = s;
+			} else {
+				for (unsigned i = 0; i < W; i++) {                // any a, any state: the reference's own expression
+					const int d = (int)ra_row[i] - s;
+					s += d > 0 ? (d + h) / a : (d - h) / a;
+					ra_row[i] = (int16_t)s;
+				}
+				audio[3] = s;
+			}
+		}
+		__syncthreads();
+		if (tid < active && !serial) {
+			int s = start[tid];
+			unsigned i = b;
+			for (; i + 4 <= e; i += 4) {
+				const uint2 v = *reinterpret_cast<const uint2 *>(&ra_row[i]);
+				const int xs[4] = {lo16(v.x), hi16(v.x), lo16(v.y), hi16(v.y)};
+				int ys[4];
+#pragma unroll
+				for (int q = 0; q < 4; q++) {
+					s = deemph_step_d<EVEN, D24>(s, xs[q] + xoff, xs[q], magic, bias);
+					ys[q] = s;
+				}
+				*reinterpret_cast<uint2 *>(&ra_row[i]) = make_uint2(pack_iq(ys[0], ys[1]), pack_iq(ys[2], ys[3]));
+			}
+			for (; i < e; i++) {
+				const int x = ra_row[i];
+				s = deemph_step_d<EVEN, D24>(s, x + xoff, x, magic, bias);
+				ra_row[i] = (int16_t)s;
+			}
+		}
+		__syncthreads();
+	} else if (tid == 0) {
+		audio[3] = avg_in;
+	}
+	if (slow > 0) {
+		const u64 p0 = (u64)audio[2];
+		const int ratio = fast / slow;
+		for (unsigned j = tid; j < J; j += 256) {
+			const u64 wb = j ? lpr_end(j - 1, fast, slow, p0) : 0, we = lpr_end(j, fast, slow, p0);
+			int sum = j ? 0 : audio[1];
+			for (u64 i = wb; i < we; i++)
+				sum += ra_row[i];
+			row_g[j] = (int16_t)(sum / ratio);
+		}
+		if (tid == 0) {
+			const u64 wb = J ? lpr_end(J - 1, fast, slow, p0) : 0;
+			int sum = J ? 0 : audio[1];
+			for (u64 i = wb; i < W; i++)
+				sum += ra_row[i];
+			audio[4] = sum;
+			audio[5] = (int)(p0 + (u64)W * (u64)slow - (u64)J * (u64)fast);
+		}
+	} else {
+		if (deemph)
+			for (unsigned i = tid; i < W; i += 256)
+				row_g[i] = ra_row[i];
+		if (tid == 0) { audio[4] = audio[1]; audio[5] = audio[2]; }
+	}
+}
+
+extern "C" int rxk_fm_row_audio(void *stream, int16_t *row, unsigned W, int deemph, int a, int warm, int serial, int fast, int slow, unsigned J, int *audio)
+{
+	if (!W)
+		return 0;
+	hipStream_t s = (hipStream_t)stream;
+	const unsigned mg = deemph ? deemph_magic(a) : 0u;
+	const int bias = deemph ? bias_for(a) : 0;
+	const size_t lds = ((size_t)W * 2 + 15) & ~(size_t)15;
+#define GO(EV, D) hipLaunchKernelGGL((k_fm_row_audio<EV, D>), dim3(1), dim3(256), lds, s, row, W, deemph, a, mg, bias, warm, serial, fast, slow, J, audio)
+	if (deemph && deemph_d24(a)) { if (a & 1) GO(false, true); else GO(true, true); }
+	else { if (!deemph || (a & 1)) GO(false, false); else GO(true, false); }
+#undef GO
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_fm_block_dd(void *stream, const int16_t *blk, unsigned n, int ds, int p0, int now_r, int now_j, int pre_r, int pre_j,
+                               int custom_atan, uint32_t *lp, int16_t *pcm, int16_t *keep, rxk_blk_out *out, int *audio_in, int avg, int now_lpr,
+                               int prev_lpr_index)
+{
+	const unsigned long long M = ((unsigned long long)p0 + n) / (unsigned long long)ds;
+	unsigned grid = (unsigned)((M + 1 + 3) / 4);
+	if (grid > 2048)
+		grid = 2048;
+	hipLaunchKernelGGL(k_fm_block_dd, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint32_t *)blk, n, ds, p0, now_r, now_j, pre_r, pre_j,
+	                   custom_atan, rxgpu_knob("RXGPU_FLAG_ALL") ? atoi(rxgpu_knob("RXGPU_FLAG_ALL")) : 0, lp, pcm, keep, out, audio_in, avg, now_lpr, prev_lpr_index);
 	LAUNCH_RET();
 }
 

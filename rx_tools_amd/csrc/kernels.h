@@ -67,6 +67,20 @@ typedef struct rxk_flag_rec {
  * |v_dev - v_host| <= (1.33e-15 / 3.14159 + 2.2e-16) * 16384 = 1.06e-11 < 2^-36.  2^-33 leaves a factor 8. */
 #define RXK_LIBM_WINDOW 0x1p-33
 
+/* what k_fm_block_dd leaves for the host: low_pass's and fm_demod's carries, the libm samples it could not decide */
+#define RXK_BLK_FLAGS 64
+typedef struct rxk_blk_out {
+	int now_r, now_j, prev_index, pre_r, pre_j, flag_cnt, pad[2];
+	rxk_flag_rec rec[RXK_BLK_FLAGS];
+} rxk_blk_out;
+/* low_pass (rtl_fm.c:351-371) + fm_demod (584-615, -A std | fast | ale) of one pre-scaled block in one launch (the drop-in's single blocks);
+ * lp, pcm: (p0 + n) / ds entries; audio_in: the three seeds rxk_ch_audio takes ({avg, now_lpr, prev_lpr_index}) */
+int rxk_fm_block_dd(void *stream, const int16_t *blk, unsigned n, int ds, int p0, int now_r, int now_j, int pre_r, int pre_j,
+                    int custom_atan, uint32_t *lp, int16_t *pcm, int16_t *keep, rxk_blk_out *out, int *audio_in, int avg, int now_lpr,
+                    int prev_lpr_index);
+/* deemph_filter + low_pass_real on one short row held in LDS (W <= 24 000 samples); audio: {avg, now_lpr, prev_lpr_index} in, the same out at +3 */
+int rxk_fm_row_audio(void *stream, int16_t *row, unsigned W, int deemph, int a, int warm, int serial, int fast, int slow, unsigned J, int *audio);
+
 enum { RXK_FIRST_LOWPASS = 0, RXK_FIRST_UNIFORM = 1 };
 
 /* F0+F1+F2 fused (rtl_fm.c:845-848, 309-327, 351-371): cs16 -> scaled -> rotated ->

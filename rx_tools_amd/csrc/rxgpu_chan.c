@@ -149,7 +149,7 @@ long rxgpu_chan_host_fixups(const rxgpu_chan *s) { return s ? s->fixups : 0; }
 /* samples until trajectories from the two ends of the int16 range are fewer than `a` apart (then at most one adjacent pair
  * of candidates merges per sample, which is what the mask tracking relies on): the gap g shrinks by at least floor(g / a) per
  * sample (k_fm_deemph_scan's argument).  a <= 64, so the candidates also fit the 64-bit mask. */
-static int chan_warm(int a)
+int rxgpu_deemph_warm64(int a)
 {
 	int n = 0;
 	long long g = 65535;
@@ -256,7 +256,7 @@ int rxgpu_chan_run(rxgpu_chan *s, const int16_t *d_iq, size_t n_blocks, size_t b
 		RX_HIP(hipMemcpyAsync(s->audio_dev[0], s->audio_host, nc * 12, hipMemcpyHostToDevice, st));
 		rxgpu_prof_begin("ch_audio");
 		RX_K(rxk_ch_audio(st, d_out, out_stride, total, s->p.n_channels, s->p.deemph, s->p.deemph_a,
-		                  s->p.deemph && !serial ? chan_warm(s->p.deemph_a) : 8, serial, s->p.rate_out, s->p.rate_out2 > 0 ? s->p.rate_out2 : 0, J,
+		                  s->p.deemph && !serial ? rxgpu_deemph_warm64(s->p.deemph_a) : 8, serial, s->p.rate_out, s->p.rate_out2 > 0 ? s->p.rate_out2 : 0, J,
 		                  s->audio_dev[0], s->audio_dev[1], s->audio_y, s->max_windows));
 		rxgpu_prof_end("ch_audio");
 		RX_HIP(hipMemcpyAsync(s->audio_host, s->audio_dev[1], nc * 12, hipMemcpyDeviceToHost, st));

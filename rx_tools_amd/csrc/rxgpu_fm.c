@@ -1335,6 +1335,7 @@ static struct {
 	int16_t *cb_in, *cb_pre[2];
 	int *cb_rdc;                         /* dc_avgI/Q, the block averages, the int64 sums */
 	int16_t *fd_in;                      /* full_demod's own upload buffer (the demod thread's; the callback's are the dongle thread's) */
+	unsigned char *fb_dev, *fb_host;     /* the single-block path (dropin_fast_block): device rows + header, their pinned host mirror */
 	pthread_mutex_t cb_lock;             /* one callback at a time per demod_state */
 	int cb_lock_ready;
 } g_side[SIDECARS];
@@ -1395,6 +1396,8 @@ int rxgpu_dropin_release(const struct demod_state *d)
 			rxgpu_fm_stream_destroy(g_side[i].s);
 		hipFree(g_side[i].cb_in); hipFree(g_side[i].cb_rdc); hipFree(g_side[i].cb_pre[0]); hipFree(g_side[i].cb_pre[1]);
 		hipFree(g_side[i].fd_in);
+		hipFree(g_side[i].fb_dev);
+		if (g_side[i].fb_host) hipHostFree(g_side[i].fb_host);
 		pthread_mutex_t keep = g_side[i].cb_lock;
 		memset(&g_side[i], 0, sizeof(g_side[i]));
 		g_side[i].cb_lock = keep;
@@ -1518,6 +1521,98 @@ void rxgpu_fm_dropin_release(void)
 	pthread_mutex_unlock(&g_side_lock);
 }
 
+/* ---- the drop-in's single blocks of the plain FM chain: k_fm_block_dd + k_fm_row_audio, carries as kernel arguments, ONE copy back.
+ * (rxgpu_fm_stream_run on one block: a dozen launches over four streams, carries up and down -- 84 us of 177 per 1 MiB block pair in round 3.) */
+#define FB_HDR 2048                      /* rxk_blk_out, then audio_in[3], audio_out[3] at FB_AUDIO */
+#define FB_AUDIO 1600
+#define FB_MCAP (RXGPU_MAXIMUM_BUF_LENGTH / 2 / 8 + 64)
+#define FB_BYTES (FB_HDR + 10 * (size_t)FB_MCAP + 256)
+
+static int dropin_fast_ok(const rxgpu_fm_params *p, const struct demod_state *d)
+{
+	const char *k = rxgpu_knob("RXGPU_DROPIN_FAST");                 /* "0": always the general path (A/B, tests) */
+	if (k && k[0] == '0')
+		return 0;
+	if (p->mode != RXGPU_MODE_FM || p->downsample_passes || p->squelch_level || p->dc_block_audio || p->post_downsample > 1 || p->custom_atan == 2)
+		return 0;
+	if (p->downsample < 8 || d->prev_index < 0 || d->prev_index >= p->downsample || d->lp_len < 2)
+		return 0;
+	if (((long)d->prev_index + d->lp_len / 2) / p->downsample < 1)   /* no decimated sample: fm_demod's corner cases stay where they are handled */
+		return 0;
+	if (p->deemph && p->deemph_a < 1)
+		return 0;
+	if (p->rate_out2 > 0 && (p->rate_out < p->rate_out2 || p->rate_out <= 0 || d->prev_lpr_index < 0 || d->prev_lpr_index >= p->rate_out))
+		return 0;
+	return 1;
+}
+
+static int dropin_fast_block(int slot, struct demod_state *d, const rxgpu_fm_params *p, const int16_t *d_block, int timing, double *t_a)
+{
+	hipStream_t st = rxgpu_hip_stream2();
+	if (!g_side[slot].fb_dev) {
+		if (hipMalloc((void **)&g_side[slot].fb_dev, FB_BYTES) != hipSuccess || hipHostMalloc((void **)&g_side[slot].fb_host, FB_BYTES, 0) != hipSuccess ||
+		    hipMemset(g_side[slot].fb_dev, 0, FB_HDR) != hipSuccess)
+			return rxgpu_fail(RXGPU_ENOMEM, "single-block workspace allocation failed");
+	}
+	unsigned char *dev = g_side[slot].fb_dev, *host = g_side[slot].fb_host;
+	const unsigned n = (unsigned)d->lp_len / 2;
+	const int ds = p->downsample;
+	const unsigned long long M = ((unsigned long long)d->prev_index + n) / (unsigned long long)ds;
+	const int resample = p->rate_out2 > 0;
+	const unsigned long long J = resample ? ((unsigned long long)d->prev_lpr_index + M * (unsigned long long)p->rate_out2) / (unsigned long long)p->rate_out : M;
+	const size_t row_b = (2 * (size_t)M + 15) & ~(size_t)15;
+	rxk_blk_out *hdr = (rxk_blk_out *)dev;
+	int *audio = (int *)(dev + FB_AUDIO);
+	int16_t *pcm = (int16_t *)(dev + FB_HDR);                    /* the demodulated row, then (in place) the result */
+	uint32_t *lp = (uint32_t *)(dev + FB_HDR + row_b);
+	int16_t *keep = (int16_t *)(dev + FB_HDR + row_b + 4 * (size_t)M + 16);   /* the demodulated row once more: what a host fix-up starts again from */
+	const int avg = g_side[slot].avg;
+	const int serial = p->deemph && (p->deemph_a < 2 || p->deemph_a > 64 || avg < -32768 || avg > 32767);
+	const int warm = p->deemph && !serial ? rxgpu_deemph_warm64(p->deemph_a) : 8;
+	RX_K(rxk_fm_block_dd(st, d_block, n, ds, d->prev_index, d->now_r, d->now_j, d->pre_r, d->pre_j, p->custom_atan, lp, pcm, keep, hdr, audio,
+	                     avg, d->now_lpr, d->prev_lpr_index));
+	const size_t back = FB_HDR + row_b + 4 * (size_t)M;
+	for (int attempt = 0; ; attempt++) {
+		RX_K(rxk_fm_row_audio(st, pcm, (unsigned)M, p->deemph, p->deemph_a, warm, serial, p->rate_out, resample ? p->rate_out2 : 0, (unsigned)J, audio));
+		RX_HIP(hipMemcpyAsync(host, dev, back, hipMemcpyDeviceToHost, st));
+		RX_HIP(hipStreamSynchronize(st));
+		const rxk_blk_out *h = (const rxk_blk_out *)host;
+		if (!h->flag_cnt || attempt)
+			break;
+		/* libm samples the device could not decide: the host's libm, like fixup_from; then the audio stages again from the row as demodulated */
+		const int cnt = h->flag_cnt;
+		RX_HIP(hipMemsetAsync(&hdr->flag_cnt, 0, sizeof(int), st));
+		if (cnt > RXK_BLK_FLAGS) {
+			RX_HIP(hipStreamSynchronize(st));
+			return RXGPU_EUNSUPPORTED;
+		}
+		RX_HIP(hipMemcpyAsync(pcm, keep, 2 * (size_t)M, hipMemcpyDeviceToDevice, st));
+		for (int i = 0; i < cnt; i++) {
+			const rxk_flag_rec *f = &h->rec[i];
+			const int16_t v = (int16_t)polar_discriminant_host(f->ar, f->aj, f->br, f->bj);
+			RX_HIP(hipMemcpyAsync(pcm + f->m, &v, 2, hipMemcpyHostToDevice, st));
+			RX_HIP(hipStreamSynchronize(st));                    /* v lives on this stack frame */
+		}
+		if (g_side[slot].s)
+			g_side[slot].s->fixups += cnt;
+	}
+	if (timing) { const double t_b = now_us(); g_dt[3] += t_b - *t_a; *t_a = t_b; }
+	const rxk_blk_out *h = (const rxk_blk_out *)host;
+	const int *audio_out = (const int *)(host + FB_AUDIO) + 3;
+	memcpy(d->result, host + FB_HDR, 2 * (size_t)J);
+	memcpy(d->lowpassed, host + FB_HDR + row_b, 4 * (size_t)M);
+	d->lp_len = (int)(2 * M);
+	d->result_len = (int)J;
+	d->now_r = h->now_r; d->now_j = h->now_j; d->prev_index = h->prev_index;
+	d->pre_r = h->pre_r; d->pre_j = h->pre_j;
+	g_side[slot].avg = audio_out[0];
+	d->now_lpr = audio_out[1]; d->prev_lpr_index = audio_out[2];
+	g_side[slot].dev_valid = 0;
+	g_side[slot].last_sr_valid = 0;
+	if (timing) { g_dt[4] += now_us() - *t_a; g_dt[6] += 1; }
+	return RXGPU_OK;
+}
+
 void rxgpu_full_demod(struct demod_state *d)
 {
 	const int timing = dt_on();
@@ -1574,33 +1669,8 @@ void rxgpu_full_demod(struct demod_state *d)
 		g_side[slot].p = p;
 	}
 	rxgpu_fm_stream *s = g_side[slot].s;
-	rxgpu_fm_carry c;
-	memset(&c, 0, sizeof(c));
-	c.now_r = d->now_r; c.now_j = d->now_j; c.prev_index = d->prev_index;
-	c.pre_r = d->pre_r; c.pre_j = d->pre_j;
-	memcpy(c.lp_i_hist, d->lp_i_hist, sizeof(c.lp_i_hist));
-	memcpy(c.lp_q_hist, d->lp_q_hist, sizeof(c.lp_q_hist));
-	memcpy(c.droop_i_hist, d->droop_i_hist, sizeof(c.droop_i_hist));
-	memcpy(c.droop_q_hist, d->droop_q_hist, sizeof(c.droop_q_hist));
-	c.deemph_avg = g_side[slot].avg;
-	c.now_lpr = d->now_lpr; c.prev_lpr_index = d->prev_lpr_index;
-	c.squelch_hits = d->squelch_hits; c.dc_avg = d->dc_avg;
-	rxgpu_fm_stream_set_carry(s, &c);
-	const int pre_r_in = d->pre_r, pre_j_in = d->pre_j;
-	size_t got = 0;
 	hipStream_t sb = rxgpu_hip_stream2();
-	const size_t cap = (size_t)RXGPU_MAXIMUM_BUF_LENGTH + 16;
-	if (s->stage_out_cap < cap) {
-		hipFree(s->stage_out);
-		s->stage_out = NULL; s->stage_out_cap = 0;
-		if (hipMalloc((void **)&s->stage_out, cap * 2) != hipSuccess) {
-			rxgpu_fail(RXGPU_ENOMEM, "hipMalloc failed");
-			die("rxgpu_full_demod");
-		}
-		s->stage_out_cap = cap;
-	}
 	const int16_t *d_block;
-	if (timing) { t_b = now_us(); g_dt[2] += t_b - t_a; t_a = t_b; }
 	if (g_side[slot].dev_valid && g_side[slot].dev_len == d->lp_len && d->lp_len > 0 && g_side[slot].cb_pre[g_side[slot].dev_slot]) {
 		/* the block is the one rxgpu_callback pre-staged: it is still in HBM, no second trip over PCIe.  (The caller
 		 * holds d->rw like the reference's demod thread, rtl_fm.c:922-924, so the callback cannot publish meanwhile.) */
@@ -1623,6 +1693,40 @@ void rxgpu_full_demod(struct demod_state *d)
 		}
 		d_block = g_side[slot].fd_in;
 	}
+	/* one block of the plain chain (low_pass -> fm_demod -> deemph_filter -> low_pass_real): two launches and one copy back */
+	if (dropin_fast_ok(&p, d)) {
+		const int rc = dropin_fast_block(slot, d, &p, d_block, timing, &t_a);
+		if (rc == RXGPU_OK)
+			return;
+		if (rc != RXGPU_EUNSUPPORTED)
+			die("rxgpu_full_demod");
+		/* more undecided libm samples than the block header holds: the general path, nothing has been written to *d yet */
+	}
+	rxgpu_fm_carry c;
+	memset(&c, 0, sizeof(c));
+	c.now_r = d->now_r; c.now_j = d->now_j; c.prev_index = d->prev_index;
+	c.pre_r = d->pre_r; c.pre_j = d->pre_j;
+	memcpy(c.lp_i_hist, d->lp_i_hist, sizeof(c.lp_i_hist));
+	memcpy(c.lp_q_hist, d->lp_q_hist, sizeof(c.lp_q_hist));
+	memcpy(c.droop_i_hist, d->droop_i_hist, sizeof(c.droop_i_hist));
+	memcpy(c.droop_q_hist, d->droop_q_hist, sizeof(c.droop_q_hist));
+	c.deemph_avg = g_side[slot].avg;
+	c.now_lpr = d->now_lpr; c.prev_lpr_index = d->prev_lpr_index;
+	c.squelch_hits = d->squelch_hits; c.dc_avg = d->dc_avg;
+	rxgpu_fm_stream_set_carry(s, &c);
+	const int pre_r_in = d->pre_r, pre_j_in = d->pre_j;
+	size_t got = 0;
+	const size_t cap = (size_t)RXGPU_MAXIMUM_BUF_LENGTH + 16;
+	if (s->stage_out_cap < cap) {
+		hipFree(s->stage_out);
+		s->stage_out = NULL; s->stage_out_cap = 0;
+		if (hipMalloc((void **)&s->stage_out, cap * 2) != hipSuccess) {
+			rxgpu_fail(RXGPU_ENOMEM, "hipMalloc failed");
+			die("rxgpu_full_demod");
+		}
+		s->stage_out_cap = cap;
+	}
+	if (timing) { t_b = now_us(); g_dt[2] += t_b - t_a; t_a = t_b; }
 	if (rxgpu_fm_stream_run(s, d_block, 1, (size_t)d->lp_len, s->stage_out, s->stage_out_cap, &got, NULL) != RXGPU_OK)
 		die("rxgpu_full_demod");
 	g_side[slot].dev_valid = 0;

@@ -16,6 +16,7 @@
 int rxgpu_fail(int code, const char *fmt, ...);
 /* make sure rxgpu_init ran (auto-initialises with device -1) */
 int rxgpu_ensure_init(void);
+int rxgpu_deemph_warm64(int a);          /* rxgpu_chan.c: samples that bring any two int16 de-emphasis states within 64 of each other */
 hipStream_t rxgpu_hip_stream(void);
 hipStream_t rxgpu_hip_stream2(void);   /* second stream: the latency-bound tail of a pipelined rx_fm run */
 hipStream_t rxgpu_hip_stream4(void);   /* fourth stream: small kernels that prepare the NEXT run's stream-A launch while this run's is still going */

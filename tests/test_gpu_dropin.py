@@ -317,6 +317,31 @@ ANY_LENGTH_PARAMS = [
 ]
 
 
+FAST_BLOCK_PARAMS = [
+    dict(downsample=118), dict(downsample=118, custom_atan=1), dict(downsample=118, custom_atan=3), dict(downsample=8, custom_atan=1, deemph_a=2),
+    dict(downsample=30, deemph_a=64), dict(downsample=30, deemph_a=65), dict(downsample=50, deemph_a=1), dict(downsample=118, deemph_a=200, custom_atan=1),
+    dict(downsample=118, deemph=0), dict(downsample=40, rate_out2=-1), dict(downsample=40, deemph=0, rate_out2=-1, custom_atan=1),
+    dict(downsample=25, rate_out=96000, rate_out2=48000, deemph_a=7), dict(downsample=1000, custom_atan=1), dict(downsample=2000, custom_atan=0),
+]
+
+
+@pytest.mark.parametrize("env", [{}, {"RXGPU_FLAG_ALL": "2"}, {"RXGPU_DROPIN_FAST": "0"}])
+@pytest.mark.parametrize("kw", FAST_BLOCK_PARAMS)
+def test_dropin_single_block_path(kw, env, monkeypatch):
+    """the drop-in's single blocks of the plain FM chain (k_fm_block_dd + k_ch_audio: two launches, carries as kernel arguments, one copy back)
+    against the reference itself, length after length; with every libm sample handed to the host WRONG ($RXGPU_FLAG_ALL=2: the block's first
+    sample is patched and the audio stages run again from the row as demodulated; -A std blocks have more such samples than the block header
+    holds and take the general path); and the same calls through the general path ($RXGPU_DROPIN_FAST=0)"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    R.lib().rxgpu_knobs_reload()
+    try:
+        test_dropin_takes_every_block_length_the_reference_takes(kw)
+    finally:
+        monkeypatch.undo()
+        R.lib().rxgpu_knobs_reload()
+
+
 @pytest.mark.parametrize("kw", ANY_LENGTH_PARAMS)
 def test_dropin_takes_every_block_length_the_reference_takes(kw):
     """readStream may return ANY element count (rtl_fm.c:894-899): the drop-in, call after call with a different length -- primes,
