@@ -575,6 +575,7 @@ def main():
             g.demod_target = C.pointer(d)
             blk = d_iq[:block_len].cpu().numpy().copy()
             R.check(L.rxgpu_dropin_pin(C.addressof(d), C.addressof(g)))      # what the INTEGRATION.md patch does once at start-up
+            R.check(L.rxgpu_pin(blk.ctypes.data, blk.nbytes))                # ... and for the dongle thread's read buffer (rtl_fm.c:873)
             for _ in range(5):
                 L.rxgpu_callback(blk.ctypes.data, block_len, C.addressof(g))
                 L.rxgpu_full_demod(C.addressof(d))
@@ -599,11 +600,13 @@ def main():
                              "full_demod: set-up (params, side-car, carries in)": ph[2] / ph[6], "full_demod: run (kernels, carries back)": ph[3] / ph[6],
                              "full_demod: D2H of result[] and lowpassed[], struct fields": ph[4] / ph[6]}
             R.check(L.rxgpu_dropin_unpin(C.addressof(d), C.addressof(g)))
+            L.rxgpu_unpin(blk.ctypes.data)
+            L.rxgpu_dropin_release(C.addressof(d))
             host_fed["dropin_block_us"] = {"callback": t_cb * 1e6, "callback+full_demod": t_both * 1e6,
                                            "block_complex_samples": block_len // 2,
                                            "MSample/s": (block_len // 2) / t_both / 1e6, "phase_us": breakdown,
                                            "note": "one 1 MiB block per call pair: H2D raw, pre-stage kernel, D2H into buf16/lowpassed[]; "
-                                                   "full_demod consumes the copy left in HBM, D2H of lowpassed[]/result[] only"}
+                                                   "full_demod consumes the copy left in HBM: k_fm_block_dd + k_fm_row_audio, one copy back (header, result[], lowpassed[])"}
         del d_iq
         torch.cuda.empty_cache()
         value = world * T * args.steps / dt / 1e6

@@ -10,8 +10,9 @@ os.environ["RXGPU_DROPIN_TIMING"] = "1"
 block_len = 2 * 131072
 blk0 = R.synth.sig_fm(block_len // 2)
 names = ["callback: H2D + pre-stage + D2H", "callback: hand-off", "full_demod: set-up", "full_demod: run", "full_demod: copy back + struct"]
-for rep in range(3):
-    for fast in ("1", "0"):
+import itertools
+for rep in range(2):
+    for fast, pinbuf in itertools.product(("1", "0"), (0, 1)):
         os.environ["RXGPU_DROPIN_FAST"] = fast
         L.rxgpu_knobs_reload()
         d = DemodState()
@@ -25,6 +26,7 @@ for rep in range(3):
         g = DongleState(); g.demod_target = C.pointer(d)
         blk = blk0.copy()
         R.check(L.rxgpu_dropin_pin(C.addressof(d), C.addressof(g)))
+        if pinbuf: R.check(L.rxgpu_pin(blk.ctypes.data, blk.nbytes))      # the dongle thread's read buffer (rtl_fm.c:873), one more line of the patch
         for _ in range(10):
             L.rxgpu_callback(blk.ctypes.data, block_len, C.addressof(g)); L.rxgpu_full_demod(C.addressof(d))
         ph = (C.c_double * 7)(); L.rxgpu_dropin_timing(ph, 7)
@@ -35,6 +37,7 @@ for rep in range(3):
         t = (time.perf_counter() - t0) / nb
         L.rxgpu_dropin_timing(ph, 7)
         p = list(ph)
-        print("fast=%s  pair %.1f us  %s" % (fast, t * 1e6, {n: round(v / (p[5] if i < 2 else p[6]), 1) for i, (n, v) in enumerate(zip(names, p[:5]))}), flush=True)
+        print("fast=%s read buffer pinned=%d  pair %.1f us  %s" % (fast, pinbuf, t * 1e6, {n: round(v / (p[5] if i < 2 else p[6]), 1) for i, (n, v) in enumerate(zip(names, p[:5]))}), flush=True)
         R.check(L.rxgpu_dropin_unpin(C.addressof(d), C.addressof(g)))
+        if pinbuf: L.rxgpu_unpin(blk.ctypes.data)
         L.rxgpu_dropin_release(C.addressof(d))
