@@ -970,11 +970,18 @@ def main():
         L.rxgpu_prof_reset()
         L.rxgpu_prof_enable(args.prof_level)
         barrier()
+        import gc
+        gc.collect()
+        gc.disable()                                              # a generation-2 collection over this process's heap costs milliseconds: not inside 20 runs of 0.6 ms
+        step_ms = []
         t0 = time.perf_counter()
         for _ in range(steps):
-            ch.run(d_iq.data_ptr(), n_blocks, block_len, d_out.data_ptr(), windows)
+            t1 = time.perf_counter()
+            ch.run(d_iq.data_ptr(), n_blocks, block_len, d_out.data_ptr(), windows)      # synchronous
+            step_ms.append((time.perf_counter() - t1) * 1e3)
         barrier()
         dt = max_over_ranks(time.perf_counter() - t0)
+        gc.enable()
         L.rxgpu_prof_enable(0)
         ms, launches = prof("ch_fft")
         chan_fix = ch.host_fixups
@@ -1002,7 +1009,7 @@ def main():
         result["channeliser"] = {
             "metric": "256-channel NBFM channeliser, capture MSample/s (extension: fix_fft per 1024-sample window + fm_demod per channel)",
             "value": world * T * steps / dt / 1e6, "unit": "MSample/s", "n_gpus": world, "steps": steps,
-            "ms_per_step": dt / steps * 1e3, "dtype": "int16/int32",
+            "ms_per_step": dt / steps * 1e3, "step_ms_min_median_max": [min(step_ms), sorted(step_ms)[len(step_ms) // 2], max(step_ms)], "dtype": "int16/int32",
             "config": {"workload": "BASELINE configs[4]: 256 channels x 19.5 kHz from one 20 Msps capture, N=1024, -A fast",
                        "blocks_per_step": n_blocks, "parallelism": "replicas x%d" % world, "host_fixups_last_step": int(chan_fix)},
             "roofline": {"bound": "hbm", "kernel": "k_ch_fft", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

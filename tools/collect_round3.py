@@ -118,7 +118,7 @@ def main():
     e = chain_entry(src, "rx_power", 3, 4.0 * 512 * 599 * 8192, "bench.py --workload rx_power --steps 2 --warmup 1: three 512-pass launches of the configs[2] geometry")
     if e:
         chains["rx_power configs[2]"] = e
-    e = chain_entry(src, "chan", 6, 4.0 * 2048 * 131072, "bench.py --workload chan --steps 2 --warmup 1 (5 timed + 1 warm-up run of 1 GiB)")
+    e = chain_entry(src, "chan", 6, 4.0 * 2048 * 131072, "tools/chan_once.py: six runs of the bench shape, 1 GiB of capture each (round 3 and the first half of round 4: bench.py --workload chan --steps 2 --warmup 1)")
     if e:
         chains["channeliser"] = e
     json.dump(chains, open(os.path.join(dst, "%s_pmc_chains.json" % tag), "w"), indent=1)
