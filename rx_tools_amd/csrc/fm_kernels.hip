@@ -3489,6 +3489,8 @@ __global__ __launch_bounds__(256) void k_ch_audio(
 	int16_t *row = rows + c * row_stride;
 	int16_t *yrow = slow > 0 ? y_rows + c * y_stride : row;      // where the (de-emphasised) samples go before resampling
 	const int avg_in = audio_in[3 * c];
+	// rows that start on a 16-byte boundary are walked eight samples per load (a channel's row starts wherever its stride puts it)
+	const bool vec = (((size_t)row | (size_t)yrow) & 15u) == 0;
 	if (deemph) {
 		const int h = a / 2, xoff = h + bias * a;
 		// chunks of at least `warm` samples, multiples of 8, so that every chunk but the first has its warm-up inside the row
@@ -3504,10 +3506,27 @@ __global__ __launch_bounds__(256) void k_ch_audio(
 				lo = hi = avg_in;
 			} else {
 				lo = -32768; hi = 32767;
-				for (u64 i = b - (u64)warm; i < b; i++) {
-					const int x = row[i];
-					lo = deemph_step_d<EVEN, D24>(lo, x + xoff, x, magic, bias);
-					hi = deemph_step_d<EVEN, D24>(hi, x + xoff, x, magic, bias);
+				if (vec) {
+					// eight samples per load, the next eight on their way (b and warm are multiples of 8): a chain step is five instructions, a
+					// load's latency hundreds of cycles -- sample by sample this kernel ran at the speed of its loads
+					uint4 cur = *reinterpret_cast<const uint4 *>(&row[b - (u64)warm]);
+					for (u64 i = b - (u64)warm; i < b; i += 8) {
+						const uint4 nxt = *reinterpret_cast<const uint4 *>(&row[i + 8 < b ? i + 8 : i]);
+						const uint32_t ww[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+						for (int q = 0; q < 8; q++) {
+							const int x = (q & 1) ? hi16(ww[q >> 1]) : lo16(ww[q >> 1]);
+							lo = deemph_step_d<EVEN, D24>(lo, x + xoff, x, magic, bias);
+							hi = deemph_step_d<EVEN, D24>(hi, x + xoff, x, magic, bias);
+						}
+						cur = nxt;
+					}
+				} else {
+					for (u64 i = b - (u64)warm; i < b; i++) {
+						const int x = row[i];
+						lo = deemph_step_d<EVEN, D24>(lo, x + xoff, x, magic, bias);
+						hi = deemph_step_d<EVEN, D24>(hi, x + xoff, x, magic, bias);
+					}
 				}
 			}
 			int gap = hi - lo;
@@ -3515,7 +3534,19 @@ __global__ __launch_bounds__(256) void k_ch_audio(
 			const int lo_start = lo;
 			int cnt = gap + 1;
 			u64 mask = (((u64)1 << gap) - 1);
-			for (u64 i = b; i < e; i++)
+			u64 i = b;
+			if (vec && i + 8 <= e) {
+				uint4 cur = *reinterpret_cast<const uint4 *>(&row[i]);
+				for (; i + 8 <= e; i += 8) {
+					const uint4 nxt = *reinterpret_cast<const uint4 *>(&row[i + 16 <= e ? i + 8 : i]);
+					const uint32_t ww[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+					for (int q = 0; q < 8; q++)
+						deemph_track<EVEN, D24>(lo, cnt, mask, (q & 1) ? hi16(ww[q >> 1]) : lo16(ww[q >> 1]), a, xoff, magic, bias);
+					cur = nxt;
+				}
+			}
+			for (; i < e; i++)
 				deemph_track<EVEN, D24>(lo, cnt, mask, (int)row[i], a, xoff, magic, bias);
 			tab[tid] = make_uint4((uint32_t)lo_start, ((uint32_t)lo & 0xffffu) | ((uint32_t)gap << 16), (uint32_t)mask, (uint32_t)(mask >> 32));
 		}
@@ -3536,7 +3567,26 @@ __global__ __launch_bounds__(256) void k_ch_audio(
 		if (tid < active) {
 			int s = start[tid];
 			if (!serial) {
-				for (u64 i = b; i < e; i++) {
+				u64 i = b;
+				if (vec && i + 8 <= e) {
+					uint4 cur = *reinterpret_cast<const uint4 *>(&row[i]);
+					for (; i + 8 <= e; i += 8) {
+						const uint4 nxt = *reinterpret_cast<const uint4 *>(&row[i + 16 <= e ? i + 8 : i]);
+						const uint32_t ww[4] = {cur.x, cur.y, cur.z, cur.w};
+						uint32_t yy[4];
+#pragma unroll
+						for (int q = 0; q < 4; q++) {
+							const int x0 = lo16(ww[q]), x1 = hi16(ww[q]);
+							s = deemph_step_d<EVEN, D24>(s, x0 + xoff, x0, magic, bias);
+							const int y0 = s;
+							s = deemph_step_d<EVEN, D24>(s, x1 + xoff, x1, magic, bias);
+							yy[q] = pack_iq(y0, s);
+						}
+						*reinterpret_cast<uint4 *>(&yrow[i]) = make_uint4(yy[0], yy[1], yy[2], yy[3]);
+						cur = nxt;
+					}
+				}
+				for (; i < e; i++) {
 					const int x = row[i];
 					s = deemph_step_d<EVEN, D24>(s, x + xoff, x, magic, bias);
 					yrow[i] = (int16_t)s;
@@ -3562,12 +3612,33 @@ __global__ __launch_bounds__(256) void k_ch_audio(
 	if (slow > 0) {
 		const u64 p0 = (u64)audio_in[3 * c + 2];
 		const int ratio = fast / slow;
-		for (u64 j = tid; j < J; j += 256) {
-			const u64 wb = j ? lpr_end(j - 1, fast, slow, p0) : 0, we = lpr_end(j, fast, slow, p0);
-			int sum = j ? 0 : audio_in[3 * c + 1];
-			for (u64 i = wb; i < we; i++)
-				sum += yrow[i];
-			row[j] = (int16_t)(sum / ratio);
+		// four outputs per turn, the first four samples of each window requested before any is summed (a window has fast / slow or one more)
+		for (u64 j0 = tid; j0 < J; j0 += 4 * 256) {
+			u64 wb[4], we[4];
+			int pre[4][4];
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				const u64 j = j0 + (u64)q * 256;
+				const u64 jj = j < J ? j : J - 1;
+				wb[q] = jj ? lpr_end(jj - 1, fast, slow, p0) : 0;
+				we[q] = lpr_end(jj, fast, slow, p0);
+#pragma unroll
+				for (int t = 0; t < 4; t++)
+					pre[q][t] = yrow[wb[q] + t < W ? wb[q] + t : W - 1];
+			}
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				const u64 j = j0 + (u64)q * 256;
+				if (j >= J)
+					break;
+				int sum = j ? 0 : audio_in[3 * c + 1];
+#pragma unroll
+				for (int t = 0; t < 4; t++)
+					sum += wb[q] + t < we[q] ? pre[q][t] : 0;
+				for (u64 i = wb[q] + 4; i < we[q]; i++)
+					sum += yrow[i];
+				row[j] = (int16_t)(sum / ratio);
+			}
 		}
 		if (tid == 0) {
 			const u64 wb = J ? lpr_end(J - 1, fast, slow, p0) : 0;
