@@ -232,6 +232,8 @@ int rxk_fm_demod_lit(void *stream, const int16_t *lp, int L, int mode, int custo
                      const int *atan_lut, int flag_all);
 
 /* rtlsdr_callback's scale + rotate alone (rtl_fm.c:845-857), n_complex samples */
+/* ... with the raw block and a second copy of the result in page-locked HOST memory the device addresses (zero-copy: one launch, no DMA) */
+int rxk_fm_prestage_zc(void *stream, const int16_t *in_host, unsigned n_complex, int rotate, int16_t *out_dev, int16_t *out_host);
 int rxk_fm_prestage(void *stream, const int16_t *in, unsigned n_complex, int rotate, int16_t *out);
 
 /* channeliser (extension): fix_fft per window, selected bins as [channel][window]; then fm_demod per channel */

@@ -1336,6 +1336,9 @@ static struct {
 	int *cb_rdc;                         /* dc_avgI/Q, the block averages, the int64 sums */
 	int16_t *fd_in;                      /* full_demod's own upload buffer (the demod thread's; the callback's are the dongle thread's) */
 	unsigned char *fb_dev, *fb_host;     /* the single-block path (dropin_fast_block): device rows + header, their pinned host mirror */
+	const void *zc_in, *zc_out;          /* the callback's zero-copy form: the host buffers whose device addresses are cached below ... */
+	void *zc_in_dev, *zc_out_dev;
+	unsigned zc_gen;                     /* ... as of this rxgpu_pin_generation(); zc_in_dev == NULL: looked up, not page-locked */
 	pthread_mutex_t cb_lock;             /* one callback at a time per demod_state */
 	int cb_lock_ready;
 } g_side[SIDECARS];
@@ -1430,6 +1433,7 @@ static int pin_range(const void *ptr, size_t bytes, int on)
 	/* exactly the member's bytes, NOT rounded out to pages: the runtime resolves a host pointer by the registered
 	 * ranges, and a foreign buffer that merely shares a boundary page with the struct must not resolve to this one
 	 * (its copies would then fail with hipErrorInvalidValue as soon as they run past the registration's end) */
+	rxgpu_pin_changed();
 	if (on)
 		RX_HIP(hipHostRegister((void *)ptr, bytes, hipHostRegisterDefault));
 	else
@@ -1514,6 +1518,10 @@ void rxgpu_fm_dropin_release(void)
 		g_side[i].s = NULL;
 		hipFree(g_side[i].cb_in); hipFree(g_side[i].cb_rdc); hipFree(g_side[i].cb_pre[0]); hipFree(g_side[i].cb_pre[1]);
 		hipFree(g_side[i].fd_in);
+		hipFree(g_side[i].fb_dev);
+		if (g_side[i].fb_host) hipHostFree(g_side[i].fb_host);
+		g_side[i].fb_dev = g_side[i].fb_host = NULL;
+		g_side[i].zc_gen = 0;
 		g_side[i].cb_in = g_side[i].cb_pre[0] = g_side[i].cb_pre[1] = g_side[i].fd_in = NULL;
 		g_side[i].cb_rdc = NULL;
 		g_side[i].dev_valid = 0;
@@ -1825,8 +1833,36 @@ void rxgpu_callback(int16_t *buf, uint32_t len, void *ctx)
 	const int w = g_side[side].dev_valid ? g_side[side].dev_slot ^ 1 : 0;
 	int16_t *pre = g_side[side].cb_pre[w];
 	hipStream_t st = rxgpu_hip_stream3();            /* its own stream: the demod thread's runs use the other two */
-	int ok = !len || hipMemcpyAsync(cb_in, buf, (size_t)len * 2, hipMemcpyHostToDevice, st) == hipSuccess;
-	if (ok && len && d->dc_block_raw) {
+	/* Both the read buffer and buf16[] page-locked (rxgpu_pin / rxgpu_dropin_pin): the block crosses PCIe inside ONE launch.
+	 * The device addresses are looked up once per buffer pair and registration state. */
+	int zc = 0;
+	if (len && !d->dc_block_raw && !(rxgpu_knob("RXGPU_DROPIN_ZC") && rxgpu_knob("RXGPU_DROPIN_ZC")[0] == '0')) {
+		const unsigned gen = rxgpu_pin_generation();
+		if (g_side[side].zc_gen != gen || g_side[side].zc_in != (const void *)buf || g_side[side].zc_out != (const void *)s->buf16) {
+			void *a = NULL, *b = NULL;
+			void *a_end = NULL;
+			/* the whole block, not just its first byte (a caller may have page-locked less than it reads), and 8-byte pieces */
+			if (hipHostGetDevicePointer(&a, buf, 0) != hipSuccess || hipHostGetDevicePointer(&a_end, (char *)buf + RXGPU_MAXIMUM_BUF_LENGTH * 2 - 1, 0) != hipSuccess ||
+			    hipHostGetDevicePointer(&b, s->buf16, 0) != hipSuccess || (((size_t)a | (size_t)b) & 7u)) {
+				(void)hipGetLastError();                 /* not page-locked: the copies below */
+				a = b = NULL;
+			}
+			g_side[side].zc_in = buf; g_side[side].zc_out = s->buf16;
+			g_side[side].zc_in_dev = a; g_side[side].zc_out_dev = b;
+			g_side[side].zc_gen = gen;
+		}
+		zc = g_side[side].zc_in_dev != NULL && g_side[side].zc_out_dev != NULL;
+	}
+	int ok = 1;
+	if (zc) {
+		ok = rxk_fm_prestage_zc(st, (const int16_t *)g_side[side].zc_in_dev, len / 2, !s->offset_tuning, pre, (int16_t *)g_side[side].zc_out_dev) == 0 &&
+		     hipStreamSynchronize(st) == hipSuccess;
+	} else if (len) {
+		ok = hipMemcpyAsync(cb_in, buf, (size_t)len * 2, hipMemcpyHostToDevice, st) == hipSuccess;
+	}
+	if (zc) {
+		/* done */
+	} else if (ok && len && d->dc_block_raw) {
 		/* rtl_fm.c:850-852: scale, dc_block_raw_filter, rotate; cb_rdc = state[2] | avg[2] | sums[2] */
 		int state[2] = { d->dc_avgI, d->dc_avgQ };
 		ok = hipMemcpyAsync(cb_rdc, state, 8, hipMemcpyHostToDevice, st) == hipSuccess &&

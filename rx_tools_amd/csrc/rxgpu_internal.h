@@ -16,6 +16,8 @@
 int rxgpu_fail(int code, const char *fmt, ...);
 /* make sure rxgpu_init ran (auto-initialises with device -1) */
 int rxgpu_ensure_init(void);
+unsigned rxgpu_pin_generation(void);   /* rxgpu_rt.c: changes whenever host memory is page-locked or released */
+void rxgpu_pin_changed(void);
 int rxgpu_deemph_warm64(int a);          /* rxgpu_chan.c: samples that bring any two int16 de-emphasis states within 64 of each other */
 hipStream_t rxgpu_hip_stream(void);
 hipStream_t rxgpu_hip_stream2(void);   /* second stream: the latency-bound tail of a pipelined rx_fm run */

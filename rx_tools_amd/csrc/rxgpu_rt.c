@@ -45,7 +45,7 @@ static int init_locked(int device);
 static const char *const g_knob_names[] = {
 	"RXGPU_FUSE_A", "RXGPU_NO_FUSED_DD", "RXGPU_NO_TILED", "RXGPU_DEEMPH_CHUNK", "RXGPU_NO_SMALL", "RXGPU_DEEMPH_TOPCAP", "RXGPU_FLAG_ALL",
 	"RXGPU_HOST_CHUNK", "RXGPU_DROPIN_TIMING", "RXGPU_BOXCAR_PLAIN", "RXGPU_FIFTH_PLAIN", "RXGPU_FFT_GENERIC", "RXGPU_FFT_STAGEWISE",
-	"RXGPU_SCAN_DEFERRED", "RXGPU_CH_WPG", "RXGPU_CH_GPW", "RXGPU_DROPIN_FAST", "RXGPU_DEC_NARROW", "RXGPU_DSM_LDS", "RXGPU_SCAN_T", "RXGPU_FF_PAD", "RXGPU_FR_GENERIC", "RXGPU_DD_TW",
+	"RXGPU_SCAN_DEFERRED", "RXGPU_CH_WPG", "RXGPU_CH_GPW", "RXGPU_DROPIN_FAST", "RXGPU_DROPIN_ZC", "RXGPU_DEC_NARROW", "RXGPU_DSM_LDS", "RXGPU_SCAN_T", "RXGPU_FF_PAD", "RXGPU_FR_GENERIC", "RXGPU_DD_TW",
 	"RXGPU_FFT_TW", "RXGPU_CH_DENSE", "RXGPU_NO_DEC_TABLE", "RXGPU_APPLY_ILP", "RXGPU_CAS_MAILBOX", "RXGPU_SDR_V", "RXGPU_EXP0", "RXGPU_EXP1", "RXGPU_EXP2", "RXGPU_EXP3",
 };
 #define N_KNOBS ((int)(sizeof(g_knob_names) / sizeof(g_knob_names[0])))
@@ -166,6 +166,11 @@ hipStream_t rxgpu_hip_stream3(void) { return g_stream3; }
 hipStream_t rxgpu_hip_stream4(void) { return g_stream4; }
 
 /* Host buffers the caller wants DMA'd without a bounce (SURVEY.md section 8b "Ownership"): page-lock them in place. */
+/* page-lock registrations come and go: whoever caches a device address of host memory keys it with this */
+static volatile unsigned g_pin_gen = 1;
+unsigned rxgpu_pin_generation(void) { return g_pin_gen; }
+void rxgpu_pin_changed(void) { __sync_fetch_and_add(&g_pin_gen, 1); }
+
 int rxgpu_pin(void *ptr, size_t bytes)
 {
 	int rc;
@@ -174,6 +179,7 @@ int rxgpu_pin(void *ptr, size_t bytes)
 	if ((rc = rxgpu_ensure_init()) != RXGPU_OK)
 		return rc;
 	RX_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+	rxgpu_pin_changed();
 	return RXGPU_OK;
 }
 
@@ -181,6 +187,7 @@ int rxgpu_unpin(void *ptr)
 {
 	if (!ptr)
 		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_unpin: null pointer");
+	rxgpu_pin_changed();
 	RX_HIP(hipHostUnregister(ptr));
 	return RXGPU_OK;
 }

@@ -342,8 +342,16 @@ def test_dropin_single_block_path(kw, env, monkeypatch):
         R.lib().rxgpu_knobs_reload()
 
 
+@pytest.mark.parametrize("kw", [dict(downsample=118), dict(downsample=6), dict(downsample_passes=3, comp_fir_size=9), dict(downsample=118, offset_tuning=1)])
+def test_dropin_callback_zero_copy(kw):
+    """buf16[] and the read buffer page-locked (rxgpu_dropin_pin + rxgpu_pin, what INTEGRATION.md's patch does): rxgpu_callback then reads the raw
+    block from and writes the scaled one to host memory inside one launch (k_fm_prestage_zc); every length against the reference, the device
+    addresses looked up again whenever a registration changed"""
+    test_dropin_takes_every_block_length_the_reference_takes(kw, pin=True)
+
+
 @pytest.mark.parametrize("kw", ANY_LENGTH_PARAMS)
-def test_dropin_takes_every_block_length_the_reference_takes(kw):
+def test_dropin_takes_every_block_length_the_reference_takes(kw, pin=False):
     """readStream may return ANY element count (rtl_fm.c:894-899): the drop-in, call after call with a different length -- primes,
     two samples, reads shorter than the decimation, an empty read -- against the reference ITSELF (oracle/_ref: its own
     rtlsdr_callback + full_demod on its own struct), including the shapes where the C reads pre_r/pre_j from in front of
@@ -361,6 +369,7 @@ def test_dropin_takes_every_block_length_the_reference_takes(kw):
     d.thread = r.thread = 0x00007F3A5C1E9700
     s = DongleState()
     s.demod_target = C.pointer(d)
+    s.offset_tuning = kw.get("offset_tuning", 0)
     L.rxgpu_deemph_state(C.addressof(d)).contents.value = 0
     rng = np.random.default_rng(abs(hash(str(sorted(kw.items())))) % (1 << 31))
     lens = [2 * 4099, 2 * 97, 2, 2 * 33, 0, 2 * 7, 2 * 65537, 2 * 131071, 2 * 1, 2 * 129, 2 * 100000, 4, 6, 2 * 1009, 2 * 131072, 2 * 12]
@@ -369,11 +378,18 @@ def test_dropin_takes_every_block_length_the_reference_takes(kw):
         lens = [v for v in lens if v]                     # the reference divides by zero on an empty read with -E rdc (rtl_fm.c:711)
     iq = sig_fm(sum(lens) // 2 + 8, seed=77)
     pos = 0
+    if pin:
+        R.check(L.rxgpu_dropin_pin(C.addressof(d), C.addressof(s)))
+        rbuf = np.zeros(262144, np.int16)                 # the dongle thread's read buffer: MAXIMUM_BUF_LENGTH int16, page-locked as a whole
+        R.check(L.rxgpu_pin(rbuf.ctypes.data, rbuf.nbytes))
     try:
         for ln in lens:
             blk = np.ascontiguousarray(iq[pos:pos + max(ln, 2)])
             pos += ln
             a, b = blk.copy(), blk.copy()
+            if pin:
+                rbuf[:len(blk)] = blk
+                b = rbuf
             F.ref_fm_callback(ptr16(a), C.c_uint32(ln), C.byref(rs))
             L.rxgpu_callback(b.ctypes.data, ln, C.addressof(s))
             assert d.lp_len == r.lp_len == ln
@@ -383,3 +399,6 @@ def test_dropin_takes_every_block_length_the_reference_takes(kw):
             _same_state(d, r, L, kw.get("mode", 0) == 0 and r.lp_len < 2)
     finally:
         L.rxgpu_set_demod_functions(None, None, None, None, None)
+        if pin:
+            L.rxgpu_unpin(rbuf.ctypes.data)
+            L.rxgpu_dropin_unpin(C.addressof(d), C.addressof(s))

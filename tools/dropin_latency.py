@@ -12,8 +12,9 @@ blk0 = R.synth.sig_fm(block_len // 2)
 names = ["callback: H2D + pre-stage + D2H", "callback: hand-off", "full_demod: set-up", "full_demod: run", "full_demod: copy back + struct"]
 import itertools
 for rep in range(2):
-    for fast, pinbuf in itertools.product(("1", "0"), (0, 1)):
+    for fast, pinbuf, zc in (("1", 0, "1"), ("1", 1, "1"), ("1", 1, "0"), ("0", 0, "1"), ("0", 1, "0")):
         os.environ["RXGPU_DROPIN_FAST"] = fast
+        os.environ["RXGPU_DROPIN_ZC"] = zc
         L.rxgpu_knobs_reload()
         d = DemodState()
         d.rate_in = d.rate_out = 170000
@@ -37,7 +38,7 @@ for rep in range(2):
         t = (time.perf_counter() - t0) / nb
         L.rxgpu_dropin_timing(ph, 7)
         p = list(ph)
-        print("fast=%s read buffer pinned=%d  pair %.1f us  %s" % (fast, pinbuf, t * 1e6, {n: round(v / (p[5] if i < 2 else p[6]), 1) for i, (n, v) in enumerate(zip(names, p[:5]))}), flush=True)
+        print("fast=%s read buffer pinned=%d zero-copy=%s  pair %.1f us  %s" % (fast, pinbuf, zc if pinbuf else "-", t * 1e6, {n: round(v / (p[5] if i < 2 else p[6]), 1) for i, (n, v) in enumerate(zip(names, p[:5]))}), flush=True)
         R.check(L.rxgpu_dropin_unpin(C.addressof(d), C.addressof(g)))
         if pinbuf: L.rxgpu_unpin(blk.ctypes.data)
         L.rxgpu_dropin_release(C.addressof(d))
