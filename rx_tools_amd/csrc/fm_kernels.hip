@@ -853,7 +853,7 @@ __device__ __forceinline__ void blk_window(const uint32_t *__restrict__ blk, lon
 
 __global__ __launch_bounds__(256) void k_fm_block_dd(const uint32_t *__restrict__ blk, unsigned n, int ds, int p0, int now_r, int now_j,
                                                      int pre_r, int pre_j, int custom_atan, int flag_all, uint32_t *__restrict__ lp,
-                                                     int16_t *__restrict__ pcm, int16_t *__restrict__ keep, rxk_blk_out *__restrict__ out,
+                                                     uint32_t *__restrict__ lp_host, int16_t *__restrict__ pcm, int16_t *__restrict__ keep, rxk_blk_out *__restrict__ out,
                                                      int *__restrict__ audio_in, int avg, int now_lpr, int prev_lpr_index)
 {
 	const unsigned lane = threadIdx.x & 63u;
@@ -886,6 +886,7 @@ __global__ __launch_bounds__(256) void k_fm_block_dd(const uint32_t *__restrict_
 			continue;
 		const int ar = (int16_t)si, aj = (int16_t)sq;
 		lp[m] = pack_iq(ar, aj);
+		lp_host[m] = pack_iq(ar, aj);                            // lowpassed[] for the caller, straight into the page-locked mirror
 		const int cr = (int)((unsigned)ar * (unsigned)br + (unsigned)aj * (unsigned)bj);
 		const int cj = (int)((unsigned)aj * (unsigned)br - (unsigned)ar * (unsigned)bj);
 		int v;
@@ -4390,7 +4391,9 @@ extern "C" int rxk_ch_demod(void *stream, const uint32_t *chan_lp, u64 total_win
 // prev_lpr_index} in, the same three out at audio + 3.
 template <bool EVEN, bool D24>
 __global__ __launch_bounds__(256) void k_fm_row_audio(int16_t *__restrict__ row_g, unsigned W, int deemph, int a, unsigned magic, int bias, int warm,
-                                                      int serial, int fast, int slow, unsigned J, int *__restrict__ audio)
+                                                      int serial, int fast, int slow, unsigned J, int *__restrict__ audio,
+                                                      int16_t *__restrict__ row_h, int *__restrict__ audio_h, const uint32_t *__restrict__ hdr,
+                                                      uint32_t *__restrict__ hdr_h, unsigned hdr_words)
 {
 	extern __shared__ __attribute__((aligned(16))) int16_t ra_row[];       // [W] the samples, then (in place) the de-emphasised ones
 	__shared__ uint4 tab[256];
@@ -4398,6 +4401,10 @@ __global__ __launch_bounds__(256) void k_fm_row_audio(int16_t *__restrict__ row_
 	const int tid = threadIdx.x;
 	for (unsigned i = tid; i < W; i += 256)
 		ra_row[i] = row_g[i];
+	// row_h, audio_h, hdr_h: the page-locked host mirror of the result row, the three audio carries and k_fm_block_dd's header -- what the
+	// caller reads after the stream's synchronisation, no copy operation in between
+	for (unsigned i = tid; i < hdr_words; i += 256)
+		hdr_h[i] = hdr[i];
 	const int avg_in = audio[0];
 	__syncthreads();
 	if (deemph) {
@@ -4452,14 +4459,14 @@ __global__ __launch_bounds__(256) void k_fm_row_audio(int16_t *__restrict__ row_
 					start[t] = s;
 					s = ctab_apply(tab[t], s);
 				}
-				audio[3] = s;
+				audio[3] = s; audio_h[0] = s;
 			} else {
 				for (unsigned i = 0; i < W; i++) {                // any a, any state: the reference's own expression
 					const int d = (int)ra_row[i] - s;
 					s += d > 0 ? (d + h) / a : (d - h) / a;
 					ra_row[i] = (int16_t)s;
 				}
-				audio[3] = s;
+				audio[3] = s; audio_h[0] = s;
 			}
 		}
 		__syncthreads();
@@ -4485,7 +4492,7 @@ __global__ __launch_bounds__(256) void k_fm_row_audio(int16_t *__restrict__ row_
 		}
 		__syncthreads();
 	} else if (tid == 0) {
-		audio[3] = avg_in;
+		audio[3] = avg_in; audio_h[0] = avg_in;
 	}
 	if (slow > 0) {
 		const u64 p0 = (u64)audio[2];
@@ -4496,24 +4503,28 @@ __global__ __launch_bounds__(256) void k_fm_row_audio(int16_t *__restrict__ row_
 			for (u64 i = wb; i < we; i++)
 				sum += ra_row[i];
 			row_g[j] = (int16_t)(sum / ratio);
+			row_h[j] = (int16_t)(sum / ratio);
 		}
 		if (tid == 0) {
 			const u64 wb = J ? lpr_end(J - 1, fast, slow, p0) : 0;
 			int sum = J ? 0 : audio[1];
 			for (u64 i = wb; i < W; i++)
 				sum += ra_row[i];
-			audio[4] = sum;
-			audio[5] = (int)(p0 + (u64)W * (u64)slow - (u64)J * (u64)fast);
+			audio[4] = sum; audio_h[1] = sum;
+			audio[5] = (int)(p0 + (u64)W * (u64)slow - (u64)J * (u64)fast); audio_h[2] = audio[5];
 		}
 	} else {
-		if (deemph)
-			for (unsigned i = tid; i < W; i += 256)
+		for (unsigned i = tid; i < W; i += 256) {
+			if (deemph)
 				row_g[i] = ra_row[i];
-		if (tid == 0) { audio[4] = audio[1]; audio[5] = audio[2]; }
+			row_h[i] = ra_row[i];
+		}
+		if (tid == 0) { audio[4] = audio[1]; audio[5] = audio[2]; audio_h[1] = audio[1]; audio_h[2] = audio[2]; }
 	}
 }
 
-extern "C" int rxk_fm_row_audio(void *stream, int16_t *row, unsigned W, int deemph, int a, int warm, int serial, int fast, int slow, unsigned J, int *audio)
+extern "C" int rxk_fm_row_audio(void *stream, int16_t *row, unsigned W, int deemph, int a, int warm, int serial, int fast, int slow, unsigned J, int *audio,
+                                int16_t *row_h, int *audio_h, const void *hdr, void *hdr_h, unsigned hdr_words)
 {
 	if (!W)
 		return 0;
@@ -4521,7 +4532,8 @@ extern "C" int rxk_fm_row_audio(void *stream, int16_t *row, unsigned W, int deem
 	const unsigned mg = deemph ? deemph_magic(a) : 0u;
 	const int bias = deemph ? bias_for(a) : 0;
 	const size_t lds = ((size_t)W * 2 + 15) & ~(size_t)15;
-#define GO(EV, D) hipLaunchKernelGGL((k_fm_row_audio<EV, D>), dim3(1), dim3(256), lds, s, row, W, deemph, a, mg, bias, warm, serial, fast, slow, J, audio)
+#define GO(EV, D) hipLaunchKernelGGL((k_fm_row_audio<EV, D>), dim3(1), dim3(256), lds, s, row, W, deemph, a, mg, bias, warm, serial, fast, slow, J, audio, \
+		row_h, audio_h, (const uint32_t *)hdr, (uint32_t *)hdr_h, hdr_words)
 	if (deemph && deemph_d24(a)) { if (a & 1) GO(false, true); else GO(true, true); }
 	else { if (!deemph || (a & 1)) GO(false, false); else GO(true, false); }
 #undef GO
@@ -4529,15 +4541,15 @@ extern "C" int rxk_fm_row_audio(void *stream, int16_t *row, unsigned W, int deem
 }
 
 extern "C" int rxk_fm_block_dd(void *stream, const int16_t *blk, unsigned n, int ds, int p0, int now_r, int now_j, int pre_r, int pre_j,
-                               int custom_atan, uint32_t *lp, int16_t *pcm, int16_t *keep, rxk_blk_out *out, int *audio_in, int avg, int now_lpr,
-                               int prev_lpr_index)
+                               int custom_atan, uint32_t *lp, uint32_t *lp_host, int16_t *pcm, int16_t *keep, rxk_blk_out *out, int *audio_in, int avg,
+                               int now_lpr, int prev_lpr_index)
 {
 	const unsigned long long M = ((unsigned long long)p0 + n) / (unsigned long long)ds;
 	unsigned grid = (unsigned)((M + 1 + 3) / 4);
 	if (grid > 2048)
 		grid = 2048;
 	hipLaunchKernelGGL(k_fm_block_dd, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint32_t *)blk, n, ds, p0, now_r, now_j, pre_r, pre_j,
-	                   custom_atan, rxgpu_knob("RXGPU_FLAG_ALL") ? atoi(rxgpu_knob("RXGPU_FLAG_ALL")) : 0, lp, pcm, keep, out, audio_in, avg, now_lpr, prev_lpr_index);
+	                   custom_atan, rxgpu_knob("RXGPU_FLAG_ALL") ? atoi(rxgpu_knob("RXGPU_FLAG_ALL")) : 0, lp, lp_host, pcm, keep, out, audio_in, avg, now_lpr, prev_lpr_index);
 	LAUNCH_RET();
 }
 

@@ -1577,12 +1577,15 @@ static int dropin_fast_block(int slot, struct demod_state *d, const rxgpu_fm_par
 	const int avg = g_side[slot].avg;
 	const int serial = p->deemph && (p->deemph_a < 2 || p->deemph_a > 64 || avg < -32768 || avg > 32767);
 	const int warm = p->deemph && !serial ? rxgpu_deemph_warm64(p->deemph_a) : 8;
-	RX_K(rxk_fm_block_dd(st, d_block, n, ds, d->prev_index, d->now_r, d->now_j, d->pre_r, d->pre_j, p->custom_atan, lp, pcm, keep, hdr, audio,
+	/* the page-locked mirror, same layout: the kernels write what the caller gets straight into it (hipHostMalloc'd memory has one address on both sides) */
+	uint32_t *lp_h = (uint32_t *)(host + FB_HDR + row_b);
+	int16_t *row_h = (int16_t *)(host + FB_HDR);
+	int *audio_h = (int *)(host + FB_AUDIO) + 3;
+	RX_K(rxk_fm_block_dd(st, d_block, n, ds, d->prev_index, d->now_r, d->now_j, d->pre_r, d->pre_j, p->custom_atan, lp, lp_h, pcm, keep, hdr, audio,
 	                     avg, d->now_lpr, d->prev_lpr_index));
-	const size_t back = FB_HDR + row_b + 4 * (size_t)M;
 	for (int attempt = 0; ; attempt++) {
-		RX_K(rxk_fm_row_audio(st, pcm, (unsigned)M, p->deemph, p->deemph_a, warm, serial, p->rate_out, resample ? p->rate_out2 : 0, (unsigned)J, audio));
-		RX_HIP(hipMemcpyAsync(host, dev, back, hipMemcpyDeviceToHost, st));
+		RX_K(rxk_fm_row_audio(st, pcm, (unsigned)M, p->deemph, p->deemph_a, warm, serial, p->rate_out, resample ? p->rate_out2 : 0, (unsigned)J, audio,
+		                      row_h, audio_h, hdr, host, (unsigned)(sizeof(rxk_blk_out) / 4)));
 		RX_HIP(hipStreamSynchronize(st));
 		const rxk_blk_out *h = (const rxk_blk_out *)host;
 		if (!h->flag_cnt || attempt)
