@@ -7,12 +7,14 @@
  *
  * rtlsdr_callback (rtl_fm.c:828) is `static` and called from inside the file: no linker can redirect it.  By default it stays the
  * reference's CPU code (a scale/rotate loop over one block, ~0.5 ms per MiB) and rxgpu_full_demod uploads lowpassed[];
- * `make PATCH=1` compiles a scratch copy in which that one call site (rtl_fm.c:899) is rewritten to rxgpu_callback.
+ * `make PATCH=1` compiles a scratch copy in which that one call site (rtl_fm.c:899) is rewritten to rxgpu_dropin_callback below.
  */
 #include <rxgpu.h>
 
 struct demod_state;
 void full_demod(struct demod_state *d) __attribute__((weak));       /* rtl_fm.c:759: overridable */
+/* what `make PATCH=1` turns the call at rtl_fm.c:899 into (defined behind the #include: it needs the file's MAXIMUM_BUF_LENGTH) */
+static void rxgpu_dropin_callback(int16_t *buf, uint32_t len, void *ctx);
 
 #include RXGPU_REF_RTL_FM_C
 
@@ -29,6 +31,20 @@ static int rxgpu_dropin_fm_setup(void)
 	if (rxgpu_dropin_pin(&demod, &dongle) != RXGPU_OK)
 		fprintf(stderr, "rx_fm (rxgpu): buffers stay pageable: %s\n", rxgpu_last_error());
 	return RXGPU_OK;
+}
+
+/* PATCH=1: rxgpu_callback, with the dongle thread's read buffer (malloc'd at rtl_fm.c:873, MAXIMUM_BUF_LENGTH int16) page-locked the first
+ * time it is seen -- together with buf16[] (rxgpu_dropin_pin above) that lets the block cross PCIe inside one launch (k_fm_prestage_zc).
+ * The buffer lives as long as the thread; the registration goes with the process. */
+static void rxgpu_dropin_callback(int16_t *buf, uint32_t len, void *ctx)
+{
+	static int16_t *seen;
+	if (buf != seen) {
+		seen = buf;
+		if (rxgpu_pin(buf, (size_t)MAXIMUM_BUF_LENGTH * sizeof(int16_t)) != RXGPU_OK)
+			fprintf(stderr, "rx_fm (rxgpu): the read buffer stays pageable: %s\n", rxgpu_last_error());
+	}
+	rxgpu_callback(buf, len, ctx);
 }
 
 /* -L (rtl_fm.c:792-807): the level line lives inside full_demod on the file-static counters above; this is that block behind the
