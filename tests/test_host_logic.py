@@ -170,3 +170,23 @@ def test_newest_round_profiles_hold_what_bench_reads():
     if rnd == "r04":
         legs = json.load(open(os.path.join(root, "profiles", "r04_pmc_power_legs.json")))
         assert len(legs) == 4 and all(v["valu_wave_instr_per_launch"] > 0 and v["hbm_bytes_per_launch"] > 0 for v in legs.values())
+
+
+def test_every_tuning_knob_the_sources_read_is_in_the_snapshot_table():
+    """rxgpu_knob() aborts on a name the snapshot table (rxgpu_rt.c, g_knob_names) does not hold -- on the launch path of whoever asks: every
+    name the library's sources pass to it has to be registered, and INTEGRATION.md has to list the ones a user may set"""
+    import glob
+    import re
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(ROOT, "rx_tools_amd", "csrc")
+    used = set()
+    for f in glob.glob(os.path.join(csrc, "*")):
+        if f.endswith((".c", ".hip", ".h")):
+            used |= set(re.findall(r'rxgpu_knob\("(\w+)"\)', open(f).read()))
+    src = open(os.path.join(csrc, "rxgpu_rt.c")).read()
+    tab = src[src.index("g_knob_names[] = {"):]
+    table = set(re.findall(r'"(RXGPU_\w+)"', tab[:tab.index("};")]))
+    assert used and used <= table, sorted(used - table)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    undocumented = sorted(k for k in used if k not in doc and not re.match(r"RXGPU_EXP\d$", k))
+    assert not undocumented, undocumented
