@@ -90,7 +90,10 @@ int rxgpu_prof_get(const char *name, double *total_ms, long *launches);
  * (-E adc with no demodulated sample: division by result_len == 0, rtl_fm.c:693; -E rdc on an empty read, rtl_fm.c:711): those print to
  * stderr and exit(1) -- there is no CPU fallback.
  * If the block in d->lowpassed is the one rxgpu_callback handed over last (same demod_state, same lp_len, nobody
- * called rxgpu_dropin_invalidate), the copy it left in HBM is used and the block does not cross PCIe a second time. */
+ * called rxgpu_dropin_invalidate), the copy it left in HBM is used and the block does not cross PCIe a second time.
+ * A block of the plain FM chain (low_pass with downsample >= 8, fm_demod -A std | fast | ale, deemph_filter, low_pass_real; no -F, squelch,
+ * dc block, -o) takes two launches and no copy operation (~40 us per 1 MiB); every other shape the general stream path (~105 us).
+ * Same results either way ($RXGPU_DROPIN_FAST=0 takes the general path always). */
 void rxgpu_full_demod(struct demod_state *d);
 /* a caller that edits d->lowpassed between rxgpu_callback and rxgpu_full_demod says so here */
 void rxgpu_dropin_invalidate(const struct demod_state *d);
@@ -118,7 +121,10 @@ int rxgpu_dropin_timing(double *us, int n);
 
 /* Replaces rtlsdr_callback(buf, len, ctx) at rtl_fm.c:899 (definition 828-863):
  * mute-zero, CS16 -> 8-bit-range scale, rotate16_90 unless offset tuning, hand-off into
- * s->demod_target->lowpassed under d->rw, signal d->ready.  len = int16 count. */
+ * s->demod_target->lowpassed under d->rw, signal d->ready.  len = int16 count.
+ * With buf16[] page-locked (rxgpu_dropin_pin) AND the whole read buffer `buf` (MAXIMUM_BUF_LENGTH int16, rtl_fm.c:871-873) page-locked
+ * with rxgpu_pin, the block crosses PCIe inside one launch that reads `buf` and writes buf16[] (30 instead of 47-55 us per 1 MiB);
+ * otherwise an H2D copy, the kernel and a D2H copy.  Same bytes either way ($RXGPU_DROPIN_ZC=0 keeps the copies). */
 void rxgpu_callback(int16_t *buf, uint32_t len, void *ctx);
 
 /* full_demod dispatches on d->mode_demod, a pointer into the reference's own code (rtl_fm.c:154, 808-809).
