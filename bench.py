@@ -34,6 +34,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import re
 import sys
 import time
 
@@ -148,6 +149,7 @@ def cpu_baseline_fm(block_len, budget_s, lib_name="libref_fm.so", ds=118):
     rep(0.2)                                            # pre-fault, warm caches
     best, median, rates = _timed_reps(rep, budget_s)
     return {"value": best / 1e6, "median": median / 1e6, "unit": "MSample/s", "cores": 1, "kind": kind,
+            "sample_short": "3 x %.1f s, blocks of %d complex samples, rtlsdr_callback+full_demod ds=%d, 1 thread, %s" % (budget_s / 3, block_len // 2, ds, cpu_model()),
             "sample": "3 repetitions of %.1f s over blocks of %d complex samples, rtlsdr_callback+full_demod, ds=%d wbfm, 1 thread, %s (%s)"
                       % (budget_s / 3, block_len // 2, ds, "gcc -O0 (the reference's default build)" if "O0" in lib_name else "gcc -O2", cpu_model())}
 
@@ -200,6 +202,7 @@ def cpu_baseline_power(plan, budget_s, lib_name="libref_power.so"):
         kind = "port"
     best, median, rates = _timed_reps(rep, budget_s)
     return {"value": best / 1e6, "median": median / 1e6, "unit": "Mbins/s", "cores": 1, "kind": kind,
+            "sample_short": "3 x %.1f s, scanner() over tune buffers of %d int16 (N=%d), 1 thread, %s" % (budget_s / 3, plan.buf_len, n, cpu_model()),
             "sample": "3 repetitions of %.1f s over tune buffers of %d int16 (N=%d), scanner() per-tune chain, 1 thread, %s (%s)"
                       % (budget_s / 3, plan.buf_len, n, "gcc -O0 (the reference's default build)" if "O0" in lib_name else "gcc -O2", cpu_model())}
 
@@ -301,7 +304,18 @@ def hoist(result, parity_all, world):
                                 if "parity_sharded" in pw else {k: pw.get("parity", {}).get(k) for k in ("parity_checker", "parity_tunes_compared", "parity_passes")}),
             "rx_power_cpu_baseline_Mbins_per_s_1core": (pw.get("cpu_baseline") or {}).get("value"),
             "rx_power_cpu_baseline_kind": (pw.get("cpu_baseline") or {}).get("kind"),
-            "parity_all_legs": dict(parity_all), "n_ranks": world})
+            "parity_all_legs": dict(parity_all), "n_ranks": world,
+            # the same answers as plain scalars (what compact() prints)
+            "gather_impl": ("librxgpu: one ncclGroup{ncclGather avg int64, ncclGather samples int32}" if "rxgpu_power_gather" in c["gather"]
+                            else "torch.distributed.gather" if "torch.distributed" in c["gather"] else "none (single process)"),
+            "rccl_library": os.path.basename(c["gather"].split(" from ")[1].split(" ")[0]) if " from " in c["gather"] else None,
+            "passes_per_step": c["passes_per_step"],
+            "rx_power_1gpu_same_run_Mbins_per_s": pw.get("one_gpu_same_run_Mbins_per_s"),
+            "rx_power_speedup_vs_1gpu": (pw["value"] / pw["one_gpu_same_run_Mbins_per_s"]) if pw.get("one_gpu_same_run_Mbins_per_s") else None,
+            "rx_power_parity_tunes": (pw.get("parity_sharded") or pw.get("parity") or {}).get("parity_tunes_compared"),
+            "rx_power_parity_ranks": (pw.get("parity_sharded") or {}).get("parity_ranks"),
+            "rx_power_padding_rows_zero": (pw.get("parity_sharded") or {}).get("parity_padding_rows_zero"),
+            "rx_fm_replicas_MSample_per_s": result.get("value")})
     if not isinstance(roof, dict):
         return
     legs = {}
@@ -339,6 +353,111 @@ def hoist(result, parity_all, world):
     roof["legs"] = legs
 
 
+LEG_SHORT = {"rx_fm ds=6 (-M wbfm default)": "fm_ds6", "rx_fm ds=5 (configs[0], 240 kHz)": "fm_ds5", "rx_fm -F ds=128": "fm_F_ds128", "rx_fm -M wbfm -F 9": "fm_wbfm_F9",
+             "rx_power N=4096 (configs[2])": "pw_4096", "channeliser 256 ch": "chan256", "channeliser 256 ch, NCO -> low_pass mode": "chan256_nco",
+             "rx_power full-scale input": "pw_4096_fullscale_hamming", "rx_power -f 100M:100.1M:10 -F 9: N=16384": "pw_16384_F9",
+             "rx_power -f 100M:100.1M:10 (boxcar ds=28)": "pw_16384_boxcar", "rx_power -f 100M:100.2M:10 (boxcar ds=14)": "pw_32768_boxcar",
+             "rx_power -f 100M:102.8M:20": "pw_262144",
+             "channeliser 256 ch, -A std (NBFM default)": "chan256_std", "channeliser 256 ch, deemph + low_pass_real": "chan256_audio"}
+COMPACT_LIMIT = 8192           # the driver kept the 4-16 KB lines of rounds 1-3 and dropped round 4's 25 KB one
+
+
+def _num(x, digits=5):
+    """a finite float rounded to `digits` significant figures, ints and bools as they are, anything else (NaN, inf, text) -> None"""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, int):
+        return x
+    try:
+        x = float(x)
+    except (TypeError, ValueError):
+        return None
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float("%.*g" % (digits, x))
+
+
+def leg_key(label):
+    if label in LEG_SHORT:
+        return LEG_SHORT[label]
+    k = label.replace("rx_power ", "pw ").replace("rx_sdr ", "sdr ").replace("rx_fm host-fed ", "hostfed ")
+    k = re.sub(r"\(rxgpu_pin\)|one tune|input", "", k)
+    return re.sub(r"[^A-Za-z0-9.=>+-]+", "_", k).strip("_")[:40]
+
+
+def compact(result, full_path=None):
+    """The ONE stdout line: the contract's scalars, `config`, `roofline` (with every other leg as {b: bound, f: fraction of it, t: HBM traffic over
+    algorithmic bytes, ok: parity verdict}), `cpu_baseline`, `parity_ok` -- numbers and short names only, no nested object deeper than 3, under
+    COMPACT_LIMIT bytes.  Everything else this run measured is the full record (`full`: a file under gpurun_out/, also on stderr)."""
+    out = {k: (_num(result.get(k), 7) if k in ("value", "ms_per_step") else result.get(k))
+           for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    cfg = result.get("config") or {}
+    c = {"workload": cfg.get("workload_short") or str(cfg.get("workload", ""))[:120]}
+    for k in ("blocks_per_step", "block_complex_samples", "bytes_per_step", "parallelism", "host_fixups_timed_loop", "passes_per_step", "n_ranks", "rccl_ranks",
+              "rccl_gathers_enqueued", "gather_impl", "rccl_library", "gather_bytes_per_rank", "tunes_per_rank", "tunes_rank0", "rx_power_Mbins_per_s", "rx_power_ms_per_step",
+              "rx_power_1gpu_same_run_Mbins_per_s", "rx_power_speedup_vs_1gpu", "scan_us_rank0", "gather_us_rank0", "rx_power_parity_ok", "rx_power_parity_tunes",
+              "rx_power_parity_ranks", "rx_power_padding_rows_zero", "rx_power_cpu_baseline_Mbins_per_s_1core", "rx_fm_replicas_MSample_per_s"):
+        if k in cfg and cfg[k] is not None:
+            c[k] = _num(cfg[k], 6) if isinstance(cfg[k], float) else cfg[k]
+    out["config"] = c
+    roof = result.get("roofline") or {}
+    r = {k: (_num(roof.get(k), 6) if not isinstance(roof.get(k), str) else roof.get(k))
+         for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "frac_of_box_read_only",
+                   "hbm_achieved", "hbm_frac") if k in roof}
+    if isinstance(roof.get("box_ceilings"), dict):
+        r["box_read_only_GBs"] = _num(roof["box_ceilings"].get("read_only_GBs"), 5)
+    legs = {}
+    for label, v in (roof.get("legs") or {}).items():
+        t = v.get("traffic_over_algorithmic")
+        if t is None and v.get("traffic_frac") and v.get("hbm_frac"):
+            t = v["traffic_frac"] / v["hbm_frac"]
+        e = {"b": v.get("bound"), "f": _num(v.get("frac"), 4), "t": _num(t, 4), "ok": v.get("parity_ok")}
+        if v.get("bound") not in ("hbm", "pcie") and v.get("hbm_frac") is not None:
+            e["hbm_f"] = _num(v["hbm_frac"], 4)
+        legs[leg_key(label)] = e
+    if legs:
+        r["legs"] = legs
+    out["roofline"] = r
+    cb = result.get("cpu_baseline")
+    if isinstance(cb, dict):
+        out["cpu_baseline"] = {"value": _num(cb.get("value"), 6), "median": _num(cb.get("median"), 6), "unit": cb.get("unit"), "cores": cb.get("cores"),
+                               "kind": cb.get("kind"), "sample": cb.get("sample_short") or str(cb.get("sample", ""))[:160]}
+        ac = cb.get("all_cores")
+        if isinstance(ac, dict) and ac.get("value"):
+            out["cpu_baseline"]["all_cores_value"] = _num(ac["value"], 6)
+            out["cpu_baseline"]["all_cores"] = ac.get("cores")
+    if "parity_ok" in result:
+        out["parity_ok"] = result["parity_ok"]
+    if result.get("parity_checked_samples") is not None:
+        out["parity_checked_samples"] = result["parity_checked_samples"]
+    if result.get("parity_checker"):
+        out["parity_checker"] = str(result["parity_checker"]).split(" ")[0]
+    if result.get("parity_all_legs"):
+        out["parity_all_legs"] = result["parity_all_legs"]
+    if full_path:
+        out["full"] = full_path
+    line = json.dumps(out, allow_nan=False, separators=(",", ":"))
+    if len(line) >= COMPACT_LIMIT:                               # cannot happen with today's legs (~3 KB); if it ever does, the legs go first
+        out["roofline"].pop("legs", None)
+        line = json.dumps(out, allow_nan=False, separators=(",", ":"))
+    return line
+
+
+def self_launch(argv, n):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: become `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...
+    bench.py <the same arguments>` on a free local port (one process per GPU; the launcher's own stdout carries rank 0's line)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + list(argv)
+    sys.stderr.write("bench.py: --gpus %d without a torchrun environment: exec %s\n" % (n, " ".join(cmd)))
+    sys.stderr.flush()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.execv(sys.executable, cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -357,6 +476,8 @@ def main():
     ap.add_argument("--allow-torch-gather", action="store_true",
                     help="N>1 only: if librxgpu's own RCCL communicator cannot be created, gather through torch.distributed instead of failing")
     ap.add_argument("--no-parity", action="store_true", help="skip the full-size comparison with the CPU reference")
+    ap.add_argument("--full-out", default=os.path.join(ROOT, "gpurun_out", "bench_full.json"),
+                    help="where rank 0 writes the full record (every leg, every parity dict); stdout carries the compact line only")
     args = ap.parse_args()
     if args.cpu_worker:
         cpu_worker(args.cpu_worker, args.cpu_seconds, args.cpu_lib)
@@ -371,8 +492,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            self_launch(sys.argv[1:], args.gpus)                 # does not return
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # $RXGPU_BENCH_SHARE_GPU=1 (test hook, tests/test_gpu_power.py): every rank on device 0 and torch.distributed over gloo -- with
     # $RXGPU_RCCL_LIB pointing at tests/fake_rccl.c this runs the N > 1 path of this file on a box with ONE GPU (RCCL refuses two
     # ranks per device).  Not a measurement.
@@ -638,10 +760,11 @@ def main():
             "metric": "rx_fm full_demod complex IQ MSample/s (20 Msps WBFM geometry, ds=118)",
             "value": value, "unit": "MSample/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int16/int32 (fp32 fma for the cs16 scale, fp64 for one atan2 per block)",
+            "vs_baseline": None, "dtype": "int16/int32", "dtype_note": "fp32 fma for the cs16 scale (equal on all 65536 inputs), fp64 for one atan2 per block",
             "data": "synthetic",
             "config": {"workload": "rx_fm WBFM 20.06 Msps -> 170 ksps -> 32 ksps: callback scale+rotate, low_pass ds=118, "
                                    "polar_disc_fast, deemph a=13, low_pass_real (BASELINE configs[1])",
+                       "workload_short": "rx_fm WBFM 20.06 Msps, callback+full_demod, ds=118 -> 170 ksps -> 32 ksps (BASELINE configs[1])",
                        "blocks_per_step": n_blocks, "block_complex_samples": block_len // 2,
                        "bytes_per_step": 4 * T, "parallelism": "replicas x%d (rx_fm does not shard)" % world,
                        "capture": "non-repeating, generated on the device (seeded): FM carrier at -fs/4, 1 kHz tone, 75 kHz deviation, +-128 LSB noise",
@@ -734,6 +857,25 @@ def main():
         ms, launches = prof("pw_fft")
         gms, gl = prof("pw_gather")
         observed = comm.observed if comm is not None else (0, 1)
+        # N > 1: the whole sweep on rank 0's GPU alone, same process, same clocks -- the 1-GPU point of the strong-scaling curve inside the same line
+        one_gpu_rate = None
+        if world > 1:
+            if rank == 0:
+                ps1 = R.PowerScan(R.PowerParams(plan.bin_e, plan.buf_len, plan.downsample, plan.downsample_passes, 1, 0, 0), total_tunes, wc, sw)
+                d_in1 = torch.randint(-100, 101, (passes, total_tunes, plan.buf_len), dtype=torch.int16, device=dev, generator=g)
+                d_a1 = torch.zeros((total_tunes, n), dtype=torch.int64, device=dev)
+                d_s1 = torch.zeros(total_tunes, dtype=torch.int32, device=dev)
+                for _ in range(max(2, args.warmup)):
+                    ps1.run(d_in1.data_ptr(), passes, total_tunes, d_a1.data_ptr(), d_s1.data_ptr())
+                L.rxgpu_sync()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    ps1.run(d_in1.data_ptr(), passes, total_tunes, d_a1.data_ptr(), d_s1.data_ptr())
+                L.rxgpu_sync()
+                one_gpu_rate = passes * total_tunes * (plan.buf_len // 2) * args.steps / (time.perf_counter() - t1) / 1e6
+                ps1.close()
+                del d_in1, d_a1, d_s1
+            barrier()
         bins_per_step_all = passes * total_tunes * (plan.buf_len // 2)
         bins_local = passes * mine * (plan.buf_len // 2)
         hbm_achieved = (4.0 * bins_local) / (ms / launches * 1e-3) / 1e9 if launches else 0.0
@@ -752,8 +894,9 @@ def main():
         pw = {
             "metric": "rx_power FFT bins/s (scanner() chain, -f 24M:1.7G:1k geometry)",
             "value": bins_per_step_all * args.steps / dt / 1e6, "unit": "Mbins/s", "n_gpus": world,
-            "ms_per_step": dt / args.steps * 1e3, "scaling": "strong", "dtype": "int16/int32/int64",
+            "ms_per_step": dt / args.steps * 1e3, "scaling": "strong", "dtype": "int16/int32/int64", "one_gpu_same_run_Mbins_per_s": one_gpu_rate,
             "config": {"workload": "599 tunes x 16384 int16, N=4096, 2 FFT blocks/tune/pass, rectangle window (BASELINE configs[2]/[3])",
+                       "workload_short": "rx_power -f 24M:1.7G:1k: 599 tunes x 16384 int16, N=4096 (BASELINE configs[2]/[3])",
                        "passes_per_step": passes, "tunes_this_rank": mine, "tunes_per_rank_padded": per,
                        "rccl_ranks": observed[1], "rccl_ranks_source": "ncclCommCount, checked by rxgpu_comm_create" if comm is not None else "no communicator",
                        "rccl_gathers_enqueued": comm.gathers if comm is not None else 0,
@@ -1115,7 +1258,19 @@ def main():
         if parity_all:
             result["parity_all_legs"] = parity_all
             result["parity_ok"] = all(parity_all.values())
-        print(json.dumps(result))
+        full = json.dumps(result)
+        full_path = None
+        try:
+            os.makedirs(os.path.dirname(args.full_out), exist_ok=True)
+            with open(args.full_out, "w") as f:
+                f.write(full + "\n")
+            full_path = os.path.relpath(args.full_out, ROOT)
+        except OSError as e:
+            sys.stderr.write("bench.py: full record not written to %s: %s\n" % (args.full_out, e))
+        sys.stderr.write("BENCH_FULL " + full + "\n")
+        sys.stderr.flush()
+        print(compact(result, full_path))                          # the ONE stdout line
+        sys.stdout.flush()
         if result.get("parity_ok") is False:
             sys.stderr.write("bench.py: GPU output differs from the CPU reference at bench size: %s\n" % sorted(k for k, v in parity_all.items() if not v))
             sys.exit(3)

@@ -48,7 +48,7 @@ void rxgpu_dropin_scanner(size_t channel)
 {
 	static int ready;
 	static unsigned char got[MAX_TUNES];
-	int i, missed = 0;
+	int i, missed = 0, n_read;
 	if (!ready) {
 		rxgpu_dropin_power_setup();
 		ready = 1;
@@ -60,7 +60,7 @@ void rxgpu_dropin_scanner(size_t channel)
 		int flags = 0, r;
 		long long timeNs = 0;
 		if (do_exit >= 2)
-			return;
+			break;                                                 /* the reference returns here with tunes [0, i) already integrated */
 		if ((int64_t)SoapySDRDevice_getFrequency(dev, SOAPY_SDR_RX, channel) != ts->freq)
 			retune(dev, stream, ts->freq, channel);
 		r = SoapySDRDevice_readStream(dev, stream, buffs, tunes[0].buf_len, &flags, &timeNs, 1000000);
@@ -69,6 +69,11 @@ void rxgpu_dropin_scanner(size_t channel)
 			fprintf(stderr, "Error: reading stream %d\n", r);      /* the reference skips the tune's compute (`continue`) */
 			missed++;
 		}
+	}
+	n_read = i;
+	for (; i < tune_count; i++) {
+		got[i] = 0;                                                    /* an interrupted sweep: the tunes never read count as missed */
+		missed++;
 	}
 	/* the compute half, every tune that was read: one call when none was missed */
 	if (!missed) {
@@ -81,9 +86,9 @@ void rxgpu_dropin_scanner(size_t channel)
 	/* some reads failed: the runs of tunes that were read go one by one, merged at once (another array start per call) */
 	if (rxgpu_scan_sync(tunes, tune_count) != RXGPU_OK || rxgpu_scan_deferred(0) != RXGPU_OK)
 		rxgpu_dropin_die("rxgpu_scan_sync");
-	for (i = 0; i < tune_count; ) {
+	for (i = 0; i < n_read; ) {
 		int j = i;
-		while (j < tune_count && got[j])
+		while (j < n_read && got[j])
 			j++;
 		/* scanner() takes the geometry from tunes[0] for every tune (rtl_power.c:676-678); frequency_range gives them all the same */
 		if (j > i && rxgpu_scan(&tunes[i], j - i, window_coefs, Sinewave, boxcar, comp_fir_size, peak_hold) != RXGPU_OK)

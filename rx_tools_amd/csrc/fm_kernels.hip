@@ -4413,7 +4413,7 @@ __global__ __launch_bounds__(256) void k_fm_row_audio(int16_t *__restrict__ row_
 		const unsigned w0 = serial ? W : min((unsigned)warm, W);
 		// (the walk over the chunk tables is one thread's, ~250 cycles per table, a step of a chain ~50: chunks of 48 balance the two at W ~ 1000)
 		unsigned Cn = (W - w0 + 254) / 255;
-		Cn = Cn < 48 ? 48 : Cn;
+		Cn = Cn < 48 ? 48 : ((Cn + 7) & ~7u);                 // a multiple of 8: the chunk starts stay 8-byte aligned for the uint2 reads below
 		const int active = 1 + (int)((W - w0 + Cn - 1) / Cn);
 		const unsigned b = tid ? w0 + (unsigned)(tid - 1) * Cn : 0u, e = tid ? min(W, b + Cn) : w0;
 		if (tid < active && !serial) {

@@ -311,6 +311,10 @@ int rxgpu_power_scan_run_sharded(rxgpu_power_scan *s, rxgpu_comm *c, const int16
 		return rc;
 	const int k = c->pend_next;
 	c->pend_next ^= 1;
+	/* two entries: a caller rotating three or more buffer sets would evict a gather that may still be reading its send buffers --
+	 * the scan stream then waits for the evicted gather before anything later can be scanned into those buffers */
+	if (c->pend[k].valid)
+		RX_HIP(hipStreamWaitEvent(sa, c->pend[k].ev, 0));
 	if (!c->pend[k].ev)
 		RX_HIP(hipEventCreateWithFlags(&c->pend[k].ev, hipEventDisableTiming));
 	RX_HIP(hipEventRecord(c->pend[k].ev, sc));

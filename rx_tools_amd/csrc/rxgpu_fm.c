@@ -1339,9 +1339,11 @@ static struct {
 	const void *zc_in, *zc_out;          /* the callback's zero-copy form: the host buffers whose device addresses are cached below ... */
 	void *zc_in_dev, *zc_out_dev;
 	unsigned zc_gen;                     /* ... as of this rxgpu_pin_generation(); zc_in_dev == NULL: looked up, not page-locked */
-	pthread_mutex_t cb_lock;             /* one callback at a time per demod_state */
-	int cb_lock_ready;
 } g_side[SIDECARS];
+/* one callback at a time per side-car slot.  The locks live OUTSIDE the records: rxgpu_dropin_release zeroes a record while threads may be
+ * queued on its lock, and a mutex must never be copied or cleared under its waiters. */
+static pthread_mutex_t g_side_cb_lock[SIDECARS];
+static int g_side_cb_lock_ready[SIDECARS];
 static pthread_mutex_t g_side_lock = PTHREAD_MUTEX_INITIALIZER;
 
 static int side_slot(const struct demod_state *d)
@@ -1356,9 +1358,9 @@ static int side_slot(const struct demod_state *d)
 	}
 	if (found < 0 && free_slot >= 0) {
 		g_side[free_slot].d = d;
-		if (!g_side[free_slot].cb_lock_ready) {
-			pthread_mutex_init(&g_side[free_slot].cb_lock, NULL);
-			g_side[free_slot].cb_lock_ready = 1;
+		if (!g_side_cb_lock_ready[free_slot]) {
+			pthread_mutex_init(&g_side_cb_lock[free_slot], NULL);
+			g_side_cb_lock_ready[free_slot] = 1;
 		}
 		found = free_slot;
 	}
@@ -1394,18 +1396,17 @@ int rxgpu_dropin_release(const struct demod_state *d)
 			found = i;
 	if (found >= 0) {
 		const int i = found;
-		pthread_mutex_lock(&g_side[i].cb_lock);          /* a callback of this demod_state still running finishes first */
+		/* a callback of this demod_state that is INSIDE its critical section finishes first; one still queued on the lock finds
+		 * the slot no longer its own when it gets in (rxgpu_callback re-checks g_side[side].d under the lock) and resolves again */
+		pthread_mutex_lock(&g_side_cb_lock[i]);
 		if (g_side[i].s)
 			rxgpu_fm_stream_destroy(g_side[i].s);
 		hipFree(g_side[i].cb_in); hipFree(g_side[i].cb_rdc); hipFree(g_side[i].cb_pre[0]); hipFree(g_side[i].cb_pre[1]);
 		hipFree(g_side[i].fd_in);
 		hipFree(g_side[i].fb_dev);
 		if (g_side[i].fb_host) hipHostFree(g_side[i].fb_host);
-		pthread_mutex_t keep = g_side[i].cb_lock;
 		memset(&g_side[i], 0, sizeof(g_side[i]));
-		g_side[i].cb_lock = keep;
-		g_side[i].cb_lock_ready = 1;
-		pthread_mutex_unlock(&g_side[i].cb_lock);
+		pthread_mutex_unlock(&g_side_cb_lock[i]);
 	}
 	pthread_mutex_unlock(&g_side_lock);
 	return found >= 0 ? RXGPU_OK : rxgpu_fail(RXGPU_EINVAL, "rxgpu_dropin_release: no side-car for this demod_state");
@@ -1808,7 +1809,7 @@ void rxgpu_callback(int16_t *buf, uint32_t len, void *ctx)
 		rxgpu_fail(RXGPU_EINVAL, "callback length %u", len);
 		die("rxgpu_callback");
 	}
-	const int side = side_slot(d);
+	int side = side_slot(d);
 	if (side < 0) {
 		rxgpu_fail(RXGPU_ECAPACITY, "more than %d demod_state objects", SIDECARS);
 		die("rxgpu_callback");
@@ -1824,9 +1825,21 @@ void rxgpu_callback(int16_t *buf, uint32_t len, void *ctx)
 	}
 	const int timing = dt_on();
 	double t_a = timing ? now_us() : 0, t_b;
-	pthread_mutex_lock(&g_side[side].cb_lock);       /* the buffers below belong to this demod_state; one callback at a time on them */
+	/* the buffers below belong to this demod_state; one callback at a time on them.  The slot was resolved before the lock: if
+	 * rxgpu_dropin_release ran while this thread was queued, the record is zeroed (or already someone else's) -- resolve again */
+	for (;;) {
+		pthread_mutex_lock(&g_side_cb_lock[side]);
+		if (__atomic_load_n(&g_side[side].d, __ATOMIC_ACQUIRE) == d)
+			break;
+		pthread_mutex_unlock(&g_side_cb_lock[side]);
+		side = side_slot(d);
+		if (side < 0) {
+			rxgpu_fail(RXGPU_ECAPACITY, "more than %d demod_state objects", SIDECARS);
+			die("rxgpu_callback");
+		}
+	}
 	if (side_buffers(side) != RXGPU_OK) {
-		pthread_mutex_unlock(&g_side[side].cb_lock);
+		pthread_mutex_unlock(&g_side_cb_lock[side]);
 		die("rxgpu_callback");
 	}
 	int16_t *const cb_in = g_side[side].cb_in;
@@ -1882,7 +1895,7 @@ void rxgpu_callback(int16_t *buf, uint32_t len, void *ctx)
 		     hipStreamSynchronize(st) == hipSuccess;
 	}
 	if (!ok) {
-		pthread_mutex_unlock(&g_side[side].cb_lock);
+		pthread_mutex_unlock(&g_side_cb_lock[side]);
 		rxgpu_fail(RXGPU_ENODEV, "device pre-stage failed: %s", hipGetErrorString(hipGetLastError()));
 		die("rxgpu_callback");
 	}
@@ -1894,7 +1907,7 @@ void rxgpu_callback(int16_t *buf, uint32_t len, void *ctx)
 	g_side[side].dev_len = (int)len;
 	g_side[side].dev_valid = len > 0;
 	pthread_rwlock_unlock(&d->rw);
-	pthread_mutex_unlock(&g_side[side].cb_lock);
+	pthread_mutex_unlock(&g_side_cb_lock[side]);
 	pthread_mutex_lock(&d->ready_m);
 	pthread_cond_signal(&d->ready);
 	pthread_mutex_unlock(&d->ready_m);

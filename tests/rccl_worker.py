@@ -1,5 +1,5 @@
 """One rank of the multi-GPU rx_power path, everything through librxgpu: rxgpu_power_scan_run on this rank's tunes,
-ncclGather from librccl on the library's stream (rxgpu_power_gather), rank 0 feeds rxgpu_csv_dbm and compares the CSV
+ncclGather from librccl (rxgpu_power_gather: on the library's stream; the sharded entry point puts it on the copy stream behind the scan), rank 0 feeds rxgpu_csv_dbm and compares the CSV
 with the oracle's single-process sweep.  No torch.distributed: the ncclUniqueId travels through a file, the way a C
 rx_power launched once per GPU would pass it.
 
@@ -62,7 +62,7 @@ def main():
     d_avg_all = torch.zeros((world, per, n), dtype=torch.int64, device="cuda") if rank == 0 else None
     d_smp_all = torch.zeros((world, per), dtype=torch.int32, device="cuda") if rank == 0 else None
     torch.cuda.synchronize()
-    # the sharded entry point: scan of this rank's tunes + the gather, both on the library's stream, no host sync between
+    # the sharded entry point: scan of this rank's tunes on the library's stream + the gather behind it on the copy stream, no host sync between (rxgpu_sync covers both)
     R.check(L.rxgpu_power_scan_run_sharded(ps._h, comm._h, d_in.data_ptr(), passes, TOTAL_TUNES, d_avg.data_ptr(), d_smp.data_ptr(), n,
                                            d_avg_all.data_ptr() if rank == 0 else None, d_smp_all.data_ptr() if rank == 0 else None, 0))
     R.check(L.rxgpu_sync())

@@ -168,12 +168,13 @@ def test_sharded_sweep_multi_rank_on_one_gpu(world, tmp_path):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("world", [2, 4])
-def test_bench_multi_rank_path_on_one_gpu(world, tmp_path):
-    """bench.py --gpus N exactly as the driver launches it (torch.distributed.run, one process per rank), on this box's one GPU: every
-    rank on device 0, torch.distributed over gloo and librxgpu's communicator over the file transport ($RXGPU_BENCH_SHARE_GPU is the
-    hook).  The N > 1 code of bench.py -- rx_fm replicas with a max over ranks, rx_power tunes sharded through
-    rxgpu_power_scan_run_sharded with the grouped gather, one JSON line from rank 0 -- has then run before the driver's 8-GPU node runs it."""
+@pytest.mark.parametrize("world,form", [(2, "torchrun"), (4, "plain")])
+def test_bench_multi_rank_path_on_one_gpu(world, form, tmp_path):
+    """bench.py --gpus N as the driver launches it -- under torch.distributed.run ("torchrun"), and as the bare `python bench.py --gpus N` of
+    its N=1 command ("plain": bench.py re-executes itself under the launcher) -- on this box's one GPU: every rank on device 0,
+    torch.distributed over gloo and librxgpu's communicator over the file transport ($RXGPU_BENCH_SHARE_GPU is the hook).  The N > 1 code of
+    bench.py -- rx_fm replicas with a max over ranks, rx_power tunes sharded through rxgpu_power_scan_run_sharded with the grouped gather,
+    ONE compact JSON line from rank 0 on stdout, the full record in a file -- has then run before the driver's 8-GPU node runs it."""
     import json
     import os
     import socket
@@ -184,31 +185,46 @@ def test_bench_multi_rank_path_on_one_gpu(world, tmp_path):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, RXGPU_RCCL_LIB=_fake_rccl(), FAKE_RCCL_DIR=str(tmp_path), RXGPU_BENCH_SHARE_GPU="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
-           "--blocks", "256", "--passes", "8", "--cpu-seconds", "1.5"]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    full_path = str(tmp_path / "full.json")
+    args = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--blocks", "256", "--passes", "8", "--cpu-seconds", "1.5", "--full-out", full_path]
+    if form == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(root, "bench.py")] + args
+    else:
+        cmd = [sys.executable, os.path.join(root, "bench.py")] + args
     out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=800)
     assert out.returncode == 0, out.stderr.decode()[-3000:]
-    line = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    stdout_lines = [ln for ln in out.stdout.decode().splitlines() if ln.strip()]
+    assert len(stdout_lines) == 1 and len(stdout_lines[0]) < 8192            # ONE line, of a size the driver has been seen to keep
+    compact = json.loads(stdout_lines[0])
+    line = json.load(open(full_path))
     assert line["n_gpus"] == world and line["value"] > 0 and line["config"]["parallelism"].startswith("replicas x%d" % world)
     pw = line["rx_power"]
     # warm-up + steps + the one parity interval
     assert pw["n_gpus"] == world and pw["config"]["rccl_ranks"] == world and pw["config"]["rccl_gathers_enqueued"] == 4
     assert "rxgpu_power_gather" in pw["config"]["gather"] and "libfake_rccl" in pw["config"]["gather"]
     assert pw["config"]["tunes_per_rank_padded"] == -(-599 // world) and pw["value"] > 0
-    # what the driver's record keeps (top-level config / roofline / cpu_baseline) answers the scaling questions by itself:
-    cfg = line["config"]
-    assert cfg["n_ranks"] == world and cfg["rccl_ranks"] == world and cfg["rccl_gathers_enqueued"] == 4
-    assert cfg["rx_power_Mbins_per_s"] == pw["value"] and cfg["rx_power_ms_per_step"] > 0 and cfg["tunes_per_rank"] == -(-599 // world)
-    assert cfg["scan_us_rank0"] > 0 and cfg["gather_us_rank0"] > 0 and "rxgpu_power_gather" in cfg["gather"]
     # ... and the gathered rows of the sharded interval were compared with the CPU checker over every tune of every rank
     v = pw["parity_sharded"]
     assert v["parity_ok"] and v["parity_ranks"] == world and v["parity_tunes_compared"] == 599 and v["parity_passes"] == 8
     assert v["parity_padding_rows_zero"] and v["parity_inputs_regenerated_match_owner_checksums"]
-    assert cfg["rx_power_parity_ok"] is True and cfg["parity_all_legs"]["rx_power_sharded"] is True and cfg["parity_all_legs"]["rx_fm"] is True
     assert line["parity_ok"] is True and line["parity_checked_samples"] > 0
-    assert "rx_power N=4096 (configs[2])" in line["roofline"]["legs"] and "channeliser 256 ch" in line["roofline"]["legs"]
-    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] == 1 and cfg["rx_power_cpu_baseline_Mbins_per_s_1core"] > 0
+    # the compact line alone answers the scaling questions: ranks seen by the communicator, sharded bins/s beside the 1-GPU rate of the same
+    # run, the gathered rows bit-exact against the reference's scanner()
+    cfg = compact["config"]
+    assert compact["n_gpus"] == world and compact["steps"] == 2 and compact["warmup"] == 1 and compact["value"] == float("%.7g" % line["value"])
+    assert cfg["n_ranks"] == world and cfg["rccl_ranks"] == world and cfg["rccl_gathers_enqueued"] == 4 and cfg["rccl_library"].startswith("libfake_rccl")
+    assert abs(cfg["rx_power_Mbins_per_s"] / pw["value"] - 1) < 1e-4 and cfg["rx_power_ms_per_step"] > 0 and cfg["tunes_per_rank"] == -(-599 // world)
+    assert cfg["rx_power_1gpu_same_run_Mbins_per_s"] > 0 and cfg["rx_power_speedup_vs_1gpu"] > 0
+    assert cfg["scan_us_rank0"] > 0 and cfg["gather_us_rank0"] > 0 and "ncclGather" in cfg["gather_impl"]
+    assert cfg["rx_power_parity_ok"] is True and cfg["rx_power_parity_tunes"] == 599 and cfg["rx_power_parity_ranks"] == world
+    assert cfg["rx_power_padding_rows_zero"] is True
+    assert compact["parity_ok"] is True and compact["parity_all_legs"]["rx_power_sharded"] is True and compact["parity_all_legs"]["rx_fm"] is True
+    assert compact["roofline"]["legs"]["pw_4096"]["ok"] is True and "chan256" in compact["roofline"]["legs"]
+    assert compact["roofline"]["frac"] > 0 and compact["roofline"]["avg_launch_ms"] > 0
+    assert compact["cpu_baseline"]["value"] > 0 and compact["cpu_baseline"]["cores"] == 1 and cfg["rx_power_cpu_baseline_Mbins_per_s_1core"] > 0
 
 
 def test_comm_rejects_a_rank_the_communicator_does_not_report(tmp_path):

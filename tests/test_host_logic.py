@@ -190,3 +190,65 @@ def test_every_tuning_knob_the_sources_read_is_in_the_snapshot_table():
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     undocumented = sorted(k for k in used if k not in doc and not re.match(r"RXGPU_EXP\d$", k))
     assert not undocumented, undocumented
+
+
+def test_bench_compact_line_stays_small_and_strict():
+    """What bench.py prints on stdout is ONE compact line: the driver kept the 4-16 KB lines of rounds 1-3 and dropped round 4's 25 KB one
+    (BENCH_r04.json: parsed null).  compact() over the largest full records committed so far must stay under 8 KB, be strict JSON (no NaN /
+    Infinity, no object nested deeper than 3), and carry the fields the contract names."""
+    import json, os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    def depth(o):
+        return 1 + max((depth(v) for v in o.values()), default=0) if isinstance(o, dict) else 0
+
+    for name in ("r04_bench_n1.json", "r04_bench_n1_b.json", "r03_bench_n1.json"):
+        full = json.load(open(os.path.join(root, "profiles", name)))
+        full["roofline"]["poison"] = float("nan")                 # a NaN anywhere in the full record must not reach the line
+        full["value"] = float(full["value"])
+        line = bench.compact(full, "gpurun_out/bench_full.json")
+        assert "\n" not in line and len(line) < bench.COMPACT_LIMIT and len(line) < 8192, (name, len(line))
+        assert "NaN" not in line and "Infinity" not in line
+        back = json.loads(line, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))
+        assert depth(back) <= 4                                    # line -> roofline -> legs -> one leg
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                  "config", "roofline", "cpu_baseline"):
+            assert k in back, (name, k)
+        assert back["config"]["workload"] and back["value"] == float("%.7g" % full["value"])
+        r = back["roofline"]
+        assert r["bound"] == "hbm" and abs(r["frac"] - full["roofline"]["frac"]) < 1e-5 and r["peak"] == 8000.0 and r["traffic"] > 0
+        assert back["cpu_baseline"]["value"] > 0 and back["cpu_baseline"]["cores"] == 1 and back["cpu_baseline"]["kind"] == "reference"
+        if "legs" in full["roofline"]:
+            assert len(r["legs"]) == len(full["roofline"]["legs"]) and r["legs"]["fm_ds6"]["ok"] is True and 0.3 < r["legs"]["fm_ds6"]["f"] < 1.0
+            assert all(set(v) <= {"b", "f", "t", "ok", "hbm_f"} for v in r["legs"].values())
+            assert back["parity_ok"] is True and back["config"]["rccl_ranks"] == 1 and back["config"]["rx_power_Mbins_per_s"] > 0
+    # an absurdly large leg table is dropped rather than allowed to push the line over the limit
+    full["roofline"]["legs"] = {"leg %d" % i: {"bound": "hbm", "frac": 0.5, "parity_ok": True} for i in range(400)}
+    line = bench.compact(full)
+    assert len(line) < bench.COMPACT_LIMIT and "legs" not in json.loads(line)["roofline"]
+
+
+def test_bench_self_launches_when_gpus_gt_1_without_torchrun(tmp_path):
+    """`python bench.py --gpus N` (the shape of the driver's N=1 command) must not die on launch shape at N > 1: without WORLD_SIZE it re-executes
+    itself under torch.distributed.run with one process per GPU.  Checked here by pointing the re-exec at a stand-in interpreter that records its argv."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fake = tmp_path / "fakepython"
+    fake.write_text("#!/bin/sh\nprintf '%s\\n' \"$@\" > " + str(tmp_path / "argv") + "\n")
+    fake.chmod(0o755)
+    code = ("import sys, os\nsys.path.insert(0, %r)\nimport bench\nsys.executable = %r\nsys.argv = ['bench.py', '--gpus', '4', '--steps', '3', '--warmup', '1']\n"
+            "os.environ.pop('WORLD_SIZE', None)\nbench.main()\n" % (root, str(fake)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    argv = (tmp_path / "argv").read_text().split("\n")
+    assert argv[:3] == ["-m", "torch.distributed.run", "--nnodes=1"] and argv[3:5] == ["--nproc-per-node", "4"]
+    assert "--master-addr" in argv and argv[argv.index("--master-addr") + 1] == "127.0.0.1" and int(argv[argv.index("--master-port") + 1]) > 0
+    i = argv.index(os.path.join(root, "bench.py"))
+    assert argv[i + 1:i + 7] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    # under a launcher whose world size disagrees with --gpus it refuses instead of looping
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode != 0 and b"WORLD_SIZE=2" in out.stderr
