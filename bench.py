@@ -483,18 +483,24 @@ def main():
         cpu_worker(args.cpu_worker, args.cpu_seconds, args.cpu_lib)
         return
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            self_launch(sys.argv[1:], args.gpus)                 # does not return
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # stdout carries ONE line, rank 0's compact record: whatever else a library writes to file descriptor 1 on any rank (gloo's "[Gloo] Rank ..."
+    # connection notes, an RCCL debug line, the reference's own printf in a checker) goes to stderr
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     import rx_tools_amd as R
     from rx_tools_amd import shard
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-            self_launch(sys.argv[1:], args.gpus)                 # does not return
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # $RXGPU_BENCH_SHARE_GPU=1 (test hook, tests/test_gpu_power.py): every rank on device 0 and torch.distributed over gloo -- with
     # $RXGPU_RCCL_LIB pointing at tests/fake_rccl.c this runs the N > 1 path of this file on a box with ONE GPU (RCCL refuses two
     # ranks per device).  Not a measurement.
@@ -1264,11 +1270,13 @@ def main():
             os.makedirs(os.path.dirname(args.full_out), exist_ok=True)
             with open(args.full_out, "w") as f:
                 f.write(full + "\n")
-            full_path = os.path.relpath(args.full_out, ROOT)
+            full_path = os.path.relpath(args.full_out, ROOT) if os.path.abspath(args.full_out).startswith(ROOT + os.sep) else os.path.abspath(args.full_out)
         except OSError as e:
             sys.stderr.write("bench.py: full record not written to %s: %s\n" % (args.full_out, e))
         sys.stderr.write("BENCH_FULL " + full + "\n")
         sys.stderr.flush()
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
         print(compact(result, full_path))                          # the ONE stdout line
         sys.stdout.flush()
         if result.get("parity_ok") is False:

@@ -9,6 +9,6 @@ if [ -n "$2" ]; then
   echo "pytest rc=$? $(tail -1 $O/pytest.log)"; grep -E "^(FAILED|ERROR)" $O/pytest.log | head
 fi
 timeout 1200 python bench.py --steps 20 --warmup 5 --full-out $O/bench_full.json > $O/bench.json 2> $O/bench.err
-echo "bench rc=$? $(tail -3 $O/bench.err)"
+echo "bench rc=$? $(grep -v "^BENCH_FULL" $O/bench.err | tail -3)"
 echo "stdout: $(wc -l < $O/bench.json) line(s), $(wc -c < $O/bench.json) bytes"; cat $O/bench.json
 python tools/bench_show.py $O/bench_full.json 2>&1 | tail -40
