@@ -1014,8 +1014,9 @@ def main():
             R.check(L.rxgpu_scan_deferred(0))
             pw["dropin_scan_us"] = {"rxgpu_scan_per_sweep": t_scan * 1e6, "rxgpu_scan_sync_per_interval": t_sync * 1e6, "sweeps": sweeps,
                                     "Mbins/s": total_tunes * (plan.buf_len // 2) / t_scan / 1e6,
-                                    "note": "599 tunes x 16384 int16 from the caller's separate buffers: gather into pinned staging, one H2D (9.8 MB), the scan; "
-                                            "avg[] (19.6 MB) crosses PCIe once per interval, not twice per sweep"}
+                                    "zero_copy_input": bool(L.rxgpu_scan_zero_copy()),
+                                    "note": "599 tunes x 16384 int16 from the caller's separate buffers, page-locked in place once: one launch reads them across PCIe (9.8 MB) "
+                                            "into the scan's input, the call returns when they have been read; avg[] (19.6 MB) crosses PCIe once per interval, not twice per sweep"}
             if not args.no_parity:
                 want1 = torch.zeros((per, n), dtype=torch.int64, device=dev)
                 ws = torch.zeros(per, dtype=torch.int32, device=dev)

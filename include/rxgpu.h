@@ -322,6 +322,18 @@ int rxgpu_scan_sync(struct tuning_state *tunes, int tune_count);
  * interval pending is RXGPU_EINVAL. */
 int rxgpu_scan_deferred(int on);
 long rxgpu_scan_syncs(void);    /* downloads made so far (diagnostics / tests) */
+/* INPUT of rxgpu_scan: scanner() copies every tune's buf16 into fft_buf (rtl_power.c:715-720).  Here the tunes' buf16 -- malloc'd once by
+ * frequency_range and never freed (rtl_power.c:518-531) -- are page-locked in place the first time a sweep geometry sees them (exactly the
+ * buf_len int16 scanner() reads; buffers the caller page-locked itself with rxgpu_pin are used as they are) and ONE launch pulls all of them
+ * across PCIe into the scan's contiguous input: no host memcpy, no staging copy.  The call returns when that launch has read the buffers (the
+ * caller refills them at once), not when the transforms are done.  The registrations are released with the sweep geometry
+ * (rxgpu_scan_release / rxgpu_shutdown / another geometry); a buffer that cannot be page-locked, a row that is no multiple of 16 bytes,
+ * or $RXGPU_SCAN_ZC=0 select the older path (gather into pinned staging by memcpy, one H2D).  1 if the last rxgpu_scan read zero-copy. */
+int rxgpu_scan_zero_copy(void);
+/* Forget the cached sweep geometry of rxgpu_scan: its scan object, device buffers and the page-lock registrations of the tunes' buf16.
+ * For callers that free or replace their tune buffers (the reference never does); call it BEFORE freeing them.  A pending deferred
+ * interval is dropped with a line on stderr (rxgpu_scan_sync first).  rxgpu_shutdown does the same. */
+void rxgpu_scan_release(void);
 
 /* csv_dbm(ts) (rtl_power.c:774-817) writing to `file`.  Host code, NOT a device function: our restatement of the
  * reference's text formatter (one index map per printed bin), tested byte-for-byte against the reference's output.

@@ -451,6 +451,28 @@ __global__ __launch_bounds__(((1 << M) / 16 > 256) ? (1 << M) / 16 : 256) void k
 	}
 }
 
+// P1 for the drop-in (rtl_power.c:715-720): scanner() copies each tune's buf16 -- 599 separate mallocs of the caller -- into fft_buf.  Here the
+// caller's buffers are page-locked once and their device-visible addresses sit in a table: one launch pulls every tune's capture across PCIe
+// into the contiguous [tunes][buf_len] input of the scan (16-byte pieces, four on their way per lane), no host memcpy, no staging copy.
+__global__ __launch_bounds__(256) void k_pw_gather_rows(const uint4 *const *__restrict__ rows, uint4 *__restrict__ out, unsigned units_per_row)
+{
+	const uint4 *__restrict__ src = rows[blockIdx.y];
+	uint4 *__restrict__ dst = out + (size_t)blockIdx.y * units_per_row;
+	const unsigned base = blockIdx.x * 1024u + threadIdx.x;
+	uint4 v[4];
+#pragma unroll
+	for (int q = 0; q < 4; q++) {
+		const unsigned u = base + q * 256u;
+		v[q] = u < units_per_row ? src[u] : make_uint4(0, 0, 0, 0);
+	}
+#pragma unroll
+	for (int q = 0; q < 4; q++) {
+		const unsigned u = base + q * 256u;
+		if (u < units_per_row)
+			dst[u] = v[q];
+	}
+}
+
 __global__ void k_pw_samples(int *samples, int tunes, int add)
 {
 	const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1096,6 +1118,14 @@ extern "C" int rxk_pw_fft(void *stream, const int16_t *in, size_t tune_stride, s
 	else if (n <= 4096) GO(16);
 	else GO(0);
 #undef GO
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_pw_gather_rows(void *stream, const void *const *d_rows, int rows, size_t row_bytes, int16_t *out)
+{
+	const unsigned units = (unsigned)(row_bytes / 16);
+	hipLaunchKernelGGL(k_pw_gather_rows, dim3((units + 1023) / 1024, (unsigned)rows), dim3(256), 0, (hipStream_t)stream,
+	                   (const uint4 *const *)d_rows, (uint4 *)out, units);
 	LAUNCH_RET();
 }
 

@@ -513,6 +513,17 @@ static struct {
 	int64_t *d_avg;                  /* accumulated since the last sync, from zero */
 	int32_t *d_samples;
 	int64_t *h_avg;                  /* pinned: download of the accumulators (+ samples behind them) */
+	/* zero-copy input: the caller's tunes[i].buf16 are malloc'd once and never freed (rtl_power.c:518-531) -- page-locked in place the first
+	 * time they are seen, their device-visible addresses in a table the gather kernel reads (k_pw_gather_rows) */
+	const int16_t **zc_host;         /* [tune_cap] the buf16 each entry was resolved for */
+	void **zc_dev;                   /* [tune_cap] its device-visible address (host copy of the table) */
+	unsigned char *zc_owned;         /* [tune_cap] page-locked HERE (released with the cache), not by the caller's rxgpu_pin */
+	void **d_rows;                   /* the table on the device */
+	int zc_count;                    /* entries resolved; 0 = none / not usable */
+	int zc_failed;                   /* a buffer could not be page-locked: the staging path from then on (until the geometry changes) */
+	unsigned zc_gen;
+	int zc_last;                     /* the last rxgpu_scan read its input zero-copy (rxgpu_scan_zero_copy) */
+	hipEvent_t ev_gather;
 	struct tuning_state *tunes;      /* whose sums the accumulators hold */
 	int tune_count;
 	int dirty;
@@ -521,8 +532,75 @@ static struct {
 } g_scan = { .deferred = -1 };
 static pthread_mutex_t g_scan_lock = PTHREAD_MUTEX_INITIALIZER;
 
+static void scan_zc_release(void)
+{
+	if (g_scan.zc_owned && g_scan.zc_host)
+		for (int i = 0; i < g_scan.zc_count; i++)
+			if (g_scan.zc_owned[i]) {
+				rxgpu_pin_changed();
+				(void)hipHostUnregister((void *)g_scan.zc_host[i]);
+				g_scan.zc_owned[i] = 0;
+			}
+	(void)hipGetLastError();
+	g_scan.zc_count = 0;
+}
+
+/* device-visible addresses of every tune's buf16 (page-locking those that are not yet), table uploaded; 0 = use the staging path */
+static int scan_zc_resolve(struct tuning_state *tunes, int tune_count, size_t row_bytes, hipStream_t st)
+{
+	const char *e = rxgpu_knob("RXGPU_SCAN_ZC");
+	if ((e && e[0] == '0') || g_scan.zc_failed || (row_bytes & 15u) || !g_scan.zc_host)
+		return 0;
+	const unsigned gen = rxgpu_pin_generation();
+	int same = g_scan.zc_count == tune_count && g_scan.zc_gen == gen;
+	for (int i = 0; same && i < tune_count; i++)
+		same = g_scan.zc_host[i] == tunes[i].buf16;
+	if (same)
+		return 1;
+	scan_zc_release();
+	for (int i = 0; i < tune_count; i++) {
+		void *a = NULL, *a_end = NULL;
+		int16_t *b = tunes[i].buf16;
+		int owned = 0;
+		if (hipHostGetDevicePointer(&a, b, 0) != hipSuccess || hipHostGetDevicePointer(&a_end, (char *)b + row_bytes - 1, 0) != hipSuccess) {
+			(void)hipGetLastError();
+			a = NULL;
+			/* exactly the bytes scanner() reads, not the allocation (buf_len * 4, rtl_power.c:526) and not rounded out to pages */
+			if (hipHostRegister(b, row_bytes, hipHostRegisterDefault) == hipSuccess) {
+				owned = 1;
+				if (hipHostGetDevicePointer(&a, b, 0) != hipSuccess)
+					a = NULL;
+			}
+		}
+		g_scan.zc_host[i] = b;
+		g_scan.zc_dev[i] = a;
+		g_scan.zc_owned[i] = (unsigned char)owned;
+		g_scan.zc_count = i + 1;
+		if (!a || ((size_t)a & 15u)) {
+			(void)hipGetLastError();
+			scan_zc_release();
+			g_scan.zc_failed = 1;
+			return 0;
+		}
+	}
+	rxgpu_pin_changed();
+	g_scan.zc_gen = rxgpu_pin_generation();
+	if (hipMemcpyAsync(g_scan.d_rows, g_scan.zc_dev, (size_t)tune_count * sizeof(void *), hipMemcpyHostToDevice, st) != hipSuccess ||
+	    hipStreamSynchronize(st) != hipSuccess) {            /* zc_dev is pageable: the copy has read it when this returns */
+		(void)hipGetLastError();
+		scan_zc_release();
+		g_scan.zc_failed = 1;
+		return 0;
+	}
+	return 1;
+}
+
 static void scan_cache_drop(void)
 {
+	scan_zc_release();
+	free(g_scan.zc_host); free(g_scan.zc_dev); free(g_scan.zc_owned);
+	hipFree(g_scan.d_rows);
+	if (g_scan.ev_gather) hipEventDestroy(g_scan.ev_gather);
 	rxgpu_power_scan_destroy(g_scan.s);
 	free(g_scan.window_copy); free(g_scan.sine_copy);
 	for (int k = 0; k < 2; k++) {
@@ -584,6 +662,8 @@ void rxgpu_power_dropin_release(void)
 	pthread_mutex_unlock(&g_scan_lock);
 }
 
+void rxgpu_scan_release(void) { rxgpu_power_dropin_release(); }
+
 static int scan_locked(struct tuning_state *tunes, int tune_count, const int *window_coefs,
                        const int16_t *sinewave, int boxcar, int comp_fir_size, int peak_hold)
 {
@@ -638,9 +718,18 @@ static int scan_locked(struct tuning_state *tunes, int tune_count, const int *wi
 		    hipEventCreateWithFlags(&g_scan.ev_in[0], hipEventDisableTiming) != hipSuccess ||
 		    hipEventCreateWithFlags(&g_scan.ev_in[1], hipEventDisableTiming) != hipSuccess ||
 		    hipMemset(g_scan.d_avg, 0, (size_t)tune_count * n * 8) != hipSuccess ||
-		    hipMemset(g_scan.d_samples, 0, (size_t)tune_count * 4 + 4) != hipSuccess) {
+		    hipMemset(g_scan.d_samples, 0, (size_t)tune_count * 4 + 4) != hipSuccess ||
+		    hipMalloc((void **)&g_scan.d_rows, (size_t)tune_count * sizeof(void *)) != hipSuccess ||
+		    hipEventCreateWithFlags(&g_scan.ev_gather, hipEventDisableTiming) != hipSuccess) {
 			scan_cache_drop();
 			return rxgpu_fail(RXGPU_ENOMEM, "rxgpu_scan: buffer allocation failed");
+		}
+		g_scan.zc_host = calloc((size_t)tune_count, sizeof(*g_scan.zc_host));
+		g_scan.zc_dev = calloc((size_t)tune_count, sizeof(*g_scan.zc_dev));
+		g_scan.zc_owned = calloc((size_t)tune_count, 1);
+		if (!g_scan.zc_host || !g_scan.zc_dev || !g_scan.zc_owned) {
+			scan_cache_drop();
+			return rxgpu_fail(RXGPU_ENOMEM, "out of host memory");
 		}
 	}
 	g_scan.tunes = tunes;
@@ -649,16 +738,29 @@ static int scan_locked(struct tuning_state *tunes, int tune_count, const int *wi
 	/* gather the caller's scattered buffers into pinned staging (one copy instead of one per tune); the staging of two sweeps
 	 * ago has long been read */
 	const int k = (int)(g_scan.calls++ & 1);
-	if (g_scan.ev_valid[k])
-		RX_HIP(hipEventSynchronize(g_scan.ev_in[k]));
-	for (int i = 0; i < tune_count; i++)
-		memcpy(g_scan.h_in[k] + (size_t)i * p.buf_len, tunes[i].buf16, (size_t)p.buf_len * 2);
-	RX_HIP(hipMemcpyAsync(g_scan.d_in[k], g_scan.h_in[k], (size_t)tune_count * p.buf_len * 2, hipMemcpyHostToDevice, st));
+	const int zc = scan_zc_resolve(tunes, tune_count, (size_t)p.buf_len * 2, st);
+	if (zc) {
+		/* one launch reads every tune's page-locked buf16 across PCIe into the scan's input; the caller refills buf16 as soon as this
+		 * call returns (the next sweep's readStream, rtl_power.c:693-704), so the call waits for the gather -- not for the scan */
+		if (rxk_pw_gather_rows(st, (const void *const *)g_scan.d_rows, tune_count, (size_t)p.buf_len * 2, g_scan.d_in[k]) != 0)
+			return rxgpu_fail(RXGPU_ENODEV, "rxgpu_scan: gather launch failed: %s", hipGetErrorString(hipGetLastError()));
+		RX_HIP(hipEventRecord(g_scan.ev_gather, st));
+	} else {
+		/* the caller's scattered buffers into pinned staging (one copy instead of one per tune); the staging of two sweeps ago has long been read */
+		if (g_scan.ev_valid[k])
+			RX_HIP(hipEventSynchronize(g_scan.ev_in[k]));
+		for (int i = 0; i < tune_count; i++)
+			memcpy(g_scan.h_in[k] + (size_t)i * p.buf_len, tunes[i].buf16, (size_t)p.buf_len * 2);
+		RX_HIP(hipMemcpyAsync(g_scan.d_in[k], g_scan.h_in[k], (size_t)tune_count * p.buf_len * 2, hipMemcpyHostToDevice, st));
+	}
 	if ((rc = rxgpu_power_scan_run(g_scan.s, g_scan.d_in[k], 1, tune_count, g_scan.d_avg, g_scan.d_samples)) != RXGPU_OK)
 		return rc;
 	RX_HIP(hipEventRecord(g_scan.ev_in[k], st));
 	g_scan.ev_valid[k] = 1;
 	g_scan.dirty = 1;
+	g_scan.zc_last = zc;
+	if (zc && g_scan.deferred)
+		RX_HIP(hipEventSynchronize(g_scan.ev_gather));
 	if (!g_scan.deferred)
 		return scan_sync_locked(tunes);
 	return RXGPU_OK;
@@ -707,6 +809,7 @@ int rxgpu_scan_deferred(int on)
 }
 
 long rxgpu_scan_syncs(void) { return g_scan.syncs; }
+int rxgpu_scan_zero_copy(void) { return g_scan.zc_last; }
 
 /* One CSV row for a tuning_state, byte for byte what csv_dbm prints (rtl_power.c:774-817) -- a restatement, because
  * the text has to be identical: the bins are read through the index map the reference's in-place edits amount to

@@ -79,11 +79,16 @@ def test_full_demod_and_callback_dropin(kw):
         assert (d.squelch_hits, d.dc_avg, d.dc_avgI, d.dc_avgQ) == (st.squelch_hits, st.dc_avg, st.dc_avgI, st.dc_avgQ)
 
 
+@pytest.mark.parametrize("zc", [1, 0])
 @pytest.mark.parametrize("rng,flags,window", [("24M:60M:1k", (1, 0, 0), "hamming"), ("100M:105M:1M", (1, 0, 1), "rectangle"),
                                               ("100M:100.1M:100", (0, 9, 0), "blackman")])
-def test_scan_and_csv_dropin(rng, flags, window, tmp_path):
-    """rxgpu_scan on an array of struct tuning_state (+ rxgpu_csv_dbm) == the oracle's scanner()/csv_dbm, two passes; deferred mode"""
+def test_scan_and_csv_dropin(rng, flags, window, zc, tmp_path, monkeypatch):
+    """rxgpu_scan on an array of struct tuning_state (+ rxgpu_csv_dbm) == the oracle's scanner()/csv_dbm, two passes; deferred mode.
+    zc = 1: the tunes' buf16 page-locked in place by the library, one launch reads them across PCIe (the default); 0: pinned staging + H2D"""
     L, O = R.lib(), oracle()
+    monkeypatch.setenv("RXGPU_SCAN_ZC", str(zc))
+    L.rxgpu_knobs_reload()
+    L.rxgpu_scan_release()                                     # a sweep geometry cached by an earlier test decided its input path already
     R.check(L.rxgpu_scan_deferred(1))
     plan = R.plan_range(rng, 0.0, flags[0])
     tunes, n = min(plan.tune_count, 5), 1 << plan.bin_e
@@ -107,6 +112,9 @@ def test_scan_and_csv_dropin(rng, flags, window, tmp_path):
             O.rxo_power_tune(C.byref(cfg), ptr16(np.ascontiguousarray(data[t])), ptr16(work), ptr64(want_avg[t]), C.byref(smp))
             want_samples[t] = smp.value
         R.check(L.rxgpu_scan(arr, tunes, wc.ctypes.data, sw.ctypes.data, *flags))
+        assert L.rxgpu_scan_zero_copy() == zc
+        for t in range(tunes):
+            bufs[t][:] = -1                                    # the call has read the buffers when it returns: the caller refills them at once
         if p == 0:
             # the sums stay on the device until somebody asks: the struct still shows what the caller left there
             assert not any(a.any() for a in avgs) and all(arr[t].samples == 0 for t in range(tunes))
