@@ -340,6 +340,9 @@ def hoist(result, parity_all, world):
         legs["channeliser 256 ch"] = {"bound": "valu", "frac": r["valu"]["frac"], "hbm_frac": r["frac"], "MSample_per_s": ch["value"],
                                       "traffic_over_algorithmic": (r["traffic"] / r["algorithmic_bytes_per_launch"]) if r.get("traffic") else None,
                                       "parity_ok": (ch.get("parity") or {}).get("parity_ok"), "parity_checker": (ch.get("parity") or {}).get("parity_checker")}
+        for label, v in (ch.get("other_modes") or {}).items():
+            legs["channeliser 256 ch, " + label] = {"bound": "valu", "frac": None, "hbm_frac": v["frac_of_hbm_peak"], "MSample_per_s": v["value"],
+                                                    "parity_ok": (v.get("parity") or {}).get("parity_ok")}
         if ch.get("nco_mode"):
             legs["channeliser 256 ch, NCO -> low_pass mode"] = {"bound": "valu", "MSample_per_s": ch["nco_mode"]["value"], "frac": None,
                                                                "parity_ok": (ch["nco_mode"].get("parity") or {}).get("parity_ok")}
@@ -1171,6 +1174,55 @@ def main():
         }
         if chan_parity is not None:
             result["channeliser"]["parity"] = chan_parity
+        # What NBFM defaults to (rtl_fm.c:1086-1099: custom_atan = 0 unless -A fast -> libm atan2 per demodulated sample, rtl_fm.c:476-483) and the
+        # per-channel audio stages (deemph_filter + low_pass_real, every channel its own carried state): the same capture, the same launch shape
+        if rank == 0 and args.variants == "all":
+            for label, prm, audio in (("-A std (NBFM default)", R.ChanParams(bin_e, 384, n_ch, 0), False),
+                                      ("deemph + low_pass_real", R.ChanParams(bin_e, 384, n_ch, 1, 1, 7, 19531, 8000, 0), True)):
+                ch3 = R.Channeliser(prm, n_blocks, block_len, R.sine_table(bin_e))
+                for _ in range(5):
+                    ch3.run(d_iq.data_ptr(), n_blocks, block_len, d_out.data_ptr(), windows)
+                L.rxgpu_prof_reset()
+                L.rxgpu_prof_enable(2)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fix3 = 0
+                for _ in range(10):
+                    ch3.run(d_iq.data_ptr(), n_blocks, block_len, d_out.data_ptr(), windows)
+                    fix3 += ch3.host_fixups
+                torch.cuda.synchronize()
+                t3 = (time.perf_counter() - t0) / 10
+                L.rxgpu_prof_enable(0)
+                stage = {}
+                for nm in ("ch_fft", "ch_demod", "ch_audio"):
+                    sms, sn = prof(nm)
+                    if sn:
+                        stage[nm] = round(sms / sn * 1e3, 1)
+                leg = {"value": T / t3 / 1e6, "unit": "MSample/s", "ms": t3 * 1e3, "stage_us": stage, "frac_of_hbm_peak": 4.0 * T / t3 / 1e9 / HBM_PEAK_GBS,
+                       "host_fixups_per_run": fix3 / 10.0, "demodulated_samples_per_run": int(n_ch * windows)}
+                if not args.no_parity:
+                    PA = parity_module()
+                    if not audio:
+                        ch3.set_carry(np.zeros(2 * n_ch, np.int32))
+                        ch3.run(d_iq.data_ptr(), n_blocks, block_len, d_out.data_ptr(), windows)
+                        leg["parity"] = PA.chan_check(d_iq.cpu().numpy(), n_blocks, block_len, bin_e, 384, n_ch, 0, R.sine_table(bin_e), d_out.cpu().numpy(), ch3.get_carry())
+                    else:
+                        # the audio carries run through the whole stream of a channel (no block ranges to deal out): the first 16 callback blocks of every
+                        # channel, from zero carries, against the reference's own fix_fft + full_demod (deemph_filter, low_pass_real) per channel and block
+                        nba = 16
+                        ch3.set_carry(np.zeros(2 * n_ch, np.int32))
+                        ch3.set_audio_carry(np.zeros(3 * n_ch, np.int32))
+                        k3 = ch3.run(d_iq.data_ptr(), nba, block_len, d_out.data_ptr(), windows)
+                        h3 = d_iq[: nba * block_len].cpu().numpy()
+                        stream3 = PA.support.ref_chan_stream if PA.support.have_ref() else PA.support.oracle_chan_stream
+                        want3, pre3, st3 = stream3(h3, block_len, bin_e, 384, n_ch, 1, 1, 7, 19531, 8000)
+                        same3 = bool(k3 == want3.shape[1] and np.array_equal(d_out[:, :k3].cpu().numpy(), want3) and np.array_equal(ch3.get_carry(), pre3)
+                                     and np.array_equal(ch3.get_audio_carry().reshape(n_ch, 3), np.asarray(st3).reshape(n_ch, 3)))
+                        leg["parity"] = {"parity_ok": same3, "parity_checker": "reference" if PA.support.have_ref() else "port", "parity_blocks": nba,
+                                         "parity_channels": int(n_ch), "parity_audio_samples_per_channel": int(k3)}
+                    parity_all["channeliser " + label] = bool(leg["parity"]["parity_ok"])
+                ch3.close()
+                result["channeliser"].setdefault("other_modes", {})[label] = leg
         # SURVEY 8(f)2's literal definition as the second mode (rxgpu_chan_params.nco: callback scale -> integer NCO per channel -> low_pass at
         # downsample N): the same 256 channels in another fixed-point rounding, ~50 times the arithmetic of the bank -- timed on 1/8 of the capture
         if rank == 0 and args.variants == "all":

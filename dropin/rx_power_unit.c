@@ -40,8 +40,7 @@ static void rxgpu_dropin_power_setup(void)
 
 static void rxgpu_dropin_die(const char *what)
 {
-	fprintf(stderr, "rx_power (rxgpu): %s: %s\n", what, rxgpu_last_error());
-	exit(1);
+	rxgpu_fatal(what);                                             /* one line on stderr, device released, _exit(1) */
 }
 
 void rxgpu_dropin_scanner(size_t channel)

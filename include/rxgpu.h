@@ -85,16 +85,21 @@ int rxgpu_prof_get(const char *name, double *total_ms, long *launches);
  * -L level printing (rtl_fm.c:792-807) sits inside full_demod on file-static counters of rtl_fm.c: the library cannot see them, so the
  * block stays with the caller -- behind this call, fed `sr` from rxgpu_dropin_block_rms (dropin/rx_fm_unit.c does exactly that, and the
  * rx_fm built by dropin/Makefile prints the reference's level lines).
- * Not on the device path, by decision: -o with a block
- * whose demodulated length is not a multiple of the step (the reference then reads stale data); and the two shapes the reference itself dies on
- * (-E adc with no demodulated sample: division by result_len == 0, rtl_fm.c:693; -E rdc on an empty read, rtl_fm.c:711): those print to
- * stderr and exit(1) -- there is no CPU fallback.
+ * -o with a block whose demodulated length is no multiple of the step: low_pass_simple's last loop turn then sums past `len` (rtl_fm.c:373-387) but
+ * stores that sum BEHIND the len / step values it returns -- the block hands on its complete groups, the remainder is dropped; reproduced.
+ * Not on the device path, by decision: the two shapes the reference itself dies on (-E adc with no demodulated sample: division by
+ * result_len == 0, rtl_fm.c:693; -E rdc on an empty read, rtl_fm.c:711): those print to stderr and exit -- there is no CPU fallback.
  * If the block in d->lowpassed is the one rxgpu_callback handed over last (same demod_state, same lp_len, nobody
  * called rxgpu_dropin_invalidate), the copy it left in HBM is used and the block does not cross PCIe a second time.
  * A block of the plain FM chain (low_pass with downsample >= 8, fm_demod -A std | fast | ale, deemph_filter, low_pass_real; no -F, squelch,
  * dc block, -o) takes two launches and no copy operation (~40 us per 1 MiB); every other shape the general stream path (~105 us).
  * Same results either way ($RXGPU_DROPIN_FAST=0 takes the general path always). */
 void rxgpu_full_demod(struct demod_state *d);
+/* What the `void` drop-in entry points do on a device error, for callers (the files under dropin/) that want the same end: one line on stderr ("rxgpu: <what>:
+ * <rxgpu_last_error()>"; never stdout -- that is the audio / CSV stream), the library's device resources released (at most five seconds: a
+ * watchdog ends the process if the device no longer answers), then _exit(1) -- NOT exit(): no atexit handlers or static destructors of a SoapySDR
+ * driver run while the application's other threads are still inside it or hold d->rw.  A second thread that fails meanwhile waits for the first. */
+void rxgpu_fatal(const char *what);
 /* a caller that edits d->lowpassed between rxgpu_callback and rxgpu_full_demod says so here */
 void rxgpu_dropin_invalidate(const struct demod_state *d);
 /* full_demod's `sr` (rtl_fm.c:781: rms(d->lowpassed, d->lp_len, 1) of the decimated block, BEFORE a quiet block is zeroed) for the

@@ -17,7 +17,7 @@ EXPORTS = [
     "rxgpu_init", "rxgpu_shutdown", "rxgpu_device_count", "rxgpu_last_error", "rxgpu_stream", "rxgpu_sync", "rxgpu_knobs_reload",
     "rxgpu_pin", "rxgpu_unpin",
     "rxgpu_prof_enable", "rxgpu_prof_reset", "rxgpu_prof_get", "rxgpu_diag_stream_rate",
-    "rxgpu_full_demod", "rxgpu_callback", "rxgpu_deemph_state", "rxgpu_set_demod_functions", "rxgpu_dropin_invalidate", "rxgpu_dropin_block_rms", "rxgpu_dropin_release", "rxgpu_dropin_pin", "rxgpu_dropin_unpin", "rxgpu_dropin_timing",
+    "rxgpu_full_demod", "rxgpu_callback", "rxgpu_fatal", "rxgpu_deemph_state", "rxgpu_set_demod_functions", "rxgpu_dropin_invalidate", "rxgpu_dropin_block_rms", "rxgpu_dropin_release", "rxgpu_dropin_pin", "rxgpu_dropin_unpin", "rxgpu_dropin_timing",
     "rxgpu_fm_params_init", "rxgpu_fm_plan_settings",
     "rxgpu_fm_stream_create", "rxgpu_fm_stream_destroy", "rxgpu_fm_stream_set_carry", "rxgpu_fm_stream_get_carry",
     "rxgpu_fm_stream_run", "rxgpu_fm_stream_run_async", "rxgpu_fm_stream_wait", "rxgpu_fm_stream_run_host",

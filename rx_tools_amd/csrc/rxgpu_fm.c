@@ -581,11 +581,14 @@ static int run_geometry(rxgpu_fm_stream *s, size_t n_blocks, size_t block_len, s
 	g->J = g->M;
 	g->post = (p->post_downsample > 1 && p->mode != RXGPU_MODE_RAW) ? p->post_downsample : 1;
 	if (g->post > 1) {
-		/* low_pass_simple needs every block's demodulated length to be a multiple of the step (rtl_fm.c:374) */
+		/* low_pass_simple (rtl_fm.c:373-387) on a length that is no multiple of the step: its last loop turn sums past `len` -- into what
+		 * earlier blocks left in result[] -- but writes that sum to signal2[len / step], BEHIND the len / step values it returns: what a
+		 * block hands on is its complete groups, the remainder is dropped, not carried.  One block per run (the drop-in's shape) is served
+		 * that way; a multi-block run keeps the condition, because its blocks are cut out of ONE demodulated sequence by cumulative counts. */
 		const unsigned long long per = g->passes ? g->K : g->n / (unsigned long long)g->ds;
-		if ((!g->passes && g->n % (unsigned long long)g->ds) || per % (unsigned long long)g->post)
-			return rxgpu_fail(RXGPU_EUNSUPPORTED, "-o %d needs every block's demodulated length to be a multiple of it "
-			                  "(block of %llu samples, downsample %d)", g->post, g->n, g->ds);
+		if (n_blocks > 1 && ((!g->passes && g->n % (unsigned long long)g->ds) || per % (unsigned long long)g->post))
+			return rxgpu_fail(RXGPU_EUNSUPPORTED, "-o %d on a run of several blocks needs every block's demodulated length to be a multiple of it "
+			                  "(block of %llu samples, downsample %d); block by block (the drop-in) any length goes", g->post, g->n, g->ds);
 		g->J = g->M / (unsigned long long)g->post;
 	}
 	if (p->mode == RXGPU_MODE_RAW) {
@@ -1419,10 +1422,10 @@ void rxgpu_dropin_invalidate(const struct demod_state *d)
 		g_side[i].dev_valid = 0;
 }
 
+/* print once on stderr, release the device, _exit(1): rxgpu_fatal (rxgpu_rt.c) */
 static void die(const char *what)
 {
-	fprintf(stderr, "rxgpu: %s: %s\n", what, rxgpu_last_error());
-	exit(1);
+	rxgpu_fatal(what);
 }
 
 /* Page-lock the struct members the drop-in DMAs from/to (SURVEY.md section 8b "Ownership"): lowpassed[] .. result[] of
@@ -1871,7 +1874,8 @@ void rxgpu_callback(int16_t *buf, uint32_t len, void *ctx)
 	}
 	int ok = 1;
 	if (zc) {
-		ok = rxk_fm_prestage_zc(st, (const int16_t *)g_side[side].zc_in_dev, len / 2, !s->offset_tuning, pre, (int16_t *)g_side[side].zc_out_dev) == 0 &&
+		ok = !rxgpu_fault_tick() &&
+		     rxk_fm_prestage_zc(st, (const int16_t *)g_side[side].zc_in_dev, len / 2, !s->offset_tuning, pre, (int16_t *)g_side[side].zc_out_dev) == 0 &&
 		     hipStreamSynchronize(st) == hipSuccess;
 	} else if (len) {
 		ok = hipMemcpyAsync(cb_in, buf, (size_t)len * 2, hipMemcpyHostToDevice, st) == hipSuccess;
@@ -1890,7 +1894,7 @@ void rxgpu_callback(int16_t *buf, uint32_t len, void *ctx)
 		d->dc_avgI = state[0];
 		d->dc_avgQ = state[1];
 	} else if (ok && len) {
-		ok = rxk_fm_prestage(st, cb_in, len / 2, !s->offset_tuning, pre) == 0 &&
+		ok = !rxgpu_fault_tick() && rxk_fm_prestage(st, cb_in, len / 2, !s->offset_tuning, pre) == 0 &&
 		     hipMemcpyAsync(s->buf16, pre, (size_t)len * 2, hipMemcpyDeviceToHost, st) == hipSuccess &&
 		     hipStreamSynchronize(st) == hipSuccess;
 	}

@@ -4,6 +4,8 @@
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <time.h>
+#include <unistd.h>
 #include <string.h>
 
 static int g_device = -1;
@@ -46,11 +48,13 @@ static const char *const g_knob_names[] = {
 	"RXGPU_FUSE_A", "RXGPU_NO_FUSED_DD", "RXGPU_NO_TILED", "RXGPU_DEEMPH_CHUNK", "RXGPU_NO_SMALL", "RXGPU_DEEMPH_TOPCAP", "RXGPU_FLAG_ALL",
 	"RXGPU_HOST_CHUNK", "RXGPU_DROPIN_TIMING", "RXGPU_BOXCAR_PLAIN", "RXGPU_FIFTH_PLAIN", "RXGPU_FFT_GENERIC", "RXGPU_FFT_STAGEWISE",
 	"RXGPU_SCAN_DEFERRED", "RXGPU_SCAN_ZC", "RXGPU_CH_WPG", "RXGPU_CH_GPW", "RXGPU_DROPIN_FAST", "RXGPU_DROPIN_ZC", "RXGPU_DEC_NARROW", "RXGPU_DSM_LDS", "RXGPU_SCAN_T", "RXGPU_FF_PAD", "RXGPU_FR_GENERIC", "RXGPU_DD_TW",
-	"RXGPU_FFT_TW", "RXGPU_CH_DENSE", "RXGPU_NO_DEC_TABLE", "RXGPU_APPLY_ILP", "RXGPU_CAS_MAILBOX", "RXGPU_SDR_V", "RXGPU_EXP0", "RXGPU_EXP1", "RXGPU_EXP2", "RXGPU_EXP3",
+	"RXGPU_FFT_TW", "RXGPU_CH_DENSE", "RXGPU_NO_DEC_TABLE", "RXGPU_APPLY_ILP", "RXGPU_CAS_MAILBOX", "RXGPU_SDR_V", "RXGPU_EXP0", "RXGPU_EXP1", "RXGPU_EXP2", "RXGPU_EXP3", "RXGPU_FAIL_AFTER",
 };
 #define N_KNOBS ((int)(sizeof(g_knob_names) / sizeof(g_knob_names[0])))
 static const char *volatile g_knob_val[sizeof(g_knob_names) / sizeof(g_knob_names[0])];
 static pthread_mutex_t g_knob_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static volatile long g_fail_after;      /* $RXGPU_FAIL_AFTER (test hook, rxgpu_fault_tick) */
 
 void rxgpu_knobs_reload(void)
 {
@@ -63,7 +67,49 @@ void rxgpu_knobs_reload(void)
 		else if (!old || strcmp(old, e))
 			g_knob_val[i] = strdup(e);
 	}
+	{
+		const char *e = getenv("RXGPU_FAIL_AFTER");
+		g_fail_after = e ? atol(e) : 0;
+	}
 	pthread_mutex_unlock(&g_knob_lock);
+}
+
+/* Test hook ($RXGPU_FAIL_AFTER=n, read with the knobs): the n-th kernel launch of the host code from now on reports hipErrorLaunchFailure instead
+ * of being enqueued -- the way tests/test_gpu_dropin.py makes a device error happen in the middle of a stream. */
+int rxgpu_fault_tick(void)
+{
+	if (g_fail_after <= 0)
+		return 0;
+	return __sync_sub_and_fetch(&g_fail_after, 1) == 0;
+}
+
+/* The library's failure convention where the replaced function is `void` (full_demod, rtlsdr_callback, scanner: SURVEY.md 8b -- the
+ * reference prints to stderr and exits): say it ONCE on stderr -- never stdout, that is the audio / CSV stream --, release what the
+ * library holds on the device, and leave with _exit(1).  Not exit(): exit() runs the atexit handlers and static destructors of whatever
+ * SoapySDR driver is loaded while the application's other thread (dongle / demod / output) is still running, possibly inside that driver
+ * or holding d->rw -- a process that never ends.  A device that no longer answers must not hold the process either: a watchdog thread
+ * ends it after five seconds whatever rxgpu_shutdown is waiting for. */
+static void *fatal_watchdog(void *arg)
+{
+	(void)arg;
+	struct timespec ts = { 5, 0 };
+	nanosleep(&ts, NULL);
+	_exit(1);
+	return NULL;
+}
+
+void rxgpu_fatal(const char *what)
+{
+	static int once;
+	if (__sync_lock_test_and_set(&once, 1))
+		for (;;) pause();                                /* another thread is already taking the process down */
+	fprintf(stderr, "rxgpu: %s: %s\n", what ? what : "fatal", rxgpu_last_error());
+	fflush(stderr);
+	pthread_t w;
+	if (pthread_create(&w, NULL, fatal_watchdog, NULL) == 0)
+		pthread_detach(w);
+	rxgpu_shutdown();
+	_exit(1);
 }
 
 const char *rxgpu_knob(const char *name)

@@ -322,6 +322,9 @@ ANY_LENGTH_PARAMS = [
     dict(downsample_passes=3), dict(downsample_passes=3, comp_fir_size=9), dict(downsample_passes=7), dict(downsample_passes=7, squelch_level=50),
     dict(downsample_passes=4, mode=1, output_scale=2, deemph=0), dict(downsample_passes=5, mode=4), dict(downsample_passes=10, comp_fir_size=9),
     dict(downsample_passes=2, dc_block_raw=1, rdc_block_const=3),
+    # -o on demodulated lengths that are no multiple of the step: low_pass_simple (rtl_fm.c:373-387) hands on the complete groups only
+    dict(downsample=6, post_downsample=4), dict(downsample=118, post_downsample=3, custom_atan=1), dict(downsample_passes=3, post_downsample=2),
+    dict(downsample=9, mode=1, deemph=0, post_downsample=5), dict(downsample_passes=2, comp_fir_size=9, post_downsample=16, rate_out2=-1),
 ]
 
 
@@ -410,3 +413,96 @@ def test_dropin_takes_every_block_length_the_reference_takes(kw, pin=False):
         if pin:
             L.rxgpu_unpin(rbuf.ctypes.data)
             L.rxgpu_dropin_unpin(C.addressof(d), C.addressof(s))
+
+
+@pytest.mark.parametrize("fail_after,kw", [(7, dict(downsample=118)), (12, dict(downsample_passes=3, comp_fir_size=9)), (3, dict(downsample=6, squelch_level=30))])
+def test_device_error_mid_stream_ends_the_process_without_deadlock(fail_after, kw):
+    """A launch that fails in the middle of a stream ($RXGPU_FAIL_AFTER: the n-th launch of the host code reports hipErrorLaunchFailure) while
+    the application's other thread -- the dongle thread, calling rxgpu_callback and taking d->rw for its hand-off -- keeps running: the
+    process must end (rxgpu_fatal: one line on stderr, device released, _exit(1)) within seconds, with NOTHING on stdout (the audio stream)
+    and an atexit handler that would block forever never run."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import atexit, ctypes as C, os, sys, threading, time\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, rx_tools_amd as R\n"
+        "from test_gpu_dropin import fresh_demod\n"
+        "from rx_tools_amd.structs import DongleState\n"
+        "from support import sig_fm\n"
+        "atexit.register(lambda: time.sleep(3600))          # what a driver's exit handler waiting for its own thread would be\n"
+        "L = R.lib(); R.check(L.rxgpu_init(0))\n"
+        "kw = %r\n"
+        "d = fresh_demod(**kw); s = DongleState(); s.demod_target = C.pointer(d)\n"
+        "d2 = fresh_demod(**kw); s2 = DongleState(); s2.demod_target = C.pointer(d2)\n"
+        "blk = sig_fm(131072, seed=3)\n"
+        "def dongle():\n"
+        "    b = blk.copy()\n"
+        "    while True:\n"
+        "        L.rxgpu_callback(b.ctypes.data, b.size, C.addressof(s2))\n"
+        "t = threading.Thread(target=dongle, daemon=True); t.start()\n"
+        "for i in range(3):\n"
+        "    b = blk.copy(); L.rxgpu_callback(b.ctypes.data, b.size, C.addressof(s)); L.rxgpu_full_demod(C.addressof(d))\n"
+        "sys.stderr.write('warm\\n'); sys.stderr.flush()\n"
+        "os.environ['RXGPU_FAIL_AFTER'] = %r\n"
+        "L.rxgpu_knobs_reload()\n"
+        "for i in range(200):\n"
+        "    b = blk.copy(); L.rxgpu_callback(b.ctypes.data, b.size, C.addressof(s)); L.rxgpu_full_demod(C.addressof(d))\n"
+        "print('survived')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), kw, str(fail_after))
+    t0 = __import__("time").time()
+    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    took = __import__("time").time() - t0
+    err = out.stderr.decode()
+    assert out.returncode == 1, (out.returncode, err[-800:])
+    assert out.stdout == b"", out.stdout[-200:]
+    assert "warm" in err and err.count("rxgpu: ") == 1 and "launch failed" in err.split("rxgpu: ")[1], err[-800:]
+    assert took < 60
+
+
+def test_dropin_release_while_the_callback_runs():
+    """rxgpu_dropin_release against a callback of the same demod_state on another thread (round 4's advisory: the slot index was taken
+    before the lock, the locked mutex was copied and cleared): the dongle thread hammers rxgpu_callback, the main thread releases the
+    side-car again and again -- every block that comes out afterwards is still the oracle's, and nothing crashes or deadlocks"""
+    import threading
+    L, O = R.lib(), oracle()
+    R.check(L.rxgpu_init(0))
+    block_len = 8192
+    iq = sig_fm(block_len // 2, seed=9)
+    kw = dict(downsample=6)
+    d = fresh_demod(**kw)
+    s = DongleState()
+    s.demod_target = C.pointer(d)
+    stop = threading.Event()
+    calls = [0]
+
+    def dongle():
+        b = iq.copy()
+        while not stop.is_set():
+            L.rxgpu_callback(b.ctypes.data, block_len, C.addressof(s))
+            calls[0] += 1
+    t = threading.Thread(target=dongle)
+    t.start()
+    try:
+        for _ in range(300):
+            L.rxgpu_dropin_release(C.addressof(d))              # OK or "no side-car": both happen
+    finally:
+        stop.set()
+        t.join(60)
+    assert not t.is_alive() and calls[0] > 0
+    # the state the callback publishes is still right: one more block, demodulated like the oracle from a fresh state
+    L.rxgpu_dropin_release(C.addressof(d))
+    d2 = fresh_demod(**kw)
+    s2 = DongleState()
+    s2.demod_target = C.pointer(d2)
+    st = oracle_fm_state(**kw)
+    L.rxgpu_deemph_state(C.addressof(d2)).contents.value = 0
+    raw = iq.copy()
+    L.rxgpu_callback(raw.ctypes.data, block_len, C.addressof(s2))
+    lp = np.ctypeslib.as_array(d2.lowpassed)[:block_len].copy()
+    lp_len = C.c_int(block_len)
+    want = np.zeros(block_len, np.int16)
+    n_want = O.rxo_fm_full_demod(C.byref(st), ptr16(lp), C.byref(lp_len), ptr16(want))
+    L.rxgpu_full_demod(C.addressof(d2))
+    assert d2.result_len == n_want and np.array_equal(np.ctypeslib.as_array(d2.result)[:n_want], want[:n_want])
+    L.rxgpu_dropin_release(C.addressof(d2))
