@@ -40,7 +40,7 @@ static void rxgpu_dropin_power_setup(void)
 
 static void rxgpu_dropin_die(const char *what)
 {
-	rxgpu_fatal(what);                                             /* one line on stderr, device released, _exit(1) */
+	rxgpu_fatal(what);                                             /* one line on stderr, device drained, _exit(1) */
 }
 
 void rxgpu_dropin_scanner(size_t channel)

@@ -96,8 +96,8 @@ int rxgpu_prof_get(const char *name, double *total_ms, long *launches);
  * Same results either way ($RXGPU_DROPIN_FAST=0 takes the general path always). */
 void rxgpu_full_demod(struct demod_state *d);
 /* What the `void` drop-in entry points do on a device error, for callers (the files under dropin/) that want the same end: one line on stderr ("rxgpu: <what>:
- * <rxgpu_last_error()>"; never stdout -- that is the audio / CSV stream), the library's device resources released (at most five seconds: a
- * watchdog ends the process if the device no longer answers), then _exit(1) -- NOT exit(): no atexit handlers or static destructors of a SoapySDR
+ * <rxgpu_last_error()>"; never stdout -- that is the audio / CSV stream), the device drained of what is in flight (at most five seconds: a
+ * watchdog ends the process if the device no longer answers; nothing is freed under the application's other threads), then _exit(1) -- NOT exit(): no atexit handlers or static destructors of a SoapySDR
  * driver run while the application's other threads are still inside it or hold d->rw.  A second thread that fails meanwhile waits for the first. */
 void rxgpu_fatal(const char *what);
 /* a caller that edits d->lowpassed between rxgpu_callback and rxgpu_full_demod says so here */

@@ -84,11 +84,11 @@ int rxgpu_fault_tick(void)
 }
 
 /* The library's failure convention where the replaced function is `void` (full_demod, rtlsdr_callback, scanner: SURVEY.md 8b -- the
- * reference prints to stderr and exits): say it ONCE on stderr -- never stdout, that is the audio / CSV stream --, release what the
- * library holds on the device, and leave with _exit(1).  Not exit(): exit() runs the atexit handlers and static destructors of whatever
+ * reference prints to stderr and exits): say it ONCE on stderr -- never stdout, that is the audio / CSV stream --, let the device finish
+ * what is in flight, and leave with _exit(1) (the driver reclaims the device memory with the process).  Not exit(): exit() runs the atexit handlers and static destructors of whatever
  * SoapySDR driver is loaded while the application's other thread (dongle / demod / output) is still running, possibly inside that driver
  * or holding d->rw -- a process that never ends.  A device that no longer answers must not hold the process either: a watchdog thread
- * ends it after five seconds whatever rxgpu_shutdown is waiting for. */
+ * ends it after five seconds whatever the synchronisation is waiting for. */
 static void *fatal_watchdog(void *arg)
 {
 	(void)arg;
@@ -108,7 +108,10 @@ void rxgpu_fatal(const char *what)
 	pthread_t w;
 	if (pthread_create(&w, NULL, fatal_watchdog, NULL) == 0)
 		pthread_detach(w);
-	rxgpu_shutdown();
+	/* NOT rxgpu_shutdown(): that frees the drop-in's buffers and stream objects, which the application's other thread may be using this
+	 * very moment -- a use-after-free on the way out.  What is in flight is drained; the device memory goes back with the process. */
+	if (g_device >= 0)
+		(void)hipDeviceSynchronize();
 	_exit(1);
 }
 
