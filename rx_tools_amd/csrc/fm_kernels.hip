@@ -3655,6 +3655,202 @@ __global__ __launch_bounds__(256) void k_ch_audio(
 	}
 }
 
+// The same stages over a (segment, channel) grid -- k_ch_audio gives a channel ONE workgroup, i.e. one wave per SIMD on 256 CUs walking
+// dependent chains of a thousand steps: 400 us per 1 GiB capture with both stages on.  Here a channel's row is cut into chunks of >= `warm`
+// samples, 256 of them per workgroup (a segment), and the chunk tables of a row are composed in a second level as the rx_fm tree does:
+//   k_cha_track   grid (segments, channels): per thread one chunk -- warm-up on the two extreme trajectories (chunk 0: the carried state),
+//                 lowest candidate + merge mask through the chunk -> a 16-byte table in HBM
+//   k_cha_walk    grid (channels), one wave per segment: the lanes are the (at most 64) candidate start states of the segment's first chunk,
+//                 each walks the segment's tables; then one thread chains the segments from the carried state -> every segment's exact start
+//   k_cha_replay  grid (segments, channels): thread 0 walks the workgroup's 256 tables from the segment start (LDS), every thread replays its
+//                 chunk from its exact start -> the de-emphasised row (in place, or the scratch row in front of the resampler)
+//   k_cha_resample grid (outputs, channels): low_pass_real in closed form, one thread per output; one thread per channel leaves the carries
+#define CHA_MAX_SEG 8
+
+template <bool EVEN, bool D24>
+__global__ __launch_bounds__(256) void k_cha_track(const int16_t *__restrict__ rows, u64 row_stride, u64 W, int a, unsigned magic, int bias, int warm,
+                                                   unsigned chunk, unsigned n_chunks, const int *__restrict__ audio_in, uint4 *__restrict__ ctab)
+{
+	const unsigned g = blockIdx.x * 256u + threadIdx.x;
+	if (g >= n_chunks)
+		return;
+	const u64 c = blockIdx.y;
+	const int16_t *row = rows + c * row_stride;
+	const bool vec = ((size_t)row & 15u) == 0;
+	const int h = a / 2, xoff = h + bias * a;
+	const u64 b = (u64)g * chunk, e = min(W, b + chunk);
+	int lo, hi;
+	if (g == 0) {
+		lo = hi = audio_in[3 * c];
+	} else {
+		lo = -32768; hi = 32767;
+		if (vec) {
+			uint4 cur = *reinterpret_cast<const uint4 *>(&row[b - (u64)warm]);
+			for (u64 i = b - (u64)warm; i < b; i += 8) {
+				const uint4 nxt = *reinterpret_cast<const uint4 *>(&row[i + 8 < b ? i + 8 : i]);
+				const uint32_t ww[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+				for (int q = 0; q < 8; q++) {
+					const int x = (q & 1) ? hi16(ww[q >> 1]) : lo16(ww[q >> 1]);
+					lo = deemph_step_d<EVEN, D24>(lo, x + xoff, x, magic, bias);
+					hi = deemph_step_d<EVEN, D24>(hi, x + xoff, x, magic, bias);
+				}
+				cur = nxt;
+			}
+		} else {
+			for (u64 i = b - (u64)warm; i < b; i++) {
+				const int x = row[i];
+				lo = deemph_step_d<EVEN, D24>(lo, x + xoff, x, magic, bias);
+				hi = deemph_step_d<EVEN, D24>(hi, x + xoff, x, magic, bias);
+			}
+		}
+	}
+	int gap = hi - lo;
+	if (gap > 63) gap = 63;                                       // excluded by `warm`
+	const int lo_start = lo;
+	int cnt = gap + 1;
+	u64 mask = (((u64)1 << gap) - 1);
+	u64 i = b;
+	if (vec && i + 8 <= e) {
+		uint4 cur = *reinterpret_cast<const uint4 *>(&row[i]);
+		for (; i + 8 <= e; i += 8) {
+			const uint4 nxt = *reinterpret_cast<const uint4 *>(&row[i + 16 <= e ? i + 8 : i]);
+			const uint32_t ww[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+			for (int q = 0; q < 8; q++)
+				deemph_track<EVEN, D24>(lo, cnt, mask, (q & 1) ? hi16(ww[q >> 1]) : lo16(ww[q >> 1]), a, xoff, magic, bias);
+			cur = nxt;
+		}
+	}
+	for (; i < e; i++)
+		deemph_track<EVEN, D24>(lo, cnt, mask, (int)row[i], a, xoff, magic, bias);
+	ctab[c * n_chunks + g] = make_uint4((uint32_t)lo_start, ((uint32_t)lo & 0xffffu) | ((uint32_t)gap << 16), (uint32_t)mask, (uint32_t)(mask >> 32));
+}
+
+__global__ __launch_bounds__(64 * CHA_MAX_SEG) void k_cha_walk(const uint4 *__restrict__ ctab, unsigned n_chunks, const int *__restrict__ audio_in,
+                                                                int *__restrict__ audio_out, int *__restrict__ seg_start)
+{
+	extern __shared__ __attribute__((aligned(16))) uint4 cha_tab[];      // the channel's n_chunks tables
+	__shared__ int seg_end[CHA_MAX_SEG][64];
+	const u64 c = blockIdx.x;
+	const unsigned n_seg = (n_chunks + 255) / 256;
+	for (unsigned i = threadIdx.x; i < n_chunks; i += blockDim.x)
+		cha_tab[i] = ctab[c * n_chunks + i];
+	__syncthreads();
+	const unsigned sgm = threadIdx.x >> 6, k = threadIdx.x & 63;
+	if (sgm < n_seg) {
+		const unsigned g0 = sgm * 256u, g1 = min(n_chunks, g0 + 256u);
+		const uint4 t0 = cha_tab[g0];
+		const int gap = (int)(t0.y >> 16);
+		int v = (int)t0.x + min((int)k, gap);                        // lanes beyond the candidates repeat the last one
+		for (unsigned g = g0; g < g1; g++)
+			v = ctab_apply(cha_tab[g], v);
+		seg_end[sgm][k] = v;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		int v = audio_in[3 * c];
+		for (unsigned sg = 0; sg < n_seg; sg++) {
+			seg_start[c * CHA_MAX_SEG + sg] = v;
+			const uint4 t0 = cha_tab[sg * 256u];
+			int idx = v - (int)t0.x;
+			const int gap = (int)(t0.y >> 16);
+			idx = idx < 0 ? 0 : (idx > gap ? gap : idx);              // inside [0, gap] by the warm-up's guarantee
+			v = seg_end[sg][idx];
+		}
+		audio_out[3 * c] = v;
+	}
+}
+
+template <bool EVEN, bool D24>
+__global__ __launch_bounds__(256) void k_cha_replay(const int16_t *rows, u64 row_stride, u64 W, int a, unsigned magic, int bias,
+                                                    unsigned chunk, unsigned n_chunks, const uint4 *__restrict__ ctab, const int *__restrict__ seg_start,
+                                                    int16_t *y_rows, u64 y_stride)       // y_rows == rows without a resampler: in place
+{
+	__shared__ uint4 tab[256];
+	__shared__ int start[256];
+	const unsigned tid = threadIdx.x, g = blockIdx.x * 256u + tid;
+	const u64 c = blockIdx.y;
+	const int16_t *row = rows + c * row_stride;
+	int16_t *yrow = y_rows + c * y_stride;
+	const bool vec = (((size_t)row | (size_t)yrow) & 15u) == 0;
+	const unsigned active = min(256u, n_chunks - blockIdx.x * 256u);
+	if (tid < active)
+		tab[tid] = ctab[c * n_chunks + g];
+	__syncthreads();
+	if (tid == 0) {
+		int v = seg_start[c * CHA_MAX_SEG + blockIdx.x];
+		for (unsigned t = 0; t < active; t++) {
+			start[t] = v;
+			v = ctab_apply(tab[t], v);
+		}
+	}
+	__syncthreads();
+	if (tid >= active)
+		return;
+	const int h = a / 2, xoff = h + bias * a;
+	const u64 b = (u64)g * chunk, e = min(W, b + chunk);
+	int v = start[tid];
+	u64 i = b;
+	if (vec && i + 8 <= e) {
+		uint4 cur = *reinterpret_cast<const uint4 *>(&row[i]);
+		for (; i + 8 <= e; i += 8) {
+			const uint4 nxt = *reinterpret_cast<const uint4 *>(&row[i + 16 <= e ? i + 8 : i]);
+			const uint32_t ww[4] = {cur.x, cur.y, cur.z, cur.w};
+			uint32_t yy[4];
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				const int x0 = lo16(ww[q]), x1 = hi16(ww[q]);
+				v = deemph_step_d<EVEN, D24>(v, x0 + xoff, x0, magic, bias);
+				const int y0 = v;
+				v = deemph_step_d<EVEN, D24>(v, x1 + xoff, x1, magic, bias);
+				yy[q] = pack_iq(y0, v);
+			}
+			*reinterpret_cast<uint4 *>(&yrow[i]) = make_uint4(yy[0], yy[1], yy[2], yy[3]);
+			cur = nxt;
+		}
+	}
+	for (; i < e; i++) {
+		const int x = row[i];
+		v = deemph_step_d<EVEN, D24>(v, x + xoff, x, magic, bias);
+		yrow[i] = (int16_t)v;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_cha_resample(const int16_t *__restrict__ y_rows, u64 y_stride, u64 W, int fast, int slow, u64 J,
+                                                      const int *__restrict__ audio_in, int *__restrict__ audio_out, int16_t *__restrict__ rows, u64 row_stride)
+{
+	const u64 c = blockIdx.y;
+	const int16_t *yrow = y_rows + c * y_stride;
+	const u64 p0 = (u64)audio_in[3 * c + 2];
+	const int ratio = fast / slow;
+	const u64 j = (u64)blockIdx.x * 256u + threadIdx.x;
+	if (j < J) {
+		const u64 wb = j ? lpr_end(j - 1, fast, slow, p0) : 0, we = lpr_end(j, fast, slow, p0);
+		int sum = j ? 0 : audio_in[3 * c + 1];
+		for (u64 i = wb; i < we; i++)
+			sum += yrow[i];
+		rows[c * row_stride + j] = (int16_t)(sum / ratio);
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		const u64 wb = J ? lpr_end(J - 1, fast, slow, p0) : 0;
+		int sum = J ? 0 : audio_in[3 * c + 1];
+		for (u64 i = wb; i < W; i++)
+			sum += yrow[i];
+		audio_out[3 * c + 1] = sum;
+		audio_out[3 * c + 2] = (int)(p0 + W * (u64)slow - J * (u64)fast);
+	}
+}
+
+__global__ void k_cha_carry_copy(const int *__restrict__ audio_in, int *__restrict__ audio_out, int n_channels)
+{
+	const int c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c < n_channels) {
+		audio_out[3 * c + 1] = audio_in[3 * c + 1];
+		audio_out[3 * c + 2] = audio_in[3 * c + 2];
+	}
+}
+
 // ------------------------------------------------------------------ launchers
 
 #define LAUNCH_RET() return (int)hipGetLastError()
@@ -4550,6 +4746,53 @@ extern "C" int rxk_fm_block_dd(void *stream, const int16_t *blk, unsigned n, int
 		grid = 2048;
 	hipLaunchKernelGGL(k_fm_block_dd, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint32_t *)blk, n, ds, p0, now_r, now_j, pre_r, pre_j,
 	                   custom_atan, rxgpu_knob("RXGPU_FLAG_ALL") ? atoi(rxgpu_knob("RXGPU_FLAG_ALL")) : 0, lp, lp_host, pcm, keep, out, audio_in, avg, now_lpr, prev_lpr_index);
+	LAUNCH_RET();
+}
+
+// chunk length and count of the segmented form for a row of W samples; 0 chunks = the row is too short (or too long for CHA_MAX_SEG segments of
+// 256 chunks at a sane chunk length): k_ch_audio serves it
+extern "C" unsigned rxk_ch_audio_chunks(u64 W, int warm, unsigned *chunk_out)
+{
+	u64 chunk = (u64)((warm + 7) & ~7);
+	const u64 need = (W + 256u * CHA_MAX_SEG - 1) / (256u * CHA_MAX_SEG);
+	if (chunk < need)
+		chunk = (need + 7) & ~(u64)7;
+	if (chunk < 8)
+		chunk = 8;
+	const u64 n = (W + chunk - 1) / chunk;
+	if (chunk_out)
+		*chunk_out = (unsigned)chunk;
+	return (n < 64 || chunk > 4096) ? 0u : (unsigned)n;
+}
+
+// deemph on, !serial, rows long enough: the (segment, channel) grid.  ctab: n_channels * n_chunks tables; seg_start: n_channels * CHA_MAX_SEG ints.
+extern "C" int rxk_ch_audio_seg(void *stream, int16_t *rows, u64 row_stride, u64 W, int n_channels, int a, int warm, int fast, int slow, u64 J,
+                                const int *audio_in, int *audio_out, int16_t *y_rows, u64 y_stride, void *ctab_v, int *seg_start)
+{
+	uint4 *ctab = (uint4 *)ctab_v;
+	unsigned chunk = 0;
+	const unsigned n_chunks = rxk_ch_audio_chunks(W, warm, &chunk);
+	if (!n_chunks)
+		return (int)hipErrorInvalidValue;
+	hipStream_t s = (hipStream_t)stream;
+	const unsigned mg = deemph_magic(a);
+	const int bias = bias_for(a);
+	const unsigned n_seg = (n_chunks + 255) / 256;
+	int16_t *y = slow > 0 ? y_rows : rows;
+	const u64 ys = slow > 0 ? y_stride : row_stride;
+	const dim3 grid(n_seg, (unsigned)n_channels);
+#define GO(EV, D) do { \
+		hipLaunchKernelGGL((k_cha_track<EV, D>), grid, dim3(256), 0, s, rows, row_stride, W, a, mg, bias, warm, chunk, n_chunks, audio_in, ctab); \
+		hipLaunchKernelGGL(k_cha_walk, dim3((unsigned)n_channels), dim3(64 * n_seg), (size_t)n_chunks * 16, s, ctab, n_chunks, audio_in, audio_out, seg_start); \
+		hipLaunchKernelGGL((k_cha_replay<EV, D>), grid, dim3(256), 0, s, rows, row_stride, W, a, mg, bias, chunk, n_chunks, ctab, seg_start, y, ys); } while (0)
+	if (deemph_d24(a)) { if (a & 1) GO(false, true); else GO(true, true); }
+	else { if (a & 1) GO(false, false); else GO(true, false); }
+#undef GO
+	if (slow > 0)
+		hipLaunchKernelGGL(k_cha_resample, dim3((unsigned)((J + 255) / 256) ? (unsigned)((J + 255) / 256) : 1u, (unsigned)n_channels), dim3(256), 0, s,
+		                   y_rows, y_stride, W, fast, slow, J, audio_in, audio_out, rows, row_stride);
+	else
+		hipLaunchKernelGGL(k_cha_carry_copy, dim3((unsigned)(n_channels + 255) / 256), dim3(256), 0, s, audio_in, audio_out, n_channels);
 	LAUNCH_RET();
 }
 

@@ -21,6 +21,9 @@ struct rxgpu_chan {
 	int *pre_host;
 	int *audio_dev[2], *audio_host;  /* per channel {deemph avg, now_lpr, prev_lpr_index}: in / out */
 	int16_t *audio_y;                /* [n_channels][max_windows]: the de-emphasised samples in front of the resampler */
+	void *audio_ctab;                /* the (segment, channel) form of the audio stages: chunk tables [n_channels][chunks] ... */
+	int *audio_seg;                  /* ... and every segment's start state [n_channels][8] */
+	int audio_seg_on;                /* $RXGPU_CH_AUDIO_SEG != 0 at creation */
 	rxk_fm_dev *dev, *dev_host;
 	unsigned long long *flag_list, *flag_host;
 	long fixups;
@@ -61,12 +64,20 @@ int rxgpu_chan_create(rxgpu_chan **out, const rxgpu_chan_params *p, size_t max_b
 	if (!tw) { free(s); return rxgpu_fail(RXGPU_ENOMEM, "out of host memory"); }
 	rxgpu_twiddle_table(sinewave, (int)n, tw);
 	const size_t nc = (size_t)p->n_channels;
+	/* chunk tables of the segmented audio stages: at most 8 segments of 256 chunks per channel, and never more chunks than the longest row holds */
+	size_t ctab_per_channel = 2048;
+	if (p->deemph && p->deemph_a >= 2 && p->deemph_a <= 64) {
+		const size_t w8 = (size_t)((rxgpu_deemph_warm64(p->deemph_a) + 7) & ~7);
+		if ((s->max_windows + w8 - 1) / w8 < ctab_per_channel)
+			ctab_per_channel = (s->max_windows + w8 - 1) / w8 + 1;
+	}
 	if (hipMalloc((void **)&s->twiddle_dev, (n + 2) * 4) != hipSuccess ||
 	    hipMalloc((void **)&s->chan_lp, nc * s->max_windows * 4) != hipSuccess ||
 	    hipMalloc((void **)&s->pre_dev[0], nc * 8) != hipSuccess || hipMalloc((void **)&s->pre_dev[1], nc * 8) != hipSuccess ||
 	    hipMalloc((void **)&s->audio_dev[0], nc * 12) != hipSuccess || hipMalloc((void **)&s->audio_dev[1], nc * 12) != hipSuccess ||
 	    hipHostMalloc((void **)&s->audio_host, nc * 12, 0) != hipSuccess ||
 	    (p->rate_out2 > 0 && hipMalloc((void **)&s->audio_y, nc * s->max_windows * 2) != hipSuccess) ||
+	    (p->deemph && (hipMalloc(&s->audio_ctab, nc * ctab_per_channel * 16) != hipSuccess || hipMalloc((void **)&s->audio_seg, nc * 8 * 4) != hipSuccess)) ||
 	    hipMalloc((void **)&s->dev, sizeof(rxk_fm_dev)) != hipSuccess ||
 	    hipMalloc((void **)&s->flag_list, RXK_FLAG_CAP * 8) != hipSuccess ||
 	    hipHostMalloc((void **)&s->dev_host, sizeof(rxk_fm_dev), 0) != hipSuccess ||
@@ -94,6 +105,10 @@ int rxgpu_chan_create(rxgpu_chan **out, const rxgpu_chan_params *p, size_t max_b
 	}
 	memset(s->pre_host, 0, nc * 8);
 	memset(s->audio_host, 0, nc * 12);
+	{
+		const char *k = rxgpu_knob("RXGPU_CH_AUDIO_SEG");             /* "0": one workgroup per channel always (A/B, tests) */
+		s->audio_seg_on = !(k && k[0] == '0');
+	}
 	*out = s;
 	return RXGPU_OK;
 }
@@ -103,7 +118,7 @@ void rxgpu_chan_destroy(rxgpu_chan *s)
 	if (!s)
 		return;
 	hipFree(s->twiddle_dev); hipFree(s->nco_tw_dev); hipFree(s->chan_lp); hipFree(s->pre_dev[0]); hipFree(s->pre_dev[1]);
-	hipFree(s->audio_dev[0]); hipFree(s->audio_dev[1]); hipFree(s->audio_y);
+	hipFree(s->audio_dev[0]); hipFree(s->audio_dev[1]); hipFree(s->audio_y); hipFree(s->audio_ctab); hipFree(s->audio_seg);
 	if (s->audio_host) hipHostFree(s->audio_host);
 	hipFree(s->dev); hipFree(s->flag_list);
 	if (s->dev_host) hipHostFree(s->dev_host);
@@ -254,10 +269,15 @@ int rxgpu_chan_run(rxgpu_chan *s, const int16_t *d_iq, size_t n_blocks, size_t b
 			if (s->audio_host[3 * c] < -32768 || s->audio_host[3 * c] > 32767)
 				serial = 1;
 		RX_HIP(hipMemcpyAsync(s->audio_dev[0], s->audio_host, nc * 12, hipMemcpyHostToDevice, st));
+		const int warm = s->p.deemph && !serial ? rxgpu_deemph_warm64(s->p.deemph_a) : 8;
 		rxgpu_prof_begin("ch_audio");
-		RX_K(rxk_ch_audio(st, d_out, out_stride, total, s->p.n_channels, s->p.deemph, s->p.deemph_a,
-		                  s->p.deemph && !serial ? rxgpu_deemph_warm64(s->p.deemph_a) : 8, serial, s->p.rate_out, s->p.rate_out2 > 0 ? s->p.rate_out2 : 0, J,
-		                  s->audio_dev[0], s->audio_dev[1], s->audio_y, s->max_windows));
+		if (s->p.deemph && !serial && s->audio_seg_on && rxk_ch_audio_chunks(total, warm, NULL))
+			/* rows long enough to cut into segments: chunk tables per (segment, channel), composed in a second level */
+			RX_K(rxk_ch_audio_seg(st, d_out, out_stride, total, s->p.n_channels, s->p.deemph_a, warm, s->p.rate_out, s->p.rate_out2 > 0 ? s->p.rate_out2 : 0, J,
+			                      s->audio_dev[0], s->audio_dev[1], s->audio_y, s->max_windows, s->audio_ctab, s->audio_seg));
+		else
+			RX_K(rxk_ch_audio(st, d_out, out_stride, total, s->p.n_channels, s->p.deemph, s->p.deemph_a, warm, serial, s->p.rate_out,
+			                  s->p.rate_out2 > 0 ? s->p.rate_out2 : 0, J, s->audio_dev[0], s->audio_dev[1], s->audio_y, s->max_windows));
 		rxgpu_prof_end("ch_audio");
 		RX_HIP(hipMemcpyAsync(s->audio_host, s->audio_dev[1], nc * 12, hipMemcpyDeviceToHost, st));
 		RX_HIP(hipStreamSynchronize(st));

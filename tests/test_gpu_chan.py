@@ -201,6 +201,72 @@ def test_channeliser_per_channel_audio_stages(bin_e, n_channels, block_len, n_bl
     ch.close()
 
 
+# round 5: the audio stages on a (segment, channel) grid -- rows long enough to be cut into >= 64 chunks of >= warm-up length
+@pytest.mark.parametrize("bin_e,n_channels,block_len,n_blocks,a,rate_out,rate_out2,custom_atan,pad", [
+    (6, 40, 2 * 65536, 10, 7, 19531, 8000, 1, 0),         # 5120-sample rows: 80 chunks, one segment; odd a below the 24-bit step
+    (4, 12, 2 * 65536, 10, 7, 19531, 8000, 1, 0),         # 20480-sample rows: 320 chunks, two segments
+    (4, 16, 2 * 65536, 10, 13, 170000, 32000, 0, 0),      # the wbfm constants: odd a in the three-instruction range; -A std
+    (4, 9, 2 * 65536, 10, 2, 19531, -1, 1, 0),            # even a, de-emphasis only (in place), 8 segments
+    (4, 9, 2 * 65536, 6, 64, 24000, 12000, 1, 5),         # a at the top of the mask range; rows that start off any 16-byte boundary
+    (5, 20, 2 * 131072, 8, 19, 240000, 32000, 1, 0),      # 16384-sample rows, a = 19
+])
+def test_channeliser_audio_stages_segmented(bin_e, n_channels, block_len, n_blocks, a, rate_out, rate_out2, custom_atan, pad, monkeypatch):
+    """the (segment, channel) form of the per-channel audio stages == the oracle (and the reference where built), across a run boundary,
+    and == the one-workgroup-per-channel kernel ($RXGPU_CH_AUDIO_SEG=0) on the same input"""
+    from gpu_support import to_dev, torch_cuda
+    torch = torch_cuda()
+    iq = sig_noise(n_blocks * block_len, seed=40 + bin_e + a, amp=2500)
+    want, want_pre, want_state = oracle_chan_audio(iq, block_len, bin_e, 3, n_channels, custom_atan, 1, a, rate_out, rate_out2)
+    n = 1 << bin_e
+    wpb = block_len // 2 // n
+    per = (n_blocks + 1) // 2
+    d_iq = to_dev(iq)
+    results = []
+    for seg in ("1", "0"):
+        monkeypatch.setenv("RXGPU_CH_AUDIO_SEG", seg)
+        ch = R.Channeliser(R.ChanParams(bin_e, 3, n_channels, custom_atan, 1, a, rate_out, rate_out2), per, block_len, R.sine_table(bin_e))
+        outs, b = [], 0
+        while b < n_blocks:
+            nb = min(per, n_blocks - b)
+            stride = nb * wpb + pad
+            d_out = torch.zeros((n_channels, stride), dtype=torch.int16, device="cuda")
+            w = ch.run(d_iq.data_ptr() + b * block_len * 2, nb, block_len, d_out.data_ptr(), stride)
+            outs.append(d_out[:, :w].cpu().numpy())
+            b += nb
+        results.append((np.concatenate(outs, axis=1), ch.get_carry(), ch.get_audio_carry().reshape(n_channels, 3)))
+        ch.close()
+    for got, pre, state in results:
+        assert got.shape == want.shape and np.array_equal(got, want)
+        assert np.array_equal(pre, want_pre) and np.array_equal(state, want_state)
+    if have_ref():
+        ref_out, ref_pre, ref_state = ref_chan_stream(iq, block_len, bin_e, 3, n_channels, custom_atan, 1, a, rate_out, rate_out2)
+        assert np.array_equal(results[0][0], ref_out) and np.array_equal(results[0][1], ref_pre) and np.array_equal(results[0][2], ref_state)
+
+
+def test_channeliser_audio_segmented_hostile_rows():
+    """rows on which trajectories never merge (constant input: every chunk keeps its full candidate range) and rows that slam between the
+    extremes: the segmented form's candidate walk and chunk tables still give the serial filter's samples"""
+    from gpu_support import to_dev, torch_cuda
+    torch = torch_cuda()
+    bin_e, n_channels, block_len, n_blocks, a = 4, 16, 2 * 65536, 4, 7
+    n = 1 << bin_e
+    for kind in ("zeros", "dc", "alternate"):
+        if kind == "zeros":
+            iq = np.zeros(n_blocks * block_len, np.int16)
+        elif kind == "dc":
+            iq = np.full(n_blocks * block_len, 20000, np.int16)
+        else:
+            iq = np.tile(np.array([32767, 32767, -32768, -32768], np.int16), n_blocks * block_len // 4)
+        want, want_pre, want_state = oracle_chan_audio(iq, block_len, bin_e, 0, n_channels, 1, 1, a, 19531, 8000)
+        ch = R.Channeliser(R.ChanParams(bin_e, 0, n_channels, 1, 1, a, 19531, 8000), n_blocks, block_len, R.sine_table(bin_e))
+        wpb = block_len // 2 // n
+        d_out = torch.zeros((n_channels, n_blocks * wpb), dtype=torch.int16, device="cuda")
+        w = ch.run(to_dev(iq).data_ptr(), n_blocks, block_len, d_out.data_ptr(), n_blocks * wpb)
+        assert w == want.shape[1] and np.array_equal(d_out[:, :w].cpu().numpy(), want), kind
+        assert np.array_equal(ch.get_audio_carry().reshape(n_channels, 3), want_state), kind
+        ch.close()
+
+
 # ----------------------------------------------------------------------------- round 4: the NCO -> low_pass mode (SURVEY 8(f)2's literal definition)
 
 @pytest.mark.parametrize("bin_e,first_bin,n_channels,block_len,n_blocks", [
