@@ -3667,6 +3667,25 @@ __global__ __launch_bounds__(256) void k_ch_audio(
 //   k_cha_resample grid (outputs, channels): low_pass_real in closed form, one thread per output; one thread per channel leaves the carries
 #define CHA_MAX_SEG 8
 
+// A lane walks ITS chunk, so a wave's loads land on 64 different cache lines: with one 16-byte piece per lane and turn every line was fetched
+// eight times (2048 workgroups' working set does not fit any cache) and the kernels ran at the speed of that -- 160 + 213 us.  A lane now takes a
+// whole 128-byte line per turn (eight 16-byte loads back to back, the next line requested before this one is walked): every line crosses once.
+struct cha_line { uint4 u[8]; };
+__device__ __forceinline__ cha_line cha_load(const int16_t *p)
+{
+	cha_line l;
+#pragma unroll
+	for (int k = 0; k < 8; k++)
+		l.u[k] = reinterpret_cast<const uint4 *>(p)[k];
+	return l;
+}
+__device__ __forceinline__ int cha_sample(const cha_line &l, int q)        // q: compile-time after unrolling
+{
+	const uint4 u = l.u[q >> 3];
+	const uint32_t w = ((q >> 1) & 3) == 0 ? u.x : ((q >> 1) & 3) == 1 ? u.y : ((q >> 1) & 3) == 2 ? u.z : u.w;
+	return (q & 1) ? hi16(w) : lo16(w);
+}
+
 template <bool EVEN, bool D24>
 __global__ __launch_bounds__(256) void k_cha_track(const int16_t *__restrict__ rows, u64 row_stride, u64 W, int a, unsigned magic, int bias, int warm,
                                                    unsigned chunk, unsigned n_chunks, const int *__restrict__ audio_in, uint4 *__restrict__ ctab)
@@ -3684,25 +3703,24 @@ __global__ __launch_bounds__(256) void k_cha_track(const int16_t *__restrict__ r
 		lo = hi = audio_in[3 * c];
 	} else {
 		lo = -32768; hi = 32767;
-		if (vec) {
-			uint4 cur = *reinterpret_cast<const uint4 *>(&row[b - (u64)warm]);
-			for (u64 i = b - (u64)warm; i < b; i += 8) {
-				const uint4 nxt = *reinterpret_cast<const uint4 *>(&row[i + 8 < b ? i + 8 : i]);
-				const uint32_t ww[4] = {cur.x, cur.y, cur.z, cur.w};
+		u64 i = b - (u64)warm;
+		if (vec && i + 64 <= b) {
+			cha_line cur = cha_load(&row[i]);
+			for (; i + 64 <= b; i += 64) {
+				const cha_line nxt = cha_load(&row[i + 128 <= b ? i + 64 : i]);
 #pragma unroll
-				for (int q = 0; q < 8; q++) {
-					const int x = (q & 1) ? hi16(ww[q >> 1]) : lo16(ww[q >> 1]);
+				for (int q = 0; q < 64; q++) {
+					const int x = cha_sample(cur, q);
 					lo = deemph_step_d<EVEN, D24>(lo, x + xoff, x, magic, bias);
 					hi = deemph_step_d<EVEN, D24>(hi, x + xoff, x, magic, bias);
 				}
 				cur = nxt;
 			}
-		} else {
-			for (u64 i = b - (u64)warm; i < b; i++) {
-				const int x = row[i];
-				lo = deemph_step_d<EVEN, D24>(lo, x + xoff, x, magic, bias);
-				hi = deemph_step_d<EVEN, D24>(hi, x + xoff, x, magic, bias);
-			}
+		}
+		for (; i < b; i++) {
+			const int x = row[i];
+			lo = deemph_step_d<EVEN, D24>(lo, x + xoff, x, magic, bias);
+			hi = deemph_step_d<EVEN, D24>(hi, x + xoff, x, magic, bias);
 		}
 	}
 	int gap = hi - lo;
@@ -3711,14 +3729,13 @@ __global__ __launch_bounds__(256) void k_cha_track(const int16_t *__restrict__ r
 	int cnt = gap + 1;
 	u64 mask = (((u64)1 << gap) - 1);
 	u64 i = b;
-	if (vec && i + 8 <= e) {
-		uint4 cur = *reinterpret_cast<const uint4 *>(&row[i]);
-		for (; i + 8 <= e; i += 8) {
-			const uint4 nxt = *reinterpret_cast<const uint4 *>(&row[i + 16 <= e ? i + 8 : i]);
-			const uint32_t ww[4] = {cur.x, cur.y, cur.z, cur.w};
+	if (vec && i + 64 <= e) {
+		cha_line cur = cha_load(&row[i]);
+		for (; i + 64 <= e; i += 64) {
+			const cha_line nxt = cha_load(&row[i + 128 <= e ? i + 64 : i]);
 #pragma unroll
-			for (int q = 0; q < 8; q++)
-				deemph_track<EVEN, D24>(lo, cnt, mask, (q & 1) ? hi16(ww[q >> 1]) : lo16(ww[q >> 1]), a, xoff, magic, bias);
+			for (int q = 0; q < 64; q++)
+				deemph_track<EVEN, D24>(lo, cnt, mask, cha_sample(cur, q), a, xoff, magic, bias);
 			cur = nxt;
 		}
 	}
@@ -3792,21 +3809,23 @@ __global__ __launch_bounds__(256) void k_cha_replay(const int16_t *rows, u64 row
 	const u64 b = (u64)g * chunk, e = min(W, b + chunk);
 	int v = start[tid];
 	u64 i = b;
-	if (vec && i + 8 <= e) {
-		uint4 cur = *reinterpret_cast<const uint4 *>(&row[i]);
-		for (; i + 8 <= e; i += 8) {
-			const uint4 nxt = *reinterpret_cast<const uint4 *>(&row[i + 16 <= e ? i + 8 : i]);
-			const uint32_t ww[4] = {cur.x, cur.y, cur.z, cur.w};
-			uint32_t yy[4];
+	if (vec && i + 64 <= e) {
+		cha_line cur = cha_load(&row[i]);
+		for (; i + 64 <= e; i += 64) {
+			const cha_line nxt = cha_load(&row[i + 128 <= e ? i + 64 : i]);
 #pragma unroll
-			for (int q = 0; q < 4; q++) {
-				const int x0 = lo16(ww[q]), x1 = hi16(ww[q]);
-				v = deemph_step_d<EVEN, D24>(v, x0 + xoff, x0, magic, bias);
-				const int y0 = v;
-				v = deemph_step_d<EVEN, D24>(v, x1 + xoff, x1, magic, bias);
-				yy[q] = pack_iq(y0, v);
+			for (int k = 0; k < 8; k++) {
+				uint32_t yy[4];
+#pragma unroll
+				for (int q = 0; q < 4; q++) {
+					const int x0 = cha_sample(cur, 8 * k + 2 * q), x1 = cha_sample(cur, 8 * k + 2 * q + 1);
+					v = deemph_step_d<EVEN, D24>(v, x0 + xoff, x0, magic, bias);
+					const int y0 = v;
+					v = deemph_step_d<EVEN, D24>(v, x1 + xoff, x1, magic, bias);
+					yy[q] = pack_iq(y0, v);
+				}
+				reinterpret_cast<uint4 *>(&yrow[i])[k] = make_uint4(yy[0], yy[1], yy[2], yy[3]);
 			}
-			*reinterpret_cast<uint4 *>(&yrow[i]) = make_uint4(yy[0], yy[1], yy[2], yy[3]);
 			cur = nxt;
 		}
 	}
@@ -3814,6 +3833,38 @@ __global__ __launch_bounds__(256) void k_cha_replay(const int16_t *rows, u64 row
 		const int x = row[i];
 		v = deemph_step_d<EVEN, D24>(v, x + xoff, x, magic, bias);
 		yrow[i] = (int16_t)v;
+	}
+}
+
+// window bounds of low_pass_real, the same in every channel (the phase advances alike in all of them): bnd[j] = first sample of output j's window,
+// j = 0 .. J (bnd[J]: where the unfinished window starts) -- one fp64 division per entry here instead of two per output and channel
+__global__ void k_cha_bounds(u64 J, int fast, int slow, u64 p0, unsigned *__restrict__ bnd)
+{
+	const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j <= J)
+		bnd[j] = j ? (unsigned)lpr_end(j - 1, fast, slow, p0) : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_cha_resample_b(const int16_t *__restrict__ y_rows, u64 y_stride, u64 W, int ratio, u64 J, const unsigned *__restrict__ bnd,
+                                                        const int *__restrict__ audio_in, int *__restrict__ audio_out, int16_t *__restrict__ rows, u64 row_stride,
+                                                        int slow, int fast)
+{
+	const u64 c = blockIdx.y;
+	const int16_t *yrow = y_rows + c * y_stride;
+	const u64 j = (u64)blockIdx.x * 256u + threadIdx.x;
+	if (j < J) {
+		const unsigned wb = bnd[j], we = bnd[j + 1];
+		int sum = j ? 0 : audio_in[3 * c + 1];
+		for (unsigned i = wb; i < we; i++)
+			sum += yrow[i];
+		rows[c * row_stride + j] = (int16_t)(sum / ratio);
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		int sum = J ? 0 : audio_in[3 * c + 1];
+		for (u64 i = bnd[J]; i < W; i++)
+			sum += yrow[i];
+		audio_out[3 * c + 1] = sum;
+		audio_out[3 * c + 2] = (int)((u64)audio_in[3 * c + 2] + W * (u64)slow - J * (u64)fast);
 	}
 }
 
@@ -4759,6 +4810,8 @@ extern "C" unsigned rxk_ch_audio_chunks(u64 W, int warm, unsigned *chunk_out)
 		chunk = (need + 7) & ~(u64)7;
 	if (chunk < 8)
 		chunk = 8;
+	if (chunk >= 48)
+		chunk = (chunk + 63) & ~(u64)63;                              // whole 128-byte lines per lane and turn (k_cha_track)
 	const u64 n = (W + chunk - 1) / chunk;
 	if (chunk_out)
 		*chunk_out = (unsigned)chunk;
@@ -4767,7 +4820,7 @@ extern "C" unsigned rxk_ch_audio_chunks(u64 W, int warm, unsigned *chunk_out)
 
 // deemph on, !serial, rows long enough: the (segment, channel) grid.  ctab: n_channels * n_chunks tables; seg_start: n_channels * CHA_MAX_SEG ints.
 extern "C" int rxk_ch_audio_seg(void *stream, int16_t *rows, u64 row_stride, u64 W, int n_channels, int a, int warm, int fast, int slow, u64 J,
-                                const int *audio_in, int *audio_out, int16_t *y_rows, u64 y_stride, void *ctab_v, int *seg_start)
+                                const int *audio_in, int *audio_out, int16_t *y_rows, u64 y_stride, void *ctab_v, int *seg_start, unsigned *bnd, int p0)
 {
 	uint4 *ctab = (uint4 *)ctab_v;
 	unsigned chunk = 0;
@@ -4788,7 +4841,11 @@ extern "C" int rxk_ch_audio_seg(void *stream, int16_t *rows, u64 row_stride, u64
 	if (deemph_d24(a)) { if (a & 1) GO(false, true); else GO(true, true); }
 	else { if (a & 1) GO(false, false); else GO(true, false); }
 #undef GO
-	if (slow > 0)
+	if (slow > 0 && bnd && W < 0xffffffffull) {
+		hipLaunchKernelGGL(k_cha_bounds, dim3((unsigned)((J + 256) / 256)), dim3(256), 0, s, J, fast, slow, (u64)p0, bnd);
+		hipLaunchKernelGGL(k_cha_resample_b, dim3((unsigned)((J + 255) / 256) ? (unsigned)((J + 255) / 256) : 1u, (unsigned)n_channels), dim3(256), 0, s,
+		                   y_rows, y_stride, W, fast / slow, J, bnd, audio_in, audio_out, rows, row_stride, slow, fast);
+	} else if (slow > 0)
 		hipLaunchKernelGGL(k_cha_resample, dim3((unsigned)((J + 255) / 256) ? (unsigned)((J + 255) / 256) : 1u, (unsigned)n_channels), dim3(256), 0, s,
 		                   y_rows, y_stride, W, fast, slow, J, audio_in, audio_out, rows, row_stride);
 	else

@@ -260,7 +260,7 @@ int rxk_ch_demod(void *stream, const uint32_t *chan_lp, unsigned long long total
 unsigned rxk_ch_audio_chunks(unsigned long long W, int warm, unsigned *chunk_out);
 int rxk_ch_audio_seg(void *stream, int16_t *rows, unsigned long long row_stride, unsigned long long W, int n_channels, int a, int warm,
                      int fast, int slow, unsigned long long J, const int *audio_in, int *audio_out, int16_t *y_rows, unsigned long long y_stride,
-                     void *ctab, int *seg_start);
+                     void *ctab, int *seg_start, unsigned *bnd, int p0);   /* bnd: J + 1 window bounds (NULL: closed form per output), p0: the common phase */
 int rxk_ch_audio(void *stream, int16_t *rows, unsigned long long row_stride, unsigned long long W, int n_channels, int deemph, int a,
                  int warm, int serial, int fast, int slow, unsigned long long J, const int *audio_in, int *audio_out,
                  int16_t *y_rows, unsigned long long y_stride);

@@ -23,6 +23,7 @@ struct rxgpu_chan {
 	int16_t *audio_y;                /* [n_channels][max_windows]: the de-emphasised samples in front of the resampler */
 	void *audio_ctab;                /* the (segment, channel) form of the audio stages: chunk tables [n_channels][chunks] ... */
 	int *audio_seg;                  /* ... and every segment's start state [n_channels][8] */
+	unsigned *audio_bnd;             /* low_pass_real's window bounds, the same in every channel: max_windows + 2 entries */
 	int audio_seg_on;                /* $RXGPU_CH_AUDIO_SEG != 0 at creation */
 	rxk_fm_dev *dev, *dev_host;
 	unsigned long long *flag_list, *flag_host;
@@ -77,6 +78,7 @@ int rxgpu_chan_create(rxgpu_chan **out, const rxgpu_chan_params *p, size_t max_b
 	    hipMalloc((void **)&s->audio_dev[0], nc * 12) != hipSuccess || hipMalloc((void **)&s->audio_dev[1], nc * 12) != hipSuccess ||
 	    hipHostMalloc((void **)&s->audio_host, nc * 12, 0) != hipSuccess ||
 	    (p->rate_out2 > 0 && hipMalloc((void **)&s->audio_y, nc * s->max_windows * 2) != hipSuccess) ||
+	    (p->deemph && p->rate_out2 > 0 && hipMalloc((void **)&s->audio_bnd, (s->max_windows + 2) * 4) != hipSuccess) ||
 	    (p->deemph && (hipMalloc(&s->audio_ctab, nc * ctab_per_channel * 16) != hipSuccess || hipMalloc((void **)&s->audio_seg, nc * 8 * 4) != hipSuccess)) ||
 	    hipMalloc((void **)&s->dev, sizeof(rxk_fm_dev)) != hipSuccess ||
 	    hipMalloc((void **)&s->flag_list, RXK_FLAG_CAP * 8) != hipSuccess ||
@@ -118,7 +120,7 @@ void rxgpu_chan_destroy(rxgpu_chan *s)
 	if (!s)
 		return;
 	hipFree(s->twiddle_dev); hipFree(s->nco_tw_dev); hipFree(s->chan_lp); hipFree(s->pre_dev[0]); hipFree(s->pre_dev[1]);
-	hipFree(s->audio_dev[0]); hipFree(s->audio_dev[1]); hipFree(s->audio_y); hipFree(s->audio_ctab); hipFree(s->audio_seg);
+	hipFree(s->audio_dev[0]); hipFree(s->audio_dev[1]); hipFree(s->audio_y); hipFree(s->audio_ctab); hipFree(s->audio_seg); hipFree(s->audio_bnd);
 	if (s->audio_host) hipHostFree(s->audio_host);
 	hipFree(s->dev); hipFree(s->flag_list);
 	if (s->dev_host) hipHostFree(s->dev_host);
@@ -274,7 +276,8 @@ int rxgpu_chan_run(rxgpu_chan *s, const int16_t *d_iq, size_t n_blocks, size_t b
 		if (s->p.deemph && !serial && s->audio_seg_on && rxk_ch_audio_chunks(total, warm, NULL))
 			/* rows long enough to cut into segments: chunk tables per (segment, channel), composed in a second level */
 			RX_K(rxk_ch_audio_seg(st, d_out, out_stride, total, s->p.n_channels, s->p.deemph_a, warm, s->p.rate_out, s->p.rate_out2 > 0 ? s->p.rate_out2 : 0, J,
-			                      s->audio_dev[0], s->audio_dev[1], s->audio_y, s->max_windows, s->audio_ctab, s->audio_seg));
+			                      s->audio_dev[0], s->audio_dev[1], s->audio_y, s->max_windows, s->audio_ctab, s->audio_seg, s->audio_bnd,
+			                      s->p.rate_out2 > 0 ? s->audio_host[2] : 0));
 		else
 			RX_K(rxk_ch_audio(st, d_out, out_stride, total, s->p.n_channels, s->p.deemph, s->p.deemph_a, warm, serial, s->p.rate_out,
 			                  s->p.rate_out2 > 0 ? s->p.rate_out2 : 0, J, s->audio_dev[0], s->audio_dev[1], s->audio_y, s->max_windows));
