@@ -3663,8 +3663,8 @@ __global__ __launch_bounds__(256) void k_ch_audio(
 //   k_cha_walk    grid (channels), one wave per segment: the lanes are the (at most 64) candidate start states of the segment's first chunk,
 //                 each walks the segment's tables; then one thread chains the segments from the carried state -> every segment's exact start
 //   k_cha_replay  grid (segments, channels): thread 0 walks the workgroup's 256 tables from the segment start (LDS), every thread replays its
-//                 chunk from its exact start -> the de-emphasised row (in place, or the scratch row in front of the resampler)
-//   k_cha_resample grid (outputs, channels): low_pass_real in closed form, one thread per output; one thread per channel leaves the carries
+//                 chunk from its exact start -> the de-emphasised row (another buffer than the demodulated one)
+//                 and, with a resampler behind, runs low_pass_real inline on the filtered samples (k_cha_replay_rs): they never go to HBM
 #define CHA_MAX_SEG 8
 
 // A lane walks ITS chunk, so a wave's loads land on 64 different cache lines: with one 16-byte piece per lane and turn every line was fetched
@@ -3779,21 +3779,13 @@ __global__ __launch_bounds__(64 * CHA_MAX_SEG) void k_cha_walk(const uint4 *__re
 	}
 }
 
-template <bool EVEN, bool D24>
-__global__ __launch_bounds__(256) void k_cha_replay(const int16_t *rows, u64 row_stride, u64 W, int a, unsigned magic, int bias,
-                                                    unsigned chunk, unsigned n_chunks, const uint4 *__restrict__ ctab, const int *__restrict__ seg_start,
-                                                    int16_t *y_rows, u64 y_stride)       // y_rows == rows without a resampler: in place
+// shared front of the two replay kernels: the workgroup's 256 tables into LDS, thread 0 walks them from the segment's start state
+__device__ __forceinline__ int cha_chunk_start(uint4 *tab, int *start, const uint4 *__restrict__ ctab, const int *__restrict__ seg_start, u64 c,
+                                               unsigned n_chunks, unsigned active)
 {
-	__shared__ uint4 tab[256];
-	__shared__ int start[256];
-	const unsigned tid = threadIdx.x, g = blockIdx.x * 256u + tid;
-	const u64 c = blockIdx.y;
-	const int16_t *row = rows + c * row_stride;
-	int16_t *yrow = y_rows + c * y_stride;
-	const bool vec = (((size_t)row | (size_t)yrow) & 15u) == 0;
-	const unsigned active = min(256u, n_chunks - blockIdx.x * 256u);
+	const unsigned tid = threadIdx.x;
 	if (tid < active)
-		tab[tid] = ctab[c * n_chunks + g];
+		tab[tid] = ctab[c * n_chunks + blockIdx.x * 256u + tid];
 	__syncthreads();
 	if (tid == 0) {
 		int v = seg_start[c * CHA_MAX_SEG + blockIdx.x];
@@ -3803,11 +3795,32 @@ __global__ __launch_bounds__(256) void k_cha_replay(const int16_t *rows, u64 row
 		}
 	}
 	__syncthreads();
+	return tid < active ? start[tid] : 0;
+}
+
+// de-emphasis only: every thread replays its chunk from its exact start, in -> out (two buffers: the demodulated rows stay as they are)
+template <bool EVEN, bool D24>
+__global__ __launch_bounds__(256) void k_cha_replay(const int16_t *__restrict__ rows, u64 row_stride, u64 W, int a, unsigned magic, int bias,
+                                                    unsigned chunk, unsigned n_chunks, const uint4 *__restrict__ ctab, const int *__restrict__ seg_start,
+                                                    const int *__restrict__ audio_in, int *__restrict__ audio_out, int16_t *__restrict__ y_rows, u64 y_stride)
+{
+	__shared__ uint4 tab[256];
+	__shared__ int start[256];
+	const unsigned tid = threadIdx.x, g = blockIdx.x * 256u + tid;
+	const u64 c = blockIdx.y;
+	const int16_t *row = rows + c * row_stride;
+	int16_t *yrow = y_rows + c * y_stride;
+	const bool vec = (((size_t)row | (size_t)yrow) & 15u) == 0;
+	const unsigned active = min(256u, n_chunks - blockIdx.x * 256u);
+	int v = cha_chunk_start(tab, start, ctab, seg_start, c, n_chunks, active);
+	if (g == 0) {                                                 // the resampler's carries pass through
+		audio_out[3 * c + 1] = audio_in[3 * c + 1];
+		audio_out[3 * c + 2] = audio_in[3 * c + 2];
+	}
 	if (tid >= active)
 		return;
 	const int h = a / 2, xoff = h + bias * a;
 	const u64 b = (u64)g * chunk, e = min(W, b + chunk);
-	int v = start[tid];
 	u64 i = b;
 	if (vec && i + 64 <= e) {
 		cha_line cur = cha_load(&row[i]);
@@ -3836,70 +3849,79 @@ __global__ __launch_bounds__(256) void k_cha_replay(const int16_t *rows, u64 row
 	}
 }
 
-// window bounds of low_pass_real, the same in every channel (the phase advances alike in all of them): bnd[j] = first sample of output j's window,
-// j = 0 .. J (bnd[J]: where the unfinished window starts) -- one fp64 division per entry here instead of two per output and channel
-__global__ void k_cha_bounds(u64 J, int fast, int slow, u64 p0, unsigned *__restrict__ bnd)
+// de-emphasis replay with low_pass_real (rtl_fm.c:389-409) run INLINE on the filtered samples -- they never go to HBM.  The resampler's phase
+// before sample x is (p0 + x slow) mod fast and floor((p0 + x slow) / fast) outputs exist by then: a thread starts from those two numbers, owns
+// the windows that START in its chunk (the one in progress at its first sample is the left neighbour's, unless the sample in front emitted:
+// phase < slow) and walks on past its chunk to finish its last one.  The workgroup's outputs are a contiguous range: staged in LDS as int16, they
+// leave coalesced.  The thread that reaches the end of the row inside a window it owns leaves the carries (now_lpr, prev_lpr_index).
+template <bool EVEN, bool D24>
+__global__ __launch_bounds__(256) void k_cha_replay_rs(const int16_t *__restrict__ rows, u64 row_stride, u64 W, int a, unsigned magic, int bias,
+                                                       unsigned chunk, unsigned n_chunks, const uint4 *__restrict__ ctab, const int *__restrict__ seg_start,
+                                                       int fast, int slow, int ratio, float rinv, const int *__restrict__ audio_in, int *__restrict__ audio_out,
+                                                       int16_t *__restrict__ out_rows, u64 out_stride, unsigned cap)
 {
-	const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (j <= J)
-		bnd[j] = j ? (unsigned)lpr_end(j - 1, fast, slow, p0) : 0u;
-}
-
-__global__ __launch_bounds__(256) void k_cha_resample_b(const int16_t *__restrict__ y_rows, u64 y_stride, u64 W, int ratio, u64 J, const unsigned *__restrict__ bnd,
-                                                        const int *__restrict__ audio_in, int *__restrict__ audio_out, int16_t *__restrict__ rows, u64 row_stride,
-                                                        int slow, int fast)
-{
+	extern __shared__ __attribute__((aligned(16))) int16_t cha_out[];      // [cap] the workgroup's outputs
+	__shared__ uint4 tab[256];
+	__shared__ int start[256];
+	const unsigned tid = threadIdx.x, g = blockIdx.x * 256u + tid;
 	const u64 c = blockIdx.y;
-	const int16_t *yrow = y_rows + c * y_stride;
-	const u64 j = (u64)blockIdx.x * 256u + threadIdx.x;
-	if (j < J) {
-		const unsigned wb = bnd[j], we = bnd[j + 1];
-		int sum = j ? 0 : audio_in[3 * c + 1];
-		for (unsigned i = wb; i < we; i++)
-			sum += yrow[i];
-		rows[c * row_stride + j] = (int16_t)(sum / ratio);
-	}
-	if (blockIdx.x == 0 && threadIdx.x == 0) {
-		int sum = J ? 0 : audio_in[3 * c + 1];
-		for (u64 i = bnd[J]; i < W; i++)
-			sum += yrow[i];
-		audio_out[3 * c + 1] = sum;
-		audio_out[3 * c + 2] = (int)((u64)audio_in[3 * c + 2] + W * (u64)slow - J * (u64)fast);
-	}
-}
-
-__global__ __launch_bounds__(256) void k_cha_resample(const int16_t *__restrict__ y_rows, u64 y_stride, u64 W, int fast, int slow, u64 J,
-                                                      const int *__restrict__ audio_in, int *__restrict__ audio_out, int16_t *__restrict__ rows, u64 row_stride)
-{
-	const u64 c = blockIdx.y;
-	const int16_t *yrow = y_rows + c * y_stride;
+	const int16_t *row = rows + c * row_stride;
+	const bool vec = ((size_t)row & 15u) == 0;
+	const unsigned active = min(256u, n_chunks - blockIdx.x * 256u);
+	int v = cha_chunk_start(tab, start, ctab, seg_start, c, n_chunks, active);
 	const u64 p0 = (u64)audio_in[3 * c + 2];
-	const int ratio = fast / slow;
-	const u64 j = (u64)blockIdx.x * 256u + threadIdx.x;
-	if (j < J) {
-		const u64 wb = j ? lpr_end(j - 1, fast, slow, p0) : 0, we = lpr_end(j, fast, slow, p0);
-		int sum = j ? 0 : audio_in[3 * c + 1];
-		for (u64 i = wb; i < we; i++)
-			sum += yrow[i];
-		rows[c * row_stride + j] = (int16_t)(sum / ratio);
+	// first output of the workgroup: windows that started before its first sample b_wg: the emissions so far, + 1 unless the sample in front emitted
+	const u64 b_wg = (u64)blockIdx.x * 256u * chunk, e_wg = min(W, b_wg + 256ull * chunk);
+	const u64 t_wg = p0 + b_wg * (u64)slow, t_we = p0 + e_wg * (u64)slow;
+	const u64 J0 = b_wg ? t_wg / (u64)fast + ((t_wg % (u64)fast) < (u64)slow ? 0u : 1u) : 0u;
+	const u64 J1 = e_wg < W ? t_we / (u64)fast + ((t_we % (u64)fast) < (u64)slow ? 0u : 1u) : t_we / (u64)fast;   // the row's last window stays unfinished
+	if (tid < active) {
+		const int h = a / 2, xoff = h + bias * a;
+		const u64 b = (u64)g * chunk, e = min(W, b + chunk);
+		const u64 t_b = p0 + b * (u64)slow;
+		unsigned j = (unsigned)(t_b / (u64)fast - J0);                   // index (in the staging) of the window in progress at b ...
+		int p = (int)(t_b % (u64)fast);                                 // ... and the phase in front of sample b
+		bool own = g == 0 || p < slow;
+		int sum = g == 0 ? audio_in[3 * c + 1] : 0;
+		bool first = g == 0;                                            // the carried partial sum may be anything: exact division for output 0
+		u64 i = b;
+		// one sample: de-emphasis, accumulate, phase; an emission stores (int16)(sum / ratio) -- C's truncating division, by the reciprocal rounded
+		// up where that is exact (ratio <= 32, |sum| <= 33 * 32768: every window but one that starts with the carried sum)
+#define CHA_RS_STEP(X) do { \
+			const int x_ = (X); \
+			v = deemph_step_d<EVEN, D24>(v, x_ + xoff, x_, magic, bias); \
+			sum += v; p += slow; \
+			if (p >= fast) { \
+				p -= fast; \
+				if (own) cha_out[j] = (int16_t)((first || rinv == 0.0f) ? sum / ratio : (int)((float)sum * rinv)); \
+				j++; sum = 0; own = true; first = false; \
+			} } while (0)
+		if (vec && i + 64 <= e) {
+			cha_line cur = cha_load(&row[i]);
+			for (; i + 64 <= e; i += 64) {
+				const cha_line nxt = cha_load(&row[i + 128 <= e ? i + 64 : i]);
+#pragma unroll
+				for (int q = 0; q < 64; q++)
+					CHA_RS_STEP(cha_sample(cur, q));
+				cur = nxt;
+			}
+		}
+		for (; i < e; i++)
+			CHA_RS_STEP((int)row[i]);
+		// past the chunk: the window in progress is this thread's to finish (a sample whose predecessor emitted starts the neighbour's)
+		for (; i < W && p >= slow; i++)
+			CHA_RS_STEP((int)row[i]);
+#undef CHA_RS_STEP
+		if (i == W && own) {
+			audio_out[3 * c + 1] = sum;
+			audio_out[3 * c + 2] = p;
+		}
 	}
-	if (blockIdx.x == 0 && threadIdx.x == 0) {
-		const u64 wb = J ? lpr_end(J - 1, fast, slow, p0) : 0;
-		int sum = J ? 0 : audio_in[3 * c + 1];
-		for (u64 i = wb; i < W; i++)
-			sum += yrow[i];
-		audio_out[3 * c + 1] = sum;
-		audio_out[3 * c + 2] = (int)(p0 + W * (u64)slow - J * (u64)fast);
-	}
-}
-
-__global__ void k_cha_carry_copy(const int *__restrict__ audio_in, int *__restrict__ audio_out, int n_channels)
-{
-	const int c = blockIdx.x * blockDim.x + threadIdx.x;
-	if (c < n_channels) {
-		audio_out[3 * c + 1] = audio_in[3 * c + 1];
-		audio_out[3 * c + 2] = audio_in[3 * c + 2];
-	}
+	__syncthreads();
+	const unsigned cnt = (unsigned)(J1 - J0);
+	int16_t *dst = out_rows + c * out_stride + J0;
+	for (unsigned k = tid; k < cnt && k < cap; k += 256)
+		dst[k] = cha_out[k];
 }
 
 // ------------------------------------------------------------------ launchers
@@ -4818,38 +4840,54 @@ extern "C" unsigned rxk_ch_audio_chunks(u64 W, int warm, unsigned *chunk_out)
 	return (n < 64 || chunk > 4096) ? 0u : (unsigned)n;
 }
 
-// deemph on, !serial, rows long enough: the (segment, channel) grid.  ctab: n_channels * n_chunks tables; seg_start: n_channels * CHA_MAX_SEG ints.
-extern "C" int rxk_ch_audio_seg(void *stream, int16_t *rows, u64 row_stride, u64 W, int n_channels, int a, int warm, int fast, int slow, u64 J,
-                                const int *audio_in, int *audio_out, int16_t *y_rows, u64 y_stride, void *ctab_v, int *seg_start, unsigned *bnd, int p0)
+// LDS int16 slots a workgroup of k_cha_replay_rs stages its outputs in (256 chunks' worth + the window finished for a neighbour + rounding);
+// 0: the fused form does not fit (the caller keeps k_ch_audio)
+static unsigned cha_rs_cap(unsigned chunk, int fast, int slow)
+{
+	const u64 cap = (256ull * chunk * (u64)slow) / (u64)fast + 4;
+	return cap * 2 <= 40960 ? (unsigned)cap : 0u;
+}
+
+// can the (segment, channel) form serve rows of W samples (deemph on, a in 2..64, carried states inside int16)?  It reads the demodulated rows
+// from one buffer and writes the audio to another.
+extern "C" int rxk_ch_audio_seg_ok(u64 W, int warm, int fast, int slow)
+{
+	unsigned chunk = 0;
+	if (!rxk_ch_audio_chunks(W, warm, &chunk) || W >= 0x7fffffffull)
+		return 0;
+	return slow > 0 ? (cha_rs_cap(chunk, fast, slow) != 0 && fast / slow >= 1 && fast / slow <= 32) : 1;      /* windows shorter than any chunk */
+}
+
+// ctab: n_channels * n_chunks tables; seg_start: n_channels * CHA_MAX_SEG ints.  in_rows != out_rows.
+extern "C" int rxk_ch_audio_seg(void *stream, const int16_t *in_rows, u64 in_stride, int16_t *out_rows, u64 out_stride, u64 W, int n_channels, int a,
+                                int warm, int fast, int slow, const int *audio_in, int *audio_out, void *ctab_v, int *seg_start)
 {
 	uint4 *ctab = (uint4 *)ctab_v;
 	unsigned chunk = 0;
 	const unsigned n_chunks = rxk_ch_audio_chunks(W, warm, &chunk);
-	if (!n_chunks)
+	if (!n_chunks || !rxk_ch_audio_seg_ok(W, warm, fast, slow) || (const int16_t *)out_rows == in_rows)
 		return (int)hipErrorInvalidValue;
 	hipStream_t s = (hipStream_t)stream;
 	const unsigned mg = deemph_magic(a);
 	const int bias = bias_for(a);
 	const unsigned n_seg = (n_chunks + 255) / 256;
-	int16_t *y = slow > 0 ? y_rows : rows;
-	const u64 ys = slow > 0 ? y_stride : row_stride;
 	const dim3 grid(n_seg, (unsigned)n_channels);
+	const int ratio = slow > 0 ? fast / slow : 1;
+	// the reciprocal rounded UP: (int)((float)sum * rinv) is C's truncating sum / ratio for |sum| <= 34 * 32768, ratio <= 32 (rxk_fm_deemph_apply_rs_t)
+	const float rinv = (slow > 0 && ratio <= 32) ? __builtin_nextafterf((float)(1.0 / (double)ratio), __builtin_inff()) : 0.0f;
+	const unsigned cap = slow > 0 ? cha_rs_cap(chunk, fast, slow) : 0u;
 #define GO(EV, D) do { \
-		hipLaunchKernelGGL((k_cha_track<EV, D>), grid, dim3(256), 0, s, rows, row_stride, W, a, mg, bias, warm, chunk, n_chunks, audio_in, ctab); \
+		hipLaunchKernelGGL((k_cha_track<EV, D>), grid, dim3(256), 0, s, in_rows, in_stride, W, a, mg, bias, warm, chunk, n_chunks, audio_in, ctab); \
 		hipLaunchKernelGGL(k_cha_walk, dim3((unsigned)n_channels), dim3(64 * n_seg), (size_t)n_chunks * 16, s, ctab, n_chunks, audio_in, audio_out, seg_start); \
-		hipLaunchKernelGGL((k_cha_replay<EV, D>), grid, dim3(256), 0, s, rows, row_stride, W, a, mg, bias, chunk, n_chunks, ctab, seg_start, y, ys); } while (0)
+		if (slow > 0) \
+			hipLaunchKernelGGL((k_cha_replay_rs<EV, D>), grid, dim3(256), (size_t)cap * 2, s, in_rows, in_stride, W, a, mg, bias, chunk, n_chunks, ctab, seg_start, \
+			                   fast, slow, ratio, rinv, audio_in, audio_out, out_rows, out_stride, cap); \
+		else \
+			hipLaunchKernelGGL((k_cha_replay<EV, D>), grid, dim3(256), 0, s, in_rows, in_stride, W, a, mg, bias, chunk, n_chunks, ctab, seg_start, \
+			                   audio_in, audio_out, out_rows, out_stride); } while (0)
 	if (deemph_d24(a)) { if (a & 1) GO(false, true); else GO(true, true); }
 	else { if (a & 1) GO(false, false); else GO(true, false); }
 #undef GO
-	if (slow > 0 && bnd && W < 0xffffffffull) {
-		hipLaunchKernelGGL(k_cha_bounds, dim3((unsigned)((J + 256) / 256)), dim3(256), 0, s, J, fast, slow, (u64)p0, bnd);
-		hipLaunchKernelGGL(k_cha_resample_b, dim3((unsigned)((J + 255) / 256) ? (unsigned)((J + 255) / 256) : 1u, (unsigned)n_channels), dim3(256), 0, s,
-		                   y_rows, y_stride, W, fast / slow, J, bnd, audio_in, audio_out, rows, row_stride, slow, fast);
-	} else if (slow > 0)
-		hipLaunchKernelGGL(k_cha_resample, dim3((unsigned)((J + 255) / 256) ? (unsigned)((J + 255) / 256) : 1u, (unsigned)n_channels), dim3(256), 0, s,
-		                   y_rows, y_stride, W, fast, slow, J, audio_in, audio_out, rows, row_stride);
-	else
-		hipLaunchKernelGGL(k_cha_carry_copy, dim3((unsigned)(n_channels + 255) / 256), dim3(256), 0, s, audio_in, audio_out, n_channels);
 	LAUNCH_RET();
 }
 

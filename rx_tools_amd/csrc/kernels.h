@@ -254,13 +254,14 @@ int rxk_ch_demod(void *stream, const uint32_t *chan_lp, unsigned long long total
 /* per-channel deemph_filter + low_pass_real on the channeliser's [channel][window] output (one workgroup per channel);
  * audio_in/out: {avg, now_lpr, prev_lpr_index} per channel; y_rows: scratch rows when slow > 0.  warm: samples that bring any two
  * int16 start states within 64 of each other (host: deemph_warm); serial != 0: one thread per channel does the recursion */
-/* the same stages on a (segment, channel) grid (deemph on, a in 2..64, carried states inside int16): rxk_ch_audio_chunks gives the number of
- * chunk tables per channel (0: the row is too short, rxk_ch_audio serves it); ctab: n_channels * that many 16-byte tables, seg_start:
- * n_channels * 8 ints */
+/* the same stages on a (segment, channel) grid (deemph on, a in 2..64, carried states inside int16), reading the demodulated rows from one buffer
+ * and writing the audio to another: rxk_ch_audio_seg_ok says whether rows of W samples can go that way (else rxk_ch_audio serves them in place);
+ * rxk_ch_audio_chunks: chunk tables per channel.  ctab: n_channels * that many 16-byte tables, seg_start: n_channels * 8 ints */
 unsigned rxk_ch_audio_chunks(unsigned long long W, int warm, unsigned *chunk_out);
-int rxk_ch_audio_seg(void *stream, int16_t *rows, unsigned long long row_stride, unsigned long long W, int n_channels, int a, int warm,
-                     int fast, int slow, unsigned long long J, const int *audio_in, int *audio_out, int16_t *y_rows, unsigned long long y_stride,
-                     void *ctab, int *seg_start, unsigned *bnd, int p0);   /* bnd: J + 1 window bounds (NULL: closed form per output), p0: the common phase */
+int rxk_ch_audio_seg_ok(unsigned long long W, int warm, int fast, int slow);
+int rxk_ch_audio_seg(void *stream, const int16_t *in_rows, unsigned long long in_stride, int16_t *out_rows, unsigned long long out_stride,
+                     unsigned long long W, int n_channels, int a, int warm, int fast, int slow, const int *audio_in, int *audio_out,
+                     void *ctab, int *seg_start);
 int rxk_ch_audio(void *stream, int16_t *rows, unsigned long long row_stride, unsigned long long W, int n_channels, int deemph, int a,
                  int warm, int serial, int fast, int slow, unsigned long long J, const int *audio_in, int *audio_out,
                  int16_t *y_rows, unsigned long long y_stride);

@@ -20,10 +20,9 @@ struct rxgpu_chan {
 	int *pre_dev[2];                 /* carried (pre_r, pre_j) per channel: in / out */
 	int *pre_host;
 	int *audio_dev[2], *audio_host;  /* per channel {deemph avg, now_lpr, prev_lpr_index}: in / out */
-	int16_t *audio_y;                /* [n_channels][max_windows]: the de-emphasised samples in front of the resampler */
+	int16_t *audio_y;                /* [n_channels][max_windows]: the de-emphasised samples in front of the resampler (k_ch_audio), or the demodulated rows (segmented form) */
 	void *audio_ctab;                /* the (segment, channel) form of the audio stages: chunk tables [n_channels][chunks] ... */
 	int *audio_seg;                  /* ... and every segment's start state [n_channels][8] */
-	unsigned *audio_bnd;             /* low_pass_real's window bounds, the same in every channel: max_windows + 2 entries */
 	int audio_seg_on;                /* $RXGPU_CH_AUDIO_SEG != 0 at creation */
 	rxk_fm_dev *dev, *dev_host;
 	unsigned long long *flag_list, *flag_host;
@@ -77,8 +76,7 @@ int rxgpu_chan_create(rxgpu_chan **out, const rxgpu_chan_params *p, size_t max_b
 	    hipMalloc((void **)&s->pre_dev[0], nc * 8) != hipSuccess || hipMalloc((void **)&s->pre_dev[1], nc * 8) != hipSuccess ||
 	    hipMalloc((void **)&s->audio_dev[0], nc * 12) != hipSuccess || hipMalloc((void **)&s->audio_dev[1], nc * 12) != hipSuccess ||
 	    hipHostMalloc((void **)&s->audio_host, nc * 12, 0) != hipSuccess ||
-	    (p->rate_out2 > 0 && hipMalloc((void **)&s->audio_y, nc * s->max_windows * 2) != hipSuccess) ||
-	    (p->deemph && p->rate_out2 > 0 && hipMalloc((void **)&s->audio_bnd, (s->max_windows + 2) * 4) != hipSuccess) ||
+	    ((p->rate_out2 > 0 || p->deemph) && hipMalloc((void **)&s->audio_y, nc * s->max_windows * 2) != hipSuccess) ||
 	    (p->deemph && (hipMalloc(&s->audio_ctab, nc * ctab_per_channel * 16) != hipSuccess || hipMalloc((void **)&s->audio_seg, nc * 8 * 4) != hipSuccess)) ||
 	    hipMalloc((void **)&s->dev, sizeof(rxk_fm_dev)) != hipSuccess ||
 	    hipMalloc((void **)&s->flag_list, RXK_FLAG_CAP * 8) != hipSuccess ||
@@ -120,7 +118,7 @@ void rxgpu_chan_destroy(rxgpu_chan *s)
 	if (!s)
 		return;
 	hipFree(s->twiddle_dev); hipFree(s->nco_tw_dev); hipFree(s->chan_lp); hipFree(s->pre_dev[0]); hipFree(s->pre_dev[1]);
-	hipFree(s->audio_dev[0]); hipFree(s->audio_dev[1]); hipFree(s->audio_y); hipFree(s->audio_ctab); hipFree(s->audio_seg); hipFree(s->audio_bnd);
+	hipFree(s->audio_dev[0]); hipFree(s->audio_dev[1]); hipFree(s->audio_y); hipFree(s->audio_ctab); hipFree(s->audio_seg);
 	if (s->audio_host) hipHostFree(s->audio_host);
 	hipFree(s->dev); hipFree(s->flag_list);
 	if (s->dev_host) hipHostFree(s->dev_host);
@@ -199,6 +197,18 @@ int rxgpu_chan_run(rxgpu_chan *s, const int16_t *d_iq, size_t n_blocks, size_t b
 	if (out_stride < total)
 		return rxgpu_fail(RXGPU_ECAPACITY, "out_stride %zu shorter than %llu windows", out_stride, total);
 	const size_t nc = (size_t)s->p.n_channels;
+	/* per-channel audio stages: which form serves this run is known before anything is launched -- the (segment, channel) grid reads the
+	 * demodulated rows from a buffer of its own (audio_y) and writes the audio to d_out, k_ch_audio works on d_out in place */
+	const int audio_on = s->p.deemph || s->p.rate_out2 > 0;
+	int serial = s->p.deemph && (s->p.deemph_a < 2 || s->p.deemph_a > 64);
+	for (size_t c = 0; c < nc && s->p.deemph && !serial; c++)
+		if (s->audio_host[3 * c] < -32768 || s->audio_host[3 * c] > 32767)
+			serial = 1;
+	const int warm = s->p.deemph && !serial ? rxgpu_deemph_warm64(s->p.deemph_a) : 8;
+	const int seg = audio_on && s->p.deemph && !serial && s->audio_seg_on && s->audio_y &&
+	                rxk_ch_audio_seg_ok(total, warm, s->p.rate_out, s->p.rate_out2 > 0 ? s->p.rate_out2 : 0);
+	int16_t *const rows = seg ? s->audio_y : d_out;                 /* where the demodulated samples go */
+	const size_t rstride = seg ? s->max_windows : out_stride;
 	rxk_fm_dev *h = s->dev_host;
 	memset(h, 0, sizeof(*h));
 	RX_HIP(hipMemcpyAsync(s->dev, h, sizeof(*h), hipMemcpyHostToDevice, st));
@@ -209,11 +219,11 @@ int rxgpu_chan_run(rxgpu_chan *s, const int16_t *d_iq, size_t n_blocks, size_t b
 	if (s->p.nco)                                         /* SURVEY 8(f)2's literal definition: NCO -> low_pass at downsample N, per channel */
 		RX_K(rxk_ch_nco(st, d_iq, total, s->p.bin_e, s->nco_tw_dev, s->p.first_bin, s->p.n_channels, s->chan_lp));
 	else
-		RX_K(rxk_ch_fft(st, d_iq, total, s->p.bin_e, s->twiddle_dev, s->p.first_bin, s->p.n_channels, s->chan_lp, fused, d_out, out_stride,
+		RX_K(rxk_ch_fft(st, d_iq, total, s->p.bin_e, s->twiddle_dev, s->p.first_bin, s->p.n_channels, s->chan_lp, fused, rows, rstride,
 		                s->pre_dev[1]));
 	rxgpu_prof_end("ch_fft");
 	rxgpu_prof_begin("ch_demod");
-	RX_K(rxk_ch_demod(st, s->chan_lp, total, wpb, s->p.n_channels, s->p.custom_atan, s->pre_dev[0], s->pre_dev[1], d_out, out_stride,
+	RX_K(rxk_ch_demod(st, s->chan_lp, total, wpb, s->p.n_channels, s->p.custom_atan, s->pre_dev[0], s->pre_dev[1], rows, rstride,
 	                  s->dev, s->flag_list, fused));
 	rxgpu_prof_end("ch_demod");
 	RX_HIP(hipMemcpyAsync(h, s->dev, sizeof(*h), hipMemcpyDeviceToHost, st));
@@ -250,15 +260,14 @@ int rxgpu_chan_run(rxgpu_chan *s, const int16_t *d_iq, size_t n_blocks, size_t b
 				br = pre_in_copy[2 * c]; bj = pre_in_copy[2 * c + 1];
 			}
 			int16_t v = (int16_t)disc_host((int16_t)(a & 0xffff), (int16_t)(a >> 16), br, bj);
-			RX_HIP(hipMemcpy(d_out + c * out_stride + t, &v, 2, hipMemcpyHostToDevice));
+			RX_HIP(hipMemcpy(rows + c * rstride + t, &v, 2, hipMemcpyHostToDevice));
 		}
 		s->fixups = cnt;
 	}
 	free(pre_in_copy);
 	unsigned long long per_channel = total;
-	if (s->p.deemph || s->p.rate_out2 > 0) {
+	if (audio_on) {
 		/* per-channel audio stages on the finished (and, where needed, host-corrected) demodulated rows */
-		int serial = s->p.deemph && (s->p.deemph_a < 2 || s->p.deemph_a > 64);
 		unsigned long long J = total;
 		if (s->p.rate_out2 > 0) {
 			const int p0 = s->audio_host[2];                  /* the phase advances alike in every channel */
@@ -267,17 +276,12 @@ int rxgpu_chan_run(rxgpu_chan *s, const int16_t *d_iq, size_t n_blocks, size_t b
 					return rxgpu_fail(RXGPU_EINVAL, "prev_lpr_index must be the same in [0, rate_out) for every channel");
 			J = ((unsigned long long)p0 + total * (unsigned long long)s->p.rate_out2) / (unsigned long long)s->p.rate_out;
 		}
-		for (size_t c = 0; c < nc && !serial; c++)
-			if (s->audio_host[3 * c] < -32768 || s->audio_host[3 * c] > 32767)
-				serial = 1;
 		RX_HIP(hipMemcpyAsync(s->audio_dev[0], s->audio_host, nc * 12, hipMemcpyHostToDevice, st));
-		const int warm = s->p.deemph && !serial ? rxgpu_deemph_warm64(s->p.deemph_a) : 8;
 		rxgpu_prof_begin("ch_audio");
-		if (s->p.deemph && !serial && s->audio_seg_on && rxk_ch_audio_chunks(total, warm, NULL))
-			/* rows long enough to cut into segments: chunk tables per (segment, channel), composed in a second level */
-			RX_K(rxk_ch_audio_seg(st, d_out, out_stride, total, s->p.n_channels, s->p.deemph_a, warm, s->p.rate_out, s->p.rate_out2 > 0 ? s->p.rate_out2 : 0, J,
-			                      s->audio_dev[0], s->audio_dev[1], s->audio_y, s->max_windows, s->audio_ctab, s->audio_seg, s->audio_bnd,
-			                      s->p.rate_out2 > 0 ? s->audio_host[2] : 0));
+		if (seg)
+			/* rows long enough to cut into segments: chunk tables per (segment, channel), composed in a second level; low_pass_real inline */
+			RX_K(rxk_ch_audio_seg(st, rows, rstride, d_out, out_stride, total, s->p.n_channels, s->p.deemph_a, warm, s->p.rate_out,
+			                      s->p.rate_out2 > 0 ? s->p.rate_out2 : 0, s->audio_dev[0], s->audio_dev[1], s->audio_ctab, s->audio_seg));
 		else
 			RX_K(rxk_ch_audio(st, d_out, out_stride, total, s->p.n_channels, s->p.deemph, s->p.deemph_a, warm, serial, s->p.rate_out,
 			                  s->p.rate_out2 > 0 ? s->p.rate_out2 : 0, J, s->audio_dev[0], s->audio_dev[1], s->audio_y, s->max_windows));

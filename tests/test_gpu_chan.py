@@ -209,6 +209,8 @@ def test_channeliser_per_channel_audio_stages(bin_e, n_channels, block_len, n_bl
     (4, 9, 2 * 65536, 10, 2, 19531, -1, 1, 0),            # even a, de-emphasis only (in place), 8 segments
     (4, 9, 2 * 65536, 6, 64, 24000, 12000, 1, 5),         # a at the top of the mask range; rows that start off any 16-byte boundary
     (5, 20, 2 * 131072, 8, 19, 240000, 32000, 1, 0),      # 16384-sample rows, a = 19
+    (4, 6, 2 * 64, 802, 2, 19531, 8000, 1, 0),            # 1604-sample rows of a scratch whose odd rows sit off the 16-byte grid: the sample-by-sample loops
+    (4, 6, 2 * 65536, 6, 7, 48000, 32000, 1, 3),          # ratio 1 (two outputs per three samples): the most outputs a workgroup can stage
 ])
 def test_channeliser_audio_stages_segmented(bin_e, n_channels, block_len, n_blocks, a, rate_out, rate_out2, custom_atan, pad, monkeypatch):
     """the (segment, channel) form of the per-channel audio stages == the oracle (and the reference where built), across a run boundary,
