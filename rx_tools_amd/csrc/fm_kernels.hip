@@ -3661,9 +3661,9 @@ __global__ __launch_bounds__(256) void k_ch_audio(
 //   k_cha_track   grid (segments, channels): per thread one chunk -- warm-up on the two extreme trajectories (chunk 0: the carried state),
 //                 lowest candidate + merge mask through the chunk -> a 16-byte table in HBM
 //   k_cha_walk    grid (channels), one wave per segment: the lanes are the (at most 64) candidate start states of the segment's first chunk,
-//                 each walks the segment's tables; then one thread chains the segments from the carried state -> every segment's exact start
-//   k_cha_replay  grid (segments, channels): thread 0 walks the workgroup's 256 tables from the segment start (LDS), every thread replays its
-//                 chunk from its exact start -> the de-emphasised row (another buffer than the demodulated one)
+//                 each walks the segment's tables; one thread chains the segments from the carried state; one lane per segment then walks it
+//                 again from its exact start -> every chunk's start state
+//   k_cha_replay  grid (segments, channels): every thread replays its chunk from its exact start -> the de-emphasised row (another buffer than the demodulated one)
 //                 and, with a resampler behind, runs low_pass_real inline on the filtered samples (k_cha_replay_rs): they never go to HBM
 #define CHA_MAX_SEG 8
 
@@ -3745,7 +3745,7 @@ __global__ __launch_bounds__(256) void k_cha_track(const int16_t *__restrict__ r
 }
 
 __global__ __launch_bounds__(64 * CHA_MAX_SEG) void k_cha_walk(const uint4 *__restrict__ ctab, unsigned n_chunks, const int *__restrict__ audio_in,
-                                                                int *__restrict__ audio_out, int *__restrict__ seg_start)
+                                                                int *__restrict__ audio_out, int *__restrict__ chunk_start)
 {
 	extern __shared__ __attribute__((aligned(16))) uint4 cha_tab[];      // the channel's n_chunks tables
 	__shared__ int seg_end[CHA_MAX_SEG][64];
@@ -3765,10 +3765,11 @@ __global__ __launch_bounds__(64 * CHA_MAX_SEG) void k_cha_walk(const uint4 *__re
 		seg_end[sgm][k] = v;
 	}
 	__syncthreads();
+	__shared__ int seg_first[CHA_MAX_SEG];
 	if (threadIdx.x == 0) {
 		int v = audio_in[3 * c];
 		for (unsigned sg = 0; sg < n_seg; sg++) {
-			seg_start[c * CHA_MAX_SEG + sg] = v;
+			seg_first[sg] = v;
 			const uint4 t0 = cha_tab[sg * 256u];
 			int idx = v - (int)t0.x;
 			const int gap = (int)(t0.y >> 16);
@@ -3777,42 +3778,32 @@ __global__ __launch_bounds__(64 * CHA_MAX_SEG) void k_cha_walk(const uint4 *__re
 		}
 		audio_out[3 * c] = v;
 	}
-}
-
-// shared front of the two replay kernels: the workgroup's 256 tables into LDS, thread 0 walks them from the segment's start state
-__device__ __forceinline__ int cha_chunk_start(uint4 *tab, int *start, const uint4 *__restrict__ ctab, const int *__restrict__ seg_start, u64 c,
-                                               unsigned n_chunks, unsigned active)
-{
-	const unsigned tid = threadIdx.x;
-	if (tid < active)
-		tab[tid] = ctab[c * n_chunks + blockIdx.x * 256u + tid];
 	__syncthreads();
-	if (tid == 0) {
-		int v = seg_start[c * CHA_MAX_SEG + blockIdx.x];
-		for (unsigned t = 0; t < active; t++) {
-			start[t] = v;
-			v = ctab_apply(tab[t], v);
+	// every chunk's exact start state, one lane per segment: the replay kernels begin without a serial walk of their own (a workgroup's thread 0
+	// walking 256 tables held its other 255 threads for ten microseconds, four rounds of workgroups per CU)
+	if (sgm < n_seg && k == 0) {
+		const unsigned g0 = sgm * 256u, g1 = min(n_chunks, g0 + 256u);
+		int v = seg_first[sgm];
+		for (unsigned g = g0; g < g1; g++) {
+			chunk_start[c * n_chunks + g] = v;
+			v = ctab_apply(cha_tab[g], v);
 		}
 	}
-	__syncthreads();
-	return tid < active ? start[tid] : 0;
 }
 
 // de-emphasis only: every thread replays its chunk from its exact start, in -> out (two buffers: the demodulated rows stay as they are)
 template <bool EVEN, bool D24>
 __global__ __launch_bounds__(256) void k_cha_replay(const int16_t *__restrict__ rows, u64 row_stride, u64 W, int a, unsigned magic, int bias,
-                                                    unsigned chunk, unsigned n_chunks, const uint4 *__restrict__ ctab, const int *__restrict__ seg_start,
+                                                    unsigned chunk, unsigned n_chunks, const int *__restrict__ chunk_start,
                                                     const int *__restrict__ audio_in, int *__restrict__ audio_out, int16_t *__restrict__ y_rows, u64 y_stride)
 {
-	__shared__ uint4 tab[256];
-	__shared__ int start[256];
 	const unsigned tid = threadIdx.x, g = blockIdx.x * 256u + tid;
 	const u64 c = blockIdx.y;
 	const int16_t *row = rows + c * row_stride;
 	int16_t *yrow = y_rows + c * y_stride;
 	const bool vec = (((size_t)row | (size_t)yrow) & 15u) == 0;
 	const unsigned active = min(256u, n_chunks - blockIdx.x * 256u);
-	int v = cha_chunk_start(tab, start, ctab, seg_start, c, n_chunks, active);
+	int v = tid < active ? chunk_start[c * n_chunks + g] : 0;
 	if (g == 0) {                                                 // the resampler's carries pass through
 		audio_out[3 * c + 1] = audio_in[3 * c + 1];
 		audio_out[3 * c + 2] = audio_in[3 * c + 2];
@@ -3826,19 +3817,18 @@ __global__ __launch_bounds__(256) void k_cha_replay(const int16_t *__restrict__ 
 		cha_line cur = cha_load(&row[i]);
 		for (; i + 64 <= e; i += 64) {
 			const cha_line nxt = cha_load(&row[i + 128 <= e ? i + 64 : i]);
+			uint32_t yy[32];                                          // the whole 128-byte line first, then its eight stores back to back
 #pragma unroll
-			for (int k = 0; k < 8; k++) {
-				uint32_t yy[4];
-#pragma unroll
-				for (int q = 0; q < 4; q++) {
-					const int x0 = cha_sample(cur, 8 * k + 2 * q), x1 = cha_sample(cur, 8 * k + 2 * q + 1);
-					v = deemph_step_d<EVEN, D24>(v, x0 + xoff, x0, magic, bias);
-					const int y0 = v;
-					v = deemph_step_d<EVEN, D24>(v, x1 + xoff, x1, magic, bias);
-					yy[q] = pack_iq(y0, v);
-				}
-				reinterpret_cast<uint4 *>(&yrow[i])[k] = make_uint4(yy[0], yy[1], yy[2], yy[3]);
+			for (int q = 0; q < 32; q++) {
+				const int x0 = cha_sample(cur, 2 * q), x1 = cha_sample(cur, 2 * q + 1);
+				v = deemph_step_d<EVEN, D24>(v, x0 + xoff, x0, magic, bias);
+				const int y0 = v;
+				v = deemph_step_d<EVEN, D24>(v, x1 + xoff, x1, magic, bias);
+				yy[q] = pack_iq(y0, v);
 			}
+#pragma unroll
+			for (int k = 0; k < 8; k++)
+				reinterpret_cast<uint4 *>(&yrow[i])[k] = make_uint4(yy[4 * k], yy[4 * k + 1], yy[4 * k + 2], yy[4 * k + 3]);
 			cur = nxt;
 		}
 	}
@@ -3856,19 +3846,17 @@ __global__ __launch_bounds__(256) void k_cha_replay(const int16_t *__restrict__ 
 // leave coalesced.  The thread that reaches the end of the row inside a window it owns leaves the carries (now_lpr, prev_lpr_index).
 template <bool EVEN, bool D24>
 __global__ __launch_bounds__(256) void k_cha_replay_rs(const int16_t *__restrict__ rows, u64 row_stride, u64 W, int a, unsigned magic, int bias,
-                                                       unsigned chunk, unsigned n_chunks, const uint4 *__restrict__ ctab, const int *__restrict__ seg_start,
+                                                       unsigned chunk, unsigned n_chunks, const int *__restrict__ chunk_start,
                                                        int fast, int slow, int ratio, float rinv, const int *__restrict__ audio_in, int *__restrict__ audio_out,
                                                        int16_t *__restrict__ out_rows, u64 out_stride, unsigned cap)
 {
 	extern __shared__ __attribute__((aligned(16))) int16_t cha_out[];      // [cap] the workgroup's outputs
-	__shared__ uint4 tab[256];
-	__shared__ int start[256];
 	const unsigned tid = threadIdx.x, g = blockIdx.x * 256u + tid;
 	const u64 c = blockIdx.y;
 	const int16_t *row = rows + c * row_stride;
 	const bool vec = ((size_t)row & 15u) == 0;
 	const unsigned active = min(256u, n_chunks - blockIdx.x * 256u);
-	int v = cha_chunk_start(tab, start, ctab, seg_start, c, n_chunks, active);
+	int v = tid < active ? chunk_start[c * n_chunks + g] : 0;
 	const u64 p0 = (u64)audio_in[3 * c + 2];
 	// first output of the workgroup: windows that started before its first sample b_wg: the emissions so far, + 1 unless the sample in front emitted
 	const u64 b_wg = (u64)blockIdx.x * 256u * chunk, e_wg = min(W, b_wg + 256ull * chunk);
@@ -4858,7 +4846,7 @@ extern "C" int rxk_ch_audio_seg_ok(u64 W, int warm, int fast, int slow)
 	return slow > 0 ? (cha_rs_cap(chunk, fast, slow) != 0 && fast / slow >= 1 && fast / slow <= 32) : 1;      /* windows shorter than any chunk */
 }
 
-// ctab: n_channels * n_chunks tables; seg_start: n_channels * CHA_MAX_SEG ints.  in_rows != out_rows.
+// ctab: n_channels * n_chunks tables; seg_start: n_channels * n_chunks ints (every chunk's start state).  in_rows != out_rows.
 extern "C" int rxk_ch_audio_seg(void *stream, const int16_t *in_rows, u64 in_stride, int16_t *out_rows, u64 out_stride, u64 W, int n_channels, int a,
                                 int warm, int fast, int slow, const int *audio_in, int *audio_out, void *ctab_v, int *seg_start)
 {
@@ -4880,10 +4868,10 @@ extern "C" int rxk_ch_audio_seg(void *stream, const int16_t *in_rows, u64 in_str
 		hipLaunchKernelGGL((k_cha_track<EV, D>), grid, dim3(256), 0, s, in_rows, in_stride, W, a, mg, bias, warm, chunk, n_chunks, audio_in, ctab); \
 		hipLaunchKernelGGL(k_cha_walk, dim3((unsigned)n_channels), dim3(64 * n_seg), (size_t)n_chunks * 16, s, ctab, n_chunks, audio_in, audio_out, seg_start); \
 		if (slow > 0) \
-			hipLaunchKernelGGL((k_cha_replay_rs<EV, D>), grid, dim3(256), (size_t)cap * 2, s, in_rows, in_stride, W, a, mg, bias, chunk, n_chunks, ctab, seg_start, \
+			hipLaunchKernelGGL((k_cha_replay_rs<EV, D>), grid, dim3(256), (size_t)cap * 2, s, in_rows, in_stride, W, a, mg, bias, chunk, n_chunks, seg_start, \
 			                   fast, slow, ratio, rinv, audio_in, audio_out, out_rows, out_stride, cap); \
 		else \
-			hipLaunchKernelGGL((k_cha_replay<EV, D>), grid, dim3(256), 0, s, in_rows, in_stride, W, a, mg, bias, chunk, n_chunks, ctab, seg_start, \
+			hipLaunchKernelGGL((k_cha_replay<EV, D>), grid, dim3(256), 0, s, in_rows, in_stride, W, a, mg, bias, chunk, n_chunks, seg_start, \
 			                   audio_in, audio_out, out_rows, out_stride); } while (0)
 	if (deemph_d24(a)) { if (a & 1) GO(false, true); else GO(true, true); }
 	else { if (a & 1) GO(false, false); else GO(true, false); }

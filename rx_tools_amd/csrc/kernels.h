@@ -256,7 +256,7 @@ int rxk_ch_demod(void *stream, const uint32_t *chan_lp, unsigned long long total
  * int16 start states within 64 of each other (host: deemph_warm); serial != 0: one thread per channel does the recursion */
 /* the same stages on a (segment, channel) grid (deemph on, a in 2..64, carried states inside int16), reading the demodulated rows from one buffer
  * and writing the audio to another: rxk_ch_audio_seg_ok says whether rows of W samples can go that way (else rxk_ch_audio serves them in place);
- * rxk_ch_audio_chunks: chunk tables per channel.  ctab: n_channels * that many 16-byte tables, seg_start: n_channels * 8 ints */
+ * rxk_ch_audio_chunks: chunk tables per channel.  ctab: n_channels * that many 16-byte tables, seg_start: as many ints (every chunk's start state) */
 unsigned rxk_ch_audio_chunks(unsigned long long W, int warm, unsigned *chunk_out);
 int rxk_ch_audio_seg_ok(unsigned long long W, int warm, int fast, int slow);
 int rxk_ch_audio_seg(void *stream, const int16_t *in_rows, unsigned long long in_stride, int16_t *out_rows, unsigned long long out_stride,

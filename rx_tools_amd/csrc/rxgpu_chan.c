@@ -22,7 +22,7 @@ struct rxgpu_chan {
 	int *audio_dev[2], *audio_host;  /* per channel {deemph avg, now_lpr, prev_lpr_index}: in / out */
 	int16_t *audio_y;                /* [n_channels][max_windows]: the de-emphasised samples in front of the resampler (k_ch_audio), or the demodulated rows (segmented form) */
 	void *audio_ctab;                /* the (segment, channel) form of the audio stages: chunk tables [n_channels][chunks] ... */
-	int *audio_seg;                  /* ... and every segment's start state [n_channels][8] */
+	int *audio_seg;                  /* ... and every chunk's start state [n_channels][chunks] */
 	int audio_seg_on;                /* $RXGPU_CH_AUDIO_SEG != 0 at creation */
 	rxk_fm_dev *dev, *dev_host;
 	unsigned long long *flag_list, *flag_host;
@@ -77,7 +77,7 @@ int rxgpu_chan_create(rxgpu_chan **out, const rxgpu_chan_params *p, size_t max_b
 	    hipMalloc((void **)&s->audio_dev[0], nc * 12) != hipSuccess || hipMalloc((void **)&s->audio_dev[1], nc * 12) != hipSuccess ||
 	    hipHostMalloc((void **)&s->audio_host, nc * 12, 0) != hipSuccess ||
 	    ((p->rate_out2 > 0 || p->deemph) && hipMalloc((void **)&s->audio_y, nc * s->max_windows * 2) != hipSuccess) ||
-	    (p->deemph && (hipMalloc(&s->audio_ctab, nc * ctab_per_channel * 16) != hipSuccess || hipMalloc((void **)&s->audio_seg, nc * 8 * 4) != hipSuccess)) ||
+	    (p->deemph && (hipMalloc(&s->audio_ctab, nc * ctab_per_channel * 16) != hipSuccess || hipMalloc((void **)&s->audio_seg, nc * ctab_per_channel * 4) != hipSuccess)) ||
 	    hipMalloc((void **)&s->dev, sizeof(rxk_fm_dev)) != hipSuccess ||
 	    hipMalloc((void **)&s->flag_list, RXK_FLAG_CAP * 8) != hipSuccess ||
 	    hipHostMalloc((void **)&s->dev_host, sizeof(rxk_fm_dev), 0) != hipSuccess ||
