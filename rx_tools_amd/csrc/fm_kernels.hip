@@ -3747,7 +3747,7 @@ __global__ __launch_bounds__(256) void k_cha_track(const int16_t *__restrict__ r
 __global__ __launch_bounds__(64 * CHA_MAX_SEG) void k_cha_walk(const uint4 *__restrict__ ctab, unsigned n_chunks, const int *__restrict__ audio_in,
                                                                 int *__restrict__ audio_out, int *__restrict__ chunk_start)
 {
-	extern __shared__ __attribute__((aligned(16))) uint4 cha_tab[];      // the channel's n_chunks tables
+	extern __shared__ __attribute__((aligned(16))) uint4 cha_tab[];      // the channel's n_chunks tables, then n_chunks ints (the chunk starts)
 	__shared__ int seg_end[CHA_MAX_SEG][64];
 	const u64 c = blockIdx.x;
 	const unsigned n_seg = (n_chunks + 255) / 256;
@@ -3760,7 +3760,13 @@ __global__ __launch_bounds__(64 * CHA_MAX_SEG) void k_cha_walk(const uint4 *__re
 		const uint4 t0 = cha_tab[g0];
 		const int gap = (int)(t0.y >> 16);
 		int v = (int)t0.x + min((int)k, gap);                        // lanes beyond the candidates repeat the last one
-		for (unsigned g = g0; g < g1; g++)
+		// four tables requested ahead of the dependent chain (an LDS read's latency is most of a step otherwise)
+		unsigned g = g0;
+		for (; g + 4 <= g1; g += 4) {
+			const uint4 ta = cha_tab[g], tb = cha_tab[g + 1], tc = cha_tab[g + 2], td = cha_tab[g + 3];
+			v = ctab_apply(ta, v); v = ctab_apply(tb, v); v = ctab_apply(tc, v); v = ctab_apply(td, v);
+		}
+		for (; g < g1; g++)
 			v = ctab_apply(cha_tab[g], v);
 		seg_end[sgm][k] = v;
 	}
@@ -3781,14 +3787,26 @@ __global__ __launch_bounds__(64 * CHA_MAX_SEG) void k_cha_walk(const uint4 *__re
 	__syncthreads();
 	// every chunk's exact start state, one lane per segment: the replay kernels begin without a serial walk of their own (a workgroup's thread 0
 	// walking 256 tables held its other 255 threads for ten microseconds, four rounds of workgroups per CU)
+	int *const st = reinterpret_cast<int *>(cha_tab + n_chunks);       // [n_chunks] behind the tables: the starts leave coalesced
 	if (sgm < n_seg && k == 0) {
 		const unsigned g0 = sgm * 256u, g1 = min(n_chunks, g0 + 256u);
 		int v = seg_first[sgm];
-		for (unsigned g = g0; g < g1; g++) {
-			chunk_start[c * n_chunks + g] = v;
+		unsigned g = g0;
+		for (; g + 4 <= g1; g += 4) {
+			const uint4 ta = cha_tab[g], tb = cha_tab[g + 1], tc = cha_tab[g + 2], td = cha_tab[g + 3];
+			st[g] = v; v = ctab_apply(ta, v);
+			st[g + 1] = v; v = ctab_apply(tb, v);
+			st[g + 2] = v; v = ctab_apply(tc, v);
+			st[g + 3] = v; v = ctab_apply(td, v);
+		}
+		for (; g < g1; g++) {
+			st[g] = v;
 			v = ctab_apply(cha_tab[g], v);
 		}
 	}
+	__syncthreads();
+	for (unsigned i = threadIdx.x; i < n_chunks; i += blockDim.x)
+		chunk_start[c * n_chunks + i] = st[i];
 }
 
 // de-emphasis only: every thread replays its chunk from its exact start, in -> out (two buffers: the demodulated rows stay as they are)
@@ -4866,7 +4884,7 @@ extern "C" int rxk_ch_audio_seg(void *stream, const int16_t *in_rows, u64 in_str
 	const unsigned cap = slow > 0 ? cha_rs_cap(chunk, fast, slow) : 0u;
 #define GO(EV, D) do { \
 		hipLaunchKernelGGL((k_cha_track<EV, D>), grid, dim3(256), 0, s, in_rows, in_stride, W, a, mg, bias, warm, chunk, n_chunks, audio_in, ctab); \
-		hipLaunchKernelGGL(k_cha_walk, dim3((unsigned)n_channels), dim3(64 * n_seg), (size_t)n_chunks * 16, s, ctab, n_chunks, audio_in, audio_out, seg_start); \
+		hipLaunchKernelGGL(k_cha_walk, dim3((unsigned)n_channels), dim3(64 * n_seg), (size_t)n_chunks * 20, s, ctab, n_chunks, audio_in, audio_out, seg_start); \
 		if (slow > 0) \
 			hipLaunchKernelGGL((k_cha_replay_rs<EV, D>), grid, dim3(256), (size_t)cap * 2, s, in_rows, in_stride, W, a, mg, bias, chunk, n_chunks, seg_start, \
 			                   fast, slow, ratio, rinv, audio_in, audio_out, out_rows, out_stride, cap); \
