@@ -53,19 +53,26 @@ VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4.0
 SIMDS, CLOCK_GHZ = 256 * 4, 2.4
 
 
+def newest_profile(suffix):
+    """profiles/rNN_<suffix> of the newest round that has it (a round that skipped a profile section keeps the last one measured), or None"""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    return hits[-1] if hits else None
+
+
 def valu_ceiling(kernel_substr):
     """(G wave-instr/s the kernel's opcode mix can issue at most, source text) from the measured per-opcode rates; (nominal, None) without them"""
     issue = mix = None
-    for rnd in ("r04", "r03"):
-        try:
-            issue = json.load(open(os.path.join(ROOT, "profiles", rnd + "_valu_issue.json")))["ops"]
-            mix = json.load(open(os.path.join(ROOT, "profiles", rnd + "_kernel_mix.json")))
-            ops = next(v for k, v in mix.items() if kernel_substr in k)
-            break
-        except (OSError, ValueError, KeyError, StopIteration):
-            issue = mix = None
+    f_issue, f_mix = newest_profile("valu_issue.json"), newest_profile("kernel_mix.json")
+    try:
+        issue = json.load(open(f_issue))["ops"]
+        mix = json.load(open(f_mix))
+        ops = next(v for k, v in mix.items() if kernel_substr in k)
+    except (OSError, ValueError, KeyError, StopIteration, TypeError):
+        issue = mix = None
     if issue is None:
         return VALU_PEAK_GINSTR, None
+    rnd, mrnd = os.path.basename(f_issue)[:3], os.path.basename(f_mix)[:3]
     alias = {"v_pk_mad_u16": "pk_mad_i16", "v_dot2c_i32_i16": "dot2_i32_i16", "v_fma_f32": "pk_fma_f32x", "v_mov_b32_dpp": "mov_dpp_wshr", "v_or_b32": "and_b32",
              "v_xor_b32": "and_b32", "v_mov_b32": "and_b32", "v_lshrrev_b32": "lshlrev_b32", "v_add_co_u32": "add_u32", "v_addc_co_u32": "add_u32"}
     slow = min(v["wall_w8"] for k, v in issue.items() if k in ("mad_i32_i16", "pk_add_u16", "bfi_b32"))     # the half-rate class
@@ -77,7 +84,7 @@ def valu_ceiling(kernel_substr):
         total += n
     rate = total / cycles
     return rate * SIMDS * CLOCK_GHZ, ("profiles/%s_valu_issue.json (tools/valu_issue.hip: measured wave64 instructions per SIMD-cycle per opcode, 8 waves/SIMD) weighted with "
-                                      "profiles/%s_kernel_mix.json (the kernel's opcode counts): %.3f per SIMD-cycle x %d SIMDs x %.1f GHz" % (rnd, rnd, rate, SIMDS, CLOCK_GHZ))
+                                      "profiles/%s_kernel_mix.json (the kernel's opcode counts): %.3f per SIMD-cycle x %d SIMDs x %.1f GHz" % (rnd, mrnd, rate, SIMDS, CLOCK_GHZ))
 
 
 def cpu_model():
@@ -540,12 +547,11 @@ def main():
         return ms.value, n.value
 
     def pmc_summary():
-        for name in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
-            try:
-                return json.load(open(os.path.join(ROOT, "profiles", name))), "profiles/" + name
-            except (OSError, ValueError):
-                continue
-        return {}, None
+        f = newest_profile("pmc_summary.json")
+        try:
+            return json.load(open(f)), "profiles/" + os.path.basename(f)
+        except (OSError, ValueError, TypeError):
+            return {}, None
 
     def pmc_kernel(pmc, prefix, field):
         """the summary's entry for a kernel (template arguments included in its key), the one that has `field`"""
@@ -1034,8 +1040,8 @@ def main():
         # two more geometries of SURVEY 8(d) config 3, one launch shape each, rank 0 only (not part of `value`)
         more = {}
         try:
-            pw_legs_pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_power_legs.json")))
-        except (OSError, ValueError):
+            pw_legs_pmc = json.load(open(newest_profile("pmc_power_legs.json")))
+        except (OSError, ValueError, TypeError):
             pw_legs_pmc = {}
         fft_peak, _ = valu_ceiling("k_pwm_tail")
         if world == 1 and args.variants == "all":
@@ -1065,7 +1071,7 @@ def main():
                 more[label] = {"Mbins/s": in_samples / pl.downsample / t2 / 1e6, "input MSample/s": in_samples / t2 / 1e6,
                                "GB/s_in": 4.0 * in_samples / t2 / 1e9, "frac_of_hbm_peak": 4.0 * in_samples / t2 / 1e9 / HBM_PEAK_GBS,
                                "N": nn, "downsample": pl.downsample, "tunes": pl.tune_count, "passes": npasses, "ms": t2 * 1e3}
-                # which roofline binds this leg: every kernel of the launch counted (rocprofv3 --pmc, profiles/r04_pmc_power_legs.json), the live time
+                # which roofline binds this leg: every kernel of the launch counted (rocprofv3 --pmc, profiles/rNN_pmc_power_legs.json), the live time
                 # of the whole launch -- HBM traffic (fetched x2 + written) against 8 TB/s, VALU wave-instructions against the measured issue ceiling
                 cnt = next((v for k, v in pw_legs_pmc.items() if label.startswith(k)), None)
                 if cnt is None and nn == 4096 and pl.tune_count == total_tunes:
@@ -1080,7 +1086,7 @@ def main():
                     more[label].update({"traffic_GBs": tr, "traffic_frac_of_hbm_peak": tr / HBM_PEAK_GBS, "traffic_over_input_bytes": cnt["hbm_bytes_per_launch"] * sc / (4.0 * in_samples),
                                         "valu_G_wave_instr_per_s": vi, "valu_frac": vi / fft_peak,
                                         "bound": "hbm" if tr / HBM_PEAK_GBS >= vi / fft_peak else "valu", "frac": max(tr / HBM_PEAK_GBS, vi / fft_peak),
-                                        "roofline_source": "profiles/r04_pmc_power_legs.json or, N = 4096, r04_pmc_summary.json (all kernels of the launch) / live launch time"})
+                                        "roofline_source": "profiles/rNN_pmc_power_legs.json or, N = 4096, rNN_pmc_summary.json of the newest round (all kernels of the launch) / live launch time"})
                 if not args.no_parity:
                     da.zero_()
                     dsm.zero_()

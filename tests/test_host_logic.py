@@ -146,8 +146,7 @@ def test_newest_round_profiles_hold_what_bench_reads():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     import bench
-    rnd = next(r for r in ("r04", "r03") if os.path.exists(os.path.join(root, "profiles", r + "_pmc_summary.json")))
-    pmc = json.load(open(os.path.join(root, "profiles", rnd + "_pmc_summary.json")))
+    pmc = json.load(open(bench.newest_profile("pmc_summary.json")))
     assert any(k.startswith("k_fm_decimate<false, true, true") and v.get("hbm_bytes_per_launch") for k, v in pmc.items() if isinstance(v, dict))
     assert any(k.startswith("k_pw_fft4096") and v.get("SQ_INSTS_VALU") for k, v in pmc.items() if isinstance(v, dict))
     assert any(k.startswith("k_ch_fft") and v.get("SQ_INSTS_VALU") for k, v in pmc.items() if isinstance(v, dict))
@@ -162,13 +161,12 @@ def test_newest_round_profiles_hold_what_bench_reads():
         assert src is not None and 0.20 * bench.SIMDS * bench.CLOCK_GHZ < peak < 0.30 * bench.SIMDS * bench.CLOCK_GHZ
     sys.path.insert(0, os.path.join(root, "tools"))
     import kernel_mix
-    mrnd = next(r for r in ("r04", "r03") if os.path.exists(os.path.join(root, "profiles", r + "_kernel_mix.json")))
-    mix = json.load(open(os.path.join(root, "profiles", mrnd + "_kernel_mix.json")))
+    mix = json.load(open(bench.newest_profile("kernel_mix.json")))
     for names in kernel_mix.WANT.values():
         for n in names:
             assert any(n in k for k in mix), n
-    if rnd == "r04":
-        legs = json.load(open(os.path.join(root, "profiles", "r04_pmc_power_legs.json")))
+    if bench.newest_profile("pmc_power_legs.json"):
+        legs = json.load(open(bench.newest_profile("pmc_power_legs.json")))
         assert len(legs) == 4 and all(v["valu_wave_instr_per_launch"] > 0 and v["hbm_bytes_per_launch"] > 0 for v in legs.values())
 
 
