@@ -296,6 +296,15 @@ int rxgpu_chan_get_audio_carry(rxgpu_chan *s, int *audio);
  * resampled audio (*windows_out = samples per channel, the same for every channel).  Synchronous. */
 int rxgpu_chan_run(rxgpu_chan *s, const int16_t *d_iq, size_t n_blocks, size_t block_len, int16_t *d_out,
                    size_t out_stride, size_t *windows_out);
+/* The same without waiting: up to two runs in flight on the library's stream, the carries chained from run to run on the device (a channel's
+ * carry is its last bin, which no host fix-up changes), so that the host's part of run r -- reading the flag count, settling an undecided libm
+ * sample -- happens while run r + 1 computes.  rxgpu_chan_wait retires what is in flight (older run first), brings the carries home and
+ * returns the windows per channel of the LAST run; rxgpu_chan_get_carry / _set_carry / _host_fixups refer to retired runs only.  d_iq and
+ * d_out of a run must stay untouched until it is retired (the wait, or the second rxgpu_chan_run_async after it).  With the per-channel audio
+ * stages on (deemph / rate_out2) a run is finished before the call returns, like rxgpu_chan_run. */
+int rxgpu_chan_run_async(rxgpu_chan *s, const int16_t *d_iq, size_t n_blocks, size_t block_len, int16_t *d_out, size_t out_stride);
+int rxgpu_chan_wait(rxgpu_chan *s, size_t *windows_out);
+/* undecided libm samples the host settled in the runs the last rxgpu_chan_run / rxgpu_chan_wait retired */
 long rxgpu_chan_host_fixups(const rxgpu_chan *s);
 
 /* --------------------------------------------------------- rx_power: drop-in */

@@ -22,7 +22,7 @@ EXPORTS = [
     "rxgpu_fm_stream_create", "rxgpu_fm_stream_destroy", "rxgpu_fm_stream_set_carry", "rxgpu_fm_stream_get_carry",
     "rxgpu_fm_stream_run", "rxgpu_fm_stream_run_async", "rxgpu_fm_stream_wait", "rxgpu_fm_stream_run_host",
     "rxgpu_fm_stream_host_fixups",
-    "rxgpu_chan_create", "rxgpu_chan_destroy", "rxgpu_chan_set_carry", "rxgpu_chan_get_carry", "rxgpu_chan_run",
+    "rxgpu_chan_create", "rxgpu_chan_destroy", "rxgpu_chan_set_carry", "rxgpu_chan_get_carry", "rxgpu_chan_run", "rxgpu_chan_run_async", "rxgpu_chan_wait",
     "rxgpu_chan_set_audio_carry", "rxgpu_chan_get_audio_carry",
     "rxgpu_chan_host_fixups",
     "rxgpu_scan", "rxgpu_scan_sync", "rxgpu_scan_syncs", "rxgpu_scan_zero_copy", "rxgpu_scan_release", "rxgpu_scan_deferred", "rxgpu_csv_dbm", "rxgpu_power_plan_range", "rxgpu_sine_table", "rxgpu_window_coefs",
@@ -77,6 +77,8 @@ def lib():
         L.rxgpu_chan_set_audio_carry.argtypes = [C.c_void_p, C.c_void_p]
         L.rxgpu_chan_get_audio_carry.argtypes = [C.c_void_p, C.c_void_p]
         L.rxgpu_chan_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.rxgpu_chan_run_async.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.rxgpu_chan_wait.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
         L.rxgpu_chan_host_fixups.argtypes = [C.c_void_p]
         L.rxgpu_chan_host_fixups.restype = C.c_long
         L.rxgpu_power_scan_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]

@@ -15,19 +15,52 @@
 struct rxgpu_chan {
 	rxgpu_chan_params p;
 	size_t max_windows;
-	uint32_t *twiddle_dev, *chan_lp;
+	uint32_t *twiddle_dev;
 	uint32_t *nco_tw_dev;            /* p.nco: the full period of the NCO, N packed (cos, sin) from the reference's Sinewave table */
-	int *pre_dev[2];                 /* carried (pre_r, pre_j) per channel: in / out */
+	int *pre_up;                     /* carried (pre_r, pre_j) per channel as uploaded from pre_host (a run that is not chained to one before it) */
 	int *pre_host;
 	int *audio_dev[2], *audio_host;  /* per channel {deemph avg, now_lpr, prev_lpr_index}: in / out */
 	int16_t *audio_y;                /* [n_channels][max_windows]: the de-emphasised samples in front of the resampler (k_ch_audio), or the demodulated rows (segmented form) */
 	void *audio_ctab;                /* the (segment, channel) form of the audio stages: chunk tables [n_channels][chunks] ... */
 	int *audio_seg;                  /* ... and every chunk's start state [n_channels][chunks] */
 	int audio_seg_on;                /* $RXGPU_CH_AUDIO_SEG != 0 at creation */
-	rxk_fm_dev *dev, *dev_host;
-	unsigned long long *flag_list, *flag_host;
-	long fixups;
+	/* what a run leaves for its retirement, two of them in rotation (rxgpu_chan_run_async keeps up to two runs in flight) */
+	struct chan_slot {
+		int live;
+		rxk_fm_dev *dev, *dev_host;  /* flag count (device / its pinned copy, read back behind the run's kernels) */
+		unsigned long long *flag_list;
+		uint32_t *chan_lp;           /* the bins the sparse / dense demodulator pass reads -- and a host fix-up after it */
+		int *pre_out_dev;            /* the run's carries out: the next run's carries in, on the device */
+		int *pre_in_host, *pre_out_host;   /* pinned copies: carries in (a channel's first window re-evaluated on the host), carries out */
+		int16_t *rows;               /* where the run's demodulated samples went */
+		size_t rstride;
+		unsigned long long total;
+		int fused;
+		hipEvent_t done;
+	} run[2];
+	unsigned long long seq;
+	int chained;                     /* the previous enqueued run's pre_out_dev holds the carries (else pre_host does) */
+	unsigned long long *flag_host;
+	size_t last_windows;
+	long fixups, fixups_pending;
 };
+
+static int chan_slots_alloc(rxgpu_chan *s, size_t nc)
+{
+	for (int k = 0; k < 2; k++) {
+		struct chan_slot *r = &s->run[k];
+		if (hipMalloc((void **)&r->dev, sizeof(rxk_fm_dev)) != hipSuccess ||
+		    hipHostMalloc((void **)&r->dev_host, sizeof(rxk_fm_dev), 0) != hipSuccess ||
+		    hipMalloc((void **)&r->flag_list, RXK_FLAG_CAP * 8) != hipSuccess ||
+		    hipMalloc((void **)&r->chan_lp, nc * s->max_windows * 4) != hipSuccess ||
+		    hipMalloc((void **)&r->pre_out_dev, nc * 8) != hipSuccess ||
+		    hipHostMalloc((void **)&r->pre_in_host, nc * 8, 0) != hipSuccess ||
+		    hipHostMalloc((void **)&r->pre_out_host, nc * 8, 0) != hipSuccess ||
+		    hipEventCreateWithFlags(&r->done, hipEventDisableTiming) != hipSuccess)
+			return RXGPU_ENOMEM;
+	}
+	return RXGPU_OK;
+}
 
 int rxgpu_chan_create(rxgpu_chan **out, const rxgpu_chan_params *p, size_t max_blocks, size_t block_len, const int16_t *sinewave)
 {
@@ -72,15 +105,12 @@ int rxgpu_chan_create(rxgpu_chan **out, const rxgpu_chan_params *p, size_t max_b
 			ctab_per_channel = (s->max_windows + w8 - 1) / w8 + 1;
 	}
 	if (hipMalloc((void **)&s->twiddle_dev, (n + 2) * 4) != hipSuccess ||
-	    hipMalloc((void **)&s->chan_lp, nc * s->max_windows * 4) != hipSuccess ||
-	    hipMalloc((void **)&s->pre_dev[0], nc * 8) != hipSuccess || hipMalloc((void **)&s->pre_dev[1], nc * 8) != hipSuccess ||
+	    hipMalloc((void **)&s->pre_up, nc * 8) != hipSuccess ||
 	    hipMalloc((void **)&s->audio_dev[0], nc * 12) != hipSuccess || hipMalloc((void **)&s->audio_dev[1], nc * 12) != hipSuccess ||
 	    hipHostMalloc((void **)&s->audio_host, nc * 12, 0) != hipSuccess ||
 	    ((p->rate_out2 > 0 || p->deemph) && hipMalloc((void **)&s->audio_y, nc * s->max_windows * 2) != hipSuccess) ||
 	    (p->deemph && (hipMalloc(&s->audio_ctab, nc * ctab_per_channel * 16) != hipSuccess || hipMalloc((void **)&s->audio_seg, nc * ctab_per_channel * 4) != hipSuccess)) ||
-	    hipMalloc((void **)&s->dev, sizeof(rxk_fm_dev)) != hipSuccess ||
-	    hipMalloc((void **)&s->flag_list, RXK_FLAG_CAP * 8) != hipSuccess ||
-	    hipHostMalloc((void **)&s->dev_host, sizeof(rxk_fm_dev), 0) != hipSuccess ||
+	    chan_slots_alloc(s, nc) != RXGPU_OK ||
 	    hipHostMalloc((void **)&s->flag_host, RXK_FLAG_CAP * 8, 0) != hipSuccess ||
 	    hipHostMalloc((void **)&s->pre_host, nc * 8, 0) != hipSuccess ||
 	    hipMemcpy(s->twiddle_dev, tw, (n + 2) * 4, hipMemcpyHostToDevice) != hipSuccess) {
@@ -117,11 +147,17 @@ void rxgpu_chan_destroy(rxgpu_chan *s)
 {
 	if (!s)
 		return;
-	hipFree(s->twiddle_dev); hipFree(s->nco_tw_dev); hipFree(s->chan_lp); hipFree(s->pre_dev[0]); hipFree(s->pre_dev[1]);
+	hipFree(s->twiddle_dev); hipFree(s->nco_tw_dev); hipFree(s->pre_up);
+	for (int k = 0; k < 2; k++) {
+		struct chan_slot *r = &s->run[k];
+		if (r->done) { hipEventSynchronize(r->done); hipEventDestroy(r->done); }
+		hipFree(r->dev); hipFree(r->flag_list); hipFree(r->chan_lp); hipFree(r->pre_out_dev);
+		if (r->dev_host) hipHostFree(r->dev_host);
+		if (r->pre_in_host) hipHostFree(r->pre_in_host);
+		if (r->pre_out_host) hipHostFree(r->pre_out_host);
+	}
 	hipFree(s->audio_dev[0]); hipFree(s->audio_dev[1]); hipFree(s->audio_y); hipFree(s->audio_ctab); hipFree(s->audio_seg);
 	if (s->audio_host) hipHostFree(s->audio_host);
-	hipFree(s->dev); hipFree(s->flag_list);
-	if (s->dev_host) hipHostFree(s->dev_host);
 	if (s->flag_host) hipHostFree(s->flag_host);
 	if (s->pre_host) hipHostFree(s->pre_host);
 	free(s);
@@ -131,7 +167,10 @@ int rxgpu_chan_set_carry(rxgpu_chan *s, const int *pre)
 {
 	if (!s || !pre)
 		return rxgpu_fail(RXGPU_EINVAL, "null argument");
+	if (s->run[0].live || s->run[1].live)
+		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_chan_set_carry with runs in flight: rxgpu_chan_wait first");
 	memcpy(s->pre_host, pre, (size_t)s->p.n_channels * 8);
+	s->chained = 0;
 	return RXGPU_OK;
 }
 
@@ -182,12 +221,92 @@ static int disc_host(int ar, int aj, int br, int bj)
 	return (int)(atan2((double)cj, (double)cr) / 3.14159 * (1 << 14));
 }
 
-int rxgpu_chan_run(rxgpu_chan *s, const int16_t *d_iq, size_t n_blocks, size_t block_len, int16_t *d_out, size_t out_stride,
-                   size_t *windows_out)
+/* enqueue one run into slot `k`: carries in from the run before it (on the device) or from pre_host, FFT bank (+ fused discriminator),
+ * the sparse / dense demodulator pass, flag count and carries out copied to pinned memory behind them */
+static int chan_enqueue(rxgpu_chan *s, int k, const int16_t *d_iq, unsigned long long total, unsigned long long wpb, int16_t *rows, size_t rstride)
+{
+	hipStream_t st = rxgpu_hip_stream();
+	struct chan_slot *r = &s->run[k];
+	const size_t nc = (size_t)s->p.n_channels;
+	const int *pre_in;
+	memset(r->dev_host, 0, sizeof(*r->dev_host));
+	RX_HIP(hipMemsetAsync(r->dev, 0, sizeof(rxk_fm_dev), st));
+	if (s->chained) {
+		pre_in = s->run[k ^ 1].pre_out_dev;
+	} else {
+		RX_HIP(hipMemcpyAsync(s->pre_up, s->pre_host, nc * 8, hipMemcpyHostToDevice, st));
+		pre_in = s->pre_up;
+	}
+	RX_HIP(hipMemcpyAsync(r->pre_in_host, pre_in, nc * 8, hipMemcpyDeviceToHost, st));
+	/* -A fast with whole groups of windows per block: fm_demod runs inside the FFT kernel for all but each group's first window */
+	const int fused = s->p.nco ? 0 : rxk_ch_fused_ok(s->p.bin_e, wpb, s->p.custom_atan, s->p.n_channels);
+	rxgpu_prof_begin("ch_fft");
+	if (s->p.nco)                                         /* SURVEY 8(f)2's literal definition: NCO -> low_pass at downsample N, per channel */
+		RX_K(rxk_ch_nco(st, d_iq, total, s->p.bin_e, s->nco_tw_dev, s->p.first_bin, s->p.n_channels, r->chan_lp));
+	else
+		RX_K(rxk_ch_fft(st, d_iq, total, s->p.bin_e, s->twiddle_dev, s->p.first_bin, s->p.n_channels, r->chan_lp, fused, rows, rstride,
+		                r->pre_out_dev));
+	rxgpu_prof_end("ch_fft");
+	rxgpu_prof_begin("ch_demod");
+	RX_K(rxk_ch_demod(st, r->chan_lp, total, wpb, s->p.n_channels, s->p.custom_atan, pre_in, r->pre_out_dev, rows, rstride,
+	                  r->dev, r->flag_list, fused));
+	rxgpu_prof_end("ch_demod");
+	RX_HIP(hipMemcpyAsync(r->dev_host, r->dev, sizeof(rxk_fm_dev), hipMemcpyDeviceToHost, st));
+	RX_HIP(hipMemcpyAsync(r->pre_out_host, r->pre_out_dev, nc * 8, hipMemcpyDeviceToHost, st));
+	RX_HIP(hipEventRecord(r->done, st));
+	r->rows = rows; r->rstride = rstride; r->total = total; r->fused = fused;
+	r->live = 1;
+	s->chained = 1;
+	return RXGPU_OK;
+}
+
+/* wait for the run of slot `k`; libm samples the device could not decide go through the host's libm (like rxgpu_fm.c) and are patched into
+ * the run's rows -- the carries are the channels' last bins, which no fix-up changes, so the run behind it needs nothing redone */
+static int chan_retire(rxgpu_chan *s, int k)
+{
+	struct chan_slot *r = &s->run[k];
+	if (!r->live)
+		return RXGPU_OK;
+	RX_HIP(hipEventSynchronize(r->done));
+	r->live = 0;
+	rxgpu_prof_collect();
+	const size_t nc = (size_t)s->p.n_channels;
+	const unsigned long long total = r->total;
+	const int fused = r->fused;
+	const int cnt = r->dev_host->flag_cnt;
+	if (cnt) {
+		if (cnt > RXK_FLAG_CAP)
+			return rxgpu_fail(RXGPU_EUNSUPPORTED, "%d undecided libm discriminator samples (cap %d)", cnt, RXK_FLAG_CAP);
+		RX_HIP(hipMemcpy(s->flag_host, r->flag_list, (size_t)cnt * 8, hipMemcpyDeviceToHost));
+		for (int i = 0; i < cnt; i++) {
+			unsigned long long gid = s->flag_host[i], c = gid / total, t = gid - c * total;
+			uint32_t a, b;
+			int br, bj;
+			/* fused: the FFT kernel kept [channel][run] first windows, then [channel][run] last windows (flagged samples are block starts,
+			 * hence run starts); else the dense [channel][window] array */
+			const unsigned long long runs = fused ? total / (unsigned long long)fused : 0, q = fused ? t / (unsigned long long)fused : 0;
+			const uint32_t *pa = fused ? r->chan_lp + c * runs + q : r->chan_lp + gid;
+			const uint32_t *pb = fused ? r->chan_lp + nc * runs + c * runs + q - 1 : r->chan_lp + gid - 1;
+			RX_HIP(hipMemcpy(&a, pa, 4, hipMemcpyDeviceToHost));
+			if (t) {
+				RX_HIP(hipMemcpy(&b, pb, 4, hipMemcpyDeviceToHost));
+				br = (int16_t)(b & 0xffff); bj = (int16_t)(b >> 16);
+			} else {
+				br = r->pre_in_host[2 * c]; bj = r->pre_in_host[2 * c + 1];
+			}
+			int16_t v = (int16_t)disc_host((int16_t)(a & 0xffff), (int16_t)(a >> 16), br, bj);
+			RX_HIP(hipMemcpy(r->rows + c * r->rstride + t, &v, 2, hipMemcpyHostToDevice));
+		}
+		s->fixups_pending += cnt;
+	}
+	return RXGPU_OK;
+}
+
+static int chan_check_run(rxgpu_chan *s, const int16_t *d_iq, size_t n_blocks, size_t block_len, int16_t *d_out, size_t out_stride,
+                          unsigned long long *wpb_out, unsigned long long *total_out)
 {
 	if (!s || !d_iq || !d_out || !n_blocks)
 		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_chan_run: bad arguments");
-	hipStream_t st = rxgpu_hip_stream();
 	const size_t n = (size_t)1 << s->p.bin_e;
 	if (block_len < 2 || (block_len & 1) || (block_len / 2) % n)
 		return rxgpu_fail(RXGPU_EUNSUPPORTED, "block of %zu samples is not a whole number of %zu-sample windows", block_len / 2, n);
@@ -196,7 +315,66 @@ int rxgpu_chan_run(rxgpu_chan *s, const int16_t *d_iq, size_t n_blocks, size_t b
 		return rxgpu_fail(RXGPU_ECAPACITY, "channeliser created for %zu windows, run asks %llu", s->max_windows, total);
 	if (out_stride < total)
 		return rxgpu_fail(RXGPU_ECAPACITY, "out_stride %zu shorter than %llu windows", out_stride, total);
+	*wpb_out = wpb; *total_out = total;
+	return RXGPU_OK;
+}
+
+/* the two runs in flight, older first; the carries of the newest come home */
+static int chan_drain(rxgpu_chan *s)
+{
+	int rc;
+	const int newest = (int)((s->seq + 1) & 1);              /* slot of run seq - 1 */
+	if ((rc = chan_retire(s, newest ^ 1)) != RXGPU_OK || (rc = chan_retire(s, newest)) != RXGPU_OK)
+		return rc;
+	if (s->seq && s->chained)
+		memcpy(s->pre_host, s->run[newest].pre_out_host, (size_t)s->p.n_channels * 8);
+	s->fixups = s->fixups_pending;
+	s->fixups_pending = 0;
+	return RXGPU_OK;
+}
+
+int rxgpu_chan_run_async(rxgpu_chan *s, const int16_t *d_iq, size_t n_blocks, size_t block_len, int16_t *d_out, size_t out_stride)
+{
+	int rc;
+	unsigned long long wpb, total;
+	if ((rc = chan_check_run(s, d_iq, n_blocks, block_len, d_out, out_stride, &wpb, &total)) != RXGPU_OK)
+		return rc;
+	if (s->p.deemph || s->p.rate_out2 > 0)
+		/* the audio stages start from samples a host fix-up may still change: such a channeliser runs call by call */
+		return rxgpu_chan_run(s, d_iq, n_blocks, block_len, d_out, out_stride, &s->last_windows);
+	const int k = (int)(s->seq & 1);
+	if ((rc = chan_retire(s, k)) != RXGPU_OK)                /* the run two enqueues ago: its slot is this run's */
+		return rc;
+	if ((rc = chan_enqueue(s, k, d_iq, total, wpb, d_out, out_stride)) != RXGPU_OK)
+		return rc;
+	s->seq++;
+	s->last_windows = (size_t)total;
+	return RXGPU_OK;
+}
+
+int rxgpu_chan_wait(rxgpu_chan *s, size_t *windows_out)
+{
+	int rc;
+	if (!s)
+		return rxgpu_fail(RXGPU_EINVAL, "null argument");
+	if ((rc = chan_drain(s)) != RXGPU_OK)
+		return rc;
+	if (windows_out)
+		*windows_out = s->last_windows;
+	return RXGPU_OK;
+}
+
+int rxgpu_chan_run(rxgpu_chan *s, const int16_t *d_iq, size_t n_blocks, size_t block_len, int16_t *d_out, size_t out_stride,
+                   size_t *windows_out)
+{
+	int rc;
+	unsigned long long wpb, total;
+	if ((rc = chan_check_run(s, d_iq, n_blocks, block_len, d_out, out_stride, &wpb, &total)) != RXGPU_OK)
+		return rc;
+	hipStream_t st = rxgpu_hip_stream();
 	const size_t nc = (size_t)s->p.n_channels;
+	if ((rc = chan_drain(s)) != RXGPU_OK)                    /* runs a caller left in flight */
+		return rc;
 	/* per-channel audio stages: which form serves this run is known before anything is launched -- the (segment, channel) grid reads the
 	 * demodulated rows from a buffer of its own (audio_y) and writes the audio to d_out, k_ch_audio works on d_out in place */
 	const int audio_on = s->p.deemph || s->p.rate_out2 > 0;
@@ -209,62 +387,12 @@ int rxgpu_chan_run(rxgpu_chan *s, const int16_t *d_iq, size_t n_blocks, size_t b
 	                rxk_ch_audio_seg_ok(total, warm, s->p.rate_out, s->p.rate_out2 > 0 ? s->p.rate_out2 : 0);
 	int16_t *const rows = seg ? s->audio_y : d_out;                 /* where the demodulated samples go */
 	const size_t rstride = seg ? s->max_windows : out_stride;
-	rxk_fm_dev *h = s->dev_host;
-	memset(h, 0, sizeof(*h));
-	RX_HIP(hipMemcpyAsync(s->dev, h, sizeof(*h), hipMemcpyHostToDevice, st));
-	RX_HIP(hipMemcpyAsync(s->pre_dev[0], s->pre_host, nc * 8, hipMemcpyHostToDevice, st));
-	/* -A fast with whole groups of windows per block: fm_demod runs inside the FFT kernel for all but each group's first window */
-	const int fused = s->p.nco ? 0 : rxk_ch_fused_ok(s->p.bin_e, wpb, s->p.custom_atan, s->p.n_channels);
-	rxgpu_prof_begin("ch_fft");
-	if (s->p.nco)                                         /* SURVEY 8(f)2's literal definition: NCO -> low_pass at downsample N, per channel */
-		RX_K(rxk_ch_nco(st, d_iq, total, s->p.bin_e, s->nco_tw_dev, s->p.first_bin, s->p.n_channels, s->chan_lp));
-	else
-		RX_K(rxk_ch_fft(st, d_iq, total, s->p.bin_e, s->twiddle_dev, s->p.first_bin, s->p.n_channels, s->chan_lp, fused, rows, rstride,
-		                s->pre_dev[1]));
-	rxgpu_prof_end("ch_fft");
-	rxgpu_prof_begin("ch_demod");
-	RX_K(rxk_ch_demod(st, s->chan_lp, total, wpb, s->p.n_channels, s->p.custom_atan, s->pre_dev[0], s->pre_dev[1], rows, rstride,
-	                  s->dev, s->flag_list, fused));
-	rxgpu_prof_end("ch_demod");
-	RX_HIP(hipMemcpyAsync(h, s->dev, sizeof(*h), hipMemcpyDeviceToHost, st));
-	int *pre_in_copy = malloc(nc * 8);
-	if (!pre_in_copy)
-		return rxgpu_fail(RXGPU_ENOMEM, "out of host memory");
-	memcpy(pre_in_copy, s->pre_host, nc * 8);
-	RX_HIP(hipMemcpyAsync(s->pre_host, s->pre_dev[1], nc * 8, hipMemcpyDeviceToHost, st));
-	RX_HIP(hipStreamSynchronize(st));
-	rxgpu_prof_collect();
-	s->fixups = 0;
-	if (h->flag_cnt) {
-		/* libm samples the device could not decide: host libm, like rxgpu_fm.c */
-		int cnt = h->flag_cnt;
-		if (cnt > RXK_FLAG_CAP) {
-			free(pre_in_copy);
-			return rxgpu_fail(RXGPU_EUNSUPPORTED, "%d undecided libm discriminator samples (cap %d)", cnt, RXK_FLAG_CAP);
-		}
-		RX_HIP(hipMemcpy(s->flag_host, s->flag_list, (size_t)cnt * 8, hipMemcpyDeviceToHost));
-		for (int i = 0; i < cnt; i++) {
-			unsigned long long gid = s->flag_host[i], c = gid / total, t = gid - c * total;
-			uint32_t a, b;
-			int br, bj;
-			/* fused: the FFT kernel kept [channel][run] first windows, then [channel][run] last windows (flagged samples are block starts,
-			 * hence run starts); else the dense [channel][window] array */
-			const unsigned long long runs = fused ? total / (unsigned long long)fused : 0, r = fused ? t / (unsigned long long)fused : 0;
-			const uint32_t *pa = fused ? s->chan_lp + c * runs + r : s->chan_lp + gid;
-			const uint32_t *pb = fused ? s->chan_lp + nc * runs + c * runs + r - 1 : s->chan_lp + gid - 1;
-			RX_HIP(hipMemcpy(&a, pa, 4, hipMemcpyDeviceToHost));
-			if (t) {
-				RX_HIP(hipMemcpy(&b, pb, 4, hipMemcpyDeviceToHost));
-				br = (int16_t)(b & 0xffff); bj = (int16_t)(b >> 16);
-			} else {
-				br = pre_in_copy[2 * c]; bj = pre_in_copy[2 * c + 1];
-			}
-			int16_t v = (int16_t)disc_host((int16_t)(a & 0xffff), (int16_t)(a >> 16), br, bj);
-			RX_HIP(hipMemcpy(rows + c * rstride + t, &v, 2, hipMemcpyHostToDevice));
-		}
-		s->fixups = cnt;
-	}
-	free(pre_in_copy);
+	const int k = (int)(s->seq & 1);
+	if ((rc = chan_enqueue(s, k, d_iq, total, wpb, rows, rstride)) != RXGPU_OK)
+		return rc;
+	s->seq++;
+	if ((rc = chan_drain(s)) != RXGPU_OK)
+		return rc;
 	unsigned long long per_channel = total;
 	if (audio_on) {
 		/* per-channel audio stages on the finished (and, where needed, host-corrected) demodulated rows */
@@ -291,6 +419,7 @@ int rxgpu_chan_run(rxgpu_chan *s, const int16_t *d_iq, size_t n_blocks, size_t b
 		rxgpu_prof_collect();
 		per_channel = J;
 	}
+	s->last_windows = (size_t)per_channel;
 	if (windows_out)
 		*windows_out = (size_t)per_channel;
 	return RXGPU_OK;

@@ -167,6 +167,15 @@ class Channeliser:
         check(lib().rxgpu_chan_run(self._h, d_iq_ptr, n_blocks, block_len, d_out_ptr, out_stride, C.byref(n)))
         return n.value
 
+    def run_async(self, d_iq_ptr, n_blocks, block_len, d_out_ptr, out_stride):
+        """up to two runs in flight, carries chained on the device; wait() retires them"""
+        check(lib().rxgpu_chan_run_async(self._h, d_iq_ptr, n_blocks, block_len, d_out_ptr, out_stride))
+
+    def wait(self):
+        n = C.c_size_t(0)
+        check(lib().rxgpu_chan_wait(self._h, C.byref(n)))
+        return n.value
+
     @property
     def host_fixups(self):
         return lib().rxgpu_chan_host_fixups(self._h)

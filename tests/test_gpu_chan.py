@@ -201,6 +201,47 @@ def test_channeliser_per_channel_audio_stages(bin_e, n_channels, block_len, n_bl
     ch.close()
 
 
+# round 5: runs in flight
+@pytest.mark.parametrize("custom_atan,flag_all", [(1, None), (0, None), (1, "2"), (0, "1")])
+def test_channeliser_async_runs_chain_their_carries_on_the_device(custom_atan, flag_all, monkeypatch):
+    """rxgpu_chan_run_async: seven runs of different lengths enqueued back to back, two in flight, carries chained on the device, one
+    rxgpu_chan_wait at the end == the oracle's stream over the concatenation, == the same runs through the synchronous call; also with the
+    host settling libm samples run by run ($RXGPU_FLAG_ALL: every block-first / -A std sample handed to the host, 2: with a wrong value first)"""
+    from gpu_support import to_dev, torch_cuda
+    torch = torch_cuda()
+    if flag_all:
+        monkeypatch.setenv("RXGPU_FLAG_ALL", flag_all)
+    bin_e, first_bin, n_channels, block_len = 7, 20, 48, 2 * 2048
+    lens = [3, 1, 4, 1, 5, 2, 6] if not (flag_all and custom_atan == 0) else [1, 1, 1]     # -A std flags every sample: the cap is per run
+    n_blocks = sum(lens)
+    iq = sig_noise(n_blocks * block_len, seed=77, amp=3000)
+    from support import oracle_chan_stream
+    want, want_pre, _ = oracle_chan_stream(iq, block_len, bin_e, first_bin, n_channels, custom_atan)
+    wpb = block_len // 2 >> bin_e
+    d_iq = to_dev(iq)
+    res = {}
+    for mode in ("async", "sync"):
+        ch = R.Channeliser(R.ChanParams(bin_e, first_bin, n_channels, custom_atan), max(lens), block_len, R.sine_table(bin_e))
+        outs, b = [], 0
+        for nb in lens:
+            d_out = torch.zeros((n_channels, nb * wpb), dtype=torch.int16, device="cuda")
+            outs.append(d_out)
+            if mode == "async":
+                ch.run_async(d_iq.data_ptr() + b * block_len * 2, nb, block_len, d_out.data_ptr(), nb * wpb)
+            else:
+                assert ch.run(d_iq.data_ptr() + b * block_len * 2, nb, block_len, d_out.data_ptr(), nb * wpb) == nb * wpb
+            b += nb
+        if mode == "async":
+            assert ch.wait() == lens[-1] * wpb
+            if flag_all:
+                assert ch.host_fixups > 0
+        res[mode] = (np.concatenate([o.cpu().numpy() for o in outs], axis=1), ch.get_carry())
+        ch.close()
+    for got, pre in res.values():
+        assert np.array_equal(got, want) and np.array_equal(pre, want_pre)
+    R.lib().rxgpu_knobs_reload()
+
+
 # round 5: the audio stages on a (segment, channel) grid -- rows long enough to be cut into >= 64 chunks of >= warm-up length
 @pytest.mark.parametrize("bin_e,n_channels,block_len,n_blocks,a,rate_out,rate_out2,custom_atan,pad", [
     (6, 40, 2 * 65536, 10, 7, 19531, 8000, 1, 0),         # 5120-sample rows: 80 chunks, one segment; odd a below the 24-bit step
