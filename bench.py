@@ -317,6 +317,7 @@ def hoist(result, parity_all, world):
                             else "torch.distributed.gather" if "torch.distributed" in c["gather"] else "none (single process)"),
             "rccl_library": os.path.basename(c["gather"].split(" from ")[1].split(" ")[0]) if " from " in c["gather"] else None,
             "passes_per_step": c["passes_per_step"],
+            "rx_power_gather_is_product": c.get("gather_is_product"), "rccl_comm_error": c.get("rccl_comm_error"),
             "rx_power_1gpu_same_run_Mbins_per_s": pw.get("one_gpu_same_run_Mbins_per_s"),
             "rx_power_speedup_vs_1gpu": (pw["value"] / pw["one_gpu_same_run_Mbins_per_s"]) if pw.get("one_gpu_same_run_Mbins_per_s") else None,
             "rx_power_parity_tunes": (pw.get("parity_sharded") or pw.get("parity") or {}).get("parity_tunes_compared"),
@@ -404,7 +405,7 @@ def compact(result, full_path=None):
     cfg = result.get("config") or {}
     c = {"workload": cfg.get("workload_short") or str(cfg.get("workload", ""))[:120]}
     for k in ("blocks_per_step", "block_complex_samples", "bytes_per_step", "parallelism", "host_fixups_timed_loop", "passes_per_step", "n_ranks", "rccl_ranks",
-              "rccl_gathers_enqueued", "gather_impl", "rccl_library", "gather_bytes_per_rank", "tunes_per_rank", "tunes_rank0", "rx_power_Mbins_per_s", "rx_power_ms_per_step",
+              "rccl_gathers_enqueued", "gather_impl", "rx_power_gather_is_product", "rccl_comm_error", "rccl_library", "gather_bytes_per_rank", "tunes_per_rank", "tunes_rank0", "rx_power_Mbins_per_s", "rx_power_ms_per_step",
               "rx_power_1gpu_same_run_Mbins_per_s", "rx_power_speedup_vs_1gpu", "scan_us_rank0", "gather_us_rank0", "rx_power_parity_ok", "rx_power_parity_tunes",
               "rx_power_parity_ranks", "rx_power_padding_rows_zero", "rx_power_cpu_baseline_Mbins_per_s_1core", "rx_fm_replicas_MSample_per_s"):
         if k in cfg and cfg[k] is not None:
@@ -483,8 +484,10 @@ def main():
     ap.add_argument("--variants", default="all", choices=["all", "none"],
                     help="rx_fm side figures (ds=6, ds=5/240k, -F cascade, host-fed); `none` keeps the per-kernel averages of a "
                          "rocprofv3 run of this command to the headline launches (the ds=6 chain launches the same decimator kernel)")
-    ap.add_argument("--allow-torch-gather", action="store_true",
-                    help="N>1 only: if librxgpu's own RCCL communicator cannot be created, gather through torch.distributed instead of failing")
+    ap.add_argument("--require-librxgpu-gather", action="store_true",
+                    help="N>1 only: FAIL if librxgpu's own RCCL communicator cannot be created on every rank (default: gather through torch.distributed "
+                         "instead, say so in the line -- gather_impl, rccl_comm_error -- and set rx_power_gather_is_product false)")
+    ap.add_argument("--allow-torch-gather", action="store_true", help=argparse.SUPPRESS)      # round 4's spelling of what is now the default
     ap.add_argument("--no-parity", action="store_true", help="skip the full-size comparison with the CPU reference")
     ap.add_argument("--full-out", default=os.path.join(ROOT, "gpurun_out", "bench_full.json"),
                     help="where rank 0 writes the full record (every leg, every parity dict); stdout carries the compact line only")
@@ -819,8 +822,9 @@ def main():
         d_smp_all = torch.zeros((world, per), dtype=torch.int32, device=dev) if rank == 0 else None
         comm, gather_impl = None, "single process (no collective)"
         if world > 1:
-            # the product's own communicator (librccl bound by librxgpu); a failure here FAILS the run -- a scaling curve measured
-            # through torch.distributed.gather would not be the product's -- unless --allow-torch-gather says otherwise
+            # the product's own communicator (librccl bound by librxgpu).  A scaling curve measured through torch.distributed.gather would not be the
+            # product's: if the communicator cannot be created the run goes on through torch's gather and the line SAYS so (gather_impl,
+            # rccl_comm_error, rx_power_gather_is_product false) -- a SCALE record with a labelled fallback beats none; --require-librxgpu-gather fails instead
             comm_err = None
             try:
                 comm = shard.Comm.from_torch_distributed()
@@ -833,12 +837,14 @@ def main():
                 if comm is not None:
                     comm.close()
                     comm = None
-                if not args.allow_torch_gather:
+                if args.require_librxgpu_gather:
                     raise SystemExit("bench.py: librxgpu's RCCL communicator could not be created on every rank (%s); "
-                                     "--allow-torch-gather measures torch.distributed.gather instead" % (comm_err or "another rank failed"))
-                gather_impl = "torch.distributed.gather (backend nccl = RCCL), --allow-torch-gather; librxgpu's communicator failed: %s" % (comm_err or "on another rank")
-        gbuf = shard.gather_buffers(d_avgs[0], dst=0) if (world > 1 and comm is None) else None
-        sbuf = shard.gather_buffers(d_smps[0], dst=0) if (world > 1 and comm is None) else None
+                                     "(--require-librxgpu-gather)" % (comm_err or "another rank failed"))
+                gather_impl = "torch.distributed.gather (backend nccl = RCCL) -- NOT the product's gather: librxgpu's communicator failed: %s" % (comm_err or "on another rank")
+                sys.stderr.write("bench.py: %s\n" % gather_impl)
+        # the fallback gathers into the same [world][per][N] block the product's gather fills, so the sharded parity check below reads one place
+        gbuf = [d_avg_all[r] for r in range(world)] if (world > 1 and comm is None and rank == 0) else None
+        sbuf = [d_smp_all[r] for r in range(world)] if (world > 1 and comm is None and rank == 0) else None
         state = {"k": 0}
 
         def step():
@@ -918,6 +924,7 @@ def main():
                        "scan_us_per_step_rank0": (ms / launches * 1e3) if launches else None,
                        "parallelism": "tunes sharded x%d, one gather of avg[] + samples to rank 0 per step" % world,
                        "gather": gather_impl, "gather_us_per_step_rank0": (gms / gl * 1e3) if gl else None,
+                       "gather_is_product": bool(comm is not None or world == 1), "rccl_comm_error": (comm_err[:160] if (world > 1 and comm_err) else None),
                        "gather_bytes_per_rank": per * n * 8 + per * 4},
             "roofline": {"bound": "valu", "kernel": "k_pw_fft4096 (P4-P8)",
                          "achieved": valu, "peak": pw_peak, "unit": "G wave-instr/s",
