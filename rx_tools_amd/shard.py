@@ -2,7 +2,7 @@
 
 The product path is librxgpu's own (rxgpu_comm_*, rxgpu_power_gather in rxgpu_comm.c: one grouped ncclGather launch from
 librccl on the library's stream, right behind the scan kernels); `Comm` binds it.  The torch.distributed helpers below it
-are what the CPU tests (gloo) use, and bench.py only with --allow-torch-gather.
+are what the CPU tests (gloo) use, and bench.py only where librxgpu's own communicator cannot be created (labelled in its line).
 
 scanner()'s tunes are independent units (rtl_power.c:679-771: own buf16, avg, samples); nothing
 crosses tunes until csv_dbm prints rows in tune order (1047-1050).  So rank r scans tunes
