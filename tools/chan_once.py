@@ -1,5 +1,5 @@
 """tools/chan_once.py -- six runs of the bench line's channeliser shape (256 channels of a 1024-bin bank, 1 GiB of capture per run) and nothing else: what the
-counter passes of tools/profile_round4_refresh.sh profile (bench.py's own leg warms up for 40 runs and times the NCO mode too)"""
+`chan` counter passes of tools/profile_round.sh profile (bench.py's own leg warms up for 40 runs and times the NCO mode too)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
