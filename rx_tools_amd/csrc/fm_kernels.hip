@@ -3668,11 +3668,20 @@ __global__ __launch_bounds__(256) void k_ch_audio(
 #define CHA_MAX_SEG 8
 
 // A lane walks ITS chunk, so a wave's loads land on 64 different cache lines.  First form (16 bytes per lane and turn): every line crossed eight
-// times (2048 workgroups' working set fits no cache), 160 + 213 us.  Second: a whole 128-byte line per lane and turn, eight loads back to back: every
-// line once, but still one line per lane and instruction (64 requests where a coalesced instruction makes 8).  Now the WAVE fetches its 64 lines as
-// whole lines -- eight lanes share a line per instruction -- and hands each lane its own through 9 KiB of wave-private LDS (rows of 128 + 16 bytes: the
-// owner's eight ds_read_b128 meet every bank once); outputs that go back to HBM as lines take the same way in reverse.
+// times (2048 workgroups' working set fits no cache), 160 + 213 us.  Now a lane takes a whole 128-byte line per turn, eight loads back to back
+// (cha_load): every line crosses once -- for the READS that is all there is to gain (fetching the wave's 64 lines as whole lines, eight lanes
+// to a line, and handing them over through LDS left k_cha_track at 47 us and cost k_cha_replay_rs its occupancy: measured, taken out again).
+// The de-emphasised lines that go BACK to HBM are another matter: written lane by lane they are partial-line writes; k_cha_replay sends them
+// through 9 KiB of wave-private LDS (rows of 128 + 16 bytes) and stores whole lines, eight lanes to a line: 100 -> 44 us.
 struct cha_line { uint4 u[8]; };
+__device__ __forceinline__ cha_line cha_load(const int16_t *p)
+{
+	cha_line l;
+#pragma unroll
+	for (int k = 0; k < 8; k++)
+		l.u[k] = reinterpret_cast<const uint4 *>(p)[k];
+	return l;
+}
 __device__ __forceinline__ int cha_sample(const cha_line &l, int q)        // q: compile-time after unrolling
 {
 	const uint4 u = l.u[q >> 3];
@@ -3723,40 +3732,37 @@ template <bool EVEN, bool D24>
 __global__ __launch_bounds__(256) void k_cha_track(const int16_t *__restrict__ rows, u64 row_stride, u64 W, int a, unsigned magic, int bias, int warm,
                                                    unsigned chunk, unsigned n_chunks, const int *__restrict__ audio_in, uint4 *__restrict__ ctab)
 {
-	__shared__ __attribute__((aligned(16))) uint4 cha_stage[4 * CHA_STAGE_U4];
-	const unsigned lane = threadIdx.x & 63u, g_wave = blockIdx.x * 256u + (threadIdx.x & ~63u), g = g_wave + lane;
-	if (g_wave >= n_chunks)
-		return;                                                   // whole waves only: the lanes of a wave fetch for each other
-	uint4 *const stage = cha_stage + (threadIdx.x >> 6) * CHA_STAGE_U4;
-	const bool valid = g < n_chunks;
+	const unsigned g = blockIdx.x * 256u + threadIdx.x;
+	if (g >= n_chunks)
+		return;
 	const u64 c = blockIdx.y;
 	const int16_t *row = rows + c * row_stride;
-	const bool staged = ((size_t)row & 15u) == 0 && (chunk & 63u) == 0;
+	const bool vec = ((size_t)row & 15u) == 0;
 	const int h = a / 2, xoff = h + bias * a;
-	const u64 b = (u64)g * chunk, e = valid ? min(W, b + chunk) : b;
-	const bool has_warm = valid && g != 0;
-	int lo = has_warm ? -32768 : (valid ? audio_in[3 * c] : 0), hi = has_warm ? 32767 : lo;
-	const int wt = staged ? warm / 64 : 0;                        // whole turns of the warm-up; its first warm % 64 samples one by one
-	if (has_warm)
-		for (u64 i = b - (u64)warm; i < b - 64ull * (u64)wt; i++) {
+	const u64 b = (u64)g * chunk, e = min(W, b + chunk);
+	int lo, hi;
+	if (g == 0) {
+		lo = hi = audio_in[3 * c];
+	} else {
+		lo = -32768; hi = 32767;
+		u64 i = b - (u64)warm;
+		if (vec && i + 64 <= b) {
+			cha_line cur = cha_load(&row[i]);
+			for (; i + 64 <= b; i += 64) {
+				const cha_line nxt = cha_load(&row[i + 128 <= b ? i + 64 : i]);
+#pragma unroll
+				for (int q = 0; q < 64; q++) {
+					const int x = cha_sample(cur, q);
+					lo = deemph_step_d<EVEN, D24>(lo, x + xoff, x, magic, bias);
+					hi = deemph_step_d<EVEN, D24>(hi, x + xoff, x, magic, bias);
+				}
+				cur = nxt;
+			}
+		}
+		for (; i < b; i++) {
 			const int x = row[i];
 			lo = deemph_step_d<EVEN, D24>(lo, x + xoff, x, magic, bias);
 			hi = deemph_step_d<EVEN, D24>(hi, x + xoff, x, magic, bias);
-		}
-	const int nturn = staged ? (int)(chunk / 64u) : 0;
-	cha_line f;
-	if (staged)
-		f = cha_fetch(row, W, g_wave, chunk, n_chunks, -64ll * wt, lane);
-	for (int t = -wt; t < 0; t++) {
-		const cha_line cur = cha_hand_over(stage, f, lane);
-		f = cha_fetch(row, W, g_wave, chunk, n_chunks, 64ll * (t + 1), lane);       // the next turn (t + 1 == 0: the chunk's first) is on its way
-		if (has_warm) {
-#pragma unroll
-			for (int q = 0; q < 64; q++) {
-				const int x = cha_sample(cur, q);
-				lo = deemph_step_d<EVEN, D24>(lo, x + xoff, x, magic, bias);
-				hi = deemph_step_d<EVEN, D24>(hi, x + xoff, x, magic, bias);
-			}
 		}
 	}
 	int gap = hi - lo;
@@ -3765,21 +3771,19 @@ __global__ __launch_bounds__(256) void k_cha_track(const int16_t *__restrict__ r
 	int cnt = gap + 1;
 	u64 mask = (((u64)1 << gap) - 1);
 	u64 i = b;
-	for (int t = 0; t < nturn; t++) {
-		const cha_line cur = cha_hand_over(stage, f, lane);
-		if (t + 1 < nturn)
-			f = cha_fetch(row, W, g_wave, chunk, n_chunks, 64ll * (t + 1), lane);
-		if (i + 64 <= e) {                                        // (the row's last chunk may be short: its tail goes one by one below)
+	if (vec && i + 64 <= e) {
+		cha_line cur = cha_load(&row[i]);
+		for (; i + 64 <= e; i += 64) {
+			const cha_line nxt = cha_load(&row[i + 128 <= e ? i + 64 : i]);
 #pragma unroll
 			for (int q = 0; q < 64; q++)
 				deemph_track<EVEN, D24>(lo, cnt, mask, cha_sample(cur, q), a, xoff, magic, bias);
-			i += 64;
+			cur = nxt;
 		}
 	}
 	for (; i < e; i++)
 		deemph_track<EVEN, D24>(lo, cnt, mask, (int)row[i], a, xoff, magic, bias);
-	if (valid)
-		ctab[c * n_chunks + g] = make_uint4((uint32_t)lo_start, ((uint32_t)lo & 0xffffu) | ((uint32_t)gap << 16), (uint32_t)mask, (uint32_t)(mask >> 32));
+	ctab[c * n_chunks + g] = make_uint4((uint32_t)lo_start, ((uint32_t)lo & 0xffffu) | ((uint32_t)gap << 16), (uint32_t)mask, (uint32_t)(mask >> 32));
 }
 
 __global__ __launch_bounds__(64 * CHA_MAX_SEG) void k_cha_walk(const uint4 *__restrict__ ctab, unsigned n_chunks, const int *__restrict__ audio_in,
@@ -3925,24 +3929,22 @@ __global__ __launch_bounds__(256) void k_cha_replay_rs(const int16_t *__restrict
                                                        int fast, int slow, int ratio, float rinv, const int *__restrict__ audio_in, int *__restrict__ audio_out,
                                                        int16_t *__restrict__ out_rows, u64 out_stride, unsigned cap)
 {
-	extern __shared__ __attribute__((aligned(16))) uint4 cha_dyn[];         // the four waves' stages, then [cap] int16: the workgroup's outputs
-	int16_t *const cha_out = reinterpret_cast<int16_t *>(cha_dyn + 4 * CHA_STAGE_U4);
-	const unsigned tid = threadIdx.x, lane = tid & 63u, g_wave = blockIdx.x * 256u + (tid & ~63u), g = g_wave + lane;
-	uint4 *const stage = cha_dyn + (tid >> 6) * CHA_STAGE_U4;
+	extern __shared__ __attribute__((aligned(16))) int16_t cha_out[];      // [cap] the workgroup's outputs
+	const unsigned tid = threadIdx.x, g = blockIdx.x * 256u + tid;
 	const u64 c = blockIdx.y;
 	const int16_t *row = rows + c * row_stride;
-	const bool staged = ((size_t)row & 15u) == 0 && (chunk & 63u) == 0;
-	const bool valid = g < n_chunks;
-	int v = valid ? chunk_start[c * n_chunks + g] : 0;
+	const bool vec = ((size_t)row & 15u) == 0;
+	const unsigned active = min(256u, n_chunks - blockIdx.x * 256u);
+	int v = tid < active ? chunk_start[c * n_chunks + g] : 0;
 	const u64 p0 = (u64)audio_in[3 * c + 2];
 	// first output of the workgroup: windows that started before its first sample b_wg: the emissions so far, + 1 unless the sample in front emitted
 	const u64 b_wg = (u64)blockIdx.x * 256u * chunk, e_wg = min(W, b_wg + 256ull * chunk);
 	const u64 t_wg = p0 + b_wg * (u64)slow, t_we = p0 + e_wg * (u64)slow;
 	const u64 J0 = b_wg ? t_wg / (u64)fast + ((t_wg % (u64)fast) < (u64)slow ? 0u : 1u) : 0u;
 	const u64 J1 = e_wg < W ? t_we / (u64)fast + ((t_we % (u64)fast) < (u64)slow ? 0u : 1u) : t_we / (u64)fast;   // the row's last window stays unfinished
-	if (g_wave < n_chunks) {                                            // whole waves: the lanes of a wave fetch for each other
+	if (tid < active) {
 		const int h = a / 2, xoff = h + bias * a;
-		const u64 b = (u64)g * chunk, e = valid ? min(W, b + chunk) : b;
+		const u64 b = (u64)g * chunk, e = min(W, b + chunk);
 		const u64 t_b = p0 + b * (u64)slow;
 		unsigned j = (unsigned)(t_b / (u64)fast - J0);                   // index (in the staging) of the window in progress at b ...
 		int p = (int)(t_b % (u64)fast);                                 // ... and the phase in front of sample b
@@ -3961,29 +3963,23 @@ __global__ __launch_bounds__(256) void k_cha_replay_rs(const int16_t *__restrict
 				if (own) cha_out[j] = (int16_t)((first || rinv == 0.0f) ? sum / ratio : (int)((float)sum * rinv)); \
 				j++; sum = 0; own = true; first = false; \
 			} } while (0)
-		const int nturn = staged ? (int)(chunk / 64u) : 0;
-		cha_line f;
-		if (staged)
-			f = cha_fetch(row, W, g_wave, chunk, n_chunks, 0, lane);
-		for (int t = 0; t < nturn; t++) {
-			const cha_line cur = cha_hand_over(stage, f, lane);
-			if (t + 1 < nturn)
-				f = cha_fetch(row, W, g_wave, chunk, n_chunks, 64ll * (t + 1), lane);
-			if (i + 64 <= e) {
+		if (vec && i + 64 <= e) {
+			cha_line cur = cha_load(&row[i]);
+			for (; i + 64 <= e; i += 64) {
+				const cha_line nxt = cha_load(&row[i + 128 <= e ? i + 64 : i]);
 #pragma unroll
 				for (int q = 0; q < 64; q++)
 					CHA_RS_STEP(cha_sample(cur, q));
-				i += 64;
+				cur = nxt;
 			}
 		}
 		for (; i < e; i++)
 			CHA_RS_STEP((int)row[i]);
 		// past the chunk: the window in progress is this thread's to finish (a sample whose predecessor emitted starts the neighbour's)
-		if (valid)
-			for (; i < W && p >= slow; i++)
-				CHA_RS_STEP((int)row[i]);
+		for (; i < W && p >= slow; i++)
+			CHA_RS_STEP((int)row[i]);
 #undef CHA_RS_STEP
-		if (valid && i == W && own) {
+		if (i == W && own) {
 			audio_out[3 * c + 1] = sum;
 			audio_out[3 * c + 2] = p;
 		}
@@ -4916,7 +4912,7 @@ extern "C" unsigned rxk_ch_audio_chunks(u64 W, int warm, unsigned *chunk_out)
 static unsigned cha_rs_cap(unsigned chunk, int fast, int slow)
 {
 	const u64 cap = (256ull * chunk * (u64)slow) / (u64)fast + 4;
-	return 4 * CHA_STAGE_U4 * 16 + cap * 2 <= 65536 ? (unsigned)cap : 0u;   /* the waves' stages (36 KiB) + the outputs: one workgroup's 64 KiB */
+	return cap * 2 <= 40960 ? (unsigned)cap : 0u;
 }
 
 // can the (segment, channel) form serve rows of W samples (deemph on, a in 2..64, carried states inside int16)?  It reads the demodulated rows
@@ -4951,7 +4947,7 @@ extern "C" int rxk_ch_audio_seg(void *stream, const int16_t *in_rows, u64 in_str
 		hipLaunchKernelGGL((k_cha_track<EV, D>), grid, dim3(256), 0, s, in_rows, in_stride, W, a, mg, bias, warm, chunk, n_chunks, audio_in, ctab); \
 		hipLaunchKernelGGL(k_cha_walk, dim3((unsigned)n_channels), dim3(64 * n_seg), (size_t)n_chunks * 20, s, ctab, n_chunks, audio_in, audio_out, seg_start); \
 		if (slow > 0) \
-			hipLaunchKernelGGL((k_cha_replay_rs<EV, D>), grid, dim3(256), (size_t)4 * CHA_STAGE_U4 * 16 + (size_t)cap * 2, s, in_rows, in_stride, W, a, mg, bias, chunk, n_chunks, seg_start, \
+			hipLaunchKernelGGL((k_cha_replay_rs<EV, D>), grid, dim3(256), (size_t)cap * 2, s, in_rows, in_stride, W, a, mg, bias, chunk, n_chunks, seg_start, \
 			                   fast, slow, ratio, rinv, audio_in, audio_out, out_rows, out_stride, cap); \
 		else \
 			hipLaunchKernelGGL((k_cha_replay<EV, D>), grid, dim3(256), 0, s, in_rows, in_stride, W, a, mg, bias, chunk, n_chunks, seg_start, \
