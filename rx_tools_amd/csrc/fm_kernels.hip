@@ -3661,8 +3661,8 @@ __global__ __launch_bounds__(256) void k_ch_audio(
 //   k_cha_track   grid (segments, channels): per thread one chunk -- warm-up on the two extreme trajectories (chunk 0: the carried state),
 //                 lowest candidate + merge mask through the chunk -> a 16-byte table in HBM
 //   k_cha_walk    grid (channels), one wave per segment: the lanes are the (at most 64) candidate start states of the segment's first chunk,
-//                 each walks the segment's tables; one thread chains the segments from the carried state; one lane per segment then walks it
-//                 again from its exact start -> every chunk's start state
+//                 each walks the segment's tables (keeping its state in front of every 32nd); one thread chains the segments from the carried
+//                 state; eight lanes per segment then walk 32 tables each from the true candidate's checkpoints -> every chunk's start state
 //   k_cha_replay  grid (segments, channels): every thread replays its chunk from its exact start -> the de-emphasised row (another buffer than the demodulated one)
 //                 and, with a resampler behind, runs low_pass_real inline on the filtered samples (k_cha_replay_rs): they never go to HBM
 #define CHA_MAX_SEG 8
@@ -3790,60 +3790,68 @@ __global__ __launch_bounds__(64 * CHA_MAX_SEG) void k_cha_walk(const uint4 *__re
                                                                 int *__restrict__ audio_out, int *__restrict__ chunk_start)
 {
 	extern __shared__ __attribute__((aligned(16))) uint4 cha_tab[];      // the channel's n_chunks tables, then n_chunks ints (the chunk starts)
-	__shared__ int seg_end[CHA_MAX_SEG][64];
+	__shared__ int ckpt[CHA_MAX_SEG][9][64];                             // every candidate's state in front of chunks 0, 32, .. 224 of its segment, and behind the last
+	__shared__ int seg_idx[CHA_MAX_SEG];
 	const u64 c = blockIdx.x;
 	const unsigned n_seg = (n_chunks + 255) / 256;
 	for (unsigned i = threadIdx.x; i < n_chunks; i += blockDim.x)
 		cha_tab[i] = ctab[c * n_chunks + i];
 	__syncthreads();
 	const unsigned sgm = threadIdx.x >> 6, k = threadIdx.x & 63;
+	const unsigned g0 = sgm * 256u, g1 = sgm < n_seg ? min(n_chunks, g0 + 256u) : g0;
 	if (sgm < n_seg) {
-		const unsigned g0 = sgm * 256u, g1 = min(n_chunks, g0 + 256u);
 		const uint4 t0 = cha_tab[g0];
 		const int gap = (int)(t0.y >> 16);
 		int v = (int)t0.x + min((int)k, gap);                        // lanes beyond the candidates repeat the last one
 		// four tables requested ahead of the dependent chain (an LDS read's latency is most of a step otherwise)
 		unsigned g = g0;
 		for (; g + 4 <= g1; g += 4) {
+			if (((g - g0) & 31u) == 0)
+				ckpt[sgm][(g - g0) >> 5][k] = v;
 			const uint4 ta = cha_tab[g], tb = cha_tab[g + 1], tc = cha_tab[g + 2], td = cha_tab[g + 3];
 			v = ctab_apply(ta, v); v = ctab_apply(tb, v); v = ctab_apply(tc, v); v = ctab_apply(td, v);
 		}
-		for (; g < g1; g++)
+		for (; g < g1; g++) {
+			if (((g - g0) & 31u) == 0)
+				ckpt[sgm][(g - g0) >> 5][k] = v;
 			v = ctab_apply(cha_tab[g], v);
-		seg_end[sgm][k] = v;
+		}
+		ckpt[sgm][8][k] = v;                                         // the segment's end state for this candidate
 	}
 	__syncthreads();
-	__shared__ int seg_first[CHA_MAX_SEG];
 	if (threadIdx.x == 0) {
 		int v = audio_in[3 * c];
 		for (unsigned sg = 0; sg < n_seg; sg++) {
-			seg_first[sg] = v;
 			const uint4 t0 = cha_tab[sg * 256u];
 			int idx = v - (int)t0.x;
 			const int gap = (int)(t0.y >> 16);
 			idx = idx < 0 ? 0 : (idx > gap ? gap : idx);              // inside [0, gap] by the warm-up's guarantee
-			v = seg_end[sg][idx];
+			seg_idx[sg] = idx;
+			v = ckpt[sg][8][idx];
 		}
 		audio_out[3 * c] = v;
 	}
 	__syncthreads();
-	// every chunk's exact start state, one lane per segment: the replay kernels begin without a serial walk of their own (a workgroup's thread 0
-	// walking 256 tables held its other 255 threads for ten microseconds, four rounds of workgroups per CU)
+	// every chunk's exact start state: the replay kernels begin without a serial walk of their own (a workgroup's thread 0 walking 256 tables
+	// held its other 255 threads for ten microseconds, four rounds of workgroups per CU).  The segment's true candidate is known now, and its
+	// state in front of every 32nd chunk was kept: eight lanes per segment walk 32 tables each
 	int *const st = reinterpret_cast<int *>(cha_tab + n_chunks);       // [n_chunks] behind the tables: the starts leave coalesced
-	if (sgm < n_seg && k == 0) {
-		const unsigned g0 = sgm * 256u, g1 = min(n_chunks, g0 + 256u);
-		int v = seg_first[sgm];
-		unsigned g = g0;
-		for (; g + 4 <= g1; g += 4) {
-			const uint4 ta = cha_tab[g], tb = cha_tab[g + 1], tc = cha_tab[g + 2], td = cha_tab[g + 3];
-			st[g] = v; v = ctab_apply(ta, v);
-			st[g + 1] = v; v = ctab_apply(tb, v);
-			st[g + 2] = v; v = ctab_apply(tc, v);
-			st[g + 3] = v; v = ctab_apply(td, v);
-		}
-		for (; g < g1; g++) {
-			st[g] = v;
-			v = ctab_apply(cha_tab[g], v);
+	if (sgm < n_seg && k < 8) {
+		unsigned g = g0 + 32u * k;
+		const unsigned ge = min(g1, g + 32u);
+		if (g < ge) {
+			int v = ckpt[sgm][k][seg_idx[sgm]];
+			for (; g + 4 <= ge; g += 4) {
+				const uint4 ta = cha_tab[g], tb = cha_tab[g + 1], tc = cha_tab[g + 2], td = cha_tab[g + 3];
+				st[g] = v; v = ctab_apply(ta, v);
+				st[g + 1] = v; v = ctab_apply(tb, v);
+				st[g + 2] = v; v = ctab_apply(tc, v);
+				st[g + 3] = v; v = ctab_apply(td, v);
+			}
+			for (; g < ge; g++) {
+				st[g] = v;
+				v = ctab_apply(cha_tab[g], v);
+			}
 		}
 	}
 	__syncthreads();
