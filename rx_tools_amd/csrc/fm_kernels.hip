@@ -4118,6 +4118,11 @@ static int bias_for(int a) { return 65536 / a + 2; }
 // constant with a SIGNED 24-bit multiply-high (v_mul_hi_i32_i24), so it needs 2^26/a + 1 < 2^23: a >= 9.  One predicate for both.
 static bool deemph_d24(int a) { return a >= 9 && a < 256; }
 static unsigned deemph_magic(int a) { return deemph_d24(a) ? (1u << 26) / (unsigned)a + 1 : magic_for(a); }
+// the kernels that divide only through deemph_div / deemph_mul (k_ch_audio, k_cha_*, k_fm_row_audio) take the two-multiply 24-bit form from a = 5:
+// floor(t / a) == ((t << 6) * (2^26 / a + 1)) >> 32 for every t < 2^18 whenever the constant fits 24 bits UNSIGNED (a >= 5; checked for all t and
+// a = 5 .. 272).  deemph_d24 starts at 9 because the tiled rx_fm kernels' three-instruction step multiplies SIGNED 24-bit operands (de_step).
+static bool deemph_d24u(int a) { return a >= 5 && a < 256; }
+static unsigned deemph_magic_u(int a) { return deemph_d24u(a) ? (1u << 26) / (unsigned)a + 1 : magic_for(a); }
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) l++; return l; }
 
 template <typename K>
@@ -4873,12 +4878,12 @@ extern "C" int rxk_fm_row_audio(void *stream, int16_t *row, unsigned W, int deem
 	if (!W)
 		return 0;
 	hipStream_t s = (hipStream_t)stream;
-	const unsigned mg = deemph ? deemph_magic(a) : 0u;
+	const unsigned mg = deemph ? deemph_magic_u(a) : 0u;
 	const int bias = deemph ? bias_for(a) : 0;
 	const size_t lds = ((size_t)W * 2 + 15) & ~(size_t)15;
 #define GO(EV, D) hipLaunchKernelGGL((k_fm_row_audio<EV, D>), dim3(1), dim3(256), lds, s, row, W, deemph, a, mg, bias, warm, serial, fast, slow, J, audio, \
 		row_h, audio_h, (const uint32_t *)hdr, (uint32_t *)hdr_h, hdr_words)
-	if (deemph && deemph_d24(a)) { if (a & 1) GO(false, true); else GO(true, true); }
+	if (deemph && deemph_d24u(a)) { if (a & 1) GO(false, true); else GO(true, true); }
 	else { if (!deemph || (a & 1)) GO(false, false); else GO(true, false); }
 #undef GO
 	LAUNCH_RET();
@@ -4943,7 +4948,7 @@ extern "C" int rxk_ch_audio_seg(void *stream, const int16_t *in_rows, u64 in_str
 	if (!n_chunks || !rxk_ch_audio_seg_ok(W, warm, fast, slow) || (const int16_t *)out_rows == in_rows)
 		return (int)hipErrorInvalidValue;
 	hipStream_t s = (hipStream_t)stream;
-	const unsigned mg = deemph_magic(a);
+	const unsigned mg = deemph_magic_u(a);
 	const int bias = bias_for(a);
 	const unsigned n_seg = (n_chunks + 255) / 256;
 	const dim3 grid(n_seg, (unsigned)n_channels);
@@ -4960,7 +4965,7 @@ extern "C" int rxk_ch_audio_seg(void *stream, const int16_t *in_rows, u64 in_str
 		else \
 			hipLaunchKernelGGL((k_cha_replay<EV, D>), grid, dim3(256), 0, s, in_rows, in_stride, W, a, mg, bias, chunk, n_chunks, seg_start, \
 			                   audio_in, audio_out, out_rows, out_stride); } while (0)
-	if (deemph_d24(a)) { if (a & 1) GO(false, true); else GO(true, true); }
+	if (deemph_d24u(a)) { if (a & 1) GO(false, true); else GO(true, true); }
 	else { if (a & 1) GO(false, false); else GO(true, false); }
 #undef GO
 	LAUNCH_RET();
@@ -4972,11 +4977,11 @@ extern "C" int rxk_ch_audio(void *stream, int16_t *rows, u64 row_stride, u64 W, 
 	if (!W || !n_channels)
 		return 0;
 	hipStream_t s = (hipStream_t)stream;
-	const unsigned mg = deemph ? deemph_magic(a) : 0u;
+	const unsigned mg = deemph ? deemph_magic_u(a) : 0u;
 	const int bias = deemph ? bias_for(a) : 0;
 #define GO(EV, D) hipLaunchKernelGGL((k_ch_audio<EV, D>), dim3((unsigned)n_channels), dim3(256), 0, s, rows, row_stride, W, deemph, a, mg, bias, warm, serial, \
 		fast, slow, J, audio_in, audio_out, y_rows, y_stride)
-	if (deemph && deemph_d24(a)) { if (a & 1) GO(false, true); else GO(true, true); }
+	if (deemph && deemph_d24u(a)) { if (a & 1) GO(false, true); else GO(true, true); }
 	else { if (!deemph || (a & 1)) GO(false, false); else GO(true, false); }
 #undef GO
 	LAUNCH_RET();

@@ -170,6 +170,9 @@ def oracle_chan_audio(iq, block_len, bin_e, first_bin, n_channels, custom_atan, 
     (8, 32, 2 * 65536, 3, 1, 64, 24000, 12000, 1),        # a at the top of the mask range
     (8, 32, 2 * 16384, 3, 1, 200, 24000, 6000, 1),        # a > 64: one thread per channel
     (8, 16, 2 * 1024, 6, 1, 9, 24000, 8000, 1),           # four windows per block: shorter than any warm-up
+    (8, 24, 2 * 65536, 4, 1, 5, 24000, 8000, 1),          # k_ch_audio at a = 5, 6, 8 (24-bit division from a = 5)
+    (8, 24, 2 * 65536, 4, 1, 6, 24000, 12000, 1),
+    (8, 24, 2 * 65536, 4, 1, 8, 24000, -1, 1),
 ])
 def test_channeliser_per_channel_audio_stages(bin_e, n_channels, block_len, n_blocks, deemph, a, rate_out, rate_out2, custom_atan):
     from gpu_support import to_dev, torch_cuda
@@ -252,6 +255,9 @@ def test_channeliser_async_runs_chain_their_carries_on_the_device(custom_atan, f
     (5, 20, 2 * 131072, 8, 19, 240000, 32000, 1, 0),      # 16384-sample rows, a = 19
     (4, 6, 2 * 64, 802, 2, 19531, 8000, 1, 0),            # 1604-sample rows of a scratch whose odd rows sit off the 16-byte grid: the sample-by-sample loops
     (4, 6, 2 * 65536, 6, 7, 48000, 32000, 1, 3),          # ratio 1 (two outputs per three samples): the most outputs a workgroup can stage
+    (4, 8, 2 * 65536, 6, 5, 24000, 8000, 1, 0),           # a = 5, 6, 8: the smallest that take the two-multiply 24-bit division (odd and even step)
+    (4, 8, 2 * 65536, 6, 6, 24000, 12000, 1, 0),
+    (4, 8, 2 * 65536, 6, 8, 24000, -1, 1, 0),
 ])
 def test_channeliser_audio_stages_segmented(bin_e, n_channels, block_len, n_blocks, a, rate_out, rate_out2, custom_atan, pad, monkeypatch):
     """the (segment, channel) form of the per-channel audio stages == the oracle (and the reference where built), across a run boundary,

@@ -333,6 +333,7 @@ FAST_BLOCK_PARAMS = [
     dict(downsample=30, deemph_a=64), dict(downsample=30, deemph_a=65), dict(downsample=50, deemph_a=1), dict(downsample=118, deemph_a=200, custom_atan=1),
     dict(downsample=118, deemph=0), dict(downsample=40, rate_out2=-1), dict(downsample=40, deemph=0, rate_out2=-1, custom_atan=1),
     dict(downsample=25, rate_out=96000, rate_out2=48000, deemph_a=7), dict(downsample=1000, custom_atan=1), dict(downsample=2000, custom_atan=0),
+    dict(downsample=20, deemph_a=5), dict(downsample=20, deemph_a=6, custom_atan=1), dict(downsample=12, deemph_a=8),     # the 24-bit division's smallest a
 ]
 
 
