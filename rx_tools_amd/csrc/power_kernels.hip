@@ -867,6 +867,63 @@ __global__ __launch_bounds__(256) void k_pwm_head_mid(uint32_t *__restrict__ scr
 		x[(size_t)r << F] = v[r];
 }
 
+// N >= 2^17 needs two radix-16 passes in front of the tail: done by k_pwm_head + k_pwm_head_mid the block crosses HBM twice between them
+// (pass 0 out, pass 1 in).  Here both run in one launch: a thread takes the 16 values of pass 0 for TWO neighbouring columns (8-byte loads:
+// sixteen threads cover a whole 128-byte line), the workgroup -- 16 values of the pass-1 field x 32 columns that share everything above
+// and below it -- transposes 16 x 16 per column through LDS (pass 0 leaves a thread the top-field values of one pass-1 field value, pass 1
+// wants the pass-1 field values of one top-field value), pass 1, natural-order store.  One trip through the scratch copy less.
+template <int M>
+__global__ __launch_bounds__(256) void k_pwm_head2(const int16_t *__restrict__ in, size_t tune_stride, size_t pass_stride, int tunes, int nbpt,
+                                                  const int *__restrict__ window, const uint32_t *__restrict__ twiddle, const int *__restrict__ dc,
+                                                  size_t q0, size_t nq, uint32_t *__restrict__ scratch)
+{
+	typedef fft_geom<M> G;
+	constexpr int N = 1 << M, TPF = N / 16, F1 = G::f(1);           // F1 = M - 8: the bits below the pass-1 field
+	static_assert(M >= 17 && F1 >= 5, "two head passes: N >= 2^17");
+	constexpr unsigned WGB = (1u << F1) / 32u;                      // workgroups per block: 32 columns each
+	constexpr int MAT = 16 * 17 + 1;                                // a column's 16 x 16 matrix, rows padded to 17, matrices one dword apart
+	__shared__ uint32_t xch[32 * MAT];
+	const size_t ql = blockIdx.x / WGB;
+	if (ql >= nq)
+		return;
+	const unsigned a = threadIdx.x >> 4, l = threadIdx.x & 15u;
+	const unsigned low = (blockIdx.x % WGB) * 32u + 2u * l;         // this thread's two columns: low, low + 1
+	const size_t q = q0 + ql, pt = q / (size_t)nbpt;
+	const int blk = (int)(q - pt * (size_t)nbpt);
+	const size_t pass = pt / (size_t)tunes, tune = pt - pass * (size_t)tunes;
+	const uint32_t *buf = (const uint32_t *)(in + pass * pass_stride + tune * tune_stride) + (size_t)blk * N;
+	const uint32_t ave = pw_pack(dc[2 * pt], dc[2 * pt + 1]);
+	const unsigned tq = (a << F1) | low;                            // pass 0: a = the pass-1 field's value; pass 1: a = the top field's
+	uint32_t v0[16], v1[16];
+#pragma unroll
+	for (int r = 0; r < 16; r++) {
+		const uint2 x = *reinterpret_cast<const uint2 *>(buf + tq + r * TPF);
+		const int2 w = *reinterpret_cast<const int2 *>(window + tq + r * TPF);
+		const uint32_t c0 = (uint32_t)w.x & 0xffffu, c1 = (uint32_t)w.y & 0xffffu;
+		v0[r] = pw_pk_mul(pw_pk_sub(x.x, ave), c0 | (c0 << 16));     // remove_dc + window, rtl_power.c:744-758
+		v1[r] = pw_pk_mul(pw_pk_sub(x.y, ave), c1 | (c1 << 16));
+	}
+	fft_pass<M, 0>(v0, twiddle, tq);
+	fft_pass<M, 0>(v1, twiddle, tq + 1);
+#pragma unroll
+	for (int r = 0; r < 16; r++) {
+		xch[(2 * l) * MAT + a * 17 + r] = v0[r];
+		xch[(2 * l + 1) * MAT + a * 17 + r] = v1[r];
+	}
+	__syncthreads();
+#pragma unroll
+	for (int r = 0; r < 16; r++) {
+		v0[r] = xch[(2 * l) * MAT + r * 17 + a];
+		v1[r] = xch[(2 * l + 1) * MAT + r * 17 + a];
+	}
+	fft_pass<M, 1>(v0, twiddle, tq);
+	fft_pass<M, 1>(v1, twiddle, tq + 1);
+	uint32_t *dst = scratch + (ql << M) + ((size_t)a << (M - 4)) + low;
+#pragma unroll
+	for (int r = 0; r < 16; r++)
+		*reinterpret_cast<uint2 *>(dst + ((size_t)r << F1)) = make_uint2(v0[r], v1[r]);
+}
+
 // the passes H .. P-1 of one thread's 16 values, an LDS transpose between two of them.  The thread's twiddles (15 per pass) do not
 // change from one block of the launch to the next: they are loaded ONCE, in front of the pass loop, into twr[PASS - H] (round 4; they
 // used to be 15 global loads per pass and block, waited for right behind each barrier)
@@ -1014,16 +1071,23 @@ extern "C" int rxk_pw_fft_mid(void *stream, const int16_t *in, size_t tune_strid
 #define TAIL(MM, HH) do { \
 		if (peak_hold) hipLaunchKernelGGL((k_pwm_tail<MM, true, HH>), dim3(wg_x, (unsigned)groups), dim3(256), 0, s, scratch, tunes, nbpt, p0, np, ppg, tw2, (i64 *)avg, part); \
 		else hipLaunchKernelGGL((k_pwm_tail<MM, false, HH>), dim3(wg_x, (unsigned)groups), dim3(256), 0, s, scratch, tunes, nbpt, p0, np, ppg, tw2, (i64 *)avg, part); } while (0)
+		/* N >= 2^17: the first two passes in one launch (k_pwm_head2; $RXGPU_FFT_HEAD2=0: one launch each, the round-3 form, A/B and tests) */
+		const char *h2 = rxgpu_knob("RXGPU_FFT_HEAD2");
+		const bool head2 = !(h2 && h2[0] == '0') && (((size_t)in & 7u) | (tune_stride & 3u) | (pass_stride & 3u)) == 0;   /* its 8-byte loads */
+#define HEAD2(MM) hipLaunchKernelGGL((k_pwm_head2<MM>), dim3((unsigned)(nq * ((n >> 8) / 32))), dim3(256), 0, s, in, tune_stride, pass_stride, tunes, nbpt, window, tw2, dc, q0, nq, scratch)
+#define HEAD01(MM) do { if (head2) HEAD2(MM); else { HEAD0(MM); HEADN(MM, 1); } } while (0)
 		switch (bin_e) {
 		case 14: HEAD0(14); TAIL(14, 1); break;
 		case 15: HEAD0(15); TAIL(15, 1); break;
 		case 16: HEAD0(16); TAIL(16, 1); break;
-		case 17: HEAD0(17); HEADN(17, 1); TAIL(17, 2); break;
-		case 18: HEAD0(18); HEADN(18, 1); TAIL(18, 2); break;
-		case 19: HEAD0(19); HEADN(19, 1); TAIL(19, 2); break;
-		case 20: HEAD0(20); HEADN(20, 1); TAIL(20, 2); break;
-		default: HEAD0(21); HEADN(21, 1); HEADN(21, 2); TAIL(21, 3); break;
+		case 17: HEAD01(17); TAIL(17, 2); break;
+		case 18: HEAD01(18); TAIL(18, 2); break;
+		case 19: HEAD01(19); TAIL(19, 2); break;
+		case 20: HEAD01(20); TAIL(20, 2); break;
+		default: HEAD01(21); HEADN(21, 2); TAIL(21, 3); break;
 		}
+#undef HEAD01
+#undef HEAD2
 #undef TAIL
 #undef HEADN
 #undef HEAD0

@@ -272,6 +272,20 @@ def test_large_transform_paths_agree(rng, monkeypatch):
     assert np.array_equal(a, b) and np.array_equal(sa, sb)
 
 
+@pytest.mark.parametrize("rng", ["100M:102M:20", "100M:102.8M:20", "100M:102.8M:2"])
+def test_two_head_passes_in_one_launch_or_two(rng, monkeypatch):
+    """N = 2^17, 2^18, 2^21: the first two radix-16 passes fused (k_pwm_head2, the default) and as a launch each through the scratch copy
+    ($RXGPU_FFT_HEAD2=0, round 3's form) are the same fix_fft -- identical avg[] (both equal to the oracle in test_scan_bit_exact)"""
+    plan = R.plan_range(rng, 0.0, 1)
+    n = 1 << plan.bin_e
+    wc, sw = R.window_coefs("blackman", n), R.sine_table(plan.bin_e)
+    data = sig_noise(2 * plan.buf_len, seed=11, amp=32768)
+    a, sa = gpu_scan(data, 2, 1, plan, wc, sw, 1, 0, 0)
+    monkeypatch.setenv("RXGPU_FFT_HEAD2", "0")
+    b, sb = gpu_scan(data, 2, 1, plan, wc, sw, 1, 0, 0)
+    assert np.array_equal(a, b) and np.array_equal(sa, sb)
+
+
 def test_gather_of_no_tunes_is_a_noop():
     L = R.lib()
     R.check(L.rxgpu_init(0))
