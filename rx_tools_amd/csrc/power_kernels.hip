@@ -1003,10 +1003,13 @@ __global__ __launch_bounds__(256) void k_pwm_tail(const uint32_t *__restrict__ s
 	}
 	(void)p0;
 	if (partial) {
-		i64 *dst = partial + ((((size_t)blockIdx.y * tunes + tune) * (size_t)nbpt + blk) << M);
+		// in the ORDER THE THREADS HOLD THEM (thread tq's sixteen values side by side: whole 128-byte lines) -- k_pwm_reduce<true> applies the bit
+		// reversal when it folds the groups into avg.  Stored at their bins, a workgroup's values lie N/4096 bins apart: 8-byte pieces of as many
+		// lines, which cost the write path four times their bytes (PMC: 268 MB written per 67 MB of spectra at N = 2^14)
+		i64 *dst = partial + ((((size_t)blockIdx.y * tunes + tune) * (size_t)nbpt + blk) << M) + ((size_t)tq << 4);
 #pragma unroll
-		for (int r = 0; r < 16; r++)
-			dst[__brev((tq << 4) | (unsigned)r) >> (32 - M)] = acc[r];
+		for (int r = 0; r < 16; r += 2)
+			*reinterpret_cast<longlong2 *>(dst + r) = make_longlong2(acc[r], acc[r + 1]);
 		return;
 	}
 	i64 *avg_t = avg + ((size_t)tune << M);
@@ -1020,12 +1023,16 @@ __global__ __launch_bounds__(256) void k_pwm_tail(const uint32_t *__restrict__ s
 
 // avg[tune][bin] (+= | max=) over the groups and blocks of partial: x over (tune, bin), y over 16 slices of the groups (a thread's
 // loads are independent and coalesced across the workgroup; 16 atomics per bin instead of one per pass)
+// PERM: partial holds every spectrum in the tail kernel's thread order (entry i = the value of bin bit_reverse(i)): thread i still reads entry i of
+// every group -- coalesced -- and the permutation goes into the ONE atomic per bin and launch
+template <bool PERM>
 __global__ void k_pwm_reduce(const i64 *__restrict__ partial, int tunes, int nbpt, int groups, int bin_e, int peak_hold, i64 *__restrict__ avg)
 {
 	const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (gid >= ((size_t)tunes << bin_e))
 		return;
 	const size_t tune = gid >> bin_e, bin = gid & (((size_t)1 << bin_e) - 1);
+	const size_t out = PERM ? (tune << bin_e) + (size_t)(__brev((unsigned)bin) >> (32 - bin_e)) : gid;
 	const int per = (groups + (int)gridDim.y - 1) / (int)gridDim.y, g0 = (int)blockIdx.y * per, g1 = min(groups, g0 + per);
 	i64 a = 0;
 	bool any = false;
@@ -1037,8 +1044,8 @@ __global__ void k_pwm_reduce(const i64 *__restrict__ partial, int tunes, int nbp
 		}
 	if (!any)
 		return;
-	if (peak_hold) atomicMax((long long *)&avg[gid], a);
-	else if (a) atomicAdd((unsigned long long *)&avg[gid], (unsigned long long)a);
+	if (peak_hold) atomicMax((long long *)&avg[out], a);
+	else if (a) atomicAdd((unsigned long long *)&avg[out], (unsigned long long)a);
 }
 
 // eff_len a multiple of 2^(bin_e+1), bin_e = 14 .. 21; scratch: cap_blocks * 2^bin_e dwords; dc: 2 ints per (pass, tune)
@@ -1092,7 +1099,7 @@ extern "C" int rxk_pw_fft_mid(void *stream, const int16_t *in, size_t tune_strid
 #undef HEADN
 #undef HEAD0
 		if (part)
-			hipLaunchKernelGGL(k_pwm_reduce, dim3((unsigned)((((size_t)tunes << bin_e) + 255) / 256), 16), dim3(256), 0, s, part, tunes, nbpt, groups, bin_e,
+			hipLaunchKernelGGL(k_pwm_reduce<true>, dim3((unsigned)((((size_t)tunes << bin_e) + 255) / 256), 16), dim3(256), 0, s, part, tunes, nbpt, groups, bin_e,
 			                   peak_hold, (i64 *)avg);
 	}
 	LAUNCH_RET();
@@ -1145,7 +1152,7 @@ extern "C" int rxk_pw_fft(void *stream, const int16_t *in, size_t tune_stride, s
 		if (nb == 1) GO4K(1); else if (nb == 2) GO4K(2); else GO4K(4);
 #undef GO4K
 		if (part)
-			hipLaunchKernelGGL(k_pwm_reduce, dim3((unsigned)((((size_t)tunes << bin_e) + 255) / 256), 16), dim3(256), 0, s, part, tunes, 1, groups, bin_e,
+			hipLaunchKernelGGL(k_pwm_reduce<false>, dim3((unsigned)((((size_t)tunes << bin_e) + 255) / 256), 16), dim3(256), 0, s, part, tunes, 1, groups, bin_e,
 			                   peak_hold, (i64 *)avg);
 		LAUNCH_RET();
 	}
@@ -1167,7 +1174,7 @@ extern "C" int rxk_pw_fft(void *stream, const int16_t *in, size_t tune_stride, s
 		}
 #undef GOR
 		if (part)
-			hipLaunchKernelGGL(k_pwm_reduce, dim3((unsigned)((((size_t)tunes << bin_e) + 255) / 256), 16), dim3(256), 0, s, part, tunes, fpw, groups, bin_e,
+			hipLaunchKernelGGL(k_pwm_reduce<false>, dim3((unsigned)((((size_t)tunes << bin_e) + 255) / 256), 16), dim3(256), 0, s, part, tunes, fpw, groups, bin_e,
 			                   peak_hold, (i64 *)avg);
 		LAUNCH_RET();
 	}
