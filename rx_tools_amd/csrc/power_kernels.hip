@@ -1098,9 +1098,13 @@ extern "C" int rxk_pw_fft_mid(void *stream, const int16_t *in, size_t tune_strid
 #undef TAIL
 #undef HEADN
 #undef HEAD0
-		if (part)
-			hipLaunchKernelGGL(k_pwm_reduce<true>, dim3((unsigned)((((size_t)tunes << bin_e) + 255) / 256), 16), dim3(256), 0, s, part, tunes, nbpt, groups, bin_e,
-			                   peak_hold, (i64 *)avg);
+		if (part) {
+			/* the permuted fold ends in SCATTERED atomics (bit-reversed bins): one slice of the groups per 2^18 of them -- sixteen slices of a
+			 * 2^18-point spectrum were 4 M scattered atomics per launch and cost more than the linear stores had saved */
+			const unsigned slices = bin_e >= 18 ? 1u : (16u >> (bin_e > 14 ? bin_e - 14 : 0));
+			hipLaunchKernelGGL(k_pwm_reduce<true>, dim3((unsigned)((((size_t)tunes << bin_e) + 255) / 256), slices), dim3(256), 0, s, part, tunes, nbpt, groups,
+			                   bin_e, peak_hold, (i64 *)avg);
+		}
 	}
 	LAUNCH_RET();
 }
