@@ -264,9 +264,25 @@ template <int M, int PASS> __host__ __device__ constexpr int fft_skew()
 	return (fft_geom<M>::f(PASS + 1) == 0 && (fft_geom<M>::f(PASS) == 3 || fft_geom<M>::f(PASS) == 4)) ? 8 : 4;
 }
 
+// the same choice by the number of threads that exchange with each other (k_pwm_tail: a SUB-transform of the large transform; its threads are
+// an aligned run of lanes of one wave when there are at most 64 of them)
+template <int THREADS>
+__device__ __forceinline__ void fft_sync_n()
+{
+	static_assert(THREADS > 64 || 64 % THREADS == 0, "the exchanging threads must be an aligned run of lanes of one wave");
+	if constexpr (THREADS <= 64) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	} else {
+		__syncthreads();
+	}
+}
+
 // LDS transpose between the layouts of pass PASS and PASS+1.  row0 (a multiple of 8): the first row of the transform that `lds` holds --
 // a workgroup that owns rows row0 .. of a larger transform (k_pwm_tail) passes its own area and its first row
-template <int M, int PASS>
+// XT: threads that exchange with each other (default: the whole transform's N/16)
+template <int M, int PASS, int XT = (1 << M) / 16>
 __device__ __forceinline__ void fft_exchange(uint32_t (&v)[16], uint32_t *__restrict__ lds, unsigned tq, unsigned row0 = 0)
 {
 	typedef fft_geom<M> G;
@@ -278,7 +294,7 @@ __device__ __forceinline__ void fft_exchange(uint32_t (&v)[16], uint32_t *__rest
 		const unsigned col = (n >> F2) & 15u;
 		lds[row * G::ROW + (row >> 3) * SK + col] = v[r];
 	}
-	fft_sync<M>();
+	fft_sync_n<XT>();
 	const unsigned tl = tq - row0;
 #pragma unroll
 	for (int c = 0; c < 4; c++) {

@@ -976,15 +976,19 @@ __device__ __forceinline__ void pwm_tail_twiddles(uint32_t (&twr)[fft_geom<M>::P
 	if constexpr (PASS + 1 < fft_geom<M>::P)
 		pwm_tail_twiddles<M, PASS + 1, H>(twr, tw, tq);
 }
+// A sub-transform has N / 16^(H+1) threads; they only ever exchange with each other (the later passes pair indices inside the sub-transform, and
+// fft_exchange's rows are the rows of the threads that read them next).  With at most 64 of them -- N = 2^14, 2^17, 2^18, 2^21 -- they are lanes of
+// ONE wave and the four waves of the workgroup need not wait for each other three times per transform: wave-level ordering instead of s_barrier.
 template <int M, int PASS, int H>
 __device__ __forceinline__ void pwm_tail_passes(uint32_t (&v)[16], uint32_t *lds, const uint32_t (&twr)[fft_geom<M>::P - H][15], unsigned tq, unsigned row0, bool first)
 {
 	typedef fft_geom<M> G;
+	constexpr int XT = ((1 << M) >> (4 * H)) / 16;
 	if (!first)
-		__syncthreads();                                             // the transpose area: the reads of the pass before
+		fft_sync_n<XT>();                                            // the transpose area: the reads of the pass before
 	fft_pass_regs<M, PASS>(v, twr[PASS - H]);
 	if constexpr (PASS + 1 < G::P) {
-		fft_exchange<M, PASS>(v, lds, tq, row0);
+		fft_exchange<M, PASS, XT>(v, lds, tq, row0);
 		pwm_tail_passes<M, PASS + 1, H>(v, lds, twr, tq, row0, false);
 	}
 }
@@ -1035,7 +1039,7 @@ __global__ __launch_bounds__(256) void k_pwm_tail(const uint32_t *__restrict__ s
 			for (int x = 0; x < 16; x++)
 				nxt[x] = src[(size_t)x << F];
 		}
-		__syncthreads();                                             // the previous transform's reads of the transpose area
+		fft_sync_n<((1 << M) >> (4 * H)) / 16>();                      // the previous transform's reads of the transpose area
 		pwm_tail_passes<M, H, H>(v, lds, twr, tq, row0, true);
 #pragma unroll
 		for (int r = 0; r < 16; r++) {
