@@ -507,6 +507,167 @@ __global__ __launch_bounds__(256) void k_fm_decimate_small(
 	}
 }
 
+// ------------------------------------------------------------------ F0+F1+F2+F5/F6 for small decimation, a lane owns whole windows
+//
+// The barrier-free form of the kernel above (round 6).  A lane owns L = W * ds consecutive samples -- W = 2 windows for even ds, 4 for
+// odd, so that L is a whole number of 16-byte vectors -- starting at the 16-byte boundary A(G) = L G - p0 + RP, RP = p0 % 4: the
+// rotation phase of every register (rotate16_90, rtl_fm.c:309-327: position mod 4) and its place in a window are compile-time constants.
+// A wave brings a tile of 64 L samples in with NP = L / 4 LDS-DMA instructions (whole lines, wave-private LDS, no barrier anywhere),
+// every lane reads its NP vectors with ds_read_b128 (lane stride 4 NP dwords: conflict-free for odd NP), scales them with scale_pk and adds
+// them straight into W + 1 packed accumulators: the head of window W G (its first RP samples sit in the lane to the left), W - 1 whole
+// windows, and the RP samples at the end that begin window W (G + 1).  That tail and the lane's last window travel one lane to the right
+// (wave_shr:1) to complete the neighbour's first window and to be its discriminator's predecessor; what crosses a tile goes through two
+// SGPRs, and the first lane of a wave's first tile is a halo lane (1 / (64 tw) of the input read twice).  A lane stores its W consecutive
+// int16 results in one 4- or 8-byte store (never across a 16-byte unit of the tiled layout).  What this kernel cannot know stays with
+// k_fm_disc(sparse, seams = 2) exactly as for k_fm_decimate_small: the run's first two outputs, every block's libm sample, the carries.
+#define DL_HALO 8
+template <int DS> struct dl_geom {
+	static constexpr int W = (DS & 1) ? 4 : 2, L = W * DS, NP = L / 4;
+	// tiles in flight per wave (the ring of LDS stages): two while a workgroup's ring stays within 64 KiB
+	static constexpr int NS = NP <= 8 ? 2 : 1;
+};
+
+// s_waitcnt vmcnt takes an immediate; the ring below needs one of three values per (NS, NP)
+template <int N>
+__device__ __forceinline__ void dl_wait_vm()
+{
+	asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
+
+// NS: depth of the wave's ring of LDS stages = tiles in flight per wave
+template <bool ROTATE, int DS, int RP, int NS = dl_geom<DS>::NS>
+__global__ __launch_bounds__(256) void k_fm_decimate_lane(const uint32_t *__restrict__ iq, u64 T, int p0, u64 M, int16_t *__restrict__ pcm, int pcm_chl2,
+                                                          unsigned tw, unsigned n_waves, int g_a)
+{
+	constexpr int W = dl_geom<DS>::W, L = dl_geom<DS>::L, NP = dl_geom<DS>::NP;
+	static_assert(RP < DS && RP < 4, "the head of a lane's first window lies in the lane itself");
+	static_assert((NS - 1) * NP + NS < 64, "vmcnt is a 6-bit counter");
+	extern __shared__ __attribute__((aligned(16))) u32x4 dl_stage[];       // [4][NS][64 * NP] (+ the launcher's occupancy pad)
+	const unsigned lane = threadIdx.x & 63u;
+	const unsigned wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const unsigned per = gridDim.x >> 3;                     // XCD-contiguous order, as everywhere: the pieces of a line of the tiled pcm meet in one L2
+	const unsigned wgi = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+	const unsigned wave_id = wgi * 4u + wv;
+	if (wave_id >= n_waves)
+		return;
+	u32x4 *const ring = dl_stage + wv * (NS * 64 * NP);
+	const scale_k K = scale_consts();
+	// the wave's lanes: G0 .. G0 + 64 tw - 1, the first DL_HALO of them halo lanes (their results belong to the wave before; one would do, eight
+	// keep every wave's first lane at g_a mod 8 -- the lane number at which a tile starts on a 128-byte line, see dl_launch)
+	const i64 G0 = (i64)wave_id * (i64)(64u * tw - DL_HALO) + (g_a - DL_HALO);
+	const i64 Gtot = (i64)((M + W - 1) / W);
+	const i64 T4 = (i64)T - 4;
+	// tiles this wave walks: while the tile's first lane exists (the launcher's n_waves guarantees the first one does, and a tile's first
+	// non-halo lane always stores -- the vmcnt arithmetic below counts ONE store instruction per tile)
+	const i64 left = Gtot - G0;
+	const unsigned nt = left >= (i64)(64u * tw) ? tw : (unsigned)((left + 63) >> 6);
+
+	auto fetch = [&](i64 G, unsigned sidx) {
+		const i64 A = L * G - p0 + RP;
+		u32x4 *const stage = ring + sidx * (64 * NP);
+		if (A >= 0 && A + 64 * L <= (i64)T) {                // an inner tile: one uniform base, the lane's offset a constant
+			const uint32_t *base = iq + A;
+#pragma unroll
+			for (int h = 0; h < NP; h++)
+				__builtin_amdgcn_global_load_lds((const void *)(base + 4 * (64 * h + (int)lane)), (__attribute__((address_space(3))) void *)(stage + 64 * h), 16, 0, 2);
+		} else {                                             // the run's two ends: vectors outside it repeat its first / last one; they only reach
+#pragma unroll                                               // windows that k_fm_disc writes (the first two) or that do not exist (past M)
+			for (int h = 0; h < NP; h++) {
+				i64 sp = A + 4 * (64 * h + (int)lane);
+				sp = sp < 0 ? 0 : (sp > T4 ? T4 : sp);
+				__builtin_amdgcn_global_load_lds((const void *)(iq + sp), (__attribute__((address_space(3))) void *)(stage + 64 * h), 16, 0, 2);
+			}
+		}
+	};
+
+	const unsigned tile_mask = pcm_chl2 ? ((64u << pcm_chl2) - 1u) : 0u;
+	const unsigned keep = ~tile_mask | 7u;
+	uint32_t carry_t = 0, carry_a = 0;                       // the tail and the last window of the lane left of lane 0
+	i64 G = G0;
+#pragma unroll
+	for (int k = 0; k < NS; k++)
+		if ((unsigned)k < nt)
+			fetch(G0 + 64 * k, (unsigned)k);
+	unsigned sidx = 0;
+#pragma unroll 1
+	for (unsigned it = 0; it < nt; it++, G += 64) {
+		// VMEM instructions retire in issue order.  Behind tile it's NP loads were issued: the loads of tiles it+1 .. it+NS-1 and one store
+		// per tile computed since -- min(it, NS) of them; at the end of the walk, where fewer tiles are in flight, wait for everything.
+		if (it + NS <= nt) {
+			if (it >= NS) dl_wait_vm<(NS - 1) * NP + NS>(); else dl_wait_vm<(NS - 1) * NP>();
+		} else {
+			dl_wait_vm<0>();
+		}
+		u32x4 raw[NP];
+		const u32x4 *const stage = ring + sidx * (64 * NP);
+#pragma unroll
+		for (int j = 0; j < NP; j++)
+			raw[j] = stage[NP * lane + j];
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		// the stage is free as soon as its vectors sit in registers: tile it + NS goes into it
+		if (it + NS < nt)
+			fetch(G + 64 * NS, sidx);
+		sidx = sidx + 1 == NS ? 0 : sidx + 1;
+		uint32_t acc[W + 1];
+#pragma unroll
+		for (int k = 0; k <= W; k++)
+			acc[k] = 0;
+#pragma unroll
+		for (int j = 0; j < NP; j++) {
+			uint32_t x[4];
+			dec_contrib<false, ROTATE>(raw[j], x[0], x[1], x[2], x[3], K);
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				constexpr int H = DS - RP;                       // samples of the lane's first window that lie in the lane
+				const int pos = 4 * j + q, seg = pos < H ? 0 : (pos - H) / DS + 1;
+				// the first sample of a segment starts its sum
+				const bool first = pos == 0 || pos == H || (pos > H && (pos - H) % DS == 0);
+				acc[seg] = first ? x[q] : pk_add(acc[seg], x[q]);
+			}
+		}
+		uint32_t a[W];
+		if (RP)
+			a[0] = pk_add(acc[0], (uint32_t)__builtin_amdgcn_update_dpp((int)carry_t, (int)acc[W], 0x138, 0xf, 0xf, false));   // wave_shr:1, lane 0 keeps the carry
+		else
+			a[0] = acc[0];
+#pragma unroll
+		for (int k = 1; k < W; k++)
+			a[k] = acc[k];
+		const uint32_t pred = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_a, (int)a[W - 1], 0x138, 0xf, 0xf, false);
+		if (RP)
+			carry_t = (uint32_t)__builtin_amdgcn_readlane((int)acc[W], 63);
+		carry_a = (uint32_t)__builtin_amdgcn_readlane((int)a[W - 1], 63);
+		// |lowpassed| <= 128 ds: for ds <= 16 the discriminator's denominator stays below 2^24
+		int r[W];
+#pragma unroll
+		for (int k = 0; k < W; k++) {
+			int cr, cj;
+			mul_conj_pk(a[k], k ? a[k - 1] : pred, cr, cj);
+			r[k] = fast_atan2_dev<(DS <= 16)>(cj, cr);
+		}
+		// results W (G + lane) .. + W - 1; tiled layout: the bits above a tile pass through (keep), so a wave that runs into the next tile lands there
+		const i64 Mt = W * G;                                // uniform; -W for the run's very first (halo) lane
+		const i64 Bt = Mt & ~(i64)tile_mask;
+		const unsigned mt = (unsigned)(Mt - Bt) + W * lane;
+		const i64 m0 = Mt + (i64)(W * lane);
+		unsigned idx = mt;
+		if (pcm_chl2) {
+			idx = mt & keep;
+			idx |= __builtin_amdgcn_ubfe(mt, 3u, (unsigned)pcm_chl2 - 3u) << 9;
+			idx |= __builtin_amdgcn_ubfe(mt, (unsigned)pcm_chl2, 6u) << 3;
+		}
+		int16_t *dst = pcm + Bt + idx;
+		// not the halo lane, not the lanes past the run's last window; a last lane that holds fewer than W windows stores W all the same (the
+		// buffer ends in a spare tile, nothing reads past M): one store instruction per tile, whatever the lane
+		if ((it > 0 || lane >= DL_HALO || wave_id == 0) && m0 >= 0 && m0 < (i64)M) {
+			if constexpr (W == 2)
+				*reinterpret_cast<uint32_t *>(dst) = (uint32_t)(uint16_t)r[0] | ((uint32_t)(uint16_t)r[1] << 16);
+			else
+				*reinterpret_cast<uint2 *>(dst) = make_uint2((uint32_t)(uint16_t)r[0] | ((uint32_t)(uint16_t)r[1] << 16), (uint32_t)(uint16_t)r[2] | ((uint32_t)(uint16_t)r[3] << 16));
+		}
+	}
+}
+
 
 // One sample, scaled and rotated by its position in its block (exact int)
 template <bool PRESCALED>
@@ -4034,9 +4195,60 @@ extern "C" int rxk_fm_decimate(void *stream, const int16_t *iq, u64 T, int ds, i
 	LAUNCH_RET();
 }
 
+// k_fm_decimate_lane takes ds = 4 .. 12 and the even ds up to 32 (NP <= 16 vectors per lane; an odd ds needs W = 4 windows per lane, 4 ds registers
+// of raw samples: those stay with k_fm_decimate_small).  A/B in one process, pipelined 4 GiB steps (profiles/r06_ab_dec_lane.txt): level with
+// k_fm_decimate_small at ds = 5 / 6, +1..5 % at 4 / 7 / 8 / 9, +13..37 % at 10 / 11 / 12 (where the LDS-staged kernel has no unrolled window sum).
+// $RXGPU_DL_TW: tiles a wave walks (default 4), $RXGPU_DL_LDS: LDS a workgroup asks for -- the occupancy cap that leaves wave slots to the
+// audio stages of the run before (default 52000: three workgroups per CU), $RXGPU_DEC_LANE=0: k_fm_decimate_small (A/B, tests).
+static bool dl_takes(int ds) { return ds >= 4 && (ds <= 12 || (ds <= 32 && !(ds & 1))); }
+
+template <bool RT, int DS>
+static void dl_launch(hipStream_t s, const uint32_t *iq, u64 T, int p0, u64 M, int16_t *pcm, int pcm_chl2)
+{
+	constexpr int W = dl_geom<DS>::W, NP = dl_geom<DS>::NP, NS = dl_geom<DS>::NS;
+	static_assert((size_t)4 * NS * 64 * NP * 16 <= 65536, "the ring of a workgroup fits the default dynamic LDS limit");
+	const char *e = rxgpu_knob("RXGPU_DL_TW");
+	const unsigned tw = e && atoi(e) >= 1 && atoi(e) <= 4096 ? (unsigned)atoi(e) : 4u;
+	// a tile starts at sample L G - p0 + RP = 4 (NP G - c), c = (p0 - RP) / 4: on a 128-byte line iff NP G == c (mod 8).  Odd NP: one lane
+	// number g_a mod 8 does it for every tile of every wave; even NP: the g_a that leaves the fewest low bits (A/B: 3.5 % of the kernel)
+	const int c = (p0 - (p0 & 3)) / 4;
+	int g_a = 0, best = -1;
+	for (int g = 0; g < 8; g++) {
+		const int d = ((NP * g - c) % 8 + 8) % 8, z = d == 0 ? 3 : __builtin_ctz((unsigned)d);
+		if (z > best) { best = z; g_a = g; }
+	}
+	const u64 lanes = (M + W - 1) / W, per_wave = 64ull * tw - DL_HALO;
+	const unsigned n_waves = lanes > (u64)g_a ? (unsigned)((lanes - (u64)g_a + per_wave - 1) / per_wave) : 1u;
+	const unsigned grid = ((n_waves + 3) / 4 + 7u) & ~7u;
+	size_t lds = (size_t)4 * NS * 64 * NP * 16;
+	e = rxgpu_knob("RXGPU_DL_LDS");
+	const size_t floor_ = e ? (size_t)atoi(e) : 52000;
+	if (lds < floor_ && floor_ <= 65536)
+		lds = floor_;
+#define DLK(RPV) hipLaunchKernelGGL((k_fm_decimate_lane<RT, DS, RPV>), dim3(grid), dim3(256), lds, s, iq, T, p0, M, pcm, pcm_chl2, tw, n_waves, g_a)
+	switch (p0 & 3) {
+	case 0: DLK(0); break;
+	case 1: DLK(1); break;
+	case 2: DLK(2); break;
+	default: DLK(3); break;
+	}
+#undef DLK
+}
+
 extern "C" int rxk_fm_decimate_small(void *stream, const int16_t *iq, u64 T, int ds, int p0, int rotate, unsigned long long M, int16_t *pcm,
                                      int pcm_chl2)
 {
+	{
+		const char *e = rxgpu_knob("RXGPU_DEC_LANE");
+		if (!(e && e[0] == '0') && dl_takes(ds) && M) {
+			hipStream_t s = (hipStream_t)stream;
+			const uint32_t *p = (const uint32_t *)iq;
+#define DL(D) case D: if (rotate) dl_launch<true, D>(s, p, T, p0, M, pcm, pcm_chl2); else dl_launch<false, D>(s, p, T, p0, M, pcm, pcm_chl2); break
+			switch (ds) { DL(4); DL(5); DL(6); DL(7); DL(8); DL(9); DL(10); DL(11); DL(12); DL(14); DL(16); DL(18); DL(20); DL(22); DL(24); DL(26); DL(28); DL(30); DL(32); }
+#undef DL
+			LAUNCH_RET();
+		}
+	}
 	/* $RXGPU_EXP0=6400 (ds 5, 6): longer spans -- at ds = 6 a span's 1024 outputs are eight whole 128-sample chunks of the tiled pcm layout, the
 	 * sixteen runs a workgroup writes are then whole 128-byte lines (96-byte runs otherwise); A/B */
 	const char *smx = rxgpu_knob("RXGPU_EXP0");

@@ -54,6 +54,27 @@ def test_every_decimator_regime(ds, sig):
     _check(iq, block_len, n_runs=3, pipelined=True, downsample=ds)
 
 
+@pytest.mark.parametrize("tw", ["1", "2", "3", "5", None])
+@pytest.mark.parametrize("ds", [4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32])
+def test_lane_owned_window_decimator(ds, tw, monkeypatch):
+    """k_fm_decimate_lane (a lane owns W whole windows, no barrier): every ds it takes, pipelined runs whose lengths are no multiple of
+    ds * 4 so that the carried phase p0 walks through all four 16-byte alignments (one template instance each), waves of 1 / 2 / 3 / 5 / 4
+    tiles ($RXGPU_DL_TW: halo lanes, the SGPR carries across tiles, and the vmcnt arithmetic of the two-stage ring at the start and the
+    end of a wave's walk), the tiled pcm layout (de-emphasis + resampler behind it) and the linear one (deemph=0), offset tuning (no
+    rotate16_90) -- and the same bits from k_fm_decimate_small ($RXGPU_DEC_LANE=0)"""
+    if tw:
+        monkeypatch.setenv("RXGPU_DL_TW", tw)
+    block_len = 2 * (4096 + 4 * 3)              # 4108 samples per block: 4108 % ds walks p0
+    iq = sig_noise(15 * block_len, seed=100 + ds)
+    for extra in (dict(), dict(deemph=0), dict(offset_tuning=1)):
+        _check(iq, block_len, n_runs=5, pipelined=True, downsample=ds, **extra)
+    if tw is None:
+        iq = sig_fm(40 * 16384, seed=ds)        # longer runs: several waves of four tiles, whole tiles of the tiled layout
+        _check(iq, 2 * 16384, n_runs=3, pipelined=True, downsample=ds)
+        monkeypatch.setenv("RXGPU_DEC_LANE", "0")
+        _check(iq, 2 * 16384, n_runs=3, pipelined=True, downsample=ds)
+
+
 @pytest.mark.parametrize("ds,block_len", [(118, 2 * 131072), (5, 2 * 20352), (7, 4096 + 8), (1, 4096), (3, 8192),
                                           (250, 8192), (118, 2 * 1180)])
 def test_low_pass_geometries(ds, block_len):

@@ -15,6 +15,8 @@ d_iq = device_capture(torch, torch.device("cuda"), blocks * 131072, seed=5)
 d_out = torch.zeros(blocks * 131072 // (ds if ds > 0 else 8) + 64, dtype=torch.int16, device="cuda")
 kw = dict(downsample=ds) if ds > 0 else (dict(downsample_passes=-ds) if ds > -10 else dict(downsample_passes=(-ds) // 10, comp_fir_size=9))
 if ds == 5: kw.update(rate_out=240000, deemph_a=19)
+if os.environ.get("AB_KW"):                       # e.g. AB_KW=deemph=0 (no audio stages behind the discriminator: the linear pcm layout)
+    kw.update({k: int(v) for k, v in (kv.split("=") for kv in os.environ["AB_KW"].split(","))})
 def dump(names):
     out = {}
     for n in names:
