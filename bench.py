@@ -1042,6 +1042,8 @@ def main():
                 pw["dropin_scan_us"]["parity_ok"] = same
                 pw_parity_ok = pw_parity_ok and same
                 del want1, ws
+            L.rxgpu_scan_release()                                    # h_bufs is page-locked in place by rxgpu_scan: released BEFORE the array dies (rxgpu.h, LIFETIME)
+            del arr, h_bufs, h_avgs
         ps.close()
         del d_in
         # two more geometries of SURVEY 8(d) config 3, one launch shape each, rank 0 only (not part of `value`)

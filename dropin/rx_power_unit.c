@@ -40,6 +40,10 @@ static void rxgpu_dropin_power_setup(void)
 
 static void rxgpu_dropin_die(const char *what)
 {
+	/* the reference's exit(1) would write out what `file` (the CSV, rtl_power.c:1007-1016) still buffers; rxgpu_fatal leaves with _exit.
+	 * rx_power is single-threaded: nothing else can be inside stdio here */
+	if (file)
+		fflush(file);
 	rxgpu_fatal(what);                                             /* one line on stderr, device drained, _exit(1) */
 }
 

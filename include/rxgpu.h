@@ -341,7 +341,11 @@ long rxgpu_scan_syncs(void);    /* downloads made so far (diagnostics / tests) *
  * buf_len int16 scanner() reads; buffers the caller page-locked itself with rxgpu_pin are used as they are) and ONE launch pulls all of them
  * across PCIe into the scan's contiguous input: no host memcpy, no staging copy.  The call returns when that launch has read the buffers (the
  * caller refills them at once), not when the transforms are done.  The registrations are released with the sweep geometry
- * (rxgpu_scan_release / rxgpu_shutdown / another geometry); a buffer that cannot be page-locked, a row that is no multiple of 16 bytes,
+ * (rxgpu_scan_release / rxgpu_shutdown / another geometry).  LIFETIME: a buf16 that has been handed to rxgpu_scan must stay allocated
+ * until one of those -- freeing or reallocating it under its registration leaves pinned pages behind that a new allocation at the same
+ * address would alias (the gather would read the OLD pages, no error).  A call on a sub-array of the registered sweep
+ * (rxgpu_scan(&tunes[i], j - i): the drop-in's missed-read path) gathers through the rows the table already has; a shorter call on buffers
+ * the table does not know is staged; neither disturbs the full sweep's registrations.  A buffer that cannot be page-locked, a buffer that cannot be page-locked, a row that is no multiple of 16 bytes,
  * or $RXGPU_SCAN_ZC=0 select the older path (gather into pinned staging by memcpy, one H2D).  1 if the last rxgpu_scan read zero-copy. */
 int rxgpu_scan_zero_copy(void);
 /* Forget the cached sweep geometry of rxgpu_scan: its scan object, device buffers and the page-lock registrations of the tunes' buf16.

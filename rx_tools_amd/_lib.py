@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librxgpu.so")
+# $RXGPU_LIB_FLAVOUR=fi: the TEST build with the fault-injection hook (tests/test_gpu_dropin.py); the product is librxgpu.so
+LIB_PATH = os.path.join(_HERE, "librxgpu_fi.so" if os.environ.get("RXGPU_LIB_FLAVOUR") == "fi" else "librxgpu.so")
 
 
 class RxGpuError(RuntimeError):

@@ -178,6 +178,9 @@ int rxgpu_chan_get_carry(rxgpu_chan *s, int *pre)
 {
 	if (!s || !pre)
 		return rxgpu_fail(RXGPU_EINVAL, "null argument");
+	/* pre_host is brought up to date when a run is retired (chan_drain): with runs in flight it still holds an older run's carries */
+	if (s->run[0].live || s->run[1].live)
+		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_chan_get_carry with runs in flight: rxgpu_chan_wait first");
 	memcpy(pre, s->pre_host, (size_t)s->p.n_channels * 8);
 	return RXGPU_OK;
 }
@@ -194,11 +197,14 @@ int rxgpu_chan_get_audio_carry(rxgpu_chan *s, int *audio)
 {
 	if (!s || !audio)
 		return rxgpu_fail(RXGPU_EINVAL, "null argument");
+	if (s->run[0].live || s->run[1].live)
+		return rxgpu_fail(RXGPU_EINVAL, "rxgpu_chan_get_audio_carry with runs in flight: rxgpu_chan_wait first");
 	memcpy(audio, s->audio_host, (size_t)s->p.n_channels * 12);
 	return RXGPU_OK;
 }
 
-long rxgpu_chan_host_fixups(const rxgpu_chan *s) { return s ? s->fixups : 0; }
+/* -1 while runs are in flight: the count is settled when a run is retired (rxgpu_chan_wait), like the carries */
+long rxgpu_chan_host_fixups(const rxgpu_chan *s) { return !s ? 0 : (s->run[0].live || s->run[1].live) ? -1 : s->fixups; }
 
 /* samples until trajectories from the two ends of the int16 range are fewer than `a` apart (then at most one adjacent pair
  * of candidates merges per sample, which is what the mask tracking relies on): the gap g shrinks by at least floor(g / a) per

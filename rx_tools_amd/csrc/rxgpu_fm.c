@@ -1874,7 +1874,7 @@ void rxgpu_callback(int16_t *buf, uint32_t len, void *ctx)
 	}
 	int ok = 1;
 	if (zc) {
-		ok = !rxgpu_fault_tick() &&
+		ok = !RX_FAULT() &&
 		     rxk_fm_prestage_zc(st, (const int16_t *)g_side[side].zc_in_dev, len / 2, !s->offset_tuning, pre, (int16_t *)g_side[side].zc_out_dev) == 0 &&
 		     hipStreamSynchronize(st) == hipSuccess;
 	} else if (len) {
@@ -1894,7 +1894,7 @@ void rxgpu_callback(int16_t *buf, uint32_t len, void *ctx)
 		d->dc_avgI = state[0];
 		d->dc_avgQ = state[1];
 	} else if (ok && len) {
-		ok = !rxgpu_fault_tick() && rxk_fm_prestage(st, cb_in, len / 2, !s->offset_tuning, pre) == 0 &&
+		ok = !RX_FAULT() && rxk_fm_prestage(st, cb_in, len / 2, !s->offset_tuning, pre) == 0 &&
 		     hipMemcpyAsync(s->buf16, pre, (size_t)len * 2, hipMemcpyDeviceToHost, st) == hipSuccess &&
 		     hipStreamSynchronize(st) == hipSuccess;
 	}

@@ -26,8 +26,13 @@ hipStream_t rxgpu_hip_stream3(void);   /* third stream: host <-> device copies o
 
 #define RX_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
 	return rxgpu_fail(RXGPU_ENODEV, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
-int rxgpu_fault_tick(void);            /* rxgpu_rt.c: 1 when the launch about to be made is the one $RXGPU_FAIL_AFTER picked (test hook) */
-#define RX_K(call) do { int e_ = rxgpu_fault_tick() ? (int)hipErrorLaunchFailure : (call); if (e_ != 0) \
+#ifdef RXGPU_FAULT_INJECT              /* the test build (librxgpu_fi.so): $RXGPU_FAIL_AFTER makes the n-th launch fail, rxgpu_rt.c */
+int rxgpu_fault_tick(void);
+#define RX_FAULT() rxgpu_fault_tick()
+#else
+#define RX_FAULT() 0
+#endif
+#define RX_K(call) do { int e_ = RX_FAULT() ? (int)hipErrorLaunchFailure : (call); if (e_ != 0) \
 	return rxgpu_fail(RXGPU_ENODEV, "%s launch failed: %s (%s:%d)", #call, hipGetErrorString((hipError_t)e_), __FILE__, __LINE__); } while (0)
 
 /* rxgpu_shutdown: free what the drop-in entry points cache between calls (rxgpu_fm.c, rxgpu_power.c) */

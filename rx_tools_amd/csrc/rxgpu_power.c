@@ -545,18 +545,35 @@ static void scan_zc_release(void)
 	g_scan.zc_count = 0;
 }
 
-/* device-visible addresses of every tune's buf16 (page-locking those that are not yet), table uploaded; 0 = use the staging path */
-static int scan_zc_resolve(struct tuning_state *tunes, int tune_count, size_t row_bytes, hipStream_t st)
+/* Device-visible addresses of every tune's buf16 (page-locking those that are not yet), table uploaded.  Returns 1 with *row0 = the table
+ * row of tunes[0], or 0 = this call takes the staging path.
+ * LIFETIME (include/rxgpu.h, rxgpu_scan): a buffer that has been handed to rxgpu_scan stays allocated until rxgpu_scan_release() -- it is
+ * page-locked in place, and an allocation that dies under its registration leaves pinned pages behind which a later allocation at the same
+ * address would silently alias.  The reference never frees them (rtl_power.c:518-531); ctypes callers release before their arrays die.
+ * A call on a SUB-ARRAY of the registered sweep (the drop-in's missed-read path: rxgpu_scan(&tunes[i], j - i)) is looked up in the table and
+ * gathers through the rows it already has; a shorter call with buffers the table does not know is staged -- neither touches the
+ * registrations of the full sweep. */
+static int scan_zc_resolve(struct tuning_state *tunes, int tune_count, size_t row_bytes, hipStream_t st, int *row0)
 {
 	const char *e = rxgpu_knob("RXGPU_SCAN_ZC");
+	*row0 = 0;
 	if ((e && e[0] == '0') || g_scan.zc_failed || (row_bytes & 15u) || !g_scan.zc_host)
 		return 0;
 	const unsigned gen = rxgpu_pin_generation();
-	int same = g_scan.zc_count == tune_count && g_scan.zc_gen == gen;
-	for (int i = 0; same && i < tune_count; i++)
-		same = g_scan.zc_host[i] == tunes[i].buf16;
-	if (same)
-		return 1;
+	if (g_scan.zc_count >= tune_count && g_scan.zc_gen == gen) {
+		int k0 = 0;
+		while (k0 + tune_count <= g_scan.zc_count && g_scan.zc_host[k0] != tunes[0].buf16)
+			k0++;
+		int same = k0 + tune_count <= g_scan.zc_count;
+		for (int i = 0; same && i < tune_count; i++)
+			same = g_scan.zc_host[k0 + i] == tunes[i].buf16;
+		if (same) {
+			*row0 = k0;
+			return 1;
+		}
+		if (tune_count < g_scan.zc_count)
+			return 0;                                    /* part of a sweep, through buffers of its own: staged; the sweep's table stays */
+	}
 	scan_zc_release();
 	for (int i = 0; i < tune_count; i++) {
 		void *a = NULL, *a_end = NULL;
@@ -738,11 +755,12 @@ static int scan_locked(struct tuning_state *tunes, int tune_count, const int *wi
 	/* gather the caller's scattered buffers into pinned staging (one copy instead of one per tune); the staging of two sweeps
 	 * ago has long been read */
 	const int k = (int)(g_scan.calls++ & 1);
-	const int zc = scan_zc_resolve(tunes, tune_count, (size_t)p.buf_len * 2, st);
+	int row0 = 0;
+	const int zc = scan_zc_resolve(tunes, tune_count, (size_t)p.buf_len * 2, st, &row0);
 	if (zc) {
 		/* one launch reads every tune's page-locked buf16 across PCIe into the scan's input; the caller refills buf16 as soon as this
 		 * call returns (the next sweep's readStream, rtl_power.c:693-704), so the call waits for the gather -- not for the scan */
-		if (rxk_pw_gather_rows(st, (const void *const *)g_scan.d_rows, tune_count, (size_t)p.buf_len * 2, g_scan.d_in[k]) != 0)
+		if (rxk_pw_gather_rows(st, (const void *const *)g_scan.d_rows + row0, tune_count, (size_t)p.buf_len * 2, g_scan.d_in[k]) != 0)
 			return rxgpu_fail(RXGPU_ENODEV, "rxgpu_scan: gather launch failed: %s", hipGetErrorString(hipGetLastError()));
 		RX_HIP(hipEventRecord(g_scan.ev_gather, st));
 	} else {

@@ -2,6 +2,7 @@
  * per-kernel event timing.  Plain C over the HIP C API. */
 #include "rxgpu_internal.h"
 #include <pthread.h>
+#include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <time.h>
@@ -48,13 +49,15 @@ static const char *const g_knob_names[] = {
 	"RXGPU_FUSE_A", "RXGPU_NO_FUSED_DD", "RXGPU_NO_TILED", "RXGPU_DEEMPH_CHUNK", "RXGPU_NO_SMALL", "RXGPU_DEEMPH_TOPCAP", "RXGPU_FLAG_ALL",
 	"RXGPU_HOST_CHUNK", "RXGPU_DROPIN_TIMING", "RXGPU_BOXCAR_PLAIN", "RXGPU_FIFTH_PLAIN", "RXGPU_FFT_GENERIC", "RXGPU_FFT_STAGEWISE", "RXGPU_FFT_HEAD2",
 	"RXGPU_SCAN_DEFERRED", "RXGPU_SCAN_ZC", "RXGPU_CH_WPG", "RXGPU_CH_GPW", "RXGPU_CH_AUDIO_SEG", "RXGPU_DROPIN_FAST", "RXGPU_DROPIN_ZC", "RXGPU_DEC_NARROW", "RXGPU_DSM_LDS", "RXGPU_SCAN_T", "RXGPU_FF_PAD", "RXGPU_FR_GENERIC", "RXGPU_DD_TW",
-	"RXGPU_FFT_TW", "RXGPU_CH_DENSE", "RXGPU_NO_DEC_TABLE", "RXGPU_APPLY_ILP", "RXGPU_CAS_MAILBOX", "RXGPU_SDR_V", "RXGPU_EXP0", "RXGPU_EXP1", "RXGPU_EXP2", "RXGPU_EXP3", "RXGPU_FAIL_AFTER", "RXGPU_DEC_LANE", "RXGPU_DL_TW", "RXGPU_DL_LDS",
+	"RXGPU_FFT_TW", "RXGPU_CH_DENSE", "RXGPU_NO_DEC_TABLE", "RXGPU_APPLY_ILP", "RXGPU_CAS_MAILBOX", "RXGPU_SDR_V", "RXGPU_EXP0", "RXGPU_EXP1", "RXGPU_EXP2", "RXGPU_EXP3", "RXGPU_DEC_LANE", "RXGPU_DL_TW", "RXGPU_DL_LDS",
 };
 #define N_KNOBS ((int)(sizeof(g_knob_names) / sizeof(g_knob_names[0])))
 static const char *volatile g_knob_val[sizeof(g_knob_names) / sizeof(g_knob_names[0])];
 static pthread_mutex_t g_knob_lock = PTHREAD_MUTEX_INITIALIZER;
 
+#ifdef RXGPU_FAULT_INJECT
 static volatile long g_fail_after;      /* $RXGPU_FAIL_AFTER (test hook, rxgpu_fault_tick) */
+#endif
 
 void rxgpu_knobs_reload(void)
 {
@@ -67,21 +70,26 @@ void rxgpu_knobs_reload(void)
 		else if (!old || strcmp(old, e))
 			g_knob_val[i] = strdup(e);
 	}
+#ifdef RXGPU_FAULT_INJECT
 	{
 		const char *e = getenv("RXGPU_FAIL_AFTER");
 		g_fail_after = e ? atol(e) : 0;
 	}
+#endif
 	pthread_mutex_unlock(&g_knob_lock);
 }
 
-/* Test hook ($RXGPU_FAIL_AFTER=n, read with the knobs): the n-th kernel launch of the host code from now on reports hipErrorLaunchFailure instead
- * of being enqueued -- the way tests/test_gpu_dropin.py makes a device error happen in the middle of a stream. */
+/* Test hook, TEST BUILD ONLY (librxgpu_fi.so: the host files compiled with -DRXGPU_FAULT_INJECT; the shipped library has neither this
+ * function nor the call in RX_K): $RXGPU_FAIL_AFTER=n, read with the knobs -- the n-th kernel launch of the host code from now on reports
+ * hipErrorLaunchFailure instead of being enqueued, the way tests/test_gpu_dropin.py makes a device error happen in the middle of a stream. */
+#ifdef RXGPU_FAULT_INJECT
 int rxgpu_fault_tick(void)
 {
 	if (g_fail_after <= 0)
 		return 0;
 	return __sync_sub_and_fetch(&g_fail_after, 1) == 0;
 }
+#endif
 
 /* The library's failure convention where the replaced function is `void` (full_demod, rtlsdr_callback, scanner: SURVEY.md 8b -- the
  * reference prints to stderr and exits): say it ONCE on stderr -- never stdout, that is the audio / CSV stream --, let the device finish
@@ -108,6 +116,11 @@ void rxgpu_fatal(const char *what)
 	pthread_t w;
 	if (pthread_create(&w, NULL, fatal_watchdog, NULL) == 0)
 		pthread_detach(w);
+	else {
+		/* no watchdog thread: SIGALRM's default action ends the process just as surely if the device never answers */
+		signal(SIGALRM, SIG_DFL);
+		alarm(5);
+	}
 	/* NOT rxgpu_shutdown(): that frees the drop-in's buffers and stream objects, which the application's other thread may be using this
 	 * very moment -- a use-after-free on the way out.  What is in flight is drained; the device memory goes back with the process. */
 	if (g_device >= 0)

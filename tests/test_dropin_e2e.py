@@ -206,3 +206,32 @@ def test_dropin_rx_power_executable(tmp_path):
     want, plan = power_expected_rows(data, passes, rng, window, flags)
     got, err = run_dropin_rx_power(data, plan, tmp_path, args)
     assert got == want, err[-1500:]
+
+
+# BASELINE configs[2]: 599 tunes x 16384 int16 per pass, N = 4096 (rtl_power.c:431-543 plans it; 1039-1050 prints the rows in tune order)
+SWEEP_ARGS = ("24M:1.7G:1k", "rectangle", (1, 0, 0), ["-f", "24M:1.7G:1k", "-i", "2", "-1"])
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("deferred", [None, "1", "0"])
+def test_dropin_rx_power_executable_at_the_baseline_sweep(tmp_path, deferred, monkeypatch):
+    """`rx_power -f 24M:1.7G:1k -i 2 -1` through the product's executable (the reference's own main(), retune/flush reads, scanner() call and
+    csv_dbm loop around librxgpu) == the CSV text of the UNTOUCHED reference main() (libref_power.so) on the same capture, all 599 rows,
+    timestamp columns masked -- and == the oracle's rows (one pass: 2 transforms of 4096 per tune); with the sums kept on the device between sweeps ($RXGPU_SCAN_DEFERRED=1), merged per
+    sweep (=0), and the default"""
+    from support import sig_noise
+    if deferred is not None:
+        monkeypatch.setenv("RXGPU_SCAN_DEFERRED", deferred)
+    rng, window, flags, args = SWEEP_ARGS
+    # ONE sweep per report at this geometry, by the reference's own clock: retune() sleeps 5 ms per hop (rtl_power.c:563), 599 hops take 3 s,
+    # the 2 s tick has passed when the first scanner() returns (rtl_power.c:1040-1043)
+    passes = 1
+    data = sig_noise(passes * 599 * 16384, seed=608, amp=2500)
+    want, plan = power_expected_rows(data, passes, rng, window, flags)
+    assert plan.tune_count == 599 and plan.buf_len == 16384 and plan.bin_e == 12
+    got, err = run_dropin_rx_power(data, plan, tmp_path, args)
+    assert len(got) == 599, err[-1500:]
+    assert got == want, err[-1500:]
+    ref_rows, err_ref = run_power_main("power-cpu", data, plan, tmp_path, list(args))
+    assert ref_rows == got, err_ref[-1500:]

@@ -145,6 +145,54 @@ def test_scan_and_csv_dropin(rng, flags, window, zc, tmp_path, monkeypatch):
         L.rxgpu_csv_dbm(C.byref(arr[t]), f)
     libc.fclose(f)
     assert open(str(tmp_path / "o.csv")).read() == "".join(rows)
+    L.rxgpu_scan_release()                                     # bufs are page-locked in place: released before they die (rxgpu.h, LIFETIME)
+    R.check(L.rxgpu_scan_deferred(0))
+
+
+def test_scan_on_a_sub_array_keeps_the_sweeps_registrations():
+    """The drop-in's missed-read path calls rxgpu_scan(&tunes[i], j - i) between full sweeps (dropin/rx_power_unit.c): the sub-array is
+    found in the table of page-locked buffers and read zero-copy through the rows it already has; a shorter call on buffers the table
+    does not know is staged; the next full sweep is zero-copy again -- and every sum is the oracle's"""
+    L, O = R.lib(), oracle()
+    L.rxgpu_knobs_reload()
+    L.rxgpu_scan_release()
+    R.check(L.rxgpu_scan_deferred(0))
+    plan = R.plan_range("24M:60M:1k", 0.0, 1)
+    tunes, n = 6, 1 << plan.bin_e
+    wc, sw = R.window_coefs("hamming", n), R.sine_table(plan.bin_e)
+    cfg = PowerCfg(plan.bin_e, plan.buf_len, plan.downsample, plan.downsample_passes, 1, 0, 0, ptr32(wc), ptr16(sw))
+    work = np.zeros(plan.buf_len, np.int16)
+    arr, bufs, avgs = _tuning_array(plan, tunes, n)
+    other, obufs, oavgs = _tuning_array(plan, 2, n)
+    want = np.zeros((tunes, n), np.int64)
+    ws = np.zeros(tunes, np.int32)
+    owant, ows = np.zeros((2, n), np.int64), np.zeros(2, np.int32)
+
+    def feed(bs, idx, w_avg, w_smp, seed):
+        for k, t in enumerate(idx):
+            bs[t][:] = sig_noise(plan.buf_len, seed=seed + k, amp=2500)
+            smp = C.c_int(int(w_smp[t]))
+            O.rxo_power_tune(C.byref(cfg), ptr16(bs[t].copy()), ptr16(work), ptr64(w_avg[t]), C.byref(smp))
+            w_smp[t] = smp.value
+
+    feed(bufs, range(tunes), want, ws, 300)
+    R.check(L.rxgpu_scan(arr, tunes, wc.ctypes.data, sw.ctypes.data, 1, 0, 0))
+    assert L.rxgpu_scan_zero_copy() == 1
+    feed(bufs, [2, 3, 4], want, ws, 320)                       # tunes 2..4 again, as after a missed read
+    sub = C.cast(C.byref(arr, 2 * C.sizeof(TuningState)), C.POINTER(TuningState))
+    R.check(L.rxgpu_scan(sub, 3, wc.ctypes.data, sw.ctypes.data, 1, 0, 0))
+    assert L.rxgpu_scan_zero_copy() == 1
+    feed(obufs, range(2), owant, ows, 340)                     # two tunes through buffers of their own: staged, the table stays
+    R.check(L.rxgpu_scan(other, 2, wc.ctypes.data, sw.ctypes.data, 1, 0, 0))
+    assert L.rxgpu_scan_zero_copy() == 0
+    feed(bufs, range(tunes), want, ws, 360)
+    R.check(L.rxgpu_scan(arr, tunes, wc.ctypes.data, sw.ctypes.data, 1, 0, 0))
+    assert L.rxgpu_scan_zero_copy() == 1
+    for t in range(tunes):
+        assert np.array_equal(avgs[t], want[t]) and arr[t].samples == ws[t]
+    for t in range(2):
+        assert np.array_equal(oavgs[t], owant[t]) and other[t].samples == ows[t]
+    L.rxgpu_scan_release()
 
 
 def _tuning_array(plan, tunes, n):
@@ -421,7 +469,8 @@ def test_device_error_mid_stream_ends_the_process_without_deadlock(fail_after, k
     """A launch that fails in the middle of a stream ($RXGPU_FAIL_AFTER: the n-th launch of the host code reports hipErrorLaunchFailure) while
     the application's other thread -- the dongle thread, calling rxgpu_callback and taking d->rw for its hand-off -- keeps running: the
     process must end (rxgpu_fatal: one line on stderr, device released, _exit(1)) within seconds, with NOTHING on stdout (the audio stream)
-    and an atexit handler that would block forever never run."""
+    and an atexit handler that would block forever never run.  The hook exists in the TEST build of the host files only (librxgpu_fi.so,
+    $RXGPU_LIB_FLAVOUR=fi: same kernels, -DRXGPU_FAULT_INJECT); the shipped library has no such switch."""
     import os
     import subprocess
     import sys
@@ -452,7 +501,8 @@ def test_device_error_mid_stream_ends_the_process_without_deadlock(fail_after, k
         "    b = blk.copy(); L.rxgpu_callback(b.ctypes.data, b.size, C.addressof(s)); L.rxgpu_full_demod(C.addressof(d))\n"
         "print('survived')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), kw, str(fail_after))
     t0 = __import__("time").time()
-    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120,
+                         env=dict(os.environ, RXGPU_LIB_FLAVOUR="fi"))
     took = __import__("time").time() - t0
     err = out.stderr.decode()
     assert out.returncode == 1, (out.returncode, err[-800:])
