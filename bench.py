@@ -87,6 +87,21 @@ def valu_ceiling(kernel_substr):
                                       "profiles/%s_kernel_mix.json (the kernel's opcode counts): %.3f per SIMD-cycle x %d SIMDs x %.1f GHz" % (rnd, mrnd, rate, SIMDS, CLOCK_GHZ))
 
 
+def chan_mode_valu_frac(mode, samples, seconds):
+    """Fraction of the chip's VALU issue time a channeliser mode's kernels keep busy: SQ_ACTIVE_INST_VALU (quad-cycles in which a SIMD's VALU executes
+    an instruction, every pass of a multi-pass fp64 op counted) summed over the mode's kernels in the newest profiles/rNN_pmc_chan_modes.json, scaled
+    to this run's samples, over SIMDs x nominal clock x the live time.  (fraction, source) or (None, None)."""
+    f = newest_profile("pmc_chan_modes.json")
+    try:
+        m = json.load(open(f))[mode]
+        busy_s = m["valu_active_quad_cycles_per_run"] * 4.0 * (samples / float(m["samples_per_run"])) / (SIMDS * CLOCK_GHZ * 1e9)
+        return busy_s / seconds, ("%s (SQ_ACTIVE_INST_VALU of %s) x 4 cycles / (%d SIMDs x %.1f GHz x live time): the measured VALU busy share, fp64 passes included"
+                                  % (os.path.relpath(f, ROOT), ", ".join(sorted(k.split("<")[0] for k, v in m["kernels"].items() if v.get("valu_active_quad_cycles_per_step", 0) > 1e5)),
+                                     SIMDS, CLOCK_GHZ))
+    except (OSError, ValueError, KeyError, TypeError, ZeroDivisionError):
+        return None, None
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -324,6 +339,15 @@ def hoist(result, parity_all, world):
             "rx_power_parity_ranks": (pw.get("parity_sharded") or {}).get("parity_ranks"),
             "rx_power_padding_rows_zero": (pw.get("parity_sharded") or {}).get("parity_padding_rows_zero"),
             "rx_fm_replicas_MSample_per_s": result.get("value")})
+        pr = pw.get("projected_scaling")
+        if pr:                                                    # a projection from one GPU, labelled; the full record has the inputs
+            cfg["rx_power_projected_speedup"] = {w: round(v["speedup_gather_overlapped"], 3) for w, v in pr["by_world"].items()}
+        # a scaling figure must not come from the fallback unnoticed (round-5 advisory): when torch.distributed.gather stood in for the
+        # product's gather, the product's keys stay null and the measured numbers move to keys that say what they are
+        if c.get("gather_is_product") is False:
+            for k in ("rx_power_Mbins_per_s", "rx_power_ms_per_step", "rx_power_speedup_vs_1gpu"):
+                cfg[k + "_torch_gather_fallback"] = cfg[k]
+                cfg[k] = None
     if not isinstance(roof, dict):
         return
     legs = {}
@@ -349,10 +373,10 @@ def hoist(result, parity_all, world):
                                       "traffic_over_algorithmic": (r["traffic"] / r["algorithmic_bytes_per_launch"]) if r.get("traffic") else None,
                                       "parity_ok": (ch.get("parity") or {}).get("parity_ok"), "parity_checker": (ch.get("parity") or {}).get("parity_checker")}
         for label, v in (ch.get("other_modes") or {}).items():
-            legs["channeliser 256 ch, " + label] = {"bound": "valu", "frac": None, "hbm_frac": v["frac_of_hbm_peak"], "MSample_per_s": v["value"],
+            legs["channeliser 256 ch, " + label] = {"bound": "valu", "frac": v.get("valu_frac"), "hbm_frac": v["frac_of_hbm_peak"], "MSample_per_s": v["value"],
                                                     "parity_ok": (v.get("parity") or {}).get("parity_ok")}
         if ch.get("nco_mode"):
-            legs["channeliser 256 ch, NCO -> low_pass mode"] = {"bound": "valu", "MSample_per_s": ch["nco_mode"]["value"], "frac": None,
+            legs["channeliser 256 ch, NCO -> low_pass mode"] = {"bound": "valu", "MSample_per_s": ch["nco_mode"]["value"], "frac": ch["nco_mode"].get("valu_frac"),
                                                                "parity_ok": (ch["nco_mode"].get("parity") or {}).get("parity_ok")}
     for label, v in ((result.get("sdr_convert") or {}).get("legs") or {}).items():
         legs["rx_sdr " + label] = {"bound": "hbm", "frac": v["frac_of_hbm_peak"], "GBs": v["GB/s"], "frac_of_box_ceiling": v.get("frac_of_box_ceiling"),
@@ -407,7 +431,8 @@ def compact(result, full_path=None):
     for k in ("blocks_per_step", "block_complex_samples", "bytes_per_step", "parallelism", "host_fixups_timed_loop", "passes_per_step", "n_ranks", "rccl_ranks",
               "rccl_gathers_enqueued", "gather_impl", "rx_power_gather_is_product", "rccl_comm_error", "rccl_library", "gather_bytes_per_rank", "tunes_per_rank", "tunes_rank0", "rx_power_Mbins_per_s", "rx_power_ms_per_step",
               "rx_power_1gpu_same_run_Mbins_per_s", "rx_power_speedup_vs_1gpu", "scan_us_rank0", "gather_us_rank0", "rx_power_parity_ok", "rx_power_parity_tunes",
-              "rx_power_parity_ranks", "rx_power_padding_rows_zero", "rx_power_cpu_baseline_Mbins_per_s_1core", "rx_fm_replicas_MSample_per_s"):
+              "rx_power_parity_ranks", "rx_power_padding_rows_zero", "rx_power_cpu_baseline_Mbins_per_s_1core", "rx_fm_replicas_MSample_per_s",
+              "rx_power_Mbins_per_s_torch_gather_fallback", "rx_power_speedup_vs_1gpu_torch_gather_fallback", "rx_power_projected_speedup"):
         if k in cfg and cfg[k] is not None:
             c[k] = _num(cfg[k], 6) if isinstance(cfg[k], float) else cfg[k]
     out["config"] = c
@@ -897,6 +922,34 @@ def main():
                 ps1.close()
                 del d_in1, d_a1, d_s1
             barrier()
+        # PROJECTION, labelled as one (no multi-GPU node was ever offered; never part of `value`): what one rank of a world of W would do per interval,
+        # timed here as rank-shaped launches on this device -- ceil(599 / W) tunes x the same passes through the sharded entry point -- beside the time the
+        # ONE gather of avg + samples needs at the per-link xGMI rate (the root takes in W - 1 blocks over W - 1 links side by side; the gather runs on the
+        # copy stream under the next interval's scan).  When a real SCALE record exists, a shortfall against this points at the collective, not at occupancy.
+        projection = None
+        if world == 1 and args.variants == "all":
+            XGMI_LINK_GBS = 153.0
+            t_full = dt / args.steps
+            projection = {"what": "PROJECTED from 1-GPU measurements of rank-shaped launches, NOT a multi-GPU measurement", "xgmi_link_GBs_assumed": XGMI_LINK_GBS,
+                          "one_gpu_ms_per_interval": t_full * 1e3, "by_world": {}}
+            for W in (2, 4, 8):
+                per_w = (total_tunes + W - 1) // W
+                for _ in range(2):
+                    R.check(L.rxgpu_power_scan_run_sharded(ps._h, None, d_in.data_ptr(), passes, per_w, d_avgs[0].data_ptr(), d_smps[0].data_ptr(), n,
+                                                           d_avgs[0].data_ptr(), d_smps[0].data_ptr(), 0))
+                L.rxgpu_sync()
+                t1 = time.perf_counter()
+                reps = max(3, args.steps // 2)
+                for _ in range(reps):
+                    R.check(L.rxgpu_power_scan_run_sharded(ps._h, None, d_in.data_ptr(), passes, per_w, d_avgs[0].data_ptr(), d_smps[0].data_ptr(), n,
+                                                           d_avgs[0].data_ptr(), d_smps[0].data_ptr(), 0))
+                L.rxgpu_sync()
+                t_shard = (time.perf_counter() - t1) / reps
+                t_gather = (per_w * n * 8 + per_w * 4) / (XGMI_LINK_GBS * 1e9)
+                projection["by_world"][str(W)] = {
+                    "tunes_per_rank": per_w, "shard_ms": t_shard * 1e3, "gather_ms_at_link_rate": t_gather * 1e3, "gather_bytes_per_rank": per_w * n * 8 + per_w * 4,
+                    "speedup_gather_overlapped": t_full / max(t_shard, t_gather), "speedup_gather_serial": t_full / (t_shard + t_gather),
+                    "ideal": total_tunes / float(per_w)}
         bins_per_step_all = passes * total_tunes * (plan.buf_len // 2)
         bins_local = passes * mine * (plan.buf_len // 2)
         hbm_achieved = (4.0 * bins_local) / (ms / launches * 1e-3) / 1e9 if launches else 0.0
@@ -916,6 +969,7 @@ def main():
             "metric": "rx_power FFT bins/s (scanner() chain, -f 24M:1.7G:1k geometry)",
             "value": bins_per_step_all * args.steps / dt / 1e6, "unit": "Mbins/s", "n_gpus": world,
             "ms_per_step": dt / args.steps * 1e3, "scaling": "strong", "dtype": "int16/int32/int64", "one_gpu_same_run_Mbins_per_s": one_gpu_rate,
+            "projected_scaling": projection,
             "config": {"workload": "599 tunes x 16384 int16, N=4096, 2 FFT blocks/tune/pass, rectangle window (BASELINE configs[2]/[3])",
                        "workload_short": "rx_power -f 24M:1.7G:1k: 599 tunes x 16384 int16, N=4096 (BASELINE configs[2]/[3])",
                        "passes_per_step": passes, "tunes_this_rank": mine, "tunes_per_rank_padded": per,
@@ -1224,6 +1278,7 @@ def main():
                         stage[nm] = round(sms / sn * 1e3, 1)
                 leg = {"value": T / t3 / 1e6, "unit": "MSample/s", "ms": t3 * 1e3, "stage_us": stage, "frac_of_hbm_peak": 4.0 * T / t3 / 1e9 / HBM_PEAK_GBS,
                        "host_fixups_per_run": fix3 / 10.0, "demodulated_samples_per_run": int(n_ch * windows)}
+                leg["valu_frac"], leg["valu_frac_source"] = chan_mode_valu_frac("audio" if audio else "std", T, t3)
                 if not args.no_parity:
                     PA = parity_module()
                     if not audio:
@@ -1262,7 +1317,8 @@ def main():
                 ch2.run(d_iq.data_ptr(), nb2, block_len, d_o2.data_ptr(), w2)
             torch.cuda.synchronize()
             t_nco = (time.perf_counter() - t0) / 3
-            nco = {"value": T2 / t_nco / 1e6, "unit": "MSample/s", "ms": t_nco * 1e3, "blocks": nb2,
+            nco_f, nco_src = chan_mode_valu_frac("nco", T2, t_nco)
+            nco = {"value": T2 / t_nco / 1e6, "unit": "MSample/s", "ms": t_nco * 1e3, "blocks": nb2, "valu_frac": nco_f, "valu_frac_source": nco_src,
                    "note": "rxgpu_chan_params.nco = 1; N^2-ish by definition (one multiply-accumulate per sample and channel), which is why the fix_fft bank is the default"}
             if not args.no_parity:
                 PA = parity_module()

@@ -11,6 +11,8 @@
   rNN_pmc_chains.json     per rx_fm chain / rx_power / channeliser: per kernel {launches, VALU wave-instructions, shader cycles, waves waiting,
                           FETCH_SIZE, WRITE_SIZE, LDS conflict fraction} and the chain's HBM bytes per step beside its algorithmic bytes
   rNN_pmc_summary.json    the per-kernel entries bench.py reads (k_fm_decimate traffic, k_pw_fft4096 / k_ch_fftR instruction counts, per-chain traffic)
+  rNN_pmc_chan_modes.json the channeliser's other modes (-A std, audio stages, NCO): per kernel VALU wave-instructions and VALU-active quad-cycles per run
+                          -- the measured VALU busy time behind those legs' `valu` bound in the bench line
   rNN_pmc_power_legs.json the other rx_power geometries of the bench line: per kernel and per launch VALU wave-instructions, HBM bytes, shader cycles
   rNN_dropin_latency.txt  rxgpu_callback + rxgpu_full_demod per 1 MiB block, by phase
   rNN_valu_issue.json/.txt, rNN_rwmix.json/.txt   (section `probes`) wave64 instructions per SIMD-cycle per opcode; what HBM gives a read stream with writes mixed in
@@ -79,6 +81,9 @@ def chain_entry(src, prefix, steps, algorithmic_bytes_per_step, what):
             total += e["hbm_bytes_per_step"]
         if d.get("SQ_INSTS_VALU") is not None:
             e["valu_wave_instr_per_step"] = d["SQ_INSTS_VALU"] / steps
+        if d.get("SQ_ACTIVE_INST_VALU") is not None:
+            # quad-cycles in which a SIMD's VALU was executing an instruction of this kernel (a multi-pass fp64 op counts every pass)
+            e["valu_active_quad_cycles_per_step"] = d["SQ_ACTIVE_INST_VALU"] / steps
         if d.get("GRBM_GUI_ACTIVE") and d.get("SQ_INSTS_VALU") is not None:
             cyc = d["GRBM_GUI_ACTIVE"] / 8.0                                    # summed over the 8 XCDs
             e["shader_cycles_per_step"] = cyc / steps
@@ -136,6 +141,15 @@ def main():
     e = chain_entry(src, "chan", 6, 4.0 * 2048 * 131072, "tools/chan_once.py: six runs of the bench shape, 1 GiB of capture each")
     if e:
         chains["channeliser"] = e
+    modes = {}
+    for mode, samples in (("std", 2048 * 131072), ("audio", 2048 * 131072), ("nco", 256 * 131072)):
+        e = chain_entry(src, "chanmode_" + mode, 6, 4.0 * samples, "tools/chan_once.py %s: six runs of the bench leg's shape" % mode)
+        if e:
+            modes[mode] = {"samples_per_run": samples, "what": e["what"], "kernels": e["kernels"],
+                           "valu_wave_instr_per_run": sum(k.get("valu_wave_instr_per_step", 0.0) for k in e["kernels"].values()),
+                           "valu_active_quad_cycles_per_run": sum(k.get("valu_active_quad_cycles_per_step", 0.0) for k in e["kernels"].values())}
+    if modes:
+        json.dump(modes, open(os.path.join(dst, "%s_pmc_chan_modes.json" % tag), "w"), indent=1)
     if chains:
         json.dump(chains, open(os.path.join(dst, "%s_pmc_chains.json" % tag), "w"), indent=1)
         # what bench.py reads

@@ -6,7 +6,8 @@
 #   trace     rocprofv3 --kernel-trace --stats of the headline command and of the rx_fm variants
 #   chains    every rx_fm chain alone (tools/chain_once.py): issue counters, FETCH_SIZE, WRITE_SIZE
 #   power     rx_power configs[2] launches: issue, FETCH_SIZE, WRITE_SIZE, LDS counters
-#   chan      the channeliser's bench shape (tools/chan_once.py): the same four passes; the per-channel audio stages' kernel trace
+#   chan      the channeliser's bench shape (tools/chan_once.py): the same four passes; its other modes (-A std, audio stages, NCO): the issue
+#             counters behind their bound; the per-channel audio stages' kernel trace
 #   legs      the other rx_power geometries of the bench line (tools/pw_big_once.py): issue, FETCH_SIZE, WRITE_SIZE
 #   dropin    per-block latency of rxgpu_callback + rxgpu_full_demod (tools/dropin_latency.py)
 #   probes    box ceilings that do not change with the code: VALU issue per opcode (tools/valu_issue.hip), mixed read/write traffic (tools/rwmix.hip)
@@ -50,6 +51,9 @@ if has power; then
 fi
 if has chan; then
   pmc chan "$SQ|FETCH_SIZE|WRITE_SIZE|$LDS" python $REPO/tools/chan_once.py
+  for mode in std audio nco; do
+    pmc chanmode_$mode "$SQ" python $REPO/tools/chan_once.py $mode
+  done
   rm -rf $OUT/trace_chan_audio
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_chan_audio -- python $REPO/tools/chan_audio_time.py > $OUT/chan_audio.txt 2> $OUT/chan_audio.err
 fi
