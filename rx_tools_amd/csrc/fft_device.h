@@ -103,11 +103,12 @@ template <int BITS> __device__ __forceinline__ constexpr int crev(int v)
 // four stages in registers, then the workgroup transposes through LDS to the next field.  Fields
 // are taken from the top; when M is not a multiple of 4 the last field (bits 3..0) overlaps the
 // previous one and only its remaining stages run.  N/16 threads per transform.
+#include "kernels.h"
 template <int M> struct fft_geom {
 	static constexpr int P = (M + 3) / 4;                       // passes
 	static constexpr int N = 1 << M;
 	static constexpr int TPF = N / 16;                          // threads per transform
-	static constexpr int ROW = 20;                              // 16 data dwords + 4 pad per LDS row
+	static constexpr int ROW = 16;                              // 16 data dwords per LDS row; every FOUR rows the area shifts by 4 dwords (fft_exchange)
 	__host__ __device__ static constexpr int f(int p) { return (M - 4 * (p + 1)) > 0 ? (M - 4 * (p + 1)) : 0; }   // field's low bit
 	__host__ __device__ static constexpr int u(int p) { return M - 4 - f(p); }                                    // bits above the field
 	__host__ __device__ static constexpr int sp0(int p) { return (p == P - 1) ? (4 * P - M) : 0; }                // stages already done
@@ -116,8 +117,9 @@ template <int M> struct fft_geom {
 	static constexpr int TWC = M - 4;
 	static constexpr int TWS = (1 << TWC) + 8;
 	static constexpr int TW_WORDS = 8 * TWS;
-	// dwords to reserve per thread-row of a transpose area: ROW plus the skew of fft_exchange (at most 8 dwords every 8 rows)
+	// dwords to reserve per thread-row of a transpose area: ROW plus the skew of fft_exchange (4 dwords every 4 rows) = RXK_FFT_XROW (kernels.h: the launchers)
 	static constexpr int XROW = ROW + 1;
+	static_assert(XROW == RXK_FFT_XROW, "the launchers size the transpose areas with RXK_FFT_XROW");
 };
 
 // ---- twiddles from LDS (round 4; north_star: "fix_fft twiddles staged in LDS").  Stage s' of a pass indexes the table with
@@ -253,17 +255,13 @@ __device__ __forceinline__ void fft_pass_regs(uint32_t (&v)[16], const uint32_t 
 	}
 }
 
-// Row skew of the transposes.  Rows are ROW = 20 dwords (16 data + 4 pad: every lane's ds_read_b128 of its row is aligned and the eight
-// lanes of a read cycle cover all 32 banks).  The WRITE side stores one dword per lane into 64 different rows, and 20 * row mod 32 takes
-// only eight values: the rows a half-wave writes met on 2 to 4 banks (rocprofv3 round 3: 76 % of k_ch_fftR<10>'s LDS cycles were
-// conflicts).  Every eight rows the area shifts by G dwords (16-byte aligned: the read side is unchanged); G per (M, PASS) from an
-// exhaustive search over the write patterns (profiles/README.md): conflict-free for every case but the 2-way ones noted there.
-template <int M, int PASS> __host__ __device__ constexpr int fft_skew()
-{
-	// the last transpose (next field at bit 0) of a field that starts at bit 3 or 4 wants 8, everything else 4
-	return (fft_geom<M>::f(PASS + 1) == 0 && (fft_geom<M>::f(PASS) == 3 || fft_geom<M>::f(PASS) == 4)) ? 8 : 4;
-}
-
+// Layout of the transposes (round 6).  Row t (the 16 values thread t reads back with four ds_read_b128) starts at dword 16 t + 4 (t >> 2): rows
+// of 16 dwords, every four rows the area shifts by 4 dwords (16-byte aligned).  A ds_read_b128 is served in four groups of 16 lanes over 64
+// banks (MI355X_MICROARCH.md, LDS): with rows 20 dwords apart and a shift every eight rows (rounds 3-5) three of the 16 lanes of every group
+// met on a bank quad -- the reads took three times their cycles, and rocprofv3 counted 42 % of k_ch_fftR<10>'s LDS cycles as conflicts -- here
+// the 16 rows of a group fall on 16 different quads for every (M, PASS) from 2^8 to 2^13 (exhaustive over the lane groups).  The WRITE side
+// (one dword per lane into 64 different rows) is left with 2-way conflicts in one of a transform's exchanges, which a ds_write_b32 hides behind its
+// own 4-cycle data transfer.  17 dwords per row instead of 21: 4 KiB less LDS per 256 rows.
 // the same choice by the number of threads that exchange with each other (k_pwm_tail: a SUB-transform of the large transform; its threads are
 // an aligned run of lanes of one wave when there are at most 64 of them)
 template <int THREADS>
@@ -286,19 +284,19 @@ template <int M, int PASS, int XT = (1 << M) / 16>
 __device__ __forceinline__ void fft_exchange(uint32_t (&v)[16], uint32_t *__restrict__ lds, unsigned tq, unsigned row0 = 0)
 {
 	typedef fft_geom<M> G;
-	constexpr int F = G::f(PASS), F2 = G::f(PASS + 1), SK = fft_skew<M, PASS>();
+	constexpr int F = G::f(PASS), F2 = G::f(PASS + 1);
 #pragma unroll
 	for (int r = 0; r < 16; r++) {
 		const unsigned n = ((tq >> F) << (F + 4)) | ((unsigned)r << F) | (tq & ((1u << F) - 1u));
 		const unsigned row = (((n >> (F2 + 4)) << F2) | (n & ((1u << F2) - 1u))) - row0;
 		const unsigned col = (n >> F2) & 15u;
-		lds[row * G::ROW + (row >> 3) * SK + col] = v[r];
+		lds[row * G::ROW + (row >> 2) * 4 + col] = v[r];
 	}
 	fft_sync_n<XT>();
 	const unsigned tl = tq - row0;
 #pragma unroll
 	for (int c = 0; c < 4; c++) {
-		const uint4 t4 = *reinterpret_cast<const uint4 *>(&lds[tl * G::ROW + (tl >> 3) * SK + 4 * c]);
+		const uint4 t4 = *reinterpret_cast<const uint4 *>(&lds[tl * G::ROW + (tl >> 2) * 4 + 4 * c]);
 		v[4 * c] = t4.x; v[4 * c + 1] = t4.y; v[4 * c + 2] = t4.z; v[4 * c + 3] = t4.w;
 	}
 }

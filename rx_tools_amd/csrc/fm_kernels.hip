@@ -4879,8 +4879,8 @@ extern "C" int rxk_ch_fft(void *stream, const int16_t *iq, u64 total_windows, in
 	if (bin_e >= 8 && bin_e <= 12) {
 		const int CH_WPG = ch_wpg(bin_e);
 		const int GPW = fused ? fused / CH_WPG : ch_gpw(CH_WPG, 0);
-		/* N <= 1024: one transpose area (k_ch_fftR); rows of XROW = 21 dwords (fft_exchange's skew), the permuted twiddle copy, the staging */
-		const size_t shm = (size_t)((bin_e <= 10 ? 1 : 2) * 256 * 21 + 8 * ((1 << (bin_e - 4)) + 8) + n_channels * (CH_WPG + 3)) * 4;
+		/* N <= 1024: one transpose area (k_ch_fftR); rows of RXK_FFT_XROW dwords (fft_exchange's layout), the permuted twiddle copy, the staging */
+		const size_t shm = (size_t)((bin_e <= 10 ? 1 : 2) * 256 * RXK_FFT_XROW + 8 * ((1 << (bin_e - 4)) + 8) + n_channels * (CH_WPG + 3)) * 4;
 		const u64 run = (u64)CH_WPG * GPW;
 		const unsigned grid = (unsigned)(((total_windows + run - 1) / run + 7) / 8 * 8);   /* XCD-contiguous order inside the kernel */
 		hipStream_t s = (hipStream_t)stream;

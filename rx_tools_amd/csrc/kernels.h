@@ -92,6 +92,7 @@ enum { RXK_FIRST_LOWPASS = 0, RXK_FIRST_UNIFORM = 1 };
 /* pcm != NULL: also the -A fast discriminator for every output but the first two of each span.
  * lp_sparse != 0 (with pcm, ds <= RXK_LP_SPARSE_MAX_DS): lowpassed[] is only an intermediate then, and only the
  * entries rxk_fm_disc(sparse) will read are stored (the second and the last output of every span). */
+#define RXK_FFT_XROW 17                  /* dwords an LDS transpose area reserves per thread-row (fft_device.h: fft_geom<M>::XROW) */
 #define RXK_LP_SPARSE_MAX_DS 512
 int rxk_fm_decimate(void *stream, const int16_t *iq, unsigned long long T, int ds, int p0,
                     int prescaled, int rotate, uint32_t *lp_raw, uint32_t *head, uint32_t *tail, int lp_sparse, int16_t *pcm, int pcm_chl2);

@@ -1211,7 +1211,7 @@ extern "C" int rxk_pw_fft(void *stream, const int16_t *in, size_t tune_stride, s
 		 * VGPRs per lane, the transform wants ~200, and the spilling build ran 3.3x slower than the LDS radix-2 kernel below */
 		const int nb_total = eff_len / (2 * n);
 		const int T = (n / 16 > 256) ? n / 16 : 256;
-		const size_t lds_bytes = (size_t)(bin_e <= 12 ? 2 : 1) * T * 21 * 4 + 32 * 8 + (size_t)8 * ((n >> 4) + 8) * 4;   /* transposes (XROW), red, twiddle copy */
+		const size_t lds_bytes = (size_t)(bin_e <= 12 ? 2 : 1) * T * RXK_FFT_XROW * 4 + 32 * 8 + (size_t)8 * ((n >> 4) + 8) * 4;   /* transposes (XROW), red, twiddle copy */
 #define GOR(MM) do { \
 		if (lds_bytes > 64 * 1024) { \
 			(void)hipFuncSetAttribute((const void *)k_pw_fftR<MM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
