@@ -372,22 +372,10 @@ __global__ __launch_bounds__(DEC_THREADS) void k_fm_decimate(
 #define DSM_SPAN_MAX 4608                                       // samples of a span at most (see dsm_span)
 #define DSM_HALO 32                                            // >= ds: whole 16-byte vectors on either side
 
-// sum of the ds staged samples from LDS word r: the reads are issued together (a loop with a run-time trip count would wait for each
-// LDS read in turn); DSK = ds for the common small values, 0 = groups of eight with a uniform bound
-template <int DSK>
+// sum of the ds staged samples from LDS word r: the reads are issued together, in groups of eight with a uniform bound (a loop with a
+// run-time trip count would wait for each LDS read in turn)
 __device__ __forceinline__ uint32_t dsm_window(const uint32_t *sm, int r, int ds)
 {
-	if constexpr (DSK > 0) {
-		uint32_t v[DSK];
-#pragma unroll
-		for (int i = 0; i < DSK; i++)
-			v[i] = sm[r + i];
-		uint32_t a = v[0];
-#pragma unroll
-		for (int i = 1; i < DSK; i++)
-			a = pk_add(a, v[i]);
-		return a;
-	}
 	uint32_t a = 0;
 	for (int i0 = 0; i0 < ds; i0 += 8) {
 		uint32_t v[8];
@@ -403,14 +391,14 @@ __device__ __forceinline__ uint32_t dsm_window(const uint32_t *sm, int r, int ds
 
 // span of a workgroup in samples: a multiple of 256 * ds (64 * ds for ds > 18) not above 4608, so that every span holds the same
 // whole number of windows -- whatever the phase p0 -- and the four waves get whole 64-output turns of them
-static inline unsigned dsm_span(int ds, unsigned span_max = DSM_SPAN_MAX)
+static inline unsigned dsm_span(int ds)
 {
 	const unsigned unit = (ds <= 18 ? 256u : 64u) * (unsigned)ds;
-	return (span_max / unit) * unit;
+	return (DSM_SPAN_MAX / unit) * unit;
 }
 
 // NR: rounds of 256 vectors that cover the staged range (4 or 5)
-template <bool ROTATE, int DSK, int NR>
+template <bool ROTATE, int NR>
 __global__ __launch_bounds__(256) void k_fm_decimate_small(
 	const u32x4 *__restrict__ iq, u64 T, int ds, int p0, u64 M, int16_t *__restrict__ pcm, int pcm_chl2, unsigned span, unsigned span_windows)
 {
@@ -478,13 +466,13 @@ __global__ __launch_bounds__(256) void k_fm_decimate_small(
 		return;
 	uint32_t b0 = 0;
 	if (lane == 0)
-		b0 = dsm_window<DSK>(sm, rel0 + (int)__umul24(j_lo, (unsigned)ds) - ds, ds);
+		b0 = dsm_window(sm, rel0 + (int)__umul24(j_lo, (unsigned)ds) - ds, ds);
 	b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
 	for (unsigned j0 = j_lo; j0 < j_hi; j0 += 64) {
 		const unsigned j = j0 + lane;
 		// lanes past the last output stay inside the staged range and are not stored
 		const int rel = rel0 + (int)__umul24(j, (unsigned)ds);
-		const uint32_t a = dsm_window<DSK>(sm, min(rel, rel_max), ds);
+		const uint32_t a = dsm_window(sm, min(rel, rel_max), ds);
 		const uint32_t b = (uint32_t)__builtin_amdgcn_update_dpp((int)b0, (int)a, 0x138, 0xf, 0xf, false);   // wave_shr:1, lane 0 keeps b0
 		b0 = (uint32_t)__builtin_amdgcn_readlane((int)a, 63);
 		if (j >= j_hi)
@@ -492,7 +480,7 @@ __global__ __launch_bounds__(256) void k_fm_decimate_small(
 		int cr, cj;
 		mul_conj_pk(a, b, cr, cj);
 		// |lowpassed| <= 128 * ds: for ds <= 16 the discriminator's denominator stays below 2^24
-		const int16_t v = (int16_t)fast_atan2_dev<(DSK > 0 && DSK <= 16)>(cj, cr);
+		const int16_t v = (int16_t)fast_atan2_dev<false>(cj, cr);
 		if (pcm_chl2) {
 			// 32-bit form of pcm_index (two bit-field moves): the bits above a tile pass through, so an output that runs into the
 			// next tile lands there
@@ -3390,21 +3378,15 @@ __global__ __launch_bounds__(256) void k_ch_fft(const uint32_t *__restrict__ iq,
 // windows per workgroup: 32 while the [n_channels][wpg] staging fits beside the transform buffers, else 16
 static inline int ch_wpg(int bin_e)
 {
-	const char *e = rxgpu_knob("RXGPU_CH_WPG");                  /* 8 | 16 | 32: A/B of the window group (LDS per workgroup vs length of the segments written) */
-	const int w = e ? atoi(e) : 0;
-	if (w == 16 || w == 32 || (w == 8 && bin_e >= 9))        /* a group holds at least the windows of one pass over the workgroup: 16 for N = 256 */
-		return w;
-	return 16;                                               /* round 3, 256 channels: 387-392 GS/s with 16 windows per group, 367-375 with 32 */
+	(void)bin_e;
+	return 16;                                               /* round 3, 256 channels: 387-392 GS/s with 16 windows per group, 367-375 with 32; 8 no better */
 }
 // groups of WPG windows a workgroup walks (round 4): the twiddle copy, the slot arithmetic and the addresses are set up once per run of
 // WPG * GPW windows, and the last window of a group stays in LDS as the next group's predecessor -- only a RUN's first window is left to
-// k_ch_demod(sparse).  The largest of 8, 4, 2, 1 (default 4, $RXGPU_CH_GPW) that divides the callback block's windows.
+// k_ch_demod(sparse).  The largest of 4, 2, 1 that divides the callback block's windows.
 static inline int ch_gpw(int wpg, u64 wpb)
 {
-	const char *e = rxgpu_knob("RXGPU_CH_GPW");
-	int g = e && atoi(e) >= 1 && atoi(e) <= 8 ? atoi(e) : 4;
-	while (g > 1 && (g & (g - 1)))
-		g--;
+	int g = 4;
 	while (g > 1 && wpb % (u64)(wpg * g))
 		g >>= 1;
 	return g;
@@ -4175,8 +4157,8 @@ extern "C" int rxk_fm_decimate(void *stream, const int16_t *iq, u64 T, int ds, i
 	const unsigned magic24 = ((u64)(RXK_DEC_SPAN + 4 + ds) * (u64)ds < (1ull << 24)) ? (1u << 24) / (unsigned)ds + 1 : 0u;
 	const unsigned slot_cap = (RXK_DEC_SPAN + ds) / ds + 4 + 64;      /* + one turn of lanes past the last output (read, never used) */
 	/* 16-byte slot records (the prefix selection left to the reader, dec_prefix_wide) where they stay small: raw input, ds >= 64
-	 * (at most 5 KiB of LDS per workgroup); $RXGPU_DEC_NARROW keeps the 4-byte slots (A/B) */
-	const bool wide = !prescaled && ds >= 64 && !rxgpu_knob("RXGPU_DEC_NARROW");
+	 * (at most 5 KiB of LDS per workgroup); prescaled input and ds < 64 keep the 4-byte slots */
+	const bool wide = !prescaled && ds >= 64;
 	const size_t shm = (size_t)((wide ? 4 : 1) * slot_cap + 4) * sizeof(uint32_t);
 	hipStream_t s = (hipStream_t)stream;
 	const u32x4 *p = (const u32x4 *)iq;
@@ -4198,8 +4180,9 @@ extern "C" int rxk_fm_decimate(void *stream, const int16_t *iq, u64 T, int ds, i
 // k_fm_decimate_lane takes ds = 4 .. 12 and the even ds up to 32 (NP <= 16 vectors per lane; an odd ds needs W = 4 windows per lane, 4 ds registers
 // of raw samples: those stay with k_fm_decimate_small).  A/B in one process, pipelined 4 GiB steps (profiles/r06_ab_dec_lane.txt): level with
 // k_fm_decimate_small at ds = 5 / 6, +1..5 % at 4 / 7 / 8 / 9, +13..37 % at 10 / 11 / 12 (where the LDS-staged kernel has no unrolled window sum).
-// $RXGPU_DL_TW: tiles a wave walks (default 4), $RXGPU_DL_LDS: LDS a workgroup asks for -- the occupancy cap that leaves wave slots to the
-// audio stages of the run before (default 52000: three workgroups per CU), $RXGPU_DEC_LANE=0: k_fm_decimate_small (A/B, tests).
+// That A/B was taken at commit 509b7aa against the unrolled k_fm_decimate_small<., 4..8, .> instances, which this kernel then replaced.
+// $RXGPU_DL_TW: tiles a wave walks (default 4; the tests walk 1..5).  A workgroup asks for 52000 bytes of LDS -- three per CU: the occupancy cap
+// that leaves wave slots to the audio stages of the run before (A/B: 40000 / 52000 / 65536 within 1 %, no cap 4-10 % slower).
 static bool dl_takes(int ds) { return ds >= 4 && (ds <= 12 || (ds <= 32 && !(ds & 1))); }
 
 template <bool RT, int DS>
@@ -4221,10 +4204,8 @@ static void dl_launch(hipStream_t s, const uint32_t *iq, u64 T, int p0, u64 M, i
 	const unsigned n_waves = lanes > (u64)g_a ? (unsigned)((lanes - (u64)g_a + per_wave - 1) / per_wave) : 1u;
 	const unsigned grid = ((n_waves + 3) / 4 + 7u) & ~7u;
 	size_t lds = (size_t)4 * NS * 64 * NP * 16;
-	e = rxgpu_knob("RXGPU_DL_LDS");
-	const size_t floor_ = e ? (size_t)atoi(e) : 52000;
-	if (lds < floor_ && floor_ <= 65536)
-		lds = floor_;
+	if (lds < 52000)
+		lds = 52000;
 #define DLK(RPV) hipLaunchKernelGGL((k_fm_decimate_lane<RT, DS, RPV>), dim3(grid), dim3(256), lds, s, iq, T, p0, M, pcm, pcm_chl2, tw, n_waves, g_a)
 	switch (p0 & 3) {
 	case 0: DLK(0); break;
@@ -4239,8 +4220,7 @@ extern "C" int rxk_fm_decimate_small(void *stream, const int16_t *iq, u64 T, int
                                      int pcm_chl2)
 {
 	{
-		const char *e = rxgpu_knob("RXGPU_DEC_LANE");
-		if (!(e && e[0] == '0') && dl_takes(ds) && M) {
+		if (dl_takes(ds) && M) {
 			hipStream_t s = (hipStream_t)stream;
 			const uint32_t *p = (const uint32_t *)iq;
 #define DL(D) case D: if (rotate) dl_launch<true, D>(s, p, T, p0, M, pcm, pcm_chl2); else dl_launch<false, D>(s, p, T, p0, M, pcm, pcm_chl2); break
@@ -4249,38 +4229,21 @@ extern "C" int rxk_fm_decimate_small(void *stream, const int16_t *iq, u64 T, int
 			LAUNCH_RET();
 		}
 	}
-	/* $RXGPU_EXP0=6400 (ds 5, 6): longer spans -- at ds = 6 a span's 1024 outputs are eight whole 128-sample chunks of the tiled pcm layout, the
-	 * sixteen runs a workgroup writes are then whole 128-byte lines (96-byte runs otherwise); A/B */
-	const char *smx = rxgpu_knob("RXGPU_EXP0");
-	/* ds = 5 (BASELINE configs[0], 256-sample chunks) takes 6400 by default: +3 % on the pipelined step, nothing at ds = 6 (A/B, profiles/README.md); 0 keeps 4608 */
-	const unsigned span_max = smx ? ((atoi(smx) > DSM_SPAN_MAX && atoi(smx) <= 6400 && (ds == 5 || ds == 6)) ? (unsigned)atoi(smx) : DSM_SPAN_MAX)
-	                              : (ds == 5 ? 6400u : DSM_SPAN_MAX);
-	const unsigned span = dsm_span(ds, span_max);
+	/* what is left for this kernel: the odd ds from 13 to 31 (k_fm_decimate_lane would hold 4 ds registers of raw samples per lane).
+	 * The staged span, padded to a fifth of the CU's LDS: five workgroups per CU (20 waves) run the kernel as fast as eight do, and the audio
+	 * stages of the previous run -- long, latency-bound waves on the other stream -- always find slots beside them */
+	const unsigned span = dsm_span(ds);
 	const unsigned grid = ((unsigned)((T + span - 1) / span) + 7u) & ~7u;
-	/* the staged span, padded to a fifth of the CU's LDS: five workgroups per CU (20 waves) run the kernel as fast as eight do,
-	 * and the audio stages of the previous run -- long, latency-bound waves on the other stream -- always find slots beside them
-	 * (A/B in one process at ds = 6: 2 % on the pipelined step; $RXGPU_DSM_LDS sets another floor) */
 	size_t lds = (size_t)(span + 2 * DSM_HALO + 8) * 4;
-	const size_t lds_floor = rxgpu_knob("RXGPU_DSM_LDS") ? (size_t)atoi(rxgpu_knob("RXGPU_DSM_LDS")) : 32000;
-	if (lds < lds_floor && lds_floor <= 65536)
-		lds = lds_floor;
+	if (lds < 32000)
+		lds = 32000;
 	hipStream_t s = (hipStream_t)stream;
 	const u32x4 *p = (const u32x4 *)iq;
 	const bool four = (span + 2 * DSM_HALO) / 4 <= 1024;
-#define GO2(RT, K) do { if (four) hipLaunchKernelGGL((k_fm_decimate_small<RT, K, 4>), dim3(grid), dim3(256), lds, s, p, T, ds, p0, M, pcm, pcm_chl2, span, span / (unsigned)ds); \
-		else hipLaunchKernelGGL((k_fm_decimate_small<RT, K, 5>), dim3(grid), dim3(256), lds, s, p, T, ds, p0, M, pcm, pcm_chl2, span, span / (unsigned)ds); } while (0)
-	if (span > DSM_SPAN_MAX) {
-		if (rotate) { if (ds == 5) hipLaunchKernelGGL((k_fm_decimate_small<true, 5, 7>), dim3(grid), dim3(256), lds, s, p, T, ds, p0, M, pcm, pcm_chl2, span, span / (unsigned)ds);
-		              else hipLaunchKernelGGL((k_fm_decimate_small<true, 6, 7>), dim3(grid), dim3(256), lds, s, p, T, ds, p0, M, pcm, pcm_chl2, span, span / (unsigned)ds); }
-		else { if (ds == 5) hipLaunchKernelGGL((k_fm_decimate_small<false, 5, 7>), dim3(grid), dim3(256), lds, s, p, T, ds, p0, M, pcm, pcm_chl2, span, span / (unsigned)ds);
-		       else hipLaunchKernelGGL((k_fm_decimate_small<false, 6, 7>), dim3(grid), dim3(256), lds, s, p, T, ds, p0, M, pcm, pcm_chl2, span, span / (unsigned)ds); }
-		LAUNCH_RET();
-	}
-#define GO(RT) do { switch (ds) { case 4: GO2(RT, 4); break; case 5: GO2(RT, 5); break; case 6: GO2(RT, 6); break; \
-		case 7: GO2(RT, 7); break; case 8: GO2(RT, 8); break; default: GO2(RT, 0); break; } } while (0)
+#define GO(RT) do { if (four) hipLaunchKernelGGL((k_fm_decimate_small<RT, 4>), dim3(grid), dim3(256), lds, s, p, T, ds, p0, M, pcm, pcm_chl2, span, span / (unsigned)ds); \
+		else hipLaunchKernelGGL((k_fm_decimate_small<RT, 5>), dim3(grid), dim3(256), lds, s, p, T, ds, p0, M, pcm, pcm_chl2, span, span / (unsigned)ds); } while (0)
 	if (rotate) GO(true); else GO(false);
 #undef GO
-#undef GO2
 	LAUNCH_RET();
 }
 
@@ -4441,17 +4404,9 @@ extern "C" int rxk_fm_deemph_scan_t(void *stream, const int16_t *pcm_t, u64 M, i
 	hipStream_t s = (hipStream_t)stream;
 	const unsigned mg = deemph_magic(a);
 	const char *pick = rxgpu_knob("RXGPU_SCAN_T");                       /* "1": always scan_t, "0": scan_r wherever it applies (tests) */
-	if (chl2 == 8 && pick && pick[0] == '0') {
-		/* 256-sample chunks (a = 19 at 240 kHz, BASELINE configs[0]) in the register form, $RXGPU_SCAN_T=0 only: it reads every chunk once where
-		 * scan_t reads the tails twice (0.43 instead of 0.74 GB per 4 GiB of capture at ds = 5), but at 145 VGPRs per wave the kernel itself takes
-		 * 1.2 ms instead of 0.66 and the pipelined step does not move (round 4, A/B in one process): scan_t stays the default */
-		const unsigned rgrid = (unsigned)(((n_chunks + 62) / 63 + 3) / 4);
-		if (group == 16)
-			hipLaunchKernelGGL((k_fm_deemph_scan_r<16, 8>), dim3(rgrid), dim3(256), 0, s, pcm_t, M, a, mg, warm, lo0, gap_w, (uint4 *)ctab, dev);
-		else
-			hipLaunchKernelGGL((k_fm_deemph_scan_r<64, 8>), dim3(rgrid), dim3(256), 0, s, pcm_t, M, a, mg, warm, lo0, gap_w, (uint4 *)ctab, dev);
-		LAUNCH_RET();
-	}
+	/* (256-sample chunks -- a = 19 at 240 kHz, BASELINE configs[0] -- always take scan_t: the register form reads every chunk once where scan_t
+	 * reads the tails twice, 0.43 instead of 0.74 GB per 4 GiB of capture at ds = 5, but at 145 VGPRs per wave it took 1.2 ms instead of 0.66 and
+	 * the pipelined step did not move: round 4, A/B in one process; the instantiation went in round 6) */
 	if (chl2 == 7 && (pick ? pick[0] == '0' : M >= (1ull << 25))) {
 		/* 128-sample chunks of a LONG run (the small-decimation chains, where the audio stages' traffic counts): the chunk in
 		 * registers, the warm-up from the neighbouring lane; 63 chunks per wave.  Short runs keep scan_t: behind the big-ds
@@ -4719,13 +4674,13 @@ extern "C" int rxk_fm_fifth_fused(void *stream, const void *in, int stage2, int 
 #define SEAMS(RT, S2) hipLaunchKernelGGL((k_fm_fifth_seams<RT, S2>), dim3(sgrid), dim3(256), 0, s, p, n_blocks, n, fuse, hist_in, seams, hist_out)
 	/* the raw stage's workgroups take a fifth of the CU's LDS each (15 KiB of tiles + this pad): with eight per CU the kernel is no
 	 * faster, and the later passes / discriminator / audio stages of the previous run on the other stream wait for wave slots
-	 * (A/B in one process, -F ds=128 pipelined: 0.92 -> 0.98 TSample/s; $RXGPU_FF_PAD sets another pad) */
-	const size_t pad = stage2 ? 0 : rxgpu_knob("RXGPU_FF_PAD") ? (size_t)atoi(rxgpu_knob("RXGPU_FF_PAD")) : 17000;
+	 * (A/B in one process, -F ds=128 pipelined: 0.92 -> 0.98 TSample/s) */
+	const size_t pad = stage2 ? 0 : 17000;
 #define FUSED(F, RT, S2) hipLaunchKernelGGL((k_fm_fifth_fused<F, RT, S2, false>), dim3(grid), dim3(256), pad, s, p, n, tiles, tpw, seams, out, n, n >> F)
 #define GO(RT, S2) do { if (hist_in) SEAMS(RT, S2); if (fuse == 1) FUSED(1, RT, S2); else if (fuse == 2) FUSED(2, RT, S2); else FUSED(3, RT, S2); } while (0)
-	/* four (or five) passes on the raw capture: the register kernel, 16 (32) samples per lane.  Three passes stay with the LDS-tiled kernel
-	 * below -- in the -M wbfm -F 9 chain it is 3-5 % ahead (A/B) -- unless $RXGPU_FR_GENERIC=1 (tests: the LV = 3 instantiation) */
-	if (!stage2 && (fuse == 4 || fuse == 5 || (fuse == 3 && rxgpu_knob("RXGPU_FR_GENERIC")))) {
+	/* four passes on the raw capture: the register kernel, 16 samples per lane (five -- 1/32 out -- bought nothing more: round 3).  A group of three
+	 * passes that is not the whole chain (k_fm_fifth_regn<., 3, DD>, rxk_fm_fifth_dd) stays with the LDS-tiled kernel below: 3-5 % ahead there (A/B) */
+	if (!stage2 && fuse == 4) {
 		const unsigned tiles_r = ((n >> fuse) + FR_OUT - 1) / FR_OUT;
 		/* one tile per wave: walking two or four with the next one's loads in flight (what the whole-chain kernel below does) made this
 		 * one, which has half the arithmetic per byte, 5-10 % slower (A/B, -F ds=128: 1730 / 1823 / 1908 us per step) */
@@ -4734,13 +4689,13 @@ extern "C" int rxk_fm_fifth_fused(void *stream, const void *in, int stage2, int 
 		if (total > 0xfffffff0ull)
 			return (int)hipErrorInvalidValue;
 		const unsigned rgrid = (unsigned)((total + 7) / 8 * 8);
-		const unsigned sgridn = (unsigned)(((n_blocks + 1) * (fuse == 3 ? 16 : 32) + 255) / 256);
+		const unsigned sgridn = (unsigned)(((n_blocks + 1) * 32 + 255) / 256);
 #define SEAMN(RT, LVV) hipLaunchKernelGGL((k_fm_fifth_seams<RT, false, LVV>), dim3(sgridn), dim3(256), 0, s, p, n_blocks, n, fuse, hist_in, seams, hist_out)
 #define REGK(RT, LVV, T) hipLaunchKernelGGL((k_fm_fifth_regn<RT, LVV, 0, T>), dim3(rgrid), dim3(256), 0, s, p, n, tiles_r, wgs_per_block, (unsigned)total, seams, out, \
 		                                    (const uint32_t *)nullptr, 0, 0, 0, 0, 0, (int16_t *)nullptr, 0, (uint32_t *)nullptr)
 #define REGN(RT, LVV) REGK(RT, LVV, 1)
 #define GON(LVV) do { if (rotate) { if (hist_in) SEAMN(true, LVV); REGN(true, LVV); } else { if (hist_in) SEAMN(false, LVV); REGN(false, LVV); } } while (0)
-		if (fuse == 3) GON(3); else if (fuse == 4) GON(4); else GON(5);
+		GON(4);
 #undef GON
 #undef REGN
 #undef REGK
@@ -4766,10 +4721,9 @@ extern "C" int rxk_fm_fifth_dd(void *stream, const void *in, int rotate, u64 n_b
 	hipStream_t s = (hipStream_t)stream;
 	const uint32_t *p = (const uint32_t *)in;
 	const unsigned tiles_r = ((n >> fuse) / 4 + FR_OUT - 1) / FR_OUT;
-	/* tiles a wave walks, the next one's loads in flight behind the current one's arithmetic ($RXGPU_DD_TW=1|2|4) */
-	const char *tw_env = rxgpu_knob("RXGPU_DD_TW");
-	const unsigned tw = tw_env ? (unsigned)atoi(tw_env) : 2u;
-	const unsigned twn = (tw == 4 || tw == 2) && tiles_r >= 4 * tw ? tw : 1u;
+	/* two tiles per wave, the second one's loads in flight behind the first one's arithmetic (A/B round 3: 1 / 2 / 4 tiles, two is ahead); short
+	 * blocks: one */
+	const unsigned twn = tiles_r >= 8 ? 2u : 1u;
 	const unsigned wgs_per_block = (tiles_r + 4 * twn - 1) / (4 * twn);
 	const u64 total = n_blocks * (u64)wgs_per_block;
 	if (total > 0xfffffff0ull)
@@ -4777,7 +4731,7 @@ extern "C" int rxk_fm_fifth_dd(void *stream, const void *in, int rotate, u64 n_b
 	const unsigned rgrid = (unsigned)((total + 7) / 8 * 8);
 #define DDK(RT, D, T) hipLaunchKernelGGL((k_fm_fifth_regn<RT, 3, D, T>), dim3(rgrid), dim3(256), 0, s, p, n, tiles_r, wgs_per_block, (unsigned)total, seams, (uint32_t *)nullptr, \
 		                                 tails, fir ? fir[1] : 0, fir ? fir[2] : 0, fir ? fir[3] : 0, fir ? fir[4] : 0, fir ? fir[5] : 0, pcm, pcm_chl2, edges)
-#define DDT(RT, D) do { if (twn == 4) DDK(RT, D, 4); else if (twn == 2) DDK(RT, D, 2); else DDK(RT, D, 1); } while (0)
+#define DDT(RT, D) do { if (twn == 2) DDK(RT, D, 2); else DDK(RT, D, 1); } while (0)
 	if (fir) { if (rotate) DDT(true, 2); else DDT(false, 2); }
 	else { if (rotate) DDT(true, 1); else DDT(false, 1); }
 #undef DDT
@@ -4888,18 +4842,13 @@ extern "C" int rxk_ch_fft(void *stream, const int16_t *iq, u64 total_windows, in
 #define GOF__(MM, FU, TW, WP) do { if (shm > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_ch_fftR<MM, FU, TW, WP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
 		hipLaunchKernelGGL((k_ch_fftR<MM, FU, TW, WP>), dim3(grid), dim3(256), shm, s, p, total_windows, twiddle + (1 << (MM - 1)), first_bin, n_channels, chan_lp, \
 		                   out, out_stride, pre_out, GPW); } while (0)
-#define GOF_(MM, FU, TW) do { if (CH_WPG == 32) GOF__(MM, FU, TW, 32); else if (CH_WPG == 8) GOF__(MM, FU, TW, 8); else GOF__(MM, FU, TW, 16); } while (0)
-		/* A/B (N = 1024 only): $RXGPU_FFT_TW=global -- the twiddles of stages 4.. through the vector cache instead of the workgroup's LDS copy */
-		const char *twk = rxgpu_knob("RXGPU_FFT_TW");
-		const bool ab_tw = bin_e == 10 && twk && twk[0] == 'g';
-#define GOF(MM, FU) do { if (MM == 10 && ab_tw) GOF_(10, FU, false); else GOF_(MM, FU, true); } while (0)
+#define GOF(MM, FU) GOF__(MM, FU, true, 16)
 #define GOC(MM) do { if (fused) GOF(MM, true); else GOF(MM, false); } while (0)
 		switch (bin_e) {
 		case 8: GOC(8); break; case 9: GOC(9); break; case 10: GOC(10); break; case 11: GOC(11); break; default: GOC(12); break;
 		}
 #undef GOC
 #undef GOF
-#undef GOF_
 #undef GOF__
 		LAUNCH_RET();
 	}

@@ -1124,9 +1124,8 @@ extern "C" int rxk_pw_fft_mid(void *stream, const int16_t *in, size_t tune_strid
 #define TAIL(MM, HH) do { \
 		if (peak_hold) hipLaunchKernelGGL((k_pwm_tail<MM, true, HH>), dim3(wg_x, (unsigned)groups), dim3(256), 0, s, scratch, tunes, nbpt, p0, np, ppg, tw2, (i64 *)avg, part); \
 		else hipLaunchKernelGGL((k_pwm_tail<MM, false, HH>), dim3(wg_x, (unsigned)groups), dim3(256), 0, s, scratch, tunes, nbpt, p0, np, ppg, tw2, (i64 *)avg, part); } while (0)
-		/* N >= 2^17: the first two passes in one launch (k_pwm_head2; $RXGPU_FFT_HEAD2=0: one launch each, the round-3 form, A/B and tests) */
-		const char *h2 = rxgpu_knob("RXGPU_FFT_HEAD2");
-		const bool head2 = !(h2 && h2[0] == '0') && (((size_t)in & 7u) | (tune_stride & 3u) | (pass_stride & 3u)) == 0;   /* its 8-byte loads */
+		/* N >= 2^17: the first two passes in one launch (k_pwm_head2); input that is not 8-byte aligned (its loads) takes one launch each */
+		const bool head2 = (((size_t)in & 7u) | (tune_stride & 3u) | (pass_stride & 3u)) == 0;
 #define HEAD2(MM) hipLaunchKernelGGL((k_pwm_head2<MM>), dim3((unsigned)(nq * ((n >> 8) / 32))), dim3(256), 0, s, in, tune_stride, pass_stride, tunes, nbpt, window, tw2, dc, q0, nq, scratch)
 #define HEAD01(MM) do { if (head2) HEAD2(MM); else { HEAD0(MM); HEADN(MM, 1); } } while (0)
 		switch (bin_e) {
@@ -1188,17 +1187,14 @@ extern "C" int rxk_pw_fft(void *stream, const int16_t *in, size_t tune_stride, s
 	dim3 grid((unsigned)tunes, (unsigned)groups);
 	hipStream_t s = (hipStream_t)stream;
 	const int fpw = n >= 4096 ? 1 : 4096 / n;                       /* transforms side by side in a k_pw_fftR workgroup */
-	const bool k4096 = bin_e == 12 && (eff_len == 8192 || eff_len == 16384 || eff_len == 32768) && !rxgpu_knob("RXGPU_FFT_GENERIC");
+	const bool k4096 = bin_e == 12 && (eff_len == 8192 || eff_len == 16384 || eff_len == 32768);
 	i64 *part = (partial && bin_e >= 8 && bin_e <= 13 && eff_len % (2 * n) == 0 &&
 	             (size_t)groups * tunes * fpw * (size_t)n <= partial_cap) ? (i64 *)partial : nullptr;
 	if (k4096) {
 		const int nb = eff_len / 8192;
 #define GO4K_(NB, TWL) do { if (peak_hold) hipLaunchKernelGGL((k_pw_fft4096<NB, true, TWL>), grid, dim3(256), 0, s, in, tune_stride, pass_stride, passes, window, twiddle + 2048, passes_per_group, (i64 *)avg, part); \
 		else hipLaunchKernelGGL((k_pw_fft4096<NB, false, TWL>), grid, dim3(256), 0, s, in, tune_stride, pass_stride, passes, window, twiddle + 2048, passes_per_group, (i64 *)avg, part); } while (0)
-	/* $RXGPU_FFT_TW=global: the twiddles of stages 4-11 through the vector cache (rounds 1-3) instead of the workgroup's LDS copy (A/B) */
-	const char *tw_knob = rxgpu_knob("RXGPU_FFT_TW");
-	const bool tw_global = tw_knob && tw_knob[0] == 'g';
-#define GO4K(NB) do { if (tw_global) GO4K_(NB, false); else GO4K_(NB, true); } while (0)
+#define GO4K(NB) GO4K_(NB, true)
 		if (nb == 1) GO4K(1); else if (nb == 2) GO4K(2); else GO4K(4);
 #undef GO4K
 		if (part)
@@ -1206,7 +1202,7 @@ extern "C" int rxk_pw_fft(void *stream, const int16_t *in, size_t tune_stride, s
 			                   peak_hold, (i64 *)avg);
 		LAUNCH_RET();
 	}
-	if (bin_e >= 8 && bin_e <= 13 && eff_len % (2 * n) == 0 && !rxgpu_knob("RXGPU_FFT_GENERIC")) {
+	if (bin_e >= 8 && bin_e <= 13 && eff_len % (2 * n) == 0) {
 		/* register-blocked kernel for every power of two from 256 to 8192.  2^14 was tried (round 2): N/16 = 1024 threads leave 128
 		 * VGPRs per lane, the transform wants ~200, and the spilling build ran 3.3x slower than the LDS radix-2 kernel below */
 		const int nb_total = eff_len / (2 * n);

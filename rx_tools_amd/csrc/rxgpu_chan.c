@@ -23,7 +23,6 @@ struct rxgpu_chan {
 	int16_t *audio_y;                /* [n_channels][max_windows]: the de-emphasised samples in front of the resampler (k_ch_audio), or the demodulated rows (segmented form) */
 	void *audio_ctab;                /* the (segment, channel) form of the audio stages: chunk tables [n_channels][chunks] ... */
 	int *audio_seg;                  /* ... and every chunk's start state [n_channels][chunks] */
-	int audio_seg_on;                /* $RXGPU_CH_AUDIO_SEG != 0 at creation */
 	/* what a run leaves for its retirement, two of them in rotation (rxgpu_chan_run_async keeps up to two runs in flight) */
 	struct chan_slot {
 		int live;
@@ -135,10 +134,6 @@ int rxgpu_chan_create(rxgpu_chan **out, const rxgpu_chan_params *p, size_t max_b
 	}
 	memset(s->pre_host, 0, nc * 8);
 	memset(s->audio_host, 0, nc * 12);
-	{
-		const char *k = rxgpu_knob("RXGPU_CH_AUDIO_SEG");             /* "0": one workgroup per channel always (A/B, tests) */
-		s->audio_seg_on = !(k && k[0] == '0');
-	}
 	*out = s;
 	return RXGPU_OK;
 }
@@ -389,7 +384,7 @@ int rxgpu_chan_run(rxgpu_chan *s, const int16_t *d_iq, size_t n_blocks, size_t b
 		if (s->audio_host[3 * c] < -32768 || s->audio_host[3 * c] > 32767)
 			serial = 1;
 	const int warm = s->p.deemph && !serial ? rxgpu_deemph_warm64(s->p.deemph_a) : 8;
-	const int seg = audio_on && s->p.deemph && !serial && s->audio_seg_on && s->audio_y &&
+	const int seg = audio_on && s->p.deemph && !serial && s->audio_y &&
 	                rxk_ch_audio_seg_ok(total, warm, s->p.rate_out, s->p.rate_out2 > 0 ? s->p.rate_out2 : 0);
 	int16_t *const rows = seg ? s->audio_y : d_out;                 /* where the demodulated samples go */
 	const size_t rstride = seg ? s->max_windows : out_stride;

@@ -84,8 +84,8 @@ struct rxgpu_fm_stream {
 	int group, warm, lo0, hi0, gap_w;
 	int chunk;                           /* de-emphasis scan: samples per chunk */
 	int topcap_override;                 /* $RXGPU_DEEMPH_TOPCAP: forces the multi-level scan (tests) */
-	/* plan knobs, read once at creation (rxgpu_knob): $RXGPU_FUSE_A, _NO_FUSED_DD, _NO_TILED, _NO_SMALL, _DEEMPH_CHUNK, _HOST_CHUNK */
-	int k_fuse_a, k_no_fused_dd, k_no_tiled, k_no_small, k_deemph_chunk;
+	/* plan knobs, read once at creation (rxgpu_knob): $RXGPU_DEEMPH_CHUNK, $RXGPU_HOST_CHUNK */
+	int k_deemph_chunk;
 	unsigned long long k_host_chunk;
 	int flag_all;                        /* $RXGPU_FLAG_ALL: every libm discriminator sample goes through the host re-evaluation (tests) */
 	int allow_empty;                     /* the drop-in: a block that yields no decimated sample is legal (the struct-memory reads the
@@ -215,11 +215,6 @@ int rxgpu_fm_stream_create(rxgpu_fm_stream **out, const rxgpu_fm_params *params,
 		s->topcap_override = (e && atoi(e) > 0) ? atoi(e) : 0;
 		e = rxgpu_knob("RXGPU_FLAG_ALL");
 		s->flag_all = (e && atoi(e) > 0) ? atoi(e) : 0;
-		e = rxgpu_knob("RXGPU_FUSE_A");
-		s->k_fuse_a = e ? atoi(e) : 0;
-		s->k_no_fused_dd = rxgpu_knob("RXGPU_NO_FUSED_DD") != NULL;
-		s->k_no_tiled = rxgpu_knob("RXGPU_NO_TILED") != NULL;
-		s->k_no_small = rxgpu_knob("RXGPU_NO_SMALL") != NULL;
 		e = rxgpu_knob("RXGPU_DEEMPH_CHUNK");
 		s->k_deemph_chunk = e ? atoi(e) : 0;
 		e = rxgpu_knob("RXGPU_HOST_CHUNK");
@@ -654,14 +649,13 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 	RX_HIP(hipMemsetAsync(s->flag_cnt_dev + db, 0, sizeof(int), sb));
 	/* -F on the raw capture: the first fused group of fifth_order passes reads 8/9 of all the bytes of the run; like the
 	 * boxcar decimator it goes on stream A, so that it overlaps the later passes and the audio stages of the run before */
-	/* four passes in that group where the cascade has them (the next group then reads 1/16 of the capture, not 1/8); $RXGPU_FUSE_A=3 keeps three */
-	const int fuse_a_env = s->k_fuse_a;
-	const int fuse_a_max = (fuse_a_env >= 3 && fuse_a_env <= 5) ? fuse_a_env : 4;
+	/* four passes in that group where the cascade has them (the next group then reads 1/16 of the capture, not 1/8; five bought nothing more) */
+	const int fuse_a_max = 4;
 	const int fuse_a = (g->passes && !g->literal && !prescaled && (g->n % RXK_FIFTH_TILE) == 0 && s->cas_a[0]) ? (g->passes < fuse_a_max ? g->passes : fuse_a_max) : 0;
 	/* a three-pass cascade is the whole of the group: the droop FIR and the discriminator ride in the same launch and only pcm leaves it
-	 * ($RXGPU_NO_FUSED_DD=1: the separate kernels) */
+	 * (squelch, -A std / lut, am / usb / lsb / raw and other FIR sizes take the separate kernels) */
 	const int fuse_dd = fuse_a == 3 && g->passes == 3 && p->mode == RXGPU_MODE_FM && !p->squelch_level && p->custom_atan == 1 &&
-	                    (p->comp_fir_size == 9 || p->comp_fir_size == 0) && !s->k_no_fused_dd;
+	                    (p->comp_fir_size == 9 || p->comp_fir_size == 0);
 	const int fresh = !s->chained;
 
 	if (!s->chained) {
@@ -709,8 +703,9 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 	const int split = p->squelch_level != 0 || p->mode != RXGPU_MODE_FM;
 	int lit_done = 0;                        /* the literal per-block path did squelch and demodulation itself */
 	/* de-emphasis + resampler behind an fm discriminator: hand them the demodulated samples in the tiled layout their
-	 * lane-per-chunk kernels stream (rxk_fm_deemph_scan_t / _apply_rs_t).  $RXGPU_NO_TILED keeps the LDS-staged kernels. */
-	if (!split && !g->literal && p->deemph && s->group && p->rate_out2 > 0 && g->post == 1 && !p->dc_block_audio && !s->k_no_tiled)
+	 * lane-per-chunk kernels stream (rxk_fm_deemph_scan_t / _apply_rs_t).  The LDS-staged kernels keep: no resampler behind the de-emphasis,
+	 * even a or a < 9 or a > 255 (rxk_fm_deemph_tiled_ok), -o, -E adc, squelch and the non-fm demodulators in front. */
+	if (!split && !g->literal && p->deemph && s->group && p->rate_out2 > 0 && g->post == 1 && !p->dc_block_audio)
 	{
 		/* $RXGPU_DEEMPH_CHUNK=256 forces the larger chunk where the warm-up would fit 128 (tests of that template; measured: no
 		 * gain -- the scan's warm-up weighs less, but the resampler's per-wave staging doubles and with it the LDS a workgroup needs
@@ -724,8 +719,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 		 * (the drop-in, which must hand lowpassed[] back, runs prescaled) */
 		const int lp_sparse = fused_disc && !prescaled && g->ds <= RXK_LP_SPARSE_MAX_DS;
 		/* small decimation on the raw capture: the direct kernel (samples staged in LDS, a thread per output, no seams) */
-		const int small = g->fast && fused_disc && !prescaled && g->ds >= RXK_DEC_SMALL_MIN && g->ds <= RXK_DEC_SMALL_MAX &&
-		                  !s->k_no_small;
+		const int small = g->fast && fused_disc && !prescaled && g->ds >= RXK_DEC_SMALL_MIN && g->ds <= RXK_DEC_SMALL_MAX;
 		if (g->fast) {
 			s->lp_final = s->lp_raw[db];
 			/* buffer set `db` was last read by the audio chain two runs ago */

@@ -355,8 +355,7 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 			/* (eff % (2 * n_fft): with a partial last FFT block the transform reads past the tune's compact output into the next tune's;
 			 * the plain kernel below zero-fills up to n_read like the in-place original.  The reference's planner never makes that
 			 * geometry, rxgpu_power_scan_create accepts it.) */
-			if (ds >= 4 && ds <= RXK_DEC_MAX_DS && nc % (unsigned long long)ds == 0 && T % 4 == 0 && eff % (2 * n_fft) == 0 &&
-			    !rxgpu_knob("RXGPU_BOXCAR_PLAIN")) {
+			if (ds >= 4 && ds <= RXK_DEC_MAX_DS && nc % (unsigned long long)ds == 0 && T % 4 == 0 && eff % (2 * n_fft) == 0) {
 				/* whole windows per buffer: the sums over the concatenated buffers are low_pass (rtl_fm.c:351-371) on an already
 				 * scaled, unrotated stream -- the rx_fm decimator, then its per-span seam entries; output compact, eff_len per buffer */
 				const size_t n_spans = (size_t)((T + RXK_DEC_SPAN - 1) / RXK_DEC_SPAN) + 1;
@@ -381,7 +380,7 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 			for (int j = 0; j < ds_p;) {
 				/* up to three passes per launch while the pass input is whole tiles; otherwise one pass at a time */
 				int fuse = ds_p - j < 3 ? ds_p - j : 3;
-				while (fuse > 0 && (n_in % RXK_FIFTH_TILE || rxgpu_knob("RXGPU_FIFTH_PLAIN")))
+				while (fuse > 0 && n_in % RXK_FIFTH_TILE)
 					fuse = 0;
 				if (fuse) {
 					RX_K(rxk_pw_fifth_fused(st, src, n_bufs, (unsigned)n_in, (unsigned)(buf_len / 2), fuse, s->work[which], (unsigned)(buf_len / 2)));
@@ -409,7 +408,7 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 	int groups = (4096 + tunes - 1) / tunes;
 	/* few tunes (a narrow sweep with fine bins): thousands of passes land on the same N bins.  Fewer, longer groups, and their
 	 * spectra go to a partial buffer that one reduction folds into avg[] instead of int64 atomics from every group */
-	const int few = p->bin_e >= 8 && p->bin_e <= 13 && eff_len % (2 << p->bin_e) == 0 && tunes <= 64 && !rxgpu_knob("RXGPU_FFT_GENERIC");
+	const int few = p->bin_e >= 8 && p->bin_e <= 13 && eff_len % (2 << p->bin_e) == 0 && tunes <= 64;
 	if (few)
 		groups = (1024 + tunes - 1) / tunes;
 	if (groups > passes) groups = passes;
@@ -428,10 +427,10 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 	}
 	rxgpu_prof_begin("pw_fft");
 	/* N = 2^14 .. 2^21 (the reference's limit) with whole blocks: the register-blocked transform in two to four launches over a scratch
-	 * copy (rxk_pw_fft_mid: radix-16 passes through HBM until a sub-transform fits a workgroup); $RXGPU_FFT_STAGEWISE keeps the
-	 * one-launch-per-radix-2-stage network for N > 2^15 */
-	const int mid = p->bin_e >= 14 && p->bin_e <= 21 && eff_len % (2 << p->bin_e) == 0 && !rxgpu_knob("RXGPU_FFT_GENERIC") &&
-	                !(p->bin_e > 15 && rxgpu_knob("RXGPU_FFT_STAGEWISE"));
+	 * copy (rxk_pw_fft_mid: radix-16 passes through HBM until a sub-transform fits a workgroup); a buffer that is no whole number of
+	 * transforms (the reference's planner never makes one; rxgpu_power_scan_create accepts it) takes the one-launch-per-radix-2-stage
+	 * network for N > 2^15 and the LDS radix-2 kernel below that */
+	const int mid = p->bin_e >= 14 && p->bin_e <= 21 && eff_len % (2 << p->bin_e) == 0;
 	if (p->bin_e > PW_LDS_BIN_E || mid) {
 		const size_t total = (size_t)passes * (size_t)tunes * (size_t)n_blocks, n = (size_t)1 << p->bin_e;
 		size_t want = ((size_t)1 << 28) / n;                /* up to 1 GiB of scratch */

@@ -118,12 +118,14 @@ def test_channeliser_host_fixups_forced(monkeypatch, flag_all, bin_e, first_bin,
     assert np.array_equal(pre, want_pre)
 
 
-@pytest.mark.parametrize("wpg,gpw", [("8", "8"), ("8", "2"), ("16", "1"), ("16", "8"), ("32", "4"), ("32", "1")])
-def test_channeliser_window_groups_and_runs(monkeypatch, wpg, gpw):
-    """every shape of the fused kernel's run ($RXGPU_CH_WPG windows per group x $RXGPU_CH_GPW groups per workgroup) gives the same samples"""
-    monkeypatch.setenv("RXGPU_CH_WPG", wpg)
-    monkeypatch.setenv("RXGPU_CH_GPW", gpw)
-    for bin_e, first_bin, n_channels, block_len, n_blocks in ((10, 384, 256, 2 * 131072, 3), (9, 500, 100, 2 * 32768, 5), (11, 2000, 96, 2 * 131072, 3)):
+@pytest.mark.parametrize("gpw", [4, 2, 1])
+def test_channeliser_window_groups_and_runs(gpw):
+    """every shape of the fused kernel's run -- 16 windows per group x the 4, 2 or 1 groups per workgroup that divide a callback block's windows --
+    gives the same samples"""
+    for bin_e, first_bin, n_channels, blocks16, n_blocks in ((10, 384, 256, 8, 3), (9, 500, 100, 12, 5), (11, 2000, 96, 4, 3)):
+        # a block of (blocks16 + odd part) * gpw groups of 16 windows: gpw = 4 -> a multiple of 64 windows, 2 -> of 32 only, 1 -> of 16 only
+        wpb = 16 * (blocks16 * 4 if gpw == 4 else (blocks16 * 2 + 1) * 2 if gpw == 2 else blocks16 * 4 + 1)
+        block_len = 2 * (wpb << bin_e)
         iq = sig_fm(n_blocks * block_len // 2, seed=76, amp=9000)
         want, want_pre = oracle_chan(iq, block_len, bin_e, first_bin, n_channels, 1)
         got, pre, _ = gpu_chan(iq, block_len, bin_e, first_bin, n_channels, 1, n_runs=2)
@@ -259,9 +261,9 @@ def test_channeliser_async_runs_chain_their_carries_on_the_device(custom_atan, f
     (4, 8, 2 * 65536, 6, 6, 24000, 12000, 1, 0),
     (4, 8, 2 * 65536, 6, 8, 24000, -1, 1, 0),
 ])
-def test_channeliser_audio_stages_segmented(bin_e, n_channels, block_len, n_blocks, a, rate_out, rate_out2, custom_atan, pad, monkeypatch):
-    """the (segment, channel) form of the per-channel audio stages == the oracle (and the reference where built), across a run boundary,
-    and == the one-workgroup-per-channel kernel ($RXGPU_CH_AUDIO_SEG=0) on the same input"""
+def test_channeliser_audio_stages_segmented(bin_e, n_channels, block_len, n_blocks, a, rate_out, rate_out2, custom_atan, pad):
+    """the (segment, channel) form of the per-channel audio stages == the oracle (and the reference where built), across a run boundary
+    (rows too short for the grid take the one-workgroup-per-channel kernel: test_channeliser_audio_stages covers those)"""
     from gpu_support import to_dev, torch_cuda
     torch = torch_cuda()
     iq = sig_noise(n_blocks * block_len, seed=40 + bin_e + a, amp=2500)
@@ -271,8 +273,7 @@ def test_channeliser_audio_stages_segmented(bin_e, n_channels, block_len, n_bloc
     per = (n_blocks + 1) // 2
     d_iq = to_dev(iq)
     results = []
-    for seg in ("1", "0"):
-        monkeypatch.setenv("RXGPU_CH_AUDIO_SEG", seg)
+    for _ in range(1):
         ch = R.Channeliser(R.ChanParams(bin_e, 3, n_channels, custom_atan, 1, a, rate_out, rate_out2), per, block_len, R.sine_table(bin_e))
         outs, b = [], 0
         while b < n_blocks:

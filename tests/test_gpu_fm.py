@@ -61,7 +61,7 @@ def test_lane_owned_window_decimator(ds, tw, monkeypatch):
     ds * 4 so that the carried phase p0 walks through all four 16-byte alignments (one template instance each), waves of 1 / 2 / 3 / 5 / 4
     tiles ($RXGPU_DL_TW: halo lanes, the SGPR carries across tiles, and the vmcnt arithmetic of the two-stage ring at the start and the
     end of a wave's walk), the tiled pcm layout (de-emphasis + resampler behind it) and the linear one (deemph=0), offset tuning (no
-    rotate16_90) -- and the same bits from k_fm_decimate_small ($RXGPU_DEC_LANE=0)"""
+    rotate16_90)"""
     if tw:
         monkeypatch.setenv("RXGPU_DL_TW", tw)
     block_len = 2 * (4096 + 4 * 3)              # 4108 samples per block: 4108 % ds walks p0
@@ -70,8 +70,6 @@ def test_lane_owned_window_decimator(ds, tw, monkeypatch):
         _check(iq, block_len, n_runs=5, pipelined=True, downsample=ds, **extra)
     if tw is None:
         iq = sig_fm(40 * 16384, seed=ds)        # longer runs: several waves of four tiles, whole tiles of the tiled layout
-        _check(iq, 2 * 16384, n_runs=3, pipelined=True, downsample=ds)
-        monkeypatch.setenv("RXGPU_DEC_LANE", "0")
         _check(iq, 2 * 16384, n_runs=3, pipelined=True, downsample=ds)
 
 
@@ -174,14 +172,11 @@ def test_fifth_order_two_fused_stages(passes, fir, n):
     _check(iq, 2 * n, n_runs=2, pipelined=True, downsample_passes=passes, comp_fir_size=fir, offset_tuning=1)
 
 
-@pytest.mark.parametrize("env,passes", [({"RXGPU_FUSE_A": "3", "RXGPU_FR_GENERIC": "1"}, 3), ({"RXGPU_FUSE_A": "3", "RXGPU_FR_GENERIC": "1"}, 7),
-                                        ({"RXGPU_FUSE_A": "5"}, 5), ({"RXGPU_FUSE_A": "5"}, 9), ({"RXGPU_FUSE_A": "3"}, 7)])
-def test_first_group_depths(env, passes, monkeypatch):
-    """the register kernel of the first group is one template for 3, 4 and 5 passes (4 is what every other test runs); the knobs
-    that pick the other depths -- and the LDS-tiled kernel for three -- give the same bits, seams and histories included"""
+@pytest.mark.parametrize("passes", [3, 4, 5, 7, 9])
+def test_first_group_depths(passes):
+    """the first group of a cascade: three passes are the whole chain in the register kernel (k_fm_fifth_regn<., 3, DD>), four or more put four
+    into it (<., 4, 0>) and the rest into LDS-tiled groups of up to three -- seams and histories included, on inputs that reach the 32-bit sums"""
     from gpu_support import carry_tuple, carry_from_oracle_state
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
     n = 131072
     # +32767 everywhere without the rotation: every tap is +128 after the scale and the level-4 tap sum reaches 2^15 (32-bit sums there)
     for iq, off in ((sig_fm(3 * n, seed=61), 0), (sig_noise(6 * n, seed=62), 1), (np.full(6 * n, -32768, np.int16), 0), (np.full(6 * n, 32767, np.int16), 1)):
@@ -194,10 +189,10 @@ def test_first_group_depths(env, passes, monkeypatch):
 @pytest.mark.parametrize("fir", [9, 0])
 @pytest.mark.parametrize("extra", [dict(), dict(offset_tuning=1), dict(deemph=0), dict(rate_out2=0), dict(dc_block_audio=1),
                                    dict(rate_out=250000, rate_out2=48000, deemph_a=7)])
-def test_whole_chain_in_the_cascade_kernel(fir, extra, monkeypatch):
+def test_whole_chain_in_the_cascade_kernel(fir, extra):
     """three fifth_order passes, the droop FIR and the -A fast discriminator in ONE launch (k_fm_fifth_regn<.., 3, DD> + k_fm_fifth_tails +
     k_fm_dd_edges): oracle bits and carries for every audio tail behind it, one run and chained pipelined runs (histories, pre_r/pre_j and
-    the FIR's nine samples crossing block and run seams), and the same bits as the separate kernels ($RXGPU_NO_FUSED_DD)"""
+    the FIR's nine samples crossing block and run seams), and the same carries as the separate kernels, which -A std takes (custom_atan=0)"""
     from gpu_support import gpu_fm_stream, carry_tuple, carry_from_oracle_state
     n = 16384
     params = dict(downsample_passes=3, comp_fir_size=fir, **extra)
@@ -210,18 +205,17 @@ def test_whole_chain_in_the_cascade_kernel(fir, extra, monkeypatch):
     iq = sig_fm(13 * n, seed=83, amp=12000.0, noise=2000)
     _check(iq, 2 * n, n_runs=4, pipelined=True, **params)
     _check(iq, 2 * n, n_runs=3, **params)
+    # the separate kernels (k_fm_fifth_fused + k_fm_droop_disc) on the same capture: another discriminator, the same cascade and FIR histories
     fused = gpu_fm_stream(iq, 2 * n, n_runs=4, pipelined=True, **params)
-    monkeypatch.setenv("RXGPU_NO_FUSED_DD", "1")
-    plain = gpu_fm_stream(iq, 2 * n, n_runs=4, pipelined=True, **params)
-    assert np.array_equal(fused[0], plain[0]) and carry_tuple(fused[2]) == carry_tuple(plain[2])
+    plain = gpu_fm_stream(iq, 2 * n, n_runs=4, pipelined=True, custom_atan=0, **params)
+    assert carry_tuple(fused[2])[8:] == carry_tuple(plain[2])[8:]
+    _check(iq, 2 * n, n_runs=4, pipelined=True, custom_atan=0, **params)
 
 
-@pytest.mark.parametrize("tw", ["1", "2", "4"])
-def test_whole_chain_kernel_block_shapes_and_libm_records(tw, monkeypatch):
-    """block lengths from one tile (2048 samples: 256 outputs, two waves) to 2^18 with one, two and four tiles walked per wave, and every
+def test_whole_chain_kernel_block_shapes_and_libm_records(monkeypatch):
+    """block lengths from one tile (2048 samples: 256 outputs, two waves; one tile per wave) to 2^18 (two tiles walked per wave), and every
     block's first sample flagged for the host (flag_all): the records k_fm_dd_edges writes are re-evaluated with libm and patched into
     the tiled pcm like k_fm_droop_disc's"""
-    monkeypatch.setenv("RXGPU_DD_TW", tw)
     for n, nb in ((2048, 9), (4096, 5), (6144, 3), (262144, 2), (2048 * 59, 2), (2048 * 15, 3)):
         iq = sig_fm(nb * n, seed=90 + nb, amp=7000.0, noise=500)
         _check(iq, 2 * n, downsample_passes=3, comp_fir_size=9)
@@ -687,12 +681,13 @@ def test_raw_dc_block_any_block_length(block_len):
     (dict(downsample=7, deemph_a=63), 2 * 7 * 1234 + 8, 3),                       # odd block geometry, a at the top of the GS=64 range
 ])
 @pytest.mark.parametrize("tiled", [True, False])
-def test_tiled_audio_path_equals_staged_path(params, block_len, n_runs, tiled, monkeypatch):
+def test_tiled_audio_path_and_staged_path(params, block_len, n_runs, tiled):
     """the lane-per-chunk kernels on the tiled stream (k_fm_deemph_scan_t / up0 / down0 / apply_rs_t: de-emphasis with the
-    resampler inline) and the LDS-staged kernels ($RXGPU_NO_TILED) both reproduce the oracle, sample for sample and carry
-    for carry, also pipelined across runs whose lengths are not multiples of a chunk"""
+    resampler inline) and the LDS-staged kernels -- what the same chain takes when `a` is even (here: a + 1) -- both reproduce the
+    oracle, sample for sample and carry for carry, also pipelined across runs whose lengths are not multiples of a chunk"""
     if not tiled:
-        monkeypatch.setenv("RXGPU_NO_TILED", "1")
+        a = params.get("deemph_a", 13)                            # FmParams.wbfm(): 13 (75 us at 170 kHz)
+        params = dict(params, deemph_a=(a + 1) if a % 2 else a)
     n_blocks = 4 * n_runs + 1
     iq = sig_fm(n_blocks * block_len // 2, seed=55, amp=9000.0, noise=900)
     _check(iq, block_len, n_runs=n_runs, pipelined=n_runs > 1, **params)

@@ -258,31 +258,40 @@ def test_comm_rejects_a_rank_the_communicator_does_not_report(tmp_path):
     assert os.environ.get("RXGPU_RCCL_LIB") == env_before
 
 
-@pytest.mark.parametrize("rng", ["100M:102M:40", "100M:102.8M:20"])
-def test_large_transform_paths_agree(rng, monkeypatch):
-    """N = 2^16 / 2^18: the radix-16 path and the one-launch-per-stage network ($RXGPU_FFT_STAGEWISE) are two implementations of the
-    same fix_fft -- identical avg[] (and both equal to the oracle in test_scan_bit_exact)"""
-    plan = R.plan_range(rng, 0.0, 1)
+def test_buffer_that_is_no_whole_number_of_large_transforms():
+    """N = 2^16 with 1.5 transforms per decimated buffer (boxcar ds = 2 on 3 * 2^17 int16: the second transform is half samples, half the zeros
+    the boxcar leaves behind, rtl_power.c:723-733) -- a geometry the reference's planner never makes and rxgpu_power_scan_create accepts: it takes
+    the one-launch-per-radix-2-stage network (k_pwb_*) instead of the radix-16 passes, and gives the oracle's sums"""
+    import types
+    plan = types.SimpleNamespace(bin_e=16, buf_len=3 << 17, downsample=2, downsample_passes=0)
     n = 1 << plan.bin_e
     wc, sw = R.window_coefs("hamming", n), R.sine_table(plan.bin_e)
-    data = sig_noise(3 * plan.buf_len, seed=5, amp=32768)
-    a, sa = gpu_scan(data, 3, 1, plan, wc, sw, 1, 0, 0)
-    monkeypatch.setenv("RXGPU_FFT_STAGEWISE", "1")
-    b, sb = gpu_scan(data, 3, 1, plan, wc, sw, 1, 0, 0)
-    assert np.array_equal(a, b) and np.array_equal(sa, sb)
+    data = sig_noise(2 * plan.buf_len, seed=5, amp=12000)
+    want, ws = oracle_scan(data, 2, 1, plan, wc, sw, 1, 0, 0)
+    got, gs = gpu_scan(data, 2, 1, plan, wc, sw, 1, 0, 0)
+    assert np.array_equal(got, want) and np.array_equal(gs, ws)
 
 
 @pytest.mark.parametrize("rng", ["100M:102M:20", "100M:102.8M:20", "100M:102.8M:2"])
-def test_two_head_passes_in_one_launch_or_two(rng, monkeypatch):
-    """N = 2^17, 2^18, 2^21: the first two radix-16 passes fused (k_pwm_head2, the default) and as a launch each through the scratch copy
-    ($RXGPU_FFT_HEAD2=0, round 3's form) are the same fix_fft -- identical avg[] (both equal to the oracle in test_scan_bit_exact)"""
+def test_two_head_passes_in_one_launch_or_two(rng):
+    """N = 2^17, 2^18, 2^21: the first two radix-16 passes fused (k_pwm_head2: 8-byte loads) and -- what an input that is not 8-byte aligned
+    takes -- as a launch each through the scratch copy (k_pwm_head + k_pwm_head_mid) are the same fix_fft: identical avg[] (the aligned form equals
+    the oracle in test_scan_bit_exact)"""
+    from gpu_support import to_dev, torch_cuda
+    torch = torch_cuda()
     plan = R.plan_range(rng, 0.0, 1)
     n = 1 << plan.bin_e
     wc, sw = R.window_coefs("blackman", n), R.sine_table(plan.bin_e)
     data = sig_noise(2 * plan.buf_len, seed=11, amp=32768)
     a, sa = gpu_scan(data, 2, 1, plan, wc, sw, 1, 0, 0)
-    monkeypatch.setenv("RXGPU_FFT_HEAD2", "0")
-    b, sb = gpu_scan(data, 2, 1, plan, wc, sw, 1, 0, 0)
+    s = R.PowerScan(R.PowerParams(plan.bin_e, plan.buf_len, plan.downsample, plan.downsample_passes, 1, 0, 0), 1, wc, sw)
+    d_in = to_dev(np.concatenate([np.zeros(2, np.int16), data]))               # the capture starts 4 bytes into the allocation
+    d_avg = torch.zeros((1, n), dtype=torch.int64, device="cuda")
+    d_samples = torch.zeros(1, dtype=torch.int32, device="cuda")
+    s.run(d_in.data_ptr() + 4, 2, 1, d_avg.data_ptr(), d_samples.data_ptr())
+    R.check(R.lib().rxgpu_sync())
+    b, sb = d_avg.cpu().numpy(), d_samples.cpu().numpy()
+    s.close()
     assert np.array_equal(a, b) and np.array_equal(sa, sb)
 
 
