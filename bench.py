@@ -1085,8 +1085,11 @@ def main():
             pw["dropin_scan_us"] = {"rxgpu_scan_per_sweep": t_scan * 1e6, "rxgpu_scan_sync_per_interval": t_sync * 1e6, "sweeps": sweeps,
                                     "Mbins/s": total_tunes * (plan.buf_len // 2) / t_scan / 1e6,
                                     "zero_copy_input": bool(L.rxgpu_scan_zero_copy()),
-                                    "note": "599 tunes x 16384 int16 from the caller's separate buffers, page-locked in place once: one launch reads them across PCIe (9.8 MB) "
-                                            "into the scan's input, the call returns when they have been read; avg[] (19.6 MB) crosses PCIe once per interval, not twice per sweep"}
+                                    "sync_in_place": bool(L.rxgpu_scan_sync_in_place()),
+                                    "pcie_bound_us_per_sweep": total_tunes * plan.buf_len * 2 / 55.5e3, "pcie_bound_us_per_sync": total_tunes * n * 8 / 55.5e3,
+                                    "note": "599 tunes x 16384 int16 = 19.6 MB per sweep from the caller's separate buffers, page-locked in place once: one launch on the copy stream "
+                                            "reads them across PCIe into the scan's input, the call returns when they have been read; avg[] (19.6 MB of int64) is merged in place "
+                                            "by one launch per interval (host rows += device accumulators across PCIe); bounds: one hipMemcpy of the same bytes at 55.5 GB/s"}
             if not args.no_parity:
                 want1 = torch.zeros((per, n), dtype=torch.int64, device=dev)
                 ws = torch.zeros(per, dtype=torch.int32, device=dev)

@@ -336,6 +336,11 @@ int rxgpu_scan_sync(struct tuning_state *tunes, int tune_count);
  * interval pending is RXGPU_EINVAL. */
 int rxgpu_scan_deferred(int on);
 long rxgpu_scan_syncs(void);    /* downloads made so far (diagnostics / tests) */
+/* Diagnostics: with $RXGPU_DROPIN_TIMING=1 rxgpu_scan / rxgpu_scan_sync accumulate host-clock microseconds per phase -- us[0] scan: geometry check +
+ * the table of page-locked rows, [1] scan: gather launch (or staging), [2] scan: enqueue of the transforms, [3] scan: wait until the caller's buffers
+ * have been read, [4] sync: wait for the accumulators' D2H, [5] sync: merge into avg[] / samples, [6] scans, [7] syncs.  Copies up to n (<= 8)
+ * values, clears the table, returns how many. */
+int rxgpu_scan_timing(double *us, int n);
 /* INPUT of rxgpu_scan: scanner() copies every tune's buf16 into fft_buf (rtl_power.c:715-720).  Here the tunes' buf16 -- malloc'd once by
  * frequency_range and never freed (rtl_power.c:518-531) -- are page-locked in place the first time a sweep geometry sees them (exactly the
  * buf_len int16 scanner() reads; buffers the caller page-locked itself with rxgpu_pin are used as they are) and ONE launch pulls all of them
@@ -348,6 +353,11 @@ long rxgpu_scan_syncs(void);    /* downloads made so far (diagnostics / tests) *
  * the table does not know is staged; neither disturbs the full sweep's registrations.  A buffer that cannot be page-locked, a buffer that cannot be page-locked, a row that is no multiple of 16 bytes,
  * or $RXGPU_SCAN_ZC=0 select the older path (gather into pinned staging by memcpy, one H2D).  1 if the last rxgpu_scan read zero-copy. */
 int rxgpu_scan_zero_copy(void);
+/* OUTPUT of rxgpu_scan_sync (and of every rxgpu_scan in the default mode): the tunes' avg[] -- malloc'd once by frequency_range like buf16, the same
+ * LIFETIME rule -- are page-locked in place the first time they are merged into, and ONE launch adds (peak hold: maxes) the device's accumulators into
+ * them across PCIe; the host adds the sample counts.  The same conditions select the older path (D2H of the accumulators, additions on the calling
+ * thread).  1 if the last merge ran in place. */
+int rxgpu_scan_sync_in_place(void);
 /* Forget the cached sweep geometry of rxgpu_scan: its scan object, device buffers and the page-lock registrations of the tunes' buf16.
  * For callers that free or replace their tune buffers (the reference never does); call it BEFORE freeing them.  A pending deferred
  * interval is dropped with a line on stderr (rxgpu_scan_sync first).  rxgpu_shutdown does the same. */

@@ -473,6 +473,33 @@ __global__ __launch_bounds__(256) void k_pw_gather_rows(const uint4 *const *__re
 	}
 }
 
+// rxgpu_scan_sync's merge in place: host row r (a tune's avg[], page-locked, device-visible) += or max= the device's accumulator row r, which is
+// zeroed on the way; 16-byte units = two int64 (rtl_power.c:760-768 does the same sums one sweep at a time)
+__global__ __launch_bounds__(256) void k_pw_merge_rows(uint4 *const *__restrict__ rows, uint4 *__restrict__ acc, unsigned units_per_row, int peak)
+{
+	uint4 *__restrict__ dst = rows[blockIdx.y];
+	uint4 *__restrict__ src = acc + (size_t)blockIdx.y * units_per_row;
+	const unsigned base = blockIdx.x * 1024u + threadIdx.x;
+	uint4 h[4], d[4];
+#pragma unroll
+	for (int q = 0; q < 4; q++) {
+		const unsigned u = base + q * 256u;
+		h[q] = u < units_per_row ? dst[u] : make_uint4(0, 0, 0, 0);
+		d[q] = u < units_per_row ? src[u] : make_uint4(0, 0, 0, 0);
+	}
+#pragma unroll
+	for (int q = 0; q < 4; q++) {
+		const unsigned u = base + q * 256u;
+		if (u >= units_per_row)
+			continue;
+		const i64 h0 = (i64)(((unsigned long long)h[q].y << 32) | h[q].x), h1 = (i64)(((unsigned long long)h[q].w << 32) | h[q].z);
+		const i64 d0 = (i64)(((unsigned long long)d[q].y << 32) | d[q].x), d1 = (i64)(((unsigned long long)d[q].w << 32) | d[q].z);
+		const i64 r0 = peak ? (d0 > h0 ? d0 : h0) : h0 + d0, r1 = peak ? (d1 > h1 ? d1 : h1) : h1 + d1;
+		dst[u] = make_uint4((unsigned)r0, (unsigned)((unsigned long long)r0 >> 32), (unsigned)r1, (unsigned)((unsigned long long)r1 >> 32));
+		src[u] = make_uint4(0, 0, 0, 0);
+	}
+}
+
 __global__ void k_pw_samples(int *samples, int tunes, int add)
 {
 	const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1243,6 +1270,14 @@ extern "C" int rxk_pw_gather_rows(void *stream, const void *const *d_rows, int r
 	const unsigned units = (unsigned)(row_bytes / 16);
 	hipLaunchKernelGGL(k_pw_gather_rows, dim3((units + 1023) / 1024, (unsigned)rows), dim3(256), 0, (hipStream_t)stream,
 	                   (const uint4 *const *)d_rows, (uint4 *)out, units);
+	LAUNCH_RET();
+}
+
+extern "C" int rxk_pw_merge_rows(void *stream, void *const *d_rows, int rows, size_t row_bytes, long long *acc, int peak_hold)
+{
+	const unsigned units = (unsigned)(row_bytes / 16);
+	hipLaunchKernelGGL(k_pw_merge_rows, dim3((units + 1023) / 1024, (unsigned)rows), dim3(256), 0, (hipStream_t)stream,
+	                   (uint4 *const *)d_rows, (uint4 *)acc, units, peak_hold);
 	LAUNCH_RET();
 }
 

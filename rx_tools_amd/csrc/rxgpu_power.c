@@ -498,6 +498,49 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
  * pointer the caller has handed to the call that is running -- rxgpu_scan_sync(tunes, n), rxgpu_csv_dbm(&tunes[i]) -- so a pending
  * interval that meets another array, count or geometry FAILS rxgpu_scan (RXGPU_EINVAL: sync first), and one that is still pending at
  * rxgpu_shutdown / rxgpu_power_dropin_release is dropped with a line on stderr: the old array may be gone by then. */
+/* A table of caller buffers page-locked in place -- one per tune, malloc'd once by frequency_range and never freed (rtl_power.c:518-531) -- with
+ * their device-visible addresses in an array a kernel reads. */
+struct zc_table {
+	const void **host;               /* [cap] the buffer each entry was resolved for */
+	void **dev;                      /* [cap] its device-visible address (host copy of the table) */
+	unsigned char *owned;            /* [cap] page-locked HERE (released with the cache), not by the caller's rxgpu_pin */
+	void **d_tab;                    /* the table on the device */
+	int count;                       /* entries resolved; 0 = none / not usable */
+	int failed;                      /* a buffer could not be page-locked: the copying path from then on (until the geometry changes) */
+	unsigned gen;
+};
+
+/* Where rxgpu_scan / rxgpu_scan_sync spend their time (host clock, $RXGPU_DROPIN_TIMING=1; rxgpu_scan_timing reads and clears):
+ *   0 scan: geometry check + the table of page-locked rows     1 scan: gather launch (or staging memcpy + H2D enqueue)
+ *   2 scan: enqueue of the transforms                           3 scan: wait until the gather has read the caller's buffers
+ *   4 sync: D2H of the accumulators (wait)                      5 sync: merge into the caller's avg[] / samples
+ *   6 scans, 7 syncs */
+static double g_st[8];
+static int g_st_on = -1;
+static double st_now(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec * 1e6 + (double)ts.tv_nsec * 1e-3;
+}
+static int st_on(void)
+{
+	if (g_st_on < 0) {
+		const char *e = rxgpu_knob("RXGPU_DROPIN_TIMING");
+		g_st_on = e && atoi(e) > 0;
+	}
+	return g_st_on;
+}
+int rxgpu_scan_timing(double *us, int n)
+{
+	g_st_on = -1;                                        /* the switch is looked at again (rxgpu_knobs_reload in between) */
+	for (int i = 0; i < n && i < 8; i++) {
+		us[i] = g_st[i];
+		g_st[i] = 0;
+	}
+	return n < 8 ? n : 8;
+}
+
 static struct {
 	rxgpu_power_scan *s;
 	rxgpu_power_params p;
@@ -514,15 +557,12 @@ static struct {
 	int64_t *h_avg;                  /* pinned: download of the accumulators (+ samples behind them) */
 	/* zero-copy input: the caller's tunes[i].buf16 are malloc'd once and never freed (rtl_power.c:518-531) -- page-locked in place the first
 	 * time they are seen, their device-visible addresses in a table the gather kernel reads (k_pw_gather_rows) */
-	const int16_t **zc_host;         /* [tune_cap] the buf16 each entry was resolved for */
-	void **zc_dev;                   /* [tune_cap] its device-visible address (host copy of the table) */
-	unsigned char *zc_owned;         /* [tune_cap] page-locked HERE (released with the cache), not by the caller's rxgpu_pin */
-	void **d_rows;                   /* the table on the device */
-	int zc_count;                    /* entries resolved; 0 = none / not usable */
-	int zc_failed;                   /* a buffer could not be page-locked: the staging path from then on (until the geometry changes) */
-	unsigned zc_gen;
+	struct zc_table zin;             /* the tunes' buf16: the gather's rows */
+	struct zc_table zavg;            /* the tunes' avg[]: rxgpu_scan_sync's merge runs on them in place (round 6) */
 	int zc_last;                     /* the last rxgpu_scan read its input zero-copy (rxgpu_scan_zero_copy) */
+	int zc_sync_last;                /* the last merge ran on the caller's avg[] in place */
 	hipEvent_t ev_gather;
+	hipEvent_t ev_fft;               /* the transforms of the latest sweep are enqueued behind this */
 	struct tuning_state *tunes;      /* whose sums the accumulators hold */
 	int tune_count;
 	int dirty;
@@ -531,81 +571,104 @@ static struct {
 } g_scan = { .deferred = -1 };
 static pthread_mutex_t g_scan_lock = PTHREAD_MUTEX_INITIALIZER;
 
-static void scan_zc_release(void)
+static void zc_release(struct zc_table *z)
 {
-	if (g_scan.zc_owned && g_scan.zc_host)
-		for (int i = 0; i < g_scan.zc_count; i++)
-			if (g_scan.zc_owned[i]) {
+	if (z->owned && z->host)
+		for (int i = 0; i < z->count; i++)
+			if (z->owned[i]) {
 				rxgpu_pin_changed();
-				(void)hipHostUnregister((void *)g_scan.zc_host[i]);
-				g_scan.zc_owned[i] = 0;
+				(void)hipHostUnregister((void *)z->host[i]);
+				z->owned[i] = 0;
 			}
 	(void)hipGetLastError();
-	g_scan.zc_count = 0;
+	z->count = 0;
 }
 
-/* Device-visible addresses of every tune's buf16 (page-locking those that are not yet), table uploaded.  Returns 1 with *row0 = the table
- * row of tunes[0], or 0 = this call takes the staging path.
+static void zc_free(struct zc_table *z)
+{
+	zc_release(z);
+	free(z->host); free(z->dev); free(z->owned);
+	hipFree(z->d_tab);
+	memset(z, 0, sizeof(*z));
+}
+
+static int zc_alloc(struct zc_table *z, int cap)
+{
+	z->host = calloc((size_t)cap, sizeof(*z->host));
+	z->dev = calloc((size_t)cap, sizeof(*z->dev));
+	z->owned = calloc((size_t)cap, 1);
+	return z->host && z->dev && z->owned && hipMalloc((void **)&z->d_tab, (size_t)cap * sizeof(void *)) == hipSuccess;
+}
+
+static const void *tune_buf16(const struct tuning_state *t) { return t->buf16; }
+static const void *tune_avg(const struct tuning_state *t) { return t->avg; }
+
+/* Device-visible addresses of every tune's buffer (`field`: buf16 or avg), page-locking those that are not yet, table uploaded.  Returns 1 with
+ * *row0 = the table row of tunes[0], or 0 = this call takes the copying path.
  * LIFETIME (include/rxgpu.h, rxgpu_scan): a buffer that has been handed to rxgpu_scan stays allocated until rxgpu_scan_release() -- it is
  * page-locked in place, and an allocation that dies under its registration leaves pinned pages behind which a later allocation at the same
  * address would silently alias.  The reference never frees them (rtl_power.c:518-531); ctypes callers release before their arrays die.
  * A call on a SUB-ARRAY of the registered sweep (the drop-in's missed-read path: rxgpu_scan(&tunes[i], j - i)) is looked up in the table and
- * gathers through the rows it already has; a shorter call with buffers the table does not know is staged -- neither touches the
+ * goes through the rows it already has; a shorter call with buffers the table does not know is copied -- neither touches the
  * registrations of the full sweep. */
-static int scan_zc_resolve(struct tuning_state *tunes, int tune_count, size_t row_bytes, hipStream_t st, int *row0)
+static int zc_resolve(struct zc_table *z, const void *(*field)(const struct tuning_state *), struct tuning_state *tunes, int tune_count, size_t row_bytes,
+                      hipStream_t st, int *row0)
 {
 	const char *e = rxgpu_knob("RXGPU_SCAN_ZC");
 	*row0 = 0;
-	if ((e && e[0] == '0') || g_scan.zc_failed || (row_bytes & 15u) || !g_scan.zc_host)
+	if ((e && e[0] == '0') || z->failed || (row_bytes & 15u) || !z->host)
 		return 0;
 	const unsigned gen = rxgpu_pin_generation();
-	if (g_scan.zc_count >= tune_count && g_scan.zc_gen == gen) {
+	if (z->count >= tune_count && z->gen == gen) {
 		int k0 = 0;
-		while (k0 + tune_count <= g_scan.zc_count && g_scan.zc_host[k0] != tunes[0].buf16)
+		while (k0 + tune_count <= z->count && z->host[k0] != field(&tunes[0]))
 			k0++;
-		int same = k0 + tune_count <= g_scan.zc_count;
+		int same = k0 + tune_count <= z->count;
 		for (int i = 0; same && i < tune_count; i++)
-			same = g_scan.zc_host[k0 + i] == tunes[i].buf16;
+			same = z->host[k0 + i] == field(&tunes[i]);
 		if (same) {
 			*row0 = k0;
 			return 1;
 		}
-		if (tune_count < g_scan.zc_count)
-			return 0;                                    /* part of a sweep, through buffers of its own: staged; the sweep's table stays */
+		if (tune_count < z->count)
+			return 0;                                    /* part of a sweep, through buffers of its own: copied; the sweep's table stays */
 	}
-	scan_zc_release();
+	zc_release(z);
 	for (int i = 0; i < tune_count; i++) {
 		void *a = NULL, *a_end = NULL;
-		int16_t *b = tunes[i].buf16;
+		void *b = (void *)field(&tunes[i]);
 		int owned = 0;
 		if (hipHostGetDevicePointer(&a, b, 0) != hipSuccess || hipHostGetDevicePointer(&a_end, (char *)b + row_bytes - 1, 0) != hipSuccess) {
 			(void)hipGetLastError();
 			a = NULL;
-			/* exactly the bytes scanner() reads, not the allocation (buf_len * 4, rtl_power.c:526) and not rounded out to pages */
+			/* exactly the bytes that are used, not the allocation (buf16: buf_len * 4, rtl_power.c:526) and not rounded out to pages */
 			if (hipHostRegister(b, row_bytes, hipHostRegisterDefault) == hipSuccess) {
 				owned = 1;
 				if (hipHostGetDevicePointer(&a, b, 0) != hipSuccess)
 					a = NULL;
 			}
 		}
-		g_scan.zc_host[i] = b;
-		g_scan.zc_dev[i] = a;
-		g_scan.zc_owned[i] = (unsigned char)owned;
-		g_scan.zc_count = i + 1;
+		z->host[i] = b;
+		z->dev[i] = a;
+		z->owned[i] = (unsigned char)owned;
+		z->count = i + 1;
 		if (!a || ((size_t)a & 15u)) {
 			(void)hipGetLastError();
-			scan_zc_release();
-			g_scan.zc_failed = 1;
+			zc_release(z);
+			z->failed = 1;
 			return 0;
 		}
 	}
 	rxgpu_pin_changed();
-	g_scan.zc_gen = rxgpu_pin_generation();
-	if (hipMemcpyAsync(g_scan.d_rows, g_scan.zc_dev, (size_t)tune_count * sizeof(void *), hipMemcpyHostToDevice, st) != hipSuccess ||
-	    hipStreamSynchronize(st) != hipSuccess) {            /* zc_dev is pageable: the copy has read it when this returns */
+	/* both tables pin: each one's generation is what IT left behind (the other table's registrations are this library's own and do not move) */
+	z->gen = rxgpu_pin_generation();
+	if (z == &g_scan.zin && g_scan.zavg.count) g_scan.zavg.gen = z->gen;
+	if (z == &g_scan.zavg && g_scan.zin.count) g_scan.zin.gen = z->gen;
+	if (hipMemcpyAsync(z->d_tab, z->dev, (size_t)tune_count * sizeof(void *), hipMemcpyHostToDevice, st) != hipSuccess ||
+	    hipStreamSynchronize(st) != hipSuccess) {            /* dev[] is pageable: the copy has read it when this returns */
 		(void)hipGetLastError();
-		scan_zc_release();
-		g_scan.zc_failed = 1;
+		zc_release(z);
+		z->failed = 1;
 		return 0;
 	}
 	return 1;
@@ -613,10 +676,10 @@ static int scan_zc_resolve(struct tuning_state *tunes, int tune_count, size_t ro
 
 static void scan_cache_drop(void)
 {
-	scan_zc_release();
-	free(g_scan.zc_host); free(g_scan.zc_dev); free(g_scan.zc_owned);
-	hipFree(g_scan.d_rows);
+	zc_free(&g_scan.zin);
+	zc_free(&g_scan.zavg);
 	if (g_scan.ev_gather) hipEventDestroy(g_scan.ev_gather);
+	if (g_scan.ev_fft) hipEventDestroy(g_scan.ev_fft);
 	rxgpu_power_scan_destroy(g_scan.s);
 	free(g_scan.window_copy); free(g_scan.sine_copy);
 	for (int k = 0; k < 2; k++) {
@@ -643,24 +706,44 @@ static int scan_sync_locked(struct tuning_state *tunes)
 	const int tc = g_scan.tune_count;
 	const size_t n = (size_t)1 << g_scan.p.bin_e;
 	int32_t *h_samples = (int32_t *)(g_scan.h_avg + (size_t)tc * n);
-	RX_HIP(hipMemcpyAsync(g_scan.h_avg, g_scan.d_avg, (size_t)tc * n * 8, hipMemcpyDeviceToHost, st));
+	const int timing = st_on();
+	double t_a = timing ? st_now() : 0;
+	/* The merge IN PLACE (round 6): the tunes' avg[] -- one malloc each, never freed, like buf16 -- are page-locked once and ONE launch adds (or
+	 * maxes) the device's accumulators into them across PCIe, reading and writing the host rows and zeroing the accumulators as it goes: the link
+	 * carries 19.6 MB each way at once and the host adds nothing but the 599 sample counts.  Before: D2H of the accumulators, then 2.45 M int64
+	 * additions on this thread -- 1.2-1.5 ms per interval at the configs[2] geometry, two thirds of it the additions. */
+	int row0 = 0;
+	const int zc = zc_resolve(&g_scan.zavg, tune_avg, tunes, tc, n * 8, st, &row0);
+	g_scan.zc_sync_last = zc;
+	if (zc) {
+		rxgpu_prof_begin("pw_zc_merge");
+		if (rxk_pw_merge_rows(st, (void *const *)g_scan.zavg.d_tab + row0, tc, n * 8, (long long *)g_scan.d_avg, g_scan.p.peak_hold) != 0)
+			return rxgpu_fail(RXGPU_ENODEV, "rxgpu_scan_sync: merge launch failed: %s", hipGetErrorString(hipGetLastError()));
+		rxgpu_prof_end("pw_zc_merge");
+	} else {
+		RX_HIP(hipMemcpyAsync(g_scan.h_avg, g_scan.d_avg, (size_t)tc * n * 8, hipMemcpyDeviceToHost, st));
+		RX_HIP(hipMemsetAsync(g_scan.d_avg, 0, (size_t)tc * n * 8, st));
+	}
 	RX_HIP(hipMemcpyAsync(h_samples, g_scan.d_samples, (size_t)tc * 4, hipMemcpyDeviceToHost, st));
-	RX_HIP(hipMemsetAsync(g_scan.d_avg, 0, (size_t)tc * n * 8, st));
 	RX_HIP(hipMemsetAsync(g_scan.d_samples, 0, (size_t)tc * 4, st));
 	RX_HIP(hipStreamSynchronize(st));
+	if (timing) { const double t_b = st_now(); g_st[4] += t_b - t_a; t_a = t_b; }
 	for (int i = 0; i < tc; i++) {
-		int64_t *avg = tunes[i].avg;
-		const int64_t *delta = g_scan.h_avg + (size_t)i * n;
-		if (g_scan.p.peak_hold) {
-			for (size_t j = 0; j < n; j++)
-				if (delta[j] > avg[j])
-					avg[j] = delta[j];
-		} else {
-			for (size_t j = 0; j < n; j++)
-				avg[j] += delta[j];
+		if (!zc) {
+			int64_t *avg = tunes[i].avg;
+			const int64_t *delta = g_scan.h_avg + (size_t)i * n;
+			if (g_scan.p.peak_hold) {
+				for (size_t j = 0; j < n; j++)
+					if (delta[j] > avg[j])
+						avg[j] = delta[j];
+			} else {
+				for (size_t j = 0; j < n; j++)
+					avg[j] += delta[j];
+			}
 		}
 		tunes[i].samples += h_samples[i];
 	}
+	if (timing) { g_st[5] += st_now() - t_a; g_st[7] += 1; }
 	g_scan.dirty = 0;
 	g_scan.tunes = NULL;                             /* nothing pending: no pointer of the caller's is kept */
 	g_scan.syncs++;
@@ -735,15 +818,12 @@ static int scan_locked(struct tuning_state *tunes, int tune_count, const int *wi
 		    hipEventCreateWithFlags(&g_scan.ev_in[1], hipEventDisableTiming) != hipSuccess ||
 		    hipMemset(g_scan.d_avg, 0, (size_t)tune_count * n * 8) != hipSuccess ||
 		    hipMemset(g_scan.d_samples, 0, (size_t)tune_count * 4 + 4) != hipSuccess ||
-		    hipMalloc((void **)&g_scan.d_rows, (size_t)tune_count * sizeof(void *)) != hipSuccess ||
+		    hipEventCreateWithFlags(&g_scan.ev_fft, hipEventDisableTiming) != hipSuccess ||
 		    hipEventCreateWithFlags(&g_scan.ev_gather, hipEventDisableTiming) != hipSuccess) {
 			scan_cache_drop();
 			return rxgpu_fail(RXGPU_ENOMEM, "rxgpu_scan: buffer allocation failed");
 		}
-		g_scan.zc_host = calloc((size_t)tune_count, sizeof(*g_scan.zc_host));
-		g_scan.zc_dev = calloc((size_t)tune_count, sizeof(*g_scan.zc_dev));
-		g_scan.zc_owned = calloc((size_t)tune_count, 1);
-		if (!g_scan.zc_host || !g_scan.zc_dev || !g_scan.zc_owned) {
+		if (!zc_alloc(&g_scan.zin, tune_count) || !zc_alloc(&g_scan.zavg, tune_count)) {
 			scan_cache_drop();
 			return rxgpu_fail(RXGPU_ENOMEM, "out of host memory");
 		}
@@ -751,17 +831,26 @@ static int scan_locked(struct tuning_state *tunes, int tune_count, const int *wi
 	g_scan.tunes = tunes;
 	g_scan.tune_count = tune_count;
 	hipStream_t st = rxgpu_hip_stream();
-	/* gather the caller's scattered buffers into pinned staging (one copy instead of one per tune); the staging of two sweeps
-	 * ago has long been read */
+	const int timing = st_on();
+	double t_a = timing ? st_now() : 0, t_b;
 	const int k = (int)(g_scan.calls++ & 1);
 	int row0 = 0;
-	const int zc = scan_zc_resolve(tunes, tune_count, (size_t)p.buf_len * 2, st, &row0);
+	const int zc = zc_resolve(&g_scan.zin, tune_buf16, tunes, tune_count, (size_t)p.buf_len * 2, st, &row0);
+	if (timing) { t_b = st_now(); g_st[0] += t_b - t_a; t_a = t_b; }
 	if (zc) {
 		/* one launch reads every tune's page-locked buf16 across PCIe into the scan's input; the caller refills buf16 as soon as this
-		 * call returns (the next sweep's readStream, rtl_power.c:693-704), so the call waits for the gather -- not for the scan */
-		if (rxk_pw_gather_rows(st, (const void *const *)g_scan.d_rows + row0, tune_count, (size_t)p.buf_len * 2, g_scan.d_in[k]) != 0)
+		 * call returns (the next sweep's readStream, rtl_power.c:693-704), so the call waits for the gather -- not for the scan.
+		 * On the COPY stream (round 6): behind the transforms of the sweep before on the compute stream it started 64 us late; the input
+		 * buffers rotate, buffer k was last read by the transforms of two sweeps ago (ev_in) */
+		hipStream_t sc = rxgpu_hip_stream3();
+		if (g_scan.ev_valid[k])
+			RX_HIP(hipStreamWaitEvent(sc, g_scan.ev_in[k], 0));
+		rxgpu_prof_begin_on("pw_zc_gather", sc);
+		if (rxk_pw_gather_rows(sc, (const void *const *)g_scan.zin.d_tab + row0, tune_count, (size_t)p.buf_len * 2, g_scan.d_in[k]) != 0)
 			return rxgpu_fail(RXGPU_ENODEV, "rxgpu_scan: gather launch failed: %s", hipGetErrorString(hipGetLastError()));
-		RX_HIP(hipEventRecord(g_scan.ev_gather, st));
+		rxgpu_prof_end_on("pw_zc_gather", sc);
+		RX_HIP(hipEventRecord(g_scan.ev_gather, sc));
+		RX_HIP(hipStreamWaitEvent(st, g_scan.ev_gather, 0));
 	} else {
 		/* the caller's scattered buffers into pinned staging (one copy instead of one per tune); the staging of two sweeps ago has long been read */
 		if (g_scan.ev_valid[k])
@@ -770,14 +859,17 @@ static int scan_locked(struct tuning_state *tunes, int tune_count, const int *wi
 			memcpy(g_scan.h_in[k] + (size_t)i * p.buf_len, tunes[i].buf16, (size_t)p.buf_len * 2);
 		RX_HIP(hipMemcpyAsync(g_scan.d_in[k], g_scan.h_in[k], (size_t)tune_count * p.buf_len * 2, hipMemcpyHostToDevice, st));
 	}
+	if (timing) { t_b = st_now(); g_st[1] += t_b - t_a; t_a = t_b; }
 	if ((rc = rxgpu_power_scan_run(g_scan.s, g_scan.d_in[k], 1, tune_count, g_scan.d_avg, g_scan.d_samples)) != RXGPU_OK)
 		return rc;
+	if (timing) { t_b = st_now(); g_st[2] += t_b - t_a; t_a = t_b; }
 	RX_HIP(hipEventRecord(g_scan.ev_in[k], st));
 	g_scan.ev_valid[k] = 1;
 	g_scan.dirty = 1;
 	g_scan.zc_last = zc;
 	if (zc && g_scan.deferred)
 		RX_HIP(hipEventSynchronize(g_scan.ev_gather));
+	if (timing) { g_st[3] += st_now() - t_a; g_st[6] += 1; }
 	if (!g_scan.deferred)
 		return scan_sync_locked(tunes);
 	return RXGPU_OK;
@@ -827,6 +919,7 @@ int rxgpu_scan_deferred(int on)
 
 long rxgpu_scan_syncs(void) { return g_scan.syncs; }
 int rxgpu_scan_zero_copy(void) { return g_scan.zc_last; }
+int rxgpu_scan_sync_in_place(void) { return g_scan.zc_sync_last; }
 
 /* One CSV row for a tuning_state, byte for byte what csv_dbm prints (rtl_power.c:774-817) -- a restatement, because
  * the text has to be identical: the bins are read through the index map the reference's in-place edits amount to
