@@ -3,8 +3,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# $RXGPU_LIB_FLAVOUR=fi: the TEST build with the fault-injection hook (tests/test_gpu_dropin.py); the product is librxgpu.so
-LIB_PATH = os.path.join(_HERE, "librxgpu_fi.so" if os.environ.get("RXGPU_LIB_FLAVOUR") == "fi" else "librxgpu.so")
+# $RXGPU_LIB_FLAVOUR=fi: the TEST build with the fault-injection hook (tests/test_gpu_dropin.py); any other name: a scratch build
+# librxgpu_<name>.so beside it (A/B of compile-time choices on one box); the product is librxgpu.so
+_FLAVOUR = os.environ.get("RXGPU_LIB_FLAVOUR", "")
+LIB_PATH = os.path.join(_HERE, "librxgpu_%s.so" % _FLAVOUR if _FLAVOUR.isalnum() else "librxgpu.so")
 
 
 class RxGpuError(RuntimeError):

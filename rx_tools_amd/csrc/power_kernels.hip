@@ -1025,6 +1025,8 @@ __device__ __forceinline__ void pwm_tail_passes(uint32_t (&v)[16], uint32_t *lds
 // partial != NULL: the accumulators go, without atomics, to partial[((group * tunes + tune) * nbpt + blk) * N + bin] and k_pwm_reduce folds
 // them into avg -- with one tune every pass of a sweep lands on the same N bins, and int64 atomics on a few thousand addresses were
 // three quarters of this kernel's time
+// 129-151 VGPRs: three waves per SIMD.  Forcing four (__launch_bounds__(256, 4): 128 VGPRs, 2-25 dwords of twiddles spilled to scratch) LOSES -- round 6,
+// A/B of two builds on one box (tools/pw_big_time.py): N = 2^16 163 -> 128, 2^18 182 -> 164, 2^20 159 -> 129 G bins/s, 2^17 / 2^21 (two spilled dwords) level.
 template <int M, bool PEAK, int H = 1>
 __global__ __launch_bounds__(256) void k_pwm_tail(const uint32_t *__restrict__ scratch, int tunes, int nbpt, int p0, int np, int ppg,
                                                  const uint32_t *__restrict__ twiddle, i64 *__restrict__ avg, i64 *__restrict__ partial)
