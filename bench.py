@@ -646,21 +646,30 @@ def main():
                     sv.run_async(d_iq.data_ptr(), n_blocks, block_len, d_o.data_ptr(), d_o.numel())
                 sv.wait()
                 k = max(20, args.steps)                                # the side figures get as many timed steps as the headline
-                L.rxgpu_prof_reset()
-                L.rxgpu_prof_enable(2)
-                tv = time.perf_counter()
-                for _ in range(k):
-                    sv.run_async(d_iq.data_ptr(), n_blocks, block_len, d_o.data_ptr(), d_o.numel())
-                sv.wait()
-                tv = time.perf_counter() - tv
-                L.rxgpu_prof_enable(0)
-                stages = {}
-                for nm in ("fm_decimate", "fm_fifth", "fm_fifth2", "fm_droop", "fm_disc", "fm_deemph", "fm_resample"):
-                    sms, sn = prof(nm)
-                    if sn:
-                        stages[nm] = round(sms / sn * 1e3, 1)
+                # two timed loops of k steps, the faster one reported (both kept in `loops_ms_per_step`): a side figure should not hang on one
+                # transient of the box (round 6: a full run showed ds=6 at 0.42 and 0.50 minutes apart on unchanged code); `value` is never treated so
+                loops = []
+                for _ in range(2):
+                    L.rxgpu_prof_reset()
+                    L.rxgpu_prof_enable(2)
+                    tv = time.perf_counter()
+                    for _ in range(k):
+                        sv.run_async(d_iq.data_ptr(), n_blocks, block_len, d_o.data_ptr(), d_o.numel())
+                    sv.wait()
+                    tv = time.perf_counter() - tv
+                    L.rxgpu_prof_enable(0)
+                    loops.append(tv)
+                    if tv > min(loops):
+                        continue                                       # the stage times below stay those of the faster loop
+                    stages = {}
+                    for nm in ("fm_decimate", "fm_fifth", "fm_fifth2", "fm_droop", "fm_disc", "fm_deemph", "fm_resample"):
+                        sms, sn = prof(nm)
+                        if sn:
+                            stages[nm] = round(sms / sn * 1e3, 1)
+                tv = min(loops)
                 variant_kw[label] = kw
                 variants[label] = {"value": T * k / tv / 1e6, "unit": "MSample/s", "ms_per_step": tv / k * 1e3, "steps": k,
+                                   "loops_ms_per_step": [round(t / k * 1e3, 4) for t in loops], "timing": "the faster of two loops of %d pipelined steps" % k,
                                    "frac_of_hbm_peak": 4.0 * T * k / tv / 1e9 / HBM_PEAK_GBS, "stage_us_per_step": stages,
                                    "host_fixups": int(sv.host_fixups)}
                 sv.close()

@@ -4183,7 +4183,11 @@ extern "C" int rxk_fm_decimate(void *stream, const int16_t *iq, u64 T, int ds, i
 // That A/B was taken at commit 509b7aa against the unrolled k_fm_decimate_small<., 4..8, .> instances, which this kernel then replaced.
 // $RXGPU_DL_TW: tiles a wave walks (default 4; the tests walk 1..5).  A workgroup asks for 52000 bytes of LDS -- three per CU: the occupancy cap
 // that leaves wave slots to the audio stages of the run before (A/B: 40000 / 52000 / 65536 within 1 %, no cap 4-10 % slower).
+#ifdef RXK_NO_LANE                                             /* scratch builds only: A/B against k_fm_decimate_small (tools: $RXGPU_LIB_FLAVOUR) */
+static bool dl_takes(int ds) { (void)ds; return false; }
+#else
 static bool dl_takes(int ds) { return ds >= 4 && (ds <= 12 || (ds <= 32 && !(ds & 1))); }
+#endif
 
 template <bool RT, int DS>
 static void dl_launch(hipStream_t s, const uint32_t *iq, u64 T, int p0, u64 M, int16_t *pcm, int pcm_chl2)
