@@ -15,6 +15,8 @@
                           -- the measured VALU busy time behind those legs' `valu` bound in the bench line
   rNN_pmc_power_legs.json the other rx_power geometries of the bench line: per kernel and per launch VALU wave-instructions, HBM bytes, shader cycles
   rNN_dropin_latency.txt  rxgpu_callback + rxgpu_full_demod per 1 MiB block, by phase
+  rNN_scan_latency.txt    rxgpu_scan / rxgpu_scan_sync on the configs[2] sweep, by phase, beside one hipMemcpy of the same bytes (tools/scan_latency.py)
+  rNN_pw_big_time.txt     G bins/s of the large-N rx_power geometries, one tune each (tools/pw_big_time.py)
   rNN_valu_issue.json/.txt, rNN_rwmix.json/.txt   (section `probes`) wave64 instructions per SIMD-cycle per opcode; what HBM gives a read stream with writes mixed in
 
 Only what the profile directory holds is written: a section that was not run leaves the round without that file and bench.py falls back to the newest
@@ -113,7 +115,7 @@ def main():
     for pat, name in (("bench_n1.json", "%s_bench_n1.json"), ("bench_full.json", "%s_bench_full.json"), ("trace_bench_full.json", "%s_bench_profiled_run.json"),
                       ("trace/*/*_kernel_stats.csv", "%s_bench_kernel_stats.csv"), ("trace_variants/*/*_kernel_stats.csv", "%s_variants_kernel_stats.csv"),
                       ("trace_chan_audio/*/*_kernel_stats.csv", "%s_chan_audio_kernel_stats.csv"), ("chan_audio.txt", "%s_chan_audio.txt"),
-                      ("dropin_latency.txt", "%s_dropin_latency.txt"),
+                      ("dropin_latency.txt", "%s_dropin_latency.txt"), ("scan_latency.txt", "%s_scan_latency.txt"), ("pw_big_time.txt", "%s_pw_big_time.txt"),
                       ("valu_issue.json", "%s_valu_issue.json"), ("valu_issue.txt", "%s_valu_issue.txt"),
                       ("rwmix.json", "%s_rwmix.json"), ("rwmix.txt", "%s_rwmix.txt")):
         f = one(os.path.join(src, pat))
