@@ -94,6 +94,12 @@ def chan_mode_valu_frac(mode, samples, seconds):
     f = newest_profile("pmc_chan_modes.json")
     try:
         m = json.load(open(f))[mode]
+        if mode == "nco":
+            # k_ch_nco is straight-line adds, ands and shifts, half of which issue twice per quad-cycle (0.29 instructions per SIMD-cycle measured): its
+            # bound is the issue ceiling of its own opcode mix, like the transform kernels' (valu_ceiling), not one instruction per quad-cycle
+            peak, src = valu_ceiling("k_ch_nco")
+            rate = m["valu_wave_instr_per_run"] * (samples / float(m["samples_per_run"])) / seconds / 1e9
+            return rate / peak, "%s (SQ_INSTS_VALU) / live time against %s" % (os.path.relpath(f, ROOT), src or "the nominal ceiling")
         busy_s = m["valu_active_quad_cycles_per_run"] * 4.0 * (samples / float(m["samples_per_run"])) / (SIMDS * CLOCK_GHZ * 1e9)
         return busy_s / seconds, ("%s (SQ_ACTIVE_INST_VALU of %s) x 4 cycles / (%d SIMDs x %.1f GHz x live time): the measured VALU busy share, fp64 passes included"
                                   % (os.path.relpath(f, ROOT), ", ".join(sorted(k.split("<")[0] for k, v in m["kernels"].items() if v.get("valu_active_quad_cycles_per_step", 0) > 1e5)),
@@ -947,13 +953,14 @@ def main():
                     R.check(L.rxgpu_power_scan_run_sharded(ps._h, None, d_in.data_ptr(), passes, per_w, d_avgs[0].data_ptr(), d_smps[0].data_ptr(), n,
                                                            d_avgs[0].data_ptr(), d_smps[0].data_ptr(), 0))
                 L.rxgpu_sync()
-                t1 = time.perf_counter()
-                reps = max(3, args.steps // 2)
-                for _ in range(reps):
+                reps, ts = max(5, args.steps // 2), []
+                for _ in range(reps):                              # launch by launch, the median: one slow launch of a 0.6 ms shard must not halve the figure
+                    t1 = time.perf_counter()
                     R.check(L.rxgpu_power_scan_run_sharded(ps._h, None, d_in.data_ptr(), passes, per_w, d_avgs[0].data_ptr(), d_smps[0].data_ptr(), n,
                                                            d_avgs[0].data_ptr(), d_smps[0].data_ptr(), 0))
-                L.rxgpu_sync()
-                t_shard = (time.perf_counter() - t1) / reps
+                    L.rxgpu_sync()
+                    ts.append(time.perf_counter() - t1)
+                t_shard = sorted(ts)[len(ts) // 2]
                 t_gather = (per_w * n * 8 + per_w * 4) / (XGMI_LINK_GBS * 1e9)
                 projection["by_world"][str(W)] = {
                     "tunes_per_rank": per_w, "shard_ms": t_shard * 1e3, "gather_ms_at_link_rate": t_gather * 1e3, "gather_bytes_per_rank": per_w * n * 8 + per_w * 4,

@@ -13,7 +13,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "rx_tools_amd", "csrc")
 WANT = {"power_kernels.hip": ["k_pw_fft4096ILi2ELb0ELb1E", "k_pwm_tailILi14ELb0ELi1E", "k_pwm_tailILi18ELb0ELi2E", "k_pwm_headILi18E"],
-        "fm_kernels.hip": ["k_ch_fftRILi10ELb1ELb1ELi16E", "k_fm_decimate_laneILb1ELi6ELi0E", "k_fm_fifth_regnILb1ELi4E"]}
+        "fm_kernels.hip": ["k_ch_fftRILi10ELb1ELb1ELi16E", "k_fm_decimate_laneILb1ELi6ELi0E", "k_fm_fifth_regnILb1ELi4E", "k_ch_ncoILi0E"]}
 
 
 def main():
