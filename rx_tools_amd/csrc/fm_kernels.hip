@@ -2313,9 +2313,17 @@ __device__ __forceinline__ uint32_t fifth_pk32(uint32_t a, uint32_t b, uint32_t 
 // ... and for inputs of any magnitude (rx_power's buffers are raw int16)
 __device__ __forceinline__ uint32_t fifth_int(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t e, uint32_t f)
 {
-	const int si = (lo16(a) + (lo16(b) + lo16(e)) * 5 + (lo16(c) + lo16(d)) * 10 + lo16(f)) >> 4;
-	const int sq = (hi16(a) + (hi16(b) + hi16(e)) * 5 + (hi16(c) + hi16(d)) * 10 + hi16(f)) >> 4;
-	return pack_iq(si, sq);
+	// twelve v_mad_i32_i16 straight from the packed halves (op_sel picks Q), no unpacking: the 16-bit pre-additions of fifth_pk32 would wrap here
+	int si, sq;
+	asm("v_mad_i32_i16 %0, %2, 1, 0\n\tv_mad_i32_i16 %1, %2, 1, 0 op_sel:[1,0,0,0]\n\t"
+	    "v_mad_i32_i16 %0, %7, 1, %0\n\tv_mad_i32_i16 %1, %7, 1, %1 op_sel:[1,0,0,0]\n\t"
+	    "v_mad_i32_i16 %0, %3, 5, %0\n\tv_mad_i32_i16 %1, %3, 5, %1 op_sel:[1,0,0,0]\n\t"
+	    "v_mad_i32_i16 %0, %6, 5, %0\n\tv_mad_i32_i16 %1, %6, 5, %1 op_sel:[1,0,0,0]\n\t"
+	    "v_mad_i32_i16 %0, %4, 10, %0\n\tv_mad_i32_i16 %1, %4, 10, %1 op_sel:[1,0,0,0]\n\t"
+	    "v_mad_i32_i16 %0, %5, 10, %0\n\tv_mad_i32_i16 %1, %5, 10, %1 op_sel:[1,0,0,0]"
+	    : "=&v"(si), "=&v"(sq) : "v"(a), "v"(b), "v"(c), "v"(d), "v"(e), "v"(f));
+	// (si >> 4) & 0xffff | (sq >> 4) << 16: the int16 stores of rtl_power.c:599-606
+	return (uint32_t)__builtin_amdgcn_ubfe((unsigned)si, 4u, 16u) | (((unsigned)sq << 12) & 0xffff0000u);
 }
 // MODE 0: packed int16 (sums below 2^15), 1: 32-bit sums of values below 2^14, 2: 32-bit sums of anything
 template <int MODE>
@@ -2653,7 +2661,8 @@ __device__ __forceinline__ uint32_t fr_shr(uint32_t v)
 // lane's NIN values, X[-t] (t = 1..5) sitting `hops` = ceil(t / NIN) lanes to the left at register NIN * hops - t -- that many wave_shr moves
 // away; at a block's start the same five places (in lanes 5 - hops) take the seam history instead.  WIDE levels (the fourth pass on: its
 // inputs reach 1024) sum in 32 bits.  Seams: 5 LV dwords per block (k_fm_fifth_seams<.., LV>).  n % 2^LV == 0.
-template <int NIN, bool WIDE>
+// MODE: fifth_any's (0 packed int16 sums, 1 32-bit sums of values below 2^14, 2 any int16: rx_power's raw buffers)
+template <int NIN, int MODE>
 __device__ __forceinline__ void fr_level(uint32_t (&in)[NIN], uint32_t (&out)[NIN / 2], unsigned lane, bool first, const uint32_t *__restrict__ sm)
 {
 	if (first) {
@@ -2681,12 +2690,13 @@ __device__ __forceinline__ void fr_level(uint32_t (&in)[NIN], uint32_t (&out)[NI
 			const int i = 2 * k - 5 + q;
 			tap[q] = i >= 0 ? in[i >= 0 ? i : 0] : xm[i < 0 ? -i : 1];
 		}
-		out[k] = WIDE ? fifth_pk32(tap[0], tap[1], tap[2], tap[3], tap[4], tap[5]) : fifth_pk(tap[0], tap[1], tap[2], tap[3], tap[4], tap[5]);
+		out[k] = fifth_any<MODE>(tap[0], tap[1], tap[2], tap[3], tap[4], tap[5]);
 	}
 }
 
 // LEFT more levels on NIN values per lane; DONE = passes already behind them (their seams at sm + 5 DONE; 32-bit sums from the fourth on)
-template <int NIN, int LEFT, int DONE>
+// FIXED >= 0: that arithmetic mode at every level (rx_power: 2)
+template <int NIN, int LEFT, int DONE, int FIXED = -1>
 __device__ __forceinline__ void fr_cascade(uint32_t (&in)[NIN], uint32_t (&res)[NIN >> LEFT], unsigned lane, bool first, const uint32_t *__restrict__ sm)
 {
 	if constexpr (LEFT == 0) {
@@ -2695,8 +2705,8 @@ __device__ __forceinline__ void fr_cascade(uint32_t (&in)[NIN], uint32_t (&res)[
 			res[k] = in[k];
 	} else {
 		uint32_t o[NIN / 2];
-		fr_level<NIN, (DONE >= 3)>(in, o, lane, first, sm + 5 * DONE);
-		fr_cascade<NIN / 2, LEFT - 1, DONE + 1>(o, res, lane, first, sm);
+		fr_level<NIN, FIXED >= 0 ? FIXED : (DONE >= 3 ? 1 : 0)>(in, o, lane, first, sm + 5 * DONE);
+		fr_cascade<NIN / 2, LEFT - 1, DONE + 1, FIXED>(o, res, lane, first, sm);
 	}
 }
 
@@ -2845,6 +2855,187 @@ __global__ __launch_bounds__(256) void k_fm_fifth_regn(const uint32_t *__restric
 		}
 		if (TW > 1 && tile + 4 >= tiles_per_block)
 			break;
+	}
+}
+
+// ------------------------------------------------------------------ rx_power: the stateless cascade in registers (round 6)
+//
+// rx_power -F: `downsample_passes` stateless fifth_order passes per buffer (rtl_power.c:582-607 via 734-737), the droop FIR (626-654 via 739-742),
+// then remove_dc (609-624).  Four passes through the LDS-tiled kernels crossed HBM nine times at the 1/16 rate (three passes out, the fourth in and
+// out, the FIR in and out, the dc sums in, the transform's head in) -- 1.73 x the input bytes at N = 2^14.  Here: k_fm_fifth_regn's shape on RAW int16
+// (no scale, no rotation, 32-bit tap sums at every level: fifth_int), four level-LV outputs per lane, the FIR over the neighbouring lanes' outputs
+// (wave_shr moves, as the rx_fm whole-chain kernel does), one 16-byte store per lane, and the buffer's dc sums on the way out (a wave never straddles a
+// buffer: one wave reduction, two int64 atomics).  The buffers are STATELESS and eased in: the first five outputs of every pass come from special
+// formulas on the pass input's samples 0..8 (rtl_power.c:595-597 and the d == e quirk of the loop's first turns) -- they contaminate exactly the
+// first five outputs of the NEXT pass and nothing else (output k >= 5 reads inputs >= 5).  This kernel computes the regular formula everywhere (the
+// halo lanes of a buffer's first tile hold clamped garbage); k_pw_fifth_fix then recomputes a buffer's first 5 (with the FIR: 14) final samples from
+// the raw buffer, literally, overwrites them and corrects the sums by what changed.
+template <int LV, bool FIR, int TW>
+__global__ __launch_bounds__(256) void k_pw_fifth_regn(const uint32_t *__restrict__ in, unsigned n, unsigned in_stride, unsigned tiles_per_block, unsigned wgs_per_block,
+                                                       unsigned total_wgs, uint32_t *__restrict__ out, unsigned out_stride, int f1, int f2, int f3, int f4, int f5,
+                                                       i64 *__restrict__ sums)
+{
+	constexpr int NOUT = 4, R = NOUT << LV, NP = R / 4;
+	static_assert(LV >= 1 && NP <= 16, "at most 64 samples per lane");
+	const unsigned lane = threadIdx.x & 63u;
+	const unsigned per = gridDim.x >> 3;
+	const unsigned wgi = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+	if (wgi >= total_wgs)
+		return;
+	const unsigned blk32 = wgi / wgs_per_block;
+	const unsigned wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	// a workgroup takes 4 TW consecutive tiles of its buffer, four at a time: wave wv walks tiles base + wv, base + 4 + wv, ... -- with 16 KiB of
+	// stage per wave only ten waves fit a CU, so a wave keeps the NEXT tile's loads in flight behind the tile it computes
+	unsigned tile = (wgi - blk32 * wgs_per_block) * (4 * TW) + wv;
+	if (tile >= tiles_per_block)
+		return;
+	const u64 blk = blk32;
+	const uint32_t *braw = in + blk * (u64)in_stride;
+	const unsigned K = n >> LV;
+	__shared__ u32x4 stage[4][64 * NP];
+	const int s_max = (int)n - 4;
+	const unsigned rot = (lane * NP) / 16u;
+	auto fetch = [&](unsigned t) {
+#pragma unroll
+		for (int h = 0; h < NP; h++) {
+			const unsigned slot = 64u * h + lane, sl = slot / NP, sj = (slot - (sl * NP) / 16u) % NP;
+			int sp = (int)(t * (FR_OUT * R)) - 5 * R + (int)(4u * (sl * NP + sj));
+			sp = sp < 0 ? 0 : (sp > s_max ? s_max : sp);
+			__builtin_amdgcn_global_load_lds((const void *)(braw + sp), (__attribute__((address_space(3))) void *)&stage[wv][64 * h], 16, 0, 2);
+		}
+	};
+	fetch(tile);
+	int si = 0, sq = 0;                                      // the wave's share of the buffer's dc sums: 4 TW int16 per lane, far inside int32
+#pragma unroll 1
+	for (int it = 0; it < TW; it++, tile += 4) {
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		uint32_t x[R];
+#pragma unroll
+		for (int j = 0; j < NP; j++) {
+			const u32x4 v = stage[wv][NP * lane + ((j + rot) % NP)];
+			x[4 * j] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
+		}
+		if constexpr (TW > 1) {
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+			if (it + 1 < TW && tile + 4 < tiles_per_block)
+				fetch(tile + 4);
+		}
+		uint32_t w[NOUT];
+		fr_cascade<R, LV, 0, 2>(x, w, lane, false, nullptr);
+		uint32_t y[4];
+		if constexpr (FIR) {
+			uint32_t W[13];                                      // W[i] = level-LV sample 4l - 9 + i
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				W[9 + k] = w[k];
+				W[5 + k] = fr_shr(w[k]);
+				W[1 + k] = fr_shr(W[5 + k]);
+			}
+			W[0] = fr_shr(W[4]);
+#pragma unroll
+			for (int k = 0; k < 4; k++)
+				y[k] = droop9(W + k, f1, f2, f3, f4, f5);
+		} else {
+#pragma unroll
+			for (int k = 0; k < 4; k++)
+				y[k] = w[k];
+		}
+		const unsigned j = tile * FR_OUT + lane - 5u;
+		if (lane >= 5u && 4u * j < K) {
+			__builtin_nontemporal_store((u32x4){y[0], y[1], y[2], y[3]}, reinterpret_cast<u32x4 *>(out + blk * (u64)out_stride + 4u * j));
+			si += lo16(y[0]) + lo16(y[1]) + lo16(y[2]) + lo16(y[3]);
+			sq += hi16(y[0]) + hi16(y[1]) + hi16(y[2]) + hi16(y[3]);
+		}
+		if (TW > 1 && tile + 4 >= tiles_per_block)
+			break;
+	}
+	if (sums) {
+		for (int off = 32; off; off >>= 1) { si += __shfl_down(si, off); sq += __shfl_down(sq, off); }
+		if (lane == 0) {
+			atomicAdd((unsigned long long *)&sums[2 * blk], (unsigned long long)(i64)si);
+			atomicAdd((unsigned long long *)&sums[2 * blk + 1], (unsigned long long)(i64)sq);
+		}
+	}
+}
+
+// the first NFIX final samples of every buffer, literally, over what k_pw_fifth_regn left there; the dc sums follow.  One wave per buffer: the levels' first
+// samples in LDS, a lane per output (at most 105 per level), wave-level ordering between the levels.
+__device__ __forceinline__ uint32_t pw_fifth_head1(const uint32_t *s, int k)
+{
+	int r[2];
+#pragma unroll
+	for (int h = 0; h < 2; h++) {
+#define G(i) (h ? hi16(s[i]) : lo16(s[i]))
+		if (k == 0) r[h] = ((G(0) + G(1)) * 10 + (G(2) + G(3)) * 5 + G(3) + G(5)) >> 4;
+		else if (k == 1) r[h] = ((G(1) + G(2)) * 10 + (G(0) + G(3)) * 5 + G(4) + G(5)) >> 4;
+		else if (k == 2) r[h] = (G(0) + (G(1) + G(4)) * 5 + (G(2) + G(3)) * 10 + G(5)) >> 4;
+		else if (k == 3) r[h] = (G(2) + (G(3) + G(5)) * 5 + (G(4) + G(5)) * 10 + G(6)) >> 4;
+		else if (k == 4) r[h] = (G(4) + (G(5) + G(7)) * 5 + (G(5) + G(6)) * 10 + G(8)) >> 4;
+		else r[h] = (G(2 * k - 5) + (G(2 * k - 4) + G(2 * k - 1)) * 5 + (G(2 * k - 3) + G(2 * k - 2)) * 10 + G(2 * k)) >> 4;
+#undef G
+	}
+	return pack_iq(r[0], r[1]);
+}
+
+template <int LV, bool FIR>
+__global__ __launch_bounds__(256) void k_pw_fifth_fix(const uint32_t *__restrict__ in, unsigned n_bufs, unsigned in_stride, uint32_t *__restrict__ out, unsigned out_stride,
+                                                      const int *__restrict__ fir, i64 *__restrict__ sums)
+{
+	constexpr int NFIX = FIR ? 14 : 5, CMAX = 216;               // samples needed at level p for NFIX at level LV: c(p - 1) = max(2 c(p) - 1, 9); LV = 4: 209 raw at most
+	static_assert(LV == 4, "the level buffers are sized for four passes");
+	__shared__ uint32_t lv[4][2][CMAX];
+	const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+	const unsigned b = blockIdx.x * 4 + wv;
+	if (b >= n_bufs)
+		return;
+	int cnt[LV + 1];
+	cnt[LV] = NFIX;
+#pragma unroll
+	for (int p = LV; p > 0; p--)
+		cnt[p - 1] = 2 * cnt[p] - 1 > 9 ? 2 * cnt[p] - 1 : 9;
+	const uint32_t *src = in + (u64)b * in_stride;
+	uint32_t *cur = lv[wv][0], *nxt = lv[wv][1];
+	for (int i = (int)lane; i < cnt[0]; i += 64)
+		cur[i] = src[i];
+#pragma unroll
+	for (int p = 1; p <= LV; p++) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		for (int k = (int)lane; k < cnt[p]; k += 64)
+			nxt[k] = pw_fifth_head1(cur, k);
+		uint32_t *t = cur; cur = nxt; nxt = t;
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	// cur[0 .. NFIX): level-LV samples; with the FIR: samples 0..8 pass through, 9.. are filtered from the nine before (rtl_power.c:626-654)
+	i64 di = 0, dq = 0;
+	if (lane < NFIX) {
+		const int d = (int)lane;
+		uint32_t fin;
+		if (!FIR || d < 9) {
+			fin = cur[d];
+		} else {
+			const uint32_t *h = cur + d - 9;
+			const int si = __mul24(lo16(h[0]) + lo16(h[8]), fir[1]) + __mul24(lo16(h[1]) + lo16(h[7]), fir[2]) + __mul24(lo16(h[2]) + lo16(h[6]), fir[3]) +
+			               __mul24(lo16(h[3]) + lo16(h[5]), fir[4]) + __mul24(lo16(h[4]), fir[5]);
+			const int sq = __mul24(hi16(h[0]) + hi16(h[8]), fir[1]) + __mul24(hi16(h[1]) + hi16(h[7]), fir[2]) + __mul24(hi16(h[2]) + hi16(h[6]), fir[3]) +
+			               __mul24(hi16(h[3]) + hi16(h[5]), fir[4]) + __mul24(hi16(h[4]), fir[5]);
+			fin = pack_iq(si >> 15, sq >> 15);
+		}
+		uint32_t *dst = out + (u64)b * out_stride + d;
+		const uint32_t old = *dst;
+		di = lo16(fin) - lo16(old);
+		dq = hi16(fin) - hi16(old);
+		*dst = fin;
+	}
+	if (sums) {
+		for (int off = 8; off; off >>= 1) { di += __shfl_down(di, off); dq += __shfl_down(dq, off); }
+		if (lane == 0) {
+			atomicAdd((unsigned long long *)&sums[2 * (u64)b], (unsigned long long)di);
+			atomicAdd((unsigned long long *)&sums[2 * (u64)b + 1], (unsigned long long)dq);
+		}
 	}
 }
 
@@ -5183,5 +5374,36 @@ extern "C" int rxk_pw_fifth_fused(void *stream, const int16_t *in, unsigned long
 #define FUSED(F) hipLaunchKernelGGL((k_fm_fifth_fused<F, false, true, true>), dim3(grid), dim3(256), 0, s, p, n, tiles, tpw, nullptr, o, in_stride, out_stride)
 	if (fuse == 1) FUSED(1); else if (fuse == 2) FUSED(2); else FUSED(3);
 #undef FUSED
+	LAUNCH_RET();
+}
+
+// four stateless passes (+ the droop FIR: fir = cic_9_tables[4] on the device, or NULL) in registers, the buffers' dc sums accumulated into sums[2 * buffer],
+// [2 * buffer + 1] (zeroed by the caller; NULL: none).  n % 64 == 0, n >= 256; strides in complex samples, multiples of 4; out 16-byte aligned
+extern "C" int rxk_pw_fifth_regn4(void *stream, const int16_t *in, unsigned long long n_bufs, unsigned n, unsigned in_stride, const int *fir_dev, const int *fir_host,
+                                  int16_t *out, unsigned out_stride, long long *sums)
+{
+	hipStream_t s = (hipStream_t)stream;
+	constexpr int LV = 4, TW = 2;
+	const unsigned tiles_r = ((n >> LV) / 4 + FR_OUT - 1) / FR_OUT;
+	const unsigned twn = tiles_r >= 4 * TW ? TW : 1;
+	const unsigned wgs_per_block = (tiles_r + 4 * twn - 1) / (4 * twn);
+	const u64 total = n_bufs * (u64)wgs_per_block;
+	if (total > 0xfffffff0ull || n_bufs > 0x7fffffffull)
+		return (int)hipErrorInvalidValue;
+	const unsigned rgrid = (unsigned)((total + 7) / 8 * 8);
+	const uint32_t *p = (const uint32_t *)in;
+	uint32_t *o = (uint32_t *)out;
+	const unsigned fgrid = (unsigned)((n_bufs + 3) / 4);
+	const int f1 = fir_host ? fir_host[1] : 0, f2 = fir_host ? fir_host[2] : 0, f3 = fir_host ? fir_host[3] : 0, f4 = fir_host ? fir_host[4] : 0, f5 = fir_host ? fir_host[5] : 0;
+#define PWR(FI, T) hipLaunchKernelGGL((k_pw_fifth_regn<LV, FI, T>), dim3(rgrid), dim3(256), 0, s, p, n, in_stride, tiles_r, wgs_per_block, (unsigned)total, o, out_stride, \
+		                              f1, f2, f3, f4, f5, (i64 *)sums)
+	if (fir_host) {
+		if (twn == TW) PWR(true, TW); else PWR(true, 1);
+		hipLaunchKernelGGL((k_pw_fifth_fix<LV, true>), dim3(fgrid), dim3(256), 0, s, p, (unsigned)n_bufs, in_stride, o, out_stride, fir_dev, (i64 *)sums);
+	} else {
+		if (twn == TW) PWR(false, TW); else PWR(false, 1);
+		hipLaunchKernelGGL((k_pw_fifth_fix<LV, false>), dim3(fgrid), dim3(256), 0, s, p, (unsigned)n_bufs, in_stride, o, out_stride, fir_dev, (i64 *)sums);
+	}
+#undef PWR
 	LAUNCH_RET();
 }

@@ -299,6 +299,10 @@ int rxk_pw_fifth(void *stream, const int16_t *in, int16_t *out, size_t n_bufs, i
  * n % RXK_FIFTH_TILE == 0 */
 int rxk_pw_fifth_fused(void *stream, const int16_t *in, unsigned long long n_bufs, unsigned n, unsigned in_stride, int fuse,
                        int16_t *out, unsigned out_stride);
+/* four stateless fifth_order passes (+ droop FIR when fir_host != NULL: cic_9_tables[4], fir_dev the same table on the device) in registers, one launch +
+ * a fix-up of each buffer's first samples; sums != NULL: remove_dc's sums of every output buffer into sums[2 b], sums[2 b + 1] (zeroed by the caller) */
+int rxk_pw_fifth_regn4(void *stream, const int16_t *in, unsigned long long n_bufs, unsigned n, unsigned in_stride, const int *fir_dev, const int *fir_host,
+                       int16_t *out, unsigned out_stride, long long *sums);
 /* generic_fir (rtl_power.c:626-654) over n complex samples per buffer */
 int rxk_pw_droop(void *stream, const int16_t *in, int16_t *out, size_t n_bufs, int n, int stride, const int *fir);
 /* P9 rms_power sums: t[b] = sum s, p[b] = sum s^2 (int64, exact) per buffer, then the fp64
@@ -320,9 +324,11 @@ int rxk_fm_post_downsample(void *stream, const int16_t *in, unsigned long long n
 /* bin_e 14 .. 21, eff_len a multiple of 2^(bin_e+1): the register-blocked transform as two to four launches (radix-16 passes through a
  * scratch copy in HBM until a sub-transform fits one workgroup, then the independent sub-transforms), same scratch / dc workspaces as
  * rxk_pw_fft_big; returns < 0 if the geometry does not fit */
+/* where the dc workspace (2 ints per (pass, tune), then -- 16-byte aligned -- 2 int64 per (pass, tune)) keeps remove_dc's sums */
+long long *rxk_pw_dc_sums(int *dc, size_t n_pass_tunes);
 int rxk_pw_fft_mid(void *stream, const int16_t *in, size_t tune_stride, size_t pass_stride, int passes, int tunes,
                    int bin_e, int eff_len, const int *window, const uint32_t *twiddle, int peak_hold,
-                   uint32_t *scratch, size_t cap_blocks, int *dc, long long *avg, long long *partial, size_t partial_cap);
+                   uint32_t *scratch, size_t cap_blocks, int *dc, long long *avg, long long *partial, size_t partial_cap, int dc_sums_done);
 /* workgroups the second launch aims for; partial needs (RXK_PWM_TARGET_WG / 4 + tunes * blocks per tune) * 2^bin_e int64 to be used */
 #define RXK_PWM_TARGET_WG 2048
 int rxk_pw_fft_big(void *stream, const int16_t *in, size_t tune_stride, size_t pass_stride, int passes, int tunes,

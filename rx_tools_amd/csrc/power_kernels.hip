@@ -799,10 +799,15 @@ __global__ void k_pwb_dc_fin(const i64 *__restrict__ sums, int n, int eff_len, i
 }
 
 // dc: 2 ints per (pass, tune), then -- 16-byte aligned -- 2 int64 per (pass, tune) of scratch for the sums (RXK_PW_DC_BYTES per pair)
+extern "C" long long *rxk_pw_dc_sums(int *dc, size_t n_pass_tunes)
+{
+	return (long long *)(dc + ((2 * n_pass_tunes + 3) & ~(size_t)3));
+}
+
 static void pwb_dc(hipStream_t s, const int16_t *in, size_t tune_stride, size_t pass_stride, int passes, int tunes, int eff_len, int *dc)
 {
 	const size_t n = (size_t)passes * tunes;
-	i64 *sums = (i64 *)(dc + ((2 * n + 3) & ~(size_t)3));
+	i64 *sums = (i64 *)rxk_pw_dc_sums(dc, n);
 	(void)hipMemsetAsync(sums, 0, n * 16, s);
 	// enough workgroups to fill the chip (about eight per CU), slices of at least 16 KiB
 	int slices = (int)((2048 + n - 1) / n);
@@ -1126,7 +1131,7 @@ __global__ void k_pwm_reduce(const i64 *__restrict__ partial, int tunes, int nbp
 // eff_len a multiple of 2^(bin_e+1), bin_e = 14 .. 21; scratch: cap_blocks * 2^bin_e dwords; dc: 2 ints per (pass, tune)
 extern "C" int rxk_pw_fft_mid(void *stream, const int16_t *in, size_t tune_stride, size_t pass_stride, int passes, int tunes,
                               int bin_e, int eff_len, const int *window, const uint32_t *twiddle, int peak_hold,
-                              uint32_t *scratch, size_t cap_blocks, int *dc, long long *avg, long long *partial, size_t partial_cap)
+                              uint32_t *scratch, size_t cap_blocks, int *dc, long long *avg, long long *partial, size_t partial_cap, int dc_sums_done)
 {
 	hipStream_t s = (hipStream_t)stream;
 	const size_t n = (size_t)1 << bin_e;
@@ -1135,7 +1140,13 @@ extern "C" int rxk_pw_fft_mid(void *stream, const int16_t *in, size_t tune_strid
 	if (bin_e < 14 || bin_e > 21 || !nbpt || (size_t)eff_len % (2 * n) || cap_blocks < per_pass)
 		return -1;
 	const uint32_t *tw2 = twiddle + (n >> 1);                        // the doubled half of rxgpu_twiddle_table (bfly_pk)
-	pwb_dc(s, in, tune_stride, pass_stride, passes, tunes, eff_len, dc);
+	/* dc_sums_done: the producer of `in` (rxk_pw_fifth_regn4) left remove_dc's sums where pwb_dc would have put them (rxk_pw_dc_sums) -- only the division is left */
+	if (dc_sums_done) {
+		const size_t npt = (size_t)passes * tunes;
+		hipLaunchKernelGGL(k_pwb_dc_fin, dim3((unsigned)((npt + 255) / 256)), dim3(256), 0, s, (const i64 *)rxk_pw_dc_sums(dc, npt), (int)npt, eff_len, dc);
+	} else {
+		pwb_dc(s, in, tune_stride, pass_stride, passes, tunes, eff_len, dc);
+	}
 	const int max_np = (int)(cap_blocks / per_pass);
 	for (int p0 = 0; p0 < passes; p0 += max_np) {
 		const int np = passes - p0 < max_np ? passes - p0 : max_np;

@@ -336,6 +336,7 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 
 	const int16_t *fft_in = d_in;
 	int eff_len = buf_len;
+	int dc_sums_done = 0;                             /* the downsampler left remove_dc's sums in big_dc (rxk_pw_fifth_regn4) */
 	size_t fft_tune_stride = (size_t)buf_len, fft_pass_stride = (size_t)tunes * (size_t)buf_len;
 	if (ds > 1 && (p->boxcar || ds_p)) {
 		const size_t need = n_bufs * (size_t)buf_len * 2;
@@ -373,6 +374,27 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 			} else {
 				RX_K(rxk_pw_boxcar(st, d_in, s->work[0], n_bufs, buf_len, ds, n_read));
 			}
+			fft_in = s->work[0];
+		} else if (ds_p == 4 && (buf_len / 2) % 64 == 0 && buf_len / 2 >= 1024 && ((size_t)d_in & 15u) == 0 && (buf_len / 2) % 4 == 0 &&
+		           (p->comp_fir_size == 9 || p->comp_fir_size == 0) && n_bufs < ((size_t)1 << 31)) {
+			/* four passes (ds = 16): the register cascade -- passes, droop FIR and remove_dc's sums in one launch, the 1/16-rate buffers
+			 * written once (rtl_power.c:734-745).  The sums go where the large-N transform's dc pass would have put them. */
+			const int fir = p->comp_fir_size == 9;
+			long long *sums = NULL;
+			const int eff = buf_len / ds;
+			if (p->bin_e >= 14 && p->bin_e <= 21 && eff % (2 << p->bin_e) == 0) {
+				if (s->big_dc_cap < (size_t)passes * (size_t)tunes) {
+					hipFree(s->big_dc);
+					s->big_dc = NULL; s->big_dc_cap = 0;
+					RX_HIP(hipMalloc((void **)&s->big_dc, (size_t)passes * (size_t)tunes * 24 + 64));
+					s->big_dc_cap = (size_t)passes * (size_t)tunes;
+				}
+				sums = rxk_pw_dc_sums(s->big_dc, (size_t)passes * (size_t)tunes);
+				RX_HIP(hipMemsetAsync(sums, 0, (size_t)passes * (size_t)tunes * 16, st));
+				dc_sums_done = 1;
+			}
+			RX_K(rxk_pw_fifth_regn4(st, d_in, n_bufs, (unsigned)(buf_len / 2), (unsigned)(buf_len / 2), fir ? s->fir_dev : NULL, fir ? cic_9_tables[4] : NULL,
+			                        s->work[0], (unsigned)(buf_len / 2), sums));
 			fft_in = s->work[0];
 		} else {                                           /* rtl_power.c:734-743 */
 			const int16_t *src = d_in;
@@ -462,7 +484,7 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 			}
 			RX_K(rxk_pw_fft_mid(st, fft_in, fft_tune_stride, fft_pass_stride, passes, tunes, p->bin_e, eff_len,
 			                    s->window_dev, s->twiddle_dev, p->peak_hold, s->big_scratch, s->big_cap_blocks, s->big_dc, (long long *)d_avg,
-			                    (long long *)s->big_partial, s->big_partial_cap));
+			                    (long long *)s->big_partial, s->big_partial_cap, dc_sums_done));
 		}
 		else
 			RX_K(rxk_pw_fft_big(st, fft_in, fft_tune_stride, fft_pass_stride, passes, tunes, p->bin_e, eff_len,

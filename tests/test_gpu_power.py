@@ -258,6 +258,30 @@ def test_comm_rejects_a_rank_the_communicator_does_not_report(tmp_path):
     assert os.environ.get("RXGPU_RCCL_LIB") == env_before
 
 
+@pytest.mark.parametrize("bin_e,blocks,fir,amp,tunes,passes", [
+    (14, 1, 9, 32768, 1, 3),       # the bench leg's shape (-f 100M:100.1M:10 -F 9), full scale: every 32-bit tap sum, the FIR's wrap
+    (14, 1, 0, 32768, 2, 2),       # no FIR: the cascade's samples themselves are the transform's input
+    (14, 2, 9, 9000, 3, 2),        # two transforms per buffer, several tunes: the sums of each (pass, tune)
+    (12, 2, 9, 32768, 3, 2),       # N = 4096 behind the same cascade: the transform kernel takes the dc from its registers, no sums wanted
+    (10, 4, 0, 20000, 2, 1),       # N = 1024
+    (15, 1, 9, 32768, 1, 2),       # N = 2^15
+])
+def test_four_stateless_passes_in_registers(bin_e, blocks, fir, amp, tunes, passes):
+    """-F with downsample_passes = 4 (ds = 16): k_pw_fifth_regn (four eased-in fifth_order passes + droop FIR + remove_dc's sums in one launch, rtl_power.c:582-654,
+    734-745) + k_pw_fifth_fix (each buffer's first samples, literally) == the oracle's scanner(): buffers of one and two transforms, with and without the FIR,
+    full-scale noise and constant full-scale input (the saturated tap sums), N from 2^10 to 2^15"""
+    import types
+    n = 1 << bin_e
+    plan = types.SimpleNamespace(bin_e=bin_e, buf_len=2 * n * 16 * blocks, downsample=16, downsample_passes=4)
+    wc, sw = R.window_coefs("hamming", n), R.sine_table(bin_e)
+    for data in (sig_noise(passes * tunes * plan.buf_len, seed=21 + bin_e, amp=amp),
+                 np.full(passes * tunes * plan.buf_len, 32767 if fir else -32768, np.int16)):
+        want, ws = oracle_scan(data, passes, tunes, plan, wc, sw, 0, fir, 0)
+        got, gs = gpu_scan(data, passes, tunes, plan, wc, sw, 0, fir, 0)
+        bad = np.argwhere(got != want)
+        assert bad.size == 0 and np.array_equal(gs, ws), "first mismatch at %s (%d bad)" % (bad[0] if bad.size else None, len(bad))
+
+
 def test_buffer_that_is_no_whole_number_of_large_transforms():
     """N = 2^16 with 1.5 transforms per decimated buffer (boxcar ds = 2 on 3 * 2^17 int16: the second transform is half samples, half the zeros
     the boxcar leaves behind, rtl_power.c:723-733) -- a geometry the reference's planner never makes and rxgpu_power_scan_create accepts: it takes
