@@ -741,7 +741,9 @@ __global__ __launch_bounds__(256) void k_pwb_dc(const int16_t *__restrict__ in, 
                                                 int eff_len, int slices, i64 *__restrict__ sums)
 {
 	__shared__ i64 red[8];
-	const int pt = blockIdx.x / slices, sl = blockIdx.x - pt * slices, tid = threadIdx.x;
+	// the buffers in REVERSE order: what this pass touched last is what the transform's first workgroups read first (Infinity Cache, A/B round 6)
+	const int ptr_ = blockIdx.x / slices, sl = blockIdx.x - ptr_ * slices, tid = threadIdx.x;
+	const int pt = (int)(gridDim.x / slices) - 1 - ptr_;
 	const int pass = pt / tunes, tune = pt - pass * tunes;
 	const uint32_t *buf = (const uint32_t *)(in + (size_t)pass * pass_stride + (size_t)tune * tune_stride);
 	const int L = eff_len;
