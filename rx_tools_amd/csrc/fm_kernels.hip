@@ -4682,10 +4682,29 @@ extern "C" int rxk_fm_resample(void *stream, const int16_t *y, u64 n, int fast, 
 // A few bytes from one place to another as ONE WAVE.  hipMemcpyAsync of 4..240 bytes becomes a blit kernel whose workgroup
 // waits for room while an HBM-bound kernel fills the chip -- rocprofv3 showed the 4-byte copy of the flag count sitting for a
 // millisecond in front of the audio stages, and the next run's decimator waiting for those.  dst may be pinned host memory.
+// a device buffer into its page-locked host mirror (16-byte aligned both sides): 16-byte units, the odd bytes at the end one by one
+__global__ __launch_bounds__(256) void k_copy_mirror(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, unsigned n)
+{
+	const unsigned units = n >> 4;
+	for (unsigned u = blockIdx.x * 256u + threadIdx.x; u < units; u += gridDim.x * 256u)
+		reinterpret_cast<uint4 *>(dst)[u] = reinterpret_cast<const uint4 *>(src)[u];
+	if (blockIdx.x == 0 && threadIdx.x < (n & 15u))
+		dst[(units << 4) + threadIdx.x] = src[(units << 4) + threadIdx.x];
+}
+
 __global__ void k_copy_small(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, unsigned n)
 {
 	for (unsigned i = threadIdx.x; i < n; i += 64)
 		dst[i] = src[i];
+}
+
+extern "C" int rxk_copy_mirror(void *stream, void *dst, const void *src, unsigned bytes)
+{
+	if (!bytes)
+		return 0;
+	const unsigned grid = (bytes / 16 + 255) / 256;
+	hipLaunchKernelGGL(k_copy_mirror, dim3(grid ? (grid > 64 ? 64 : grid) : 1), dim3(256), 0, (hipStream_t)stream, (uint8_t *)dst, (const uint8_t *)src, bytes);
+	LAUNCH_RET();
 }
 
 extern "C" int rxk_copy_small(void *stream, void *dst, const void *src, unsigned bytes)

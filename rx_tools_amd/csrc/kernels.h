@@ -176,6 +176,8 @@ int rxk_fm_dc_block(void *stream, int16_t *y, unsigned long long M, rxk_fm_block
  * run (deemph_avg, now_lpr, prev_lpr_index, dc_avg) are copied to snap[0..4) so that the stages can be redone later */
 /* a few bytes as one wave (not a blit kernel): device -> device, or device -> pinned host */
 int rxk_copy_small(void *stream, void *dst, const void *src, unsigned bytes);
+/* a device buffer into a page-locked host mirror (both 16-byte aligned), 16-byte units: the drop-in's lowpassed[] on its way home */
+int rxk_copy_mirror(void *stream, void *dst, const void *src, unsigned bytes);
 int rxk_fm_carry_advance(void *stream, rxk_fm_dev *dev, int advance, int *snap);
 /* redo of audio stages: their carries-in from a snapshot (snap != NULL) or from the carries-out of the run before */
 int rxk_fm_audio_carry(void *stream, rxk_fm_dev *dev, const int *snap);

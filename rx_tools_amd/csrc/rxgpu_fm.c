@@ -87,6 +87,10 @@ struct rxgpu_fm_stream {
 	/* plan knobs, read once at creation (rxgpu_knob): $RXGPU_DEEMPH_CHUNK, $RXGPU_HOST_CHUNK */
 	int k_deemph_chunk;
 	unsigned long long k_host_chunk;
+	/* one_stream (the drop-in's per-block streams): stream A, stream B and the seam stream are ONE stream -- a run of one block has nothing to
+	 * overlap, and every hop between streams is an event the next kernel waits behind (round 6: 84 -> see profiles/r06_dropin_latency.txt) */
+	int one_stream;
+	int16_t *lp_mirror;                  /* one_stream runs: a page-locked host mirror the run's decimated IQ (lp_final) is written into at the end of the run */
 	int flag_all;                        /* $RXGPU_FLAG_ALL: every libm discriminator sample goes through the host re-evaluation (tests) */
 	int allow_empty;                     /* the drop-in: a block that yields no decimated sample is legal (the struct-memory reads the
 	                                      * reference then makes are reproduced by rxgpu_full_demod on the real struct) */
@@ -520,7 +524,7 @@ static int run_audio_stages(rxgpu_fm_stream *s, hipStream_t st, unsigned long lo
 		rxgpu_prof_end_on("fm_resample", st);
 	} else if (audio == pcm && M) {
 		/* no stage wrote d_out yet: the demodulator output is the result */
-		RX_HIP(hipMemcpyAsync(d_out, pcm, M * 2, hipMemcpyDeviceToDevice, st));
+		RX_HIP(hipMemcpyAsync(d_out, pcm, M * 2, hipMemcpyDefault, st));    /* d_out may be a page-locked host mirror (the drop-in) */
 	}
 	if (!(p->deemph && M) || !resample)
 		RX_K(rxk_fm_passthrough_carry(st, s->dev, !(p->deemph && M), !resample));
@@ -618,11 +622,13 @@ static void block_lengths(const rxgpu_fm_stream *s, const struct run_geom *g, si
  * data, latency-bound) on stream B behind an event, so that the next run's decimator overlaps
  * this run's audio stages.  Carries stay on the device between chained runs. */
 static int retire_slot(rxgpu_fm_stream *s, int slot);
+static hipStream_t fm_sa(const rxgpu_fm_stream *s) { return s->one_stream ? rxgpu_hip_stream2() : rxgpu_hip_stream(); }
+static hipStream_t fm_sd(const rxgpu_fm_stream *s) { return s->one_stream ? rxgpu_hip_stream2() : rxgpu_hip_stream4(); }
 
 static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_blocks, size_t block_len,
                        int16_t *d_out, const struct run_geom *g)
 {
-	hipStream_t sa = rxgpu_hip_stream(), sb = rxgpu_hip_stream2();
+	hipStream_t sa = fm_sa(s), sb = rxgpu_hip_stream2();
 	const rxgpu_fm_params *p = &s->p;
 	const int16_t *d_iq = d_iq_in;
 	int prescaled = p->prescaled;
@@ -801,7 +807,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 			/* The group's seam histories need nothing from the previous run but its archive (a few samples, written by ITS seam
 			 * kernel): they go on a stream of their own and are ready long before stream A gets to this run -- left on stream A,
 			 * the history copy and the seam kernel sat between two HBM-bound launches (50-150 us of an idle chip per run). */
-			hipStream_t sd = rxgpu_hip_stream4();
+			hipStream_t sd = fm_sd(s);
 			if (fresh) {
 				RX_HIP(hipEventRecord(s->ev_up, sb));    /* the history upload above went through stream B */
 				RX_HIP(hipStreamWaitEvent(sd, s->ev_up, 0));
@@ -913,7 +919,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 			                 s->blk.first_mode, g->K, p->custom_atan, 0, s->pcm, s->dev, flag_rec, flag_cnt, 0, n_blocks, s->atan_lut, 0, s->flag_all, 0));
 			rxgpu_prof_end_on("fm_disc", sb);
 		} else if (p->mode == RXGPU_MODE_RAW) {
-			RX_HIP(hipMemcpyAsync(d_out, lpw, g->M * 4, hipMemcpyDeviceToDevice, sb));
+			RX_HIP(hipMemcpyAsync(d_out, lpw, g->M * 4, hipMemcpyDefault, sb));
 			RX_K(rxk_fm_passthrough_carry(sb, s->dev, 1, 1));
 		} else {
 			RX_K(rxk_fm_simple_demod(sb, lpw, g->M, p->mode, p->output_scale, s->pcm));
@@ -943,6 +949,13 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 	if (p->rate_out2 > 0 && p->mode != RXGPU_MODE_RAW)
 		s->h_prev_lpr_index = (int)((unsigned long long)g->pr0 + (g->M / (unsigned long long)g->post) * (unsigned long long)p->rate_out2 -
 		                            g->J * (unsigned long long)p->rate_out);
+	if (s->lp_mirror) {
+		/* the drop-in hands lowpassed[] back: lp_len' int16 (odd on some -F shapes), never fewer than two -- every fifth_order pass rewrites
+		 * lowpassed[0] and [1] even for an empty block (rtl_fm.c:419-423) */
+		const int lp_len_out = g->passes ? (g->literal ? g->lf : (int)(2 * g->K)) : (int)(2 * g->M);
+		const size_t back = g->passes ? (size_t)(lp_len_out > 2 ? lp_len_out : 2) : (size_t)lp_len_out;
+		RX_K(rxk_copy_mirror(sb, s->lp_mirror, s->lp_final, (unsigned)(back * 2)));
+	}
 	s->chained = 1;
 	s->last_fuse_a = fuse_a;
 	s->last_fuse_dd = fuse_dd;
@@ -965,7 +978,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
  * of those runs (decimated IQ, discriminator carries, the other pcm samples) is final already. */
 static int fixup_from(rxgpu_fm_stream *s, int slot)
 {
-	hipStream_t sa = rxgpu_hip_stream(), sb = rxgpu_hip_stream2();
+	hipStream_t sa = fm_sa(s), sb = rxgpu_hip_stream2();
 	int rc;
 	RX_HIP(hipStreamSynchronize(sa));
 	RX_HIP(hipStreamSynchronize(sb));
@@ -1020,7 +1033,7 @@ static int retire_slot(rxgpu_fm_stream *s, int slot)
 /* Wait for everything enqueued, settle undecided libm samples, read the carries back. */
 static int finish_runs(rxgpu_fm_stream *s)
 {
-	hipStream_t sa = rxgpu_hip_stream(), sb = rxgpu_hip_stream2();
+	hipStream_t sa = fm_sa(s), sb = rxgpu_hip_stream2();
 	rxk_fm_dev *h = s->dev_host;
 	const rxgpu_fm_params *p = &s->p;
 	int rc;
@@ -1033,7 +1046,7 @@ static int finish_runs(rxgpu_fm_stream *s)
 		 * enqueue would trip over again, and say so to whoever asks for the carries -- set_carry + a replay recovers */
 		hipStreamSynchronize(sa);
 		hipStreamSynchronize(sb);
-		hipStreamSynchronize(rxgpu_hip_stream4());       /* the seam/history kernels of a -F run that was enqueued ahead */
+		hipStreamSynchronize(fm_sd(s));                  /* the seam/history kernels of a -F run that was enqueued ahead */
 		s->rec[0].live = s->rec[1].live = 0;
 		s->flag_cnt_host[0] = s->flag_cnt_host[1] = 0;
 		s->pending = 0;
@@ -1333,6 +1346,7 @@ static struct {
 	int *cb_rdc;                         /* dc_avgI/Q, the block averages, the int64 sums */
 	int16_t *fd_in;                      /* full_demod's own upload buffer (the demod thread's; the callback's are the dongle thread's) */
 	unsigned char *fb_dev, *fb_host;     /* the single-block path (dropin_fast_block): device rows + header, their pinned host mirror */
+	unsigned char *gb_host;              /* the general path's page-locked mirror of result[] and lowpassed[] (rxgpu_full_demod) */
 	const void *zc_in, *zc_out;          /* the callback's zero-copy form: the host buffers whose device addresses are cached below ... */
 	void *zc_in_dev, *zc_out_dev;
 	unsigned zc_gen;                     /* ... as of this rxgpu_pin_generation(); zc_in_dev == NULL: looked up, not page-locked */
@@ -1402,6 +1416,7 @@ int rxgpu_dropin_release(const struct demod_state *d)
 		hipFree(g_side[i].fd_in);
 		hipFree(g_side[i].fb_dev);
 		if (g_side[i].fb_host) hipHostFree(g_side[i].fb_host);
+		if (g_side[i].gb_host) hipHostFree(g_side[i].gb_host);
 		memset(&g_side[i], 0, sizeof(g_side[i]));
 		pthread_mutex_unlock(&g_side_cb_lock[i]);
 	}
@@ -1518,7 +1533,8 @@ void rxgpu_fm_dropin_release(void)
 		hipFree(g_side[i].fd_in);
 		hipFree(g_side[i].fb_dev);
 		if (g_side[i].fb_host) hipHostFree(g_side[i].fb_host);
-		g_side[i].fb_dev = g_side[i].fb_host = NULL;
+		if (g_side[i].gb_host) hipHostFree(g_side[i].gb_host);
+		g_side[i].fb_dev = g_side[i].fb_host = g_side[i].gb_host = NULL;
 		g_side[i].zc_gen = 0;
 		g_side[i].cb_in = g_side[i].cb_pre[0] = g_side[i].cb_pre[1] = g_side[i].fd_in = NULL;
 		g_side[i].cb_rdc = NULL;
@@ -1675,6 +1691,7 @@ void rxgpu_full_demod(struct demod_state *d)
 		if (rxgpu_fm_stream_create(&g_side[slot].s, &p, 1, RXGPU_MAXIMUM_BUF_LENGTH) != RXGPU_OK)
 			die("rxgpu_full_demod");
 		g_side[slot].s->allow_empty = 1;                /* a block that completes no window is legal here, see below */
+		g_side[slot].s->one_stream = 1;                 /* one block per run: nothing to overlap, no event hops between streams */
 		g_side[slot].p = p;
 	}
 	rxgpu_fm_stream *s = g_side[slot].s;
@@ -1726,17 +1743,16 @@ void rxgpu_full_demod(struct demod_state *d)
 	const int pre_r_in = d->pre_r, pre_j_in = d->pre_j;
 	size_t got = 0;
 	const size_t cap = (size_t)RXGPU_MAXIMUM_BUF_LENGTH + 16;
-	if (s->stage_out_cap < cap) {
-		hipFree(s->stage_out);
-		s->stage_out = NULL; s->stage_out_cap = 0;
-		if (hipMalloc((void **)&s->stage_out, cap * 2) != hipSuccess) {
-			rxgpu_fail(RXGPU_ENOMEM, "hipMalloc failed");
-			die("rxgpu_full_demod");
-		}
-		s->stage_out_cap = cap;
+	/* result[] and lowpassed[] come home through a page-locked mirror the run's last kernels write themselves (hipHostMalloc'd memory has one address on
+	 * both sides): no copy call behind the run -- two of them, each staged and waited for by the runtime, were 21 us per block (round 6) */
+	if (!g_side[slot].gb_host && hipHostMalloc((void **)&g_side[slot].gb_host, (size_t)RXGPU_MAXIMUM_BUF_LENGTH * 4 + 128, 0) != hipSuccess) {
+		rxgpu_fail(RXGPU_ENOMEM, "hipHostMalloc failed");
+		die("rxgpu_full_demod");
 	}
+	int16_t *const m_res = (int16_t *)g_side[slot].gb_host, *const m_lp = m_res + cap + 16;
+	s->lp_mirror = m_lp;
 	if (timing) { t_b = now_us(); g_dt[2] += t_b - t_a; t_a = t_b; }
-	if (rxgpu_fm_stream_run(s, d_block, 1, (size_t)d->lp_len, s->stage_out, s->stage_out_cap, &got, NULL) != RXGPU_OK)
+	if (rxgpu_fm_stream_run(s, d_block, 1, (size_t)d->lp_len, m_res, cap, &got, NULL) != RXGPU_OK)
 		die("rxgpu_full_demod");
 	g_side[slot].dev_valid = 0;
 	rxgpu_fm_stream_get_carry(s, &c);
@@ -1745,21 +1761,14 @@ void rxgpu_full_demod(struct demod_state *d)
 		rxgpu_fail(RXGPU_ECAPACITY, "result needs %zu int16", got);
 		die("rxgpu_full_demod");
 	}
-	if (got && hipMemcpyAsync(d->result, s->stage_out, got * 2, hipMemcpyDeviceToHost, sb) != hipSuccess) {
-		rxgpu_fail(RXGPU_ENODEV, "copy of the result failed");
-		die("rxgpu_full_demod");
-	}
-	/* decimated IQ back into lowpassed[], like the CPU's in-place stages leave it: lp_len' int16 (odd on some -F shapes), and
-	 * never fewer than two -- every fifth_order pass rewrites lowpassed[0] and [1] even for an empty block */
 	const struct run_geom *g = &s->last;
 	const int lp_len_out = g->passes ? (g->literal ? g->lf : (int)(2 * g->K)) : (int)(2 * g->M);
 	{
 		const size_t back = g->passes ? (size_t)(lp_len_out > 2 ? lp_len_out : 2) : (size_t)lp_len_out;
-		if ((back && hipMemcpyAsync(d->lowpassed, s->lp_final, back * 2, hipMemcpyDeviceToHost, sb) != hipSuccess) ||
-		    hipStreamSynchronize(sb) != hipSuccess) {
-			rxgpu_fail(RXGPU_ENODEV, "copy of decimated IQ failed");
-			die("rxgpu_full_demod");
-		}
+		if (got)
+			memcpy(d->result, m_res, got * 2);
+		if (back)
+			memcpy(d->lowpassed, m_lp, back * 2);
 		d->lp_len = lp_len_out;
 	}
 	d->result_len = (int)got;
