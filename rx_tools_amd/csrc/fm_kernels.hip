@@ -5114,8 +5114,8 @@ extern "C" int rxk_ch_demod(void *stream, const uint32_t *chan_lp, u64 total_win
 // reference's own expression.  W <= row_cap samples (the launcher's LDS size).  row: in (demodulated) / out (result); audio: {avg, now_lpr,
 // prev_lpr_index} in, the same three out at audio + 3.
 template <bool EVEN, bool D24>
-__global__ __launch_bounds__(256) void k_fm_row_audio(int16_t *__restrict__ row_g, unsigned W, int deemph, int a, unsigned magic, int bias, int warm,
-                                                      int serial, int fast, int slow, unsigned J, int *__restrict__ audio,
+__global__ __launch_bounds__(256) void k_fm_row_audio(const int16_t *row_g, int16_t *row_out, unsigned W, int deemph, int a, unsigned magic, int bias,
+                                                      int warm, int serial, int fast, int slow, unsigned J, const int *audio, int *audio_out,
                                                       int16_t *__restrict__ row_h, int *__restrict__ audio_h, const uint32_t *__restrict__ hdr,
                                                       uint32_t *__restrict__ hdr_h, unsigned hdr_words)
 {
@@ -5183,14 +5183,14 @@ __global__ __launch_bounds__(256) void k_fm_row_audio(int16_t *__restrict__ row_
 					start[t] = s;
 					s = ctab_apply(tab[t], s);
 				}
-				audio[3] = s; audio_h[0] = s;
+				audio_out[0] = s; audio_h[0] = s;
 			} else {
 				for (unsigned i = 0; i < W; i++) {                // any a, any state: the reference's own expression
 					const int d = (int)ra_row[i] - s;
 					s += d > 0 ? (d + h) / a : (d - h) / a;
 					ra_row[i] = (int16_t)s;
 				}
-				audio[3] = s; audio_h[0] = s;
+				audio_out[0] = s; audio_h[0] = s;
 			}
 		}
 		__syncthreads();
@@ -5216,7 +5216,7 @@ __global__ __launch_bounds__(256) void k_fm_row_audio(int16_t *__restrict__ row_
 		}
 		__syncthreads();
 	} else if (tid == 0) {
-		audio[3] = avg_in; audio_h[0] = avg_in;
+		audio_out[0] = avg_in; audio_h[0] = avg_in;
 	}
 	if (slow > 0) {
 		const u64 p0 = (u64)audio[2];
@@ -5226,7 +5226,8 @@ __global__ __launch_bounds__(256) void k_fm_row_audio(int16_t *__restrict__ row_
 			int sum = j ? 0 : audio[1];
 			for (u64 i = wb; i < we; i++)
 				sum += ra_row[i];
-			row_g[j] = (int16_t)(sum / ratio);
+			if (row_out)
+				row_out[j] = (int16_t)(sum / ratio);
 			row_h[j] = (int16_t)(sum / ratio);
 		}
 		if (tid == 0) {
@@ -5234,21 +5235,22 @@ __global__ __launch_bounds__(256) void k_fm_row_audio(int16_t *__restrict__ row_
 			int sum = J ? 0 : audio[1];
 			for (u64 i = wb; i < W; i++)
 				sum += ra_row[i];
-			audio[4] = sum; audio_h[1] = sum;
-			audio[5] = (int)(p0 + (u64)W * (u64)slow - (u64)J * (u64)fast); audio_h[2] = audio[5];
+			const int pl = (int)(p0 + (u64)W * (u64)slow - (u64)J * (u64)fast);
+			audio_out[1] = sum; audio_h[1] = sum;
+			audio_out[2] = pl; audio_h[2] = pl;
 		}
 	} else {
 		for (unsigned i = tid; i < W; i += 256) {
-			if (deemph)
-				row_g[i] = ra_row[i];
+			if (row_out && (deemph || row_out != row_g))
+				row_out[i] = ra_row[i];
 			row_h[i] = ra_row[i];
 		}
-		if (tid == 0) { audio[4] = audio[1]; audio[5] = audio[2]; audio_h[1] = audio[1]; audio_h[2] = audio[2]; }
+		if (tid == 0) { const int nl = audio[1], pl = audio[2]; audio_out[1] = nl; audio_out[2] = pl; audio_h[1] = nl; audio_h[2] = pl; }
 	}
 }
 
-extern "C" int rxk_fm_row_audio(void *stream, int16_t *row, unsigned W, int deemph, int a, int warm, int serial, int fast, int slow, unsigned J, int *audio,
-                                int16_t *row_h, int *audio_h, const void *hdr, void *hdr_h, unsigned hdr_words)
+extern "C" int rxk_fm_row_audio(void *stream, const int16_t *row, int16_t *row_out, unsigned W, int deemph, int a, int warm, int serial, int fast, int slow,
+                                unsigned J, const int *audio, int *audio_out, int16_t *row_h, int *audio_h, const void *hdr, void *hdr_h, unsigned hdr_words)
 {
 	if (!W)
 		return 0;
@@ -5256,7 +5258,7 @@ extern "C" int rxk_fm_row_audio(void *stream, int16_t *row, unsigned W, int deem
 	const unsigned mg = deemph ? deemph_magic_u(a) : 0u;
 	const int bias = deemph ? bias_for(a) : 0;
 	const size_t lds = ((size_t)W * 2 + 15) & ~(size_t)15;
-#define GO(EV, D) hipLaunchKernelGGL((k_fm_row_audio<EV, D>), dim3(1), dim3(256), lds, s, row, W, deemph, a, mg, bias, warm, serial, fast, slow, J, audio, \
+#define GO(EV, D) hipLaunchKernelGGL((k_fm_row_audio<EV, D>), dim3(1), dim3(256), lds, s, row, row_out, W, deemph, a, mg, bias, warm, serial, fast, slow, J, audio, audio_out, \
 		row_h, audio_h, (const uint32_t *)hdr, (uint32_t *)hdr_h, hdr_words)
 	if (deemph && deemph_d24u(a)) { if (a & 1) GO(false, true); else GO(true, true); }
 	else { if (!deemph || (a & 1)) GO(false, false); else GO(true, false); }

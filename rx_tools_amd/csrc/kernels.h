@@ -78,9 +78,11 @@ typedef struct rxk_blk_out {
 int rxk_fm_block_dd(void *stream, const int16_t *blk, unsigned n, int ds, int p0, int now_r, int now_j, int pre_r, int pre_j,
                     int custom_atan, uint32_t *lp, uint32_t *lp_host, int16_t *pcm, int16_t *keep, rxk_blk_out *out, int *audio_in, int avg,
                     int now_lpr, int prev_lpr_index);
-/* deemph_filter + low_pass_real on one short row held in LDS (W <= 24 000 samples); audio: {avg, now_lpr, prev_lpr_index} in, the same out at +3 */
-int rxk_fm_row_audio(void *stream, int16_t *row, unsigned W, int deemph, int a, int warm, int serial, int fast, int slow, unsigned J, int *audio,
-                     int16_t *row_h, int *audio_h, const void *hdr, void *hdr_h, unsigned hdr_words);
+/* deemph_filter + low_pass_real on one short row held in LDS (W <= RXK_ROW_AUDIO_MAX samples); audio: {avg, now_lpr, prev_lpr_index} in, the same
+ * three out at audio_out; row_out: the result in device memory (row itself for in place, NULL for none) */
+#define RXK_ROW_AUDIO_MAX 24000u
+int rxk_fm_row_audio(void *stream, const int16_t *row, int16_t *row_out, unsigned W, int deemph, int a, int warm, int serial, int fast, int slow,
+                     unsigned J, const int *audio, int *audio_out, int16_t *row_h, int *audio_h, const void *hdr, void *hdr_h, unsigned hdr_words);
 /* row_h, audio_h, hdr_h: device-addressable HOST memory that receives the result row, the three audio carries and a copy of hdr[0 .. hdr_words) */
 
 enum { RXK_FIRST_LOWPASS = 0, RXK_FIRST_UNIFORM = 1 };

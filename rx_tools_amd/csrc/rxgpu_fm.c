@@ -55,6 +55,7 @@ struct rxgpu_fm_stream {
 	void *ctab;                                    /* tiled path: compact 16-byte chunk tables (scan_t -> up0 / down0) */
 	int *cstart;                                   /* tiled path: exact start state per chunk (down0 -> apply_rs_t) */
 	int tiled;                                     /* pcm[] of the run in hand is in the tiled layout: chunk log2, else 0 */
+	int row_audio;                                 /* the run in hand is one short block whose audio stages are rxk_fm_row_audio's one launch */
 	int *lvl_tab, *lvl_lo, *lvl_gap, *lvl_start;   /* tree levels, packed back to back */
 	size_t lvl_cap;
 	/* libm samples the device could not decide, per run slot (seq & 1): count + records on the device, mirrors in pinned memory */
@@ -108,7 +109,7 @@ struct rxgpu_fm_stream {
 		int live;                        /* enqueued, not retired */
 		unsigned long long seq;
 		struct run_geom g;
-		int tiled;
+		int tiled, row_audio;
 		int16_t *d_out, *pcm;
 		rxk_fm_blocks blk;
 		size_t n_blocks;
@@ -429,6 +430,17 @@ static int run_audio_stages(rxgpu_fm_stream *s, hipStream_t st, unsigned long lo
 	const int resample = p->rate_out2 > 0;
 	int16_t *deemph_dst = resample ? s->y : d_out;
 	const int16_t *pcm = s->pcm;
+	if (s->row_audio && M) {
+		/* one short block (the drop-in's) whose carries the host knows: both stages in one workgroup with the row in LDS, not the tree's six launches */
+		const int avg = s->carry.deemph_avg;
+		const int serial = p->deemph && (p->deemph_a < 2 || p->deemph_a > 64 || avg < -32768 || avg > 32767);
+		const int warm = p->deemph && !serial ? rxgpu_deemph_warm64(p->deemph_a) : 8;
+		rxgpu_prof_begin_on("fm_deemph", st);
+		RX_K(rxk_fm_row_audio(st, pcm, NULL, (unsigned)M, p->deemph, p->deemph_a, warm, serial, p->rate_out, resample ? p->rate_out2 : 0, (unsigned)J,
+		                      &s->dev->in_deemph_avg, &s->dev->out_deemph_avg, d_out, &s->dev->out_deemph_avg, NULL, NULL, 0));
+		rxgpu_prof_end_on("fm_deemph", st);
+		return RXGPU_OK;
+	}
 	if (s->tiled && M) {
 		/* the small-decimation chain: lane-per-chunk kernels on the tiled stream, de-emphasis and low_pass_real in two
 		 * passes over pcm[] with the tree on compact tables in between; the filtered audio itself never reaches HBM */
@@ -711,7 +723,9 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 	/* de-emphasis + resampler behind an fm discriminator: hand them the demodulated samples in the tiled layout their
 	 * lane-per-chunk kernels stream (rxk_fm_deemph_scan_t / _apply_rs_t).  The LDS-staged kernels keep: no resampler behind the de-emphasis,
 	 * even a or a < 9 or a > 255 (rxk_fm_deemph_tiled_ok), -o, -E adc, squelch and the non-fm demodulators in front. */
-	if (!split && !g->literal && p->deemph && s->group && p->rate_out2 > 0 && g->post == 1 && !p->dc_block_audio)
+	s->tiled = 0;
+	s->row_audio = s->one_stream && fresh && g->M <= RXK_ROW_AUDIO_MAX && g->post == 1 && !p->dc_block_audio && (p->deemph || p->rate_out2 > 0);
+	if (!split && !g->literal && p->deemph && s->group && p->rate_out2 > 0 && g->post == 1 && !p->dc_block_audio && !s->row_audio)
 	{
 		/* $RXGPU_DEEMPH_CHUNK=256 forces the larger chunk where the warm-up would fit 128 (tests of that template; measured: no
 		 * gain -- the scan's warm-up weighs less, but the resampler's per-wave staging doubles and with it the LDS a workgroup needs
@@ -967,6 +981,7 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 	s->rec[db].d_out = d_out;
 	s->rec[db].pcm = s->pcm;
 	s->rec[db].tiled = s->tiled;
+	s->rec[db].row_audio = s->row_audio;
 	s->rec[db].blk = s->blk;
 	s->rec[db].n_blocks = n_blocks;
 	return RXGPU_OK;
@@ -1009,6 +1024,7 @@ static int fixup_from(rxgpu_fm_stream *s, int slot)
 		s->pcm = r->pcm;
 		s->blk = r->blk;
 		s->tiled = r->tiled;
+		s->row_audio = r->row_audio;
 		if ((rc = run_audio_stages(s, sb, r->g.M, r->g.J, r->d_out)) != RXGPU_OK)
 			return rc;
 	}
@@ -1598,8 +1614,8 @@ static int dropin_fast_block(int slot, struct demod_state *d, const rxgpu_fm_par
 	RX_K(rxk_fm_block_dd(st, d_block, n, ds, d->prev_index, d->now_r, d->now_j, d->pre_r, d->pre_j, p->custom_atan, lp, lp_h, pcm, keep, hdr, audio,
 	                     avg, d->now_lpr, d->prev_lpr_index));
 	for (int attempt = 0; ; attempt++) {
-		RX_K(rxk_fm_row_audio(st, pcm, (unsigned)M, p->deemph, p->deemph_a, warm, serial, p->rate_out, resample ? p->rate_out2 : 0, (unsigned)J, audio,
-		                      row_h, audio_h, hdr, host, (unsigned)(sizeof(rxk_blk_out) / 4)));
+		RX_K(rxk_fm_row_audio(st, pcm, pcm, (unsigned)M, p->deemph, p->deemph_a, warm, serial, p->rate_out, resample ? p->rate_out2 : 0, (unsigned)J, audio,
+		                      audio + 3, row_h, audio_h, hdr, host, (unsigned)(sizeof(rxk_blk_out) / 4)));
 		RX_HIP(hipStreamSynchronize(st));
 		const rxk_blk_out *h = (const rxk_blk_out *)host;
 		if (!h->flag_cnt || attempt)
