@@ -118,6 +118,11 @@ def oracle_sdr_convert(fmt, data):
     return out
 
 
+# the reference's lowpassed[] holds MAXIMUM_BUF_LENGTH int16 (rtl_fm.c:64-65, 107): longer blocks only exist on the GPU side and in the restatement
+REF_FM_MAX_BLOCK = 16 * 16384
+REF_CROSS_CHECK = os.environ.get("RXTEST_NO_REF_CROSS_CHECK", "") == ""
+
+
 def have_ref():
     return all(os.path.exists(os.path.join(ORACLE_DIR, "_ref", f))
                for f in ("libref_fm.so", "libref_power.so", "libref_sdr.so"))
@@ -186,6 +191,7 @@ def ref_power():
         L.ref_power_sinewave.restype = i16p
         L.ref_power_setup.argtypes = [C.c_char_p, C.c_double, C.c_char_p]
         L.ref_power_scan.argtypes = [i16p, C.c_int]
+        L.ref_power_scan_tuned.argtypes = [i16p, C.c_int]
         L.ref_power_csv.argtypes = [C.c_char_p]
         L.FIX_MPY.restype = C.c_int16
         L.FIX_MPY.argtypes = [C.c_int16, C.c_int16]
@@ -194,6 +200,22 @@ def ref_power():
 
 
 # --------------------------------------------------------------- reference-state helpers
+
+def ref_power_scan_first(rng, crop, window, flags, data, passes, tunes):
+    """avg[] / samples of the first `tunes` tunes of the sweep `rng` after `passes` scanner() calls of the REFERENCE itself (libref_power.so: its own
+    frequency_range, window, sine_table, scanner, rtl_power.c:670-771) on data laid out [pass][tune][buf_len]; the tunes behind them read zeros"""
+    from rx_tools_amd.structs import TuningState
+    P = ref_power()
+    P.ref_power_set_flags(*flags)
+    n = P.ref_power_setup(rng.encode(), crop, window.encode())
+    ts = (TuningState * n).from_address(P.ref_power_tunes())
+    buf_len, N = ts[0].buf_len, 1 << ts[0].bin_e
+    full = np.zeros((passes, n, buf_len), np.int16)
+    full[:, :tunes] = np.asarray(data, np.int16).reshape(passes, tunes, buf_len)
+    P.ref_power_scan_tuned(ptr16(full), passes)          # (scanner() without retune()'s flush reads: device I/O, not the chain)
+    avg = np.stack([np.ctypeslib.as_array(ts[i].avg, (N,)).copy() for i in range(tunes)])
+    return avg, np.array([ts[i].samples for i in range(tunes)], np.int32)
+
 
 def ref_fm_reset(L, **params):
     """Fresh wbfm-style parameter set on the reference's global demod/dongle
@@ -268,7 +290,7 @@ def ref_fm_stream(L, iq, block_len, **params):
     """callback + full_demod over consecutive blocks through the reference itself."""
     d, s = ref_fm_reset(L, **params)
     n_blocks = len(iq) // block_len
-    out = np.zeros(len(iq) // 2 + 16, dtype=np.int16)
+    out = np.zeros(len(iq) + 16, dtype=np.int16)           # raw_demod at downsample 1 hands back as many int16 as went in
     scratch = np.zeros(block_len, dtype=np.int16)
     lens = []
     pos = 0
@@ -290,6 +312,11 @@ def oracle_fm_stream(iq, block_len, **params):
     out = np.zeros(len(iq) + 16, dtype=np.int16)           # raw_demod at downsample 1 hands back as many int16 as went in
     lens = np.zeros(n_blocks, dtype=np.int32)
     total = L.rxo_fm_stream(C.byref(st), ptr16(iq), n_blocks, block_len, ptr16(out), ptr32(lens))
+    if REF_CROSS_CHECK and have_ref() and 0 < block_len <= REF_FM_MAX_BLOCK and n_blocks:
+        # where the reference built in place travelled with the tree (oracle/_ref), the expected values ARE the reference's: the restatement's
+        # output is held to rtl_fm.c's own rtlsdr_callback + full_demod on this very input before anything is compared with it
+        r_out, r_lens, _ = ref_fm_stream(ref_fm(), iq[:n_blocks * block_len], block_len, **params)
+        assert np.array_equal(r_lens, lens) and np.array_equal(r_out, out[:total]), "oracle != reference on this input: %r" % (params,)
     return out[:total].copy(), lens, st
 
 

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import rx_tools_amd as R
-from support import oracle, sig_noise, PowerCfg, ptr16, ptr32, ptr64
+from support import oracle, sig_noise, PowerCfg, ptr16, ptr32, ptr64, have_ref, ref_power_scan_first
 
 pytestmark = pytest.mark.gpu
 
@@ -88,6 +88,10 @@ def test_scan_bit_exact(rng, crop, window, flags, amp, passes, max_tunes):
     sw = R.sine_table(plan.bin_e)
     data = sig_noise(passes * tunes * plan.buf_len, seed=777, amp=amp)
     want_avg, want_samples = oracle_scan(data, passes, tunes, plan, wc, sw, *flags)
+    if have_ref() and passes * plan.tune_count <= 5000:          # (the reference runs every tune of the sweep, the ones past max_tunes on zeros)
+        # oracle/_ref travelled with the tree: the expected values are held to the reference's own scanner() on this input first
+        ref_avg, ref_samples = ref_power_scan_first(rng, crop, window, flags, data, passes, tunes)
+        assert np.array_equal(ref_avg, want_avg) and np.array_equal(ref_samples, want_samples), "oracle != reference"
     got_avg, got_samples = gpu_scan(data, passes, tunes, plan, wc, sw, *flags)
     assert np.array_equal(got_samples, want_samples)
     bad = np.argwhere(got_avg != want_avg)
