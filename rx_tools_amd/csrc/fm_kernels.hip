@@ -2870,6 +2870,73 @@ __global__ __launch_bounds__(256) void k_fm_fifth_regn(const uint32_t *__restric
 // first five outputs of the NEXT pass and nothing else (output k >= 5 reads inputs >= 5).  This kernel computes the regular formula everywhere (the
 // halo lanes of a buffer's first tile hold clamped garbage); k_pw_fifth_fix then recomputes a buffer's first 5 (with the FIR: 14) final samples from
 // the raw buffer, literally, overwrites them and corrects the sums by what changed.
+// The cascade on PAIRS of one component: register j of a level holds (X[2j-1], X[2j]) of I (or of Q) -- a window X[2k-5 .. 2k] is then three
+// whole registers, pairs k-2, k-1, k, and its 32-bit tap sum three v_dot2_i32_i16 with the coefficient pairs (1,5), (10,10), (5,1): six per complex
+// output where fifth_int spends twelve v_mad_i32_i16.  Cost: one v_perm_b32 per raw sample (I|Q words -> pairs), three wave_shr moves per level and
+// component (the left lane's last two pairs and its last output), the same shift-and-pack as before -- now of two neighbouring outputs of one component.
+typedef short pp_s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int pp_dot(uint32_t pair, uint32_t coef, int acc)
+{
+	return __builtin_amdgcn_sdot2(__builtin_bit_cast(pp_s16x2, pair), __builtin_bit_cast(pp_s16x2, coef), acc, false);
+}
+// NPAIR pairs in (samples -1 .. 2 NPAIR - 2 of the lane's window), NPAIR 32-bit tap sums out (outputs 0 .. NPAIR - 1, rtl_power.c:599-606 before the shift)
+template <int NPAIR>
+__device__ __forceinline__ void pp_level(const uint32_t (&p)[NPAIR], int (&sum)[NPAIR])
+{
+	static_assert(NPAIR >= 2, "the two pairs to the left sit in ONE neighbouring lane");
+	const uint32_t m1 = fr_shr(p[NPAIR - 1]), m2 = fr_shr(p[NPAIR - 2]);          // pairs -1, -2
+#pragma unroll
+	for (int k = 0; k < NPAIR; k++) {
+		const uint32_t a = k >= 2 ? p[k >= 2 ? k - 2 : 0] : (k == 1 ? m1 : m2), b = k >= 1 ? p[k >= 1 ? k - 1 : 0] : m1;
+		// (the chain's first link in the three-source form with the inline constant 0: the accumulating two-source form wants a zeroed register first)
+		int s0;
+		asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(s0) : "v"(a), "s"(0x00050001u));
+		sum[k] = pp_dot(p[k], 0x00010005u, pp_dot(b, 0x000a000au, s0));
+	}
+}
+// the next level's pairs: ((sum[2m-1] >> 4) & 0xffff) | (sum[2m] >> 4) << 16 -- the int16 stores of rtl_power.c:599-606, two at a time
+template <int NPAIR>
+__device__ __forceinline__ void pp_pack(const int (&sum)[NPAIR], uint32_t (&q)[NPAIR / 2])
+{
+	const int left = (int)fr_shr((uint32_t)sum[NPAIR - 1]);                       // output -1
+#pragma unroll
+	for (int m = 0; m < NPAIR / 2; m++) {
+		const int lo = m ? sum[m ? 2 * m - 1 : 0] : left;
+		q[m] = (uint32_t)__builtin_amdgcn_ubfe((unsigned)lo, 4u, 16u) | (((unsigned)sum[2 * m] << 12) & 0xffff0000u);
+	}
+}
+template <int NPAIR, int LEFT>
+__device__ __forceinline__ void pp_cascade(const uint32_t (&pi)[NPAIR], const uint32_t (&pq)[NPAIR], uint32_t (&res)[NPAIR >> (LEFT - 1)])
+{
+	int si[NPAIR], sq[NPAIR];
+	pp_level<NPAIR>(pi, si);
+	pp_level<NPAIR>(pq, sq);
+	if constexpr (LEFT == 1) {
+#pragma unroll
+		for (int k = 0; k < NPAIR; k++)
+			res[k] = (uint32_t)__builtin_amdgcn_ubfe((unsigned)si[k], 4u, 16u) | (((unsigned)sq[k] << 12) & 0xffff0000u);
+	} else {
+		uint32_t qi[NPAIR / 2], qq[NPAIR / 2];
+		pp_pack<NPAIR>(si, qi);
+		pp_pack<NPAIR>(sq, qq);
+		pp_cascade<NPAIR / 2, LEFT - 1>(qi, qq, res);
+	}
+}
+// LV stateless passes on the lane's R raw I|Q words -> its R >> LV level-LV words (what fr_cascade<R, LV, 0, 2> computes)
+template <int R, int LV>
+__device__ __forceinline__ void pp_cascade_raw(const uint32_t (&x)[R], uint32_t (&w)[R >> LV])
+{
+	uint32_t pi[R / 2], pq[R / 2];
+	const uint32_t xm1 = fr_shr(x[R - 1]);
+#pragma unroll
+	for (int j = 0; j < R / 2; j++) {
+		const uint32_t a = j ? x[j ? 2 * j - 1 : 0] : xm1, b = x[2 * j];
+		pi[j] = __builtin_amdgcn_perm(b, a, 0x05040100u);                          // (I of a, I of b)
+		pq[j] = __builtin_amdgcn_perm(b, a, 0x07060302u);                          // (Q of a, Q of b)
+	}
+	pp_cascade<R / 2, LV>(pi, pq, w);
+}
+
 template <int LV, bool FIR, int TW>
 __global__ __launch_bounds__(256) void k_pw_fifth_regn(const uint32_t *__restrict__ in, unsigned n, unsigned in_stride, unsigned tiles_per_block, unsigned wgs_per_block,
                                                        unsigned total_wgs, uint32_t *__restrict__ out, unsigned out_stride, int f1, int f2, int f3, int f4, int f5,
@@ -2921,7 +2988,7 @@ __global__ __launch_bounds__(256) void k_pw_fifth_regn(const uint32_t *__restric
 				fetch(tile + 4);
 		}
 		uint32_t w[NOUT];
-		fr_cascade<R, LV, 0, 2>(x, w, lane, false, nullptr);
+		pp_cascade_raw<R, LV>(x, w);
 		uint32_t y[4];
 		if constexpr (FIR) {
 			uint32_t W[13];                                      // W[i] = level-LV sample 4l - 9 + i

@@ -332,9 +332,12 @@ int rxk_fm_post_downsample(void *stream, const int16_t *in, unsigned long long n
 long long *rxk_pw_dc_sums(int *dc, size_t n_pass_tunes);
 int rxk_pw_fft_mid(void *stream, const int16_t *in, size_t tune_stride, size_t pass_stride, int passes, int tunes,
                    int bin_e, int eff_len, const int *window, const uint32_t *twiddle, int peak_hold,
-                   uint32_t *scratch, size_t cap_blocks, int *dc, long long *avg, long long *partial, size_t partial_cap, int dc_sums_done);
+                   uint32_t *scratch, size_t cap_blocks, int *dc, long long *avg, long long *partial, size_t partial_cap, int dc_sums_done,
+                   int *samples, int samples_add);     /* samples != NULL: samples[tune] += samples_add in one of the launches (no rxk_pw_samples needed) */
 /* workgroups the second launch aims for; partial needs (RXK_PWM_TARGET_WG / 4 + tunes * blocks per tune) * 2^bin_e int64 to be used */
+#ifndef RXK_PWM_TARGET_WG
 #define RXK_PWM_TARGET_WG 2048
+#endif
 int rxk_pw_fft_big(void *stream, const int16_t *in, size_t tune_stride, size_t pass_stride, int passes, int tunes,
                    int bin_e, int eff_len, const int *window, const uint32_t *twiddle, int peak_hold,
                    uint32_t *scratch, size_t cap_blocks, int *dc, long long *avg);

@@ -790,9 +790,12 @@ __global__ __launch_bounds__(256) void k_pwb_dc(const int16_t *__restrict__ in, 
 	}
 }
 
-__global__ void k_pwb_dc_fin(const i64 *__restrict__ sums, int n, int eff_len, int *__restrict__ dc)
+// (samples != NULL: the launch's `samples[tune] += add`, rtl_power.c:769, rides along -- one launch of a few threads less per scan)
+__global__ void k_pwb_dc_fin(const i64 *__restrict__ sums, int n, int eff_len, int *__restrict__ dc, int *__restrict__ samples = nullptr, int tunes = 0, int add = 0)
 {
 	const int pt = blockIdx.x * blockDim.x + threadIdx.x;
+	if (samples && pt < tunes)
+		samples[pt] += add;
 	if (pt >= n)
 		return;
 	const i64 L = eff_len;
@@ -806,7 +809,8 @@ extern "C" long long *rxk_pw_dc_sums(int *dc, size_t n_pass_tunes)
 	return (long long *)(dc + ((2 * n_pass_tunes + 3) & ~(size_t)3));
 }
 
-static void pwb_dc(hipStream_t s, const int16_t *in, size_t tune_stride, size_t pass_stride, int passes, int tunes, int eff_len, int *dc)
+static void pwb_dc(hipStream_t s, const int16_t *in, size_t tune_stride, size_t pass_stride, int passes, int tunes, int eff_len, int *dc,
+                   int *samples = nullptr, int add = 0)
 {
 	const size_t n = (size_t)passes * tunes;
 	i64 *sums = (i64 *)rxk_pw_dc_sums(dc, n);
@@ -817,7 +821,7 @@ static void pwb_dc(hipStream_t s, const int16_t *in, size_t tune_stride, size_t 
 	if (slices > max_slices) slices = max_slices;
 	if (slices < 1) slices = 1;
 	hipLaunchKernelGGL(k_pwb_dc, dim3((unsigned)(n * slices)), dim3(256), 0, s, in, tune_stride, pass_stride, tunes, eff_len, slices, sums);
-	hipLaunchKernelGGL(k_pwb_dc_fin, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sums, (int)n, eff_len, dc);
+	hipLaunchKernelGGL(k_pwb_dc_fin, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sums, (int)n, eff_len, dc, samples, tunes, add);
 }
 
 // block q = (pass * tunes + tune) * nbpt + blk;  this launch covers blocks q0 .. q0+nq
@@ -1116,16 +1120,30 @@ __global__ void k_pwm_reduce(const i64 *__restrict__ partial, int tunes, int nbp
 	const size_t tune = gid >> bin_e, bin = gid & (((size_t)1 << bin_e) - 1);
 	const size_t out = PERM ? (tune << bin_e) + (size_t)(__brev((unsigned)bin) >> (32 - bin_e)) : gid;
 	const int per = (groups + (int)gridDim.y - 1) / (int)gridDim.y, g0 = (int)blockIdx.y * per, g1 = min(groups, g0 + per);
-	i64 a = 0;
-	bool any = false;
-	for (int g = g0; g < g1; g++)
-		for (int b = 0; b < nbpt; b++) {
-			const i64 v = partial[((((size_t)g * tunes + tune) * (size_t)nbpt + b) << bin_e) + bin];
-			a = peak_hold ? ((!any || v > a) ? v : a) : a + v;
-			any = true;
-		}
-	if (!any)
+	if (g0 >= g1)
 		return;
+	// (every entry is a sum or a maximum of |X|^2: none is negative, 0 is the identity of both folds)
+	i64 a = 0;
+	const size_t gstep = ((size_t)tunes * (size_t)nbpt) << bin_e;
+	const i64 *src = partial + ((((size_t)g0 * tunes + tune) * (size_t)nbpt) << bin_e) + bin;
+	int g = g0;
+	// eight groups' entries on their way at once: one dependent load per group left a thread waiting a memory latency per group (25 of the
+	// 366 us of an N = 2^18 launch went to this kernel)
+	for (; g + 8 <= g1; g += 8, src += 8 * gstep)
+		for (int b = 0; b < nbpt; b++) {
+			i64 v[8];
+#pragma unroll
+			for (int u = 0; u < 8; u++)
+				v[u] = __builtin_nontemporal_load(src + (size_t)u * gstep + ((size_t)b << bin_e));
+#pragma unroll
+			for (int u = 0; u < 8; u++)
+				a = peak_hold ? (v[u] > a ? v[u] : a) : a + v[u];
+		}
+	for (; g < g1; g++, src += gstep)
+		for (int b = 0; b < nbpt; b++) {
+			const i64 v = src[(size_t)b << bin_e];
+			a = peak_hold ? (v > a ? v : a) : a + v;
+		}
 	if (peak_hold) atomicMax((long long *)&avg[out], a);
 	else if (a) atomicAdd((unsigned long long *)&avg[out], (unsigned long long)a);
 }
@@ -1133,7 +1151,8 @@ __global__ void k_pwm_reduce(const i64 *__restrict__ partial, int tunes, int nbp
 // eff_len a multiple of 2^(bin_e+1), bin_e = 14 .. 21; scratch: cap_blocks * 2^bin_e dwords; dc: 2 ints per (pass, tune)
 extern "C" int rxk_pw_fft_mid(void *stream, const int16_t *in, size_t tune_stride, size_t pass_stride, int passes, int tunes,
                               int bin_e, int eff_len, const int *window, const uint32_t *twiddle, int peak_hold,
-                              uint32_t *scratch, size_t cap_blocks, int *dc, long long *avg, long long *partial, size_t partial_cap, int dc_sums_done)
+                              uint32_t *scratch, size_t cap_blocks, int *dc, long long *avg, long long *partial, size_t partial_cap, int dc_sums_done,
+                              int *samples, int samples_add)
 {
 	hipStream_t s = (hipStream_t)stream;
 	const size_t n = (size_t)1 << bin_e;
@@ -1145,9 +1164,10 @@ extern "C" int rxk_pw_fft_mid(void *stream, const int16_t *in, size_t tune_strid
 	/* dc_sums_done: the producer of `in` (rxk_pw_fifth_regn4) left remove_dc's sums where pwb_dc would have put them (rxk_pw_dc_sums) -- only the division is left */
 	if (dc_sums_done) {
 		const size_t npt = (size_t)passes * tunes;
-		hipLaunchKernelGGL(k_pwb_dc_fin, dim3((unsigned)((npt + 255) / 256)), dim3(256), 0, s, (const i64 *)rxk_pw_dc_sums(dc, npt), (int)npt, eff_len, dc);
+		hipLaunchKernelGGL(k_pwb_dc_fin, dim3((unsigned)((npt + 255) / 256)), dim3(256), 0, s, (const i64 *)rxk_pw_dc_sums(dc, npt), (int)npt, eff_len, dc,
+		                   samples, tunes, samples_add);
 	} else {
-		pwb_dc(s, in, tune_stride, pass_stride, passes, tunes, eff_len, dc);
+		pwb_dc(s, in, tune_stride, pass_stride, passes, tunes, eff_len, dc, samples, samples_add);
 	}
 	const int max_np = (int)(cap_blocks / per_pass);
 	for (int p0 = 0; p0 < passes; p0 += max_np) {

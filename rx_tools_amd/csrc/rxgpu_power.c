@@ -447,6 +447,7 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 				s->big_partial_cap = need;
 		}
 	}
+	int samples_done = 0;
 	rxgpu_prof_begin("pw_fft");
 	/* N = 2^14 .. 2^21 (the reference's limit) with whole blocks: the register-blocked transform in two to four launches over a scratch
 	 * copy (rxk_pw_fft_mid: radix-16 passes through HBM until a sub-transform fits a workgroup); a buffer that is no whole number of
@@ -484,7 +485,8 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 			}
 			RX_K(rxk_pw_fft_mid(st, fft_in, fft_tune_stride, fft_pass_stride, passes, tunes, p->bin_e, eff_len,
 			                    s->window_dev, s->twiddle_dev, p->peak_hold, s->big_scratch, s->big_cap_blocks, s->big_dc, (long long *)d_avg,
-			                    (long long *)s->big_partial, s->big_partial_cap, dc_sums_done));
+			                    (long long *)s->big_partial, s->big_partial_cap, dc_sums_done, d_samples, n_blocks * ds * passes));   /* + rtl_power.c:769 */
+			samples_done = 1;
 		}
 		else
 			RX_K(rxk_pw_fft_big(st, fft_in, fft_tune_stride, fft_pass_stride, passes, tunes, p->bin_e, eff_len,
@@ -495,7 +497,8 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 		                few ? (long long *)s->big_partial : NULL, few ? s->big_partial_cap : 0));
 	}
 	rxgpu_prof_end("pw_fft");
-	RX_K(rxk_pw_samples(st, d_samples, tunes, n_blocks * ds * passes));   /* rtl_power.c:769 */
+	if (!samples_done)
+		RX_K(rxk_pw_samples(st, d_samples, tunes, n_blocks * ds * passes));   /* rtl_power.c:769 */
 	return RXGPU_OK;
 }
 
