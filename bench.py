@@ -1113,6 +1113,23 @@ def main():
                 R.check(L.rxgpu_sync())
                 same = bool(np.array_equal(h_avgs, sweeps * want1[:total_tunes].cpu().numpy()) and all(arr[t].samples == sweeps * int(ws[t]) for t in range(total_tunes)))
                 pw["dropin_scan_us"]["parity_ok"] = same
+            # the interval AFTER a report: csv_dbm has zeroed every row it printed (rtl_power.c:815-817) and said so (rxgpu_csv_dbm does by itself,
+            # the drop-in around the reference's own csv_dbm through rxgpu_scan_rows_cleared): the merge writes, it does not read
+            h_avgs[:] = 0
+            for t in range(total_tunes):
+                arr[t].samples = 0
+            R.check(L.rxgpu_scan_deferred(1))
+            assert L.rxgpu_scan_rows_cleared(arr, total_tunes) == total_tunes
+            for _ in range(2):
+                R.check(L.rxgpu_scan(arr, total_tunes, wc.ctypes.data, sw.ctypes.data, 1, 0, 0))
+            R.check(L.rxgpu_sync())
+            t0 = time.perf_counter()
+            R.check(L.rxgpu_scan_sync(arr, total_tunes))
+            pw["dropin_scan_us"]["rxgpu_scan_sync_per_interval_after_csv_dbm"] = (time.perf_counter() - t0) * 1e6
+            R.check(L.rxgpu_scan_deferred(0))
+            if not args.no_parity:
+                pw["dropin_scan_us"]["parity_ok"] = bool(pw["dropin_scan_us"]["parity_ok"] and np.array_equal(h_avgs, 2 * want1[:total_tunes].cpu().numpy())
+                                                         and all(arr[t].samples == 2 * int(ws[t]) for t in range(total_tunes)))
                 pw_parity_ok = pw_parity_ok and same
                 del want1, ws
             L.rxgpu_scan_release()                                    # h_bufs is page-locked in place by rxgpu_scan: released BEFORE the array dies (rxgpu.h, LIFETIME)

@@ -107,4 +107,6 @@ void rxgpu_dropin_csv_dbm(struct tuning_state *ts)
 	if (rxgpu_scan_sync(tunes, tune_count) != RXGPU_OK)
 		rxgpu_dropin_die("rxgpu_scan_sync");
 	rxgpu_dropin_ref_csv_dbm(ts);
+	/* the file's csv_dbm has zeroed the row (rtl_power.c:815-817): the next interval's merge need not read it across the link */
+	rxgpu_scan_rows_cleared(ts, 1);
 }

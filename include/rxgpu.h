@@ -358,6 +358,12 @@ int rxgpu_scan_zero_copy(void);
  * them across PCIe; the host adds the sample counts.  The same conditions select the older path (D2H of the accumulators, additions on the calling
  * thread).  1 if the last merge ran in place. */
 int rxgpu_scan_sync_in_place(void);
+/* csv_dbm ends by zeroing the row it printed (rtl_power.c:815-817).  rxgpu_csv_dbm does the same and remembers it: the next in-place merge into a sweep
+ * whose rows are ALL known to hold zeros writes the accumulators over them instead of reading, adding and writing back -- 19.6 MB one way across
+ * the link at the configs[2] geometry, not both ways.  A caller that keeps the reference's own csv_dbm says so with this call after its loop over the
+ * tunes; it is a promise that avg[] of tunes[0 .. tune_count) hold zeros NOW and are written by nothing but this library until the
+ * next merge.  Rows the library has not page-locked (the copying path) are ignored.  Returns the number of rows marked. */
+int rxgpu_scan_rows_cleared(const struct tuning_state *tunes, int tune_count);
 /* Forget the cached sweep geometry of rxgpu_scan: its scan object, device buffers and the page-lock registrations of the tunes' buf16.
  * For callers that free or replace their tune buffers (the reference never does); call it BEFORE freeing them.  A pending deferred
  * interval is dropped with a line on stderr (rxgpu_scan_sync first).  rxgpu_shutdown does the same. */

@@ -28,7 +28,7 @@ EXPORTS = [
     "rxgpu_chan_create", "rxgpu_chan_destroy", "rxgpu_chan_set_carry", "rxgpu_chan_get_carry", "rxgpu_chan_run", "rxgpu_chan_run_async", "rxgpu_chan_wait",
     "rxgpu_chan_set_audio_carry", "rxgpu_chan_get_audio_carry",
     "rxgpu_chan_host_fixups",
-    "rxgpu_scan", "rxgpu_scan_sync", "rxgpu_scan_syncs", "rxgpu_scan_zero_copy", "rxgpu_scan_sync_in_place", "rxgpu_scan_release", "rxgpu_scan_deferred", "rxgpu_scan_timing", "rxgpu_csv_dbm", "rxgpu_power_plan_range", "rxgpu_sine_table", "rxgpu_window_coefs",
+    "rxgpu_scan", "rxgpu_scan_sync", "rxgpu_scan_syncs", "rxgpu_scan_zero_copy", "rxgpu_scan_sync_in_place", "rxgpu_scan_rows_cleared", "rxgpu_scan_release", "rxgpu_scan_deferred", "rxgpu_scan_timing", "rxgpu_csv_dbm", "rxgpu_power_plan_range", "rxgpu_sine_table", "rxgpu_window_coefs",
     "rxgpu_power_scan_create", "rxgpu_power_scan_destroy", "rxgpu_power_scan_run",
     "rxgpu_comm_unique_id", "rxgpu_comm_create", "rxgpu_comm_adopt", "rxgpu_comm_destroy", "rxgpu_comm_rank", "rxgpu_comm_world",
     "rxgpu_comm_gathers", "rxgpu_comm_library", "rxgpu_shard_tunes", "rxgpu_power_gather", "rxgpu_power_scan_run_sharded",

@@ -289,7 +289,7 @@ int rxk_pw_samples(void *stream, int *samples, int tunes, int add);
  * one launch copies every row into out[rows][row_bytes] */
 int rxk_pw_gather_rows(void *stream, const void *const *d_rows, int rows, size_t row_bytes, int16_t *out);
 /* host row r (a tune's avg[], page-locked, device-visible address d_rows[r]) += or max= acc row r of row_bytes / 8 int64, acc zeroed */
-int rxk_pw_merge_rows(void *stream, void *const *d_rows, int rows, size_t row_bytes, long long *acc, int peak_hold);
+int rxk_pw_merge_rows(void *stream, void *const *d_rows, int rows, size_t row_bytes, long long *acc, int peak_hold, int host_rows_zero);   /* host_rows_zero: the rows hold zeros -- written, not read */
 /* P2 boxcar (rtl_power.c:723-733): every buffer of buf_len int16 -> same-size buffer whose
  * complex slot k holds the wrapped sum of samples [k*ds,(k+1)*ds), zero elsewhere */
 int rxk_pw_boxcar(void *stream, const int16_t *in, int16_t *out, size_t n_bufs, int buf_len, int ds, int n_write);

@@ -475,6 +475,8 @@ __global__ __launch_bounds__(256) void k_pw_gather_rows(const uint4 *const *__re
 
 // rxgpu_scan_sync's merge in place: host row r (a tune's avg[], page-locked, device-visible) += or max= the device's accumulator row r, which is
 // zeroed on the way; 16-byte units = two int64 (rtl_power.c:760-768 does the same sums one sweep at a time)
+// HZ: the host rows are known to hold zeros (rxgpu_csv_dbm cleared them): not read, the accumulators are written over them
+template <bool HZ>
 __global__ __launch_bounds__(256) void k_pw_merge_rows(uint4 *const *__restrict__ rows, uint4 *__restrict__ acc, unsigned units_per_row, int peak)
 {
 	uint4 *__restrict__ dst = rows[blockIdx.y];
@@ -484,7 +486,7 @@ __global__ __launch_bounds__(256) void k_pw_merge_rows(uint4 *const *__restrict_
 #pragma unroll
 	for (int q = 0; q < 4; q++) {
 		const unsigned u = base + q * 256u;
-		h[q] = u < units_per_row ? dst[u] : make_uint4(0, 0, 0, 0);
+		h[q] = (!HZ && u < units_per_row) ? dst[u] : make_uint4(0, 0, 0, 0);
 		d[q] = u < units_per_row ? src[u] : make_uint4(0, 0, 0, 0);
 	}
 #pragma unroll
@@ -1308,11 +1310,15 @@ extern "C" int rxk_pw_gather_rows(void *stream, const void *const *d_rows, int r
 	LAUNCH_RET();
 }
 
-extern "C" int rxk_pw_merge_rows(void *stream, void *const *d_rows, int rows, size_t row_bytes, long long *acc, int peak_hold)
+extern "C" int rxk_pw_merge_rows(void *stream, void *const *d_rows, int rows, size_t row_bytes, long long *acc, int peak_hold, int host_rows_zero)
 {
 	const unsigned units = (unsigned)(row_bytes / 16);
-	hipLaunchKernelGGL(k_pw_merge_rows, dim3((units + 1023) / 1024, (unsigned)rows), dim3(256), 0, (hipStream_t)stream,
-	                   (uint4 *const *)d_rows, (uint4 *)acc, units, peak_hold);
+	if (host_rows_zero)
+		hipLaunchKernelGGL(k_pw_merge_rows<true>, dim3((units + 1023) / 1024, (unsigned)rows), dim3(256), 0, (hipStream_t)stream,
+		                   (uint4 *const *)d_rows, (uint4 *)acc, units, peak_hold);
+	else
+		hipLaunchKernelGGL(k_pw_merge_rows<false>, dim3((units + 1023) / 1024, (unsigned)rows), dim3(256), 0, (hipStream_t)stream,
+		                   (uint4 *const *)d_rows, (uint4 *)acc, units, peak_hold);
 	LAUNCH_RET();
 }
 

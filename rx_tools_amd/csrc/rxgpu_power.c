@@ -529,6 +529,8 @@ struct zc_table {
 	const void **host;               /* [cap] the buffer each entry was resolved for */
 	void **dev;                      /* [cap] its device-visible address (host copy of the table) */
 	unsigned char *owned;            /* [cap] page-locked HERE (released with the cache), not by the caller's rxgpu_pin */
+	unsigned char *zero;             /* [cap] (avg rows) the row holds zeros: rxgpu_csv_dbm cleared it after the last merge and nothing else writes it */
+	int zero_hint;                   /* where rxgpu_csv_dbm's next row is expected */
 	void **d_tab;                    /* the table on the device */
 	int count;                       /* entries resolved; 0 = none / not usable */
 	int failed;                      /* a buffer could not be page-locked: the copying path from then on (until the geometry changes) */
@@ -612,7 +614,7 @@ static void zc_release(struct zc_table *z)
 static void zc_free(struct zc_table *z)
 {
 	zc_release(z);
-	free(z->host); free(z->dev); free(z->owned);
+	free(z->host); free(z->dev); free(z->owned); free(z->zero);
 	hipFree(z->d_tab);
 	memset(z, 0, sizeof(*z));
 }
@@ -622,7 +624,8 @@ static int zc_alloc(struct zc_table *z, int cap)
 	z->host = calloc((size_t)cap, sizeof(*z->host));
 	z->dev = calloc((size_t)cap, sizeof(*z->dev));
 	z->owned = calloc((size_t)cap, 1);
-	return z->host && z->dev && z->owned && hipMalloc((void **)&z->d_tab, (size_t)cap * sizeof(void *)) == hipSuccess;
+	z->zero = calloc((size_t)cap, 1);
+	return z->host && z->dev && z->owned && z->zero && hipMalloc((void **)&z->d_tab, (size_t)cap * sizeof(void *)) == hipSuccess;
 }
 
 static const void *tune_buf16(const struct tuning_state *t) { return t->buf16; }
@@ -659,6 +662,7 @@ static int zc_resolve(struct zc_table *z, const void *(*field)(const struct tuni
 			return 0;                                    /* part of a sweep, through buffers of its own: copied; the sweep's table stays */
 	}
 	zc_release(z);
+	memset(z->zero, 0, (size_t)tune_count);
 	for (int i = 0; i < tune_count; i++) {
 		void *a = NULL, *a_end = NULL;
 		void *b = (void *)field(&tunes[i]);
@@ -741,11 +745,21 @@ static int scan_sync_locked(struct tuning_state *tunes)
 	const int zc = zc_resolve(&g_scan.zavg, tune_avg, tunes, tc, n * 8, st, &row0);
 	g_scan.zc_sync_last = zc;
 	if (zc) {
+		/* rows this library's own csv_dbm zeroed after the last merge (rtl_power.c:815-817 does the same) and that nothing has written since
+		 * -- the reference touches avg[] in scanner() and csv_dbm only -- need not be READ across the link: sum and maximum with zero are the
+		 * accumulator itself, the merge is then one write stream (19.6 MB one way, not both) */
+		int all_zero = 1;
+		for (int i = 0; i < tc; i++) {
+			all_zero &= g_scan.zavg.zero[row0 + i];
+			g_scan.zavg.zero[row0 + i] = 0;
+		}
 		rxgpu_prof_begin("pw_zc_merge");
-		if (rxk_pw_merge_rows(st, (void *const *)g_scan.zavg.d_tab + row0, tc, n * 8, (long long *)g_scan.d_avg, g_scan.p.peak_hold) != 0)
+		if (rxk_pw_merge_rows(st, (void *const *)g_scan.zavg.d_tab + row0, tc, n * 8, (long long *)g_scan.d_avg, g_scan.p.peak_hold, all_zero) != 0)
 			return rxgpu_fail(RXGPU_ENODEV, "rxgpu_scan_sync: merge launch failed: %s", hipGetErrorString(hipGetLastError()));
 		rxgpu_prof_end("pw_zc_merge");
 	} else {
+		if (g_scan.zavg.zero && g_scan.zavg.count)
+			memset(g_scan.zavg.zero, 0, (size_t)g_scan.zavg.count);      /* the host adds below: no row stays known-zero */
 		RX_HIP(hipMemcpyAsync(g_scan.h_avg, g_scan.d_avg, (size_t)tc * n * 8, hipMemcpyDeviceToHost, st));
 		RX_HIP(hipMemsetAsync(g_scan.d_avg, 0, (size_t)tc * n * 8, st));
 	}
@@ -988,4 +1002,26 @@ void rxgpu_csv_dbm(struct tuning_state *ts, void *file)
 	fprintf(f, "%.2f\n", 10 * log10(tail));
 	memset(ts->avg, 0, (size_t)len * sizeof(ts->avg[0]));
 	ts->samples = 0;
+	(void)rxgpu_scan_rows_cleared(ts, 1);                  /* (the next merge into this row need not read it: scan_sync_locked) */
+}
+
+int rxgpu_scan_rows_cleared(const struct tuning_state *tunes, int tune_count)
+{
+	int marked = 0;
+	if (!tunes || tune_count < 1)
+		return 0;
+	pthread_mutex_lock(&g_scan_lock);
+	struct zc_table *z = &g_scan.zavg;
+	for (int i = 0; i < tune_count && z->zero; i++)
+		for (int k = 0; k < z->count; k++) {
+			const int idx = (z->zero_hint + k) % z->count;
+			if (z->host[idx] == (const void *)tunes[i].avg) {
+				z->zero[idx] = 1;
+				z->zero_hint = idx + 1;
+				marked++;
+				break;
+			}
+		}
+	pthread_mutex_unlock(&g_scan_lock);
+	return marked;
 }

@@ -149,6 +149,57 @@ def test_scan_and_csv_dropin(rng, flags, window, zc, tmp_path, monkeypatch):
     R.check(L.rxgpu_scan_deferred(0))
 
 
+@pytest.mark.parametrize("peak", [0, 1])
+def test_report_intervals_merge_into_rows_csv_dbm_cleared(peak, tmp_path):
+    """rx_power's loop for several report intervals (rtl_power.c:1039-1050): sweeps, then csv_dbm for every tune -- which prints and ZEROES avg[]
+    (rtl_power.c:815-817; rxgpu_csv_dbm does the same and remembers it).  The merge of the next interval finds rows it knows to be zero and writes
+    the accumulators over them without reading them across the link; an interval in which only SOME rows were printed falls back to the reading
+    merge, and the rows that were not printed keep adding up.  Every CSV row == the oracle's, every interval."""
+    L, O = R.lib(), oracle()
+    L.rxgpu_knobs_reload()
+    L.rxgpu_scan_release()
+    R.check(L.rxgpu_scan_deferred(1))
+    plan = R.plan_range("24M:60M:1k", 0.0, 1)
+    tunes, n = 5, 1 << plan.bin_e
+    wc, sw = R.window_coefs("hamming", n), R.sine_table(plan.bin_e)
+    cfg = PowerCfg(plan.bin_e, plan.buf_len, plan.downsample, plan.downsample_passes, 1, 0, peak, ptr32(wc), ptr16(sw))
+    work = np.zeros(plan.buf_len, np.int16)
+    arr, bufs, avgs = _tuning_array(plan, tunes, n)
+    want = np.zeros((tunes, n), np.int64)
+    ws = np.zeros(tunes, np.int32)
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fclose.argtypes = [C.c_void_p]
+    buf = C.create_string_buffer(1 << 20)
+    seed = 900
+    for interval, printed in enumerate([range(tunes), range(tunes), range(3), range(tunes), range(tunes)]):
+        for sweep in range(2):
+            for t in range(tunes):
+                bufs[t][:] = sig_noise(plan.buf_len, seed=seed, amp=2500)
+                seed += 1
+                smp = C.c_int(int(ws[t]))
+                O.rxo_power_tune(C.byref(cfg), ptr16(bufs[t].copy()), ptr16(work), ptr64(want[t]), C.byref(smp))
+                ws[t] = smp.value
+            R.check(L.rxgpu_scan(arr, tunes, wc.ctypes.data, sw.ctypes.data, 1, 0, peak))
+        path = str(tmp_path / ("i%d.csv" % interval))
+        f = libc.fopen(path.encode(), b"wb")
+        rows = []
+        for t in printed:
+            smp = C.c_int(int(ws[t]))
+            O.rxo_csv_row(buf, len(buf), arr[t].freq, plan.rate, plan.bin_e, plan.downsample, plan.crop, ptr64(want[t]), C.byref(smp))
+            rows.append(buf.value.decode())
+            L.rxgpu_csv_dbm(C.byref(arr[t]), f)
+            want[t][:] = 0                                     # csv_dbm's own reset (rtl_power.c:815-817), the oracle's row function leaves it to the caller
+            ws[t] = 0
+        libc.fclose(f)
+        assert open(path).read() == "".join(rows), "interval %d" % interval
+        assert L.rxgpu_scan_sync_in_place() == 1
+        for t in range(tunes):
+            assert np.array_equal(avgs[t], want[t]) and arr[t].samples == ws[t], (interval, t)
+    L.rxgpu_scan_release()
+    R.check(L.rxgpu_scan_deferred(0))
+
+
 def test_scan_on_a_sub_array_keeps_the_sweeps_registrations():
     """The drop-in's missed-read path calls rxgpu_scan(&tunes[i], j - i) between full sweeps (dropin/rx_power_unit.c): the sub-array is
     found in the table of page-locked buffers and read zero-copy through the rows it already has; a shorter call on buffers the table

@@ -42,10 +42,23 @@ for _ in range(intervals):
     t_scan += t1 - t0; t_sync += t2 - t1
 L.rxgpu_prof_enable(0)
 L.rxgpu_scan_timing(ph, 8)
+# the interval after a report: every row zeroed by csv_dbm and known to be (rxgpu_scan_rows_cleared): the merge writes without reading
+t_cl = 0.0
+for _ in range(intervals):
+    for a in avgs:
+        a[:] = 0
+    assert L.rxgpu_scan_rows_cleared(arr, T) == T
+    for _ in range(2):
+        R.check(L.rxgpu_scan(arr, T, wc.ctypes.data, sw.ctypes.data, 1, 0, 0))
+    R.check(L.rxgpu_sync())
+    t1 = time.perf_counter()
+    R.check(L.rxgpu_scan_sync(arr, T))
+    t_cl += time.perf_counter() - t1
 names = ["scan: table", "scan: gather launch", "scan: transforms enqueue", "scan: wait for gather", "sync: D2H wait", "sync: host merge"]
 print("mode %s  zero_copy %d  merge in place %d" % (mode, L.rxgpu_scan_zero_copy(), L.rxgpu_scan_sync_in_place()))
 print("rxgpu_scan      %.1f us per sweep   phases: %s" % (t_scan / (sweeps * intervals) * 1e6, ", ".join("%s %.1f" % (names[i], ph[i] / ph[6]) for i in range(4))))
 print("rxgpu_scan_sync %.1f us per interval phases: %s" % (t_sync / intervals * 1e6, ", ".join("%s %.1f" % (names[i], ph[i] / ph[7]) for i in (4, 5))))
+print("rxgpu_scan_sync %.1f us per interval when csv_dbm has cleared the rows (write-only merge)" % (t_cl / intervals * 1e6))
 for nm in ("pw_zc_gather", "pw_fft", "pw_zc_merge"):
     ms, k = C.c_double(0), C.c_long(0)
     L.rxgpu_prof_get(nm.encode(), C.byref(ms), C.byref(k))
