@@ -453,6 +453,23 @@ def test_dropin_single_block_path(kw, env, monkeypatch):
         R.lib().rxgpu_knobs_reload()
 
 
+@pytest.mark.parametrize("fast", ["1", "0"])
+@pytest.mark.parametrize("signal", ["fm", "noise", "steps"])
+@pytest.mark.parametrize("kw", [dict(downsample=12, deemph_a=9), dict(downsample=12, deemph_a=63, custom_atan=1), dict(downsample=16, deemph_a=33, rate_out2=-1),
+                                dict(downsample=30, deemph_a=15), dict(downsample=118, deemph_a=13), dict(downsample=11, deemph_a=21, rate_out=96000, rate_out2=8000)])
+def test_dropin_short_rows_on_hostile_signals(kw, signal, fast, monkeypatch):
+    """k_fm_row_audio (a one-block run's de-emphasis + low_pass_real: chunked warm-up from the ends of the int16 range, candidate tracking, the chunk
+    tables walked by one thread, replay) against the reference itself, block after block of every length, for a = 9 ... 63 on an FM signal, on full-scale
+    noise and on a carrier that slews the filter from rail to rail -- through the two-launch path and through the general one"""
+    monkeypatch.setenv("RXGPU_DROPIN_FAST", fast)
+    R.lib().rxgpu_knobs_reload()
+    try:
+        test_dropin_takes_every_block_length_the_reference_takes(kw, signal=signal)
+    finally:
+        monkeypatch.undo()
+        R.lib().rxgpu_knobs_reload()
+
+
 @pytest.mark.parametrize("kw", [dict(downsample=118), dict(downsample=6), dict(downsample_passes=3, comp_fir_size=9), dict(downsample=118, offset_tuning=1)])
 def test_dropin_callback_zero_copy(kw):
     """buf16[] and the read buffer page-locked (rxgpu_dropin_pin + rxgpu_pin, what INTEGRATION.md's patch does): rxgpu_callback then reads the raw
@@ -462,7 +479,7 @@ def test_dropin_callback_zero_copy(kw):
 
 
 @pytest.mark.parametrize("kw", ANY_LENGTH_PARAMS)
-def test_dropin_takes_every_block_length_the_reference_takes(kw, pin=False):
+def test_dropin_takes_every_block_length_the_reference_takes(kw, pin=False, signal="fm"):
     """readStream may return ANY element count (rtl_fm.c:894-899): the drop-in, call after call with a different length -- primes,
     two samples, reads shorter than the decimation, an empty read -- against the reference ITSELF (oracle/_ref: its own
     rtlsdr_callback + full_demod on its own struct), including the shapes where the C reads pre_r/pre_j from in front of
@@ -488,6 +505,14 @@ def test_dropin_takes_every_block_length_the_reference_takes(kw, pin=False):
     if kw.get("dc_block_raw"):
         lens = [v for v in lens if v]                     # the reference divides by zero on an empty read with -E rdc (rtl_fm.c:711)
     iq = sig_fm(sum(lens) // 2 + 8, seed=77)
+    if signal == "noise":                                 # full-scale noise: the discriminator's output jumps over the whole int16 range from sample to sample
+        iq = sig_noise(sum(lens) + 16, seed=78, amp=32768)
+    elif signal == "steps":                               # a carrier whose phase steps by +-90 degrees in long runs: the de-emphasis state slews from rail to rail
+        ph = np.repeat(np.random.default_rng(5).integers(0, 2, sum(lens) // 2 // 37 + 2) * 2 - 1, 37)[:sum(lens) // 2 + 8]
+        ang = np.cumsum(ph * (np.pi / 2))
+        iq = np.empty(2 * len(ang), np.int16)
+        iq[0::2] = np.round(30000 * np.cos(ang)).astype(np.int16)
+        iq[1::2] = np.round(30000 * np.sin(ang)).astype(np.int16)
     pos = 0
     if pin:
         R.check(L.rxgpu_dropin_pin(C.addressof(d), C.addressof(s)))
