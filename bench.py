@@ -911,8 +911,9 @@ def main():
                 shard.gather_rows(d_avgs[b], dst=0, out=gbuf)
                 shard.gather_rows(d_smps[b], dst=0, out=sbuf)
 
-        t_s = time.perf_counter()
-        while (time.perf_counter() - t_s) * 1e3 < args.settle_ms:  # (see the rx_fm leg; every rank runs it for the same wall time)
+        # (see the rx_fm leg.  A step holds a collective when N > 1: every rank must run the SAME number of them, so the count is fixed --
+        # a step of the whole sweep is ~5 ms on one GPU -- not taken from each rank's own clock)
+        for _ in range(int(args.settle_ms / 5.0 + 0.999) if args.settle_ms > 0 else 0):
             step()
             L.rxgpu_sync()
         for _ in range(args.warmup):

@@ -217,11 +217,15 @@ __device__ __forceinline__ uint32_t dec_prefix_wide(const uint4 *slot4, unsigned
 // DISC: also run the -A fast discriminator (F5/F6) for every output whose predecessor was completed
 // by this workgroup too (all but its first two), while the sums are still in LDS/registers; the
 // two seam outputs per workgroup and each block's libm sample are left to k_fm_disc.
-template <bool PRESCALED, bool ROTATE, bool DISC, bool DIV24, bool WIDE = false>
+// DCS (rx_power's boxcar in front of a large transform, rtl_power.c:723-733 then 609-624): remove_dc's sums of the decimated buffers ride along --
+// every wave leaves the sums of the outputs it stored (int I, int Q) at dc_sums[(span * 4 + wave)] (here: an int2 array, one entry per wave of every
+// span); the seam kernel adds a span's four, its own output, and does the buffer's atomics.  The transform then only divides (no pass of its own
+// over the block).
+template <bool PRESCALED, bool ROTATE, bool DISC, bool DIV24, bool WIDE = false, bool DCS = false>
 __global__ __launch_bounds__(DEC_THREADS) void k_fm_decimate(
 	const u32x4 *__restrict__ iq, u64 T, int ds, int p0, unsigned magic, unsigned magic24,
 	uint32_t *__restrict__ lp_raw, uint32_t *__restrict__ head, uint32_t *__restrict__ tail, unsigned slot_cap,
-	int lp_sparse, int16_t *__restrict__ pcm, int pcm_chl2)
+	int lp_sparse, int16_t *__restrict__ pcm, int pcm_chl2, i64 *__restrict__ dc_sums = nullptr, unsigned outs_per_buf = 1)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 	static_assert(!(WIDE && PRESCALED), "wide slots ride on the biased scan of the raw path");
@@ -309,6 +313,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_fm_decimate(
 	const unsigned per_wave = (n_b + 3) / 4;
 	const unsigned j_lo = wave * per_wave, j_hi = min(n_b, j_lo + per_wave);
 	uint32_t c1 = 0, c2 = 0;                                 // P(j-1), P(j-2) for the turn's first lane
+	int dsi = 0, dsq = 0;                                    // DCS: this lane's share of the buffer's sums (a few hundred int16 at most)
 	if (j_lo < j_hi) {
 		if (j_lo >= 1) c1 = PREFIX_AT(j_lo - 1);
 		if (j_lo >= 2) c2 = PREFIX_AT(j_lo - 2);
@@ -325,6 +330,10 @@ __global__ __launch_bounds__(DEC_THREADS) void k_fm_decimate(
 		const uint32_t a = pk_sub(pj, pm);
 		if (!lp_sparse && j)
 			lp_raw[m_base + j] = a;
+		if (DCS && j) {
+			dsi += lo16(a);
+			dsq += hi16(a);
+		}
 		if (DISC && j >= 2) {
 			int cr, cj;
 			mul_conj_pk(a, pk_sub(pm, pmm), cr, cj);
@@ -334,6 +343,18 @@ __global__ __launch_bounds__(DEC_THREADS) void k_fm_decimate(
 			else
 				__builtin_nontemporal_store(v, &pcm[m_base + j]);
 		}
+	}
+	if (DCS) {
+		// (a workgroup lives a few microseconds: no LDS shuffles, no 64-bit division in its tail -- six DPP adds per sum, the buffer from the span number)
+#define DPP_ADD(V, CTRL, ROWS) V += __builtin_amdgcn_update_dpp(0, V, CTRL, ROWS, 0xf, true)
+		DPP_ADD(dsi, 0x111, 0xf); DPP_ADD(dsq, 0x111, 0xf); DPP_ADD(dsi, 0x112, 0xf); DPP_ADD(dsq, 0x112, 0xf);
+		DPP_ADD(dsi, 0x114, 0xf); DPP_ADD(dsq, 0x114, 0xf); DPP_ADD(dsi, 0x118, 0xf); DPP_ADD(dsq, 0x118, 0xf);
+		DPP_ADD(dsi, 0x142, 0xa); DPP_ADD(dsq, 0x142, 0xa); DPP_ADD(dsi, 0x143, 0xc); DPP_ADD(dsq, 0x143, 0xc);
+#undef DPP_ADD
+		// a plain store per wave (k_pw_boxcar_seams adds the four and does the atomics: int64 atomics HERE kept every wave resident for their round
+		// trip -- 743 against 620 us for the launch's decimator, more than the dc pass they replaced)
+		if (lane == 63)
+			reinterpret_cast<int2 *>(dc_sums)[(size_t)wgi * 4 + wave] = make_int2(dsi, dsq);
 	}
 	// the first window ending in the span goes out in head/tail form; with a sparse lowpassed[] only the entries the seam kernel
 	// reads are kept: the span's second output and its last one
@@ -4403,6 +4424,24 @@ __global__ __launch_bounds__(256) void k_cha_replay_rs(const int16_t *__restrict
 // ------------------------------------------------------------------ launchers
 
 #define LAUNCH_RET() return (int)hipGetLastError()
+
+// rx_power's boxcar with the sums of every wave's stored outputs left in wave_sums[span * 4 + wave] = {I, Q} (k_fm_decimate<.., DCS>): prescaled input,
+// no rotation, phase 0
+extern "C" int rxk_pw_boxcar_sums(void *stream, const int16_t *iq, u64 T, int ds, uint32_t *lp_raw, uint32_t *head, uint32_t *tail, int *wave_sums)
+{
+	const unsigned grid = (unsigned)((T + RXK_DEC_SPAN - 1) / RXK_DEC_SPAN);
+	const unsigned magic = (unsigned)((1ull << 32) / (unsigned)ds + 1);
+	const unsigned magic24 = ((u64)(RXK_DEC_SPAN + 4 + ds) * (u64)ds < (1ull << 24)) ? (1u << 24) / (unsigned)ds + 1 : 0u;
+	const unsigned slot_cap = (RXK_DEC_SPAN + ds) / ds + 4 + 64;
+	const size_t shm = (size_t)(slot_cap + 4) * sizeof(uint32_t);
+	if (magic24)
+		hipLaunchKernelGGL((k_fm_decimate<true, false, false, true, false, true>), dim3(grid), dim3(DEC_THREADS), shm, (hipStream_t)stream, (const u32x4 *)iq, T, ds, 0,
+		                   magic, magic24, lp_raw, head, tail, slot_cap, 0, (int16_t *)nullptr, 0, (i64 *)wave_sums, 1u);
+	else
+		hipLaunchKernelGGL((k_fm_decimate<true, false, false, false, false, true>), dim3(grid), dim3(DEC_THREADS), shm, (hipStream_t)stream, (const u32x4 *)iq, T, ds, 0,
+		                   magic, magic24, lp_raw, head, tail, slot_cap, 0, (int16_t *)nullptr, 0, (i64 *)wave_sums, 1u);
+	LAUNCH_RET();
+}
 
 extern "C" int rxk_fm_decimate(void *stream, const int16_t *iq, u64 T, int ds, int p0, int prescaled, int rotate,
                                uint32_t *lp_raw, uint32_t *head, uint32_t *tail, int lp_sparse, int16_t *pcm, int pcm_chl2)

@@ -294,7 +294,11 @@ int rxk_pw_merge_rows(void *stream, void *const *d_rows, int rows, size_t row_by
  * complex slot k holds the wrapped sum of samples [k*ds,(k+1)*ds), zero elsewhere */
 int rxk_pw_boxcar(void *stream, const int16_t *in, int16_t *out, size_t n_bufs, int buf_len, int ds, int n_write);
 /* P2 through rxk_fm_decimate (prescaled, no rotation) when buffers hold whole windows: finish the per-span seam entries */
-int rxk_pw_boxcar_seams(void *stream, uint32_t *lp, const uint32_t *head, const uint32_t *tail, unsigned long long T, int ds);
+int rxk_pw_boxcar_seams(void *stream, uint32_t *lp, const uint32_t *head, const uint32_t *tail, unsigned long long T, int ds,
+                        long long *dc_sums, const int *wave_sums, unsigned spans_per_buf);
+/* dc_sums != NULL: the spans' wave sums (rxk_pw_boxcar_sums) and seam outputs join their buffers' remove_dc sums, spans_per_buf = buf_len / 2 / RXK_DEC_SPAN */
+/* the boxcar over buffers that are whole spans, every wave leaving the sums of the outputs it stored in wave_sums[(span * 4 + wave) * 2 + {0: I, 1: Q}] */
+int rxk_pw_boxcar_sums(void *stream, const int16_t *iq, unsigned long long T, int ds, uint32_t *lp_raw, uint32_t *head, uint32_t *tail, int *wave_sums);
 /* n_write: complex slots per buffer actually produced (what the transform will read); <= 0: all of them */
 /* P3 one stateless fifth_order pass on I and Q (rtl_power.c:582-607, 656-662): n_in complex
  * samples per buffer -> ceil(n_in/2); strides in complex samples */

@@ -540,22 +540,40 @@ __global__ void k_pw_boxcar(const uint32_t *__restrict__ in, uint32_t *__restric
 // When every buffer holds a whole number of boxcar windows, P2 over the concatenated buffers IS rx_fm's low_pass without
 // scale and rotation: the fast decimator of fm_kernels.hip (coalesced 16-byte loads, wave prefix scan) does the sums at
 // HBM rate and leaves the first window ending in each of its spans in head/tail form; this finishes those.
+// dc_sums != NULL (rxk_pw_boxcar_sums in front): the span's four wave sums (wave_sums[span * 4 + wave] = {I, Q}) and its seam output join the
+// remove_dc sums of the span's buffer (spans_per_buf whole spans per buffer)
 __global__ void k_pw_boxcar_seams(uint32_t *__restrict__ lp, const uint32_t *__restrict__ head, const uint32_t *__restrict__ tail,
-                                  u64 n_spans, u64 M, int ds)
+                                  u64 n_spans, u64 M, int ds, i64 *__restrict__ dc_sums, const int2 *__restrict__ wave_sums, unsigned spans_per_buf)
 {
 	const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
 	if (g >= n_spans)
 		return;
 	const u64 m = (g << RXK_DEC_SPAN_LOG2) / (u64)ds;          // windows completed before the span = the first one ending in it
-	if (m < M)
-		lp[m] = pw_pk_add(g ? tail[g - 1] : 0u, head[g]);
+	i64 si = 0, sq = 0;
+	if (m < M) {
+		const uint32_t v = pw_pk_add(g ? tail[g - 1] : 0u, head[g]);
+		lp[m] = v;
+		si = pw_lo(v);
+		sq = pw_hi(v);
+	}
+	if (dc_sums) {
+#pragma unroll
+		for (int w = 0; w < 4; w++) {
+			const int2 p = wave_sums[g * 4 + w];
+			si += p.x;
+			sq += p.y;
+		}
+		const u64 buf = g / spans_per_buf;
+		atomicAdd((unsigned long long *)&dc_sums[2 * buf], (unsigned long long)si);
+		atomicAdd((unsigned long long *)&dc_sums[2 * buf + 1], (unsigned long long)sq);
+	}
 }
-
-extern "C" int rxk_pw_boxcar_seams(void *stream, uint32_t *lp, const uint32_t *head, const uint32_t *tail, unsigned long long T, int ds)
+extern "C" int rxk_pw_boxcar_seams(void *stream, uint32_t *lp, const uint32_t *head, const uint32_t *tail, unsigned long long T, int ds,
+                                   long long *dc_sums, const int *wave_sums, unsigned spans_per_buf)
 {
 	const u64 n_spans = (T + RXK_DEC_SPAN - 1) / RXK_DEC_SPAN;
 	hipLaunchKernelGGL(k_pw_boxcar_seams, dim3((unsigned)((n_spans + 255) / 256)), dim3(256), 0, (hipStream_t)stream, lp, head, tail,
-	                   n_spans, T / (u64)ds, ds);
+	                   n_spans, T / (u64)ds, ds, (i64 *)dc_sums, (const int2 *)wave_sums, spans_per_buf);
 	return (int)hipGetLastError();
 }
 

@@ -363,12 +363,33 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 				if (s->bx_cap < n_spans) {
 					hipFree(s->bx_head); hipFree(s->bx_tail);
 					s->bx_head = s->bx_tail = NULL; s->bx_cap = 0;
-					RX_HIP(hipMalloc((void **)&s->bx_head, n_spans * 4));
+					RX_HIP(hipMalloc((void **)&s->bx_head, n_spans * 4 + 16 + n_spans * 32));     /* + four {I, Q} wave sums per span (rxk_pw_boxcar_sums) */
 					RX_HIP(hipMalloc((void **)&s->bx_tail, n_spans * 4));
 					s->bx_cap = n_spans;
 				}
-				RX_K(rxk_fm_decimate(st, d_in, T, ds, 0, 1, 0, (uint32_t *)s->work[0], s->bx_head, s->bx_tail, 0, NULL, 0));
-				RX_K(rxk_pw_boxcar_seams(st, (uint32_t *)s->work[0], s->bx_head, s->bx_tail, T, ds));
+#ifdef RXGPU_NO_BOX_SUMS                                   /* (scratch build for the A/B) */
+				if (0) {
+#else
+				if (nc % RXK_DEC_SPAN == 0 && p->bin_e >= 14 && p->bin_e <= 21) {
+#endif
+					/* buffers of whole spans in front of the large-N transform: remove_dc's sums ride in the decimator (every output a span
+					 * stores) and in the seam kernel (the one it leaves), where the transform's own dc pass would have put them */
+					if (s->big_dc_cap < n_bufs) {
+						hipFree(s->big_dc);
+						s->big_dc = NULL; s->big_dc_cap = 0;
+						RX_HIP(hipMalloc((void **)&s->big_dc, n_bufs * 24 + 64));
+						s->big_dc_cap = n_bufs;
+					}
+					long long *sums = rxk_pw_dc_sums(s->big_dc, n_bufs);
+					RX_HIP(hipMemsetAsync(sums, 0, n_bufs * 16, st));
+					int *wave_sums = (int *)(s->bx_head + ((s->bx_cap + 1) & ~(size_t)1));   /* behind the head entries, 8-byte aligned */
+					RX_K(rxk_pw_boxcar_sums(st, d_in, T, ds, (uint32_t *)s->work[0], s->bx_head, s->bx_tail, wave_sums));
+					RX_K(rxk_pw_boxcar_seams(st, (uint32_t *)s->work[0], s->bx_head, s->bx_tail, T, ds, sums, wave_sums, (unsigned)(nc / RXK_DEC_SPAN)));
+					dc_sums_done = 1;
+				} else {
+					RX_K(rxk_fm_decimate(st, d_in, T, ds, 0, 1, 0, (uint32_t *)s->work[0], s->bx_head, s->bx_tail, 0, NULL, 0));
+					RX_K(rxk_pw_boxcar_seams(st, (uint32_t *)s->work[0], s->bx_head, s->bx_tail, T, ds, NULL, NULL, 1));
+				}
 				fft_tune_stride = (size_t)eff;
 				fft_pass_stride = (size_t)tunes * (size_t)eff;
 			} else {

@@ -192,7 +192,8 @@ def test_bench_multi_rank_path_on_one_gpu(world, form, tmp_path):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     full_path = str(tmp_path / "full.json")
-    args = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--blocks", "256", "--passes", "8", "--cpu-seconds", "1.5", "--full-out", full_path]
+    # (--settle-ms 10: two untimed steps of the sharded sweep in front of the warm-up, each with its gather)
+    args = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--settle-ms", "10", "--blocks", "256", "--passes", "8", "--cpu-seconds", "1.5", "--full-out", full_path]
     if form == "torchrun":
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.join(root, "bench.py")] + args
@@ -206,8 +207,8 @@ def test_bench_multi_rank_path_on_one_gpu(world, form, tmp_path):
     line = json.load(open(full_path))
     assert line["n_gpus"] == world and line["value"] > 0 and line["config"]["parallelism"].startswith("replicas x%d" % world)
     pw = line["rx_power"]
-    # warm-up + steps + the one parity interval
-    assert pw["n_gpus"] == world and pw["config"]["rccl_ranks"] == world and pw["config"]["rccl_gathers_enqueued"] == 4
+    # settle + warm-up + steps + the one parity interval
+    assert pw["n_gpus"] == world and pw["config"]["rccl_ranks"] == world and pw["config"]["rccl_gathers_enqueued"] == 6
     assert "rxgpu_power_gather" in pw["config"]["gather"] and "libfake_rccl" in pw["config"]["gather"]
     assert pw["config"]["tunes_per_rank_padded"] == -(-599 // world) and pw["value"] > 0
     # ... and the gathered rows of the sharded interval were compared with the CPU checker over every tune of every rank
@@ -219,7 +220,7 @@ def test_bench_multi_rank_path_on_one_gpu(world, form, tmp_path):
     # run, the gathered rows bit-exact against the reference's scanner()
     cfg = compact["config"]
     assert compact["n_gpus"] == world and compact["steps"] == 2 and compact["warmup"] == 1 and compact["value"] == float("%.7g" % line["value"])
-    assert cfg["n_ranks"] == world and cfg["rccl_ranks"] == world and cfg["rccl_gathers_enqueued"] == 4 and cfg["rccl_library"].startswith("libfake_rccl")
+    assert cfg["n_ranks"] == world and cfg["rccl_ranks"] == world and cfg["rccl_gathers_enqueued"] == 6 and cfg["rccl_library"].startswith("libfake_rccl")
     assert abs(cfg["rx_power_Mbins_per_s"] / pw["value"] - 1) < 1e-4 and cfg["rx_power_ms_per_step"] > 0 and cfg["tunes_per_rank"] == -(-599 // world)
     assert cfg["rx_power_1gpu_same_run_Mbins_per_s"] > 0 and cfg["rx_power_speedup_vs_1gpu"] > 0
     assert cfg["scan_us_rank0"] > 0 and cfg["gather_us_rank0"] > 0 and "ncclGather" in cfg["gather_impl"]
