@@ -2961,7 +2961,7 @@ __device__ __forceinline__ void pp_cascade_raw(const uint32_t (&x)[R], uint32_t 
 template <int LV, bool FIR, int TW>
 __global__ __launch_bounds__(256) void k_pw_fifth_regn(const uint32_t *__restrict__ in, unsigned n, unsigned in_stride, unsigned tiles_per_block, unsigned wgs_per_block,
                                                        unsigned total_wgs, uint32_t *__restrict__ out, unsigned out_stride, int f1, int f2, int f3, int f4, int f5,
-                                                       i64 *__restrict__ sums)
+                                                       int2 *__restrict__ wave_part)
 {
 	constexpr int NOUT = 4, R = NOUT << LV, NP = R / 4;
 	static_assert(LV >= 1 && NP <= 16, "at most 64 samples per lane");
@@ -2975,8 +2975,11 @@ __global__ __launch_bounds__(256) void k_pw_fifth_regn(const uint32_t *__restric
 	// a workgroup takes 4 TW consecutive tiles of its buffer, four at a time: wave wv walks tiles base + wv, base + 4 + wv, ... -- with 16 KiB of
 	// stage per wave only ten waves fit a CU, so a wave keeps the NEXT tile's loads in flight behind the tile it computes
 	unsigned tile = (wgi - blk32 * wgs_per_block) * (4 * TW) + wv;
-	if (tile >= tiles_per_block)
+	if (tile >= tiles_per_block) {
+		if (wave_part && lane == 0)
+			wave_part[(size_t)wgi * 4 + wv] = make_int2(0, 0);
 		return;
+	}
 	const u64 blk = blk32;
 	const uint32_t *braw = in + blk * (u64)in_stride;
 	const unsigned K = n >> LV;
@@ -3037,12 +3040,16 @@ __global__ __launch_bounds__(256) void k_pw_fifth_regn(const uint32_t *__restric
 		if (TW > 1 && tile + 4 >= tiles_per_block)
 			break;
 	}
-	if (sums) {
-		for (int off = 32; off; off >>= 1) { si += __shfl_down(si, off); sq += __shfl_down(sq, off); }
-		if (lane == 0) {
-			atomicAdd((unsigned long long *)&sums[2 * blk], (unsigned long long)(i64)si);
-			atomicAdd((unsigned long long *)&sums[2 * blk + 1], (unsigned long long)(i64)sq);
-		}
+	if (wave_part) {
+		// the wave's share as ONE plain store (k_pw_fifth_fix adds a buffer's shares): int64 atomics here kept the wave resident for their round trip
+		// (the boxcar decimator's measurement, k_fm_decimate<.., DCS>)
+#define DPP_ADD(V, CTRL, ROWS) V += __builtin_amdgcn_update_dpp(0, V, CTRL, ROWS, 0xf, true)
+		DPP_ADD(si, 0x111, 0xf); DPP_ADD(sq, 0x111, 0xf); DPP_ADD(si, 0x112, 0xf); DPP_ADD(sq, 0x112, 0xf);
+		DPP_ADD(si, 0x114, 0xf); DPP_ADD(sq, 0x114, 0xf); DPP_ADD(si, 0x118, 0xf); DPP_ADD(sq, 0x118, 0xf);
+		DPP_ADD(si, 0x142, 0xa); DPP_ADD(sq, 0x142, 0xa); DPP_ADD(si, 0x143, 0xc); DPP_ADD(sq, 0x143, 0xc);
+#undef DPP_ADD
+		if (lane == 63)
+			wave_part[(size_t)wgi * 4 + wv] = make_int2(si, sq);
 	}
 }
 
@@ -3067,7 +3074,7 @@ __device__ __forceinline__ uint32_t pw_fifth_head1(const uint32_t *s, int k)
 
 template <int LV, bool FIR>
 __global__ __launch_bounds__(256) void k_pw_fifth_fix(const uint32_t *__restrict__ in, unsigned n_bufs, unsigned in_stride, uint32_t *__restrict__ out, unsigned out_stride,
-                                                      const int *__restrict__ fir, i64 *__restrict__ sums)
+                                                      const int *__restrict__ fir, i64 *__restrict__ sums, const int2 *__restrict__ wave_part, unsigned parts_per_buf)
 {
 	constexpr int NFIX = FIR ? 14 : 5, CMAX = 216;               // samples needed at level p for NFIX at level LV: c(p - 1) = max(2 c(p) - 1, 9); LV = 4: 209 raw at most
 	static_assert(LV == 4, "the level buffers are sized for four passes");
@@ -3119,10 +3126,16 @@ __global__ __launch_bounds__(256) void k_pw_fifth_fix(const uint32_t *__restrict
 		*dst = fin;
 	}
 	if (sums) {
-		for (int off = 8; off; off >>= 1) { di += __shfl_down(di, off); dq += __shfl_down(dq, off); }
+		// the buffer's sums: the shares k_pw_fifth_regn's waves left (computed with the regular formula everywhere) + what the first samples changed
+		for (unsigned k = lane; k < parts_per_buf; k += 64) {
+			const int2 p = wave_part[(size_t)b * parts_per_buf + k];
+			di += p.x;
+			dq += p.y;
+		}
+		for (int off = 32; off; off >>= 1) { di += __shfl_down(di, off); dq += __shfl_down(dq, off); }
 		if (lane == 0) {
-			atomicAdd((unsigned long long *)&sums[2 * (u64)b], (unsigned long long)di);
-			atomicAdd((unsigned long long *)&sums[2 * (u64)b + 1], (unsigned long long)dq);
+			sums[2 * (u64)b] = di;                               // the only writer: no atomics, nothing to zero first
+			sums[2 * (u64)b + 1] = dq;
 		}
 	}
 }
@@ -5506,11 +5519,21 @@ extern "C" int rxk_pw_fifth_fused(void *stream, const int16_t *in, unsigned long
 
 // four stateless passes (+ the droop FIR: fir = cic_9_tables[4] on the device, or NULL) in registers, the buffers' dc sums accumulated into sums[2 * buffer],
 // [2 * buffer + 1] (zeroed by the caller; NULL: none).  n % 64 == 0, n >= 256; strides in complex samples, multiples of 4; out 16-byte aligned
+// wave_part (sums != NULL): rxk_pw_fifth_regn4_parts(n_bufs, n) int pairs of scratch, one per wave
+extern "C" unsigned long long rxk_pw_fifth_regn4_parts(unsigned long long n_bufs, unsigned n)
+{
+	const unsigned tiles_r = ((n >> 4) / 4 + FR_OUT - 1) / FR_OUT;
+	const unsigned twn = tiles_r >= 4 * 2 ? 2 : 1;
+	return n_bufs * (unsigned long long)((tiles_r + 4 * twn - 1) / (4 * twn)) * 4ull;
+}
+
 extern "C" int rxk_pw_fifth_regn4(void *stream, const int16_t *in, unsigned long long n_bufs, unsigned n, unsigned in_stride, const int *fir_dev, const int *fir_host,
-                                  int16_t *out, unsigned out_stride, long long *sums)
+                                  int16_t *out, unsigned out_stride, long long *sums, int *wave_part)
 {
 	hipStream_t s = (hipStream_t)stream;
 	constexpr int LV = 4, TW = 2;
+	if (sums && !wave_part)
+		return (int)hipErrorInvalidValue;
 	const unsigned tiles_r = ((n >> LV) / 4 + FR_OUT - 1) / FR_OUT;
 	const unsigned twn = tiles_r >= 4 * TW ? TW : 1;
 	const unsigned wgs_per_block = (tiles_r + 4 * twn - 1) / (4 * twn);
@@ -5523,13 +5546,13 @@ extern "C" int rxk_pw_fifth_regn4(void *stream, const int16_t *in, unsigned long
 	const unsigned fgrid = (unsigned)((n_bufs + 3) / 4);
 	const int f1 = fir_host ? fir_host[1] : 0, f2 = fir_host ? fir_host[2] : 0, f3 = fir_host ? fir_host[3] : 0, f4 = fir_host ? fir_host[4] : 0, f5 = fir_host ? fir_host[5] : 0;
 #define PWR(FI, T) hipLaunchKernelGGL((k_pw_fifth_regn<LV, FI, T>), dim3(rgrid), dim3(256), 0, s, p, n, in_stride, tiles_r, wgs_per_block, (unsigned)total, o, out_stride, \
-		                              f1, f2, f3, f4, f5, (i64 *)sums)
+		                              f1, f2, f3, f4, f5, sums ? (int2 *)wave_part : (int2 *)nullptr)
 	if (fir_host) {
 		if (twn == TW) PWR(true, TW); else PWR(true, 1);
-		hipLaunchKernelGGL((k_pw_fifth_fix<LV, true>), dim3(fgrid), dim3(256), 0, s, p, (unsigned)n_bufs, in_stride, o, out_stride, fir_dev, (i64 *)sums);
+		hipLaunchKernelGGL((k_pw_fifth_fix<LV, true>), dim3(fgrid), dim3(256), 0, s, p, (unsigned)n_bufs, in_stride, o, out_stride, fir_dev, (i64 *)sums, (const int2 *)wave_part, wgs_per_block * 4u);
 	} else {
 		if (twn == TW) PWR(false, TW); else PWR(false, 1);
-		hipLaunchKernelGGL((k_pw_fifth_fix<LV, false>), dim3(fgrid), dim3(256), 0, s, p, (unsigned)n_bufs, in_stride, o, out_stride, fir_dev, (i64 *)sums);
+		hipLaunchKernelGGL((k_pw_fifth_fix<LV, false>), dim3(fgrid), dim3(256), 0, s, p, (unsigned)n_bufs, in_stride, o, out_stride, fir_dev, (i64 *)sums, (const int2 *)wave_part, wgs_per_block * 4u);
 	}
 #undef PWR
 	LAUNCH_RET();

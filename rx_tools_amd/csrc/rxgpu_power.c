@@ -209,6 +209,8 @@ struct rxgpu_power_scan {
 	int16_t *work[2];
 	size_t work_cap;
 	uint32_t *bx_head, *bx_tail;  /* boxcar through the rx_fm decimator: per-span seam partials */
+	int *regn_part;               /* -F register cascade: every wave's share of remove_dc's sums (rxk_pw_fifth_regn4) */
+	size_t regn_part_cap;
 	size_t bx_cap;
 	long long *rms_t, *rms_p;
 	size_t rms_cap;
@@ -303,7 +305,7 @@ void rxgpu_power_scan_destroy(rxgpu_power_scan *s)
 		return;
 	hipFree(s->window_dev); hipFree(s->twiddle_dev); hipFree(s->fir_dev);
 	hipFree(s->work[0]); hipFree(s->work[1]);
-	hipFree(s->bx_head); hipFree(s->bx_tail);
+	hipFree(s->bx_head); hipFree(s->bx_tail); hipFree(s->regn_part);
 	hipFree(s->big_scratch); hipFree(s->big_dc); hipFree(s->big_partial);
 	hipFree(s->rms_t); hipFree(s->rms_p);
 	free(s);
@@ -411,11 +413,17 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 					s->big_dc_cap = (size_t)passes * (size_t)tunes;
 				}
 				sums = rxk_pw_dc_sums(s->big_dc, (size_t)passes * (size_t)tunes);
-				RX_HIP(hipMemsetAsync(sums, 0, (size_t)passes * (size_t)tunes * 16, st));
+				const size_t parts = (size_t)rxk_pw_fifth_regn4_parts(n_bufs, (unsigned)(buf_len / 2));
+				if (s->regn_part_cap < parts) {
+					hipFree(s->regn_part);
+					s->regn_part = NULL; s->regn_part_cap = 0;
+					RX_HIP(hipMalloc((void **)&s->regn_part, parts * 8));
+					s->regn_part_cap = parts;
+				}
 				dc_sums_done = 1;
 			}
 			RX_K(rxk_pw_fifth_regn4(st, d_in, n_bufs, (unsigned)(buf_len / 2), (unsigned)(buf_len / 2), fir ? s->fir_dev : NULL, fir ? cic_9_tables[4] : NULL,
-			                        s->work[0], (unsigned)(buf_len / 2), sums));
+			                        s->work[0], (unsigned)(buf_len / 2), sums, s->regn_part));
 			fft_in = s->work[0];
 		} else {                                           /* rtl_power.c:734-743 */
 			const int16_t *src = d_in;
