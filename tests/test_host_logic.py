@@ -179,7 +179,7 @@ def test_every_tuning_knob_the_sources_read_is_in_the_snapshot_table():
     csrc = os.path.join(ROOT, "rx_tools_amd", "csrc")
     used = set()
     for f in glob.glob(os.path.join(csrc, "*")):
-        if f.endswith((".c", ".hip", ".h")):
+        if f.endswith((".c", ".hip", ".h", ".inc")):
             used |= set(re.findall(r'rxgpu_knob\("(\w+)"\)', open(f).read()))
     src = open(os.path.join(csrc, "rxgpu_rt.c")).read()
     tab = src[src.index("g_knob_names[] = {"):]
