@@ -5,7 +5,7 @@
 #   bench     the driver's bench command (compact line + full record), every leg checked against the reference at size
 #   trace     rocprofv3 --kernel-trace --stats of the headline command and of the rx_fm variants
 #   chains    every rx_fm chain alone (tools/chain_once.py): issue counters, FETCH_SIZE, WRITE_SIZE
-#   power     rx_power configs[2] launches: issue, FETCH_SIZE, WRITE_SIZE, LDS counters
+#   power     rx_power configs[2] launches: issue, FETCH_SIZE, WRITE_SIZE, LDS counters (--settle-ms 0: the per-launch figures divide by steps + warmup)
 #   chan      the channeliser's bench shape (tools/chan_once.py): the same four passes; its other modes (-A std, audio stages, NCO): the issue
 #             counters behind their bound; the per-channel audio stages' kernel trace
 #   legs      the other rx_power geometries of the bench line (tools/pw_big_once.py): issue, FETCH_SIZE, WRITE_SIZE
@@ -38,8 +38,8 @@ if has bench; then
 fi
 if has trace; then
   rm -rf $OUT/trace $OUT/trace_variants
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $REPO/bench.py --steps 20 --warmup 5 --variants none --no-parity --full-out $OUT/trace_bench_full.json > $OUT/trace_bench.json 2> $OUT/trace.log
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_variants -- python $REPO/bench.py --steps 5 --warmup 2 --cpu-seconds 0 --workload rx_fm --no-parity --full-out $OUT/trace_variants_full.json > $OUT/trace_variants.json 2> $OUT/trace_variants.log
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $REPO/bench.py --steps 20 --warmup 5 --settle-ms 0 --variants none --no-parity --full-out $OUT/trace_bench_full.json > $OUT/trace_bench.json 2> $OUT/trace.log
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_variants -- python $REPO/bench.py --steps 5 --warmup 2 --settle-ms 0 --cpu-seconds 0 --workload rx_fm --no-parity --full-out $OUT/trace_variants_full.json > $OUT/trace_variants.json 2> $OUT/trace_variants.log
 fi
 if has chains; then
   for ds in 118 6 5 -7 -39; do
@@ -47,7 +47,7 @@ if has chains; then
   done
 fi
 if has power; then
-  pmc rx_power "$SQ|FETCH_SIZE|WRITE_SIZE|$LDS" python $REPO/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --workload rx_power --variants none --no-parity --full-out $OUT/pmc_power_full.json
+  pmc rx_power "$SQ|FETCH_SIZE|WRITE_SIZE|$LDS" python $REPO/bench.py --steps 2 --warmup 1 --settle-ms 0 --cpu-seconds 0 --workload rx_power --variants none --no-parity --full-out $OUT/pmc_power_full.json
 fi
 if has chan; then
   pmc chan "$SQ|FETCH_SIZE|WRITE_SIZE|$LDS" python $REPO/tools/chan_once.py
