@@ -287,6 +287,29 @@ def test_four_stateless_passes_in_registers(bin_e, blocks, fir, amp, tunes, pass
         assert bad.size == 0 and np.array_equal(gs, ws), "first mismatch at %s (%d bad)" % (bad[0] if bad.size else None, len(bad))
 
 
+@pytest.mark.parametrize("bin_e,ds,blocks,tunes,passes,peak", [
+    (14, 4, 1, 3, 2, 0),      # four spans per buffer, six buffers: every span's wave sums and seam output land in their own buffer's pair
+    (14, 8, 2, 2, 3, 1),      # two transforms per buffer (remove_dc runs over the whole buffer, rtl_power.c:744-745), peak hold
+    (15, 6, 1, 2, 2, 0),      # ds = 6: windows straddle the span seams (16384 % 6 != 0), the seam kernel's outputs carry their share
+    (14, 5, 1, 1, 2, 0),      # buf_len / 2 = 81920 = five spans
+])
+def test_boxcar_with_remove_dc_sums_riding_in_the_decimator(bin_e, ds, blocks, tunes, passes, peak):
+    """rx_power's boxcar in front of a large transform where the buffers are whole 16384-sample spans: k_fm_decimate<.., DCS> leaves every wave's share
+    of remove_dc's sums (rtl_power.c:609-624) and k_pw_boxcar_seams adds a span's four, its seam output, and does the buffer's atomics -- the transform
+    runs no dc pass of its own.  Several tunes and passes (buffer boundaries at span boundaries), full-scale noise and a constant: == the oracle's scanner()"""
+    import types
+    n = 1 << bin_e
+    plan = types.SimpleNamespace(bin_e=bin_e, buf_len=2 * n * ds * blocks, downsample=ds, downsample_passes=0)
+    assert (plan.buf_len // 2) % 16384 == 0
+    wc, sw = R.window_coefs("hamming", n), R.sine_table(bin_e)
+    for data in (sig_noise(passes * tunes * plan.buf_len, seed=40 + ds, amp=32768),
+                 np.full(passes * tunes * plan.buf_len, -32768, np.int16)):
+        want, ws = oracle_scan(data, passes, tunes, plan, wc, sw, 1, 0, peak)
+        got, gs = gpu_scan(data, passes, tunes, plan, wc, sw, 1, 0, peak)
+        bad = np.argwhere(got != want)
+        assert bad.size == 0 and np.array_equal(gs, ws), "first mismatch at %s (%d bad)" % (bad[0] if bad.size else None, len(bad))
+
+
 def test_buffer_that_is_no_whole_number_of_large_transforms():
     """N = 2^16 with 1.5 transforms per decimated buffer (boxcar ds = 2 on 3 * 2^17 int16: the second transform is half samples, half the zeros
     the boxcar leaves behind, rtl_power.c:723-733) -- a geometry the reference's planner never makes and rxgpu_power_scan_create accepts: it takes
