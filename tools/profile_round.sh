@@ -38,8 +38,8 @@ if has bench; then
 fi
 if has trace; then
   rm -rf $OUT/trace $OUT/trace_variants
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $REPO/bench.py --steps 20 --warmup 5 --settle-ms 0 --variants none --no-parity --full-out $OUT/trace_bench_full.json > $OUT/trace_bench.json 2> $OUT/trace.log
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_variants -- python $REPO/bench.py --steps 5 --warmup 2 --settle-ms 0 --cpu-seconds 0 --workload rx_fm --no-parity --full-out $OUT/trace_variants_full.json > $OUT/trace_variants.json 2> $OUT/trace_variants.log
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $REPO/bench.py --steps 20 --warmup 5 --variants none --no-parity --full-out $OUT/trace_bench_full.json > $OUT/trace_bench.json 2> $OUT/trace.log
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_variants -- python $REPO/bench.py --steps 5 --warmup 2 --cpu-seconds 0 --workload rx_fm --no-parity --full-out $OUT/trace_variants_full.json > $OUT/trace_variants.json 2> $OUT/trace_variants.log
 fi
 if has chains; then
   for ds in 118 6 5 -7 -39; do
