@@ -451,6 +451,101 @@ __global__ __launch_bounds__(((1 << M) / 16 > 256) ? (1 << M) / 16 : 256) void k
 	}
 }
 
+// k_pw_fftR for N = 256 ... 2048 where a tune buffer is a few groups of side-by-side transforms (the usual 16384-int16 buffer: two groups): k_pw_fft4096's
+// shape instead of the two passes over the buffer above.  A thread takes ALL its samples of the pass into registers at once (NG groups x 16 values),
+// remove_dc's sums come from those registers, the NEXT pass's samples are requested while this one is transformed, and the input is read once.
+// Measured at the configs[2] buffer shape (599 tunes x 16384 int16 x 256 passes): the two-pass form 315-337 G bins/s for N = 256 ... 2048 -- under
+// N = 4096's 485 although it has a quarter to a twelfth fewer stages per bin.
+template <int M, int NG, bool PEAK>
+__global__ __launch_bounds__(256) void k_pw_fftR2(
+	const int16_t *__restrict__ in, size_t tune_stride, size_t pass_stride, int passes,
+	const int *__restrict__ window, const uint32_t *__restrict__ twiddle, int ppg, i64 *__restrict__ avg, i64 *__restrict__ partial)
+{
+	typedef fft_geom<M> G;
+	constexpr int N = G::N, TPF = G::TPF, T = 256, FPW = T / TPF;
+	static_assert(M >= 8 && M <= 11 && TPF <= 256, "side-by-side transforms in one 256-thread workgroup");
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+	uint32_t *xa = lds, *xb = lds + T * G::XROW;
+	i64 *red = (i64 *)(lds + 2 * T * G::XROW);
+	uint32_t *tl = (uint32_t *)(red + 32);
+	const int tid = threadIdx.x, fid = tid / TPF;
+	const unsigned tq = tid % TPF;
+	const int tune = blockIdx.x;
+	const int p_begin = blockIdx.y * ppg, p_end = min(passes, p_begin + ppg);
+	fft_tw_fill<M>(tl, twiddle, tid, T);                   // ordered by the pass loop's first __syncthreads
+	unsigned ta[3][4];
+	fft_tw_addr_all<M>(tq, ta);
+	uint32_t wcoef[16];
+#pragma unroll
+	for (int r = 0; r < 16; r++) {
+		const uint32_t c = (uint32_t)window[tq + r * TPF] & 0xffffu;
+		wcoef[r] = c | (c << 16);
+	}
+	i64 acc[16];
+#pragma unroll
+	for (int r = 0; r < 16; r++)
+		acc[r] = 0;
+	i64 *avg_t = avg + (size_t)tune * N;
+	constexpr int L = 2 * NG * FPW * N;                    // int16 of a tune buffer that take part
+	uint32_t dn[NG][16];
+	if (p_begin < p_end) {
+		const uint32_t *buf0 = (const uint32_t *)(in + (size_t)p_begin * pass_stride + (size_t)tune * tune_stride);
+#pragma unroll
+		for (int g = 0; g < NG; g++)
+#pragma unroll
+			for (int r = 0; r < 16; r++)
+				dn[g][r] = buf0[(g * FPW + fid) * N + tq + r * TPF];
+	}
+	for (int pass = p_begin; pass < p_end; pass++) {
+		uint32_t d[NG][16];
+		int si = 0, sq = 0;                                    // 16 NG int16 per lane: far inside int32
+#pragma unroll
+		for (int g = 0; g < NG; g++)
+#pragma unroll
+			for (int r = 0; r < 16; r++) {
+				d[g][r] = dn[g][r];
+				si = pw_dot(d[g][r], 0x00000001u, si);
+				sq = pw_dot(d[g][r], 0x00010000u, sq);
+			}
+		if (pass + 1 < p_end) {
+			const uint32_t *bufn = (const uint32_t *)(in + (size_t)(pass + 1) * pass_stride + (size_t)tune * tune_stride);
+#pragma unroll
+			for (int g = 0; g < NG; g++)
+#pragma unroll
+				for (int r = 0; r < 16; r++)
+					dn[g][r] = bufn[(g * FPW + fid) * N + tq + r * TPF];
+		}
+		for (int off = 32; off; off >>= 1) { si += __shfl_down(si, off); sq += __shfl_down(sq, off); }
+		__syncthreads();
+		if ((tid & 63) == 0) { red[tid >> 6] = si; red[16 + (tid >> 6)] = sq; }
+		__syncthreads();
+		const i64 ti64 = red[0] + red[1] + red[2] + red[3], tq64 = red[16] + red[17] + red[18] + red[19];
+		const uint32_t ave = pw_pack((int)(short)(ti64 / L), (int)(short)(tq64 / (L - 1)));   // rtl_power.c:609-624 via 744-745
+#pragma unroll
+		for (int g = 0; g < NG; g++) {
+			uint32_t v[16];
+#pragma unroll
+			for (int r = 0; r < 16; r++)
+				v[r] = pw_pk_mul(pw_pk_sub(d[g][r], ave), wcoef[r]);                   // window, rtl_power.c:749-758
+			fft_reg<M, true, true>(v, tq, xa + fid * TPF * G::XROW, xb + fid * TPF * G::XROW, twiddle, tl, ta);
+#pragma unroll
+			for (int r = 0; r < 16; r++) {
+				const i64 pw = (i64)pw_norm(v[r]);
+				acc[r] = PEAK ? (pw > acc[r] ? pw : acc[r]) : acc[r] + pw;
+			}
+		}
+	}
+	// few tunes: the groups' spectra go to partial[((group * tunes + tune) * FPW + fid) * N + bin] and k_pwm_reduce folds them in
+	i64 *dst = partial ? partial + ((((size_t)blockIdx.y * gridDim.x + tune) * FPW + fid) << M) : nullptr;
+#pragma unroll
+	for (int r = 0; r < 16; r++) {
+		const unsigned bin = __brev((tq << 4) | (unsigned)r) >> (32 - M);
+		if (dst) dst[bin] = acc[r];
+		else if (PEAK) atomicMax((long long *)&avg_t[bin], acc[r]);
+		else if (acc[r]) atomicAdd((unsigned long long *)&avg_t[bin], (unsigned long long)acc[r]);
+	}
+}
+
 // P1 for the drop-in (rtl_power.c:715-720): scanner() copies each tune's buf16 -- 599 separate mallocs of the caller -- into fft_buf.  Here the
 // caller's buffers are page-locked once and their device-visible addresses sit in a table: one launch pulls every tune's capture across PCIe
 // into the contiguous [tunes][buf_len] input of the scan (16-byte pieces, four on their way per lane), no host memcpy, no staging copy.
@@ -1296,10 +1391,21 @@ extern "C" int rxk_pw_fft(void *stream, const int16_t *in, size_t tune_stride, s
 			(void)hipFuncSetAttribute((const void *)k_pw_fftR<MM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); } \
 		if (peak_hold) hipLaunchKernelGGL((k_pw_fftR<MM, true>), grid, dim3(T), lds_bytes, s, in, tune_stride, pass_stride, passes, nb_total, window, twiddle + (1 << (MM - 1)), passes_per_group, (i64 *)avg, part); \
 		else hipLaunchKernelGGL((k_pw_fftR<MM, false>), grid, dim3(T), lds_bytes, s, in, tune_stride, pass_stride, passes, nb_total, window, twiddle + (1 << (MM - 1)), passes_per_group, (i64 *)avg, part); } while (0)
+		/* N = 256 ... 2048 with one, two or four groups of side-by-side transforms per buffer: the buffer in registers, read once (k_pw_fftR2) */
+		const int ng = (bin_e <= 11 && nb_total % fpw == 0) ? nb_total / fpw : 0;
+#define GOR2_(MM, NGG) do { \
+		if (peak_hold) hipLaunchKernelGGL((k_pw_fftR2<MM, NGG, true>), grid, dim3(256), lds_bytes, s, in, tune_stride, pass_stride, passes, window, twiddle + (1 << (MM - 1)), passes_per_group, (i64 *)avg, part); \
+		else hipLaunchKernelGGL((k_pw_fftR2<MM, NGG, false>), grid, dim3(256), lds_bytes, s, in, tune_stride, pass_stride, passes, window, twiddle + (1 << (MM - 1)), passes_per_group, (i64 *)avg, part); } while (0)
+#define GOR2(MM) do { if (ng == 1) GOR2_(MM, 1); else if (ng == 2) GOR2_(MM, 2); else GOR2_(MM, 4); } while (0)
+		if (ng == 1 || ng == 2 || ng == 4) {
+			switch (bin_e) { case 8: GOR2(8); break; case 9: GOR2(9); break; case 10: GOR2(10); break; default: GOR2(11); break; }
+		} else
 		switch (bin_e) {
 		case 8: GOR(8); break; case 9: GOR(9); break; case 10: GOR(10); break; case 11: GOR(11); break;
 		case 12: GOR(12); break; default: GOR(13); break;
 		}
+#undef GOR2
+#undef GOR2_
 #undef GOR
 		if (part)
 			hipLaunchKernelGGL(k_pwm_reduce<false>, dim3((unsigned)((((size_t)tunes << bin_e) + 255) / 256), 16), dim3(256), 0, s, part, tunes, fpw, groups, bin_e,

@@ -310,6 +310,30 @@ def test_boxcar_with_remove_dc_sums_riding_in_the_decimator(bin_e, ds, blocks, t
         assert bad.size == 0 and np.array_equal(gs, ws), "first mismatch at %s (%d bad)" % (bad[0] if bad.size else None, len(bad))
 
 
+@pytest.mark.parametrize("bin_e,buf_len,tunes,passes,peak,window", [
+    (8, 8192, 3, 5, 0, "hamming"),       # one group of 16 side-by-side transforms per buffer
+    (8, 16384, 70, 2, 0, "rectangle"),   # two groups; more than 64 tunes: the accumulators go to avg[] by atomics, not through the partial buffer
+    (9, 32768, 2, 3, 1, "blackman"),     # four groups, peak hold
+    (10, 16384, 5, 4, 0, "hamming"),     # N = 1024: a transform's 64 threads are one wave (wave-level ordering in the exchanges)
+    (11, 8192, 2, 3, 0, "bartlett"),     # N = 2048, one group of two transforms
+    (11, 32768, 1, 2, 1, "rectangle"),   # N = 2048, four groups
+    (10, 4096, 2, 2, 0, "hamming"),      # HALF a group per buffer (two of four side-by-side transforms): the two-pass form keeps this shape
+])
+def test_small_transforms_with_the_buffer_in_registers(bin_e, buf_len, tunes, passes, peak, window):
+    """N = 256 ... 2048 (k_pw_fftR2: a thread holds all its samples of the pass -- one, two or four groups of side-by-side transforms --, remove_dc from
+    the registers, the next pass on its way, rtl_power.c:744-768) on full-scale noise and on a constant, with and without peak hold, few and many tunes
+    == the oracle's scanner(); a buffer that is no whole number of groups stays with k_pw_fftR"""
+    import types
+    n = 1 << bin_e
+    plan = types.SimpleNamespace(bin_e=bin_e, buf_len=buf_len, downsample=1, downsample_passes=0)
+    wc, sw = R.window_coefs(window, n), R.sine_table(bin_e)
+    for data in (sig_noise(passes * tunes * buf_len, seed=60 + bin_e, amp=32768), np.full(passes * tunes * buf_len, 32767, np.int16)):
+        want, ws = oracle_scan(data, passes, tunes, plan, wc, sw, 1, 0, peak)
+        got, gs = gpu_scan(data, passes, tunes, plan, wc, sw, 1, 0, peak)
+        bad = np.argwhere(got != want)
+        assert bad.size == 0 and np.array_equal(gs, ws), "first mismatch at %s (%d bad)" % (bad[0] if bad.size else None, len(bad))
+
+
 def test_buffer_that_is_no_whole_number_of_large_transforms():
     """N = 2^16 with 1.5 transforms per decimated buffer (boxcar ds = 2 on 3 * 2^17 int16: the second transform is half samples, half the zeros
     the boxcar leaves behind, rtl_power.c:723-733) -- a geometry the reference's planner never makes and rxgpu_power_scan_create accepts: it takes
