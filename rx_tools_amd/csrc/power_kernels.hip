@@ -457,16 +457,17 @@ __global__ __launch_bounds__(((1 << M) / 16 > 256) ? (1 << M) / 16 : 256) void k
 // Measured at the configs[2] buffer shape (599 tunes x 16384 int16 x 256 passes): the two-pass form 315-337 G bins/s for N = 256 ... 2048 -- under
 // N = 4096's 485 although it has a quarter to a twelfth fewer stages per bin.
 template <int M, int NG, bool PEAK>
-__global__ __launch_bounds__(256) void k_pw_fftR2(
+__global__ __launch_bounds__(((1 << M) / 16 > 256) ? (1 << M) / 16 : 256) void k_pw_fftR2(
 	const int16_t *__restrict__ in, size_t tune_stride, size_t pass_stride, int passes,
 	const int *__restrict__ window, const uint32_t *__restrict__ twiddle, int ppg, i64 *__restrict__ avg, i64 *__restrict__ partial)
 {
 	typedef fft_geom<M> G;
-	constexpr int N = G::N, TPF = G::TPF, T = 256, FPW = T / TPF;
-	static_assert(M >= 8 && M <= 11 && TPF <= 256, "side-by-side transforms in one 256-thread workgroup");
+	constexpr int N = G::N, TPF = G::TPF, T = TPF > 256 ? TPF : 256, FPW = T / TPF;
+	constexpr bool DB = M <= 12;                           // N = 8192 (512 threads): one transpose area, a barrier between its uses
+	static_assert(M >= 8 && M <= 13, "side-by-side transforms in one workgroup, or one transform of 512 threads");
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-	uint32_t *xa = lds, *xb = lds + T * G::XROW;
-	i64 *red = (i64 *)(lds + 2 * T * G::XROW);
+	uint32_t *xa = lds, *xb = DB ? lds + T * G::XROW : lds;
+	i64 *red = (i64 *)(lds + (DB ? 2 : 1) * T * G::XROW);
 	uint32_t *tl = (uint32_t *)(red + 32);
 	const int tid = threadIdx.x, fid = tid / TPF;
 	const unsigned tq = tid % TPF;
@@ -519,7 +520,9 @@ __global__ __launch_bounds__(256) void k_pw_fftR2(
 		__syncthreads();
 		if ((tid & 63) == 0) { red[tid >> 6] = si; red[16 + (tid >> 6)] = sq; }
 		__syncthreads();
-		const i64 ti64 = red[0] + red[1] + red[2] + red[3], tq64 = red[16] + red[17] + red[18] + red[19];
+		i64 ti64 = 0, tq64 = 0;
+#pragma unroll
+		for (int w = 0; w < T / 64; w++) { ti64 += red[w]; tq64 += red[16 + w]; }
 		const uint32_t ave = pw_pack((int)(short)(ti64 / L), (int)(short)(tq64 / (L - 1)));   // rtl_power.c:609-624 via 744-745
 #pragma unroll
 		for (int g = 0; g < NG; g++) {
@@ -527,7 +530,7 @@ __global__ __launch_bounds__(256) void k_pw_fftR2(
 #pragma unroll
 			for (int r = 0; r < 16; r++)
 				v[r] = pw_pk_mul(pw_pk_sub(d[g][r], ave), wcoef[r]);                   // window, rtl_power.c:749-758
-			fft_reg<M, true, true>(v, tq, xa + fid * TPF * G::XROW, xb + fid * TPF * G::XROW, twiddle, tl, ta);
+			fft_reg<M, DB, true>(v, tq, xa + fid * TPF * G::XROW, xb + fid * TPF * G::XROW, twiddle, tl, ta);
 #pragma unroll
 			for (int r = 0; r < 16; r++) {
 				const i64 pw = (i64)pw_norm(v[r]);
@@ -1392,13 +1395,16 @@ extern "C" int rxk_pw_fft(void *stream, const int16_t *in, size_t tune_stride, s
 		if (peak_hold) hipLaunchKernelGGL((k_pw_fftR<MM, true>), grid, dim3(T), lds_bytes, s, in, tune_stride, pass_stride, passes, nb_total, window, twiddle + (1 << (MM - 1)), passes_per_group, (i64 *)avg, part); \
 		else hipLaunchKernelGGL((k_pw_fftR<MM, false>), grid, dim3(T), lds_bytes, s, in, tune_stride, pass_stride, passes, nb_total, window, twiddle + (1 << (MM - 1)), passes_per_group, (i64 *)avg, part); } while (0)
 		/* N = 256 ... 2048 with one, two or four groups of side-by-side transforms per buffer: the buffer in registers, read once (k_pw_fftR2) */
-		const int ng = (bin_e <= 11 && nb_total % fpw == 0) ? nb_total / fpw : 0;
+		const int ng = (nb_total % fpw == 0) ? nb_total / fpw : 0;
 #define GOR2_(MM, NGG) do { \
-		if (peak_hold) hipLaunchKernelGGL((k_pw_fftR2<MM, NGG, true>), grid, dim3(256), lds_bytes, s, in, tune_stride, pass_stride, passes, window, twiddle + (1 << (MM - 1)), passes_per_group, (i64 *)avg, part); \
-		else hipLaunchKernelGGL((k_pw_fftR2<MM, NGG, false>), grid, dim3(256), lds_bytes, s, in, tune_stride, pass_stride, passes, window, twiddle + (1 << (MM - 1)), passes_per_group, (i64 *)avg, part); } while (0)
+		if (lds_bytes > 64 * 1024) { \
+			(void)hipFuncSetAttribute((const void *)k_pw_fftR2<MM, NGG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+			(void)hipFuncSetAttribute((const void *)k_pw_fftR2<MM, NGG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); } \
+		if (peak_hold) hipLaunchKernelGGL((k_pw_fftR2<MM, NGG, true>), grid, dim3(T), lds_bytes, s, in, tune_stride, pass_stride, passes, window, twiddle + (1 << (MM - 1)), passes_per_group, (i64 *)avg, part); \
+		else hipLaunchKernelGGL((k_pw_fftR2<MM, NGG, false>), grid, dim3(T), lds_bytes, s, in, tune_stride, pass_stride, passes, window, twiddle + (1 << (MM - 1)), passes_per_group, (i64 *)avg, part); } while (0)
 #define GOR2(MM) do { if (ng == 1) GOR2_(MM, 1); else if (ng == 2) GOR2_(MM, 2); else GOR2_(MM, 4); } while (0)
-		if (ng == 1 || ng == 2 || ng == 4) {
-			switch (bin_e) { case 8: GOR2(8); break; case 9: GOR2(9); break; case 10: GOR2(10); break; default: GOR2(11); break; }
+		if ((ng == 1 || ng == 2 || ng == 4) && bin_e != 12) {                /* (N = 4096 with these buffers is k_pw_fft4096's, above) */
+			switch (bin_e) { case 8: GOR2(8); break; case 9: GOR2(9); break; case 10: GOR2(10); break; case 11: GOR2(11); break; default: GOR2(13); break; }
 		} else
 		switch (bin_e) {
 		case 8: GOR(8); break; case 9: GOR(9); break; case 10: GOR(10); break; case 11: GOR(11); break;

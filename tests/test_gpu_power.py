@@ -318,9 +318,12 @@ def test_boxcar_with_remove_dc_sums_riding_in_the_decimator(bin_e, ds, blocks, t
     (11, 8192, 2, 3, 0, "bartlett"),     # N = 2048, one group of two transforms
     (11, 32768, 1, 2, 1, "rectangle"),   # N = 2048, four groups
     (10, 4096, 2, 2, 0, "hamming"),      # HALF a group per buffer (two of four side-by-side transforms): the two-pass form keeps this shape
+    (13, 16384, 3, 3, 0, "hamming"),     # N = 8192: one transform of 512 threads per buffer, one transpose area
+    (13, 32768, 2, 2, 1, "rectangle"),   # ... two per buffer, peak hold
+    (13, 65536, 1, 2, 0, "blackman"),    # ... four
 ])
 def test_small_transforms_with_the_buffer_in_registers(bin_e, buf_len, tunes, passes, peak, window):
-    """N = 256 ... 2048 (k_pw_fftR2: a thread holds all its samples of the pass -- one, two or four groups of side-by-side transforms --, remove_dc from
+    """N = 256 ... 2048 and 8192 (k_pw_fftR2: a thread holds all its samples of the pass -- one, two or four groups of side-by-side transforms --, remove_dc from
     the registers, the next pass on its way, rtl_power.c:744-768) on full-scale noise and on a constant, with and without peak hold, few and many tunes
     == the oracle's scanner(); a buffer that is no whole number of groups stays with k_pw_fftR"""
     import types
