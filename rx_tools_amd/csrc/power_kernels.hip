@@ -464,7 +464,7 @@ __global__ __launch_bounds__(((1 << M) / 16 > 256) ? (1 << M) / 16 : 256) void k
 	typedef fft_geom<M> G;
 	constexpr int N = G::N, TPF = G::TPF, T = TPF > 256 ? TPF : 256, FPW = T / TPF;
 	constexpr bool DB = M <= 12;                           // N = 8192 (512 threads): one transpose area, a barrier between its uses
-	static_assert(M >= 8 && M <= 13, "side-by-side transforms in one workgroup, or one transform of 512 threads");
+	static_assert(M >= 5 && M <= 13, "side-by-side transforms in one workgroup (N >= 32: two threads per transform), or one transform of 512 threads");
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 	uint32_t *xa = lds, *xb = DB ? lds + T * G::XROW : lds;
 	i64 *red = (i64 *)(lds + (DB ? 2 : 1) * T * G::XROW);
@@ -1417,6 +1417,21 @@ extern "C" int rxk_pw_fft(void *stream, const int16_t *in, size_t tune_stride, s
 			hipLaunchKernelGGL(k_pwm_reduce<false>, dim3((unsigned)((((size_t)tunes << bin_e) + 255) / 256), 16), dim3(256), 0, s, part, tunes, fpw, groups, bin_e,
 			                   peak_hold, (i64 *)avg);
 		LAUNCH_RET();
+	}
+	if (bin_e >= 5 && bin_e <= 7 && eff_len % (2 * n) == 0) {
+		/* N = 32 ... 128 (coarse bins: the classic -f 88M:108M:125k): the same register-blocked kernel, 128 ... 32 transforms side by side in a workgroup */
+		const int nb_total = eff_len / (2 * n), ng = (nb_total % fpw == 0) ? nb_total / fpw : 0;
+		const size_t lds_bytes = (size_t)2 * 256 * RXK_FFT_XROW * 4 + 32 * 8 + (size_t)8 * ((n >> 4) + 8) * 4;
+#define GOS_(MM, NGG) do { \
+		if (peak_hold) hipLaunchKernelGGL((k_pw_fftR2<MM, NGG, true>), grid, dim3(256), lds_bytes, s, in, tune_stride, pass_stride, passes, window, twiddle + (1 << (MM - 1)), passes_per_group, (i64 *)avg, (i64 *)nullptr); \
+		else hipLaunchKernelGGL((k_pw_fftR2<MM, NGG, false>), grid, dim3(256), lds_bytes, s, in, tune_stride, pass_stride, passes, window, twiddle + (1 << (MM - 1)), passes_per_group, (i64 *)avg, (i64 *)nullptr); } while (0)
+#define GOS(MM) do { if (ng == 1) GOS_(MM, 1); else if (ng == 2) GOS_(MM, 2); else GOS_(MM, 4); } while (0)
+		if (ng == 1 || ng == 2 || ng == 4) {
+			if (bin_e == 5) GOS(5); else if (bin_e == 6) GOS(6); else GOS(7);
+			LAUNCH_RET();
+		}
+#undef GOS
+#undef GOS_
 	}
 #define GO(A) do { \
 		if (shm > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_pw_fft<A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \

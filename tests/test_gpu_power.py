@@ -321,9 +321,14 @@ def test_boxcar_with_remove_dc_sums_riding_in_the_decimator(bin_e, ds, blocks, t
     (13, 16384, 3, 3, 0, "hamming"),     # N = 8192: one transform of 512 threads per buffer, one transpose area
     (13, 32768, 2, 2, 1, "rectangle"),   # ... two per buffer, peak hold
     (13, 65536, 1, 2, 0, "blackman"),    # ... four
+    (5, 16384, 8, 3, 0, "hamming"),      # N = 32 (two threads per transform, 128 side by side): the coarse-bin sweeps
+    (5, 8192, 70, 2, 1, "rectangle"),    # ... one group, many tunes, peak hold
+    (6, 16384, 3, 2, 0, "blackman"),     # N = 64
+    (7, 32768, 2, 2, 0, "hamming"),      # N = 128, four groups
+    (7, 16384, 5, 3, 1, "bartlett"),     # N = 128, peak hold
 ])
 def test_small_transforms_with_the_buffer_in_registers(bin_e, buf_len, tunes, passes, peak, window):
-    """N = 256 ... 2048 and 8192 (k_pw_fftR2: a thread holds all its samples of the pass -- one, two or four groups of side-by-side transforms --, remove_dc from
+    """N = 32 ... 2048 and 8192 (k_pw_fftR2: a thread holds all its samples of the pass -- one, two or four groups of side-by-side transforms --, remove_dc from
     the registers, the next pass on its way, rtl_power.c:744-768) on full-scale noise and on a constant, with and without peak hold, few and many tunes
     == the oracle's scanner(); a buffer that is no whole number of groups stays with k_pw_fftR"""
     import types

@@ -8,7 +8,7 @@ L = R.lib(); R.check(L.rxgpu_init(0))
 g = torch.Generator(device="cuda"); g.manual_seed(3)
 tunes, passes, buf_len = 599, 256, 16384
 di = torch.randint(-100, 101, (passes, tunes, buf_len), dtype=torch.int16, device="cuda", generator=g)
-for bin_e in (8, 9, 10, 11, 12, 13):
+for bin_e in (int(v) for v in (sys.argv[1:] or "8 9 10 11 12 13".split())):
     nn = 1 << bin_e
     ps = R.PowerScan(R.PowerParams(bin_e, buf_len, 1, 0, 1, 0, 0), tunes, R.window_coefs("rectangle", nn), R.sine_table(bin_e))
     da = torch.zeros((tunes, nn), dtype=torch.int64, device="cuda"); dsm = torch.zeros(tunes, dtype=torch.int32, device="cuda")
