@@ -1368,7 +1368,7 @@ extern "C" int rxk_pw_fft(void *stream, const int16_t *in, size_t tune_stride, s
 	hipStream_t s = (hipStream_t)stream;
 	const int fpw = n >= 4096 ? 1 : 4096 / n;                       /* transforms side by side in a k_pw_fftR workgroup */
 	const bool k4096 = bin_e == 12 && (eff_len == 8192 || eff_len == 16384 || eff_len == 32768);
-	i64 *part = (partial && bin_e >= 8 && bin_e <= 13 && eff_len % (2 * n) == 0 &&
+	i64 *part = (partial && bin_e >= 5 && bin_e <= 13 && eff_len % (2 * n) == 0 &&
 	             (size_t)groups * tunes * fpw * (size_t)n <= partial_cap) ? (i64 *)partial : nullptr;
 	if (k4096) {
 		const int nb = eff_len / 8192;
@@ -1423,11 +1423,14 @@ extern "C" int rxk_pw_fft(void *stream, const int16_t *in, size_t tune_stride, s
 		const int nb_total = eff_len / (2 * n), ng = (nb_total % fpw == 0) ? nb_total / fpw : 0;
 		const size_t lds_bytes = (size_t)2 * 256 * RXK_FFT_XROW * 4 + 32 * 8 + (size_t)8 * ((n >> 4) + 8) * 4;
 #define GOS_(MM, NGG) do { \
-		if (peak_hold) hipLaunchKernelGGL((k_pw_fftR2<MM, NGG, true>), grid, dim3(256), lds_bytes, s, in, tune_stride, pass_stride, passes, window, twiddle + (1 << (MM - 1)), passes_per_group, (i64 *)avg, (i64 *)nullptr); \
-		else hipLaunchKernelGGL((k_pw_fftR2<MM, NGG, false>), grid, dim3(256), lds_bytes, s, in, tune_stride, pass_stride, passes, window, twiddle + (1 << (MM - 1)), passes_per_group, (i64 *)avg, (i64 *)nullptr); } while (0)
+		if (peak_hold) hipLaunchKernelGGL((k_pw_fftR2<MM, NGG, true>), grid, dim3(256), lds_bytes, s, in, tune_stride, pass_stride, passes, window, twiddle + (1 << (MM - 1)), passes_per_group, (i64 *)avg, part); \
+		else hipLaunchKernelGGL((k_pw_fftR2<MM, NGG, false>), grid, dim3(256), lds_bytes, s, in, tune_stride, pass_stride, passes, window, twiddle + (1 << (MM - 1)), passes_per_group, (i64 *)avg, part); } while (0)
 #define GOS(MM) do { if (ng == 1) GOS_(MM, 1); else if (ng == 2) GOS_(MM, 2); else GOS_(MM, 4); } while (0)
 		if (ng == 1 || ng == 2 || ng == 4) {
 			if (bin_e == 5) GOS(5); else if (bin_e == 6) GOS(6); else GOS(7);
+			if (part)
+				hipLaunchKernelGGL(k_pwm_reduce<false>, dim3((unsigned)((((size_t)tunes << bin_e) + 255) / 256), 16), dim3(256), 0, s, part, tunes, fpw, groups, bin_e,
+				                   peak_hold, (i64 *)avg);
 			LAUNCH_RET();
 		}
 #undef GOS

@@ -459,7 +459,7 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 	int groups = (4096 + tunes - 1) / tunes;
 	/* few tunes (a narrow sweep with fine bins): thousands of passes land on the same N bins.  Fewer, longer groups, and their
 	 * spectra go to a partial buffer that one reduction folds into avg[] instead of int64 atomics from every group */
-	const int few = p->bin_e >= 8 && p->bin_e <= 13 && eff_len % (2 << p->bin_e) == 0 && tunes <= 64;
+	const int few = p->bin_e >= 5 && p->bin_e <= 13 && eff_len % (2 << p->bin_e) == 0 && tunes <= 64;
 	if (few)
 		groups = (1024 + tunes - 1) / tunes;
 	if (groups > passes) groups = passes;

@@ -6,7 +6,7 @@ import torch
 import rx_tools_amd as R
 L = R.lib(); R.check(L.rxgpu_init(0))
 g = torch.Generator(device="cuda"); g.manual_seed(3)
-tunes, passes, buf_len = 599, 256, 16384
+tunes, passes, buf_len = int(os.environ.get("PW_TUNES", "599")), int(os.environ.get("PW_PASSES", "256")), 16384
 di = torch.randint(-100, 101, (passes, tunes, buf_len), dtype=torch.int16, device="cuda", generator=g)
 for bin_e in (int(v) for v in (sys.argv[1:] or "8 9 10 11 12 13".split())):
     nn = 1 << bin_e
