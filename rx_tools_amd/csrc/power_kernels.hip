@@ -805,7 +805,32 @@ __global__ __launch_bounds__(256) void k_pw_rms_sums(const int16_t *__restrict__
 		return;
 	const int16_t *src = in + b * (size_t)buf_len;
 	i64 t = 0, p = 0;
-	for (int i = threadIdx.x; i < buf_len; i += 256) {
+	int i0 = 0;
+	if ((((size_t)src) & 15) == 0) {
+		// 16-byte loads, four on their way per lane; per dword (two int16) one v_dot2 for the sum and one for the squares (x0^2 + x1^2 <= 2^31: an
+		// unsigned 32-bit value, added into 64 bits).  The first version read one int16 per load and multiplied in 64 bits: 1.97 TB/s of input
+		const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+		const int nv = buf_len / 8;
+		for (int v = threadIdx.x; v < nv; v += 1024) {
+			uint4 w[4];
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+				w[u] = v + 256 * u < nv ? s4[v + 256 * u] : make_uint4(0, 0, 0, 0);
+			int ts = 0;
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const uint32_t d[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					ts = pw_dot(d[k], 0x00010001u, ts);                       // 32 int16 per turn: far inside int32
+					p += (i64)pw_norm(d[k]);
+				}
+			}
+			t += ts;
+		}
+		i0 = nv * 8;
+	}
+	for (int i = i0 + threadIdx.x; i < buf_len; i += 256) {
 		const i64 s = src[i];
 		t += s;
 		p += s * s;

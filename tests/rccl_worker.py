@@ -61,6 +61,7 @@ def main():
         d_smp[count:] = 77
     d_avg_all = torch.zeros((world, per, n), dtype=torch.int64, device="cuda") if rank == 0 else None
     d_smp_all = torch.zeros((world, per), dtype=torch.int32, device="cuda") if rank == 0 else None
+    torch.cuda.synchronize()                  # torch's fills are on its stream, the library adds to these arrays on its own
     torch.cuda.synchronize()
     # the sharded entry point: scan of this rank's tunes on the library's stream + the gather behind it on the copy stream, no host sync between (rxgpu_sync covers both)
     R.check(L.rxgpu_power_scan_run_sharded(ps._h, comm._h, d_in.data_ptr(), passes, TOTAL_TUNES, d_avg.data_ptr(), d_smp.data_ptr(), n,

@@ -38,6 +38,7 @@ def gpu_scan(data, passes, tunes, plan, window, sinewave, boxcar, comp_fir, peak
     d_in = to_dev(data)
     d_avg = torch.zeros((tunes, n), dtype=torch.int64, device="cuda") if avg0 is None else to_dev(avg0)
     d_samples = torch.zeros(tunes, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()                  # torch's fills run on ITS stream: they must have landed before the library's stream adds to these arrays
     s.run(d_in.data_ptr(), passes, tunes, d_avg.data_ptr(), d_samples.data_ptr())
     R.check(R.lib().rxgpu_sync())
     out = d_avg.cpu().numpy(), d_samples.cpu().numpy()
@@ -342,6 +343,21 @@ def test_small_transforms_with_the_buffer_in_registers(bin_e, buf_len, tunes, pa
         assert bad.size == 0 and np.array_equal(gs, ws), "first mismatch at %s (%d bad)" % (bad[0] if bad.size else None, len(bad))
 
 
+@pytest.mark.parametrize("buf_len,peak", [(16384, 0), (16384, 1), (16390, 0), (4098, 0)])
+def test_rms_power_path_full_scale(buf_len, peak):
+    """bin_e == 0 (bins of 1 MHz and more: rms_power, rtl_power.c:403-429, 710-713): sum and sum of squares of a buffer's int16 -- 16-byte loads, the pair
+    of squares of a dword as one unsigned 32-bit value (2 x 32768^2 = 2^31 at full scale) -- on full-scale noise and on a constant -32768; buffers
+    whose length leaves every second one misaligned take the element-wise form.  == the oracle's scanner(), fp64 dc term included"""
+    import types
+    plan = types.SimpleNamespace(bin_e=0, buf_len=buf_len, downsample=1, downsample_passes=0)
+    wc, sw = R.window_coefs("rectangle", 1), R.sine_table(0)
+    tunes, passes = 5, 3
+    for data in (sig_noise(passes * tunes * buf_len, seed=9, amp=32768), np.full(passes * tunes * buf_len, -32768, np.int16)):
+        want, ws = oracle_scan(data, passes, tunes, plan, wc, sw, 1, 0, peak)
+        got, gs = gpu_scan(data, passes, tunes, plan, wc, sw, 1, 0, peak)
+        assert np.array_equal(got, want) and np.array_equal(gs, ws)
+
+
 def test_buffer_that_is_no_whole_number_of_large_transforms():
     """N = 2^16 with 1.5 transforms per decimated buffer (boxcar ds = 2 on 3 * 2^17 int16: the second transform is half samples, half the zeros
     the boxcar leaves behind, rtl_power.c:723-733) -- a geometry the reference's planner never makes and rxgpu_power_scan_create accepts: it takes
@@ -372,6 +388,7 @@ def test_two_head_passes_in_one_launch_or_two(rng):
     d_in = to_dev(np.concatenate([np.zeros(2, np.int16), data]))               # the capture starts 4 bytes into the allocation
     d_avg = torch.zeros((1, n), dtype=torch.int64, device="cuda")
     d_samples = torch.zeros(1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
     s.run(d_in.data_ptr() + 4, 2, 1, d_avg.data_ptr(), d_samples.data_ptr())
     R.check(R.lib().rxgpu_sync())
     b, sb = d_avg.cpu().numpy(), d_samples.cpu().numpy()
@@ -396,6 +413,7 @@ def test_gather_without_a_communicator_is_a_copy():
     a = torch.arange(3 * 8, dtype=torch.int64, device="cuda").reshape(3, 8)
     s = torch.arange(3, dtype=torch.int32, device="cuda")
     a2, s2 = torch.zeros_like(a), torch.zeros_like(s)
+    torch.cuda.synchronize()
     R.check(L.rxgpu_power_gather(None, a.data_ptr(), s.data_ptr(), 3, 8, a2.data_ptr(), s2.data_ptr(), 0))
     R.check(L.rxgpu_sync())
     assert torch.equal(a, a2) and torch.equal(s, s2)
