@@ -309,10 +309,11 @@ int rxk_pw_fifth_fused(void *stream, const int16_t *in, unsigned long long n_buf
                        int16_t *out, unsigned out_stride);
 /* four stateless fifth_order passes (+ droop FIR when fir_host != NULL: cic_9_tables[4], fir_dev the same table on the device) in registers, one launch +
  * a fix-up of each buffer's first samples; sums != NULL: remove_dc's sums of every output buffer into sums[2 b], sums[2 b + 1] (zeroed by the caller) */
-int rxk_pw_fifth_regn4(void *stream, const int16_t *in, unsigned long long n_bufs, unsigned n, unsigned in_stride, const int *fir_dev, const int *fir_host,
-                       int16_t *out, unsigned out_stride, long long *sums, int *wave_part);
-/* sums != NULL: wave_part = rxk_pw_fifth_regn4_parts(n_bufs, n) int PAIRS of scratch (every wave leaves its share there, the fix kernel adds them: sums need no zeroing) */
-unsigned long long rxk_pw_fifth_regn4_parts(unsigned long long n_bufs, unsigned n);
+int rxk_pw_fifth_regn(void *stream, const int16_t *in, unsigned long long n_bufs, unsigned n, unsigned in_stride, int lv, const int *fir_dev, const int *fir_host,
+                      int16_t *out, unsigned out_stride, long long *sums, int *wave_part);
+/* lv = 2, 3 or 4 stateless passes in registers.  sums != NULL: wave_part = rxk_pw_fifth_regn_parts(n_bufs, n, lv) int PAIRS of scratch (every wave leaves its share
+ * there, the fix kernel adds them: sums need no zeroing) */
+unsigned long long rxk_pw_fifth_regn_parts(unsigned long long n_bufs, unsigned n, int lv);
 /* generic_fir (rtl_power.c:626-654) over n complex samples per buffer */
 int rxk_pw_droop(void *stream, const int16_t *in, int16_t *out, size_t n_bufs, int n, int stride, const int *fir);
 /* P9 rms_power sums: t[b] = sum s, p[b] = sum s^2 (int64, exact) per buffer, then the fp64

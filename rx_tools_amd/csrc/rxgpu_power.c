@@ -398,7 +398,7 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 				RX_K(rxk_pw_boxcar(st, d_in, s->work[0], n_bufs, buf_len, ds, n_read));
 			}
 			fft_in = s->work[0];
-		} else if (ds_p == 4 && (buf_len / 2) % 64 == 0 && buf_len / 2 >= 1024 && ((size_t)d_in & 15u) == 0 && (buf_len / 2) % 4 == 0 &&
+		} else if (ds_p >= 2 && ds_p <= 4 && (buf_len / 2) % (4 << ds_p) == 0 && buf_len / 2 >= (64 << ds_p) && ((size_t)d_in & 15u) == 0 && (buf_len / 2) % 4 == 0 &&
 		           (p->comp_fir_size == 9 || p->comp_fir_size == 0) && n_bufs < ((size_t)1 << 31)) {
 			/* four passes (ds = 16): the register cascade -- passes, droop FIR and remove_dc's sums in one launch, the 1/16-rate buffers
 			 * written once (rtl_power.c:734-745).  The sums go where the large-N transform's dc pass would have put them. */
@@ -413,7 +413,7 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 					s->big_dc_cap = (size_t)passes * (size_t)tunes;
 				}
 				sums = rxk_pw_dc_sums(s->big_dc, (size_t)passes * (size_t)tunes);
-				const size_t parts = (size_t)rxk_pw_fifth_regn4_parts(n_bufs, (unsigned)(buf_len / 2));
+				const size_t parts = (size_t)rxk_pw_fifth_regn_parts(n_bufs, (unsigned)(buf_len / 2), ds_p);
 				if (s->regn_part_cap < parts) {
 					hipFree(s->regn_part);
 					s->regn_part = NULL; s->regn_part_cap = 0;
@@ -422,13 +422,23 @@ int rxgpu_power_scan_run(rxgpu_power_scan *s, const int16_t *d_in, int passes, i
 				}
 				dc_sums_done = 1;
 			}
-			RX_K(rxk_pw_fifth_regn4(st, d_in, n_bufs, (unsigned)(buf_len / 2), (unsigned)(buf_len / 2), fir ? s->fir_dev : NULL, fir ? cic_9_tables[4] : NULL,
+			RX_K(rxk_pw_fifth_regn(st, d_in, n_bufs, (unsigned)(buf_len / 2), (unsigned)(buf_len / 2), ds_p, fir ? s->fir_dev : NULL, fir ? cic_9_tables[ds_p] : NULL,
 			                        s->work[0], (unsigned)(buf_len / 2), sums, s->regn_part));
 			fft_in = s->work[0];
 		} else {                                           /* rtl_power.c:734-743 */
 			const int16_t *src = d_in;
-			int n_in = buf_len / 2, which = 0;
-			for (int j = 0; j < ds_p;) {
+			int n_in = buf_len / 2, which = 0, j0 = 0;
+			if (ds_p > 4 && (buf_len / 2) % 64 == 0 && buf_len / 2 >= 1024 && ((size_t)d_in & 15u) == 0 && n_bufs < ((size_t)1 << 31)) {
+				/* more than four passes: the first four -- 15/16 of the cascade's samples -- in the register kernel (no FIR, no sums there: those come
+				 * behind the LAST pass), the rest on the 1/16-rate buffers below.  Every pass is stateless and eased in (rtl_power.c:582-607), so a
+				 * later pass only needs the level-4 buffers right from their first sample, which k_pw_fifth_fix sees to */
+				RX_K(rxk_pw_fifth_regn(st, d_in, n_bufs, (unsigned)(buf_len / 2), (unsigned)(buf_len / 2), 4, NULL, NULL, s->work[0], (unsigned)(buf_len / 2), NULL, NULL));
+				src = s->work[0];
+				n_in >>= 4;
+				which = 1;
+				j0 = 4;
+			}
+			for (int j = j0; j < ds_p;) {
 				/* up to three passes per launch while the pass input is whole tiles; otherwise one pass at a time */
 				int fuse = ds_p - j < 3 ? ds_p - j : 3;
 				while (fuse > 0 && n_in % RXK_FIFTH_TILE)

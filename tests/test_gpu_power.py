@@ -358,6 +358,26 @@ def test_rms_power_path_full_scale(buf_len, peak):
         assert np.array_equal(got, want) and np.array_equal(gs, ws)
 
 
+@pytest.mark.parametrize("bin_e,ds_p,fir,tunes,passes", [
+    (10, 5, 9, 2, 2), (10, 6, 0, 1, 2), (10, 7, 9, 2, 1), (12, 5, 0, 3, 2), (14, 5, 9, 1, 2), (8, 8, 9, 1, 2),
+    (10, 2, 0, 3, 2), (12, 2, 9, 2, 2), (14, 2, 9, 1, 2), (11, 3, 9, 2, 3), (13, 3, 0, 2, 2), (15, 3, 9, 1, 2), (14, 3, 0, 2, 1),
+])
+def test_stateless_passes_other_than_four(bin_e, ds_p, fir, tunes, passes):
+    """-F with five to eight passes (ds = 32 ... 256, rtl_power.c:734-745): the first four in the register kernel (k_pw_fifth_regn without FIR and sums,
+    k_pw_fifth_fix for every buffer's first level-4 samples), the others on the 1/16-rate buffers, then the droop FIR and remove_dc as before; with two
+    or three passes (ds = 4, 8): the whole cascade, the FIR and -- in front of a large transform -- the sums in the register kernel (k_pw_fifth_regn<2>,
+    <3>) -- on full-scale noise and on a constant == the oracle's scanner()"""
+    import types
+    n = 1 << bin_e
+    plan = types.SimpleNamespace(bin_e=bin_e, buf_len=2 * n << ds_p, downsample=1 << ds_p, downsample_passes=ds_p)
+    wc, sw = R.window_coefs("hamming", n), R.sine_table(bin_e)
+    for data in (sig_noise(passes * tunes * plan.buf_len, seed=70 + ds_p, amp=32768), np.full(passes * tunes * plan.buf_len, 32767, np.int16)):
+        want, ws = oracle_scan(data, passes, tunes, plan, wc, sw, 0, fir, 0)
+        got, gs = gpu_scan(data, passes, tunes, plan, wc, sw, 0, fir, 0)
+        bad = np.argwhere(got != want)
+        assert bad.size == 0 and np.array_equal(gs, ws), "first mismatch at %s (%d bad)" % (bad[0] if bad.size else None, len(bad))
+
+
 def test_buffer_that_is_no_whole_number_of_large_transforms():
     """N = 2^16 with 1.5 transforms per decimated buffer (boxcar ds = 2 on 3 * 2^17 int16: the second transform is half samples, half the zeros
     the boxcar leaves behind, rtl_power.c:723-733) -- a geometry the reference's planner never makes and rxgpu_power_scan_create accepts: it takes
