@@ -98,6 +98,14 @@ enum { RXK_FIRST_LOWPASS = 0, RXK_FIRST_UNIFORM = 1 };
 #define RXK_LP_SPARSE_MAX_DS 512
 int rxk_fm_decimate(void *stream, const int16_t *iq, unsigned long long T, int ds, int p0,
                     int prescaled, int rotate, uint32_t *lp_raw, uint32_t *head, uint32_t *tail, int lp_sparse, int16_t *pcm, int pcm_chl2);
+/* ... on the raw capture of an -E rdc run whose blocks are whole spans: the block averages (rxk_fm_rdc with out == NULL: sums + recursion only) are
+ * subtracted from the scaled samples inside the decimator */
+int rxk_fm_disc_rdc(void *stream, const int16_t *iq, unsigned long long T, int ds, int p0, unsigned long long n_per_block, int rotate, int seams, const uint32_t *lp_raw,
+                    const uint32_t *head, const uint32_t *tail, uint32_t *lp, unsigned long long M, int custom_atan, int16_t *pcm, rxk_fm_dev *dev,
+                    rxk_flag_rec *flag_list, int *flag_cnt, int sparse, unsigned long long n_blocks, const int *atan_lut, int lp_sparse, int flag_all, int pcm_chl2,
+                    const int *rdc_avg);      /* rxk_fm_disc behind rxk_fm_decimate_rdc */
+int rxk_fm_decimate_rdc(void *stream, const int16_t *iq, unsigned long long T, int ds, int p0, int rotate, uint32_t *lp_raw, uint32_t *head, uint32_t *tail,
+                        int lp_sparse, int16_t *pcm, int pcm_chl2, const int *rdc_avg, unsigned spans_per_block);
 /* pcm_chl2 != 0: pcm[] is written in the tiled layout of the lane-per-chunk audio kernels (chunks of 2^pcm_chl2 samples, see
  * pcm_index in fm_kernels.hip); rxk_fm_disc takes the same argument */
 

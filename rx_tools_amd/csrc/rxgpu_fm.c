@@ -26,6 +26,7 @@
 struct run_geom {
 	unsigned long long n, T, M, K, J;
 	int passes, ds, p0, pr0, rotate, fast, post;
+	int rdc_fused;                       /* -E rdc: the decimator subtracts the block averages itself (no corrected copy of the capture) */
 	int literal;                         /* -F on blocks that are not whole tiles: the per-block int16-indexed kernels */
 	int lf;                              /* literal: int16 count of a block's lowpassed[] after the cascade, (2n) >> passes (may be odd) */
 };
@@ -556,6 +557,7 @@ static int run_geometry(rxgpu_fm_stream *s, size_t n_blocks, size_t block_len, s
 	g->pr0 = s->h_prev_lpr_index;
 	g->rotate = !p->prescaled && !p->offset_tuning && !p->dc_block_raw;   /* the -E rdc pre-pass rotates */
 	g->K = 0;
+	g->rdc_fused = 0;
 	g->fast = 0;
 	g->literal = 0;
 	g->lf = 0;
@@ -582,6 +584,10 @@ static int run_geometry(rxgpu_fm_stream *s, size_t n_blocks, size_t block_len, s
 			                  "reference's fm_demod read pre_r/pre_j from in front of lowpassed[] (rtl_fm.c:612-613); only the drop-in, block by block "
 			                  "on the real struct, reproduces that", g->n, g->ds);
 		g->fast = g->ds >= 4 && g->ds <= RXK_DEC_MAX_DS && (g->n % 4) == 0 && g->n >= (unsigned long long)g->ds;
+		/* -E rdc in front of the span decimator, blocks of whole spans: the averages are subtracted there (rxk_fm_decimate_rdc) */
+		g->rdc_fused = p->dc_block_raw && !p->prescaled && g->fast && g->ds > RXK_DEC_SMALL_MAX && g->n % RXK_DEC_SPAN == 0;
+		if (g->rdc_fused)
+			g->rotate = !p->offset_tuning;
 	}
 	if (g->M > s->max_M)
 		return rxgpu_fail(RXGPU_ECAPACITY, "workspace too small for %llu decimated samples", g->M);
@@ -655,11 +661,13 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 		 * rotate16_90 -- written out once, the chain then runs on it as prescaled input */
 		RX_HIP(hipMemcpyAsync(s->rdc_state, &s->carry.dc_avgI, 8, hipMemcpyHostToDevice, sa));
 		RX_K(rxk_fm_rdc(sa, d_iq_in, n_blocks, g->n, 0, !p->offset_tuning, p->rdc_block_const, s->rdc_state, s->rdc_sums,
-		                s->rdc_avg, s->rdc_buf));
+		                s->rdc_avg, g->rdc_fused ? NULL : s->rdc_buf));
 		RX_HIP(hipEventRecord(s->ev_rdc, sa));
 		RX_HIP(hipStreamWaitEvent(sb, s->ev_rdc, 0));
-		d_iq = s->rdc_buf;
-		prescaled = 1;
+		if (!g->rdc_fused) {
+			d_iq = s->rdc_buf;
+			prescaled = 1;
+		}
 	}
 	rxk_fm_dev *h = s->dev_host;
 	if (p->deemph)
@@ -748,6 +756,9 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 			rxgpu_prof_begin_on("fm_decimate", sa);
 			if (small)
 				RX_K(rxk_fm_decimate_small(sa, d_iq, g->T, g->ds, g->p0, g->rotate, g->M, s->pcm, s->tiled));
+			else if (g->rdc_fused)
+				RX_K(rxk_fm_decimate_rdc(sa, d_iq, g->T, g->ds, g->p0, g->rotate, s->lp_raw[db], s->head[db], s->tail[db],
+				                         lp_sparse, fused_disc ? s->pcm : NULL, s->tiled, s->rdc_avg, (unsigned)(g->n / RXK_DEC_SPAN)));
 			else
 				RX_K(rxk_fm_decimate(sa, d_iq, g->T, g->ds, g->p0, prescaled, g->rotate, s->lp_raw[db], s->head[db], s->tail[db],
 				                     lp_sparse, fused_disc ? s->pcm : NULL, s->tiled));
@@ -761,6 +772,11 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 		}
 		rxgpu_prof_begin_on("fm_disc", sb);
 		/* fast path: lp_raw is finished in place (only seam entries change) and becomes the final decimated IQ */
+		if (g->rdc_fused)
+			RX_K(rxk_fm_disc_rdc(sb, d_iq, g->T, g->ds, g->p0, g->n, g->rotate, g->fast, s->lp_raw[db], s->head[db], s->tail[db], s->lp_raw[db], g->M,
+			                     p->custom_atan, split ? NULL : s->pcm, s->dev, flag_rec, flag_cnt, fused_disc, n_blocks, s->atan_lut, lp_sparse, s->flag_all,
+			                     s->tiled, s->rdc_avg));
+		else
 		RX_K(rxk_fm_disc(sb, d_iq, g->T, g->ds, g->p0, g->n, prescaled, g->rotate, small ? 2 : g->fast, g->fast ? s->lp_raw[db] : s->lp,
 		                 s->head[db], s->tail[db], g->fast ? s->lp_raw[db] : s->lp, g->M, RXK_FIRST_LOWPASS, 0, p->custom_atan, 1,
 		                 split ? NULL : s->pcm, s->dev, flag_rec, flag_cnt, fused_disc, n_blocks, s->atan_lut, g->fast ? lp_sparse : 0, s->flag_all, s->tiled));

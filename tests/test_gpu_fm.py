@@ -260,6 +260,12 @@ def test_host_reevaluation_of_libm_samples(ds, block_len, std, monkeypatch):
     (dict(downsample=6, dc_block_raw=1, rdc_block_const=3), 2 * 6000),
     (dict(downsample_passes=3, comp_fir_size=9, dc_block_raw=1), 16384),
     (dict(downsample=10, dc_block_raw=1, offset_tuning=1, custom_atan=0), 8192),
+    # blocks of whole 16384-sample spans in front of the span decimator: the averages are subtracted inside it (k_fm_decimate<.., RDC>), no corrected copy
+    (dict(downsample=118, dc_block_raw=1), 2 * 16384),
+    (dict(downsample=118, dc_block_raw=1, rdc_block_const=1), 2 * 32768),             # two spans per block, the fastest-moving average
+    (dict(downsample=40, dc_block_raw=1, rdc_block_const=5, custom_atan=0), 2 * 16384),  # 4-byte slots, the separate discriminator (-A std)
+    (dict(downsample=64, dc_block_raw=1, offset_tuning=1), 2 * 16384),                 # no rotation: one dc word for all four phases; wide slots
+    (dict(downsample=33, dc_block_raw=1, mode=1, deemph=0, squelch_level=20), 2 * 16384),  # am + squelch behind it
 ])
 def test_post_downsample_and_raw_dc_block(params, block_len):
     """-o (low_pass_simple, rtl_fm.c:373-387) and -E rdc (dc_block_raw_filter, rtl_fm.c:699-721), several runs with
