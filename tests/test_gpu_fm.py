@@ -276,6 +276,18 @@ def test_post_downsample_and_raw_dc_block(params, block_len):
         assert (carry.dc_avgI, carry.dc_avgQ) == (st.dc_avgI, st.dc_avgQ)
 
 
+@pytest.mark.parametrize("ds", [1, 2, 3])
+@pytest.mark.parametrize("extra", [dict(), dict(mode=4, deemph=0, rate_out2=-1), dict(mode=1, deemph=0), dict(offset_tuning=1, custom_atan=0), dict(dc_block_raw=1)])
+def test_decimation_below_four(ds, extra):
+    """ds = 1, 2, 3 (k_fm_decimate_tiny: twelve samples per thread, the windows that end in them, the samples in front of the thread's edge read again,
+    the run's first window from the carried now_r/now_j): blocks of 4100 samples -- no multiple of 3 or 12, so the phase prev_index walks through
+    every value from run to run and the last thread of a run is ragged -- fm / raw / am / unrotated / -E rdc chains, three runs, against the oracle"""
+    block_len = 2 * 4100
+    for sig in ("fm", "noise_full"):
+        iq = _signals(12 * block_len)[sig]
+        _check(iq, block_len, n_runs=3, downsample=ds, **extra)
+
+
 def test_random_parameter_sweep():
     """seeded random parameter sets -- every switch of the chain at once -- HIP against the oracle, two runs each"""
     rng = np.random.default_rng(20260925)
