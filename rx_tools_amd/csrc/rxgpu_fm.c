@@ -932,6 +932,13 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 				s->lp_final = s->lp;
 			}
 		}
+		if (!split && !fused_dd && p->custom_atan == 1 && p->comp_fir_size != 9 && ((size_t)s->lp_final & 15u) == 0) {
+			/* -F without the droop FIR, -A fast: the four-outputs-per-thread discriminator (rxk_fm_droop_disc without a filter) */
+			rxgpu_prof_begin_on("fm_disc", sb);
+			RX_K(rxk_fm_droop_disc(sb, s->lp_final, g->M, NULL, NULL, NULL, NULL, g->K, s->pcm, s->tiled, s->dev, flag_rec, flag_cnt, s->flag_all));
+			rxgpu_prof_end_on("fm_disc", sb);
+			fused_dd = 1;
+		}
 		if (!split && !fused_dd) {
 			rxgpu_prof_begin_on("fm_disc", sb);
 			RX_K(rxk_fm_disc(sb, d_iq, g->T, 1, 0, g->n, prescaled, g->rotate, 0, s->lp_final, NULL, NULL, NULL, g->M,
