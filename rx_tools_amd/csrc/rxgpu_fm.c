@@ -772,7 +772,13 @@ static int enqueue_run(rxgpu_fm_stream *s, const int16_t *d_iq_in, size_t n_bloc
 		}
 		rxgpu_prof_begin_on("fm_disc", sb);
 		/* fast path: lp_raw is finished in place (only seam entries change) and becomes the final decimated IQ */
-		if (g->rdc_fused)
+		if (!g->fast && g->M && !split && p->custom_atan == 1 && g->p0 == 0 && g->n % (unsigned long long)g->ds == 0 &&
+		    g->M == n_blocks * (g->n / (unsigned long long)g->ds) && ((size_t)s->lp & 15u) == 0)
+			/* behind the one-thread-per-output decimator (ds < 4), whole windows per block: every block's first output is every (n / ds)-th one, no
+			 * carry is left over -- the four-outputs-per-thread discriminator (no filter) instead of the dense kernel */
+			RX_K(rxk_fm_droop_disc(sb, s->lp, g->M, NULL, NULL, NULL, NULL, g->n / (unsigned long long)g->ds, s->pcm, s->tiled, s->dev, flag_rec, flag_cnt,
+			                       s->flag_all));
+		else if (g->rdc_fused)
 			RX_K(rxk_fm_disc_rdc(sb, d_iq, g->T, g->ds, g->p0, g->n, g->rotate, g->fast, s->lp_raw[db], s->head[db], s->tail[db], s->lp_raw[db], g->M,
 			                     p->custom_atan, split ? NULL : s->pcm, s->dev, flag_rec, flag_cnt, fused_disc, n_blocks, s->atan_lut, lp_sparse, s->flag_all,
 			                     s->tiled, s->rdc_avg));
